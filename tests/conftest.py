@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def synth_reg(N, d, seed=0):
+    """SURVEY 8(d) synthetic regression recipe (same draw order as make_golden.py)."""
+    rng = np.random.RandomState(seed)
+    x = rng.randn(N, d)
+    w = rng.randn(d, 1)
+    y = np.sin(x @ w / np.sqrt(d)) + 0.1 * rng.randn(N, 1)
+    return x, y
+
+
+def synth_cls(N, d, seed=0):
+    rng = np.random.RandomState(seed)
+    x = rng.randn(N, d)
+    w = rng.randn(d, 1)
+    y = np.sign(x @ w / np.sqrt(d) + 0.3 * rng.randn(N, 1))
+    y[y == 0] = 1
+    return x, y
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from pygps_amd import _lib
+    return _lib.load()

@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the REFERENCE
+(marionmari/pyGPs, read-only at /root/reference) in the build container.
+
+This script is the provenance record for every *.npz in this directory.  It is
+run by hand, here only:
+
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [ids...]
+
+It puts a 3-file `past` shim (tests/golden/_shim) and /root/reference on
+sys.path, imports pyGPs unmodified, runs the cases of SURVEY.md section 8(c) and
+stores plain arrays / scalars (inputs and captured outputs) -- no reference
+source, bytecode or pickled objects.  Nothing on the GPU box imports this file.
+
+Reference call sites exercised: Core/gp.py:289-345 (getPosterior),
+Core/inf.py:353-384 (Exact.evaluate), Core/inf.py:731-806 (EP.evaluate),
+Core/cov.py:796-828 / 887-938 / 1124-1182 (RBF / RBFard / Matern),
+Core/opt.py:282-328 (Minimize.findMin), Optimization/minimize.py:41-172.
+"""
+import os
+import sys
+import time
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "_shim"))
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import scipy  # noqa: E402
+import pyGPs  # noqa: E402  (the reference)
+from pyGPs.Core import opt as ref_opt  # noqa: E402
+
+META = dict(numpy=np.__version__, scipy=scipy.__version__,
+            reference="marionmari/pyGPs v1.3.5 @ /root/reference")
+
+
+def save(name, **arrs):
+    arrs["meta"] = np.array(repr(META))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
+    print("wrote", name, flush=True)
+
+
+def synth_reg(N, d, seed=0):
+    """SURVEY 8(d) synthetic regression recipe (draw order is the contract)."""
+    rng = np.random.RandomState(seed)
+    x = rng.randn(N, d)
+    w = rng.randn(d, 1)
+    y = np.sin(x @ w / np.sqrt(d)) + 0.1 * rng.randn(N, 1)
+    return x, y
+
+
+def synth_cls(N, d, seed=0):
+    rng = np.random.RandomState(seed)
+    x = rng.randn(N, d)
+    w = rng.randn(d, 1)
+    y = np.sign(x @ w / np.sqrt(d) + 0.3 * rng.randn(N, 1))
+    y[y == 0] = 1
+    return x, y
+
+
+def dn(d):
+    return dict(dnlZ_mean=np.array(d.mean, dtype=float), dnlZ_cov=np.array(d.cov, dtype=float),
+                dnlZ_lik=np.array(d.lik, dtype=float))
+
+
+# ----------------------------------------------------------------------------- G1 / G1b / G1c
+def g1():
+    data = np.load("/root/reference/pyGPs/Demo/Regression/regression_data.npz")
+    x, y, xs = data["x"], data["y"], data["xstar"]
+    m = pyGPs.GPR()
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    ym, ys2, fm, fs2, lp = m.predict(xs[:3])
+    save("G1_regression_default", x=x, y=y, xstar=xs, nlZ=nlZ, alpha=post.alpha, L=post.L, sW=post.sW,
+         mean_hyp=np.array(m.meanfunc.hyp), cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp),
+         pred3_ym=ym, pred3_ys2=ys2, pred3_fm=fm, pred3_fs2=fs2, **dn(dnlZ))
+    # G1b: optimise (Minimize, 40 line searches) then predict on all of xstar
+    traj = {}
+    orig_run = ref_opt.minimize.run
+
+    def spy(f, X, *a, **k):
+        out = orig_run(f, X.copy(), *a, **k)
+        traj["X0"] = np.array(X, dtype=float)
+        traj["fX"] = np.array(out[1], dtype=float)
+        traj["nls"] = out[2]
+        traj["Xopt"] = np.array(out[0], dtype=float)
+        return out
+    ref_opt.minimize.run = spy
+    try:
+        m.optimize(x, y)
+    finally:
+        ref_opt.minimize.run = orig_run
+    ym, ys2, fm, fs2, lp = m.predict(xs)
+    save("G1b_regression_optimized", x=x, y=y, xstar=xs, nlZ=m.nlZ,
+         mean_hyp=np.array(m.meanfunc.hyp), cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp),
+         ym=ym, ys2=ys2, fm=fm, fs2=fs2, min_X0=traj["X0"], min_fX=traj["fX"], min_nls=traj["nls"],
+         min_Xopt=traj["Xopt"], alpha=m.posterior.alpha, **dn(m.dnlZ))
+
+
+# ----------------------------------------------------------------------------- G2 / G3
+def g2():
+    np.random.seed(0)
+    x = np.random.normal(0, 1, (20, 3))
+    y = np.random.random((20,))
+    m = pyGPs.GPR()
+    nlZ, dnlZ, post = m.getPosterior(x, y)          # mean stays Zero (Q8)
+    save("G2_seed0_rbf_zero_mean", x=x, y=y, nlZ=nlZ, alpha=post.alpha, L=post.L, sW=post.sW,
+         cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp), **dn(dnlZ))
+    m = pyGPs.GPR()
+    k = pyGPs.cov.RBFard(log_ell_list=[0.1, 0.4, -0.2], log_sigma=0.2)
+    m.setPrior(mean=pyGPs.mean.Zero(), kernel=k)
+    nlZ, dnlZ, post = m.getPosterior(x, y)
+    save("G3_seed0_rbfard_zero_mean", x=x, y=y, nlZ=nlZ, alpha=post.alpha, L=post.L, sW=post.sW,
+         cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp), **dn(dnlZ))
+
+
+# ----------------------------------------------------------------------------- G4 / G5 kernels, all modes
+def kernel_dump(prefix, k, x, z, out):
+    nh = len(k.hyp)
+    out[prefix + "_hyp"] = np.array(k.hyp, dtype=float)
+    out[prefix + "_K_train"] = k.getCovMatrix(x=x, mode="train")
+    out[prefix + "_K_cross"] = k.getCovMatrix(x=x, z=z, mode="cross")
+    out[prefix + "_K_self"] = k.getCovMatrix(z=z, mode="self_test")
+    for i in range(nh):
+        out["%s_dK%d_train" % (prefix, i)] = k.getDerMatrix(x=x, mode="train", der=i)
+        out["%s_dK%d_cross" % (prefix, i)] = k.getDerMatrix(x=x, z=z, mode="cross", der=i)
+        out["%s_dK%d_self" % (prefix, i)] = k.getDerMatrix(z=z, mode="self_test", der=i)
+
+
+def g4():
+    np.random.seed(0)
+    x = np.random.normal(0, 1, (20, 3))
+    _ = np.random.random((20,))
+    z = np.random.normal(0, 1, (10, 3))
+    out = dict(x=x, z=z)
+    kernel_dump("rbf", pyGPs.cov.RBF(0.3, 0.2), x, z, out)
+    kernel_dump("rbfard", pyGPs.cov.RBFard(log_ell_list=[0.1, 0.4, -0.2], log_sigma=0.2), x, z, out)
+    for d in (1, 3, 5, 7):
+        kernel_dump("matern%d" % d, pyGPs.cov.Matern(0.3, d, 0.2), x, z, out)
+    save("G4_kernels_seed0", **out)
+    # G5: the reference's own unit-test setup (Testing/unit_test_cov.py:22-30): large distances
+    n, nn, D = 20, 10, 2
+    np.random.seed(0)
+    x = np.random.randn(n, D) * 20
+    z = np.random.randn(nn, D) * 20
+    out = dict(x=x, z=z)
+    kernel_dump("rbf", pyGPs.cov.RBF(), x, z, out)
+    kernel_dump("rbfard", pyGPs.cov.RBFard(D=D), x, z, out)
+    kernel_dump("matern3", pyGPs.cov.Matern(), x, z, out)
+    save("G5_kernels_unit_test_setup", **out)
+
+
+def g4b():
+    x, y = synth_reg(256, 16)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.Matern(np.log(np.sqrt(16.0)), 5, 0.0))
+    m.setNoise(np.log(0.1))
+    m.setData(x, y)
+    nlZ, post = m.getPosterior(der=False)
+    save("G4b_matern5_N256", x=x, y=y, nlZ=nlZ, alpha=post.alpha, L=post.L, sW=post.sW,
+         mean_hyp=np.array(m.meanfunc.hyp), cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp),
+         para=np.array([5]))
+
+
+# ----------------------------------------------------------------------------- G6 (cfg 2 scale)
+def g6(N):
+    d = 16
+    x, y = synth_reg(N, d)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+    m.setNoise(np.log(0.1))
+    m.setData(x, y)
+    t = time.time()
+    nlZ, dnlZ, post = m.getPosterior()
+    dt = time.time() - t
+    xs = x[:3] + 0.1
+    ym, ys2, fm, fs2, lp = m.predict(xs)
+    aidx = np.arange(0, N, 257)
+    lflat = np.arange(0, N * N, 257 * 131 + 1)
+    save("G6_rbf_d16_N%d" % N, N=N, d=d, seed=0, nlZ=nlZ, mean_hyp=np.array(m.meanfunc.hyp),
+         cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp),
+         alpha_idx=aidx, alpha_sample=post.alpha[aidx, 0], L_flat_idx=lflat, L_sample=post.L.ravel()[lflat],
+         L_diag=np.diag(post.L).copy(), pred_xs=xs, pred_ym=ym, pred_ys2=ys2, pred_fm=fm, pred_fs2=fs2,
+         ref_seconds=dt, **dn(dnlZ))
+
+
+# ----------------------------------------------------------------------------- G7 (cfg 3 scale)
+def g7(N):
+    d = 64
+    x, y = synth_reg(N, d)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBFard(log_ell_list=[float(np.log(np.sqrt(d)))] * d, log_sigma=0.0))
+    m.setNoise(np.log(0.1))
+    m.setData(x, y)
+    t = time.time()
+    nlZ, dnlZ, post = m.getPosterior()
+    dt = time.time() - t
+    aidx = np.arange(0, N, 257)
+    save("G7_rbfard_d64_N%d" % N, N=N, d=d, seed=0, nlZ=nlZ, mean_hyp=np.array(m.meanfunc.hyp),
+         cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp),
+         alpha_idx=aidx, alpha_sample=post.alpha[aidx, 0], L_diag=np.diag(post.L).copy(),
+         ref_seconds=dt, **dn(dnlZ))
+
+
+# ----------------------------------------------------------------------------- G8 (cfg 5, EP)
+def g8():
+    data = np.load("/root/reference/pyGPs/Demo/Classification/classification_data.npz")
+    x, y, xs = data["x"], data["y"], data["xstar"]
+    m = pyGPs.GPC()
+    nlZ, dnlZ, post = m.getPosterior(x, y)
+    ym, ys2, fm, fs2, lp = m.predict(xs[:5])
+    save("G8i_classification_demo_ep", x=x, y=y, xstar5=xs[:5], nlZ=nlZ, alpha=post.alpha, L=post.L, sW=post.sW,
+         cov_hyp=np.array(m.covfunc.hyp), ttau=m.inffunc.last_ttau, tnu=m.inffunc.last_tnu,
+         pred_ym=ym, pred_ys2=ys2, pred_fm=fm, pred_fs2=fs2, **dn(dnlZ))
+    for N in (128, 512):
+        d = 32
+        x, y = synth_cls(N, d)
+        m = pyGPs.GPC()
+        m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+        nlZ, dnlZ, post = m.getPosterior(x, y)
+        save("G8ii_ep_d32_N%d" % N, N=N, d=d, seed=0, nlZ=nlZ, alpha=post.alpha, sW=post.sW,
+             L_diag=np.diag(post.L).copy(), cov_hyp=np.array(m.covfunc.hyp),
+             ttau=m.inffunc.last_ttau, tnu=m.inffunc.last_tnu, **dn(dnlZ))
+
+
+# ----------------------------------------------------------------------------- G9 (cfg 4, restarts)
+def g9():
+    N, d = 512, 16
+    x, y = synth_reg(N, d)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+    m.setNoise(np.log(0.1))
+    m.setData(x, y)
+    hyp0 = np.array(m.meanfunc.hyp + m.covfunc.hyp + m.likfunc.hyp)
+    m.setOptimizer("Minimize", num_restarts=8)
+    runs = []
+    orig_run = ref_opt.minimize.run
+
+    def spy(f, X, *a, **k):
+        X0 = np.array(X, dtype=float)
+        rec = dict(X0=X0, ok=False)
+        runs.append(rec)
+        out = orig_run(f, X, *a, **k)
+        if out is not None:
+            rec.update(ok=True, Xopt=np.array(out[0], dtype=float), f=float(out[1][-1]), nls=int(out[2]),
+                       nfx=len(out[1]))
+        return out
+    ref_opt.minimize.run = spy
+    np.random.seed(123)
+    try:
+        m.optimize(x, y)
+    finally:
+        ref_opt.minimize.run = orig_run
+    R = len(runs)
+    nh = len(hyp0)
+    X0 = np.stack([r["X0"] for r in runs])
+    ok = np.array([r["ok"] for r in runs])
+    Xopt = np.stack([r.get("Xopt", np.full(nh, np.nan)) for r in runs])
+    fopt = np.array([r.get("f", np.nan) for r in runs])
+    nls = np.array([r.get("nls", -1) for r in runs])
+    final = np.array(m.meanfunc.hyp + m.covfunc.hyp + m.likfunc.hyp)
+    save("G9_restarts_N512", N=N, d=d, seed=0, np_seed=123, num_restarts=8, numIterations=40,
+         hyp0=hyp0, run_X0=X0, run_ok=ok, run_Xopt=Xopt, run_f=fopt, run_nls=nls, n_runs=R,
+         best_hyp=final, best_nlZ=m.nlZ)
+
+
+CASES = {
+    "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
+    "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
+    "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048),
+}
+
+if __name__ == "__main__":
+    ids = sys.argv[1:] or ["g1", "g2", "g4", "g4b", "g8", "g9", "g6_2048", "g7_1024"]
+    for i in ids:
+        t = time.time()
+        CASES[i]()
+        print("  %s done in %.1fs" % (i, time.time() - t), flush=True)

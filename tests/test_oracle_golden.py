@@ -1,0 +1,136 @@
+"""CPU: pin the oracle (oracle/gp_oracle.py) to the golden vectors recorded from the reference."""
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, synth_reg, synth_cls
+from oracle import gp_oracle as O
+
+KINDS = {"rbf": (O.RBF, 0), "rbfard": (O.RBFARD, 0), "matern1": (O.MATERN, 1), "matern3": (O.MATERN, 3),
+         "matern5": (O.MATERN, 5), "matern7": (O.MATERN, 7)}
+
+
+@pytest.mark.parametrize("fix,names", [("G4_kernels_seed0", list(KINDS)),
+                                       ("G5_kernels_unit_test_setup", ["rbf", "rbfard", "matern3"])])
+def test_kernels_all_modes(fix, names):
+    g = golden(fix)
+    x, z = g["x"], g["z"]
+    for nm in names:
+        kind, para = KINDS[nm]
+        hyp = g[nm + "_hyp"]
+        for mode, kw in (("train", dict(x=x)), ("cross", dict(x=x, z=z)), ("self", dict(z=z))):
+            m = "self_test" if mode == "self" else mode
+            K = O.cov_matrix(kind, hyp, para, mode=m, **kw)
+            assert K.shape == g["%s_K_%s" % (nm, mode)].shape
+            np.testing.assert_allclose(K, g["%s_K_%s" % (nm, mode)], rtol=1e-13, atol=1e-300)
+            for i in range(len(hyp)):
+                dK = O.der_matrix(kind, hyp, para, mode=m, der=i, **kw)
+                np.testing.assert_allclose(dK, g["%s_dK%d_%s" % (nm, i, mode)], rtol=1e-12, atol=1e-300)
+
+
+def _check_fit(g, out, tol=1e-11):
+    assert relerr(out["nlZ"], g["nlZ"]) < tol
+    assert relerr(out["alpha"], g["alpha"]) < 1e-9
+    assert relerr(out["L"], g["L"]) < 1e-11
+    assert np.all(np.tril(out["L"], -1) == 0)
+    assert relerr(out["sW"], g["sW"]) < 1e-14
+    for k in ("dnlZ_cov", "dnlZ_lik", "dnlZ_mean"):
+        if k in g.files and g[k].size:
+            assert relerr(out[k], g[k]) < 1e-9, k
+
+
+@pytest.mark.parametrize("faithful", [True, False])
+def test_G1_regression_default(faithful):
+    g = golden("G1_regression_default")
+    x, y = g["x"], g["y"]
+    n = x.shape[0]
+    c = g["mean_hyp"][0]
+    assert abs(c - y.mean()) < 1e-15                    # Q8: setData -> Const(mean(y))
+    out = O.exact_fit(O.RBF, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, c * np.ones((n, 1)), np.ones((n, 1)),
+                      faithful=faithful)
+    _check_fit(g, out)
+    ym, ys2, fm, fs2 = O.predict(O.RBF, g["cov_hyp"], 0, g["lik_hyp"][0], x, out["alpha"], out["L"], out["sW"],
+                                 g["xstar"][:3], c * np.ones((3, 1)))
+    assert relerr(ym, g["pred3_ym"]) < 1e-11 and relerr(ys2, g["pred3_ys2"]) < 1e-10
+
+
+@pytest.mark.parametrize("fix,kind", [("G2_seed0_rbf_zero_mean", O.RBF), ("G3_seed0_rbfard_zero_mean", O.RBFARD)])
+@pytest.mark.parametrize("faithful", [True, False])
+def test_G2_G3(fix, kind, faithful):
+    g = golden(fix)
+    x, y = g["x"], g["y"].reshape(-1, 1)
+    out = O.exact_fit(kind, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, np.zeros_like(y), None, faithful=faithful)
+    _check_fit(g, out)
+
+
+def test_G4b_matern5_value_path():
+    g = golden("G4b_matern5_N256")
+    x, y = g["x"], g["y"]
+    c = g["mean_hyp"][0]
+    out = O.exact_fit(O.MATERN, g["cov_hyp"], 5, g["lik_hyp"][0], x, y, c * np.ones_like(y), None, nargout=2)
+    assert relerr(out["nlZ"], g["nlZ"]) < 1e-12
+    assert relerr(out["alpha"], g["alpha"]) < 1e-9 and relerr(out["L"], g["L"]) < 1e-11
+
+
+def test_G6_N2048_scale_and_recipe():
+    g = golden("G6_rbf_d16_N2048")
+    x, y = synth_reg(2048, 16)
+    c = g["mean_hyp"][0]
+    assert abs(c - y.mean()) < 1e-15
+    out = O.exact_fit(O.RBF, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y),
+                      faithful=False)
+    assert relerr(out["nlZ"], g["nlZ"]) < 1e-11
+    assert relerr(out["alpha"][g["alpha_idx"], 0], g["alpha_sample"]) < 1e-8
+    assert relerr(np.diag(out["L"]), g["L_diag"]) < 1e-11
+    assert relerr(out["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-10
+    for k in ("dnlZ_cov", "dnlZ_lik", "dnlZ_mean"):
+        assert relerr(out[k], g[k]) < 1e-8, k
+
+
+def test_G7_N1024_ard_both_gradient_forms():
+    g = golden("G7_rbfard_d64_N1024")
+    x, y = synth_reg(1024, 64)
+    c = g["mean_hyp"][0]
+    for faithful in (True, False):          # False uses the W@X contraction the GPU path also uses
+        out = O.exact_fit(O.RBFARD, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y),
+                          faithful=faithful)
+        assert relerr(out["nlZ"], g["nlZ"]) < 1e-11
+        assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-8
+        assert relerr(out["dnlZ_lik"], g["dnlZ_lik"]) < 1e-8
+
+
+def test_G8_ep_demo_and_synth():
+    g = golden("G8i_classification_demo_ep")
+    x, y = g["x"], g["y"]
+    out = O.ep_fit(O.RBF, g["cov_hyp"], 0, x, y, np.zeros_like(y, dtype=float))
+    assert relerr(out["nlZ"], g["nlZ"]) < 1e-10
+    assert relerr(out["alpha"], g["alpha"]) < 1e-8 and relerr(out["sW"], g["sW"]) < 1e-9
+    assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-8
+    assert relerr(out["L"], g["L"]) < 1e-9
+    ym, ys2, fm, fs2 = O.predict(O.RBF, g["cov_hyp"], 0, 0.0, x, out["alpha"], out["L"], out["sW"], g["xstar5"],
+                                 np.zeros((5, 1)), gauss=False)
+    assert relerr(ym, g["pred_ym"]) < 1e-9 and relerr(fs2, g["pred_fs2"]) < 1e-9
+    g = golden("G8ii_ep_d32_N128")
+    x, y = synth_cls(128, 32)
+    out = O.ep_fit(O.RBF, g["cov_hyp"], 0, x, y, np.zeros_like(y))
+    assert relerr(out["nlZ"], g["nlZ"]) < 1e-10 and relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-8
+    assert relerr(out["ttau"], g["ttau"]) < 1e-9
+
+
+def test_matern_correct_derivative_differs_and_matches_fd():
+    g = golden("G4_kernels_seed0")
+    x = g["x"]
+    hyp = np.array(g["matern3_hyp"])
+    good = O.der_matrix(O.MATERN, hyp, 3, x=x, mode="train", der=0, matern_reference_compat=False)
+    h = 1e-6
+    hp, hm = hyp.copy(), hyp.copy()
+    hp[0] += h; hm[0] -= h
+    fd = (O.cov_matrix(O.MATERN, hp, 3, x=x, mode="train") - O.cov_matrix(O.MATERN, hm, 3, x=x, mode="train")) / (2 * h)
+    assert np.max(np.abs(good - fd)) < 1e-8
+    assert np.max(np.abs(g["matern3_dK0_train"] - fd)) > 1e-2      # the reference's is wrong
+
+
+def test_non_pd_raises_linalgerror():
+    with pytest.raises(np.linalg.LinAlgError):
+        O.jitchol(np.ones((4, 4)))
+    with pytest.raises(Exception, match="Wrong sizes"):
+        O.solve_chol(np.eye(3), np.ones((4, 1)))
