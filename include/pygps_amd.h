@@ -1,0 +1,122 @@
+/* pygps_amd -- C ABI of the MI355X-native exact-GP core (drop-in for the hot path of
+ * marionmari/pyGPs: Core/cov.py kernel-matrix construction + Core/inf.py Exact/EP inference +
+ * Core/tools.py jitchol/solve_chol + Core/gp.py predict).
+ *
+ * Plain C, caller-owned host buffers, fp64, numpy row-major unless stated.  No exception crosses
+ * the ABI.  Every function returns an int status:
+ *      0            ok
+ *     >0            LAPACK-style info: 1-based index of the first non-positive pivot
+ *                   (the shim raises numpy.linalg.LinAlgError, as Core/tools.py:66-77 does)
+ *     -1 .. -99     bad argument (index of the offending argument; the shim raises the reference's
+ *                   plain Exception with the reference's message)
+ *     <= -100       HIP runtime failure (pgp_strerror gives the text; the shim raises RuntimeError)
+ *
+ * One pgp_ctx = one device + one HIP stream + one workspace pool; NOT thread-safe; calls are
+ * synchronous (stream-synchronised before return).  Multi-GPU = one process / one ctx per GPU.
+ *
+ * The Python binding a pyGPs maintainer would add is pygps_amd/_lib.py (ctypes); see INTEGRATION.md.
+ */
+#ifndef PYGPS_AMD_H
+#define PYGPS_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgp_ctx pgp_ctx;
+typedef struct pgp_factor pgp_factor; /* device-resident posterior: factor R, alpha, sW, inputs */
+
+/* covariance kinds            reference class                      */
+#define PGP_COV_RBF 0     /* Core/cov.py:786-828   hyp=[log ell, log sf]               */
+#define PGP_COV_RBFARD 1  /* Core/cov.py:872-938   hyp=[log ell_1..log ell_D, log sf]  */
+#define PGP_COV_MATERN 2  /* Core/cov.py:1078-1182 hyp=[log ell, log sf], para=d in {1,3,5,7} */
+/* modes of getCovMatrix / getDerMatrix (Core/cov.py:81-111) */
+#define PGP_MODE_TRAIN 0
+#define PGP_MODE_CROSS 1
+#define PGP_MODE_SELF_TEST 2
+/* flags */
+#define PGP_FLAG_MATERN_REFERENCE_DER 1 /* reproduce Core/cov.py:1173-1177 (derivative of K, not t) */
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int pgp_init(int device, pgp_ctx** ctx_out);
+void pgp_destroy(pgp_ctx* ctx);
+const char* pgp_strerror(int status);
+const char* pgp_version(void);
+int pgp_device_info(pgp_ctx* ctx, int* n_cu, int* sclk_mhz, double* hbm_gib, char* name, int name_len);
+
+/* ---- kernel plug-in: Kernel.getCovMatrix / getDerMatrix (Core/cov.py:81-111) ---------------
+ * der < 0 : covariance value; der >= 0 : derivative w.r.t. hyper `der` (log-space).
+ * TRAIN: x (n,d) -> out (n,n).  CROSS: x (n,d), z (m,d) -> out (n,m).  SELF_TEST: z (m,d) -> out (m,1).
+ * Error codes: -3 unknown mode, -4 derivative index does not exist, -5/-7 missing x / z.        */
+int pgp_cov(pgp_ctx* ctx, int kind, int mode, int der, const double* x, int64_t n, const double* z, int64_t m,
+            int64_t d, const double* hyp, int nhyp, int para, int flags, double* out);
+
+/* ---- data residency -------------------------------------------------------------------------
+ * The optimiser calls the fit hundreds of times with identical (x, y) and only hyp changing
+ * (Core/opt.py:70-75), so x and y are uploaded once.                                            */
+int pgp_set_data(pgp_ctx* ctx, const double* x, int64_t n, int64_t d, const double* y);
+
+/* ---- inference plug-in: Exact.evaluate (Core/inf.py:353-384) ---------------------------------
+ * Uses the data of the last pgp_set_data.  mvec: prior mean m (n); dm: (nmean, n) rows = derivative
+ * of m w.r.t. each mean hyper (NULL if nmean == 0).  want = nargout (1: post, 2: +nlZ, 3: +dnlZ).
+ * alpha_out (n), nlZ_out (1), dnlZ_out (nmean + ncov + 1, order mean|cov|lik as Core/opt.py:77-80).
+ * factor_out (optional): handle keeping R (upper, R'R = K/sn2 + I), alpha, sW on the device.   */
+int pgp_exact_fit(pgp_ctx* ctx, int kind, const double* covhyp, int ncov, int para, int flags, double log_sn,
+                  const double* mvec, const double* dm, int nmean, int want, double* alpha_out, double* nlZ_out,
+                  double* dnlZ_out, pgp_factor** factor_out);
+
+/* post.L as numpy expects it: (n,n) row-major UPPER factor, exact zeros below the diagonal
+ * (Core/gp.py:393 branches on that).                                                           */
+int pgp_factor_to_host(pgp_ctx* ctx, pgp_factor* f, double* L_out);
+int64_t pgp_factor_n(pgp_factor* f);
+void pgp_factor_free(pgp_ctx* ctx, pgp_factor* f);
+
+/* ---- GP.predict (Core/gp.py:349-437), Cholesky parametrisation -------------------------------
+ * fmu = ms + Ks' alpha ; fs2 = max(kss - colsum((R'^-1 (sW o Ks))^2), 0).                       */
+int pgp_predict(pgp_ctx* ctx, pgp_factor* f, const double* xs, int64_t ns, const double* ms, double* fmu,
+                double* fs2);
+
+/* ---- EP.evaluate with lik.Erf (Core/inf.py:731-806, 174-189; Core/lik.py:295-366) ----------
+ * ttau/tnu (n): in = warm start (ignored if warm == 0), out = final site parameters.           */
+int pgp_ep_fit(pgp_ctx* ctx, int kind, const double* covhyp, int ncov, int para, int flags, const double* mvec,
+               const double* dm, int nmean, int want, int warm, double* ttau, double* tnu, double* alpha_out,
+               double* sW_out, double* nlZ_out, double* dnlZ_out, int* sweeps_out, pgp_factor** factor_out);
+
+/* ---- helper functions: tools.jitchol / tools.solve_chol (Core/tools.py:31-97) ----------------
+ * pgp_potrf: A (n,n) symmetric row-major in -> lower Cholesky factor (row-major, zeros above) out.
+ * pgp_potrs: R (n,n) UPPER factor row-major, Bm (n,nrhs) row-major in -> X = (R'R)^-1 Bm out.   */
+int pgp_potrf(pgp_ctx* ctx, const double* A, int64_t n, double* L_out);
+int pgp_potrs(pgp_ctx* ctx, const double* R, int64_t n, const double* Bm, int64_t nrhs, double* X_out);
+
+/* ---- measurement ------------------------------------------------------------------------------
+ * Stage timings (ms, HIP events on the ctx stream) of the last fit, and -- when profiling is on --
+ * per-kernel-class totals (launches, ms, algorithmic flops, algorithmic bytes).                 */
+#define PGP_STAGE_ASSEMBLE 0
+#define PGP_STAGE_POTRF 1
+#define PGP_STAGE_SOLVE 2
+#define PGP_STAGE_TRTRI 3
+#define PGP_STAGE_LAUUM 4
+#define PGP_STAGE_GRAD 5
+#define PGP_STAGE_TOTAL 6
+#define PGP_NSTAGE 7
+int pgp_last_timings(pgp_ctx* ctx, double* ms_out /* PGP_NSTAGE */);
+int pgp_set_profiling(pgp_ctx* ctx, int on);
+int pgp_profile_classes(void);
+const char* pgp_profile_class_name(int cls);
+int pgp_profile_read(pgp_ctx* ctx, int cls, int64_t* launches, double* ms, double* flops, double* bytes);
+int pgp_profile_reset(pgp_ctx* ctx);
+/* tuning knobs (outer panel width of the blocked Cholesky, look-ahead on/off ...) */
+int pgp_set_option(pgp_ctx* ctx, const char* name, int value);
+
+/* ---- self-test hooks (used by tests/ only) ----------------------------------------------------
+ * Column-major GEMM on host buffers through the fp64 MFMA kernel.                                */
+int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_diag, int kmode, int koff,
+                  double alpha, double beta, const double* A, int64_t lda, const double* B, int64_t ldb,
+                  double* C, int64_t ldc, int M, int N, int K, int iters, double* ms_out);
+int pgp_test_mfma_peak(pgp_ctx* ctx, int iters, double* tflops_out);
+int pgp_test_mfma_cycles(pgp_ctx* ctx, int iters, int nacc, int waves_per_simd, double* out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

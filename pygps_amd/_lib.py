@@ -1,0 +1,155 @@
+"""ctypes binding of libpygps_amd.so (C ABI: include/pygps_amd.h).
+
+This is the stub a pyGPs maintainer would add to call the MI355X core from
+Core/cov.py, Core/inf.py and Core/tools.py.  There is NO
+CPU fallback: if the shared library is missing, or no GPU is visible, every
+entry point raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpygps_amd.so")
+
+COV_RBF, COV_RBFARD, COV_MATERN = 0, 1, 2
+MODE_TRAIN, MODE_CROSS, MODE_SELF_TEST = 0, 1, 2
+FLAG_MATERN_REFERENCE_DER = 1
+STAGES = ("assemble", "potrf", "solve", "trtri", "lauum", "grad", "total")
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); also used by tests/test_capi_symbols.py against include/pygps_amd.h
+SIGNATURES = {
+    "pgp_init": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "pgp_destroy": (None, [_vp]),
+    "pgp_strerror": (C.c_char_p, [C.c_int]),
+    "pgp_version": (C.c_char_p, []),
+    "pgp_device_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_char_p, C.c_int]),
+    "pgp_cov": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _i64, _dp, _i64, _i64, _dp, C.c_int, C.c_int,
+                          C.c_int, _dp]),
+    "pgp_set_data": (C.c_int, [_vp, _dp, _i64, _i64, _dp]),
+    "pgp_exact_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int,
+                                C.c_int, _dp, _dp, _dp, C.POINTER(_vp)]),
+    "pgp_factor_to_host": (C.c_int, [_vp, _vp, _dp]),
+    "pgp_factor_n": (_i64, [_vp]),
+    "pgp_factor_free": (None, [_vp, _vp]),
+    "pgp_predict": (C.c_int, [_vp, _vp, _dp, _i64, _dp, _dp, _dp]),
+    "pgp_ep_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
+                             _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "pgp_potrf": (C.c_int, [_vp, _dp, _i64, _dp]),
+    "pgp_potrs": (C.c_int, [_vp, _dp, _i64, _dp, _i64, _dp]),
+    "pgp_last_timings": (C.c_int, [_vp, _dp]),
+    "pgp_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "pgp_profile_classes": (C.c_int, []),
+    "pgp_profile_class_name": (C.c_char_p, [C.c_int]),
+    "pgp_profile_read": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), _dp, _dp, _dp]),
+    "pgp_profile_reset": (C.c_int, [_vp]),
+    "pgp_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "pgp_test_gemm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                C.c_double, _dp, _i64, _dp, _i64, _dp, _i64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                _dp]),
+    "pgp_test_mfma_peak": (C.c_int, [_vp, C.c_int, _dp]),
+    "pgp_test_mfma_cycles": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
+}
+
+_lock = threading.Lock()
+_dll = None
+_ctx = {}
+
+
+def load():
+    """dlopen the library and attach the prototypes.  Raises if it is not built."""
+    global _dll
+    with _lock:
+        if _dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    "pygps_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+            dll = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(dll, name)          # AttributeError if the .so lacks a declared symbol
+                fn.restype = res
+                fn.argtypes = args
+            _dll = dll
+    return _dll
+
+
+def strerror(rc):
+    return load().pgp_strerror(rc).decode()
+
+
+def check(rc, what="pygps_amd", arg_messages=None):
+    """Map the C status convention onto the reference's exception behaviour
+    (Core/tools.py:66-77 LinAlgError; plain Exception for argument errors)."""
+    if rc == 0:
+        return
+    if rc > 0:
+        raise np.linalg.LinAlgError("kernel matrix not positive definite, even with jitter. (first bad pivot %d)" % rc)
+    if rc <= -100:
+        raise RuntimeError("%s: %s" % (what, strerror(rc)))
+    if arg_messages and rc in arg_messages:
+        raise Exception(arg_messages[rc])
+    raise Exception("%s: bad argument (code %d)" % (what, rc))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def f64(a):
+    """C-contiguous float64 view/copy of a."""
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def default_device():
+    return int(os.environ.get("LOCAL_RANK", os.environ.get("PYGPS_AMD_DEVICE", "0")))
+
+
+def ctx(device=None):
+    """Process-wide context per device (one device + one stream + one workspace pool)."""
+    if device is None:
+        device = default_device()
+    dll = load()
+    with _lock:
+        h = _ctx.get(device)
+        if h is None:
+            out = _vp()
+            rc = dll.pgp_init(device, C.byref(out))
+            if rc != 0:
+                raise RuntimeError("pygps_amd: cannot initialise HIP device %d: %s (no CPU fallback)"
+                                   % (device, dll.pgp_strerror(rc).decode()))
+            h = out
+            _ctx[device] = h
+    return h
+
+
+def device_info(device=None):
+    dll = load()
+    ncu, clk, gib = C.c_int(), C.c_int(), C.c_double()
+    name = C.create_string_buffer(256)
+    check(dll.pgp_device_info(ctx(device), C.byref(ncu), C.byref(clk), C.byref(gib), name, 256))
+    return dict(name=name.value.decode(), n_cu=ncu.value, sclk_mhz=clk.value, hbm_gib=gib.value)
+
+
+def last_timings(device=None):
+    out = np.zeros(len(STAGES))
+    check(load().pgp_last_timings(ctx(device), ptr(out)))
+    return dict(zip(STAGES, out.tolist()))
+
+
+def profile(device=None):
+    """{class name: dict(launches, ms, flops, bytes)} accumulated since the last reset."""
+    dll = load()
+    res = {}
+    for i in range(dll.pgp_profile_classes()):
+        n, ms, fl, by = _i64(), C.c_double(), C.c_double(), C.c_double()
+        check(dll.pgp_profile_read(ctx(device), i, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+        res[dll.pgp_profile_class_name(i).decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value,
+                                                           bytes=by.value)
+    return res

@@ -1,0 +1,628 @@
+// C ABI (include/pygps_amd.h) + host-side drivers: blocked right-looking Cholesky with a two-level
+// panel (outer K = 512 trailing updates on the fp64 MFMA GEMM, inner 128-wide leaves), recursive
+// triangular inverse, W^T W, fused gradient reduce.  See DESIGN.md for the pipeline.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ctx.h"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void pgp_set_last_hip_error(hipError_t e, const char* what, const char* file, int line) {
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+}
+
+void prof_collect(pgp_ctx* c) {
+    if (c->recs.empty()) return;
+    (void)hipStreamSynchronize(c->st);
+    for (auto& r : c->recs) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        c->pc_ms[r.cls] += ms; c->pc_flops[r.cls] += r.flops; c->pc_bytes[r.cls] += r.bytes; c->pc_launch[r.cls]++;
+        c->ev_pool.push_back(r.e0); c->ev_pool.push_back(r.e1);
+    }
+    c->recs.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* pgp_version(void) { return "pygps_amd 0.1 (gfx950)"; }
+
+const char* pgp_strerror(int status) {
+    if (status == 0) return "ok";
+    if (status > 0) return "kernel matrix not positive definite";
+    if (status <= PGP_ERR_HIP) return g_err[0] ? g_err : "HIP runtime failure";
+    return "bad argument";
+}
+
+int pgp_init(int device, pgp_ctx** ctx_out) {
+    if (!ctx_out) return -2;
+    HIP_TRY(hipSetDevice(device));
+    pgp_ctx* c = new pgp_ctx();
+    c->device = device;
+    HIP_TRY(hipGetDeviceProperties(&c->prop, device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    memset(c->last_ms, 0, sizeof(c->last_ms));
+    memset(c->pc_ms, 0, sizeof(c->pc_ms)); memset(c->pc_flops, 0, sizeof(c->pc_flops));
+    memset(c->pc_bytes, 0, sizeof(c->pc_bytes)); memset(c->pc_launch, 0, sizeof(c->pc_launch));
+    HIP_TRY(hipMalloc((void**)&c->scal, 256 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->info_dev, sizeof(int)));
+    *ctx_out = c;
+    return PGP_OK;
+}
+
+void pgp_destroy(pgp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->st);
+    for (auto& kv : c->pool) (void)hipFree(kv.second);
+    void* bufs[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev, c->W, c->T, c->Binv, c->inv16, c->alpha_dev, c->m_dev,
+                    c->rvec, c->zvec, c->partial, c->scal, c->info_dev};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->st);
+    delete c;
+}
+
+int pgp_device_info(pgp_ctx* c, int* n_cu, int* sclk_mhz, double* hbm_gib, char* name, int name_len) {
+    if (!c) return -1;
+    if (n_cu) *n_cu = c->prop.multiProcessorCount;
+    if (sclk_mhz) *sclk_mhz = c->prop.clockRate / 1000;
+    if (hbm_gib) *hbm_gib = (double)c->prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0);
+    if (name && name_len > 0) { strncpy(name, c->prop.name, name_len - 1); name[name_len - 1] = 0; }
+    return PGP_OK;
+}
+
+int pgp_set_option(pgp_ctx* c, const char* name, int value) {
+    if (!c || !name) return -1;
+    if (!strcmp(name, "nb_outer")) { if (value < 1) return -3; c->nb_outer = value; return PGP_OK; }
+    if (!strcmp(name, "small_tile_below")) { c->small_tile_below = value; return PGP_OK; }
+    return -2;
+}
+
+int pgp_last_timings(pgp_ctx* c, double* ms_out) {
+    if (!c || !ms_out) return -1;
+    memcpy(ms_out, c->last_ms, sizeof(c->last_ms));
+    return PGP_OK;
+}
+int pgp_set_profiling(pgp_ctx* c, int on) { if (!c) return -1; c->prof = on != 0; return PGP_OK; }
+int pgp_profile_classes(void) { return PC_COUNT; }
+const char* pgp_profile_class_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : "?"; }
+int pgp_profile_read(pgp_ctx* c, int cls, int64_t* launches, double* ms, double* flops, double* bytes) {
+    if (!c || cls < 0 || cls >= PC_COUNT) return -1;
+    prof_collect(c);
+    if (launches) *launches = c->pc_launch[cls];
+    if (ms) *ms = c->pc_ms[cls];
+    if (flops) *flops = c->pc_flops[cls];
+    if (bytes) *bytes = c->pc_bytes[cls];
+    return PGP_OK;
+}
+int pgp_profile_reset(pgp_ctx* c) {
+    if (!c) return -1;
+    prof_collect(c);
+    memset(c->pc_ms, 0, sizeof(c->pc_ms)); memset(c->pc_flops, 0, sizeof(c->pc_flops));
+    memset(c->pc_bytes, 0, sizeof(c->pc_bytes)); memset(c->pc_launch, 0, sizeof(c->pc_launch));
+    return PGP_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// host-side helpers
+// ------------------------------------------------------------------------------------------------
+
+static int matern_d(int para) { return (para == 1 || para == 3 || para == 5 || para == 7) ? para : 3; }
+
+// per-coordinate scales of the reference: RBF x/ell (cov.py:804); RBFard x*(1/ell_k) (:893-899);
+// Matern sqrt(d)*x/ell (:1141)
+int fill_scale(int kind, const double* hyp, int nhyp, int para, long d, std::vector<double>& sc) {
+    sc.assign(d, 1.0);
+    if (kind == PGP_COV_RBF) {
+        if (nhyp != 2) return -10;
+        const double ell = exp(hyp[0]);
+        for (auto& s : sc) s = 1.0 / ell;
+    } else if (kind == PGP_COV_RBFARD) {
+        if (nhyp != d + 1) return -10;
+        for (long k = 0; k < d; ++k) sc[k] = 1.0 / exp(hyp[k]);
+    } else if (kind == PGP_COV_MATERN) {
+        if (nhyp != 2) return -10;
+        const double ell = exp(hyp[0]);
+        for (auto& s : sc) s = sqrt((double)matern_d(para)) / ell;
+    } else {
+        return -2;
+    }
+    return PGP_OK;
+}
+
+CovParams make_cp(int kind, const double* hyp, int nhyp, int para, int flags, int der, long d) {
+    CovParams cp;
+    cp.kind = kind; cp.der = der; cp.md = matern_d(para);
+    cp.ref_der = (flags & PGP_FLAG_MATERN_REFERENCE_DER) ? 1 : 0;
+    cp.D = (int)d;
+    cp.sf2 = exp(2.0 * hyp[nhyp - 1]);
+    return cp;
+}
+
+// upload host x (n,d) scaled+transposed into a fresh device buffer XsT (dpad x ldp)
+static int upload_scaled(pgp_ctx* c, const double* x_dev, long n, long d, const std::vector<double>& sc, double* XsT,
+                         long ldp, int dpad, double* scale_dev) {
+    HIP_TRY(hipMemcpyAsync(scale_dev, sc.data(), d * sizeof(double), hipMemcpyHostToDevice, c->st));
+    return scale_transpose_launch(x_dev, n, (int)d, scale_dev, XsT, ldp, dpad, c->st);
+}
+
+int gemm_prof(pgp_ctx* c, int cls, GemmArgs g) {
+    if (g.batch < 1) g.batch = 1;
+    ProfScope ps(c, cls, g.flops, 0.0);
+    return gemm_f64_launch(g, c->st);
+}
+
+// Blocked right-looking Cholesky of the (mrows x np) column-major lower matrix F (mrows >= np; rows
+// beyond np are "augmented" right-hand-side rows that receive the forward substitution for free).
+int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows) {
+    const int nblk = (int)(np / 128);
+    const int q = c->nb_outer;
+    for (int s0 = 0; s0 < nblk; s0 += q) {
+        const int s1 = std::min(s0 + q, nblk);
+        for (int cb = s0; cb < s1; ++cb) {
+            double* Acc = F + (long)cb * 128 + (long)cb * 128 * ld;
+            {
+                ProfScope ps(c, PC_LEAF, 128.0 * 128.0 * 128.0 / 3.0, 0.0);
+                CHK(leaf_potrf_launch(Acc, ld, c->inv16 + (long)cb * 2048, c->info_dev, cb * 128, c->st));
+            }
+            const long rows_below = mrows - (long)(cb + 1) * 128;
+            if (rows_below > 0) {
+                ProfScope ps(c, PC_TRSM, (double)rows_below * 128.0 * 128.0, 0.0);
+                CHK(trsm_rows_launch(Acc + 128, ld, rows_below, Acc, ld, c->inv16 + (long)cb * 2048, c->st));
+            }
+            if (cb + 1 < s1) {               // inner update of the rest of this outer panel, K = 128
+                GemmArgs g{};
+                g.A = Acc + 128; g.lda = ld; g.a_kc = 0;
+                g.B = Acc + 128; g.ldb = ld; g.b_kc = 0;
+                g.C = F + (long)(cb + 1) * 128 + (long)(cb + 1) * 128 * ld; g.ldc = ld;
+                g.M = (int)rows_below; g.N = (s1 - 1 - cb) * 128; g.K = 128;
+                g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
+                const long t128 = (long)(g.M / 128) * (g.N / 128);
+                g.tile = t128 < c->small_tile_below ? 64 : 128;
+                g.flops = 2.0 * 128.0 * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
+                CHK(gemm_prof(c, PC_GEMM_INNER, g));
+            }
+        }
+        if (s1 < nblk) {                     // trailing update, K = (s1 - s0) * 128
+            GemmArgs g{};
+            const double* P = F + (long)s1 * 128 + (long)s0 * 128 * ld;
+            g.A = P; g.lda = ld; g.a_kc = 0;
+            g.B = P; g.ldb = ld; g.b_kc = 0;
+            g.C = F + (long)s1 * 128 + (long)s1 * 128 * ld; g.ldc = ld;
+            g.M = (int)(mrows - (long)s1 * 128); g.N = (int)(np - (long)s1 * 128); g.K = (s1 - s0) * 128;
+            g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
+            const long t128 = (long)(g.M / 128) * (g.N / 128) / 2;
+            g.tile = t128 < c->small_tile_below ? 64 : 128;
+            g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
+            CHK(gemm_prof(c, PC_GEMM_TRAIL, g));
+        }
+    }
+    return PGP_OK;
+}
+
+// W = L^-1 (column-major lower, np x np).  Level 0: batched inversion of the 128-blocks; then the
+// recursion  W21 = -W22 (L21 W11)  bottom-up.  Levels whose nodes all share one shape run as ONE
+// batched launch per product.
+struct TriNode { int lo, mid, hi, depth; };
+static void tri_nodes(int lo, int hi, int depth, std::vector<TriNode>& out) {
+    if (hi - lo <= 1) return;
+    int half = 1;
+    while (half * 2 < hi - lo) half *= 2;          // largest power of two < size  (== size/2 for powers of two)
+    const int mid = lo + half;
+    out.push_back({lo, mid, hi, depth});
+    tri_nodes(lo, mid, depth + 1, out);
+    tri_nodes(mid, hi, depth + 1, out);
+}
+
+static int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ldw, double* T, long np) {
+    const int nblk = (int)(np / 128);
+    {
+        ProfScope ps(c, PC_LEAFINV, (double)nblk * 128.0 * 128.0 * 128.0 / 3.0, 0.0);
+        CHK(leaf_inv_launch(L, ldl, W, ldw, nblk, c->st));
+    }
+    std::vector<TriNode> nodes;
+    tri_nodes(0, nblk, 0, nodes);
+    int maxd = -1;
+    for (auto& nd : nodes) maxd = std::max(maxd, nd.depth);
+    for (int dep = maxd; dep >= 0; --dep) {
+        std::vector<TriNode> lv;
+        for (auto& nd : nodes) if (nd.depth == dep) lv.push_back(nd);
+        if (lv.empty()) continue;
+        std::sort(lv.begin(), lv.end(), [](const TriNode& a, const TriNode& b) { return a.lo < b.lo; });
+        bool uniform = true;
+        const int h1 = lv[0].mid - lv[0].lo, h2 = lv[0].hi - lv[0].mid;
+        const int step = lv.size() > 1 ? lv[1].lo - lv[0].lo : 0;
+        for (size_t i = 0; i < lv.size(); ++i)
+            if (lv[i].mid - lv[i].lo != h1 || lv[i].hi - lv[i].mid != h2 || lv[i].lo != lv[0].lo + (int)i * step)
+                uniform = false;
+        const size_t ngroups = uniform ? 1 : lv.size();
+        for (size_t gi = 0; gi < ngroups; ++gi) {
+            const TriNode& nd = lv[gi];
+            const int a1 = (nd.mid - nd.lo) * 128, a2 = (nd.hi - nd.mid) * 128;
+            const long o1 = (long)nd.lo * 128, o2 = (long)nd.mid * 128;
+            const int batch = uniform ? (int)lv.size() : 1;
+            const long bstep = (long)step * 128;
+            const long t128 = (long)(a2 / 128) * (a1 / 128) * batch;
+            // T (a2 x a1) = L21 * W11            k >= j0 (W11 lower triangular)
+            GemmArgs g{};
+            g.A = L + o2 + o1 * ldl; g.lda = ldl; g.a_kc = 0;
+            g.B = W + o1 + o1 * ldw; g.ldb = ldw; g.b_kc = 1;
+            g.C = T; g.ldc = a2;
+            g.M = a2; g.N = a1; g.K = a1; g.alpha = 1.0; g.beta = 0.0;
+            g.kmode = KM_GE_J; g.koff = 0;
+            g.batch = batch; g.sA = bstep * (1 + ldl); g.sB = bstep * (1 + ldw); g.sC = (long)a1 * a2;
+            g.tile = t128 < c->small_tile_below ? 64 : 128;
+            g.flops = (double)batch * (double)a2 * a1 * a1;
+            CHK(gemm_prof(c, PC_GEMM_TRTRI, g));
+            // W21 = -W22 * T                     k < i0 + TM (W22 lower triangular)
+            GemmArgs h{};
+            h.A = W + o2 + o2 * ldw; h.lda = ldw; h.a_kc = 0;
+            h.B = T; h.ldb = a2; h.b_kc = 1;
+            h.C = W + o2 + o1 * ldw; h.ldc = ldw;
+            h.M = a2; h.N = a1; h.K = a2; h.alpha = -1.0; h.beta = 0.0;
+            h.kmode = KM_LT_I; h.koff = 0;
+            h.batch = batch; h.sA = bstep * (1 + ldw); h.sB = (long)a1 * a2; h.sC = bstep * (1 + ldw);
+            h.tile = g.tile;
+            h.flops = (double)batch * (double)a2 * a2 * a1;
+            CHK(gemm_prof(c, PC_GEMM_TRTRI, h));
+        }
+    }
+    return PGP_OK;
+}
+
+// Binv (lower) = W^T W
+static int lauum_lower(pgp_ctx* c, const double* W, long ldw, double* Binv, long ldb, long np) {
+    GemmArgs g{};
+    g.A = W; g.lda = ldw; g.a_kc = 1;
+    g.B = W; g.ldb = ldw; g.b_kc = 1;
+    g.C = Binv; g.ldc = ldb;
+    g.M = (int)np; g.N = (int)np; g.K = (int)np; g.alpha = 1.0; g.beta = 0.0;
+    g.tri = 2; g.mask_diag = 1; g.kmode = KM_GE_I; g.koff = 0;
+    const long t128 = (np / 128) * (np / 128 + 1) / 2;
+    g.tile = t128 < c->small_tile_below ? 64 : 128;
+    g.flops = (double)np * np * np / 3.0;
+    return gemm_prof(c, PC_GEMM_LAUUM, g);
+}
+
+static int ensure_workspace(pgp_ctx* c, long np) {
+    if (c->ws_np == np) return PGP_OK;
+    (void)hipStreamSynchronize(c->st);
+    void* olds[] = {c->W, c->T, c->Binv, c->inv16, c->alpha_dev, c->m_dev, c->rvec, c->zvec};
+    for (void* b : olds) if (b) (void)hipFree(b);
+    c->W = c->T = c->Binv = c->inv16 = c->alpha_dev = c->m_dev = c->rvec = c->zvec = nullptr;
+    const size_t nn = (size_t)np * np * sizeof(double);
+    HIP_TRY(hipMalloc((void**)&c->W, nn));
+    HIP_TRY(hipMemsetAsync(c->W, 0, nn, c->st));
+    HIP_TRY(hipMalloc((void**)&c->Binv, nn));
+    HIP_TRY(hipMemsetAsync(c->Binv, 0, nn, c->st));
+    HIP_TRY(hipMalloc((void**)&c->T, std::max<size_t>(nn / 4, 128 * 128 * sizeof(double))));
+    HIP_TRY(hipMalloc((void**)&c->inv16, (size_t)(np / 128) * 2048 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->alpha_dev, np * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->m_dev, np * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->rvec, np * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->zvec, np * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->alpha_dev, 0, np * sizeof(double), c->st));
+    HIP_TRY(hipMemsetAsync(c->rvec, 0, np * sizeof(double), c->st));
+    c->ws_np = np;
+    return PGP_OK;
+}
+
+static int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F) {
+    const size_t bytes = (size_t)ldf * np * sizeof(double);
+    auto it = c->pool.find(bytes);
+    if (it != c->pool.end()) { *F = (double*)it->second; c->pool.erase(it); return PGP_OK; }
+    HIP_TRY(hipMalloc((void**)F, bytes));
+    HIP_TRY(hipMemsetAsync(*F, 0, bytes, c->st));     // strict-upper tiles and augmented rows stay 0 forever
+    return PGP_OK;
+}
+
+extern "C" {
+
+int pgp_set_data(pgp_ctx* c, const double* x, int64_t n, int64_t d, const double* y) {
+    if (!c) return -1;
+    if (!x) return -2;
+    if (n <= 0) return -3;
+    if (d <= 0) return -4;
+    HIP_TRY(hipSetDevice(c->device));
+    (void)hipStreamSynchronize(c->st);
+    void* olds[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev};
+    for (void* b : olds) if (b) (void)hipFree(b);
+    c->x_dev = c->y_dev = c->XsT = c->scale_dev = nullptr;
+    c->n = n; c->d = d; c->np = round_up(n, 128); c->ldf = c->np + 128; c->dpad = (int)round_up(d, SKC);
+    HIP_TRY(hipMalloc((void**)&c->x_dev, n * d * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->y_dev, c->np * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->XsT, (size_t)c->dpad * c->np * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->scale_dev, c->dpad * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->x_dev, x, n * d * sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipMemsetAsync(c->y_dev, 0, c->np * sizeof(double), c->st));
+    if (y) HIP_TRY(hipMemcpyAsync(c->y_dev, y, n * sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    return PGP_OK;
+}
+
+int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para, int flags, double log_sn,
+                  const double* mvec, const double* dm, int nmean, int want, double* alpha_out, double* nlZ_out,
+                  double* dnlZ_out, pgp_factor** factor_out) {
+    if (!c) return -1;
+    if (c->n <= 0) return -1;
+    if (kind < 0 || kind > 2) return -2;
+    if (!covhyp) return -3;
+    if (want < 1 || want > 3) return -11;
+    HIP_TRY(hipSetDevice(c->device));
+    const long n = c->n, d = c->d, np = c->np, ldf = c->ldf;
+    std::vector<double> sc;
+    CHK(fill_scale(kind, covhyp, ncov, para, d, sc));
+    CHK(ensure_workspace(c, np));
+    const long need = hadamard_partial_count(np, ncov);
+    if (want >= 3 && c->partial_cap < need) {
+        if (c->partial) (void)hipFree(c->partial);
+        HIP_TRY(hipMalloc((void**)&c->partial, need * sizeof(double)));
+        c->partial_cap = need;
+    }
+    const double sn2 = exp(2.0 * log_sn);
+    CovParams cp = make_cp(kind, covhyp, ncov, para, flags, -1, d);
+    double* F = nullptr;
+    CHK(alloc_factor_buffer(c, np, ldf, &F));
+    hipStream_t st = c->st;
+    HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
+    if (mvec) HIP_TRY(hipMemcpyAsync(c->m_dev, mvec, n * sizeof(double), hipMemcpyHostToDevice, st));
+    else HIP_TRY(hipMemsetAsync(c->m_dev, 0, n * sizeof(double), st));
+
+    // ---- S1': fused assembly of B = K/sn2 + I into the factor buffer --------------------------
+    HIP_TRY(hipEventRecord(c->ev[0], st));
+    CHK(upload_scaled(c, c->x_dev, n, d, sc, c->XsT, np, c->dpad, c->scale_dev));
+    {
+        ProfScope ps(c, PC_ASSEMBLE, 0.0, 8.0 * (double)np * (np + 1) / 2.0 + 8.0 * (double)n * d);
+        CHK(cov_factor_launch(c->XsT, np, n, np, c->dpad, cp, 1.0 / sn2, F, ldf, st));
+    }
+    CHK(aug_rhs_launch(c->y_dev, c->m_dev, n, F, ldf, np, c->rvec, st));
+    // ---- S2: Cholesky (forward substitution of the augmented row rides along) ------------------
+    HIP_TRY(hipEventRecord(c->ev[1], st));
+    CHK(potrf_blocked(c, F, ldf, np, np + 128));
+    HIP_TRY(hipEventRecord(c->ev[2], st));
+    int info = 0;
+    // ---- S5a/S3: W = L^-1, alpha = W^T z / sn2 (or blocked back-substitution when W is not needed)
+    CHK(gather_strided_launch(F + np, ldf, np, c->zvec, st));
+    if (want >= 3) {
+        CHK(trtri_lower(c, F, ldf, c->W, np, c->T, np));
+        HIP_TRY(hipEventRecord(c->ev[3], st));
+        { ProfScope ps(c, PC_SMALL, 0.0, 4.0 * (double)np * np);
+          CHK(col_dot_launch(c->W, np, np, c->zvec, 1, 1.0 / sn2, c->alpha_dev, st)); }
+    } else {
+        { ProfScope ps(c, PC_LEAFINV, 0.0, 0.0);
+          CHK(leaf_inv_launch(F, ldf, c->W, np, (int)(np / 128), st)); }
+        HIP_TRY(hipEventRecord(c->ev[3], st));
+        { ProfScope ps(c, PC_SMALL, 0.0, 4.0 * (double)np * np);
+          CHK(trsv_bwd_launch(F, ldf, c->W, np, c->zvec, c->alpha_dev, (int)(np / 128), st)); }
+    }
+    // scalars: logdet, z'z   (note zvec is consumed by the back-substitution, so z'z comes from F)
+    CHK(logdet_ztz_launch(F, ldf, n, F + np, ldf, c->scal, st));
+    HIP_TRY(hipEventRecord(c->ev[4], st));
+    // ---- S5b: B^-1 = W^T W ; S6: gradient reduce ------------------------------------------------
+    if (want >= 3) {
+        CHK(lauum_lower(c, c->W, np, c->Binv, np, np));
+        HIP_TRY(hipEventRecord(c->ev[5], st));
+        // alpha currently holds W^T z / sn2 = B^-1 r / sn2  (already the final alpha)
+        { ProfScope ps(c, PC_HADAMARD, 0.0, 8.0 * (double)np * (np + 1) / 2.0 + 8.0 * (double)n * d);
+          CHK(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, sn2, c->Binv, np, c->alpha_dev, c->partial,
+                                     c->scal + 8, st)); }
+    } else {
+        HIP_TRY(hipEventRecord(c->ev[5], st));
+    }
+    HIP_TRY(hipEventRecord(c->ev[6], st));
+    // ---- results to host -------------------------------------------------------------------------
+    std::vector<double> sc_host(8 + ncov + 1, 0.0);
+    if (want < 3) {   // back-substitution produced L^-T z; scale to alpha = B^-1 r / sn2
+        // (col_dot path already applied 1/sn2)
+    }
+    HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(sc_host.data(), c->scal, (8 + ncov + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+    std::vector<double> alpha_h(n);
+    HIP_TRY(hipMemcpyAsync(alpha_h.data(), c->alpha_dev, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (want < 3) for (auto& a : alpha_h) a /= sn2;
+    {
+        float ms;
+        const int map[6][2] = {{0, 1}, {1, 2}, {3, 4}, {2, 3}, {4, 5}, {5, 6}};   // assemble, potrf, solve, trtri, lauum, grad
+        for (int i = 0; i < 6; ++i) { (void)hipEventElapsedTime(&ms, c->ev[map[i][0]], c->ev[map[i][1]]); c->last_ms[i] = ms; }
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[6]); c->last_ms[PGP_STAGE_TOTAL] = ms;
+    }
+    if (c->prof) prof_collect(c);
+    if (info != 0) {
+        pool_free(c, (size_t)ldf * np * sizeof(double), nullptr);
+        // the buffer now holds NaNs: scrub before it can be reused
+        (void)hipMemsetAsync(F, 0, (size_t)ldf * np * sizeof(double), st);
+        (void)hipStreamSynchronize(st);
+        pool_free(c, (size_t)ldf * np * sizeof(double), F);
+        return info > (int)n ? (int)n : info;
+    }
+    if (alpha_out) memcpy(alpha_out, alpha_h.data(), n * sizeof(double));
+    if (want >= 2 && nlZ_out) {
+        const double logdet = sc_host[0], ztz = sc_host[1];
+        *nlZ_out = 0.5 * ztz / sn2 + logdet + 0.5 * (double)n * log(2.0 * M_PI * sn2);
+    }
+    if (want >= 3 && dnlZ_out) {
+        for (int i = 0; i < nmean; ++i) {                 // Core/inf.py:378-381
+            double s = 0.0;
+            for (long j = 0; j < n; ++j) s += dm[(long)i * n + j] * alpha_h[j];
+            dnlZ_out[i] = -s;
+        }
+        for (int h = 0; h < ncov; ++h) dnlZ_out[nmean + h] = 0.5 * sc_host[8 + h];      // inf.py:377
+        dnlZ_out[nmean + ncov] = sc_host[8 + ncov];                                     // inf.py:374
+    }
+    if (factor_out) {
+        pgp_factor* f = new pgp_factor();
+        f->n = n; f->np = np; f->ldf = ldf; f->F = F; f->dpad = c->dpad; f->d = (int)d; f->cp = cp; f->sn2 = sn2;
+        f->sw = 1.0 / sqrt(sn2); f->scale = sc; f->Wd = nullptr;
+        HIP_TRY(hipMalloc((void**)&f->alpha, np * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(f->alpha, 0, np * sizeof(double), st));
+        HIP_TRY(hipMemcpyAsync(f->alpha, alpha_h.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMalloc((void**)&f->XsT, (size_t)c->dpad * np * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(f->XsT, c->XsT, (size_t)c->dpad * np * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *factor_out = f;
+    } else {
+        pool_free(c, (size_t)ldf * np * sizeof(double), F);
+    }
+    return PGP_OK;
+}
+
+int64_t pgp_factor_n(pgp_factor* f) { return f ? f->n : 0; }
+
+int pgp_factor_to_host(pgp_ctx* c, pgp_factor* f, double* L_out) {
+    if (!c || !f) return -1;
+    if (!L_out) return -3;
+    HIP_TRY(hipSetDevice(c->device));
+    // row-major upper R(r, c) lives at F[r*ldf + c]; copy the n x n corner
+    HIP_TRY(hipMemcpy2DAsync(L_out, f->n * sizeof(double), f->F, f->ldf * sizeof(double), f->n * sizeof(double), f->n,
+                             hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    return PGP_OK;
+}
+
+void pgp_factor_free(pgp_ctx* c, pgp_factor* f) {
+    if (!f) return;
+    if (c) {
+        (void)hipSetDevice(c->device);
+        // augmented rows / upper tiles of a pooled buffer must be zero when it is reused: the factor only ever
+        // wrote the lower triangle + row np, and row np is rewritten by every fit, so it can go back as is.
+        pool_free(c, (size_t)f->ldf * f->np * sizeof(double), f->F);
+    }
+    if (f->alpha) (void)hipFree(f->alpha);
+    if (f->XsT) (void)hipFree(f->XsT);
+    if (f->Wd) (void)hipFree(f->Wd);
+    delete f;
+}
+
+// ---- kernel plug-in ------------------------------------------------------------------------------
+int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n, const double* z, int64_t m,
+            int64_t d, const double* hyp, int nhyp, int para, int flags, double* out) {
+    if (!c) return -1;
+    if (kind < 0 || kind > 2) return -2;
+    if (mode < 0 || mode > 2) return -3;
+    if (!hyp) return -10;
+    if (!out) return -14;
+    if (mode != PGP_MODE_SELF_TEST && !x) return -5;
+    if (mode != PGP_MODE_TRAIN && !z) return -7;
+    if (d <= 0) return -9;
+    if (kind == PGP_COV_RBFARD && nhyp != d + 1) return -11;
+    if (kind != PGP_COV_RBFARD && nhyp != 2) return -11;
+    const int nder = (kind == PGP_COV_MATERN) ? 3 : nhyp;           // Matern accepts der == 2 (cov.py:1178)
+    if (der >= nder) return -4;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->st;
+    CovParams cp = make_cp(kind, hyp, nhyp, para, flags, der, d);
+    if (mode == PGP_MODE_SELF_TEST) {
+        // A = 0: value sf2*f(0); derivatives per Core/cov.py:815-817, 924-925, 1163-1177
+        double val;
+        if (der < 0) val = cp.sf2;
+        else if (kind == PGP_COV_RBF) val = der == 0 ? 0.0 : 2.0 * cp.sf2;
+        else if (kind == PGP_COV_RBFARD) val = der < d ? 0.0 : 2.0 * cp.sf2;
+        else {
+            const double K = cp.sf2;   // matern at t = 0
+            if (der == 2) val = 0.0;
+            else if (cp.ref_der) {
+                auto poly = [&](double t) { switch (cp.md) { case 1: return 1.0; case 3: return 1.0 + t;
+                    case 5: return 1.0 + t + t * t / 3.0; default: return 1.0 + t + 2.0 * t * t / 5.0 + t * t * t / 15.0; } };
+                auto dpoly = [&](double t) { switch (cp.md) { case 1: return 1.0; case 3: return t;
+                    case 5: return (t + t * t) / 3.0; default: return (t + 3.0 * t * t + t * t * t) / 15.0; } };
+                val = der == 0 ? cp.sf2 * dpoly(K) * K * exp(-K) : 2.0 * cp.sf2 * poly(K) * exp(-K);
+            } else val = der == 0 ? 0.0 : 2.0 * cp.sf2;
+        }
+        for (int64_t i = 0; i < m; ++i) out[i] = val;
+        return PGP_OK;
+    }
+    std::vector<double> sc;
+    CHK(fill_scale(kind, hyp, nhyp, para, d, sc));
+    const int dpad = (int)round_up(d, SKC);
+    const long ldr = round_up(n, 128), ldc = (mode == PGP_MODE_CROSS) ? round_up(m, 128) : 0;
+    const long mm = (mode == PGP_MODE_CROSS) ? m : n;
+    double *xd = nullptr, *zd = nullptr, *XrT = nullptr, *XcT = nullptr, *scd = nullptr, *od = nullptr;
+    HIP_TRY(hipMalloc((void**)&xd, n * d * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&XrT, (size_t)dpad * ldr * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&scd, dpad * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&od, (size_t)n * mm * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(xd, x, n * d * sizeof(double), hipMemcpyHostToDevice, st));
+    int rc = upload_scaled(c, xd, n, d, sc, XrT, ldr, dpad, scd);
+    if (rc == PGP_OK && mode == PGP_MODE_CROSS) {
+        HIP_TRY(hipMalloc((void**)&zd, m * d * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&XcT, (size_t)dpad * ldc * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(zd, z, m * d * sizeof(double), hipMemcpyHostToDevice, st));
+        rc = scale_transpose_launch(zd, m, (int)d, scd, XcT, ldc, dpad, st);
+    }
+    if (rc == PGP_OK) {
+        ProfScope ps(c, PC_ASSEMBLE, 0.0, 8.0 * (double)n * mm + 8.0 * (double)(n + (mode == PGP_MODE_CROSS ? m : 0)) * d);
+        if (mode == PGP_MODE_TRAIN) rc = cov_sym_launch(XrT, ldr, n, dpad, cp, od, st);
+        else rc = cov_rect_launch(XrT, ldr, n, XcT, ldc, m, dpad, cp, od, m, st);
+    }
+    if (rc == PGP_OK) {
+        hipError_t e = hipMemcpyAsync(out, od, (size_t)n * mm * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { pgp_set_last_hip_error(e, "cov copy-out", __FILE__, __LINE__); rc = PGP_ERR_HIP; }
+    }
+    if (c->prof) prof_collect(c);
+    void* bufs[] = {xd, zd, XrT, XcT, scd, od};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    return rc;
+}
+
+// ---- helper functions ------------------------------------------------------------------------------
+int pgp_potrf(pgp_ctx* c, const double* A, int64_t n, double* L_out) {
+    if (!c) return -1;
+    if (!A) return -2;
+    if (n <= 0) return -3;
+    if (!L_out) return -4;
+    HIP_TRY(hipSetDevice(c->device));
+    const long np = round_up(n, 128);
+    hipStream_t st = c->st;
+    double* F = nullptr;
+    HIP_TRY(hipMalloc((void**)&F, (size_t)np * np * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(F, 0, (size_t)np * np * sizeof(double), st));
+    // symmetric input: row-major == column-major; copy the n x n corner, identity on the padding
+    HIP_TRY(hipMemcpy2DAsync(F, np * sizeof(double), A, n * sizeof(double), n * sizeof(double), n, hipMemcpyHostToDevice, st));
+    std::vector<double> ones(np - n, 1.0);
+    if (np > n)
+        HIP_TRY(hipMemcpy2DAsync(F + n + n * np, (np + 1) * sizeof(double), ones.data(), sizeof(double), sizeof(double),
+                                 np - n, hipMemcpyHostToDevice, st));
+    const long save_ws = c->ws_np;
+    (void)save_ws;
+    double* inv16_save = c->inv16;
+    double* inv16 = nullptr;
+    HIP_TRY(hipMalloc((void**)&inv16, (size_t)(np / 128) * 2048 * sizeof(double)));
+    c->inv16 = inv16;
+    HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
+    int rc = potrf_blocked(c, F, np, np, np);
+    c->inv16 = inv16_save;
+    int info = 0;
+    if (rc == PGP_OK) {
+        HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (rc == PGP_OK && info == 0) {
+        // device holds column-major lower L; numpy wants row-major lower => transpose on the host
+        std::vector<double> tmp((size_t)n * n);
+        HIP_TRY(hipMemcpy2D(tmp.data(), n * sizeof(double), F, np * sizeof(double), n * sizeof(double), n,
+                            hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t j = 0; j < n; ++j) L_out[i * n + j] = (j <= i) ? tmp[(size_t)j * n + i] : 0.0;
+    }
+    if (c->prof) prof_collect(c);
+    (void)hipFree(F);
+    (void)hipFree(inv16);
+    if (rc != PGP_OK) return rc;
+    return info > (int)n ? (int)n : info;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// Shared declarations for the MI355X (gfx950) exact-GP core.  Internal header: the public
+// C ABI is include/pygps_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+
+#define PGP_OK 0
+#define PGP_ERR_HIP (-100)
+#define PGP_ERR_ARG (-1)
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            pgp_set_last_hip_error(e__, #expr, __FILE__, __LINE__);                         \
+            return PGP_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+void pgp_set_last_hip_error(hipError_t e, const char* what, const char* file, int line);
+
+// ------------------------------------------------------------------------------------------
+// fp64 MFMA GEMM family (gemm_f64.hip).  All matrices are column-major ("Fortran") views:
+//   C(m,n) at C[m + n*ldc].
+// Operand storage is described per operand:
+//   *_kc == 0 : "M-contiguous"  A(m,k) at A[m + k*lda]   (column-major M x K)
+//   *_kc == 1 : "K-contiguous"  A(m,k) at A[k + m*lda]   (column-major K x M, i.e. A^T stored)
+// The kernel computes, per 128x128 (or 64x64) tile,
+//   C = alpha * sum_{k in range(tile)} A(m,k) B(n,k)  + beta * C        alpha in {+1,-1}, beta in {0,1}
+// ------------------------------------------------------------------------------------------
+enum GemmKMode {
+    KM_FULL = 0,     // k in [0, K)
+    KM_GE_I = 1,     // k in [i0 + koff, K)        (i0 = first row of the tile)
+    KM_GE_J = 2,     // k in [j0 + koff, K)        (j0 = first column of the tile)
+    KM_LT_I = 3,     // k in [0, i0 + TM + koff)
+};
+
+struct GemmArgs {
+    const double* A; long lda; int a_kc;
+    const double* B; long ldb; int b_kc;
+    double* C; long ldc;
+    int M, N, K;            // multiples of the tile size / 16
+    double alpha, beta;
+    int tri;                // 1: only tiles with (i0 + tri_off >= j0); diagonal tiles (==) masked to i>=j if mask_diag
+    int tri_off;            // row offset of C's row 0 relative to its column 0 in the parent matrix
+    int mask_diag;
+    int kmode; int koff;
+    int batch; long sA, sB, sC;   // batch strides in elements
+    int tile;               // 128 or 64
+    double flops;           // algorithmic flops of this launch (for profiling; filled by caller)
+};
+
+int gemm_f64_launch(const GemmArgs& g, hipStream_t st);

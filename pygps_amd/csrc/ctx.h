@@ -1,0 +1,107 @@
+// Internal: context / factor structs shared by the host-side drivers (capi.hip, predict.hip, ep.hip).
+#pragma once
+#include <map>
+#include <vector>
+
+#include "../../include/pygps_amd.h"
+#include "kernels.h"
+#include "sqdist_tile.h"
+
+enum ProfClass { PC_ASSEMBLE = 0, PC_GEMM_TRAIL, PC_GEMM_INNER, PC_LEAF, PC_TRSM, PC_LEAFINV, PC_GEMM_TRTRI,
+                 PC_GEMM_LAUUM, PC_HADAMARD, PC_SMALL, PC_COUNT };
+static const char* const kProfNames[PC_COUNT] = {
+    "cov_tile_kernel(assemble)", "gemm_f64(potrf trailing syrk)", "gemm_f64(potrf inner update)",
+    "leaf_potrf_kernel", "trsm_rows_kernel", "leaf_inv_kernel", "gemm_f64(trtri)", "gemm_f64(lauum W^T W)",
+    "hadamard_reduce_kernel", "small/O(N) kernels"};
+
+struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
+
+struct pgp_factor {
+    long n, np, ldf;
+    double* F;            // (ldf x np) column-major lower factor == row-major upper R (+ augmented rows)
+    double* alpha;        // n
+    double* XsT;          // dpad x np scaled coordinates used for this fit
+    double* Wd;           // np x 128 : inverted diagonal blocks (lazy, for predict)
+    int dpad, d;
+    CovParams cp;
+    double sn2;
+    double sw;            // sW entries (1/sqrt(sn2)) for Exact
+    std::vector<double> scale;
+};
+
+struct pgp_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    hipDeviceProp_t prop;
+    // pooled device buffers, keyed by byte size
+    std::multimap<size_t, void*> pool;
+    // data
+    long n = 0, d = 0, np = 0, ldf = 0;
+    int dpad = 0;
+    double *x_dev = nullptr, *y_dev = nullptr, *XsT = nullptr, *scale_dev = nullptr;
+    // fit workspace (sized for np)
+    long ws_np = 0;
+    double *W = nullptr, *T = nullptr, *Binv = nullptr, *inv16 = nullptr, *alpha_dev = nullptr, *m_dev = nullptr,
+           *rvec = nullptr, *zvec = nullptr, *partial = nullptr, *scal = nullptr;
+    long partial_cap = 0;
+    int* info_dev = nullptr;
+    hipEvent_t ev[PGP_NSTAGE + 2];
+    double last_ms[PGP_NSTAGE];
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+    double pc_ms[PC_COUNT], pc_flops[PC_COUNT], pc_bytes[PC_COUNT];
+    int64_t pc_launch[PC_COUNT];
+    // options
+    int nb_outer = 4;     // leaves (128 columns each) per outer panel -> trailing update K = 512
+    int small_tile_below = 256;   // use 64x64 tiles when a GEMM has fewer 128-tiles than this
+};
+
+#define CHK(x)                      \
+    do {                            \
+        int rc__ = (x);             \
+        if (rc__ != PGP_OK) return rc__; \
+    } while (0)
+
+static inline int pool_alloc(pgp_ctx* c, size_t bytes, void** out) {
+    auto it = c->pool.find(bytes);
+    if (it != c->pool.end()) {
+        *out = it->second;
+        c->pool.erase(it);
+        return PGP_OK;
+    }
+    HIP_TRY(hipMalloc(out, bytes));
+    return PGP_OK;
+}
+static inline void pool_free(pgp_ctx* c, size_t bytes, void* p) {
+    if (p) c->pool.insert({bytes, p});
+}
+
+struct ProfScope {
+    pgp_ctx* c; int cls; double flops, bytes; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(pgp_ctx* c_, int cls_, double f, double b) : c(c_), cls(cls_), flops(f), bytes(b) {
+        if (!c->prof) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        e0 = get(); e1 = get();
+        (void)hipEventRecord(e0, c->st);
+    }
+    ~ProfScope() {
+        if (!c->prof) return;
+        (void)hipEventRecord(e1, c->st);
+        c->recs.push_back({cls, e0, e1, flops, bytes});
+    }
+};
+
+
+void prof_collect(pgp_ctx* c);
+static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
+int fill_scale(int kind, const double* hyp, int nhyp, int para, long d, std::vector<double>& sc);
+CovParams make_cp(int kind, const double* hyp, int nhyp, int para, int flags, int der, long d);
+int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows);
+int gemm_prof(pgp_ctx* c, int cls, GemmArgs g);

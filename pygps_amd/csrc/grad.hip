@@ -1,0 +1,263 @@
+// Gradient Hadamard-reduce and the O(N)/O(N^2) HBM-bound helpers of Exact.evaluate
+// (reference: Core/inf.py:370-381).
+//
+//   hadamard_reduce_kernel   one pass over B^-1 (upper row-major view of the column-major lower
+//        result of W^T W) that recomputes K tile-wise from the LDS-staged coordinates and accumulates,
+//        for Q = B^-1/sn2 - alpha alpha^T, the sums  sum_ij Q_ij dK_h,ij  for EVERY covariance hyper at
+//        once plus sn2*tr(Q) -- the reference re-builds a full N x N derivative matrix per hyper
+//        (65 times for SEard d=64).  Algorithmic bytes: 8 N(N+1)/2 (B^-1 triangle) + 8 N d.
+//        Deterministic: per-block partials, fixed-order final reduction (no float atomics).
+//   col_dot_kernel           alpha' = W^T z           (W = L^-1 column-major lower)
+//   logdet_ztz_kernel        sum log L_jj, z'z, alpha'alpha
+#include "kernels.h"
+#include "sqdist_tile.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block of 256 threads: reduce `v`, result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* red /* 4 doubles */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// partial[blk * nacc + h]: h < ncov -> sum Q dK_h ; h == ncov -> sn2 * trace(Q)
+__global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __restrict__ XT, long ldp, long n, int dpad,
+                                                              CovParams cp, int ncov, double inv_sn2, double sn2,
+                                                              const double* __restrict__ Binv, long ldb,
+                                                              const double* __restrict__ alpha,
+                                                              double* __restrict__ partial, long nt) {
+    __shared__ __attribute__((aligned(16))) double sm[2 * SKC * ST];
+    __shared__ double red[4];
+    const long b = blockIdx.x;
+    long r = (long)(((2.0 * nt + 1.0) - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)b)) * 0.5);
+    if (r < 0) r = 0;
+    while (r > 0 && r * nt - r * (r - 1) / 2 > b) --r;
+    while ((r + 1) * nt - (r + 1) * r / 2 <= b) ++r;
+    const long ti = r, tj = ti + (b - (r * nt - r * (r - 1) / 2));
+    const long r0 = ti * ST, c0 = tj * ST;
+    double s[4][4];
+    sqdist_tile(XT, ldp, r0, XT, ldp, c0, dpad, sm, s);
+
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    double w[4][4];                 // weight * Q_rc * K_rc   (ARD) -- or per-hyper accumulators below
+    double g0 = 0.0, g1 = 0.0, tq = 0.0;
+    double ar[4], ac[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long rr = r0 + 4 * tr + a;
+        ar[a] = rr < n ? alpha[rr] : 0.0;
+    }
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq) {
+        const long cc = c0 + 2 * tc + (bq & 1) + 32 * (bq >> 1);
+        ac[bq] = cc < n ? alpha[cc] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long rr = r0 + 4 * tr + a;
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh) {
+            const long cb = c0 + 2 * tc + 32 * bh;
+            const double2_t bv = *(const double2_t*)(Binv + rr * ldb + cb);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int bq = 2 * bh + e;
+                const long cc = cb + e;
+                double wt = (cc > rr) ? 2.0 : (cc == rr ? 1.0 : 0.0);     // symmetric: count the mirror
+                if (rr >= n || cc >= n) wt = 0.0;                          // padding
+                const double q = bv[e] * inv_sn2 - ar[a] * ac[bq];
+                const double wq = (wt != 0.0) ? wt * q : 0.0;             // never let unused entries in
+                if (cc == rr && rr < n) tq += sn2 * q;
+                if (cp.kind == 1) {
+                    const double K = cov_value(cp, s[a][bq]);
+                    w[a][bq] = wq * K;
+                    g1 += 2.0 * wq * K;                                    // d/d log sf
+                } else {
+                    CovParams c0p = cp; c0p.der = 0;
+                    CovParams c1p = cp; c1p.der = 1;
+                    g0 += wq * cov_deriv(c0p, s[a][bq], 0.0);
+                    g1 += wq * cov_deriv(c1p, s[a][bq], 0.0);
+                    w[a][bq] = 0.0;
+                }
+            }
+        }
+    }
+    double* out = partial + b * (long)(ncov + 1);
+    if (cp.kind == 1) {
+        // ARD length-scales: G_k = sum_rc w_rc (xs_rk - xs_ck)^2, 16 coordinates per staged slab
+        double* xr = sm;
+        double* xc = sm + SKC * ST;
+        for (int k0 = 0; k0 < dpad; k0 += SKC) {
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int v = t + p * 256;
+                const int k = v >> 5, pr = v & 31;
+                *(double2_t*)(xr + k * ST + 2 * pr) = *(const double2_t*)(XT + (long)(k0 + k) * ldp + r0 + 2 * pr);
+                *(double2_t*)(xc + k * ST + 2 * pr) = *(const double2_t*)(XT + (long)(k0 + k) * ldp + c0 + 2 * pr);
+            }
+            __syncthreads();
+            double gk[SKC];
+#pragma unroll
+            for (int k = 0; k < SKC; ++k) {
+                const double2_t r01 = *(const double2_t*)(xr + k * ST + 4 * tr);
+                const double2_t r23 = *(const double2_t*)(xr + k * ST + 4 * tr + 2);
+                const double2_t c01 = *(const double2_t*)(xc + k * ST + 2 * tc);
+                const double2_t c23 = *(const double2_t*)(xc + k * ST + 2 * tc + 32);
+                const double rv[4] = {r01[0], r01[1], r23[0], r23[1]};
+                const double cv[4] = {c01[0], c01[1], c23[0], c23[1]};
+                double acc = 0.0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int bq = 0; bq < 4; ++bq) {
+                        const double df = rv[a] - cv[bq];
+                        acc = fma(w[a][bq], df * df, acc);
+                    }
+                gk[k] = acc;
+            }
+#pragma unroll
+            for (int k = 0; k < SKC; ++k) {
+                const double tot = block_sum(gk[k], red);
+                if (t == 0 && k0 + k < cp.D) out[k0 + k] = tot;
+            }
+        }
+        const double t1 = block_sum(g1, red);
+        const double t2 = block_sum(tq, red);
+        if (t == 0) { out[cp.D] = t1; out[ncov] = t2; }
+    } else {
+        const double t0 = block_sum(g0, red);
+        const double t1 = block_sum(g1, red);
+        const double t2 = block_sum(tq, red);
+        if (t == 0) { out[0] = t0; out[1] = t1; out[ncov] = t2; }
+    }
+}
+
+// out[h] = sum_b partial[b*nacc + h], fixed order; one block per h
+__global__ __launch_bounds__(256) void final_reduce_kernel(const double* __restrict__ partial, long nblk, int nacc,
+                                                           double* __restrict__ out) {
+    __shared__ double red[4];
+    const int h = blockIdx.x;
+    double v = 0.0;
+    for (long b = threadIdx.x; b < nblk; b += 256) v += partial[b * nacc + h];
+    const double tot = block_sum(v, red);
+    if (threadIdx.x == 0) out[h] = tot;
+}
+
+// y[j] = scale * sum_{i >= j} W(i,j) z[i*zs]   (W column-major lower, n x n); one wave per column
+__global__ __launch_bounds__(256) void col_dot_kernel(const double* __restrict__ W, long ldw, long n,
+                                                      const double* __restrict__ z, long zs, double scale,
+                                                      double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const double* col = W + j * ldw;
+    double v = 0.0;
+    for (long i = (j & ~63L) + lane; i < n; i += 64)
+        if (i >= j) v = fma(col[i], z[i * zs], v);
+    v = wave_sum(v);
+    if (lane == 0) y[j] = scale * v;
+}
+
+// out[0] = sum_{j<n} log L(j,j) ; out[1] = sum_{j<n} z_j^2 ; (z strided by zs)
+__global__ __launch_bounds__(256) void logdet_ztz_kernel(const double* __restrict__ L, long ldl, long n,
+                                                         const double* __restrict__ z, long zs,
+                                                         double* __restrict__ out) {
+    __shared__ double red[4];
+    double a = 0.0, b = 0.0;
+    for (long j = threadIdx.x; j < n; j += 256) {
+        a += log(L[j + j * ldl]);
+        const double zj = z[j * zs];
+        b = fma(zj, zj, b);
+    }
+    const double ta = block_sum(a, red);
+    const double tb = block_sum(b, red);
+    if (threadIdx.x == 0) { out[0] = ta; out[1] = tb; }
+}
+
+// out[0] = sum v_i^2, out[1] = sum u_i v_i
+__global__ __launch_bounds__(256) void dot2_kernel(const double* __restrict__ u, const double* __restrict__ v, long n,
+                                                   double* __restrict__ out) {
+    __shared__ double red[4];
+    double a = 0.0, b = 0.0;
+    for (long j = threadIdx.x; j < n; j += 256) {
+        a = fma(v[j], v[j], a);
+        b = fma(u[j], v[j], b);
+    }
+    const double ta = block_sum(a, red);
+    const double tb = block_sum(b, red);
+    if (threadIdx.x == 0) { out[0] = ta; out[1] = tb; }
+}
+
+// augmented right-hand-side row of the factor buffer: F(np, j) = y_j - m_j (j < n)
+__global__ void aug_rhs_kernel(const double* __restrict__ y, const double* __restrict__ m, long n, double* __restrict__ F,
+                               long ldf, long row, double* __restrict__ rvec) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) {
+        const double r = y[j] - m[j];
+        F[row + j * ldf] = r;
+        rvec[j] = r;
+    }
+}
+
+__global__ void zero_upper_strip_kernel(double* __restrict__ F, long ldf, long np, long row0, long nrows) {
+    // zero F(row0 .. row0+nrows-1, 0..np-1)
+    const long j = (long)blockIdx.x;
+    for (long i = threadIdx.x; i < nrows; i += blockDim.x) F[row0 + i + j * ldf] = 0.0;
+}
+
+}  // namespace
+
+int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovParams& cp, int ncov,
+                           double sn2, const double* Binv, long ldb, const double* alpha, double* partial,
+                           double* out_dev, hipStream_t st) {
+    const long nt = np / ST;
+    const long nblk = nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(hadamard_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, cp, ncov,
+                       1.0 / sn2, sn2, Binv, ldb, alpha, partial, nt);
+    hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)(ncov + 1)), dim3(256), 0, st, partial, nblk, ncov + 1,
+                       out_dev);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+long hadamard_partial_count(long np, int ncov) {
+    const long nt = np / ST;
+    return nt * (nt + 1) / 2 * (long)(ncov + 1);
+}
+
+int col_dot_launch(const double* W, long ldw, long n, const double* z, long zs, double scale, double* y,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(col_dot_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, W, ldw, n, z, zs, scale, y);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+int logdet_ztz_launch(const double* L, long ldl, long n, const double* z, long zs, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(logdet_ztz_kernel, dim3(1), dim3(256), 0, st, L, ldl, n, z, zs, out);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+int dot2_launch(const double* u, const double* v, long n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(dot2_kernel, dim3(1), dim3(256), 0, st, u, v, n, out);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+int aug_rhs_launch(const double* y, const double* m, long n, double* F, long ldf, long row, double* rvec,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(aug_rhs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, m, n, F, ldf, row, rvec);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+int zero_strip_launch(double* F, long ldf, long np, long row0, long nrows, hipStream_t st) {
+    hipLaunchKernelGGL(zero_upper_strip_kernel, dim3((unsigned)np), dim3(128), 0, st, F, ldf, np, row0, nrows);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}

@@ -1,0 +1,37 @@
+// Launch wrappers of the device kernels (internal).
+#pragma once
+#include "common.h"
+
+struct CovParams;
+
+// panel.hip
+int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st);
+int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl, const double* inv16,
+                     hipStream_t st);
+int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, int nblocks, hipStream_t st);
+int trsv_bwd_launch(const double* L, long ldl, const double* W, long ldw, double* z, double* a_out, int nblk,
+                    hipStream_t st);
+int gather_strided_launch(const double* src, long stride, long n, double* dst, hipStream_t st);
+
+// assemble.hip
+int scale_transpose_launch(const double* x, long n, int d, const double* scale_dev, double* XsT, long ldp, int dpad,
+                           hipStream_t st);
+int cov_sym_launch(const double* XT, long ldp, long n, int dpad, const CovParams& cp, double* out, hipStream_t st);
+int cov_rect_launch(const double* XrT, long ldr, long n, const double* XcT, long ldc, long m, int dpad,
+                    const CovParams& cp, double* out, long ldo, hipStream_t st);
+int cov_factor_launch(const double* XT, long ldp, long n, long np, int dpad, const CovParams& cp, double inv_sn2,
+                      double* Bf, long ldf, hipStream_t st);
+int self_fill_launch(double* out, long m, double val, hipStream_t st);
+
+// grad.hip
+int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovParams& cp, int ncov,
+                           double sn2, const double* Binv, long ldb, const double* alpha, double* partial,
+                           double* out_dev, hipStream_t st);
+long hadamard_partial_count(long np, int ncov);
+int col_dot_launch(const double* W, long ldw, long n, const double* z, long zs, double scale, double* y,
+                   hipStream_t st);
+int logdet_ztz_launch(const double* L, long ldl, long n, const double* z, long zs, double* out, hipStream_t st);
+int dot2_launch(const double* u, const double* v, long n, double* out, hipStream_t st);
+int aug_rhs_launch(const double* y, const double* m, long n, double* F, long ldf, long row, double* rvec,
+                   hipStream_t st);
+int zero_strip_launch(double* F, long ldf, long np, long row0, long nrows, hipStream_t st);

@@ -1,0 +1,114 @@
+// Shared device code: the 64x64 pairwise squared-distance tile and the covariance scalar maps.
+// Used by assemble.hip (kernel-matrix construction) and grad.hip (Hadamard-reduce that recomputes
+// K tile-wise instead of re-reading it).
+//
+// Inputs are the *scaled, transposed* coordinates XsT[k*ldp + p] = x[p][k] * scale_k (k-major, so a
+// 64-point slab of one coordinate is one contiguous 512-byte run; coalesced loads, LDS-staged 16
+// coordinates at a time).  The distance is accumulated in the difference form sum_k (a_k - b_k)^2,
+// like scipy's cdist('sqeuclidean') that the reference calls (Core/cov.py:804) -- no |a|^2+|b|^2-2ab
+// cancellation, K(x,x) = sf2 exactly.
+#pragma once
+#include "common.h"
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+struct CovParams {
+    int kind;        // PGP_COV_*
+    int der;         // -1 value, >=0 derivative index
+    int md;          // Matern d (1,3,5,7)
+    int ref_der;     // Matern: reproduce the reference's derivative-of-K quirk (Core/cov.py:1173-1177)
+    int D;           // input dimension (ARD: der < D selects a length-scale)
+    double sf2;      // exp(2 log sf)
+};
+
+constexpr int ST = 64;      // tile edge
+constexpr int SKC = 16;     // coordinates staged per step
+
+// thread t of 256 owns rows r = 4*(t/16) + a (a<4) and columns c = 2*(t%16) + e + 32*b (e<2, b<2);
+// s[a][2*b + e] accumulates |x_r - z_c|^2.
+__device__ __forceinline__ void sqdist_tile(const double* __restrict__ XrT, long ldr, long r0,
+                                            const double* __restrict__ XcT, long ldc, long c0, int dpad,
+                                            double* __restrict__ sm /* 2*SKC*ST doubles */, double (&s)[4][4]) {
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    double* xr = sm;
+    double* xc = sm + SKC * ST;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s[a][b] = 0.0;
+    for (int k0 = 0; k0 < dpad; k0 += SKC) {
+        // 2 * 16 * 64 doubles = 1024 double2; 4 per thread
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int v = t + p * 256;            // 0..511 : k = v / 32, pair = v % 32
+            const int k = v >> 5, pr = v & 31;
+            *(double2_t*)(xr + k * ST + 2 * pr) = *(const double2_t*)(XrT + (long)(k0 + k) * ldr + r0 + 2 * pr);
+            *(double2_t*)(xc + k * ST + 2 * pr) = *(const double2_t*)(XcT + (long)(k0 + k) * ldc + c0 + 2 * pr);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SKC; ++k) {
+            const double2_t r01 = *(const double2_t*)(xr + k * ST + 4 * tr);
+            const double2_t r23 = *(const double2_t*)(xr + k * ST + 4 * tr + 2);
+            const double2_t c01 = *(const double2_t*)(xc + k * ST + 2 * tc);
+            const double2_t c23 = *(const double2_t*)(xc + k * ST + 2 * tc + 32);
+            const double rv[4] = {r01[0], r01[1], r23[0], r23[1]};
+            const double cv[4] = {c01[0], c01[1], c23[0], c23[1]};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double df = rv[a] - cv[b];
+                    s[a][b] = fma(df, df, s[a][b]);
+                }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ double matern_poly(int d, double t) {
+    switch (d) {
+        case 1: return 1.0;
+        case 3: return 1.0 + t;
+        case 5: return 1.0 + t + t * t / 3.0;
+        default: return 1.0 + t + 2.0 * t * t / 5.0 + t * t * t / 15.0;
+    }
+}
+__device__ __forceinline__ double matern_dpoly(int d, double t) {
+    switch (d) {
+        case 1: return 1.0;
+        case 3: return t;
+        case 5: return (t + t * t) / 3.0;
+        default: return (t + 3.0 * t * t + t * t * t) / 15.0;
+    }
+}
+
+// covariance value k(x,z) from the scaled squared distance s
+__device__ __forceinline__ double cov_value(const CovParams& p, double s) {
+    if (p.kind == 2) {                    // Matern: t = sqrt(d) |x-z| / ell (scale folded into XsT)
+        const double t = sqrt(s);
+        return p.sf2 * matern_poly(p.md, t) * exp(-t);
+    }
+    return p.sf2 * exp(-0.5 * s);         // RBF / RBFard
+}
+
+// derivative w.r.t. hyper p.der; dk2 = scaled squared difference in coordinate p.der (ARD only)
+__device__ __forceinline__ double cov_deriv(const CovParams& p, double s, double dk2) {
+    if (p.kind == 0) {                    // RBF: Core/cov.py:823-825
+        const double K = p.sf2 * exp(-0.5 * s);
+        return p.der == 0 ? K * s : 2.0 * K;
+    }
+    if (p.kind == 1) {                    // RBFard: Core/cov.py:922-936
+        const double K = p.sf2 * exp(-0.5 * s);
+        return p.der < p.D ? K * dk2 : 2.0 * K;
+    }
+    const double t = sqrt(s);             // Matern
+    if (p.der == 2) return 0.0;
+    if (p.ref_der) {                      // Core/cov.py:1173-1177: dmfunc / mfunc applied to K, not t
+        const double K = p.sf2 * matern_poly(p.md, t) * exp(-t);
+        return p.der == 0 ? p.sf2 * matern_dpoly(p.md, K) * K * exp(-K)
+                          : 2.0 * p.sf2 * matern_poly(p.md, K) * exp(-K);
+    }
+    return p.der == 0 ? p.sf2 * matern_dpoly(p.md, t) * t * exp(-t)
+                      : 2.0 * p.sf2 * matern_poly(p.md, t) * exp(-t);
+}

@@ -1,0 +1,140 @@
+// Self-test / calibration hooks (tests/ and bench.py only): host-buffer GEMM through the MFMA kernel,
+// and an fp64 MFMA issue-rate micro-benchmark used to restate the roofline peak from measurement.
+#include <vector>
+
+#include "ctx.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters, double a0, double b0) {
+    double4_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double a = a0 + threadIdx.x * 1e-9, b = b0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456) out[0] = s;      // keep the chain alive
+}
+// one wave per SIMD (or two), NACC independent accumulators, timed with s_memtime by lane 0
+template <int NACC, bool VACC>
+__global__ __launch_bounds__(256) void mfma_cycles_kernel(long long* out, int iters, double a0) {
+    double4_t acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double a = a0 + threadIdx.x * 1e-9, b = 1.0;
+    const long long t0 = __builtin_readcyclecounter();
+    const long long w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            if (VACC) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            else acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    const long long t1 = __builtin_readcyclecounter();
+    const long long w1 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = t1 - t0; out[1] = w1 - w0; }
+    if (s == 123.456) out[2] = (long long)s;
+}
+}  // namespace
+
+extern "C" {
+
+// out[0] = shader cycles (s_memtime) for iters*nacc MFMAs on one wave, out[1] = 100 MHz wall ticks,
+// out[2] = kernel ms (events).  waves_per_simd in {1,2}.
+int pgp_test_mfma_cycles(pgp_ctx* c, int iters, int nacc, int waves_per_simd, double* out3) {
+    if (!c || !out3) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 32));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const int blocks = waves_per_simd > 0 ? c->prop.multiProcessorCount * waves_per_simd : -waves_per_simd;
+    for (int rep = 0; rep < 2; ++rep) {
+        HIP_TRY(hipEventRecord(e0, c->st));
+        if (nacc == 1) hipLaunchKernelGGL((mfma_cycles_kernel<1, false>), dim3(blocks), dim3(256), 0, c->st, d, iters, 1.0);
+        else if (nacc == 4) hipLaunchKernelGGL((mfma_cycles_kernel<4, false>), dim3(blocks), dim3(256), 0, c->st, d, iters, 1.0);
+        else if (nacc == 8) hipLaunchKernelGGL((mfma_cycles_kernel<8, false>), dim3(blocks), dim3(256), 0, c->st, d, iters, 1.0);
+        else if (nacc == -4) hipLaunchKernelGGL((mfma_cycles_kernel<4, true>), dim3(blocks), dim3(256), 0, c->st, d, iters, 1.0);
+        else hipLaunchKernelGGL((mfma_cycles_kernel<8, true>), dim3(blocks), dim3(256), 0, c->st, d, iters, 1.0);
+        HIP_TRY(hipEventRecord(e1, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+    }
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    long long h[2];
+    HIP_TRY(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+    out3[0] = (double)h[0]; out3[1] = (double)h[1]; out3[2] = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
+    return PGP_OK;
+}
+
+int pgp_test_mfma_peak(pgp_ctx* ctx, int iters, double* tflops_out) {
+    if (!ctx || !tflops_out) return -1;
+    pgp_ctx* c = ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    double* out = nullptr;
+    HIP_TRY(hipMalloc((void**)&out, 8));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const int blocks = prop.multiProcessorCount * 2;     // 8 waves / CU = 2 per SIMD
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, c->st, out, 16, 1.0, 1.0);   // warm-up
+    HIP_TRY(hipEventRecord(e0, c->st));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, c->st, out, iters, 1.0, 1.0);
+    HIP_TRY(hipEventRecord(e1, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2048.0;
+    *tflops_out = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+    return PGP_OK;
+}
+
+int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_diag, int kmode, int koff,
+                  double alpha, double beta, const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
+                  int64_t ldc, int M, int N, int K, int iters, double* ms_out) {
+    if (!ctx) return -1;
+    pgp_ctx* c = ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t an = (size_t)lda * (a_kc ? M : K), bn = (size_t)ldb * (b_kc ? N : K), cn = (size_t)ldc * N;
+    double *Ad, *Bd, *Cd;
+    HIP_TRY(hipMalloc((void**)&Ad, an * 8)); HIP_TRY(hipMalloc((void**)&Bd, bn * 8)); HIP_TRY(hipMalloc((void**)&Cd, cn * 8));
+    HIP_TRY(hipMemcpy(Ad, A, an * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(Bd, B, bn * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(Cd, C, cn * 8, hipMemcpyHostToDevice));
+    GemmArgs g{};
+    g.A = Ad; g.lda = lda; g.a_kc = a_kc; g.B = Bd; g.ldb = ldb; g.b_kc = b_kc; g.C = Cd; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.tri = tri; g.tri_off = 0; g.mask_diag = mask_diag;
+    g.kmode = kmode; g.koff = koff; g.batch = 1; g.tile = tile;
+    int rc = gemm_f64_launch(g, c->st);
+    HIP_TRY(hipStreamSynchronize(c->st));
+    if (rc == PGP_OK) HIP_TRY(hipMemcpy(C, Cd, cn * 8, hipMemcpyDeviceToHost));
+    if (rc == PGP_OK && iters > 0 && ms_out) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, c->st));
+        for (int i = 0; i < iters; ++i) rc = gemm_f64_launch(g, c->st);
+        HIP_TRY(hipEventRecord(e1, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    (void)hipFree(Ad); (void)hipFree(Bd); (void)hipFree(Cd);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+"""GPU: C-ABI level parity of the HIP kernels against numpy / the oracle (bit layouts, edge sizes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, synth_reg
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(lib, tile, a_kc, b_kc, tri, mask, kmode, alpha, beta, M, N, K, seed=0):
+    from pygps_amd import _lib
+    rng = np.random.RandomState(seed)
+    A = rng.randn(M, K)            # A(m,k)
+    B = rng.randn(N, K)            # B(n,k)
+    C0 = rng.randn(M, N)
+    Ast = np.asfortranarray(A) if not a_kc else np.asfortranarray(A.T)     # column-major M x K or K x M
+    Bst = np.asfortranarray(B) if not b_kc else np.asfortranarray(B.T)
+    Cst = np.asfortranarray(C0.copy())
+    lda = Ast.shape[0]
+    ldb = Bst.shape[0]
+    ms = C.c_double()
+    rc = lib.pgp_test_gemm(_lib.ctx(), tile, a_kc, b_kc, tri, mask, kmode, 0, alpha, beta,
+                           Ast.ctypes.data_as(_lib._dp), lda, Bst.ctypes.data_as(_lib._dp), ldb,
+                           Cst.ctypes.data_as(_lib._dp), M, M, N, K, 0, C.byref(ms))
+    assert rc == 0, _lib.strerror(rc)
+    # numpy reference with the same k-range clipping per tile
+    ref = C0.copy()
+    T = tile
+    for i0 in range(0, M, T):
+        for j0 in range(0, N, T):
+            if tri and i0 < j0:
+                continue
+            k0, k1 = 0, K
+            if kmode == 1:
+                k0 = i0
+            elif kmode == 2:
+                k0 = j0
+            elif kmode == 3:
+                k1 = min(K, i0 + T)
+            blk = alpha * (A[i0:i0 + T, k0:k1] @ B[j0:j0 + T, k0:k1].T) + beta * C0[i0:i0 + T, j0:j0 + T]
+            if tri and mask and i0 == j0:
+                keep = np.tril(np.ones((T, T), dtype=bool))
+                blk = np.where(keep, blk, C0[i0:i0 + T, j0:j0 + T])
+            ref[i0:i0 + T, j0:j0 + T] = blk
+    return np.array(Cst), ref
+
+
+@pytest.mark.parametrize("tile", [128, 64])
+@pytest.mark.parametrize("a_kc,b_kc", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_layouts_asymmetric(lib, tile, a_kc, b_kc):
+    got, ref = _gemm(lib, tile, a_kc, b_kc, 0, 0, 0, 1.0, 0.0, 256, 384, 160)
+    assert relerr(got, ref) < 1e-13
+    got, ref = _gemm(lib, tile, a_kc, b_kc, 0, 0, 0, -1.0, 1.0, 384, 256, 48, seed=1)
+    assert relerr(got, ref) < 1e-13
+
+
+@pytest.mark.parametrize("tile", [128, 64])
+def test_gemm_tri_and_kmodes(lib, tile):
+    for tri in (1, 2):
+        got, ref = _gemm(lib, tile, 0, 0, tri, 1, 0, -1.0, 1.0, 512, 512, 128, seed=2)
+        assert relerr(got, ref) < 1e-13
+    got, ref = _gemm(lib, tile, 1, 1, 2, 1, 1, 1.0, 0.0, 512, 512, 512, seed=3)     # lauum shape
+    assert relerr(got, ref) < 1e-13
+    got, ref = _gemm(lib, tile, 0, 1, 0, 0, 2, 1.0, 0.0, 256, 256, 256, seed=4)     # T = L21 W11
+    assert relerr(got, ref) < 1e-13
+    got, ref = _gemm(lib, tile, 0, 1, 0, 0, 3, -1.0, 0.0, 256, 256, 256, seed=5)    # W21 = -W22 T
+    assert relerr(got, ref) < 1e-13
+
+
+@pytest.mark.parametrize("n", [1, 20, 128, 129, 300, 1024])
+def test_potrf_helper_matches_lapack(lib, n):
+    from pygps_amd import _lib
+    rng = np.random.RandomState(n)
+    G = rng.randn(n, n)
+    A = G @ G.T / n + np.eye(n)
+    L = np.zeros((n, n))
+    rc = lib.pgp_potrf(_lib.ctx(), _lib.ptr(A), n, _lib.ptr(L))
+    assert rc == 0
+    ref = np.linalg.cholesky(A)
+    assert relerr(L, ref) < 1e-12
+    assert np.all(np.triu(L, 1) == 0)
+
+
+def test_potrf_reports_first_bad_pivot(lib):
+    from pygps_amd import _lib
+    n = 200
+    A = np.eye(n)
+    A[150, 150] = -1.0
+    L = np.zeros((n, n))
+    rc = lib.pgp_potrf(_lib.ctx(), _lib.ptr(A), n, _lib.ptr(L))
+    assert rc == 151
+
+
+def _fit(lib, kind, cov_hyp, para, log_sn, x, y, m, dm, want=3, flags=0, factor=True):
+    from pygps_amd import _lib
+    n, d = x.shape
+    ctx = _lib.ctx()
+    x = _lib.f64(x); y = _lib.f64(y).ravel()
+    _lib.check(lib.pgp_set_data(ctx, _lib.ptr(x), n, d, _lib.ptr(y)))
+    cov_hyp = _lib.f64(cov_hyp)
+    nmean = 0 if dm is None else dm.shape[0]
+    alpha = np.zeros(n); nlZ = np.zeros(1); dn = np.zeros(nmean + len(cov_hyp) + 1)
+    fh = C.c_void_p()
+    mv = _lib.f64(m).ravel()
+    dmv = None if dm is None else _lib.f64(dm)
+    rc = lib.pgp_exact_fit(ctx, kind, _lib.ptr(cov_hyp), len(cov_hyp), para, flags, float(log_sn), _lib.ptr(mv),
+                           _lib.ptr(dmv), nmean, want, _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(dn),
+                           C.byref(fh) if factor else None)
+    _lib.check(rc)
+    out = dict(alpha=alpha.reshape(n, 1), nlZ=float(nlZ[0]), dnlZ=dn)
+    if factor:
+        L = np.zeros((n, n))
+        _lib.check(lib.pgp_factor_to_host(ctx, fh, _lib.ptr(L)))
+        lib.pgp_factor_free(ctx, fh)
+        out["L"] = L
+    return out
+
+
+@pytest.mark.parametrize("N,d", [(20, 3), (129, 2), (700, 5), (2048, 16)])
+@pytest.mark.parametrize("want", [3, 2])
+def test_exact_fit_rbf_vs_oracle(lib, N, d, want):
+    x, y = synth_reg(N, d, seed=N)
+    c = float(y.mean())
+    hyp = np.array([np.log(np.sqrt(d)), 0.1])
+    ref = O.exact_fit(O.RBF, hyp, 0, np.log(0.1), x, y, c * np.ones_like(y), np.ones_like(y), nargout=want,
+                      faithful=False)
+    got = _fit(lib, 0, hyp, 0, np.log(0.1), x, y, c * np.ones(N), np.ones((1, N)), want=want)
+    assert relerr(got["nlZ"], ref["nlZ"]) < 1e-10                      # north_star: 1e-8
+    assert relerr(got["alpha"], ref["alpha"]) < 1e-8                   # north_star: 1e-6
+    assert relerr(got["L"], ref["L"]) < 1e-10                          # north_star: 1e-6
+    assert np.all(np.tril(got["L"], -1) == 0)
+    if want == 3:
+        rg = np.concatenate([ref["dnlZ_mean"], ref["dnlZ_cov"], ref["dnlZ_lik"]])
+        assert relerr(got["dnlZ"], rg) < 1e-8
+
+
+def test_exact_fit_golden_G1_G2_G3(lib):
+    g = golden("G1_regression_default")
+    n = g["x"].shape[0]
+    got = _fit(lib, 0, g["cov_hyp"], 0, g["lik_hyp"][0], g["x"], g["y"], g["mean_hyp"][0] * np.ones(n), np.ones((1, n)))
+    assert relerr(got["nlZ"], g["nlZ"]) < 1e-10 and relerr(got["alpha"], g["alpha"]) < 1e-8
+    assert relerr(got["L"], g["L"]) < 1e-10
+    assert relerr(got["dnlZ"], np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-8
+    g = golden("G2_seed0_rbf_zero_mean")
+    got = _fit(lib, 0, g["cov_hyp"], 0, g["lik_hyp"][0], g["x"], g["y"], np.zeros(20), None)
+    assert relerr(got["nlZ"], g["nlZ"]) < 1e-10 and relerr(got["dnlZ"], np.concatenate([g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-8
+    g = golden("G3_seed0_rbfard_zero_mean")
+    got = _fit(lib, 1, g["cov_hyp"], 0, g["lik_hyp"][0], g["x"], g["y"], np.zeros(20), None)
+    assert relerr(got["nlZ"], g["nlZ"]) < 1e-10 and relerr(got["dnlZ"], np.concatenate([g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-8
+    assert relerr(got["L"], g["L"]) < 1e-10
+
+
+def test_exact_fit_golden_G6_cfg2_scale(lib):
+    for N in (2048, 8192):
+        g = golden("G6_rbf_d16_N%d" % N)
+        x, y = synth_reg(N, 16)
+        got = _fit(lib, 0, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, g["mean_hyp"][0] * np.ones(N), np.ones((1, N)))
+        assert relerr(got["nlZ"], g["nlZ"]) < 1e-9                     # north_star: 1e-8
+        assert relerr(got["alpha"][g["alpha_idx"], 0], g["alpha_sample"]) < 1e-7
+        assert relerr(np.diag(got["L"]), g["L_diag"]) < 1e-9
+        assert relerr(got["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-8
+        assert relerr(got["dnlZ"], np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7
+
+
+def test_exact_fit_golden_G7_ard_d64(lib):
+    g = golden("G7_rbfard_d64_N1024")
+    x, y = synth_reg(1024, 64)
+    got = _fit(lib, 1, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, g["mean_hyp"][0] * np.ones(1024), np.ones((1, 1024)))
+    assert relerr(got["nlZ"], g["nlZ"]) < 1e-9
+    assert relerr(got["dnlZ"], np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7
+
+
+def test_exact_fit_matern_and_nonpd(lib):
+    g = golden("G4b_matern5_N256")
+    got = _fit(lib, 2, g["cov_hyp"], 5, g["lik_hyp"][0], g["x"], g["y"], g["mean_hyp"][0] * np.ones(256), None, want=2)
+    assert relerr(got["nlZ"], g["nlZ"]) < 1e-10 and relerr(got["L"], g["L"]) < 1e-10
+    # correct Matern gradient vs the oracle with matern_reference_compat=False, and the compat flag
+    x, y = g["x"], g["y"]
+    for flags, compat in ((0, False), (1, True)):
+        ref = O.exact_fit(O.MATERN, g["cov_hyp"], 5, g["lik_hyp"][0], x, y, np.zeros_like(y), None, faithful=False,
+                          matern_reference_compat=compat)
+        got = _fit(lib, 2, g["cov_hyp"], 5, g["lik_hyp"][0], x, y, np.zeros(256), None, flags=flags)
+        assert relerr(got["dnlZ"], np.concatenate([ref["dnlZ_cov"], ref["dnlZ_lik"]])) < 1e-8
+    # non-PD: a huge signal / tiny noise ratio with duplicated points
+    xx = np.zeros((40, 2)); yy = np.zeros((40, 1))
+    with pytest.raises(np.linalg.LinAlgError):
+        _fit(lib, 0, np.array([0.0, 40.0]), 0, -40.0, xx, yy, np.zeros(40), None)
+
+
+def test_cov_all_modes_vs_golden(lib):
+    from pygps_amd import _lib
+    kinds = {"rbf": (0, 0), "rbfard": (1, 0), "matern1": (2, 1), "matern3": (2, 3), "matern5": (2, 5), "matern7": (2, 7)}
+    for fix, names in (("G4_kernels_seed0", list(kinds)), ("G5_kernels_unit_test_setup", ["rbf", "rbfard", "matern3"])):
+        g = golden(fix)
+        x, z = _lib.f64(g["x"]), _lib.f64(g["z"])
+        n, d = x.shape
+        m = z.shape[0]
+        for nm in names:
+            kind, para = kinds[nm]
+            hyp = _lib.f64(g[nm + "_hyp"])
+            for der in [-1] + list(range(len(hyp))):
+                key = "K" if der < 0 else "dK%d" % der
+                for mode, mname, shape in ((0, "train", (n, n)), (1, "cross", (n, m)), (2, "self", (m, 1))):
+                    out = np.zeros(shape)
+                    rc = lib.pgp_cov(_lib.ctx(), kind, mode, der, _lib.ptr(x), n, _lib.ptr(z), m, d, _lib.ptr(hyp),
+                                     len(hyp), para, _lib.FLAG_MATERN_REFERENCE_DER, _lib.ptr(out))
+                    assert rc == 0
+                    ref = g["%s_%s_%s" % (nm, key, mname)]
+                    assert np.max(np.abs(out - ref)) <= 1e-13 * max(1.0, np.max(np.abs(ref))), (fix, nm, key, mname)
+
+
+def test_mfma_peak_reported(lib):
+    from pygps_amd import _lib
+    tf = C.c_double()
+    assert lib.pgp_test_mfma_peak(_lib.ctx(), 20000, C.byref(tf)) == 0
+    print("fp64 MFMA issue-rate peak: %.1f TFLOP/s" % tf.value, _lib.device_info())
+    assert tf.value > 20

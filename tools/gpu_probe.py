@@ -1,0 +1,89 @@
+"""Ad-hoc measurements on the GPU box (not part of the test-suite)."""
+import ctypes as C
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from pygps_amd import _lib
+
+lib = _lib.load()
+ctx = _lib.ctx()
+print(_lib.device_info())
+
+
+def mfma():
+    for wps in (-1, 1, 2, 4):
+        for nacc in (8, -8, -4):
+            out = np.zeros(3)
+            iters = 200000 // abs(nacc)
+            lib.pgp_test_mfma_cycles(ctx, iters, nacc, wps, _lib.ptr(out))
+            n = iters * abs(nacc)
+            cyc = out[0] / n
+            mhz = out[0] / (out[1] / 100e6) / 1e6
+            nb = 256 * wps if wps > 0 else -wps
+            tf = nb * 4 * n * 2048 / (out[2] * 1e-3) / 1e12
+            print("waves/SIMD(or -blocks) %d nacc %d: %.1f shader-cycles/MFMA, shader clock %.0f MHz, kernel %.2f ms -> %.1f TF"
+                  % (wps, nacc, cyc, mhz, out[2], tf))
+
+
+def gemm(M, N, K, tile=128, a_kc=0, b_kc=0, tri=0, iters=5):
+    rng = np.random.RandomState(0)
+    A = np.asfortranarray(rng.randn(M if not a_kc else K, K if not a_kc else M))
+    B = np.asfortranarray(rng.randn(N if not b_kc else K, K if not b_kc else N))
+    Cm = np.asfortranarray(rng.randn(M, N))
+    ms = C.c_double()
+    rc = lib.pgp_test_gemm(ctx, tile, a_kc, b_kc, tri, 1 if tri else 0, 0, 0, -1.0, 1.0, _lib.ptr(A), A.shape[0],
+                           _lib.ptr(B), B.shape[0], _lib.ptr(Cm), M, M, N, K, iters, C.byref(ms))
+    assert rc == 0
+    fl = 2.0 * M * N * K * (0.5 if tri else 1.0)
+    print("gemm M=%d N=%d K=%d tile=%d kc=(%d,%d) tri=%d: %.3f ms  %.1f TF" % (M, N, K, tile, a_kc, b_kc, tri, ms.value,
+                                                                               fl / ms.value / 1e9))
+
+
+def fit(N, d, kind=0, want=3, reps=3, prof=True):
+    rng = np.random.RandomState(0)
+    x = rng.randn(N, d); w = rng.randn(d, 1)
+    y = (np.sin(x @ w / np.sqrt(d)) + 0.1 * rng.randn(N, 1)).ravel()
+    _lib.check(lib.pgp_set_data(ctx, _lib.ptr(x), N, d, _lib.ptr(y)))
+    hyp = np.array([np.log(np.sqrt(d)), 0.0]) if kind != 1 else np.array([np.log(np.sqrt(d))] * d + [0.0])
+    m = np.full(N, y.mean()); dm = np.ones((1, N))
+    alpha = np.zeros(N); nlZ = np.zeros(1); dn = np.zeros(1 + len(hyp) + 1)
+    for r in range(reps + 1):
+        if r == reps and prof:
+            lib.pgp_profile_reset(ctx); lib.pgp_set_profiling(ctx, 1)
+        t = time.time()
+        rc = lib.pgp_exact_fit(ctx, kind, _lib.ptr(hyp), len(hyp), 0, 0, float(np.log(0.1)), _lib.ptr(m), _lib.ptr(dm), 1,
+                               want, _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(dn), None)
+        dt = time.time() - t
+        assert rc == 0, rc
+        print("N=%d d=%d kind=%d want=%d: wall %.2f ms nlZ=%.10g  stages(ms)=%s" % (
+            N, d, kind, want, dt * 1e3, nlZ[0], {k: round(v, 3) for k, v in _lib.last_timings().items()}))
+    if prof:
+        lib.pgp_set_profiling(ctx, 0)
+        for k, v in _lib.profile().items():
+            if v["launches"]:
+                print("   %-34s launches %4d  %8.3f ms  %7.1f TF  %7.1f GB/s" % (
+                    k, v["launches"], v["ms"], v["flops"] / max(v["ms"], 1e-9) / 1e9, v["bytes"] / max(v["ms"], 1e-9) / 1e6))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["mfma", "gemm", "fit"]
+    if "mfma" in what:
+        mfma()
+    if "gemm" in what:
+        gemm(8192, 8192, 512)
+        gemm(8192, 8192, 512, tri=1)
+        gemm(8192, 8192, 128, tri=1)
+        gemm(8192, 8192, 2048, a_kc=1, b_kc=1)
+        gemm(8192, 8192, 2048, a_kc=0, b_kc=1)
+        gemm(8192, 384, 128, tile=64)
+        gemm(8192, 384, 128, tile=128)
+        gemm(4096, 4096, 4096)
+    if "fit" in what:
+        fit(8192, 16)
+        fit(8192, 16, want=2, prof=False)
+        fit(2048, 16, prof=False)
+    if "fit16k" in what:
+        fit(16384, 64, kind=1, reps=1)
