@@ -1,0 +1,12 @@
+"""pygps_amd -- MI355X-native exact-GP core behind the pyGPs API.
+
+Mirrors the module layout a pyGPs user imports (``pyGPs.cov``, ``pyGPs.inf``, ``pyGPs.GPR`` ...) for the
+hot path only: kernel-matrix construction (RBF / RBFard / Matern), Exact (and EP) inference, the
+Minimize restart loop and predict.  All arithmetic above O(N) runs in hand-written HIP kernels for
+gfx950 behind the C ABI in include/pygps_amd.h; importing the package does not need a GPU, calling
+into it does (no CPU fallback).
+"""
+from . import conf, cov, inf, lik, mean, minimize, opt, tools  # noqa: F401
+from .gp import GP, GPC, GPR  # noqa: F401
+
+__version__ = "0.1"

@@ -230,7 +230,7 @@ static int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ld
     const int nblk = (int)(np / 128);
     {
         ProfScope ps(c, PC_LEAFINV, (double)nblk * 128.0 * 128.0 * 128.0 / 3.0, 0.0);
-        CHK(leaf_inv_launch(L, ldl, W, ldw, nblk, c->st));
+        CHK(leaf_inv_launch(L, ldl, W, ldw, 128L * (1 + ldw), nblk, c->st));
     }
     std::vector<TriNode> nodes;
     tri_nodes(0, nblk, 0, nodes);
@@ -402,7 +402,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
           CHK(col_dot_launch(c->W, np, np, c->zvec, 1, 1.0 / sn2, c->alpha_dev, st)); }
     } else {
         { ProfScope ps(c, PC_LEAFINV, 0.0, 0.0);
-          CHK(leaf_inv_launch(F, ldf, c->W, np, (int)(np / 128), st)); }
+          CHK(leaf_inv_launch(F, ldf, c->W, np, 128L * (1 + np), (int)(np / 128), st)); }
         HIP_TRY(hipEventRecord(c->ev[3], st));
         { ProfScope ps(c, PC_SMALL, 0.0, 4.0 * (double)np * np);
           CHK(trsv_bwd_launch(F, ldf, c->W, np, c->zvec, c->alpha_dev, (int)(np / 128), st)); }
@@ -503,6 +503,7 @@ void pgp_factor_free(pgp_ctx* c, pgp_factor* f) {
     if (f->alpha) (void)hipFree(f->alpha);
     if (f->XsT) (void)hipFree(f->XsT);
     if (f->Wd) (void)hipFree(f->Wd);
+    if (f->sWv) (void)hipFree(f->sWv);
     delete f;
 }
 

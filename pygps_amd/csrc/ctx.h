@@ -26,6 +26,7 @@ struct pgp_factor {
     CovParams cp;
     double sn2;
     double sw;            // sW entries (1/sqrt(sn2)) for Exact
+    double* sWv = nullptr; // per-point sW (EP); nullptr for Exact
     std::vector<double> scale;
 };
 

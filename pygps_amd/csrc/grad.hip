@@ -216,7 +216,63 @@ __global__ void zero_upper_strip_kernel(double* __restrict__ F, long ldf, long n
     for (long i = threadIdx.x; i < nrows; i += blockDim.x) F[row0 + i + j * ldf] = 0.0;
 }
 
+// out[j] = add[j] + sum_i A(i,j) v[i]    (A column-major nrows x ncols); one wave per column
+__global__ __launch_bounds__(256) void col_dot_full_kernel(const double* __restrict__ A, long lda, long nrows,
+                                                           long ncols, const double* __restrict__ v,
+                                                           const double* __restrict__ add, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= ncols) return;
+    const double* col = A + j * lda;
+    double s = 0.0;
+    for (long i = lane; i < nrows; i += 64) s = fma(col[i], v[i], s);
+    s = wave_sum(s);
+    if (lane == 0) out[j] = (add ? add[j] : 0.0) + s;
+}
+
+// out[j] = max(kss - scale * sum_i A(i,j)^2, 0)
+__global__ __launch_bounds__(256) void col_sumsq_kernel(const double* __restrict__ A, long lda, long nrows,
+                                                        long ncols, double kss, double scale,
+                                                        double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= ncols) return;
+    const double* col = A + j * lda;
+    double s = 0.0;
+    for (long i = lane; i < nrows; i += 64) s = fma(col[i], col[i], s);
+    s = wave_sum(s);
+    if (lane == 0) out[j] = fmax(kss - scale * s, 0.0);
+}
+
+// A(i,j) *= s[i]
+__global__ __launch_bounds__(256) void row_scale_kernel(double* __restrict__ A, long lda, long nrows, long ncols,
+                                                        const double* __restrict__ s) {
+    const long j = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nrows && j < ncols) A[i + j * lda] *= s[i];
+}
+
 }  // namespace
+
+int col_dot_full_launch(const double* A, long lda, long nrows, long ncols, const double* v, const double* add,
+                        double* out, hipStream_t st) {
+    hipLaunchKernelGGL(col_dot_full_kernel, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, A, lda, nrows, ncols, v,
+                       add, out);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+int col_sumsq_launch(const double* A, long lda, long nrows, long ncols, double kss, double scale, double* out,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(col_sumsq_kernel, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, A, lda, nrows, ncols, kss,
+                       scale, out);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+int row_scale_launch(double* A, long lda, long nrows, long ncols, const double* s, hipStream_t st) {
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((nrows + 255) / 256), (unsigned)ncols), dim3(256), 0, st, A, lda,
+                       nrows, ncols, s);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
 
 int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovParams& cp, int ncov,
                            double sn2, const double* Binv, long ldb, const double* alpha, double* partial,

@@ -8,7 +8,7 @@ struct CovParams;
 int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st);
 int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl, const double* inv16,
                      hipStream_t st);
-int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, int nblocks, hipStream_t st);
+int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, long wstride, int nblocks, hipStream_t st);
 int trsv_bwd_launch(const double* L, long ldl, const double* W, long ldw, double* z, double* a_out, int nblk,
                     hipStream_t st);
 int gather_strided_launch(const double* src, long stride, long n, double* dst, hipStream_t st);
@@ -35,3 +35,10 @@ int dot2_launch(const double* u, const double* v, long n, double* out, hipStream
 int aug_rhs_launch(const double* y, const double* m, long n, double* F, long ldf, long row, double* rvec,
                    hipStream_t st);
 int zero_strip_launch(double* F, long ldf, long np, long row0, long nrows, hipStream_t st);
+
+// grad.hip (column reductions used by predict)
+int col_dot_full_launch(const double* A, long lda, long nrows, long ncols, const double* v, const double* add,
+                        double* out, hipStream_t st);
+int col_sumsq_launch(const double* A, long lda, long nrows, long ncols, double kss, double scale, double* out,
+                     hipStream_t st);
+int row_scale_launch(double* A, long lda, long nrows, long ncols, const double* s, hipStream_t st);

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void trsm_rows_kernel(double* __restrict__ 
 // Column c of the inverse is the forward substitution L x = e_c; 128 independent columns ->
 // threads 0..127, coefficients broadcast from LDS.
 __global__ __launch_bounds__(128, 1) void leaf_inv_kernel(const double* __restrict__ L, long ldl,
-                                                          double* __restrict__ W, long ldw) {
+                                                          double* __restrict__ Wb, long ldw, long wstride) {
     extern __shared__ __attribute__((aligned(16))) double sx[];  // sx[r*NB + c]: column c owned by thread c
     const long o = (long)blockIdx.x * NB;
     const int c = threadIdx.x;
@@ -206,7 +206,8 @@ __global__ __launch_bounds__(128, 1) void leaf_inv_kernel(const double* __restri
     }
     __syncthreads();
     // transpose through LDS so the global stores run along r (contiguous)
-    for (int cc = 0; cc < NB; ++cc) W[o + c + (o + cc) * ldw] = sx[c * NB + cc];
+    double* __restrict__ W = Wb + (long)blockIdx.x * wstride;
+    for (int cc = 0; cc < NB; ++cc) W[c + (long)cc * ldw] = sx[c * NB + cc];
 }
 
 }  // namespace
@@ -230,14 +231,14 @@ int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
-int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, int nblocks, hipStream_t st) {
+int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, long wstride, int nblocks, hipStream_t st) {
     const size_t shm = (size_t)NB * NB * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)leaf_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set = true;
     }
-    hipLaunchKernelGGL(leaf_inv_kernel, dim3(nblocks), dim3(128), shm, st, L, ldl, W, ldw);
+    hipLaunchKernelGGL(leaf_inv_kernel, dim3(nblocks), dim3(128), shm, st, L, ldl, W, ldw, wstride);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 

@@ -1,0 +1,146 @@
+// GP.predict on the device (reference: Core/gp.py:349-437, Cholesky parametrisation) and the
+// solve_chol helper (Core/tools.py:81-97), both built on one blocked multi-right-hand-side
+// triangular solve that runs on the fp64 MFMA GEMM kernel:
+//     forward  L V = Y :  for kb = 0..nb-1 :  V_kb = W_kk Y_kb ;  Y_rest -= L(rest,kb) V_kb
+//     backward L'X = Y :  for kb = nb-1..0 :  X_kb = W_kk' Y_kb ;  Y_(<kb) -= L(kb,<kb)' X_kb
+// with W_kk = inv(L_kk) from leaf_inv_kernel (the reference instead LU-factorises the triangular
+// L for every 1000-point batch, gp.py:415).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ctx.h"
+
+// Y (np x nrhs, column-major, ldy; nrhs multiple of 128: the in-place diagonal solve needs ONE row tile) is overwritten by the solution.
+static int solve_lower_multi(pgp_ctx* c, const double* L, long ldl, const double* Wd /*128 x np, ld 128*/, double* Y,
+                             long ldy, long np, int nrhs, bool trans) {
+    const int nb = (int)(np / 128);
+    const int tile = (nrhs % 128 == 0 && (long)nrhs / 128 * (np / 128) >= c->small_tile_below) ? 128 : 64;
+    for (int s = 0; s < nb; ++s) {
+        const int kb = trans ? nb - 1 - s : s;
+        const long o = (long)kb * 128;
+        GemmArgs g{};                                   // diagonal solve, in place (one WG column-tile owns its rows)
+        g.A = Wd + o * 128; g.lda = 128; g.a_kc = trans ? 1 : 0;
+        g.B = Y + o; g.ldb = ldy; g.b_kc = 1;
+        g.C = Y + o; g.ldc = ldy;
+        g.M = 128; g.N = nrhs; g.K = 128; g.alpha = 1.0; g.beta = 0.0; g.tile = 128;
+        g.flops = 128.0 * 128.0 * nrhs;
+        CHK(gemm_prof(c, PC_GEMM_INNER, g));
+        const long rest = trans ? o : np - o - 128;
+        if (rest <= 0) continue;
+        GemmArgs h{};
+        if (!trans) { h.A = L + o + 128 + o * ldl; h.lda = ldl; h.a_kc = 0; h.C = Y + o + 128; }
+        else        { h.A = L + o; h.lda = ldl; h.a_kc = 1; h.C = Y; }       // A(m,k) = L(o+k, m)
+        h.B = Y + o; h.ldb = ldy; h.b_kc = 1;
+        h.ldc = ldy; h.M = (int)rest; h.N = nrhs; h.K = 128; h.alpha = -1.0; h.beta = 1.0; h.tile = tile;
+        h.flops = 2.0 * 128.0 * (double)rest * nrhs;
+        CHK(gemm_prof(c, PC_GEMM_INNER, h));
+    }
+    return PGP_OK;
+}
+
+static int ensure_wd(pgp_ctx* c, pgp_factor* f) {
+    if (f->Wd) return PGP_OK;
+    HIP_TRY(hipMalloc((void**)&f->Wd, (size_t)128 * f->np * sizeof(double)));
+    return leaf_inv_launch(f->F, f->ldf, f->Wd, 128, 128L * 128L, (int)(f->np / 128), c->st);
+}
+
+extern "C" {
+
+int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const double* ms, double* fmu, double* fs2) {
+    if (!c) return -1;
+    if (!f) return -2;
+    if (!xs) return -3;
+    if (ns <= 0) return -4;
+    if (!fmu) return -6;
+    if (!fs2) return -7;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->st;
+    CHK(ensure_wd(c, f));
+    const long np = f->np, n = f->n;
+    const int d = f->d, dpad = f->dpad;
+    const long NSB = 1024;                                 // test points per batch (the reference uses 1000)
+    const long ldc = NSB;
+    double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *o2 = nullptr;
+    HIP_TRY(hipMalloc((void**)&xd, NSB * d * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&XcT, (size_t)dpad * ldc * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&scd, dpad * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&Ks, (size_t)np * NSB * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&msd, NSB * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&o1, NSB * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&o2, NSB * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(scd, f->scale.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
+    CovParams cp = f->cp;
+    cp.der = -1;
+    int rc = PGP_OK;
+    for (long a = 0; a < ns && rc == PGP_OK; a += NSB) {
+        const long nb_ = std::min<long>(NSB, ns - a);
+        const int nrhs = (int)round_up(nb_, 128);
+        HIP_TRY(hipMemcpyAsync(xd, xs + a * d, nb_ * d * sizeof(double), hipMemcpyHostToDevice, st));
+        if (ms) HIP_TRY(hipMemcpyAsync(msd, ms + a, nb_ * sizeof(double), hipMemcpyHostToDevice, st));
+        else HIP_TRY(hipMemsetAsync(msd, 0, nb_ * sizeof(double), st));
+        rc = scale_transpose_launch(xd, nb_, d, scd, XcT, ldc, dpad, st);
+        // Ks as column-major (np x nrhs): rows = test points, columns = training points in the tile kernel's view
+        if (rc == PGP_OK) HIP_TRY(hipMemsetAsync(Ks, 0, (size_t)np * nrhs * sizeof(double), st));
+        if (rc == PGP_OK) rc = cov_rect_launch(XcT, ldc, nb_, f->XsT, np, n, dpad, cp, Ks, np, st);
+        if (rc == PGP_OK) rc = col_dot_full_launch(Ks, np, n, nb_, f->alpha, msd, o1, st);     // fmu = ms + Ks' alpha
+        if (rc == PGP_OK && f->sWv) rc = row_scale_launch(Ks, np, n, nrhs, f->sWv, st);       // EP: sW o Ks
+        if (rc == PGP_OK) rc = solve_lower_multi(c, f->F, f->ldf, f->Wd, Ks, np, np, nrhs, false);
+        if (rc == PGP_OK) rc = col_sumsq_launch(Ks, np, n, nb_, cp.sf2, f->sWv ? 1.0 : f->sw * f->sw, o2, st);
+        if (rc == PGP_OK) {
+            HIP_TRY(hipMemcpyAsync(fmu + a, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(fs2 + a, o2, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
+    if (c->prof) prof_collect(c);
+    void* bufs[] = {xd, XcT, scd, Ks, msd, o1, o2};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    return rc;
+}
+
+int pgp_potrs(pgp_ctx* c, const double* R, int64_t n, const double* Bm, int64_t nrhs, double* X_out) {
+    if (!c) return -1;
+    if (!R) return -2;
+    if (n <= 0) return -3;
+    if (!Bm) return -4;
+    if (nrhs <= 0) return -5;
+    if (!X_out) return -6;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->st;
+    const long np = round_up(n, 128);
+    const int nr = (int)round_up(nrhs, 128);
+    double *L = nullptr, *Wd = nullptr, *Y = nullptr;
+    HIP_TRY(hipMalloc((void**)&L, (size_t)np * np * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&Wd, (size_t)128 * np * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&Y, (size_t)np * nr * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(L, 0, (size_t)np * np * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(Y, 0, (size_t)np * nr * sizeof(double), st));
+    // row-major upper R == column-major lower L (same bytes); identity on the padding
+    HIP_TRY(hipMemcpy2DAsync(L, np * sizeof(double), R, n * sizeof(double), n * sizeof(double), n, hipMemcpyHostToDevice, st));
+    std::vector<double> ones(np - n + 1, 1.0);
+    if (np > n)
+        HIP_TRY(hipMemcpy2DAsync(L + n + n * np, (np + 1) * sizeof(double), ones.data(), sizeof(double), sizeof(double),
+                                 np - n, hipMemcpyHostToDevice, st));
+    std::vector<double> yt((size_t)n * nrhs);
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < nrhs; ++j) yt[(size_t)j * n + i] = Bm[i * nrhs + j];
+    HIP_TRY(hipMemcpy2DAsync(Y, np * sizeof(double), yt.data(), n * sizeof(double), n * sizeof(double), nrhs,
+                             hipMemcpyHostToDevice, st));
+    int rc = leaf_inv_launch(L, np, Wd, 128, 128L * 128L, (int)(np / 128), st);
+    if (rc == PGP_OK) rc = solve_lower_multi(c, L, np, Wd, Y, np, np, nr, false);      // (R')^-1 = L^-1
+    if (rc == PGP_OK) rc = solve_lower_multi(c, L, np, Wd, Y, np, np, nr, true);       // R^-1 = L^-T
+    if (rc == PGP_OK) {
+        HIP_TRY(hipMemcpy2DAsync(yt.data(), n * sizeof(double), Y, np * sizeof(double), n * sizeof(double), nrhs,
+                                 hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t j = 0; j < nrhs; ++j) X_out[i * nrhs + j] = yt[(size_t)j * n + i];
+    }
+    if (c->prof) prof_collect(c);
+    (void)hipFree(L); (void)hipFree(Wd); (void)hipFree(Y);
+    return rc;
+}
+
+}  // extern "C"

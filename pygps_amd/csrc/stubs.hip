@@ -1,8 +1,6 @@
 // Entry points declared in include/pygps_amd.h whose device path is not built yet return -99.
 #include "ctx.h"
 extern "C" {
-int pgp_predict(pgp_ctx*, pgp_factor*, const double*, int64_t, const double*, double*, double*) { return -99; }
 int pgp_ep_fit(pgp_ctx*, int, const double*, int, int, int, const double*, const double*, int, int, int, double*,
                double*, double*, double*, double*, double*, int*, pgp_factor**) { return -99; }
-int pgp_potrs(pgp_ctx*, const double*, int64_t, const double*, int64_t, double*) { return -99; }
 }

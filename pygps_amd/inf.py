@@ -1,0 +1,295 @@
+"""Inference engines on the hot path (reference: pyGPs/Core/inf.py -- postStruct :59-89,
+dnlZStruct :93-128, Inference :133-172, Exact :345-384, EP :723-806).
+
+``Exact.evaluate`` keeps the reference's signature and result types but the whole body -- kernel
+assembly, Cholesky, solves, nlZ and all hyper-gradients -- is ONE call into the device pipeline
+(``pgp_exact_fit``).  x and y stay resident on the GPU between calls (the optimiser only changes
+hyp, Core/opt.py:70-75); ``post.L`` is a lazy host view of the device-resident factor so that a fit
+is not a PCIe benchmark.  No CPU fallback.
+"""
+import ctypes as C
+import hashlib
+import logging
+import weakref
+
+import numpy as np
+
+from . import _lib, cov as _cov, lik as _lik
+
+try:                                    # fast content hash for the residency check
+    import xxhash
+
+    def _digest(a):
+        return xxhash.xxh3_64_intdigest(memoryview(a).cast("B"))
+except Exception:                       # pragma: no cover
+    def _digest(a):
+        return hashlib.blake2b(memoryview(a).cast("B"), digest_size=8).digest()
+
+
+class postStruct(object):
+    """Posterior parametrisation N(m + K alpha, (K^-1 + W)^-1): alpha (n,1), sW (n,1), L (n,n) =
+    chol(I + sW sW' o K) as the UPPER factor (Core/inf.py:59-89)."""
+
+    def __init__(self):
+        self.alpha = np.array([])
+        self.L = np.array([])
+        self.sW = np.array([])
+
+    def __repr__(self):
+        return ("posterior: to get the parameters of the posterior distribution use:\n"
+                "model.posterior.alpha\nmodel.posterior.L\nmodel.posterior.sW\n"
+                "See documentation and gpml book chapter 2.3 and chapter 3.4.3 for these parameters.")
+
+    def __str__(self):
+        return ("posterior distribution described by alpha, sW and L\n"
+                "See documentation and gpml book chapter 2.3 and chapter 3.4.3 for these parameters\n"
+                "alpha:\n" + str(self.alpha) + "\nL:\n" + str(np.asarray(self.L)) + "\nsW:\n" + str(self.sW))
+
+
+class dnlZStruct(object):
+    """Partial derivatives of nlZ w.r.t. mean / cov / lik hyper-parameters (Core/inf.py:93-128)."""
+
+    def __init__(self, m, c, l):
+        self.mean = [0 for _ in range(len(m.hyp))] if m.hyp is not None else []
+        self.cov = [0 for _ in range(len(c.hyp))] if c.hyp is not None else []
+        self.lik = [0 for _ in range(len(l.hyp))] if l.hyp is not None else []
+
+    def __str__(self):
+        return ("Derivatives of mean, cov and lik functions:\nmean:" + str(self.mean) + "\ncov:" + str(self.cov)
+                + "\nlik:" + str(self.lik))
+
+    def __repr__(self):
+        return ("dnlZ: to get the derivatives of mean, cov and lik functions use:\n"
+                "model.dnlZ.mean\nmodel.dnlZ.cov\nmodel.dnlZ.lik")
+
+    def accumulateDnlZ(self, other):
+        self.mean = [a + b for a, b in zip(self.mean, other.mean)]
+        self.cov = [a + b for a, b in zip(self.cov, other.cov)]
+        self.lik = [a + b for a, b in zip(self.lik, other.lik)]
+        return self
+
+
+class DeviceFactor(object):
+    """``post.L``: the (n,n) upper Cholesky factor R (R'R = I + sW sW' o K), resident on the GPU.
+
+    Behaves like a read-only numpy array -- shape/len/indexing/np.asarray/.T all work and trigger ONE
+    device->host copy (2 GiB at n=16384) on first touch; exact zeros below the diagonal, as
+    Core/gp.py:393 requires.  ``copy.deepcopy`` shares the handle (the buffer is never rewritten).
+    ``predict`` uses the handle directly and never materialises it."""
+    ndim = 2
+    dtype = np.dtype(np.float64)
+
+    def __init__(self, handle, n, device):
+        self._h = handle
+        self._n = int(n)
+        self._dev = device
+        self._host = None
+        self._fin = weakref.finalize(self, DeviceFactor._release, handle, device)
+
+    @staticmethod
+    def _release(handle, device):
+        try:
+            _lib.load().pgp_factor_free(_lib.ctx(device), handle)
+        except Exception:       # interpreter shutdown
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def shape(self):
+        return (self._n, self._n)
+
+    @property
+    def size(self):
+        return self._n * self._n
+
+    def __len__(self):
+        return self._n
+
+    def host(self):
+        if self._host is None:
+            out = np.empty((self._n, self._n))
+            _lib.check(_lib.load().pgp_factor_to_host(_lib.ctx(self._dev), self._h, _lib.ptr(out)), "pgp_factor_to_host")
+            out.setflags(write=False)
+            self._host = out
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.host()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, idx):
+        return self.host()[idx]
+
+    @property
+    def T(self):
+        return self.host().T
+
+    def __deepcopy__(self, memo):
+        return self
+
+    def __copy__(self):
+        return self
+
+    def __getattr__(self, name):            # any other ndarray attribute/method
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.host(), name)
+
+    def __repr__(self):
+        return "DeviceFactor(n=%d, on device %d%s)" % (self._n, self._dev, ", materialised" if self._host is not None else "")
+
+
+class Inference(object):
+    """Base class (Core/inf.py:133-172)."""
+
+    def __init__(self):
+        self.logger = logging.getLogger(__name__)
+
+    def evaluate(self, meanfunc, covfunc, likfunc, x, y, nargout=1):
+        raise NotImplementedError
+
+
+class _Resident(object):
+    """Tracks which (x, y) the device context currently holds."""
+    key = {}
+
+    @classmethod
+    def ensure(cls, x, y, device):
+        k = (x.shape, _digest(x), _digest(y))
+        if cls.key.get(device) != k:
+            _lib.check(_lib.load().pgp_set_data(_lib.ctx(device), _lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(y)),
+                       "pgp_set_data")
+            cls.key[device] = k
+
+    @classmethod
+    def invalidate(cls, device=None):
+        if device is None:
+            cls.key.clear()
+        else:
+            cls.key.pop(device, None)
+
+
+def _device_kernel(covfunc):
+    if not isinstance(covfunc, _cov.Kernel) or covfunc._kind is None:
+        raise NotImplementedError(
+            "pygps_amd: only RBF, RBFard and Matern have a device covariance functor (got %s); "
+            "there is no CPU fallback" % type(covfunc).__name__)
+    return covfunc._device_params()
+
+
+def _mean_inputs(meanfunc, x):
+    n = x.shape[0]
+    m = _lib.f64(meanfunc.getMean(x)).reshape(n)
+    nm = len(meanfunc.hyp) if meanfunc.hyp else 0
+    dm = None
+    if nm:
+        dm = np.empty((nm, n))
+        for i in range(nm):
+            dm[i] = np.asarray(meanfunc.getDerMatrix(x, i), dtype=float).reshape(n)
+    return m, dm, nm
+
+
+class Exact(Inference):
+    """Exact inference for a Gaussian likelihood (Core/inf.py:345-384)."""
+
+    def __init__(self):
+        self.name = "Exact inference"
+        self.device = None
+
+    def evaluate(self, meanfunc, covfunc, likfunc, x, y, nargout=1):
+        if not isinstance(likfunc, _lik.Gauss):
+            raise Exception("Exact inference only possible with Gaussian likelihood")
+        kind, para, flags = _device_kernel(covfunc)
+        dev = _lib.default_device() if self.device is None else self.device
+        x = _lib.f64(x)
+        n, D = x.shape
+        y = _lib.f64(y).reshape(n)
+        _Resident.ensure(x, y, dev)
+        m, dm, nm = _mean_inputs(meanfunc, x)
+        hyp = _lib.f64(np.asarray(covfunc.hyp, dtype=float))
+        nc = len(hyp)
+        log_sn = float(likfunc.hyp[0])
+        alpha = np.empty(n)
+        nlZ = np.zeros(1)
+        g = np.zeros(nm + nc + 1)
+        fh = C.c_void_p()
+        rc = _lib.load().pgp_exact_fit(_lib.ctx(dev), kind, _lib.ptr(hyp), nc, int(para), int(flags), log_sn,
+                                       _lib.ptr(m), _lib.ptr(dm), nm, int(min(max(nargout, 1), 3)), _lib.ptr(alpha),
+                                       _lib.ptr(nlZ), _lib.ptr(g), C.byref(fh))
+        _lib.check(rc, "pgp_exact_fit")
+        sn2 = np.exp(2 * log_sn)
+        post = postStruct()
+        post.alpha = alpha.reshape(n, 1)
+        post.sW = np.ones((n, 1)) / np.sqrt(sn2)
+        post.L = DeviceFactor(fh, n, dev)
+        if nargout > 1:
+            nlz = np.float64(nlZ[0])
+            if nargout > 2:
+                dnlZ = dnlZStruct(meanfunc, covfunc, likfunc)
+                dnlZ.mean = [np.float64(v) for v in g[:nm]]
+                dnlZ.cov = [np.float64(v) for v in g[nm:nm + nc]]
+                dnlZ.lik = [np.float64(g[nm + nc])]
+                return post, nlz, dnlZ
+            return post, nlz
+        return post
+
+
+class EP(Inference):
+    """Expectation propagation with the probit likelihood (Core/inf.py:723-806).  The site-parameter
+    state (last_ttau / last_tnu) persists on the object across calls and warm-starts the next one,
+    exactly like the reference."""
+
+    def __init__(self):
+        self.name = "Expectation Propagation"
+        self.last_ttau = None
+        self.last_tnu = None
+        self.device = None
+        self.sweeps = 0
+
+    def evaluate(self, meanfunc, covfunc, likfunc, x, y, nargout=1):
+        if not isinstance(likfunc, _lik.Erf):
+            raise NotImplementedError("pygps_amd: EP runs on the device for lik.Erf only (no CPU fallback)")
+        kind, para, flags = _device_kernel(covfunc)
+        dev = _lib.default_device() if self.device is None else self.device
+        x = _lib.f64(x)
+        n, D = x.shape
+        y = _lib.f64(y).reshape(n)
+        _Resident.ensure(x, y, dev)
+        m, dm, nm = _mean_inputs(meanfunc, x)
+        hyp = _lib.f64(np.asarray(covfunc.hyp, dtype=float))
+        nc = len(hyp)
+        warm = self.last_ttau is not None
+        ttau = _lib.f64(self.last_ttau).reshape(n).copy() if warm else np.zeros(n)
+        tnu = _lib.f64(self.last_tnu).reshape(n).copy() if warm else np.zeros(n)
+        alpha = np.empty(n)
+        sW = np.empty(n)
+        nlZ = np.zeros(1)
+        g = np.zeros(nm + nc + 1)
+        sweeps = C.c_int()
+        fh = C.c_void_p()
+        rc = _lib.load().pgp_ep_fit(_lib.ctx(dev), kind, _lib.ptr(hyp), nc, int(para), int(flags), _lib.ptr(m),
+                                    _lib.ptr(dm), nm, int(min(max(nargout, 1), 3)), int(warm), _lib.ptr(ttau),
+                                    _lib.ptr(tnu), _lib.ptr(alpha), _lib.ptr(sW), _lib.ptr(nlZ), _lib.ptr(g),
+                                    C.byref(sweeps), C.byref(fh))
+        if rc == -99:
+            raise NotImplementedError("pygps_amd: the device EP path is not built in this version")
+        _lib.check(rc, "pgp_ep_fit")
+        self.sweeps = sweeps.value
+        if self.sweeps == 10:
+            logging.getLogger(__name__).warning("maximum number of sweeps reached in function infEP")
+        self.last_ttau = ttau.reshape(n, 1)
+        self.last_tnu = tnu.reshape(n, 1)
+        post = postStruct()
+        post.alpha = alpha.reshape(n, 1)
+        post.sW = sW.reshape(n, 1)
+        post.L = DeviceFactor(fh, n, dev)
+        if nargout > 2:
+            dnlZ = dnlZStruct(meanfunc, covfunc, likfunc)
+            dnlZ.mean = [np.float64(v) for v in g[:nm]]
+            dnlZ.cov = [np.float64(v) for v in g[nm:nm + nc]]
+            dnlZ.lik = []
+            return post, np.float64(nlZ[0]), dnlZ
+        return post, np.float64(nlZ[0])

@@ -266,8 +266,52 @@ def g9():
          best_hyp=final, best_nlZ=m.nlZ)
 
 
+# ----------------------------------------------------------------------------- minimize.py trajectories
+def rosen(v):
+    """Pure-numpy objective (value, gradient); also defined in tests/test_host_logic.py."""
+    a, b = v[:-1], v[1:]
+    f = np.sum(100.0 * (b - a ** 2) ** 2 + (1 - a) ** 2)
+    g = np.zeros_like(v)
+    g[:-1] += -400.0 * a * (b - a ** 2) - 2 * (1 - a)
+    g[1:] += 200.0 * (b - a ** 2)
+    return f, g
+
+
+def gmin():
+    from pyGPs.Optimization import minimize as refmin
+    out = {}
+    for tag, x0, length in (("a", np.array([-1.2, 1.0]), 40), ("b", np.array([-1.2, 1.0, 0.5, -0.3]), 60),
+                            ("c", np.array([2.0, -1.5, 0.7]), -45)):
+        calls = [0]
+
+        def f(v):
+            calls[0] += 1
+            return rosen(v)
+        X, fX, i = refmin.run(f, x0.copy(), length=length)
+        out.update({tag + "_x0": x0, tag + "_length": length, tag + "_X": X, tag + "_fX": np.array(fX), tag + "_i": i,
+                    tag + "_calls": calls[0]})
+    # an objective that raises on some calls (bisection path, minimize.py:88-97) and one that returns NaN (:93-94)
+    calls = [0]
+
+    def flaky(v):
+        calls[0] += 1
+        if np.abs(v).max() > 2.2:            # fails far out: only ever hit while extrapolating
+            raise ValueError("boom")
+        return rosen(v)
+    X, fX, i = refmin.run(flaky, np.array([2.0, -1.5, 0.7]), length=-40)
+    out.update(d_X=X, d_fX=np.array(fX), d_i=i, d_calls=calls[0])
+    calls = [0]
+
+    def nanny(v):
+        calls[0] += 1
+        f, g = rosen(v)
+        return (np.nan, g) if calls[0] == 4 else (f, g)
+    out["e_is_none"] = refmin.run(nanny, np.array([-1.2, 1.0]), length=20) is None
+    save("Gmin_minimize_trajectories", **out)
+
+
 CASES = {
-    "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
+    "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
     "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048),
 }

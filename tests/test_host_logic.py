@@ -1,0 +1,178 @@
+"""CPU: host-side logic of the drop-in (no GPU): the CG minimiser against trajectories recorded from the
+reference's minimize.py, the optimiser bookkeeping, likelihood scalar maps against the oracle, the
+argument checks, and the loud failure when no GPU / library is available."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import gp_oracle as O
+
+
+def rosen(v):
+    a, b = v[:-1], v[1:]
+    f = np.sum(100.0 * (b - a ** 2) ** 2 + (1 - a) ** 2)
+    g = np.zeros_like(v)
+    g[:-1] += -400.0 * a * (b - a ** 2) - 2 * (1 - a)
+    g[1:] += 200.0 * (b - a ** 2)
+    return f, g
+
+
+def test_minimize_reproduces_reference_trajectories_bit_for_bit():
+    from pygps_amd import minimize
+    g = golden("Gmin_minimize_trajectories")
+    for tag in "abc":
+        calls = [0]
+
+        def f(v):
+            calls[0] += 1
+            return rosen(v)
+        X, fX, i = minimize.run(f, g[tag + "_x0"].copy(), length=int(g[tag + "_length"]))
+        assert i == int(g[tag + "_i"]) and calls[0] == int(g[tag + "_calls"])
+        assert np.array_equal(X, g[tag + "_X"]) and np.array_equal(np.array(fX), g[tag + "_fX"])
+    calls = [0]
+
+    def flaky(v):
+        calls[0] += 1
+        if np.abs(v).max() > 2.2:            # fails far out: only ever hit while extrapolating
+            raise ValueError("boom")
+        return rosen(v)
+    X, fX, i = minimize.run(flaky, np.array([2.0, -1.5, 0.7]), length=-40)
+    assert np.array_equal(X, g["d_X"]) and np.array_equal(np.array(fX), g["d_fX"]) and i == int(g["d_i"])
+    assert calls[0] == int(g["d_calls"])
+    calls = [0]
+
+    def nanny(v):
+        calls[0] += 1
+        f, gr = rosen(v)
+        return (np.nan, gr) if calls[0] == 4 else (f, gr)
+    assert bool(g["e_is_none"]) and minimize.run(nanny, np.array([-1.2, 1.0]), length=20) is None
+
+
+class _FakeModel(object):
+    """A model whose objective is a cheap numpy function: exercises Minimize / ShardedMinimize
+    bookkeeping (restart order, RNG order, failure accounting) without a GPU."""
+
+    class _H(object):
+        def __init__(self, hyp):
+            self.hyp = list(hyp)
+
+    class _D(object):
+        def __init__(self, g):
+            self.mean, self.cov, self.lik = [g[0]], list(g[1:3]), [g[3]]
+
+    def __init__(self, fail_at=()):
+        self.meanfunc, self.covfunc, self.likfunc = self._H([0.1]), self._H([0.2, -0.3]), self._H([0.4])
+        self.x = np.zeros((4, 1)); self.y = np.zeros((4, 1))
+        self.calls = 0
+        self.fail_at = set(fail_at)
+        self.starts = []
+
+    def getPosterior(self, der=True):
+        self.calls += 1
+        v = np.array(self.meanfunc.hyp + self.covfunc.hyp + self.likfunc.hyp)
+        if any(abs(v[0] - s) < 1e-12 for s in self.fail_at):
+            raise np.linalg.LinAlgError("not PD")
+        f, g = rosen(v)
+        return f + np.sum(np.cos(3 * v)), self._D(g - 3 * np.sin(3 * v)), None
+
+
+def _conf(model, R):
+    from pygps_amd import conf
+    c = conf.random_init_conf(model.meanfunc, model.covfunc, model.likfunc)
+    c.num_restarts = R
+    return c
+
+
+def test_minimize_restarts_rng_order_and_selection():
+    from pygps_amd import opt
+    m1 = _FakeModel()
+    o1 = opt.Minimize(m1, _conf(m1, 6))
+    np.random.seed(7)
+    h1, f1 = o1.findMin(m1.x, m1.y, numIters=15)
+    assert o1.trailsCounter == 6 and o1.errorCounter == 0                # total runs = num_restarts
+    # the sharded optimiser (no process group -> single rank) must visit the same starts and pick the same optimum
+    m2 = _FakeModel()
+    o2 = opt.ShardedMinimize(m2, _conf(m2, 6))
+    np.random.seed(7)
+    h2, f2 = o2.findMin(m2.x, m2.y, numIters=15)
+    assert f1 == f2 and np.array_equal(h1, h2)
+    assert len(o2.runs) == 6 and min(r.f for r in o2.runs) == f2
+    # replay the RNG: restart-major, hyp-minor uniform(-5, 5) draws
+    np.random.seed(7)
+    table = np.array([[np.random.uniform(-5, 5) for _ in range(4)] for _ in range(5)])
+    assert table.shape == (5, 4)
+
+
+def test_minimize_failure_accounting():
+    from pygps_amd import opt
+    m = _FakeModel()
+    c = _conf(m, 4)
+    c.meanRange = [(2.0, 2.0)]                                           # every random restart starts at hyp[0] == 2.0 ...
+    m.fail_at = {2.0}                                                     # ... where the objective raises
+    o = opt.Minimize(m, c)
+    with pytest.raises(Exception, match="Over half of the trails failed"):
+        o.findMin(m.x, m.y, numIters=5)
+    with pytest.raises(Exception, match="not consistent"):
+        c.covRange = [(-1, 1)]
+    o = opt.Minimize(_FakeModel(fail_at={0.1}), None)                    # no searchConfig: a failing first run is fatal
+    with pytest.raises(Exception, match="Can not learn hyperparamters"):
+        o.findMin(None, None, numIters=5)
+
+
+def test_likelihood_scalar_maps_match_oracle():
+    from pygps_amd import inf, lik
+    rng = np.random.RandomState(0)
+    y = np.sign(rng.randn(200, 1)); mu = 4 * rng.randn(200, 1); s2 = rng.rand(200, 1) * 3
+    mu[:5] = [[-40.], [-8.], [-6.1], [-5.7], [-5.2]]; y[:5] = 1; s2[:5] = 0.01         # asymptotic branches
+    got = lik.Erf().evaluate(y, mu, s2, inf.EP(), None, 3)
+    ref = O.erf_ep_moments(y, mu, s2, 3)
+    for a, b in zip(got, ref):
+        assert np.allclose(a, b, rtol=1e-14, atol=0)
+    lp, ymu, ys2 = lik.Erf().evaluate(None, mu, s2, None, None, 3)
+    p = np.exp(O.erf_ep_moments(np.ones_like(mu), mu, s2, 1)[0])
+    assert np.allclose(ymu, 2 * p - 1) and np.allclose(ys2, 4 * p * (1 - p))
+    g = lik.Gauss(np.log(0.3))
+    lp, ymu, ys2 = g.evaluate(None, mu, s2, None, None, 3)
+    assert np.allclose(ys2, s2 + 0.09) and np.array_equal(ymu, mu)
+    lp0 = g.evaluate(y, mu, np.zeros_like(mu), None, None, 1)
+    assert np.allclose(lp0, -(y - mu) ** 2 / 0.09 / 2 - np.log(2 * np.pi * 0.09) / 2)
+
+
+def test_model_facade_host_rules():
+    import pygps_amd as pyGPs
+    m = pyGPs.GPR()
+    assert isinstance(m.meanfunc, pyGPs.mean.Zero) and m.covfunc.hyp == [0., 0.]
+    assert abs(m.likfunc.hyp[0] - np.log(0.1)) < 1e-15
+    x = np.arange(6.0); y = np.array([1., 2., 3., 4., 5., 9.])
+    m.setData(x, y)                                                      # 1-d -> (n,1); default mean -> Const(mean y) (Q8)
+    assert m.x.shape == (6, 1) and m.y.shape == (6, 1) and isinstance(m.meanfunc, pyGPs.mean.Const)
+    assert m.meanfunc.hyp == [4.0]
+    m.setPrior(mean=pyGPs.mean.Zero())
+    m.setData(x, y)
+    assert isinstance(m.meanfunc, pyGPs.mean.Zero)                       # a user-set mean is kept
+    with pytest.raises(AssertionError):
+        m.setPrior(kernel="rbf")
+    with pytest.raises(Exception, match="not set correctly"):
+        m.setOptimizer("SCG")
+    m.setOptimizer("Minimize", num_restarts=3, covRange=[(-1, 1), (-2, 2)])
+    assert m.optimizer.searchConfig.covRange == [(-1, 1), (-2, 2)] and m.optimizer.searchConfig.num_restarts == 3
+    k = pyGPs.cov.RBFard(D=3)
+    assert k.hyp == [0., 0., 0., 0.]
+    c = pyGPs.GPC()
+    with pytest.raises(Exception, match="labels different from"):
+        c.getPosterior(np.zeros((3, 1)), np.array([0., 1., 2.]))
+    d = pyGPs.inf.dnlZStruct(pyGPs.mean.Const(1.), pyGPs.cov.RBF(), pyGPs.lik.Gauss())
+    d.mean, d.cov, d.lik = [1.], [2., 3.], [4.]
+    d.accumulateDnlZ(d)
+    assert d.cov == [4., 6.]
+
+
+def test_no_gpu_fails_loudly_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import pygps_amd as pyGPs
+    with pytest.raises(RuntimeError, match="no CPU fallback|cannot initialise"):
+        pyGPs.GPR().getPosterior(np.zeros((3, 1)), np.zeros(3))
+    with pytest.raises(RuntimeError):
+        pyGPs.cov.RBF().getCovMatrix(x=np.zeros((3, 1)), mode="train")
