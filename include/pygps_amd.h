@@ -115,6 +115,7 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
                   double* C, int64_t ldc, int M, int N, int K, int iters, double* ms_out);
 int pgp_test_mfma_peak(pgp_ctx* ctx, int iters, double* tflops_out);
 int pgp_test_mfma_cycles(pgp_ctx* ctx, int iters, int nacc, int waves_per_simd, double* out3);
+int pgp_test_leaf_ticks(pgp_ctx* ctx, double* ticks_out /* 24 */);
 
 #ifdef __cplusplus
 }

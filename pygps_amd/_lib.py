@@ -55,6 +55,7 @@ SIGNATURES = {
                                 _dp]),
     "pgp_test_mfma_peak": (C.c_int, [_vp, C.c_int, _dp]),
     "pgp_test_mfma_cycles": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
+    "pgp_test_leaf_ticks": (C.c_int, [_vp, _dp]),
 }
 
 _lock = threading.Lock()

@@ -48,6 +48,11 @@ int pgp_init(int device, pgp_ctx** ctx_out) {
     c->device = device;
     HIP_TRY(hipGetDeviceProperties(&c->prop, device));
     HIP_TRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIP_TRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, hi));   // panel chain = critical path
+    }
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     memset(c->last_ms, 0, sizeof(c->last_ms));
     memset(c->pc_ms, 0, sizeof(c->pc_ms)); memset(c->pc_flops, 0, sizeof(c->pc_flops));
@@ -63,12 +68,15 @@ void pgp_destroy(pgp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
+    for (auto& kv : c->orders) (void)hipFree(kv.second.first);
     void* bufs[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev, c->W, c->T, c->Binv, c->inv16, c->alpha_dev, c->m_dev,
                     c->rvec, c->zvec, c->partial, c->scal, c->info_dev};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->st);
+    if (c->st2) (void)hipStreamDestroy(c->st2);
+    for (auto& e : c->la_ev) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -85,6 +93,9 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!c || !name) return -1;
     if (!strcmp(name, "nb_outer")) { if (value < 1) return -3; c->nb_outer = value; return PGP_OK; }
     if (!strcmp(name, "small_tile_below")) { c->small_tile_below = value; return PGP_OK; }
+    if (!strcmp(name, "xcd_order")) { c->xcd_order = value; return PGP_OK; }
+    if (!strcmp(name, "gemm_dbg")) { c->gemm_dbg = value; return PGP_OK; }
+    if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     return -2;
 }
 
@@ -158,56 +169,146 @@ static int upload_scaled(pgp_ctx* c, const double* x_dev, long n, long d, const 
     return scale_transpose_launch(x_dev, n, (int)d, scale_dev, XsT, ldp, dpad, c->st);
 }
 
-int gemm_prof(pgp_ctx* c, int cls, GemmArgs g) {
+// Tile order for a GEMM launch.  Tiles are enumerated in 8x8 super-tiles (row-major over super-tiles, so
+// for k-clipped triangular products the long-K rows come first = LPT), the list is cut into 8 contiguous
+// chunks and chunk x is handed to the blocks with blockIdx % 8 == x -- the blocks the dispatcher places on
+// XCD x.  The ~64 workgroups resident on one XCD then share 8 A and 8 B operand slabs through that XCD's
+// private 4 MiB L2 instead of streaming 64 + 8 distinct slabs through all eight L2s.  Speed only: any
+// placement computes the same result.
+static int tile_order(pgp_ctx* c, int mt, int nt, int tri, int off_tiles, const int** out, int* n) {
+    std::vector<int> key = {mt, nt, tri ? 1 : 0, off_tiles};
+    auto it = c->orders.find(key);
+    if (it != c->orders.end()) { *out = it->second.first; *n = it->second.second; return PGP_OK; }
+    // super-tiles in row-major order (long-K rows first), dealt round-robin to the 8 XCDs so that every XCD
+    // sees the same cost profile; exhausted XCD sequences are padded with (-1,-1) no-op entries
+    const int S = 8;
+    std::vector<std::vector<int>> seq(8);
+    int sidx = 0;
+    for (int SI = 0; SI * S < mt; ++SI)
+        for (int SJ = 0; SJ * S < nt; ++SJ) {
+            std::vector<int> st;
+            for (int ti = SI * S; ti < std::min(mt, SI * S + S); ++ti)
+                for (int tj = SJ * S; tj < std::min(nt, SJ * S + S); ++tj)
+                    if (!tri || ti + off_tiles >= tj) { st.push_back(ti); st.push_back(tj); }
+            if (st.empty()) continue;
+            auto& dst = seq[sidx % 8];
+            dst.insert(dst.end(), st.begin(), st.end());
+            ++sidx;
+        }
+    size_t maxlen = 0;
+    for (auto& q : seq) maxlen = std::max(maxlen, q.size() / 2);
+    const int nb = (int)maxlen * 8;
+    std::vector<int> ord(2 * (size_t)nb, -1);
+    for (int b = 0; b < nb; ++b) {
+        const int x = b % 8, idx = b / 8;
+        if ((size_t)idx < seq[x].size() / 2) { ord[2 * b] = seq[x][2 * idx]; ord[2 * b + 1] = seq[x][2 * idx + 1]; }
+    }
+    int* dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev, ord.size() * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(dev, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));          // ord goes out of scope
+    c->orders[key] = {dev, nb};
+    *out = dev; *n = nb;
+    return PGP_OK;
+}
+
+int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
+    if (!st) st = c->st;
     if (g.batch < 1) g.batch = 1;
-    ProfScope ps(c, cls, g.flops, 0.0);
-    return gemm_f64_launch(g, c->st);
+    if (c->xcd_order && !g.order) {
+        const int T = g.tile == 64 ? 64 : 128;
+        CHK(tile_order(c, g.M / T, g.N / T, g.tri, g.tri ? g.tri_off / T : 0, &g.order, &g.norder));
+    }
+    ProfScope ps(c, cls, g.flops, 0.0, st);
+    return gemm_f64_launch(g, st);
 }
 
 // Blocked right-looking Cholesky of the (mrows x np) column-major lower matrix F (mrows >= np; rows
 // beyond np are "augmented" right-hand-side rows that receive the forward substitution for free).
+//
+// Two-level blocking: leaves of 128 columns (leaf_potrf -> trsm_rows -> inner update, K = 128) inside outer
+// panels of q leaves; the trailing matrix is updated once per outer panel with K = 128 q (C is read and
+// written once per 128 q columns: HBM arithmetic intensity 16 q flop/B).
+// Look-ahead (depth 1): the update of the NEXT panel's columns (TU_a) is issued first; the next panel is
+// then factored on the high-priority stream st2 while the rest of the trailing update (TU_b) runs on st.
+static int factor_panel(pgp_ctx* c, double* F, long ld, long mrows, int s0, int s1, hipStream_t st) {
+    for (int cb = s0; cb < s1; ++cb) {
+        double* Acc = F + (long)cb * 128 + (long)cb * 128 * ld;
+        double* pack = c->inv16 + (long)cb * PACK_DOUBLES;
+        {
+            ProfScope ps(c, PC_LEAF, 128.0 * 128.0 * 128.0 / 3.0, 0.0, st);
+            CHK(leaf_potrf_launch(Acc, ld, pack, c->info_dev, cb * 128, st));
+        }
+        const long rows_below = mrows - (long)(cb + 1) * 128;
+        if (rows_below > 0) {
+            ProfScope ps(c, PC_TRSM, (double)rows_below * 128.0 * 128.0, 0.0, st);
+            CHK(trsm_rows_launch(Acc + 128, ld, rows_below, Acc, ld, pack, st));
+        }
+        if (cb + 1 < s1) {               // inner update of the rest of this outer panel, K = 128
+            GemmArgs g{};
+            g.A = Acc + 128; g.lda = ld; g.a_kc = 0;
+            g.B = Acc + 128; g.ldb = ld; g.b_kc = 0;
+            g.C = F + (long)(cb + 1) * 128 + (long)(cb + 1) * 128 * ld; g.ldc = ld;
+            g.M = (int)rows_below; g.N = (s1 - 1 - cb) * 128; g.K = 128;
+            g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
+            const long t128 = (long)(g.M / 128) * (g.N / 128);
+            g.tile = t128 < c->small_tile_below ? 64 : 128;
+            g.flops = 2.0 * 128.0 * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
+            CHK(gemm_prof(c, PC_GEMM_INNER, g, st));
+        }
+    }
+    return PGP_OK;
+}
+
+// C[rows >= r0, cols c0..c1) -= P P^T, P = F[rows, k0..k1) (block units of 128), lower part only
+static int trailing_update(pgp_ctx* c, double* F, long ld, long mrows, int k0, int k1, int c0, int c1,
+                           hipStream_t st) {
+    if (c1 <= c0) return PGP_OK;
+    GemmArgs g{};
+    g.A = F + (long)c0 * 128 + (long)k0 * 128 * ld; g.lda = ld; g.a_kc = 0;
+    g.B = g.A; g.ldb = ld; g.b_kc = 0;
+    g.C = F + (long)c0 * 128 + (long)c0 * 128 * ld; g.ldc = ld;
+    g.M = (int)(mrows - (long)c0 * 128); g.N = (c1 - c0) * 128; g.K = (k1 - k0) * 128;
+    g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
+    const long t128 = (long)(g.M / 128) * (g.N / 128) - (long)(g.N / 128) * (g.N / 128 - 1) / 2;
+    g.tile = t128 < c->small_tile_below ? 64 : 128;
+    g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
+    return gemm_prof(c, PC_GEMM_TRAIL, g, st);
+}
+
 int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows) {
     const int nblk = (int)(np / 128);
     const int q = c->nb_outer;
-    for (int s0 = 0; s0 < nblk; s0 += q) {
-        const int s1 = std::min(s0 + q, nblk);
-        for (int cb = s0; cb < s1; ++cb) {
-            double* Acc = F + (long)cb * 128 + (long)cb * 128 * ld;
-            {
-                ProfScope ps(c, PC_LEAF, 128.0 * 128.0 * 128.0 / 3.0, 0.0);
-                CHK(leaf_potrf_launch(Acc, ld, c->inv16 + (long)cb * 2048, c->info_dev, cb * 128, c->st));
-            }
-            const long rows_below = mrows - (long)(cb + 1) * 128;
-            if (rows_below > 0) {
-                ProfScope ps(c, PC_TRSM, (double)rows_below * 128.0 * 128.0, 0.0);
-                CHK(trsm_rows_launch(Acc + 128, ld, rows_below, Acc, ld, c->inv16 + (long)cb * 2048, c->st));
-            }
-            if (cb + 1 < s1) {               // inner update of the rest of this outer panel, K = 128
-                GemmArgs g{};
-                g.A = Acc + 128; g.lda = ld; g.a_kc = 0;
-                g.B = Acc + 128; g.ldb = ld; g.b_kc = 0;
-                g.C = F + (long)(cb + 1) * 128 + (long)(cb + 1) * 128 * ld; g.ldc = ld;
-                g.M = (int)rows_below; g.N = (s1 - 1 - cb) * 128; g.K = 128;
-                g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
-                const long t128 = (long)(g.M / 128) * (g.N / 128);
-                g.tile = t128 < c->small_tile_below ? 64 : 128;
-                g.flops = 2.0 * 128.0 * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
-                CHK(gemm_prof(c, PC_GEMM_INNER, g));
-            }
+    const int npanel = (nblk + q - 1) / q;
+    if (!c->lookahead || npanel < 3) {
+        for (int s0 = 0; s0 < nblk; s0 += q) {
+            const int s1 = std::min(s0 + q, nblk);
+            CHK(factor_panel(c, F, ld, mrows, s0, s1, c->st));
+            CHK(trailing_update(c, F, ld, mrows, s0, s1, s1, nblk, c->st));
         }
-        if (s1 < nblk) {                     // trailing update, K = (s1 - s0) * 128
-            GemmArgs g{};
-            const double* P = F + (long)s1 * 128 + (long)s0 * 128 * ld;
-            g.A = P; g.lda = ld; g.a_kc = 0;
-            g.B = P; g.ldb = ld; g.b_kc = 0;
-            g.C = F + (long)s1 * 128 + (long)s1 * 128 * ld; g.ldc = ld;
-            g.M = (int)(mrows - (long)s1 * 128); g.N = (int)(np - (long)s1 * 128); g.K = (s1 - s0) * 128;
-            g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
-            const long t128 = (long)(g.M / 128) * (g.N / 128) / 2;
-            g.tile = t128 < c->small_tile_below ? 64 : 128;
-            g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
-            CHK(gemm_prof(c, PC_GEMM_TRAIL, g));
-        }
+        return PGP_OK;
+    }
+    while ((int)c->la_ev.size() < 2 * npanel + 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->la_ev.push_back(e);
+    }
+    hipStream_t main = c->st, pan = c->st2;
+    // panel 0 on the main stream
+    CHK(factor_panel(c, F, ld, mrows, 0, std::min(q, nblk), main));
+    for (int p = 0; p < npanel; ++p) {
+        const int s0 = p * q, s1 = std::min(s0 + q, nblk);
+        if (s1 >= nblk) break;
+        const int n0 = s1, n1 = std::min(s1 + q, nblk);              // next panel's columns
+        // TU_a(p): next panel's columns, then hand the next panel to the panel stream
+        CHK(trailing_update(c, F, ld, mrows, s0, s1, n0, n1, main));
+        HIP_TRY(hipEventRecord(c->la_ev[2 * p], main));
+        HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
+        CHK(factor_panel(c, F, ld, mrows, n0, n1, pan));
+        HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
+        // TU_b(p): the rest of the trailing matrix, concurrently with the panel factorisation
+        CHK(trailing_update(c, F, ld, mrows, s0, s1, n1, nblk, main));
+        HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));    // next TU_a needs the factored panel
     }
     return PGP_OK;
 }
@@ -308,7 +409,7 @@ static int ensure_workspace(pgp_ctx* c, long np) {
     HIP_TRY(hipMalloc((void**)&c->Binv, nn));
     HIP_TRY(hipMemsetAsync(c->Binv, 0, nn, c->st));
     HIP_TRY(hipMalloc((void**)&c->T, std::max<size_t>(nn / 4, 128 * 128 * sizeof(double))));
-    HIP_TRY(hipMalloc((void**)&c->inv16, (size_t)(np / 128) * 2048 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->inv16, (size_t)(np / 128) * PACK_DOUBLES * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->alpha_dev, np * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->m_dev, np * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->rvec, np * sizeof(double)));
@@ -601,7 +702,7 @@ int pgp_potrf(pgp_ctx* c, const double* A, int64_t n, double* L_out) {
     (void)save_ws;
     double* inv16_save = c->inv16;
     double* inv16 = nullptr;
-    HIP_TRY(hipMalloc((void**)&inv16, (size_t)(np / 128) * 2048 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&inv16, (size_t)(np / 128) * PACK_DOUBLES * sizeof(double)));
     c->inv16 = inv16;
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
     int rc = potrf_blocked(c, F, np, np, np);

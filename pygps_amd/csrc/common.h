@@ -48,6 +48,9 @@ struct GemmArgs {
     int kmode; int koff;
     int batch; long sA, sB, sC;   // batch strides in elements
     int tile;               // 128 or 64
+    const int* order;       // optional (ti,tj) pairs per block (XCD-aware / LPT tile order built on the host); grid = norder
+    int norder;
+    int dbg;                // experiments only: 1 = no global->LDS restaging in the k-loop, 2 = no barrier, 4 = no C load/store
     double flops;           // algorithmic flops of this launch (for profiling; filled by caller)
 };
 

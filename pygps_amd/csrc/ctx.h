@@ -33,6 +33,9 @@ struct pgp_factor {
 struct pgp_ctx {
     int device = 0;
     hipStream_t st = nullptr;
+    hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky
+    std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
+    int lookahead = 1;
     hipDeviceProp_t prop;
     // pooled device buffers, keyed by byte size
     std::multimap<size_t, void*> pool;
@@ -54,6 +57,10 @@ struct pgp_ctx {
     std::vector<hipEvent_t> ev_pool;
     double pc_ms[PC_COUNT], pc_flops[PC_COUNT], pc_bytes[PC_COUNT];
     int64_t pc_launch[PC_COUNT];
+    // cached tile-order tables (device), keyed by (mt, nt, tri, tri_off_tiles)
+    std::map<std::vector<int>, std::pair<int*, int>> orders;
+    int gemm_dbg = 0;
+    int xcd_order = 0;    // 1: XCD-aware super-tile order (measured slower on MI355X for these shapes: off)
     // options
     int nb_outer = 4;     // leaves (128 columns each) per outer panel -> trailing update K = 512
     int small_tile_below = 256;   // use 64x64 tiles when a GEMM has fewer 128-tiles than this
@@ -80,8 +87,9 @@ static inline void pool_free(pgp_ctx* c, size_t bytes, void* p) {
 }
 
 struct ProfScope {
-    pgp_ctx* c; int cls; double flops, bytes; hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(pgp_ctx* c_, int cls_, double f, double b) : c(c_), cls(cls_), flops(f), bytes(b) {
+    pgp_ctx* c; int cls; double flops, bytes; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t s;
+    ProfScope(pgp_ctx* c_, int cls_, double f, double b, hipStream_t s_ = nullptr)
+        : c(c_), cls(cls_), flops(f), bytes(b), s(s_ ? s_ : c_->st) {
         if (!c->prof) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -90,11 +98,11 @@ struct ProfScope {
             return e;
         };
         e0 = get(); e1 = get();
-        (void)hipEventRecord(e0, c->st);
+        (void)hipEventRecord(e0, s);
     }
     ~ProfScope() {
         if (!c->prof) return;
-        (void)hipEventRecord(e1, c->st);
+        (void)hipEventRecord(e1, s);
         c->recs.push_back({cls, e0, e1, flops, bytes});
     }
 };
@@ -105,4 +113,4 @@ static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 int fill_scale(int kind, const double* hyp, int nhyp, int para, long d, std::vector<double>& sc);
 CovParams make_cp(int kind, const double* hyp, int nhyp, int para, int flags, int der, long d);
 int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows);
-int gemm_prof(pgp_ctx* c, int cls, GemmArgs g);
+int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);

@@ -39,7 +39,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
     const int mt = g.M / TM;
     int ti, tj;
-    if (g.tri == 2) {                               // packed lower-triangular tile index
+    if (g.order) {                                  // host-built tile order (see tile_order() in capi.hip)
+        ti = g.order[2 * blockIdx.x];
+        tj = g.order[2 * blockIdx.x + 1];
+        if (ti < 0) return;                         // padding entry
+    } else if (g.tri == 2) {                               // packed lower-triangular tile index
         const int b = blockIdx.x;
         int r = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
         while ((long)(r + 1) * (r + 2) / 2 <= b) ++r;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     for (int im = 0; im < FM; ++im)
 #pragma unroll
         for (int in = 0; in < FN; ++in) {
-            if (g.beta != 0.0) {
+            if (g.beta != 0.0 && !(g.dbg & 4)) {
                 const double* cp = C + (long)(i0 + wm + im * 16 + l15) + (long)(j0 + wn + in * 16 + l4) * g.ldc;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[im][in][r] = ab * cp[(long)(4 * r) * g.ldc];
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         int buf = 0;
         for (int kt = k0; kt < k1; kt += BK) {
             const bool more = kt + BK < k1;
-            if (more) gload(kt + BK);
+            if (more && !(g.dbg & 1)) gload(kt + BK);
             const double* sa = smem + buf * STAGE;
             const double* sb = sa + ASZ;
 #pragma unroll
@@ -190,9 +194,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                     for (int im = 0; im < FM; ++im)
                         acc[im][in] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[in], fa[im], acc[im][in], 0, 0, 0);
             }
-            if (more) sstore(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
+            if (more && !(g.dbg & 1)) sstore(buf ^ 1);
+            if (!(g.dbg & 2)) __syncthreads();
+            if (!(g.dbg & 1)) buf ^= 1;
         }
     }
 
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = nb + 4 * r;
-                if (!diag || m >= n) cp[(long)(4 * r) * g.ldc] = g.alpha * acc[im][in][r];
+                if ((!diag || m >= n) && (!(g.dbg & 4) || acc[im][in][r] == 12345.678)) cp[(long)(4 * r) * g.ldc] = g.alpha * acc[im][in][r];
             }
         }
 }
@@ -220,6 +224,7 @@ int launch_t(const GemmArgs& g, hipStream_t st) {
     const size_t shm = 2 * (ASZ + BSZ) * sizeof(double);
     const int mt = g.M / T, nt = g.N / T;
     unsigned nblk = (g.tri == 2) ? (unsigned)((long)mt * (mt + 1) / 2) : (unsigned)(mt * nt);
+    if (g.order) nblk = (unsigned)g.norder;
     dim3 grid(nblk, 1, g.batch > 0 ? g.batch : 1);
     static bool attr_set = false;
     if (!attr_set) {

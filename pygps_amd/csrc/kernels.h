@@ -5,7 +5,9 @@
 struct CovParams;
 
 // panel.hip
-int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st);
+constexpr long PACK_DOUBLES = 44 * 256;   // per-leaf packed operand image: 36 L blocks + 8 inverted pivot blocks
+int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st,
+                      long long* tick = nullptr);
 int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl, const double* inv16,
                      hipStream_t st);
 int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, long wstride, int nblocks, hipStream_t st);

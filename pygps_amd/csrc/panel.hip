@@ -20,6 +20,7 @@
 #include "kernels.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -32,154 +33,312 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// Factor the 16x16 block whose row `lane` is held in a[0..15] (lanes 0..15 of the calling wave).
-// Returns 0 or the 1-based index of the first non-positive pivot.  On return a[] holds row `lane`
-// of the lower factor (entries right of the diagonal are junk) and dinv = 1 / L(lane,lane).
-__device__ __forceinline__ int potf2_16_rows(double (&a)[16], double& dinv, int lane) {
-    int info = 0;
+// 1/sqrt(d) and sqrt(d) from v_rsq_f64 + two Newton steps (pure FMA chains, ~1 ulp): the IEEE sqrt and
+// divide sequences hipcc emits are ~35 dependent instructions per pivot, the dominant cost of the 16
+// sequential pivots.  Pivots of B = K/sn2 + I lie in [1, 1 + sf2/sn2]: no scaling needed.
+__device__ __forceinline__ void rsqrt_sqrt(double d, double& rinv, double& s) {
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = r * fma(-h * r, r, 1.5);
+    r = r * fma(-h * r, r, 1.5);
+    double q = d * r;
+    q = fma(fma(-q, q, d), 0.5 * r, q);
+    rinv = r;
+    s = q;
+}
+
+// broadcast lane `K` of each 16-lane row (DPP row_newbcast, 64-bit form on gfx90a+: one VALU op, no SGPR trip)
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) {
+    double r;       // asm (not the builtin) so that the wait states stay glued to the DPP read
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+
+// acc += (lane K's src) * mul  in ONE instruction: v_fmac_f64 with a DPP row_newbcast source.  hipcc pads no
+// hazards inside asm: a DPP read of a VGPR written by the previous VALU op needs 2 wait states, so the FIRST
+// use after `src` was produced carries an s_nop 1.
+template <int K, bool NOP>
+__device__ __forceinline__ void fmac_bcast(double& acc, double src, double mul) {
+    if (NOP)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+}
+
+template <int J, int K>
+struct Rank1 {          // a[K] -= a[J] * (lane K's a[J])   for K = J+1 .. 15
+    static __device__ __forceinline__ void run(double (&a)[16], double naj) {
+        fmac_bcast<K, K == J + 1>(a[K], a[J], naj);
+        Rank1<J, K + 1>::run(a, naj);
+    }
+};
+template <int J>
+struct Rank1<J, 16> {
+    static __device__ __forceinline__ void run(double (&)[16], double) {}
+};
+
+template <int J>
+struct PivotCol {
+    static __device__ __forceinline__ void run(double (&a)[16], double& dinv, int& info, int rl) {
+        const double d = row_bcast<J>(a[J]);
+        if (!(d > 0.0) && info == 0) info = J + 1;
+        double rinv, sq;
+        rsqrt_sqrt(d, rinv, sq);
+        a[J] = (rl == J) ? sq : a[J] * rinv;
+        if (rl == J) dinv = rinv;
+        Rank1<J, J + 1>::run(a, -a[J]);
+        PivotCol<J + 1>::run(a, dinv, info, rl);
+    }
+};
+template <>
+struct PivotCol<16> {
+    static __device__ __forceinline__ void run(double (&)[16], double&, int&, int) {}
+};
+
+// column `rl` of W = L16^-1 by forward substitution, L16(r,k) fetched from lane r's a[k] by DPP broadcast
+template <int R, int Kk>
+struct InvDot {
+    static __device__ __forceinline__ void run(double& v, const double (&a)[16], const double (&nx)[16]) {
+        fmac_bcast<R, Kk == 0>(v, a[Kk], nx[Kk]);
+        InvDot<R, Kk + 1>::run(v, a, nx);
+    }
+};
+template <int R>
+struct InvDot<R, R> {
+    static __device__ __forceinline__ void run(double&, const double (&)[16], const double (&)[16]) {}
+};
+template <int R>
+struct InvRow {
+    static __device__ __forceinline__ void run(const double (&a)[16], double dinv, double (&x)[16], double (&nx)[16],
+                                               int rl) {
+        double v = (rl == R) ? 1.0 : 0.0;
+        InvDot<R, 0>::run(v, a, nx);
+        x[R] = v * row_bcast<R>(dinv);
+        nx[R] = -x[R];
+        InvRow<R + 1>::run(a, dinv, x, nx, rl);
+    }
+};
+template <>
+struct InvRow<16> {
+    static __device__ __forceinline__ void run(const double (&)[16], double, double (&)[16], double (&)[16], int) {}
+};
+
+// Wave 0: factor the 16x16 pivot block at offset o (each 16-lane row works on its own copy; lane & 15 = row),
+// write the factor back to LDS, and its inverse both to LDS (sinv, MFMA A-operand order [k][j]) and to the
+// packed global image.  Returns nothing; a non-positive pivot is recorded in *s_info.
+__device__ __forceinline__ void pivot_block(double* __restrict__ s, double* __restrict__ sinv, int* s_info, int o,
+                                            int lane, double* __restrict__ ginv) {
+    double a[16];
+    double di = 0.0;
+    const int rl = lane & 15;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double d = readlane_f64(a[j], j);
-        if (!(d > 0.0) && info == 0) info = j + 1;
-        const double s = sqrt(d);
-        const double rinv = 1.0 / s;
-        a[j] = (lane == j) ? s : a[j] * rinv;
-        if (lane == j) dinv = rinv;
+    for (int c = 0; c < 16; ++c) a[c] = s[(o + c) * LS + o + rl];
+    int inf = 0;
+    PivotCol<0>::run(a, di, inf, rl);
+    if (lane < 16) {
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) {
-            const double lkj = readlane_f64(a[j], k);
-            a[k] = fma(-a[j], lkj, a[k]);
+        for (int c = 0; c < 16; ++c)
+            if (c <= lane) s[(o + c) * LS + o + lane] = a[c];
+    }
+    double x[16], nx[16];
+    InvRow<0>::run(a, di, x, nx, rl);
+    if (lane < 16) {                                   // lane = column k of W: W(j,k) = x[j] -> [k][j]
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const double2_t v = {x[j], x[j + 1]};
+            *(double2_t*)(sinv + lane * 16 + j) = v;
+            *(double2_t*)(ginv + lane * 16 + j) = v;
         }
     }
-    return info;
+    if (lane == 0 && inf != 0 && *s_info == 0) *s_info = o + inf;
+}
+
+// C(ri-block, rj-block) -= P(ri) P(rj)^T with P = columns o..o+15 (one 16x16 tile, 4 MFMAs)
+__device__ __forceinline__ void leaf_tile_update(double* __restrict__ s, int o, int ri, int rj, int lane) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double4_t acc0, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc0[q] = s[(rj + l4 + 4 * q) * LS + ri + l15];
+    double fa[4], fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int k = o + 4 * ks + l4;
+        fa[ks] = -s[k * LS + rj + l15];
+        fb[ks] = s[k * LS + ri + l15];
+    }
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0], fb[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1], fb[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[2], fb[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[3], fb[3], acc1, 0, 0, 0);
+    acc0 += acc1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[(rj + l4 + 4 * q) * LS + ri + l15] = acc0[q];
+}
+
+// rows ri..ri+15 of the column block o:  X <- X W^T  (W = inverted pivot block in sinv), in place
+__device__ __forceinline__ void leaf_tile_trsm(double* __restrict__ s, const double* __restrict__ sinv, int o, int ri,
+                                               int lane) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double fa[4], fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        fa[ks] = sinv[(4 * ks + l4) * 16 + l15];
+        fb[ks] = s[(o + 4 * ks + l4) * LS + ri + l15];
+    }
+    double4_t y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0], fb[0], y0, 0, 0, 0);
+    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1], fb[1], y1, 0, 0, 0);
+    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[2], fb[2], y0, 0, 0, 0);
+    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[3], fb[3], y1, 0, 0, 0);
+    y0 += y1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[(o + l4 + 4 * q) * LS + ri + l15] = y0[q];
 }
 
 __global__ __launch_bounds__(256, 2) void leaf_potrf_kernel(double* __restrict__ A, long lda,
-                                                            double* __restrict__ inv16, int* __restrict__ info,
-                                                            int info_base) {
-    extern __shared__ __attribute__((aligned(16))) double s[];   // s[c*LS + r], + dinv[128]
-    double* dinv = s + NB * LS;
-    int& s_info = *(int*)(dinv + NB);                             // keep ALL LDS in the dynamic region
+                                                            double* __restrict__ pack, int* __restrict__ info,
+                                                            int info_base, long long* __restrict__ tick) {
+    extern __shared__ __attribute__((aligned(16))) double s[];   // s[c*LS + r] | sinv[256] | info
+#define TICK(i) do { if (tick && threadIdx.x == 0) tick[i] = __builtin_readcyclecounter(); } while (0)
+    TICK(0);
+    double* sinv = s + NB * LS;
+    int* s_info = (int*)(sinv + 256);                             // keep ALL LDS in the dynamic region
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) s_info = 0;
-    // load the lower triangle (upper part of the block is never referenced)
-    for (int c = wave; c < NB; c += 4)
-        for (int r = lane; r < NB; r += 64) s[c * LS + r] = (r >= c) ? A[(long)r + (long)c * lda] : 0.0;
+    if (t == 0) *s_info = 0;
+    // load the lower triangle in 16-byte pieces (column c needs rows >= c); every load is in flight before the
+    // first LDS store: one memory latency for the whole 128 KB block
+    {
+        double2_t regs[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int c = wave + 4 * i;
+            regs[i] = (2 * lane + 1 >= c) ? *(const double2_t*)(A + (long)(2 * lane) + (long)c * lda)
+                                          : double2_t{0.0, 0.0};
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) *(double2_t*)(s + (wave + 4 * i) * LS + 2 * lane) = regs[i];
+    }
     __syncthreads();
+    TICK(1);
+    if (wave == 0) pivot_block(s, sinv, s_info, 0, lane, pack + 36 * 256);
+    __syncthreads();
+    TICK(2);
 
     for (int tb = 0; tb < 8; ++tb) {
         const int o = tb * 16;
-        // (a) pivot block: wave 0, lanes 0..15 hold one row each
-        if (wave == 0) {
-            double a[16];
-            double di = 0.0;
-            const int rl = lane & 15;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = s[(o + c) * LS + o + rl];
-            const int inf = potf2_16_rows(a, di, lane);     // lanes >= 16 compute junk on row copies
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c <= lane) s[(o + c) * LS + o + lane] = a[c];
-                dinv[o + lane] = di;
+        const int nt = 7 - tb;                               // block rows below the pivot block
+        // (b) rows below the pivot block: X <- X W^T on the MFMA, one 16-row tile per wave at a time
+        for (int i = wave; i < nt; i += 4) leaf_tile_trsm(s, sinv, o, o + 16 + 16 * i, lane);
+        __syncthreads();
+        TICK(3 + 2 * tb);
+        // (c) trailing update inside the leaf, with look-ahead: wave 0 updates the next pivot block first and
+        // factors + inverts it right away while waves 1..3 update the remaining tiles
+        if (nt > 0) {
+            if (wave == 0) {
+                leaf_tile_update(s, o, o + 16, o + 16, lane);
+                pivot_block(s, sinv, s_info, o + 16, lane, pack + (36 + tb + 1) * 256);
+            } else {
+                const int ntile = nt * (nt + 1) / 2;
+                for (int tile = wave; tile < ntile; tile += 3) {      // tile 0 = (0,0) is wave 0's
+                    int bi = 0, rem = tile;
+                    while (rem > bi) { rem -= bi + 1; ++bi; }
+                    leaf_tile_update(s, o, o + 16 + 16 * bi, o + 16 + 16 * rem, lane);
+                }
             }
-            if (lane == 0 && inf != 0 && s_info == 0) s_info = o + inf;
         }
         __syncthreads();
-        // (b) rows below the pivot block: x <- x L16^-T, one lane per row
-        const int nrow = NB - o - 16;
-        if (t < nrow) {
-            const int r = o + 16 + t;
-            double x[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) x[c] = s[(o + c) * LS + r];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double v = x[j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) v = fma(-x[k], s[(o + k) * LS + o + j], v);
-                x[j] = v * dinv[o + j];
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) s[(o + c) * LS + r] = x[c];
-        }
-        __syncthreads();
-        // (c) trailing update inside the leaf: C(bi,bj) -= P(bi) P(bj)^T for tb < bj <= bi
-        const int nt = 7 - tb;                               // remaining block rows
-        const int ntile = nt * (nt + 1) / 2;
-        const int l15 = lane & 15, l4 = lane >> 4;
-        for (int tile = wave; tile < ntile; tile += 4) {
-            int bi = 0, rem = tile;
-            while (rem > bi) { rem -= bi + 1; ++bi; }
-            const int bj = rem;                              // 0 <= bj <= bi < nt
-            const int ri = o + 16 + 16 * bi, rj = o + 16 + 16 * bj;
-            double4_t acc;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = s[(rj + l4 + 4 * q) * LS + ri + l15];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int k = o + 4 * ks + l4;
-                const double fa = -s[k * LS + rj + l15];
-                const double fb = s[k * LS + ri + l15];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s[(rj + l4 + 4 * q) * LS + ri + l15] = acc[q];
-        }
-        __syncthreads();
+        TICK(4 + 2 * tb);
     }
-    // write back the factor (lower part; the strict upper part of the block stays untouched = 0)
-    for (int c = wave; c < NB; c += 4)
-        for (int r = lane; r < NB; r += 64)
-            if (r >= c) A[(long)r + (long)c * lda] = s[c * LS + r];
-    // inverted 16x16 pivot blocks: thread (blk = t/16, col = t%16) for t < 128 solves L16 x = e_col
-    if (t < 128) {
-        const int blk = t >> 4, c = t & 15, o = blk * 16;
-        double x[16];
+    if (tick && t == 0) tick[20] = __builtin_readcyclecounter();
+    // write back the factor (lower part; the strict upper part of the block keeps its exact zeros)
+    {
+        double2_t regs[32];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            double v = (r == c) ? 1.0 : 0.0;
+        for (int i = 0; i < 32; ++i) regs[i] = *(const double2_t*)(s + (wave + 4 * i) * LS + 2 * lane);
 #pragma unroll
-            for (int k = 0; k < r; ++k) v = fma(-s[(o + k) * LS + o + r], x[k], v);
-            x[r] = (r < c) ? 0.0 : v * dinv[o + r];
+        for (int i = 0; i < 32; ++i) {
+            const int c = wave + 4 * i;
+            if (2 * lane >= c) *(double2_t*)(A + (long)(2 * lane) + (long)c * lda) = regs[i];
+            else if (2 * lane + 1 >= c) A[(long)(2 * lane + 1) + (long)c * lda] = regs[i][1];
+        }
+    }
+    // packed image of the 36 lower 16x16 blocks in MFMA A-operand order ([k][j]) for trsm_rows_kernel
+    {
+        double2_t regs[18];
+#pragma unroll
+        for (int bp = 0; bp < 18; ++bp) {
+            const int blk = 2 * bp + (t >> 7), w = t & 127, col = w >> 3, pr = w & 7;
+            const int c = (int)((sqrtf(8.0f * blk + 1.0f) - 1.0f) * 0.5f);
+            const int tb = blk - c * (c + 1) / 2;
+            regs[bp] = *(const double2_t*)(s + (16 * tb + col) * LS + 16 * c + 2 * pr);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) inv16[blk * 256 + c * 16 + r] = x[r];   // column-major 16x16
+        for (int bp = 0; bp < 18; ++bp) {
+            const int blk = 2 * bp + (t >> 7), w = t & 127, col = w >> 3, pr = w & 7;
+            *(double2_t*)(pack + blk * 256 + col * 16 + 2 * pr) = regs[bp];
+        }
     }
-    if (t == 0 && s_info != 0) atomicCAS(info, 0, info_base + s_info);
+    if (t == 0 && *s_info != 0) atomicCAS(info, 0, info_base + *s_info);
+    TICK(19);
+#undef TICK
 }
 
 // X (nrows x 128, column-major, ld) <- X * L^-T, L = 128x128 lower at Ld (ld), inv16 = 8 inverted
-// pivot blocks (column-major 16x16 each).  One wave per 16 rows.
+// pivot blocks (column-major 16x16 each).  One wave per 16 rows.  The 36 lower 16x16 blocks of L and the
+// 8 inverted pivot blocks are staged ONCE per workgroup into LDS in MFMA A-operand order
+// ([k][j], 16 contiguous doubles per k: a wave's fragment read is one contiguous 512-byte run,
+// bank-conflict free), so the solve itself never waits on global memory.
+__device__ __forceinline__ int tri_blk(int c, int t) { return c * (c + 1) / 2 + t; }   // c >= t
+
 __global__ __launch_bounds__(256, 2) void trsm_rows_kernel(double* __restrict__ X, long ldx, long nrows,
                                                            const double* __restrict__ Ld, long ldl,
-                                                           const double* __restrict__ inv16) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                           const double* __restrict__ inv16 /* packed image */) {
+    extern __shared__ __attribute__((aligned(16))) double sl[];   // 36 L blocks (strict lower + diag unused) + 8 inv blocks
+    double* si = sl + 36 * 256;
+    const int t = threadIdx.x;
+    // stage the packed operand image (44 x 256 doubles, written by leaf_potrf_kernel): 22 coalesced
+    // 16-byte loads per thread, all in flight together
+    {
+        double2_t regs[22];
+#pragma unroll
+        for (int i = 0; i < 22; ++i) regs[i] = *(const double2_t*)(inv16 + 2 * (t + 256 * i));
+#pragma unroll
+        for (int i = 0; i < 22; ++i) *(double2_t*)(sl + 2 * (t + 256 * i)) = regs[i];
+    }
+    const int lane = t & 63, wave = t >> 6;
     const long r0 = ((long)blockIdx.x * 4 + wave) * 16;
-    if (r0 >= nrows) return;
+    const bool active = r0 < nrows;
     const int l15 = lane & 15, l4 = lane >> 4;
     // acc[c][q] = X[r0 + l15][16c + l4 + 4q]
     double4_t acc[8];
+    if (active) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[c][q] = X[r0 + l15 + (long)(16 * c + l4 + 4 * q) * ldx];
+            for (int q = 0; q < 4; ++q) acc[c][q] = X[r0 + l15 + (long)(16 * c + l4 + 4 * q) * ldx];
+    }
+    __syncthreads();
+    if (!active) return;
+    const int fo = l4 * 16 + l15;                 // fragment offset inside a block for kstep 0
 #pragma unroll
     for (int tb = 0; tb < 8; ++tb) {
-        // Y^T = inv16_tb * X_tb^T          (A operand: inv16[j = l15][k = 4ks + l4])
-        double4_t y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const double fa = inv16[tb * 256 + (4 * ks + l4) * 16 + l15];
-            y = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, acc[tb][ks], y, 0, 0, 0);
-        }
+        // Y^T = inv16_tb * X_tb^T          (A operand: inv16[j = l15][k = 4ks + l4]); two partial chains
+        double4_t y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(si[tb * 256 + fo], acc[tb][0], y0, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(si[tb * 256 + 64 + fo], acc[tb][1], y1, 0, 0, 0);
+        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(si[tb * 256 + 128 + fo], acc[tb][2], y0, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(si[tb * 256 + 192 + fo], acc[tb][3], y1, 0, 0, 0);
+        const double4_t y = y0 + y1;
         acc[tb] = y;
         // X_c^T -= L(c,tb) * Y^T  for c > tb   (A operand: L[16c + l15][16tb + 4ks + l4])
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int c = tb + 1; c < 8; ++c) {
-                const double fa = -Ld[(long)(16 * c + l15) + (long)(16 * tb + 4 * ks + l4) * ldl];
+                const double fa = -sl[tri_blk(c, tb) * 256 + ks * 64 + fo];
                 acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, y[ks], acc[c], 0, 0, 0);
             }
     }
@@ -212,14 +371,15 @@ __global__ __launch_bounds__(128, 1) void leaf_inv_kernel(const double* __restri
 
 }  // namespace
 
-int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st) {
-    const size_t shm = (NB * LS + NB + 2) * sizeof(double);
+int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st,
+                      long long* tick) {
+    const size_t shm = (NB * LS + 256 + 2) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)leaf_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set = true;
     }
-    hipLaunchKernelGGL(leaf_potrf_kernel, dim3(1), dim3(256), shm, st, A, lda, inv16, info, info_base);
+    hipLaunchKernelGGL(leaf_potrf_kernel, dim3(1), dim3(256), shm, st, A, lda, inv16, info, info_base, tick);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
@@ -227,7 +387,13 @@ int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl
                      hipStream_t st) {
     if (nrows <= 0) return PGP_OK;
     const unsigned nblk = (unsigned)((nrows + 63) / 64);
-    hipLaunchKernelGGL(trsm_rows_kernel, dim3(nblk), dim3(256), 0, st, X, ldx, nrows, Ld, ldl, inv16);
+    const size_t shm = 44 * 256 * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)trsm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(trsm_rows_kernel, dim3(nblk), dim3(256), shm, st, X, ldx, nrows, Ld, ldl, inv16);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 

@@ -102,6 +102,30 @@ int pgp_test_mfma_peak(pgp_ctx* ctx, int iters, double* tflops_out) {
     return PGP_OK;
 }
 
+// phase time-stamps (s_memtime) of one leaf_potrf_kernel launch on an SPD 128x128 block: ticks_out[24]
+int pgp_test_leaf_ticks(pgp_ctx* c, double* ticks_out) {
+    if (!c || !ticks_out) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<double> A(128 * 128, 0.0);
+    for (int i = 0; i < 128; ++i)
+        for (int j = 0; j < 128; ++j) A[i + j * 128] = (i == j ? 3.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
+    double *Ad, *pk; int* info; long long* tk;
+    HIP_TRY(hipMalloc((void**)&Ad, A.size() * 8)); HIP_TRY(hipMalloc((void**)&pk, PACK_DOUBLES * 8));
+    HIP_TRY(hipMalloc((void**)&info, 4)); HIP_TRY(hipMalloc((void**)&tk, 24 * 8));
+    HIP_TRY(hipMemset(info, 0, 4)); HIP_TRY(hipMemset(tk, 0, 24 * 8));
+    for (int rep = 0; rep < 3; ++rep) {
+        HIP_TRY(hipMemcpy(Ad, A.data(), A.size() * 8, hipMemcpyHostToDevice));
+        int rc = leaf_potrf_launch(Ad, 128, pk, info, 0, c->st, tk);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->st));
+    }
+    long long h[24];
+    HIP_TRY(hipMemcpy(h, tk, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 24; ++i) ticks_out[i] = (double)h[i];
+    (void)hipFree(Ad); (void)hipFree(pk); (void)hipFree(info); (void)hipFree(tk);
+    return PGP_OK;
+}
+
 int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_diag, int kmode, int koff,
                   double alpha, double beta, const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
                   int64_t ldc, int M, int N, int K, int iters, double* ms_out) {
@@ -117,7 +141,7 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
     GemmArgs g{};
     g.A = Ad; g.lda = lda; g.a_kc = a_kc; g.B = Bd; g.ldb = ldb; g.b_kc = b_kc; g.C = Cd; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.tri = tri; g.tri_off = 0; g.mask_diag = mask_diag;
-    g.kmode = kmode; g.koff = koff; g.batch = 1; g.tile = tile;
+    g.kmode = kmode; g.koff = koff; g.batch = 1; g.tile = tile; g.dbg = c->gemm_dbg;
     int rc = gemm_f64_launch(g, c->st);
     HIP_TRY(hipStreamSynchronize(c->st));
     if (rc == PGP_OK) HIP_TRY(hipMemcpy(C, Cd, cn * 8, hipMemcpyDeviceToHost));

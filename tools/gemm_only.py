@@ -1,0 +1,22 @@
+"""A few launches of the fp64 MFMA GEMM at the Cholesky trailing-update shape, for rocprofv3 counter passes."""
+import ctypes as C
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from pygps_amd import _lib
+
+lib = _lib.load()
+ctx = _lib.ctx()
+M = N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+tri = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+rng = np.random.RandomState(0)
+A = np.asfortranarray(rng.randn(M, K))
+B = np.asfortranarray(rng.randn(N, K))
+Cm = np.asfortranarray(rng.randn(M, N))
+ms = C.c_double()
+rc = lib.pgp_test_gemm(ctx, 128, 0, 0, tri, 1 if tri else 0, 0, 0, -1.0, 1.0, _lib.ptr(A), M, _lib.ptr(B), N, _lib.ptr(Cm),
+                       M, M, N, K, 3, C.byref(ms))
+print("rc", rc, "ms", ms.value, "TF", 2.0 * M * N * K * (0.5 if tri else 1) / ms.value / 1e9)

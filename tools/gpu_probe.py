@@ -81,6 +81,38 @@ if __name__ == "__main__":
         gemm(8192, 384, 128, tile=64)
         gemm(8192, 384, 128, tile=128)
         gemm(4096, 4096, 4096)
+    if "leaf" in what:
+        tk = np.zeros(24)
+        assert lib.pgp_test_leaf_ticks(ctx, _lib.ptr(tk)) == 0
+        names = ["start", "loaded", "pivot0"] + ["b%d" % (i // 2) if i % 2 == 0 else "c%d" % (i // 2) for i in range(16)]
+        base = tk[0]
+        seq = [(names[i], tk[i]) for i in range(19)] + [("writeback", tk[20]), ("end", tk[19])]
+        prev = base
+        for nm, v in seq:
+            print("  %-10s +%7.0f cycles (%6.2f us)  total %8.0f" % (nm, v - prev, (v - prev) / 2400.0, v - base))
+            prev = v
+    if "dbg" in what:
+        for v in (0, 1, 2, 3, 4, 5, 7, 0):
+            lib.pgp_set_option(ctx, b"gemm_dbg", v)
+            print("gemm_dbg =", v)
+            gemm(8192, 8192, 512)
+            gemm(8192, 8192, 2048, a_kc=1, b_kc=1)
+        lib.pgp_set_option(ctx, b"gemm_dbg", 0)
+    if "sweep" in what:
+        for la in (1, 0):
+            for q in (2, 3, 4, 6, 8):
+                for stb in (128, 256, 512):
+                    lib.pgp_set_option(ctx, b"lookahead", la); lib.pgp_set_option(ctx, b"nb_outer", q)
+                    lib.pgp_set_option(ctx, b"small_tile_below", stb)
+                    print("lookahead", la, "nb_outer", q, "small_tile_below", stb)
+                    fit(8192, 16, reps=2, prof=False)
+        lib.pgp_set_option(ctx, b"lookahead", 1); lib.pgp_set_option(ctx, b"nb_outer", 4)
+        lib.pgp_set_option(ctx, b"small_tile_below", 256)
+    if "ab" in what:
+        for v in (0, 1, 0, 1):
+            lib.pgp_set_option(ctx, b"lookahead", v)
+            print("lookahead =", v)
+            fit(8192, 16, reps=3, prof=False)
     if "fit" in what:
         fit(8192, 16)
         fit(8192, 16, want=2, prof=False)
