@@ -181,8 +181,11 @@ def test_G9_restarts_sequential_and_sharded_single_rank(lib):
             runs = m.optimizer.runs
             assert len(runs) == int(g["n_runs"])
             f = np.array([r.f for r in runs])
-            assert int(np.argmin(f)) == int(np.argmin(g["run_f"]))              # the same restart wins
             assert relerr(f, g["run_f"]) < 1e-4
+            # several restarts reach the same optimum to ~1e-7 relative, so "which one wins" is decided in the last
+            # digits; what must agree is the SET of restarts that reach the optimum, and the winner must be in it
+            near = lambda v: set(np.flatnonzero(v < v.min() + 1e-3 * abs(v.min())).tolist())
+            assert near(f) == near(g["run_f"]) and int(np.argmin(f)) in near(g["run_f"])
 
 
 def test_exact_rejects_non_gaussian_and_unknown_kernel(lib):

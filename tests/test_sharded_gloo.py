@@ -1,0 +1,67 @@
+"""CPU, 2 processes over gloo: the restart sharding of ShardedMinimize (broadcast of the init table and data,
+per-rank share, all-gather, selection rule) must give every rank exactly what the sequential Minimize gives.
+The objective here is a numpy stand-in (tests/test_host_logic._FakeModel); the collective code path is the
+one that runs over RCCL (backend nccl) on the GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, R, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_host_logic import _FakeModel, _conf
+        from pygps_amd import opt
+        m = _FakeModel()
+        if rank != 0:                       # only rank 0 holds the real data / RNG state; the others get it by broadcast
+            m.x = np.full_like(m.x, -7.0)
+            m.y = np.full_like(m.y, -7.0)
+            np.random.seed(999)
+        else:
+            m.x = np.arange(4.0).reshape(4, 1)
+            m.y = np.arange(4.0).reshape(4, 1) * 2
+            np.random.seed(7)
+        o = opt.ShardedMinimize(m, _conf(m, R))
+        h, f = o.findMin(m.x, m.y, numIters=15)
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), h=h, f=f, x=m.x, y=m.y, calls=m.calls,
+                 runs_f=np.array([r.f for r in o.runs]), runs_nls=np.array([r.nls for r in o.runs]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R", [6, 5])
+def test_sharded_minimize_two_ranks_equals_sequential(tmp_path, R):
+    from test_host_logic import _FakeModel, _conf
+    from pygps_amd import opt
+    m = _FakeModel()
+    o = opt.Minimize(m, _conf(m, R))
+    np.random.seed(7)
+    h_seq, f_seq = o.findMin(m.x, m.y, numIters=15)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, R, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "r0.npz")
+    r1 = np.load(tmp_path / "r1.npz")
+    for r in (r0, r1):
+        assert float(r["f"]) == f_seq and np.array_equal(r["h"], h_seq)          # same optimum on every rank
+        assert np.array_equal(r["x"], np.arange(4.0).reshape(4, 1))               # data arrived by broadcast
+        assert np.array_equal(r["runs_f"], r0["runs_f"]) and len(r["runs_f"]) == R
+    # the work really was shared: each rank evaluated only its restarts
+    assert int(r0["calls"]) + int(r1["calls"]) == m.calls
+    assert 0 < int(r1["calls"]) < m.calls

@@ -1,0 +1,38 @@
+"""Turn rocprofv3 --pmc counter CSVs (FETCH_SIZE / WRITE_SIZE passes over bench.py) into
+profiles/gemm_f64_hbm_traffic.json, the per-launch HBM traffic bench.py reports as roofline.traffic.
+
+Units/corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are in KiB
+(x1024); on gfx950 FETCH_SIZE reads exactly half the bytes of a wide coalesced streaming read (16 B/lane loads,
+which is what gemm_f64 issues) -> x2; WRITE_SIZE is taken as is."""
+import csv
+import glob
+import json
+import sys
+
+
+def load(pattern, counter, match):
+    tot, n = 0.0, 0
+    for f in glob.glob(pattern, recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == counter and match in row.get("Kernel_Name", ""):
+                tot += float(row["Counter_Value"])
+                n += 1
+    return tot, n
+
+
+if __name__ == "__main__":
+    root = sys.argv[1]
+    out = sys.argv[2]
+    f, nf = load(root + "/fetch/**/*counter_collection.csv", "FETCH_SIZE", "gemm_f64_kernel")
+    w, nw = load(root + "/write/**/*counter_collection.csv", "WRITE_SIZE", "gemm_f64_kernel")
+    assert nf and nw, (nf, nw)
+    fetch_b = f * 1024.0 * 2.0 / nf
+    write_b = w * 1024.0 / nw
+    json.dump({"kernel": "gemm_f64_kernel", "launches_sampled": nf,
+               "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
+               "bytes_per_launch": fetch_b + write_b,
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python bench.py --steps 3 "
+                       "--warmup 1 --no-cpu-baseline`, all gemm_f64_kernel dispatches averaged; FETCH_SIZE x2 "
+                       "(gfx950 wide-load correction, MI355X_MICROARCH.md HBM section), KiB -> bytes"},
+              open(out, "w"), indent=1)
+    print(open(out).read())
