@@ -136,11 +136,12 @@ int scale_transpose_launch(const double* x, long n, int d, const double* scale_d
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
-int cov_sym_launch(const double* XT, long ldp, long n, int dpad, const CovParams& cp, double* out, hipStream_t st) {
+int cov_sym_launch(const double* XT, long ldp, long n, int dpad, const CovParams& cp, double* out, hipStream_t st,
+                   long ldo) {
     const long nt = (n + ST - 1) / ST;
     const long nblk = nt * (nt + 1) / 2;
     hipLaunchKernelGGL((cov_tile_kernel<MODE_SYM>), dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, XT, ldp, n,
-                       dpad, cp, 0.0, out, n, nt);
+                       dpad, cp, 0.0, out, ldo > 0 ? ldo : n, nt);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 

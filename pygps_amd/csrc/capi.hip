@@ -163,7 +163,7 @@ CovParams make_cp(int kind, const double* hyp, int nhyp, int para, int flags, in
 }
 
 // upload host x (n,d) scaled+transposed into a fresh device buffer XsT (dpad x ldp)
-static int upload_scaled(pgp_ctx* c, const double* x_dev, long n, long d, const std::vector<double>& sc, double* XsT,
+int upload_scaled(pgp_ctx* c, const double* x_dev, long n, long d, const std::vector<double>& sc, double* XsT,
                          long ldp, int dpad, double* scale_dev) {
     HIP_TRY(hipMemcpyAsync(scale_dev, sc.data(), d * sizeof(double), hipMemcpyHostToDevice, c->st));
     return scale_transpose_launch(x_dev, n, (int)d, scale_dev, XsT, ldp, dpad, c->st);
@@ -327,7 +327,7 @@ static void tri_nodes(int lo, int hi, int depth, std::vector<TriNode>& out) {
     tri_nodes(mid, hi, depth + 1, out);
 }
 
-static int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ldw, double* T, long np) {
+int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ldw, double* T, long np) {
     const int nblk = (int)(np / 128);
     {
         ProfScope ps(c, PC_LEAFINV, (double)nblk * 128.0 * 128.0 * 128.0 / 3.0, 0.0);
@@ -384,7 +384,7 @@ static int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ld
 }
 
 // Binv (lower) = W^T W
-static int lauum_lower(pgp_ctx* c, const double* W, long ldw, double* Binv, long ldb, long np) {
+int lauum_lower(pgp_ctx* c, const double* W, long ldw, double* Binv, long ldb, long np) {
     GemmArgs g{};
     g.A = W; g.lda = ldw; g.a_kc = 1;
     g.B = W; g.ldb = ldw; g.b_kc = 1;
@@ -397,7 +397,7 @@ static int lauum_lower(pgp_ctx* c, const double* W, long ldw, double* Binv, long
     return gemm_prof(c, PC_GEMM_LAUUM, g);
 }
 
-static int ensure_workspace(pgp_ctx* c, long np) {
+int ensure_workspace(pgp_ctx* c, long np) {
     if (c->ws_np == np) return PGP_OK;
     (void)hipStreamSynchronize(c->st);
     void* olds[] = {c->W, c->T, c->Binv, c->inv16, c->alpha_dev, c->m_dev, c->rvec, c->zvec};
@@ -420,7 +420,7 @@ static int ensure_workspace(pgp_ctx* c, long np) {
     return PGP_OK;
 }
 
-static int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F) {
+int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F) {
     const size_t bytes = (size_t)ldf * np * sizeof(double);
     auto it = c->pool.find(bytes);
     if (it != c->pool.end()) { *F = (double*)it->second; c->pool.erase(it); return PGP_OK; }

@@ -114,3 +114,11 @@ int fill_scale(int kind, const double* hyp, int nhyp, int para, long d, std::vec
 CovParams make_cp(int kind, const double* hyp, int nhyp, int para, int flags, int der, long d);
 int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows);
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);
+int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ldw, double* T, long np);
+int lauum_lower(pgp_ctx* c, const double* W, long ldw, double* Binv, long ldb, long np);
+int upload_scaled(pgp_ctx* c, const double* x_dev, long n, long d, const std::vector<double>& sc, double* XsT, long ldp,
+                  int dpad, double* scale_dev);
+int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F);
+int ensure_workspace(pgp_ctx* c, long np);
+int solve_lower_multi(pgp_ctx* c, const double* L, long ldl, const double* Wd, double* Y, long ldy, long np, int nrhs,
+                      bool trans);

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
                                                               CovParams cp, int ncov, double inv_sn2, double sn2,
                                                               const double* __restrict__ Binv, long ldb,
                                                               const double* __restrict__ alpha,
+                                                              const double* __restrict__ wv,
                                                               double* __restrict__ partial, long nt) {
     __shared__ __attribute__((aligned(16))) double sm[2 * SKC * ST];
     __shared__ double red[4];
@@ -51,16 +52,18 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     double w[4][4];                 // weight * Q_rc * K_rc   (ARD) -- or per-hyper accumulators below
     double g0 = 0.0, g1 = 0.0, tq = 0.0;
-    double ar[4], ac[4];
+    double ar[4], ac[4], wr[4], wc[4];        // Q_rc = Binv_rc * w_r w_c - alpha_r alpha_c  (Exact: w = 1/sn)
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const long rr = r0 + 4 * tr + a;
         ar[a] = rr < n ? alpha[rr] : 0.0;
+        wr[a] = wv ? (rr < n ? wv[rr] : 0.0) : inv_sn2;
     }
 #pragma unroll
     for (int bq = 0; bq < 4; ++bq) {
         const long cc = c0 + 2 * tc + (bq & 1) + 32 * (bq >> 1);
         ac[bq] = cc < n ? alpha[cc] : 0.0;
+        wc[bq] = wv ? (cc < n ? wv[cc] : 0.0) : 1.0;
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
                 const long cc = cb + e;
                 double wt = (cc > rr) ? 2.0 : (cc == rr ? 1.0 : 0.0);     // symmetric: count the mirror
                 if (rr >= n || cc >= n) wt = 0.0;                          // padding
-                const double q = bv[e] * inv_sn2 - ar[a] * ac[bq];
+                const double q = bv[e] * (wr[a] * wc[bq]) - ar[a] * ac[bq];
                 const double wq = (wt != 0.0) ? wt * q : 0.0;             // never let unused entries in
                 if (cc == rr && rr < n) tq += sn2 * q;
                 if (cp.kind == 1) {
@@ -276,11 +279,11 @@ int row_scale_launch(double* A, long lda, long nrows, long ncols, const double* 
 
 int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovParams& cp, int ncov,
                            double sn2, const double* Binv, long ldb, const double* alpha, double* partial,
-                           double* out_dev, hipStream_t st) {
+                           double* out_dev, hipStream_t st, const double* wv) {
     const long nt = np / ST;
     const long nblk = nt * (nt + 1) / 2;
     hipLaunchKernelGGL(hadamard_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, cp, ncov,
-                       1.0 / sn2, sn2, Binv, ldb, alpha, partial, nt);
+                       1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
     hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)(ncov + 1)), dim3(256), 0, st, partial, nblk, ncov + 1,
                        out_dev);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;

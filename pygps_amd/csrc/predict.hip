@@ -13,7 +13,7 @@
 #include "ctx.h"
 
 // Y (np x nrhs, column-major, ldy; nrhs multiple of 128: the in-place diagonal solve needs ONE row tile) is overwritten by the solution.
-static int solve_lower_multi(pgp_ctx* c, const double* L, long ldl, const double* Wd /*128 x np, ld 128*/, double* Y,
+int solve_lower_multi(pgp_ctx* c, const double* L, long ldl, const double* Wd /*128 x np, ld 128*/, double* Y,
                              long ldy, long np, int nrhs, bool trans) {
     const int nb = (int)(np / 128);
     const int tile = (nrhs % 128 == 0 && (long)nrhs / 128 * (np / 128) >= c->small_tile_below) ? 128 : 64;

@@ -197,3 +197,34 @@ def test_exact_rejects_non_gaussian_and_unknown_kernel(lib):
     with pytest.raises(NotImplementedError):
         s = pyGPs.cov.RBF() + pyGPs.cov.RBF()
         pyGPs.inf.Exact().evaluate(pyGPs.mean.Zero(), s, pyGPs.lik.Gauss(), x, y, 2)
+
+
+def test_G8_ep_classification_demo_and_synthetic(lib):
+    """cfg 5: EP.evaluate with the probit likelihood on the device vs golden vectors of the reference."""
+    import pygps_amd as pyGPs
+    from conftest import synth_cls
+    g = golden("G8i_classification_demo_ep")
+    m = pyGPs.GPC()
+    nlZ, dnlZ, post = m.getPosterior(g["x"], g["y"])
+    n = g["x"].shape[0]
+    assert type(nlZ) is np.float64 and post.L.shape == (n, n) and post.sW.shape == (n, 1)
+    assert relerr(nlZ, g["nlZ"]) < 1e-8
+    assert relerr(post.alpha, g["alpha"]) < 1e-6 and relerr(post.sW, g["sW"]) < 1e-6
+    assert relerr(np.asarray(post.L), g["L"]) < 1e-6 and np.all(np.tril(post.L, -1) == 0)
+    assert relerr(dnlZ.cov, g["dnlZ_cov"]) < 1e-6 and dnlZ.lik == [] and dnlZ.mean == []
+    assert relerr(m.inffunc.last_ttau, g["ttau"]) < 1e-6 and relerr(m.inffunc.last_tnu, g["tnu"]) < 1e-6
+    ym, ys2, fm, fs2, lp = m.predict(g["xstar5"])
+    assert relerr(ym, g["pred_ym"]) < 1e-6 and relerr(fs2, g["pred_fs2"]) < 1e-6 and relerr(ys2, g["pred_ys2"]) < 1e-6
+    # warm start (SURVEY Q10): a second call on the same EP object starts from last_ttau/last_tnu
+    nlZ2, _, _ = m.getPosterior(g["x"], g["y"])
+    assert abs(nlZ2 - nlZ) < 1e-3 * abs(nlZ)
+    for N in (128, 512):
+        g = golden("G8ii_ep_d32_N%d" % N)
+        x, y = synth_cls(N, 32)
+        m = pyGPs.GPC()
+        m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(32.0)), 0.0))
+        nlZ, dnlZ, post = m.getPosterior(x, y)
+        assert relerr(nlZ, g["nlZ"]) < 1e-8, N
+        assert relerr(dnlZ.cov, g["dnlZ_cov"]) < 1e-6
+        assert relerr(post.alpha, g["alpha"]) < 1e-6 and relerr(post.sW, g["sW"]) < 1e-6
+        assert relerr(np.diag(post.L), g["L_diag"]) < 1e-7

@@ -117,5 +117,17 @@ if __name__ == "__main__":
         fit(8192, 16)
         fit(8192, 16, want=2, prof=False)
         fit(2048, 16, prof=False)
+    if "ep" in what:
+        import pygps_amd as pyGPs
+        for N in (1024, 4096):
+            rng = np.random.RandomState(0)
+            d = 32
+            x = rng.randn(N, d); w = rng.randn(d, 1)
+            y = np.sign(x @ w / np.sqrt(d) + 0.3 * rng.randn(N, 1)); y[y == 0] = 1
+            m = pyGPs.GPC()
+            m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+            t = time.time()
+            nlZ, dnlZ, post = m.getPosterior(x, y)
+            print("EP N=%d d=%d: %.3f s, %d sweeps, nlZ=%.10g dnlZ.cov=%s" % (N, d, time.time() - t, m.inffunc.sweeps, nlZ, dnlZ.cov))
     if "fit16k" in what:
         fit(16384, 64, kind=1, reps=1)
