@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict_
                                                        const double* __restrict__ XcT, long ldc, long m, int dpad,
                                                        CovParams cp, double inv_sn2, double* __restrict__ out,
                                                        long ldo, long ntile_c) {
-    __shared__ __attribute__((aligned(16))) double sm[2 * SKC * ST];
+    constexpr int TS = ST + 2;                      // transpose-tile row stride (16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) double sm[MODE == MODE_SYM ? ST * TS : 2 * SKC * ST];
     long ti, tj;
     if (MODE == MODE_RECT) {
         ti = blockIdx.x / ntile_c;
@@ -108,15 +109,29 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict_
             }
         }
     }
-    if (MODE == MODE_SYM && ti != tj) {             // mirrored store: out[c][r], 4 consecutive r per thread
+    if (MODE == MODE_SYM && ti != tj) {
+        // mirrored store out[c][r]: transpose the tile through LDS so that the global stores are 512-byte
+        // contiguous runs (32 lanes x 16 B) instead of 32-byte pieces with a row stride between lanes
+        __syncthreads();                            // sm is free again (sqdist_tile ends with a barrier)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const long c = c0 + 2 * tc + (b & 1) + 32 * (b >> 1);
-            if (c < m) {
-                const long r = r0 + 4 * tr;
+            const int cl = 2 * tc + (b & 1) + 32 * (b >> 1);
+            *(double2_t*)(sm + cl * TS + 4 * tr) = double2_t{v[0][b], v[1][b]};
+            *(double2_t*)(sm + cl * TS + 4 * tr + 2) = double2_t{v[2][b], v[3][b]};
+        }
+        __syncthreads();
+        const int pr = t & 31, rw = t >> 5;         // 8 tile rows per pass, 32 double2 per row
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    if (r + a < n) out[c * ldo + r + a] = v[a][b];
+        for (int p = 0; p < 8; ++p) {
+            const int cl = p * 8 + rw;
+            const long c = c0 + cl, r = r0 + 2 * pr;
+            if (c < m) {
+                const double2_t val = *(const double2_t*)(sm + cl * TS + 2 * pr);
+                if (r + 1 < n && ((ldo & 1) == 0)) *(double2_t*)(out + c * ldo + r) = val;
+                else {
+                    if (r < n) out[c * ldo + r] = val[0];
+                    if (r + 1 < n) out[c * ldo + r + 1] = val[1];
+                }
             }
         }
     }

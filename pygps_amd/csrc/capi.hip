@@ -93,9 +93,24 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!c || !name) return -1;
     if (!strcmp(name, "nb_outer")) { if (value < 1) return -3; c->nb_outer = value; return PGP_OK; }
     if (!strcmp(name, "small_tile_below")) { c->small_tile_below = value; return PGP_OK; }
+    if (!strcmp(name, "trtri_small_tile_below")) { c->trtri_small_tile_below = value; return PGP_OK; }
     if (!strcmp(name, "xcd_order")) { c->xcd_order = value; return PGP_OK; }
     if (!strcmp(name, "gemm_dbg")) { c->gemm_dbg = value; return PGP_OK; }
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
+    if (!strcmp(name, "cu_reserve")) {
+        if (c->st_masked) { (void)hipStreamSynchronize(c->st_masked); (void)hipStreamDestroy(c->st_masked); c->st_masked = nullptr; }
+        c->cu_reserve = value;
+        if (value > 1) {
+            const int ncu = c->prop.multiProcessorCount;
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            for (int i = 0; i < ncu; ++i)
+                if (i % value != value - 1) mask[i / 32] |= (1u << (i % 32));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&c->st_masked, (uint32_t)mask.size(), mask.data()));
+            if (!c->ev_fork) { HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                               HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
+        }
+        return PGP_OK;
+    }
     return -2;
 }
 
@@ -294,6 +309,11 @@ int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows) {
         c->la_ev.push_back(e);
     }
     hipStream_t main = c->st, pan = c->st2;
+    if (c->st_masked) {                       // run the trailing updates on a CU subset, leave the rest to the panel stream
+        HIP_TRY(hipEventRecord(c->ev_fork, c->st));
+        HIP_TRY(hipStreamWaitEvent(c->st_masked, c->ev_fork, 0));
+        main = c->st_masked;
+    }
     // panel 0 on the main stream
     CHK(factor_panel(c, F, ld, mrows, 0, std::min(q, nblk), main));
     for (int p = 0; p < npanel; ++p) {
@@ -309,6 +329,10 @@ int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows) {
         // TU_b(p): the rest of the trailing matrix, concurrently with the panel factorisation
         CHK(trailing_update(c, F, ld, mrows, s0, s1, n1, nblk, main));
         HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));    // next TU_a needs the factored panel
+    }
+    if (main != c->st) {
+        HIP_TRY(hipEventRecord(c->ev_join, main));
+        HIP_TRY(hipStreamWaitEvent(c->st, c->ev_join, 0));
     }
     return PGP_OK;
 }
@@ -364,7 +388,7 @@ int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ldw, doub
             g.M = a2; g.N = a1; g.K = a1; g.alpha = 1.0; g.beta = 0.0;
             g.kmode = KM_GE_J; g.koff = 0;
             g.batch = batch; g.sA = bstep * (1 + ldl); g.sB = bstep * (1 + ldw); g.sC = (long)a1 * a2;
-            g.tile = t128 < c->small_tile_below ? 64 : 128;
+            g.tile = t128 < c->trtri_small_tile_below ? 64 : 128;
             g.flops = (double)batch * (double)a2 * a1 * a1;
             CHK(gemm_prof(c, PC_GEMM_TRTRI, g));
             // W21 = -W22 * T                     k < i0 + TM (W22 lower triangular)

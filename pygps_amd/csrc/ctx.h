@@ -36,6 +36,9 @@ struct pgp_ctx {
     hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
+    hipStream_t st_masked = nullptr;    // main stream of the look-ahead Cholesky restricted to a CU subset (option cu_reserve)
+    int cu_reserve = 0;                 // reserve every cu_reserve-th CU for the panel stream (0 = off)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     // pooled device buffers, keyed by byte size
     std::multimap<size_t, void*> pool;
@@ -63,6 +66,7 @@ struct pgp_ctx {
     int xcd_order = 0;    // 1: XCD-aware super-tile order (measured slower on MI355X for these shapes: off)
     // options
     int nb_outer = 4;     // leaves (128 columns each) per outer panel -> trailing update K = 512
+    int trtri_small_tile_below = 2049;   // measured: 64x64 tiles win on every recursion level at N=8192 (more, shorter tiles)
     int small_tile_below = 256;   // use 64x64 tiles when a GEMM has fewer 128-tiles than this
 };
 

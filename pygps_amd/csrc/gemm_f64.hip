@@ -97,37 +97,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
     // ---- staging helpers ----------------------------------------------------------------
     double2_t ra[AV], rb[BV];
-    auto gload = [&](int kt) {
-        if (!AKC) {
-            constexpr int VPR = TM / 2;              // double2 per k-row
-            constexpr int RPP = 256 / VPR;           // k-rows per pass
+    // per-thread source pointers of the staging loads, bumped by one k-tile per iteration (no 64-bit address
+    // arithmetic inside the k-loop: those VALU ops would sit un-overlapped at the loop head)
+    const double* pa[AV];
+    const double* pb[BV];
+    long astep, bstep;
+    if (!AKC) {
+        constexpr int VPR = TM / 2, RPP = 256 / VPR;
 #pragma unroll
-            for (int p = 0; p < AV; ++p) {
-                const int mv = t % VPR, kr = t / VPR + p * RPP;
-                ra[p] = *(const double2_t*)(A + (long)(i0 + 2 * mv) + (long)(kt + kr) * g.lda);
-            }
-        } else {
+        for (int p = 0; p < AV; ++p) pa[p] = A + (long)(i0 + 2 * (t % VPR)) + (long)(k0 + t / VPR + p * RPP) * g.lda;
+        astep = (long)BK * g.lda;
+    } else {
 #pragma unroll
-            for (int p = 0; p < AV; ++p) {
-                const int kp = t & 7, m = (t >> 3) + p * 32;
-                ra[p] = *(const double2_t*)(A + (long)(kt + 2 * kp) + (long)(i0 + m) * g.lda);
-            }
-        }
-        if (!BKC) {
-            constexpr int VPR = TN / 2;
-            constexpr int RPP = 256 / VPR;
+        for (int p = 0; p < AV; ++p) pa[p] = A + (long)(k0 + 2 * (t & 7)) + (long)(i0 + (t >> 3) + p * 32) * g.lda;
+        astep = BK;
+    }
+    if (!BKC) {
+        constexpr int VPR = TN / 2, RPP = 256 / VPR;
 #pragma unroll
-            for (int p = 0; p < BV; ++p) {
-                const int nv = t % VPR, kr = t / VPR + p * RPP;
-                rb[p] = *(const double2_t*)(B + (long)(j0 + 2 * nv) + (long)(kt + kr) * g.ldb);
-            }
-        } else {
+        for (int p = 0; p < BV; ++p) pb[p] = B + (long)(j0 + 2 * (t % VPR)) + (long)(k0 + t / VPR + p * RPP) * g.ldb;
+        bstep = (long)BK * g.ldb;
+    } else {
 #pragma unroll
-            for (int p = 0; p < BV; ++p) {
-                const int kp = t & 7, n = (t >> 3) + p * 32;
-                rb[p] = *(const double2_t*)(B + (long)(kt + 2 * kp) + (long)(j0 + n) * g.ldb);
-            }
-        }
+        for (int p = 0; p < BV; ++p) pb[p] = B + (long)(k0 + 2 * (t & 7)) + (long)(j0 + (t >> 3) + p * 32) * g.ldb;
+        bstep = BK;
+    }
+    auto gload = [&](int) {
+#pragma unroll
+        for (int p = 0; p < AV; ++p) { ra[p] = *(const double2_t*)pa[p]; pa[p] += astep; }
+#pragma unroll
+        for (int p = 0; p < BV; ++p) { rb[p] = *(const double2_t*)pb[p]; pb[p] += bstep; }
     };
     auto sstore = [&](int buf) {
         double* sa = smem + buf * STAGE;
@@ -174,25 +173,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             if (more && !(g.dbg & 1)) gload(kt + BK);
             const double* sa = smem + buf * STAGE;
             const double* sb = sa + ASZ;
-#pragma unroll
-            for (int ks = 0; ks < BK / 4; ++ks) {
+            // fragments are double-buffered in registers: the LDS reads of k-step ks+1 are issued BEFORE the 16
+            // MFMAs of k-step ks, so their latency hides behind 1024 cycles of matrix work instead of stalling
+            // the (in-order) wave once per k-step
+            double fa[2][FM], fb[2][FN];
+            auto ldfrag = [&](int ks, int slot) {
                 const int k = ks * 4 + l4;
-                double fa[FM], fb[FN];
 #pragma unroll
                 for (int im = 0; im < FM; ++im) {
                     const int m = wm + im * 16 + l15;
-                    fa[im] = AKC ? sa[m * SK + k] : sa[k * SA + m];
+                    fa[slot][im] = AKC ? sa[m * SK + k] : sa[k * SA + m];
                 }
 #pragma unroll
                 for (int in = 0; in < FN; ++in) {
                     const int n = wn + in * 16 + l15;
-                    fb[in] = BKC ? sb[n * SK + k] : sb[k * SB + n];
+                    fb[slot][in] = BKC ? sb[n * SK + k] : sb[k * SB + n];
                 }
+            };
+            ldfrag(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                if (ks + 1 < BK / 4) ldfrag(ks + 1, (ks + 1) & 1);
 #pragma unroll
                 for (int in = 0; in < FN; ++in)
 #pragma unroll
                     for (int im = 0; im < FM; ++im)
-                        acc[im][in] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[in], fa[im], acc[im][in], 0, 0, 0);
+                        acc[im][in] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ks & 1][in], fa[ks & 1][im], acc[im][in], 0, 0, 0);
             }
             if (more && !(g.dbg & 1)) sstore(buf ^ 1);
             if (!(g.dbg & 2)) __syncthreads();
@@ -221,16 +227,16 @@ int launch_t(const GemmArgs& g, hipStream_t st) {
     constexpr int SK = BK + 2;
     constexpr int ASZ = AKC ? T * SK : BK * (T + 16);
     constexpr int BSZ = BKC ? T * SK : BK * (T + 16);
-    const size_t shm = 2 * (ASZ + BSZ) * sizeof(double);
+    const size_t shm = 2 * (ASZ + BSZ) * sizeof(double) + ((g.dbg & 8) ? 20000 : 0);   // dbg 8: force 1 workgroup / CU
     const int mt = g.M / T, nt = g.N / T;
     unsigned nblk = (g.tri == 2) ? (unsigned)((long)mt * (mt + 1) / 2) : (unsigned)(mt * nt);
     if (g.order) nblk = (unsigned)g.norder;
     dim3 grid(nblk, 1, g.batch > 0 ? g.batch : 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static size_t attr_set = 0;
+    if (attr_set < shm) {
         (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set = true;
+        attr_set = shm;
     }
     hipLaunchKernelGGL((gemm_f64_kernel<T, T, AKC, BKC>), grid, dim3(256), shm, st, g);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;

@@ -5,7 +5,7 @@
 struct CovParams;
 
 // panel.hip
-constexpr long PACK_DOUBLES = 44 * 256;   // per-leaf packed operand image: 36 L blocks + 8 inverted pivot blocks
+constexpr long PACK_DOUBLES = 36 * 256;   // per-leaf packed operand image: 28 strictly-lower L blocks + 8 inverted pivot blocks
 int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st,
                       long long* tick = nullptr);
 int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl, const double* inv16,

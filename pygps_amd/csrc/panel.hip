@@ -25,7 +25,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int NB = 128;   // leaf size
-constexpr int LS = 144;   // LDS column stride (doubles): 2*LS = 32 mod 64 banks
+
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -126,22 +126,28 @@ struct InvRow<16> {
     static __device__ __forceinline__ void run(const double (&)[16], double, double (&)[16], double (&)[16], int) {}
 };
 
-// Wave 0: factor the 16x16 pivot block at offset o (each 16-lane row works on its own copy; lane & 15 = row),
-// write the factor back to LDS, and its inverse both to LDS (sinv, MFMA A-operand order [k][j]) and to the
-// packed global image.  Returns nothing; a non-positive pivot is recorded in *s_info.
-__device__ __forceinline__ void pivot_block(double* __restrict__ s, double* __restrict__ sinv, int* s_info, int o,
+// LDS storage of the leaf: the 36 lower 16x16 blocks, each stored [k][j] (column k, row j: k*16 + j) -- which is
+// exactly the MFMA A-operand order, so a fragment read is blockbase[kstep*64 + lane]: one contiguous 512-byte,
+// bank-conflict-free run.  Order: 28 strictly-lower blocks (bi > bj: bi(bi-1)/2 + bj), then the 8 diagonal blocks.
+// 74 KB: the leaf fits next to one resident gemm_f64 workgroup on a CU (look-ahead overlap).
+__device__ __forceinline__ int lblk(int bi, int bj) { return (bi == bj) ? 28 + bi : bi * (bi - 1) / 2 + bj; }
+
+// Wave 0: factor the pivot block tb (each 16-lane row works on its own copy; lane & 15 = row), write the factor
+// back to LDS, and its inverse both to LDS (sinv) and to the packed global image (ginv), [k][j] order.
+__device__ __forceinline__ void pivot_block(double* __restrict__ s, double* __restrict__ sinv, int* s_info, int tb,
                                             int lane, double* __restrict__ ginv) {
     double a[16];
     double di = 0.0;
     const int rl = lane & 15;
+    double* blk = s + lblk(tb, tb) * 256;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = s[(o + c) * LS + o + rl];
+    for (int c = 0; c < 16; ++c) a[c] = blk[c * 16 + rl];
     int inf = 0;
     PivotCol<0>::run(a, di, inf, rl);
     if (lane < 16) {
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-            if (c <= lane) s[(o + c) * LS + o + lane] = a[c];
+            if (c <= lane) blk[c * 16 + lane] = a[c];
     }
     double x[16], nx[16];
     InvRow<0>::run(a, di, x, nx, rl);
@@ -153,21 +159,22 @@ __device__ __forceinline__ void pivot_block(double* __restrict__ s, double* __re
             *(double2_t*)(ginv + lane * 16 + j) = v;
         }
     }
-    if (lane == 0 && inf != 0 && *s_info == 0) *s_info = o + inf;
+    if (lane == 0 && inf != 0 && *s_info == 0) *s_info = tb * 16 + inf;
 }
 
-// C(ri-block, rj-block) -= P(ri) P(rj)^T with P = columns o..o+15 (one 16x16 tile, 4 MFMAs)
-__device__ __forceinline__ void leaf_tile_update(double* __restrict__ s, int o, int ri, int rj, int lane) {
-    const int l15 = lane & 15, l4 = lane >> 4;
+// C(bi,bj) -= P(bi) P(bj)^T with P = column block tb (one 16x16 tile, 4 MFMAs, two accumulation chains)
+__device__ __forceinline__ void leaf_tile_update(double* __restrict__ s, int tb, int bi, int bj, int lane) {
+    double* cblk = s + lblk(bi, bj) * 256;
+    const double* pa = s + lblk(bj, tb) * 256;
+    const double* pb = s + lblk(bi, tb) * 256;
     double4_t acc0, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc0[q] = s[(rj + l4 + 4 * q) * LS + ri + l15];
+    for (int q = 0; q < 4; ++q) acc0[q] = cblk[q * 64 + lane];
     double fa[4], fb[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const int k = o + 4 * ks + l4;
-        fa[ks] = -s[k * LS + rj + l15];
-        fb[ks] = s[k * LS + ri + l15];
+        fa[ks] = -pa[ks * 64 + lane];
+        fb[ks] = pb[ks * 64 + lane];
     }
     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0], fb[0], acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1], fb[1], acc1, 0, 0, 0);
@@ -175,18 +182,18 @@ __device__ __forceinline__ void leaf_tile_update(double* __restrict__ s, int o, 
     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[3], fb[3], acc1, 0, 0, 0);
     acc0 += acc1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s[(rj + l4 + 4 * q) * LS + ri + l15] = acc0[q];
+    for (int q = 0; q < 4; ++q) cblk[q * 64 + lane] = acc0[q];
 }
 
-// rows ri..ri+15 of the column block o:  X <- X W^T  (W = inverted pivot block in sinv), in place
-__device__ __forceinline__ void leaf_tile_trsm(double* __restrict__ s, const double* __restrict__ sinv, int o, int ri,
+// block (bi, tb):  X <- X W^T  (W = inverted pivot block in sinv), in place
+__device__ __forceinline__ void leaf_tile_trsm(double* __restrict__ s, const double* __restrict__ sinv, int tb, int bi,
                                                int lane) {
-    const int l15 = lane & 15, l4 = lane >> 4;
+    double* xb = s + lblk(bi, tb) * 256;
     double fa[4], fb[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        fa[ks] = sinv[(4 * ks + l4) * 16 + l15];
-        fb[ks] = s[(o + 4 * ks + l4) * LS + ri + l15];
+        fa[ks] = sinv[ks * 64 + lane];
+        fb[ks] = xb[ks * 64 + lane];
     }
     double4_t y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
     y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0], fb[0], y0, 0, 0, 0);
@@ -195,57 +202,68 @@ __device__ __forceinline__ void leaf_tile_trsm(double* __restrict__ s, const dou
     y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[3], fb[3], y1, 0, 0, 0);
     y0 += y1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s[(o + l4 + 4 * q) * LS + ri + l15] = y0[q];
+    for (int q = 0; q < 4; ++q) xb[q * 64 + lane] = y0[q];
+}
+
+// thread t, piece i (0..17) of the 36-block image: block, column, row pair
+__device__ __forceinline__ void leaf_piece(int t, int i, int& blk, int& bi, int& bj, int& col, int& pr) {
+    const int v = t + 256 * i;
+    blk = v >> 7;
+    col = (v >> 3) & 15;
+    pr = v & 7;
+    if (blk >= 28) { bi = bj = blk - 28; }
+    else {
+        bi = (int)((sqrtf(8.0f * blk + 1.0f) + 1.0f) * 0.5f);       // bi(bi-1)/2 <= blk < bi(bi+1)/2
+        bj = blk - bi * (bi - 1) / 2;
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void leaf_potrf_kernel(double* __restrict__ A, long lda,
                                                             double* __restrict__ pack, int* __restrict__ info,
                                                             int info_base, long long* __restrict__ tick) {
-    extern __shared__ __attribute__((aligned(16))) double s[];   // s[c*LS + r] | sinv[256] | info
+    extern __shared__ __attribute__((aligned(16))) double s[];   // 36 blocks | sinv[256] | info
 #define TICK(i) do { if (tick && threadIdx.x == 0) tick[i] = __builtin_readcyclecounter(); } while (0)
     TICK(0);
-    double* sinv = s + NB * LS;
+    double* sinv = s + 36 * 256;
     int* s_info = (int*)(sinv + 256);                             // keep ALL LDS in the dynamic region
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) *s_info = 0;
-    // load the lower triangle in 16-byte pieces (column c needs rows >= c); every load is in flight before the
-    // first LDS store: one memory latency for the whole 128 KB block
+    // load the 36 lower blocks in 16-byte pieces; every load is in flight before the first LDS store
     {
-        double2_t regs[32];
+        double2_t regs[18];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int c = wave + 4 * i;
-            regs[i] = (2 * lane + 1 >= c) ? *(const double2_t*)(A + (long)(2 * lane) + (long)c * lda)
-                                          : double2_t{0.0, 0.0};
+        for (int i = 0; i < 18; ++i) {
+            int blk, bi, bj, col, pr;
+            leaf_piece(t, i, blk, bi, bj, col, pr);
+            regs[i] = *(const double2_t*)(A + (long)(16 * bi + 2 * pr) + (long)(16 * bj + col) * lda);
         }
 #pragma unroll
-        for (int i = 0; i < 32; ++i) *(double2_t*)(s + (wave + 4 * i) * LS + 2 * lane) = regs[i];
+        for (int i = 0; i < 18; ++i) *(double2_t*)(s + 2 * (t + 256 * i)) = regs[i];
     }
     __syncthreads();
     TICK(1);
-    if (wave == 0) pivot_block(s, sinv, s_info, 0, lane, pack + 36 * 256);
+    if (wave == 0) pivot_block(s, sinv, s_info, 0, lane, pack + 28 * 256);
     __syncthreads();
     TICK(2);
 
     for (int tb = 0; tb < 8; ++tb) {
-        const int o = tb * 16;
         const int nt = 7 - tb;                               // block rows below the pivot block
         // (b) rows below the pivot block: X <- X W^T on the MFMA, one 16-row tile per wave at a time
-        for (int i = wave; i < nt; i += 4) leaf_tile_trsm(s, sinv, o, o + 16 + 16 * i, lane);
+        for (int i = wave; i < nt; i += 4) leaf_tile_trsm(s, sinv, tb, tb + 1 + i, lane);
         __syncthreads();
         TICK(3 + 2 * tb);
         // (c) trailing update inside the leaf, with look-ahead: wave 0 updates the next pivot block first and
         // factors + inverts it right away while waves 1..3 update the remaining tiles
         if (nt > 0) {
             if (wave == 0) {
-                leaf_tile_update(s, o, o + 16, o + 16, lane);
-                pivot_block(s, sinv, s_info, o + 16, lane, pack + (36 + tb + 1) * 256);
+                leaf_tile_update(s, tb, tb + 1, tb + 1, lane);
+                pivot_block(s, sinv, s_info, tb + 1, lane, pack + (28 + tb + 1) * 256);
             } else {
                 const int ntile = nt * (nt + 1) / 2;
                 for (int tile = wave; tile < ntile; tile += 3) {      // tile 0 = (0,0) is wave 0's
                     int bi = 0, rem = tile;
                     while (rem > bi) { rem -= bi + 1; ++bi; }
-                    leaf_tile_update(s, o, o + 16 + 16 * bi, o + 16 + 16 * rem, lane);
+                    leaf_tile_update(s, tb, tb + 1 + bi, tb + 1 + rem, lane);
                 }
             }
         }
@@ -253,32 +271,25 @@ __global__ __launch_bounds__(256, 2) void leaf_potrf_kernel(double* __restrict__
         TICK(4 + 2 * tb);
     }
     if (tick && t == 0) tick[20] = __builtin_readcyclecounter();
-    // write back the factor (lower part; the strict upper part of the block keeps its exact zeros)
-    {
-        double2_t regs[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) regs[i] = *(const double2_t*)(s + (wave + 4 * i) * LS + 2 * lane);
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int c = wave + 4 * i;
-            if (2 * lane >= c) *(double2_t*)(A + (long)(2 * lane) + (long)c * lda) = regs[i];
-            else if (2 * lane + 1 >= c) A[(long)(2 * lane + 1) + (long)c * lda] = regs[i][1];
-        }
-    }
-    // packed image of the 36 lower 16x16 blocks in MFMA A-operand order ([k][j]) for trsm_rows_kernel
+    // write back: the factor into A (lower part only: the strict upper part of the diagonal blocks keeps its
+    // exact zeros) and the 28 strictly-lower blocks into the packed operand image for trsm_rows_kernel
     {
         double2_t regs[18];
 #pragma unroll
-        for (int bp = 0; bp < 18; ++bp) {
-            const int blk = 2 * bp + (t >> 7), w = t & 127, col = w >> 3, pr = w & 7;
-            const int c = (int)((sqrtf(8.0f * blk + 1.0f) - 1.0f) * 0.5f);
-            const int tb = blk - c * (c + 1) / 2;
-            regs[bp] = *(const double2_t*)(s + (16 * tb + col) * LS + 16 * c + 2 * pr);
-        }
+        for (int i = 0; i < 18; ++i) regs[i] = *(const double2_t*)(s + 2 * (t + 256 * i));
 #pragma unroll
-        for (int bp = 0; bp < 18; ++bp) {
-            const int blk = 2 * bp + (t >> 7), w = t & 127, col = w >> 3, pr = w & 7;
-            *(double2_t*)(pack + blk * 256 + col * 16 + 2 * pr) = regs[bp];
+        for (int i = 0; i < 18; ++i) {
+            int blk, bi, bj, col, pr;
+            leaf_piece(t, i, blk, bi, bj, col, pr);
+            double* dst = A + (long)(16 * bi + 2 * pr) + (long)(16 * bj + col) * lda;
+            if (blk < 28) {
+                *(double2_t*)dst = regs[i];
+                *(double2_t*)(pack + 2 * (t + 256 * i)) = regs[i];
+            } else if (2 * pr >= col) {
+                *(double2_t*)dst = regs[i];
+            } else if (2 * pr + 1 >= col) {
+                dst[1] = regs[i][1];
+            }
         }
     }
     if (t == 0 && *s_info != 0) atomicCAS(info, 0, info_base + *s_info);
@@ -291,22 +302,22 @@ __global__ __launch_bounds__(256, 2) void leaf_potrf_kernel(double* __restrict__
 // 8 inverted pivot blocks are staged ONCE per workgroup into LDS in MFMA A-operand order
 // ([k][j], 16 contiguous doubles per k: a wave's fragment read is one contiguous 512-byte run,
 // bank-conflict free), so the solve itself never waits on global memory.
-__device__ __forceinline__ int tri_blk(int c, int t) { return c * (c + 1) / 2 + t; }   // c >= t
+__device__ __forceinline__ int tri_blk(int c, int t) { return c * (c - 1) / 2 + t; }   // strictly lower: c > t
 
 __global__ __launch_bounds__(256, 2) void trsm_rows_kernel(double* __restrict__ X, long ldx, long nrows,
                                                            const double* __restrict__ Ld, long ldl,
                                                            const double* __restrict__ inv16 /* packed image */) {
-    extern __shared__ __attribute__((aligned(16))) double sl[];   // 36 L blocks (strict lower + diag unused) + 8 inv blocks
-    double* si = sl + 36 * 256;
+    extern __shared__ __attribute__((aligned(16))) double sl[];   // 28 strictly-lower L blocks + 8 inverted pivot blocks
+    double* si = sl + 28 * 256;
     const int t = threadIdx.x;
-    // stage the packed operand image (44 x 256 doubles, written by leaf_potrf_kernel): 22 coalesced
-    // 16-byte loads per thread, all in flight together
+    // stage the packed operand image (36 x 256 doubles = 72 KB, written by leaf_potrf_kernel): 18 coalesced
+    // 16-byte loads per thread, all in flight together.  72 KB: fits next to one resident gemm_f64 workgroup.
     {
-        double2_t regs[22];
+        double2_t regs[18];
 #pragma unroll
-        for (int i = 0; i < 22; ++i) regs[i] = *(const double2_t*)(inv16 + 2 * (t + 256 * i));
+        for (int i = 0; i < 18; ++i) regs[i] = *(const double2_t*)(inv16 + 2 * (t + 256 * i));
 #pragma unroll
-        for (int i = 0; i < 22; ++i) *(double2_t*)(sl + 2 * (t + 256 * i)) = regs[i];
+        for (int i = 0; i < 18; ++i) *(double2_t*)(sl + 2 * (t + 256 * i)) = regs[i];
     }
     const int lane = t & 63, wave = t >> 6;
     const long r0 = ((long)blockIdx.x * 4 + wave) * 16;
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(128, 1) void leaf_inv_kernel(const double* __restri
 
 int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st,
                       long long* tick) {
-    const size_t shm = (NB * LS + 256 + 2) * sizeof(double);
+    const size_t shm = (36 * 256 + 256 + 2) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)leaf_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -387,7 +398,7 @@ int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl
                      hipStream_t st) {
     if (nrows <= 0) return PGP_OK;
     const unsigned nblk = (unsigned)((nrows + 63) / 64);
-    const size_t shm = 44 * 256 * sizeof(double);
+    const size_t shm = 36 * 256 * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)trsm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

@@ -1,5 +1,6 @@
 // Self-test / calibration hooks (tests/ and bench.py only): host-buffer GEMM through the MFMA kernel,
 // and an fp64 MFMA issue-rate micro-benchmark used to restate the roofline peak from measurement.
+#include <cmath>
 #include <vector>
 
 #include "ctx.h"
@@ -123,6 +124,92 @@ int pgp_test_leaf_ticks(pgp_ctx* c, double* ticks_out) {
     HIP_TRY(hipMemcpy(h, tk, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 24; ++i) ticks_out[i] = (double)h[i];
     (void)hipFree(Ad); (void)hipFree(pk); (void)hipFree(info); (void)hipFree(tk);
+    return PGP_OK;
+}
+
+// device-only timing of the kernel-assembly tile kernel on synthetic resident coordinates:
+// mode 0 = full symmetric (n,n) output ('train'), 2 = fused lower-triangle B = K/sn2 + I.  ms_out = avg per launch.
+int pgp_test_assemble(pgp_ctx* c, int kind, int mode, int64_t n, int64_t d, int iters, double* ms_out) {
+    if (!c || !ms_out) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    const long np = round_up(n, 128);
+    const int dpad = (int)round_up(d, SKC);
+    std::vector<double> x((size_t)n * d);
+    unsigned long long s = 88172645463325252ULL;
+    for (auto& v : x) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = ((double)(s >> 11) / 9007199254740992.0 - 0.5) * 3.4; }
+    std::vector<double> hyp(kind == PGP_COV_RBFARD ? d + 1 : 2, 0.0);
+    for (size_t i = 0; i + 1 < hyp.size(); ++i) hyp[i] = 0.5 * log((double)d);
+    std::vector<double> sc;
+    CHK(fill_scale(kind, hyp.data(), (int)hyp.size(), 3, d, sc));
+    CovParams cp = make_cp(kind, hyp.data(), (int)hyp.size(), 3, 0, -1, d);
+    double *xd, *XT, *scd, *out;
+    const long ldo = mode == 2 ? np + 128 : n;
+    HIP_TRY(hipMalloc((void**)&xd, x.size() * 8)); HIP_TRY(hipMalloc((void**)&XT, (size_t)dpad * np * 8));
+    HIP_TRY(hipMalloc((void**)&scd, dpad * 8)); HIP_TRY(hipMalloc((void**)&out, (size_t)ldo * np * 8));
+    HIP_TRY(hipMemcpy(xd, x.data(), x.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(scd, sc.data(), d * 8, hipMemcpyHostToDevice));
+    CHK(scale_transpose_launch(xd, n, (int)d, scd, XT, np, dpad, c->st));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    int rc = PGP_OK;
+    for (int it = -1; it < iters && rc == PGP_OK; ++it) {
+        if (it == 0) HIP_TRY(hipEventRecord(e0, c->st));
+        rc = mode == 2 ? cov_factor_launch(XT, np, n, np, dpad, cp, 100.0, out, ldo, c->st)
+                       : cov_sym_launch(XT, np, n, dpad, cp, out, c->st, 0);
+    }
+    HIP_TRY(hipEventRecord(e1, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(xd); (void)hipFree(XT); (void)hipFree(scd); (void)hipFree(out);
+    return rc;
+}
+
+// Does a small panel kernel on the high-priority stream overlap a big trailing GEMM on the main stream?
+// out[0] = ms until the GEMM is done, out[1] = ms until the leaf kernel (issued after it, other stream) is done,
+// out[2] = same for a trsm over 4096 rows, out[3] = leaf alone.
+int pgp_test_overlap(pgp_ctx* c, double* out) {
+    if (!c || !out) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    const int N = 8192, K = 512;
+    double *A, *Cm, *L, *pk, *X; int* info;
+    HIP_TRY(hipMalloc((void**)&A, (size_t)N * K * 8)); HIP_TRY(hipMalloc((void**)&Cm, (size_t)N * N * 8));
+    HIP_TRY(hipMalloc((void**)&L, 128 * 128 * 8)); HIP_TRY(hipMalloc((void**)&pk, PACK_DOUBLES * 8));
+    HIP_TRY(hipMalloc((void**)&X, (size_t)4096 * 128 * 8)); HIP_TRY(hipMalloc((void**)&info, 4));
+    HIP_TRY(hipMemset(A, 0, (size_t)N * K * 8)); HIP_TRY(hipMemset(Cm, 0, (size_t)N * N * 8));
+    HIP_TRY(hipMemset(X, 0, (size_t)4096 * 128 * 8)); HIP_TRY(hipMemset(info, 0, 4));
+    std::vector<double> Lh(128 * 128, 0.0);
+    for (int i = 0; i < 128; ++i) Lh[i + i * 128] = 2.0;
+    HIP_TRY(hipMemcpy(L, Lh.data(), Lh.size() * 8, hipMemcpyHostToDevice));
+    GemmArgs g{};
+    g.A = A; g.lda = N; g.B = A; g.ldb = N; g.C = Cm; g.ldc = N; g.M = N; g.N = N; g.K = K;
+    g.alpha = -1.0; g.beta = 1.0; g.tile = 128; g.batch = 1;
+    hipEvent_t e0, eg, el, et;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&eg)); HIP_TRY(hipEventCreate(&el)); HIP_TRY(hipEventCreate(&et));
+    for (int rep = 0; rep < 2; ++rep) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipEventRecord(e0, c->st));
+        HIP_TRY(hipStreamWaitEvent(c->st2, e0, 0));
+        CHK(gemm_f64_launch(g, c->st));
+        HIP_TRY(hipEventRecord(eg, c->st));
+        CHK(leaf_potrf_launch(L, 128, pk, info, 0, c->st2));
+        HIP_TRY(hipEventRecord(el, c->st2));
+        CHK(trsm_rows_launch(X, 4096, 4096, L, 128, pk, c->st2));
+        HIP_TRY(hipEventRecord(et, c->st2));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    float a, b, d;
+    HIP_TRY(hipEventElapsedTime(&a, e0, eg)); HIP_TRY(hipEventElapsedTime(&b, e0, el)); HIP_TRY(hipEventElapsedTime(&d, e0, et));
+    out[0] = a; out[1] = b; out[2] = d;
+    HIP_TRY(hipEventRecord(e0, c->st2));
+    CHK(leaf_potrf_launch(L, 128, pk, info, 0, c->st2));
+    HIP_TRY(hipEventRecord(el, c->st2));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventElapsedTime(&a, e0, el));
+    out[3] = a;
+    (void)hipFree(A); (void)hipFree(Cm); (void)hipFree(L); (void)hipFree(pk); (void)hipFree(X); (void)hipFree(info);
     return PGP_OK;
 }
 

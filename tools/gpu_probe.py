@@ -28,11 +28,14 @@ def mfma():
                   % (wps, nacc, cyc, mhz, out[2], tf))
 
 
-def gemm(M, N, K, tile=128, a_kc=0, b_kc=0, tri=0, iters=5):
+def gemm(M, N, K, tile=128, a_kc=0, b_kc=0, tri=0, iters=5, fill=None):
     rng = np.random.RandomState(0)
     A = np.asfortranarray(rng.randn(M if not a_kc else K, K if not a_kc else M))
     B = np.asfortranarray(rng.randn(N if not b_kc else K, K if not b_kc else N))
     Cm = np.asfortranarray(rng.randn(M, N))
+    if fill is not None:
+        A[:] = fill; B[:] = fill; Cm[:] = fill
+        print("  (operands filled with %g)" % fill, end=" ")
     ms = C.c_double()
     rc = lib.pgp_test_gemm(ctx, tile, a_kc, b_kc, tri, 1 if tri else 0, 0, 0, -1.0, 1.0, _lib.ptr(A), A.shape[0],
                            _lib.ptr(B), B.shape[0], _lib.ptr(Cm), M, M, N, K, iters, C.byref(ms))
@@ -91,8 +94,15 @@ if __name__ == "__main__":
         for nm, v in seq:
             print("  %-10s +%7.0f cycles (%6.2f us)  total %8.0f" % (nm, v - prev, (v - prev) / 2400.0, v - base))
             prev = v
+    if "dvfs" in what:
+        for v in (0, 7):
+            lib.pgp_set_option(ctx, b"gemm_dbg", v)
+            print("gemm_dbg =", v)
+            for fill in (None, 0.0, 1.0):
+                gemm(8192, 8192, 2048, a_kc=1, b_kc=1, fill=fill, iters=8)
+        lib.pgp_set_option(ctx, b"gemm_dbg", 0)
     if "dbg" in what:
-        for v in (0, 1, 2, 3, 4, 5, 7, 0):
+        for v in (0, 8, 7, 15, 0):
             lib.pgp_set_option(ctx, b"gemm_dbg", v)
             print("gemm_dbg =", v)
             gemm(8192, 8192, 512)
@@ -108,6 +118,18 @@ if __name__ == "__main__":
                     fit(8192, 16, reps=2, prof=False)
         lib.pgp_set_option(ctx, b"lookahead", 1); lib.pgp_set_option(ctx, b"nb_outer", 4)
         lib.pgp_set_option(ctx, b"small_tile_below", 256)
+    if "trtri" in what:
+        for v in (256, 513, 1025, 4097, 256):
+            lib.pgp_set_option(ctx, b"trtri_small_tile_below", v)
+            print("trtri_small_tile_below =", v)
+            fit(8192, 16, reps=3, prof=False)
+        lib.pgp_set_option(ctx, b"trtri_small_tile_below", 256)
+    if "cumask" in what:
+        for v in (0, 8, 16, 4, 0):
+            lib.pgp_set_option(ctx, b"cu_reserve", v)
+            print("cu_reserve =", v)
+            fit(8192, 16, reps=3, prof=False)
+        lib.pgp_set_option(ctx, b"cu_reserve", 0)
     if "ab" in what:
         for v in (0, 1, 0, 1):
             lib.pgp_set_option(ctx, b"lookahead", v)
@@ -117,6 +139,18 @@ if __name__ == "__main__":
         fit(8192, 16)
         fit(8192, 16, want=2, prof=False)
         fit(2048, 16, prof=False)
+    if "overlap" in what:
+        o = np.zeros(4)
+        assert lib.pgp_test_overlap(ctx, _lib.ptr(o)) == 0
+        print("GEMM done at %.3f ms; leaf (other stream, issued after) done at %.3f ms; trsm done at %.3f ms; leaf alone %.3f ms" % tuple(o))
+    if "asm" in what:
+        for (kind, n, d) in ((0, 8192, 16), (0, 16384, 16), (1, 16384, 64), (2, 16384, 16), (0, 16384, 4)):
+            for mode in (0, 2):
+                ms = C.c_double()
+                assert lib.pgp_test_assemble(ctx, kind, mode, n, d, 10, C.byref(ms)) == 0
+                by = 8.0 * n * n * (1.0 if mode == 0 else 0.5) + 8.0 * n * d
+                print("assemble kind=%d n=%d d=%d mode=%d: %.3f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
+                    kind, n, d, mode, ms.value, by / ms.value / 1e6, by / ms.value / 1e6 / 80.0))
     if "ep" in what:
         import pygps_amd as pyGPs
         for N in (1024, 4096):
