@@ -227,9 +227,32 @@ static int tile_order(pgp_ctx* c, int mt, int nt, int tri, int off_tiles, const 
     return PGP_OK;
 }
 
+// Valid tiles of a lower-triangular (trapezoidal) tile grid, column-major like the plain 2-D grid but without
+// the empty upper tiles (a 64x64-tile grid over N=8192 would otherwise dispatch 2016 workgroups that exit at once).
+static int tri_tile_list(pgp_ctx* c, int mt, int nt, int off_tiles, const int** out, int* n) {
+    std::vector<int> key = {mt, nt, 2, off_tiles};
+    auto it = c->orders.find(key);
+    if (it != c->orders.end()) { *out = it->second.first; *n = it->second.second; return PGP_OK; }
+    std::vector<int> ord;
+    for (int tj = 0; tj < nt; ++tj)
+        for (int ti = 0; ti < mt; ++ti)
+            if (ti + off_tiles >= tj) { ord.push_back(ti); ord.push_back(tj); }
+    int* dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev, ord.size() * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(dev, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    c->orders[key] = {dev, (int)ord.size() / 2};
+    *out = dev; *n = (int)ord.size() / 2;
+    return PGP_OK;
+}
+
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
     if (!st) st = c->st;
     if (g.batch < 1) g.batch = 1;
+    if (g.tri == 1 && !g.order && !c->xcd_order) {
+        const int T = g.tile == 64 ? 64 : 128;
+        CHK(tri_tile_list(c, g.M / T, g.N / T, g.tri_off / T, &g.order, &g.norder));
+    }
     if (c->xcd_order && !g.order) {
         const int T = g.tile == 64 ? 64 : 128;
         CHK(tile_order(c, g.M / T, g.N / T, g.tri, g.tri ? g.tri_off / T : 0, &g.order, &g.norder));

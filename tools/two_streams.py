@@ -27,12 +27,15 @@ def worker(ctx, steps, out, k):
     out[k] = nlZ[0]
 
 
-for S in (1, 2, 3):
+opts = [tuple(o.split("=")) for o in sys.argv[1:]]
+for S in (1, 2):
     ctxs = []
     for k in range(S):
         h = C.c_void_p()
         assert lib.pgp_init(0, C.byref(h)) == 0
         assert lib.pgp_set_data(h, _lib.ptr(x), N, d, _lib.ptr(y)) == 0
+        for k_, v_ in opts:
+            assert lib.pgp_set_option(h, k_.encode(), int(v_)) == 0
         ctxs.append(h)
     out = [0] * S
     for steps in (2, 12):
@@ -41,6 +44,6 @@ for S in (1, 2, 3):
         [th.start() for th in ths]
         [th.join() for th in ths]
         dt = time.time() - t
-    print("streams %d: %d fits in %.1f ms -> %.2f ms/fit, %.1f fits/s  nlZ %s" % (S, S * steps, dt * 1e3, dt * 1e3 / (S * steps), S * steps / dt, out[0]))
+    print(opts, "streams %d: %d fits in %.1f ms -> %.2f ms/fit, %.1f fits/s  nlZ %s" % (S, S * steps, dt * 1e3, dt * 1e3 / (S * steps), S * steps / dt, out[0]))
     for h in ctxs:
         lib.pgp_destroy(h)
