@@ -114,13 +114,41 @@ def default_device():
     return int(os.environ.get("LOCAL_RANK", os.environ.get("PYGPS_AMD_DEVICE", "0")))
 
 
-def ctx(device=None):
-    """Process-wide context per device (one device + one stream + one workspace pool)."""
+_tls = threading.local()
+
+
+def current_slot():
+    """Index of the fit stream the calling thread works on (0 unless inside `fit_stream(k)`)."""
+    return getattr(_tls, "slot", 0)
+
+
+class fit_stream(object):
+    """`with fit_stream(k): ...` -- everything the calling thread does inside runs on context k of the device: its
+    own HIP streams, workspace pool and resident data.  A context is NOT thread-safe, so concurrent host threads
+    (e.g. two restarts optimised at once on one GPU) must each use their own slot."""
+
+    def __init__(self, k):
+        self.k = int(k)
+
+    def __enter__(self):
+        self.prev = current_slot()
+        _tls.slot = self.k
+        return self
+
+    def __exit__(self, *exc):
+        _tls.slot = self.prev
+        return False
+
+
+def ctx(device=None, slot=None):
+    """Context (one device + its HIP streams + one workspace pool) of (device, fit-stream slot); created on first use."""
     if device is None:
         device = default_device()
+    if slot is None:
+        slot = current_slot()
     dll = load()
     with _lock:
-        h = _ctx.get(device)
+        h = _ctx.get((device, slot))
         if h is None:
             out = _vp()
             rc = dll.pgp_init(device, C.byref(out))
@@ -128,7 +156,7 @@ def ctx(device=None):
                 raise RuntimeError("pygps_amd: cannot initialise HIP device %d: %s (no CPU fallback)"
                                    % (device, dll.pgp_strerror(rc).decode()))
             h = out
-            _ctx[device] = h
+            _ctx[(device, slot)] = h
     return h
 
 

@@ -135,7 +135,7 @@ class GP(object):
         ms = _lib.f64(self.meanfunc.getMean(xs)).reshape(ns)
         fmu = np.empty(ns)
         fs2 = np.empty(ns)
-        rc = _lib.load().pgp_predict(_lib.ctx(L._dev), L.handle, _lib.ptr(xs), ns, _lib.ptr(ms), _lib.ptr(fmu), _lib.ptr(fs2))
+        rc = _lib.load().pgp_predict(L.ctx, L.handle, _lib.ptr(xs), ns, _lib.ptr(ms), _lib.ptr(fmu), _lib.ptr(fs2))
         if rc == -99:
             raise NotImplementedError("pygps_amd: the device predict path is not built in this version")
         _lib.check(rc, "pgp_predict")

@@ -79,19 +79,25 @@ class DeviceFactor(object):
     ndim = 2
     dtype = np.dtype(np.float64)
 
-    def __init__(self, handle, n, device):
+    def __init__(self, handle, n, device, slot=0):
         self._h = handle
         self._n = int(n)
         self._dev = device
+        self._slot = slot
         self._host = None
-        self._fin = weakref.finalize(self, DeviceFactor._release, handle, device)
+        self._fin = weakref.finalize(self, DeviceFactor._release, handle, device, slot)
 
     @staticmethod
-    def _release(handle, device):
+    def _release(handle, device, slot):
         try:
-            _lib.load().pgp_factor_free(_lib.ctx(device), handle)
+            _lib.load().pgp_factor_free(_lib.ctx(device, slot), handle)
         except Exception:       # interpreter shutdown
             pass
+
+    @property
+    def ctx(self):
+        """The context that owns the device buffers of this factor."""
+        return _lib.ctx(self._dev, self._slot)
 
     @property
     def handle(self):
@@ -111,7 +117,7 @@ class DeviceFactor(object):
     def host(self):
         if self._host is None:
             out = np.empty((self._n, self._n))
-            _lib.check(_lib.load().pgp_factor_to_host(_lib.ctx(self._dev), self._h, _lib.ptr(out)), "pgp_factor_to_host")
+            _lib.check(_lib.load().pgp_factor_to_host(self.ctx, self._h, _lib.ptr(out)), "pgp_factor_to_host")
             out.setflags(write=False)
             self._host = out
         return self._host
@@ -159,17 +165,16 @@ class _Resident(object):
     @classmethod
     def ensure(cls, x, y, device):
         k = (x.shape, _digest(x), _digest(y))
-        if cls.key.get(device) != k:
+        where = (device, _lib.current_slot())
+        if cls.key.get(where) != k:
             _lib.check(_lib.load().pgp_set_data(_lib.ctx(device), _lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(y)),
                        "pgp_set_data")
-            cls.key[device] = k
+            cls.key[where] = k
 
     @classmethod
     def invalidate(cls, device=None):
-        if device is None:
-            cls.key.clear()
-        else:
-            cls.key.pop(device, None)
+        for k in [k for k in cls.key if device is None or k[0] == device]:
+            cls.key.pop(k, None)
 
 
 def _device_kernel(covfunc):
@@ -224,7 +229,7 @@ class Exact(Inference):
         post = postStruct()
         post.alpha = alpha.reshape(n, 1)
         post.sW = np.ones((n, 1)) / np.sqrt(sn2)
-        post.L = DeviceFactor(fh, n, dev)
+        post.L = DeviceFactor(fh, n, dev, _lib.current_slot())
         if nargout > 1:
             nlz = np.float64(nlZ[0])
             if nargout > 2:
@@ -285,7 +290,7 @@ class EP(Inference):
         post = postStruct()
         post.alpha = alpha.reshape(n, 1)
         post.sW = sW.reshape(n, 1)
-        post.L = DeviceFactor(fh, n, dev)
+        post.L = DeviceFactor(fh, n, dev, _lib.current_slot())
         if nargout > 2:
             dnlZ = dnlZStruct(meanfunc, covfunc, likfunc)
             dnlZ.mean = [np.float64(v) for v in g[:nm]]

