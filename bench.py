@@ -106,12 +106,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # self-test hook only: PYGPS_BENCH_BACKEND=gloo lets N ranks share fewer GPUs (collectives through host memory)
+    backend = os.environ.get("PYGPS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    cdev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))    # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
 
     from pygps_amd import _lib
@@ -125,8 +133,8 @@ def main():
     else:
         x, y = np.zeros((N, d)), np.zeros((N, 1))
     if dist:
-        xt = torch.from_numpy(x).cuda()
-        yt = torch.from_numpy(y).cuda()
+        xt = torch.from_numpy(x).to(cdev)
+        yt = torch.from_numpy(y).to(cdev)
         dist.broadcast(xt, src=0)
         dist.broadcast(yt, src=0)
         x, y = xt.cpu().numpy(), yt.cpu().numpy()
@@ -188,10 +196,10 @@ def main():
         fit(args.warmup + s)
     lat_ms = (time.perf_counter() - t1) / 3 * 1e3
     if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        res = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        res = torch.tensor(vals, dtype=torch.float64, device=cdev)
         parts = [torch.empty_like(res) for _ in range(world)]
         dist.all_gather(parts, res)                                              # RCCL gather of results
         vals_all = torch.stack(parts).cpu().numpy()
