@@ -523,6 +523,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     CovParams cp = make_cp(kind, covhyp, ncov, para, flags, -1, d);
     double* F = nullptr;
     CHK(alloc_factor_buffer(c, np, ldf, &F));
+    FactorGuard fguard(c, F, (size_t)ldf * np * sizeof(double));       // back to the pool on every early return
     hipStream_t st = c->st;
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
     if (mvec) HIP_TRY(hipMemcpyAsync(c->m_dev, mvec, n * sizeof(double), hipMemcpyHostToDevice, st));
@@ -589,11 +590,9 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     }
     if (c->prof) prof_collect(c);
     if (info != 0) {
-        pool_free(c, (size_t)ldf * np * sizeof(double), nullptr);
-        // the buffer now holds NaNs: scrub before it can be reused
+        // the buffer now holds NaNs: scrub it before it goes back to the pool (fguard)
         (void)hipMemsetAsync(F, 0, (size_t)ldf * np * sizeof(double), st);
         (void)hipStreamSynchronize(st);
-        pool_free(c, (size_t)ldf * np * sizeof(double), F);
         return info > (int)n ? (int)n : info;
     }
     if (alpha_out) memcpy(alpha_out, alpha_h.data(), n * sizeof(double));
@@ -612,8 +611,8 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     }
     if (factor_out) {
         pgp_factor* f = new pgp_factor();
-        f->n = n; f->np = np; f->ldf = ldf; f->F = F; f->dpad = c->dpad; f->d = (int)d; f->cp = cp; f->sn2 = sn2;
-        f->sw = 1.0 / sqrt(sn2); f->scale = sc; f->Wd = nullptr;
+        f->n = n; f->np = np; f->ldf = ldf; f->F = fguard.release(); f->dpad = c->dpad; f->d = (int)d; f->cp = cp;
+        f->sn2 = sn2; f->sw = 1.0 / sqrt(sn2); f->scale = sc; f->Wd = nullptr;
         HIP_TRY(hipMalloc((void**)&f->alpha, np * sizeof(double)));
         HIP_TRY(hipMemsetAsync(f->alpha, 0, np * sizeof(double), st));
         HIP_TRY(hipMemcpyAsync(f->alpha, alpha_h.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
@@ -621,8 +620,6 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         HIP_TRY(hipMemcpyAsync(f->XsT, c->XsT, (size_t)c->dpad * np * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         *factor_out = f;
-    } else {
-        pool_free(c, (size_t)ldf * np * sizeof(double), F);
     }
     return PGP_OK;
 }
@@ -698,33 +695,29 @@ int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n,
     const int dpad = (int)round_up(d, SKC);
     const long ldr = round_up(n, 128), ldc = (mode == PGP_MODE_CROSS) ? round_up(m, 128) : 0;
     const long mm = (mode == PGP_MODE_CROSS) ? m : n;
+    DevScratch tmp;
     double *xd = nullptr, *zd = nullptr, *XrT = nullptr, *XcT = nullptr, *scd = nullptr, *od = nullptr;
-    HIP_TRY(hipMalloc((void**)&xd, n * d * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&XrT, (size_t)dpad * ldr * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&scd, dpad * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&od, (size_t)n * mm * sizeof(double)));
+    CHK(tmp.alloc(&xd, n * d * sizeof(double)));
+    CHK(tmp.alloc(&XrT, (size_t)dpad * ldr * sizeof(double)));
+    CHK(tmp.alloc(&scd, dpad * sizeof(double)));
+    CHK(tmp.alloc(&od, (size_t)n * mm * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(xd, x, n * d * sizeof(double), hipMemcpyHostToDevice, st));
-    int rc = upload_scaled(c, xd, n, d, sc, XrT, ldr, dpad, scd);
-    if (rc == PGP_OK && mode == PGP_MODE_CROSS) {
-        HIP_TRY(hipMalloc((void**)&zd, m * d * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&XcT, (size_t)dpad * ldc * sizeof(double)));
+    CHK(upload_scaled(c, xd, n, d, sc, XrT, ldr, dpad, scd));
+    if (mode == PGP_MODE_CROSS) {
+        CHK(tmp.alloc(&zd, m * d * sizeof(double)));
+        CHK(tmp.alloc(&XcT, (size_t)dpad * ldc * sizeof(double)));
         HIP_TRY(hipMemcpyAsync(zd, z, m * d * sizeof(double), hipMemcpyHostToDevice, st));
-        rc = scale_transpose_launch(zd, m, (int)d, scd, XcT, ldc, dpad, st);
+        CHK(scale_transpose_launch(zd, m, (int)d, scd, XcT, ldc, dpad, st));
     }
-    if (rc == PGP_OK) {
+    {
         ProfScope ps(c, PC_ASSEMBLE, 0.0, 8.0 * (double)n * mm + 8.0 * (double)(n + (mode == PGP_MODE_CROSS ? m : 0)) * d);
-        if (mode == PGP_MODE_TRAIN) rc = cov_sym_launch(XrT, ldr, n, dpad, cp, od, st);
-        else rc = cov_rect_launch(XrT, ldr, n, XcT, ldc, m, dpad, cp, od, m, st);
+        if (mode == PGP_MODE_TRAIN) CHK(cov_sym_launch(XrT, ldr, n, dpad, cp, od, st));
+        else CHK(cov_rect_launch(XrT, ldr, n, XcT, ldc, m, dpad, cp, od, m, st));
     }
-    if (rc == PGP_OK) {
-        hipError_t e = hipMemcpyAsync(out, od, (size_t)n * mm * sizeof(double), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { pgp_set_last_hip_error(e, "cov copy-out", __FILE__, __LINE__); rc = PGP_ERR_HIP; }
-    }
+    HIP_TRY(hipMemcpyAsync(out, od, (size_t)n * mm * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (c->prof) prof_collect(c);
-    void* bufs[] = {xd, zd, XrT, XcT, scd, od};
-    for (void* b : bufs) if (b) (void)hipFree(b);
-    return rc;
+    return PGP_OK;
 }
 
 // ---- helper functions ------------------------------------------------------------------------------
@@ -736,42 +729,35 @@ int pgp_potrf(pgp_ctx* c, const double* A, int64_t n, double* L_out) {
     HIP_TRY(hipSetDevice(c->device));
     const long np = round_up(n, 128);
     hipStream_t st = c->st;
-    double* F = nullptr;
-    HIP_TRY(hipMalloc((void**)&F, (size_t)np * np * sizeof(double)));
+    DevScratch tmp;
+    double *F = nullptr, *pack = nullptr;
+    CHK(tmp.alloc(&F, (size_t)np * np * sizeof(double)));
+    CHK(tmp.alloc(&pack, (size_t)(np / 128) * PACK_DOUBLES * sizeof(double)));
     HIP_TRY(hipMemsetAsync(F, 0, (size_t)np * np * sizeof(double), st));
     // symmetric input: row-major == column-major; copy the n x n corner, identity on the padding
     HIP_TRY(hipMemcpy2DAsync(F, np * sizeof(double), A, n * sizeof(double), n * sizeof(double), n, hipMemcpyHostToDevice, st));
-    std::vector<double> ones(np - n, 1.0);
+    std::vector<double> ones(np - n + 1, 1.0);
     if (np > n)
         HIP_TRY(hipMemcpy2DAsync(F + n + n * np, (np + 1) * sizeof(double), ones.data(), sizeof(double), sizeof(double),
                                  np - n, hipMemcpyHostToDevice, st));
-    const long save_ws = c->ws_np;
-    (void)save_ws;
-    double* inv16_save = c->inv16;
-    double* inv16 = nullptr;
-    HIP_TRY(hipMalloc((void**)&inv16, (size_t)(np / 128) * PACK_DOUBLES * sizeof(double)));
-    c->inv16 = inv16;
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
-    int rc = potrf_blocked(c, F, np, np, np);
-    c->inv16 = inv16_save;
+    double* pack_save = c->inv16;                  // the blocked driver takes the per-leaf operand images from the ctx
+    c->inv16 = pack;
+    const int rc = potrf_blocked(c, F, np, np, np);
+    c->inv16 = pack_save;
+    CHK(rc);
     int info = 0;
-    if (rc == PGP_OK) {
-        HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
-    if (rc == PGP_OK && info == 0) {
-        // device holds column-major lower L; numpy wants row-major lower => transpose on the host
-        std::vector<double> tmp((size_t)n * n);
-        HIP_TRY(hipMemcpy2D(tmp.data(), n * sizeof(double), F, np * sizeof(double), n * sizeof(double), n,
-                            hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < n; ++i)
-            for (int64_t j = 0; j < n; ++j) L_out[i * n + j] = (j <= i) ? tmp[(size_t)j * n + i] : 0.0;
-    }
+    HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (c->prof) prof_collect(c);
-    (void)hipFree(F);
-    (void)hipFree(inv16);
-    if (rc != PGP_OK) return rc;
-    return info > (int)n ? (int)n : info;
+    if (info != 0) return info > (int)n ? (int)n : info;
+    // device holds column-major lower L; numpy wants row-major lower => transpose on the host
+    std::vector<double> host((size_t)n * n);
+    HIP_TRY(hipMemcpy2D(host.data(), n * sizeof(double), F, np * sizeof(double), n * sizeof(double), n,
+                        hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < n; ++j) L_out[i * n + j] = (j <= i) ? host[(size_t)j * n + i] : 0.0;
+    return PGP_OK;
 }
 
 }  // extern "C"

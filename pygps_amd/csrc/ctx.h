@@ -112,6 +112,29 @@ struct ProfScope {
 };
 
 
+// Owns hipMalloc'ed scratch for the duration of one API call: every early `return rc` frees it.
+struct DevScratch {
+    std::vector<void*> ptrs;
+    ~DevScratch() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+    template <typename T>
+    int alloc(T** out, size_t bytes) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        if (e != hipSuccess) { pgp_set_last_hip_error(e, "hipMalloc(scratch)", __FILE__, __LINE__); return PGP_ERR_HIP; }
+        ptrs.push_back(p);
+        *out = (T*)p;
+        return PGP_OK;
+    }
+};
+
+// Returns a pooled factor buffer to the context unless ownership was handed on (release()).
+struct FactorGuard {
+    pgp_ctx* c; double* F; size_t bytes;
+    FactorGuard(pgp_ctx* c_, double* F_, size_t b) : c(c_), F(F_), bytes(b) {}
+    ~FactorGuard() { if (F) pool_free(c, bytes, F); }
+    double* release() { double* p = F; F = nullptr; return p; }
+};
+
 void prof_collect(pgp_ctx* c);
 static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 int fill_scale(int kind, const double* hyp, int nhyp, int para, long d, std::vector<double>& sc);

@@ -62,42 +62,38 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     const int d = f->d, dpad = f->dpad;
     const long NSB = 1024;                                 // test points per batch (the reference uses 1000)
     const long ldc = NSB;
+    DevScratch tmp;
     double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *o2 = nullptr;
-    HIP_TRY(hipMalloc((void**)&xd, NSB * d * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&XcT, (size_t)dpad * ldc * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&scd, dpad * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&Ks, (size_t)np * NSB * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&msd, NSB * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&o1, NSB * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&o2, NSB * sizeof(double)));
+    CHK(tmp.alloc(&xd, NSB * d * sizeof(double)));
+    CHK(tmp.alloc(&XcT, (size_t)dpad * ldc * sizeof(double)));
+    CHK(tmp.alloc(&scd, dpad * sizeof(double)));
+    CHK(tmp.alloc(&Ks, (size_t)np * NSB * sizeof(double)));
+    CHK(tmp.alloc(&msd, NSB * sizeof(double)));
+    CHK(tmp.alloc(&o1, NSB * sizeof(double)));
+    CHK(tmp.alloc(&o2, NSB * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(scd, f->scale.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
     CovParams cp = f->cp;
     cp.der = -1;
-    int rc = PGP_OK;
-    for (long a = 0; a < ns && rc == PGP_OK; a += NSB) {
+    for (long a = 0; a < ns; a += NSB) {
         const long nb_ = std::min<long>(NSB, ns - a);
         const int nrhs = (int)round_up(nb_, 128);
         HIP_TRY(hipMemcpyAsync(xd, xs + a * d, nb_ * d * sizeof(double), hipMemcpyHostToDevice, st));
         if (ms) HIP_TRY(hipMemcpyAsync(msd, ms + a, nb_ * sizeof(double), hipMemcpyHostToDevice, st));
         else HIP_TRY(hipMemsetAsync(msd, 0, nb_ * sizeof(double), st));
-        rc = scale_transpose_launch(xd, nb_, d, scd, XcT, ldc, dpad, st);
+        CHK(scale_transpose_launch(xd, nb_, d, scd, XcT, ldc, dpad, st));
         // Ks as column-major (np x nrhs): rows = test points, columns = training points in the tile kernel's view
-        if (rc == PGP_OK) HIP_TRY(hipMemsetAsync(Ks, 0, (size_t)np * nrhs * sizeof(double), st));
-        if (rc == PGP_OK) rc = cov_rect_launch(XcT, ldc, nb_, f->XsT, np, n, dpad, cp, Ks, np, st);
-        if (rc == PGP_OK) rc = col_dot_full_launch(Ks, np, n, nb_, f->alpha, msd, o1, st);     // fmu = ms + Ks' alpha
-        if (rc == PGP_OK && f->sWv) rc = row_scale_launch(Ks, np, n, nrhs, f->sWv, st);       // EP: sW o Ks
-        if (rc == PGP_OK) rc = solve_lower_multi(c, f->F, f->ldf, f->Wd, Ks, np, np, nrhs, false);
-        if (rc == PGP_OK) rc = col_sumsq_launch(Ks, np, n, nb_, cp.sf2, f->sWv ? 1.0 : f->sw * f->sw, o2, st);
-        if (rc == PGP_OK) {
-            HIP_TRY(hipMemcpyAsync(fmu + a, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(fs2 + a, o2, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-        }
+        HIP_TRY(hipMemsetAsync(Ks, 0, (size_t)np * nrhs * sizeof(double), st));
+        CHK(cov_rect_launch(XcT, ldc, nb_, f->XsT, np, n, dpad, cp, Ks, np, st));
+        CHK(col_dot_full_launch(Ks, np, n, nb_, f->alpha, msd, o1, st));                  // fmu = ms + Ks' alpha
+        if (f->sWv) CHK(row_scale_launch(Ks, np, n, nrhs, f->sWv, st));                   // EP: sW o Ks
+        CHK(solve_lower_multi(c, f->F, f->ldf, f->Wd, Ks, np, np, nrhs, false));
+        CHK(col_sumsq_launch(Ks, np, n, nb_, cp.sf2, f->sWv ? 1.0 : f->sw * f->sw, o2, st));
+        HIP_TRY(hipMemcpyAsync(fmu + a, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(fs2 + a, o2, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
     if (c->prof) prof_collect(c);
-    void* bufs[] = {xd, XcT, scd, Ks, msd, o1, o2};
-    for (void* b : bufs) if (b) (void)hipFree(b);
-    return rc;
+    return PGP_OK;
 }
 
 int pgp_potrs(pgp_ctx* c, const double* R, int64_t n, const double* Bm, int64_t nrhs, double* X_out) {
@@ -111,10 +107,11 @@ int pgp_potrs(pgp_ctx* c, const double* R, int64_t n, const double* Bm, int64_t 
     hipStream_t st = c->st;
     const long np = round_up(n, 128);
     const int nr = (int)round_up(nrhs, 128);
+    DevScratch tmp;
     double *L = nullptr, *Wd = nullptr, *Y = nullptr;
-    HIP_TRY(hipMalloc((void**)&L, (size_t)np * np * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&Wd, (size_t)128 * np * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&Y, (size_t)np * nr * sizeof(double)));
+    CHK(tmp.alloc(&L, (size_t)np * np * sizeof(double)));
+    CHK(tmp.alloc(&Wd, (size_t)128 * np * sizeof(double)));
+    CHK(tmp.alloc(&Y, (size_t)np * nr * sizeof(double)));
     HIP_TRY(hipMemsetAsync(L, 0, (size_t)np * np * sizeof(double), st));
     HIP_TRY(hipMemsetAsync(Y, 0, (size_t)np * nr * sizeof(double), st));
     // row-major upper R == column-major lower L (same bytes); identity on the padding
@@ -128,19 +125,16 @@ int pgp_potrs(pgp_ctx* c, const double* R, int64_t n, const double* Bm, int64_t 
         for (int64_t j = 0; j < nrhs; ++j) yt[(size_t)j * n + i] = Bm[i * nrhs + j];
     HIP_TRY(hipMemcpy2DAsync(Y, np * sizeof(double), yt.data(), n * sizeof(double), n * sizeof(double), nrhs,
                              hipMemcpyHostToDevice, st));
-    int rc = leaf_inv_launch(L, np, Wd, 128, 128L * 128L, (int)(np / 128), st);
-    if (rc == PGP_OK) rc = solve_lower_multi(c, L, np, Wd, Y, np, np, nr, false);      // (R')^-1 = L^-1
-    if (rc == PGP_OK) rc = solve_lower_multi(c, L, np, Wd, Y, np, np, nr, true);       // R^-1 = L^-T
-    if (rc == PGP_OK) {
-        HIP_TRY(hipMemcpy2DAsync(yt.data(), n * sizeof(double), Y, np * sizeof(double), n * sizeof(double), nrhs,
-                                 hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (int64_t i = 0; i < n; ++i)
-            for (int64_t j = 0; j < nrhs; ++j) X_out[i * nrhs + j] = yt[(size_t)j * n + i];
-    }
+    CHK(leaf_inv_launch(L, np, Wd, 128, 128L * 128L, (int)(np / 128), st));
+    CHK(solve_lower_multi(c, L, np, Wd, Y, np, np, nr, false));      // (R')^-1 = L^-1
+    CHK(solve_lower_multi(c, L, np, Wd, Y, np, np, nr, true));       // R^-1 = L^-T
+    HIP_TRY(hipMemcpy2DAsync(yt.data(), n * sizeof(double), Y, np * sizeof(double), n * sizeof(double), nrhs,
+                             hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < nrhs; ++j) X_out[i * nrhs + j] = yt[(size_t)j * n + i];
     if (c->prof) prof_collect(c);
-    (void)hipFree(L); (void)hipFree(Wd); (void)hipFree(Y);
-    return rc;
+    return PGP_OK;
 }
 
 }  // extern "C"
