@@ -97,6 +97,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "xcd_order")) { c->xcd_order = value; return PGP_OK; }
     if (!strcmp(name, "gemm_dbg")) { c->gemm_dbg = value; return PGP_OK; }
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
+    if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
     if (!strcmp(name, "cu_reserve")) {
         if (c->st_masked) { (void)hipStreamSynchronize(c->st_masked); (void)hipStreamDestroy(c->st_masked); c->st_masked = nullptr; }
         c->cu_reserve = value;
@@ -269,7 +270,10 @@ int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
 // written once per 128 q columns: HBM arithmetic intensity 16 q flop/B).
 // Look-ahead (depth 1): the update of the NEXT panel's columns (TU_a) is issued first; the next panel is
 // then factored on the high-priority stream st2 while the rest of the trailing update (TU_b) runs on st.
-static int factor_panel(pgp_ctx* c, double* F, long ld, long mrows, int s0, int s1, hipStream_t st) {
+// rows_end(nb) = one past the last row that takes part once nb column blocks are factored
+struct RowEnd { long eoff; bool winv; long operator()(int nb) const { return winv ? eoff + (long)nb * 128 : eoff; } };
+
+static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s1, hipStream_t st) {
     for (int cb = s0; cb < s1; ++cb) {
         double* Acc = F + (long)cb * 128 + (long)cb * 128 * ld;
         double* pack = c->inv16 + (long)cb * PACK_DOUBLES;
@@ -277,7 +281,7 @@ static int factor_panel(pgp_ctx* c, double* F, long ld, long mrows, int s0, int 
             ProfScope ps(c, PC_LEAF, 128.0 * 128.0 * 128.0 / 3.0, 0.0, st);
             CHK(leaf_potrf_launch(Acc, ld, pack, c->info_dev, cb * 128, st));
         }
-        const long rows_below = mrows - (long)(cb + 1) * 128;
+        const long rows_below = re(cb + 1) - (long)(cb + 1) * 128;
         if (rows_below > 0) {
             ProfScope ps(c, PC_TRSM, (double)rows_below * 128.0 * 128.0, 0.0, st);
             CHK(trsm_rows_launch(Acc + 128, ld, rows_below, Acc, ld, pack, st));
@@ -299,14 +303,14 @@ static int factor_panel(pgp_ctx* c, double* F, long ld, long mrows, int s0, int 
 }
 
 // C[rows >= r0, cols c0..c1) -= P P^T, P = F[rows, k0..k1) (block units of 128), lower part only
-static int trailing_update(pgp_ctx* c, double* F, long ld, long mrows, int k0, int k1, int c0, int c1,
+static int trailing_update(pgp_ctx* c, double* F, long ld, RowEnd re, int k0, int k1, int c0, int c1,
                            hipStream_t st) {
     if (c1 <= c0) return PGP_OK;
     GemmArgs g{};
     g.A = F + (long)c0 * 128 + (long)k0 * 128 * ld; g.lda = ld; g.a_kc = 0;
     g.B = g.A; g.ldb = ld; g.b_kc = 0;
     g.C = F + (long)c0 * 128 + (long)c0 * 128 * ld; g.ldc = ld;
-    g.M = (int)(mrows - (long)c0 * 128); g.N = (c1 - c0) * 128; g.K = (k1 - k0) * 128;
+    g.M = (int)(re(k1) - (long)c0 * 128); g.N = (c1 - c0) * 128; g.K = (k1 - k0) * 128;
     g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
     const long t128 = (long)(g.M / 128) * (g.N / 128) - (long)(g.N / 128) * (g.N / 128 - 1) / 2;
     g.tile = t128 < c->small_tile_below ? 64 : 128;
@@ -314,15 +318,22 @@ static int trailing_update(pgp_ctx* c, double* F, long ld, long mrows, int k0, i
     return gemm_prof(c, PC_GEMM_TRAIL, g, st);
 }
 
-int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows) {
+// with_inverse: rows mrows .. mrows+np-1 of F hold an identity on entry (E region).  They ride through the sweep like
+// the augmented right-hand-side rows: E <- E L^-T = L^-T = W^T.  Row i of E stays zero left of its own column block, so
+// after nb factored column blocks only the first 128 nb rows of E take part (RowEnd): the extra work is N^3/3 flops --
+// exactly a triangular inverse -- but it runs inside the big K=512 trailing-update launches, which it also keeps
+// large when the Cholesky's own trailing matrix shrinks (tiles per launch ~ constant), instead of a separate
+// recursion of 12 small clipped GEMM launches.
+int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse) {
+    const RowEnd re{mrows, with_inverse};
     const int nblk = (int)(np / 128);
     const int q = c->nb_outer;
     const int npanel = (nblk + q - 1) / q;
     if (!c->lookahead || npanel < 3) {
         for (int s0 = 0; s0 < nblk; s0 += q) {
             const int s1 = std::min(s0 + q, nblk);
-            CHK(factor_panel(c, F, ld, mrows, s0, s1, c->st));
-            CHK(trailing_update(c, F, ld, mrows, s0, s1, s1, nblk, c->st));
+            CHK(factor_panel(c, F, ld, re, s0, s1, c->st));
+            CHK(trailing_update(c, F, ld, re, s0, s1, s1, nblk, c->st));
         }
         return PGP_OK;
     }
@@ -338,19 +349,19 @@ int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows) {
         main = c->st_masked;
     }
     // panel 0 on the main stream
-    CHK(factor_panel(c, F, ld, mrows, 0, std::min(q, nblk), main));
+    CHK(factor_panel(c, F, ld, re, 0, std::min(q, nblk), main));
     for (int p = 0; p < npanel; ++p) {
         const int s0 = p * q, s1 = std::min(s0 + q, nblk);
         if (s1 >= nblk) break;
         const int n0 = s1, n1 = std::min(s1 + q, nblk);              // next panel's columns
         // TU_a(p): next panel's columns, then hand the next panel to the panel stream
-        CHK(trailing_update(c, F, ld, mrows, s0, s1, n0, n1, main));
+        CHK(trailing_update(c, F, ld, re, s0, s1, n0, n1, main));
         HIP_TRY(hipEventRecord(c->la_ev[2 * p], main));
         HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
-        CHK(factor_panel(c, F, ld, mrows, n0, n1, pan));
+        CHK(factor_panel(c, F, ld, re, n0, n1, pan));
         HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
         // TU_b(p): the rest of the trailing matrix, concurrently with the panel factorisation
-        CHK(trailing_update(c, F, ld, mrows, s0, s1, n1, nblk, main));
+        CHK(trailing_update(c, F, ld, re, s0, s1, n1, nblk, main));
         HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));    // next TU_a needs the factored panel
     }
     if (main != c->st) {
@@ -444,6 +455,20 @@ int lauum_lower(pgp_ctx* c, const double* W, long ldw, double* Binv, long ldb, l
     return gemm_prof(c, PC_GEMM_LAUUM, g);
 }
 
+// B^-1 (lower) = E E^T with E = W^T upper triangular (column-major, lde): NT product, k >= i0
+int eet_lower(pgp_ctx* c, const double* E, long lde, double* Binv, long ldb, long np) {
+    GemmArgs g{};
+    g.A = E; g.lda = lde; g.a_kc = 0;
+    g.B = E; g.ldb = lde; g.b_kc = 0;
+    g.C = Binv; g.ldc = ldb;
+    g.M = (int)np; g.N = (int)np; g.K = (int)np; g.alpha = 1.0; g.beta = 0.0;
+    g.tri = 2; g.mask_diag = 1; g.kmode = KM_GE_I; g.koff = 0;
+    const long t128 = (np / 128) * (np / 128 + 1) / 2;
+    g.tile = t128 < c->small_tile_below ? 64 : 128;
+    g.flops = (double)np * np * np / 3.0;
+    return gemm_prof(c, PC_GEMM_LAUUM, g);
+}
+
 int ensure_workspace(pgp_ctx* c, long np) {
     if (c->ws_np == np) return PGP_OK;
     (void)hipStreamSynchronize(c->st);
@@ -488,7 +513,9 @@ int pgp_set_data(pgp_ctx* c, const double* x, int64_t n, int64_t d, const double
     void* olds[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev};
     for (void* b : olds) if (b) (void)hipFree(b);
     c->x_dev = c->y_dev = c->XsT = c->scale_dev = nullptr;
-    c->n = n; c->d = d; c->np = round_up(n, 128); c->ldf = c->np + 128; c->dpad = (int)round_up(d, SKC);
+    c->n = n; c->d = d; c->np = round_up(n, 128); c->ldf = 2 * c->np + 128;
+    // ^ factor rows | 128 augmented rhs rows | np rows of the fused inverse (E region)
+    c->dpad = (int)round_up(d, SKC);
     HIP_TRY(hipMalloc((void**)&c->x_dev, n * d * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->y_dev, c->np * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->XsT, (size_t)c->dpad * c->np * sizeof(double)));
@@ -513,7 +540,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     std::vector<double> sc;
     CHK(fill_scale(kind, covhyp, ncov, para, d, sc));
     CHK(ensure_workspace(c, np));
-    const long need = hadamard_partial_count(np, ncov);
+    const long need = std::max(hadamard_partial_count(np, ncov), 32L * np);       // also the partials of upper_matvec
     if (want >= 3 && c->partial_cap < need) {
         if (c->partial) (void)hipFree(c->partial);
         HIP_TRY(hipMalloc((void**)&c->partial, need * sizeof(double)));
@@ -537,14 +564,21 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         CHK(cov_factor_launch(c->XsT, np, n, np, c->dpad, cp, 1.0 / sn2, F, ldf, st));
     }
     CHK(aug_rhs_launch(c->y_dev, c->m_dev, n, F, ldf, np, c->rvec, st));
-    // ---- S2: Cholesky (forward substitution of the augmented row rides along) ------------------
+    const bool fused = want >= 3 && c->fused_inverse;
+    double* E = F + np + 128;                        // E(i,j) at E[i + j*ldf]: ends up as W^T = L^-T (upper triangular)
+    if (fused) CHK(identity_upper_launch(E, ldf, np, st));
+    // ---- S2: Cholesky (forward substitution of the augmented row -- and L^-T -- ride along) ----------
     HIP_TRY(hipEventRecord(c->ev[1], st));
-    CHK(potrf_blocked(c, F, ldf, np, np + 128));
+    CHK(potrf_blocked(c, F, ldf, np, np + 128, fused));
     HIP_TRY(hipEventRecord(c->ev[2], st));
     int info = 0;
     // ---- S5a/S3: W = L^-1, alpha = W^T z / sn2 (or blocked back-substitution when W is not needed)
     CHK(gather_strided_launch(F + np, ldf, np, c->zvec, st));
-    if (want >= 3) {
+    if (fused) {
+        HIP_TRY(hipEventRecord(c->ev[3], st));
+        { ProfScope ps(c, PC_SMALL, 0.0, 4.0 * (double)np * np);                      // alpha = W^T z / sn2 = E z / sn2
+          CHK(upper_matvec_launch(E, ldf, np, c->zvec, 1.0 / sn2, c->partial, c->alpha_dev, st)); }
+    } else if (want >= 3) {
         CHK(trtri_lower(c, F, ldf, c->W, np, c->T, np));
         HIP_TRY(hipEventRecord(c->ev[3], st));
         { ProfScope ps(c, PC_SMALL, 0.0, 4.0 * (double)np * np);
@@ -561,7 +595,8 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     HIP_TRY(hipEventRecord(c->ev[4], st));
     // ---- S5b: B^-1 = W^T W ; S6: gradient reduce ------------------------------------------------
     if (want >= 3) {
-        CHK(lauum_lower(c, c->W, np, c->Binv, np, np));
+        if (fused) CHK(eet_lower(c, E, ldf, c->Binv, np, np));                        // B^-1 = W^T W = E E^T
+        else CHK(lauum_lower(c, c->W, np, c->Binv, np, np));
         HIP_TRY(hipEventRecord(c->ev[5], st));
         // alpha currently holds W^T z / sn2 = B^-1 r / sn2  (already the final alpha)
         { ProfScope ps(c, PC_HADAMARD, 0.0, 8.0 * (double)np * (np + 1) / 2.0 + 8.0 * (double)n * d);

@@ -36,6 +36,7 @@ struct pgp_ctx {
     hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
+    int fused_inverse = 1;              // 1: L^-T falls out of the Cholesky sweep (appended identity rows); 0: recursive trtri
     hipStream_t st_masked = nullptr;    // main stream of the look-ahead Cholesky restricted to a CU subset (option cu_reserve)
     int cu_reserve = 0;                 // reserve every cu_reserve-th CU for the panel stream (0 = off)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -139,7 +140,7 @@ void prof_collect(pgp_ctx* c);
 static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 int fill_scale(int kind, const double* hyp, int nhyp, int para, long d, std::vector<double>& sc);
 CovParams make_cp(int kind, const double* hyp, int nhyp, int para, int flags, int der, long d);
-int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows);
+int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse = false);
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);
 int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ldw, double* T, long np);
 int lauum_lower(pgp_ctx* c, const double* W, long ldw, double* Binv, long ldb, long np);
@@ -149,3 +150,4 @@ int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F);
 int ensure_workspace(pgp_ctx* c, long np);
 int solve_lower_multi(pgp_ctx* c, const double* L, long ldl, const double* Wd, double* Y, long ldy, long np, int nrhs,
                       bool trans);
+int eet_lower(pgp_ctx* c, const double* E, long lde, double* Binv, long ldb, long np);

@@ -86,10 +86,10 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
                     w[a][bq] = wq * K;
                     g1 += 2.0 * wq * K;                                    // d/d log sf
                 } else {
-                    CovParams c0p = cp; c0p.der = 0;
-                    CovParams c1p = cp; c1p.der = 1;
-                    g0 += wq * cov_deriv(c0p, s[a][bq], 0.0);
-                    g1 += wq * cov_deriv(c1p, s[a][bq], 0.0);
+                    double d0, d1;
+                    cov_deriv01(cp, s[a][bq], d0, d1);
+                    g0 = fma(wq, d0, g0);
+                    g1 = fma(wq, d1, g1);
                     w[a][bq] = 0.0;
                 }
             }
@@ -255,7 +255,52 @@ __global__ __launch_bounds__(256) void row_scale_kernel(double* __restrict__ A, 
     if (i < nrows && j < ncols) A[i + j * lda] *= s[i];
 }
 
+// E(i,j) = (i == j) for j >= i (the upper trapezoid is the only part of the E region a fit ever dirties)
+__global__ __launch_bounds__(256) void identity_upper_kernel(double* __restrict__ E, long lde, long np) {
+    const long j = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i <= j && i < np) E[i + j * lde] = (i == j) ? 1.0 : 0.0;
+}
+
+// partial[c*np + i] = sum_{k in chunk c, k >= i} E(i,k) z[k]   (E column-major: coalesced over i)
+__global__ __launch_bounds__(256) void upper_matvec_kernel(const double* __restrict__ E, long lde, long np,
+                                                           const double* __restrict__ z, double* __restrict__ partial,
+                                                           int nchunk) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    const long kc = (np + nchunk - 1) / nchunk;
+    const long k0 = c * kc, k1 = k0 + kc < np ? k0 + kc : np;
+    if (i >= np) return;
+    double acc = 0.0;
+    for (long k = (k0 > i ? k0 : i); k < k1; ++k) acc = fma(E[i + k * lde], z[k], acc);
+    partial[(long)c * np + i] = acc;
+}
+__global__ __launch_bounds__(256) void upper_matvec_reduce_kernel(const double* __restrict__ partial, long np, int nchunk,
+                                                                  double scale, double* __restrict__ y) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= np) return;
+    double acc = 0.0;
+    for (int c = 0; c < nchunk; ++c) acc += partial[(long)c * np + i];
+    y[i] = scale * acc;
+}
+
 }  // namespace
+
+int identity_upper_launch(double* E, long lde, long np, hipStream_t st) {
+    hipLaunchKernelGGL(identity_upper_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, E, lde,
+                       np);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+int upper_matvec_launch(const double* E, long lde, long np, const double* z, double scale, double* partial, double* y,
+                        hipStream_t st) {
+    const int nchunk = 32;
+    hipLaunchKernelGGL(upper_matvec_kernel, dim3((unsigned)((np + 255) / 256), nchunk), dim3(256), 0, st, E, lde, np, z,
+                       partial, nchunk);
+    hipLaunchKernelGGL(upper_matvec_reduce_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, partial, np,
+                       nchunk, scale, y);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
 
 int col_dot_full_launch(const double* A, long lda, long nrows, long ncols, const double* v, const double* add,
                         double* out, hipStream_t st) {

@@ -45,3 +45,8 @@ int col_dot_full_launch(const double* A, long lda, long nrows, long ncols, const
 int col_sumsq_launch(const double* A, long lda, long nrows, long ncols, double kss, double scale, double* out,
                      hipStream_t st);
 int row_scale_launch(double* A, long lda, long nrows, long ncols, const double* s, hipStream_t st);
+
+// grad.hip (fused-inverse helpers)
+int identity_upper_launch(double* E, long lde, long np, hipStream_t st);
+int upper_matvec_launch(const double* E, long lde, long np, const double* z, double scale, double* partial, double* y,
+                        hipStream_t st);

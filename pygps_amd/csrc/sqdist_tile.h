@@ -112,3 +112,24 @@ __device__ __forceinline__ double cov_deriv(const CovParams& p, double s, double
     return p.der == 0 ? p.sf2 * matern_dpoly(p.md, t) * t * exp(-t)
                       : 2.0 * p.sf2 * matern_poly(p.md, t) * exp(-t);
 }
+
+// both derivatives (hyper 0 = log ell, hyper 1 = log sf) of the two-hyper kernels with ONE exp
+__device__ __forceinline__ void cov_deriv01(const CovParams& p, double s, double& d0, double& d1) {
+    if (p.kind == 0) {
+        const double K = p.sf2 * exp(-0.5 * s);
+        d0 = K * s;
+        d1 = 2.0 * K;
+        return;
+    }
+    const double t = sqrt(s);                          // Matern
+    const double e = exp(-t);
+    if (p.ref_der) {
+        const double K = p.sf2 * matern_poly(p.md, t) * e;
+        const double eK = exp(-K);
+        d0 = p.sf2 * matern_dpoly(p.md, K) * K * eK;
+        d1 = 2.0 * p.sf2 * matern_poly(p.md, K) * eK;
+    } else {
+        d0 = p.sf2 * matern_dpoly(p.md, t) * t * e;
+        d1 = 2.0 * p.sf2 * matern_poly(p.md, t) * e;
+    }
+}

@@ -118,6 +118,14 @@ if __name__ == "__main__":
                     fit(8192, 16, reps=2, prof=False)
         lib.pgp_set_option(ctx, b"lookahead", 1); lib.pgp_set_option(ctx, b"nb_outer", 4)
         lib.pgp_set_option(ctx, b"small_tile_below", 256)
+    if "qsweep" in what:
+        for q in (2, 3, 4, 6):
+            for stb in (256, 1024):
+                lib.pgp_set_option(ctx, b"nb_outer", q); lib.pgp_set_option(ctx, b"small_tile_below", stb)
+                print("nb_outer", q, "small_tile_below", stb)
+                fit(8192, 16, reps=3, prof=False)
+                fit(16384, 16, reps=2, prof=False)
+        lib.pgp_set_option(ctx, b"nb_outer", 4); lib.pgp_set_option(ctx, b"small_tile_below", 256)
     if "trtri" in what:
         for v in (256, 513, 1025, 4097, 256):
             lib.pgp_set_option(ctx, b"trtri_small_tile_below", v)
