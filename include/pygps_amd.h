@@ -30,6 +30,10 @@ typedef struct pgp_factor pgp_factor; /* device-resident posterior: factor R, al
 #define PGP_COV_RBF 0     /* Core/cov.py:786-828   hyp=[log ell, log sf]               */
 #define PGP_COV_RBFARD 1  /* Core/cov.py:872-938   hyp=[log ell_1..log ell_D, log sf]  */
 #define PGP_COV_MATERN 2  /* Core/cov.py:1078-1182 hyp=[log ell, log sf], para=d in {1,3,5,7} */
+#define PGP_COV_RBFUNIT 3 /* Core/cov.py:832-869   hyp=[log ell]                                  */
+#define PGP_COV_RQ 4      /* Core/cov.py:1304-1347 hyp=[log ell, log sf, log alpha]               */
+#define PGP_COV_PIECEPOLY 5 /* Core/cov.py:683-782 hyp=[log ell, log sf], para=v in {0,1,2,3}      */
+#define PGP_COV_NKIND 6
 /* modes of getCovMatrix / getDerMatrix (Core/cov.py:81-111) */
 #define PGP_MODE_TRAIN 0
 #define PGP_MODE_CROSS 1

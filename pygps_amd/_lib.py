@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygps_amd.so")
 
-COV_RBF, COV_RBFARD, COV_MATERN = 0, 1, 2
+COV_RBF, COV_RBFARD, COV_MATERN, COV_RBFUNIT, COV_RQ, COV_PIECEPOLY = 0, 1, 2, 3, 4, 5
 MODE_TRAIN, MODE_CROSS, MODE_SELF_TEST = 0, 1, 2
 FLAG_MATERN_REFERENCE_DER = 1
 STAGES = ("assemble", "potrf", "solve", "trtri", "lauum", "grad", "total")

@@ -168,6 +168,54 @@ class Matern(Kernel):
         return self._device_eval(x, z, mode, der)
 
 
+class _DeviceKernel(Kernel):
+    def getCovMatrix(self, x=None, z=None, mode=None):
+        self.checkInputGetCovMatrix(x, z, mode)
+        return self._device_eval(x, z, mode, None)
+
+    def getDerMatrix(self, x=None, z=None, mode=None, der=None):
+        self.checkInputGetDerMatrix(x, z, mode, der)
+        return self._device_eval(x, z, mode, der)
+
+
+class RBFunit(_DeviceKernel):
+    """Squared exponential with unit magnitude.  hyp = [log_ell]   (Core/cov.py:832-869)"""
+    _kind = _lib.COV_RBFUNIT
+    _WRONG_DER = "Wrong derivative index in RDFunit"
+
+    def __init__(self, log_ell=0.):
+        self.hyp = [log_ell]
+        self.para = []
+
+
+class RQ(_DeviceKernel):
+    """Rational quadratic, isotropic.  hyp = [log_ell, log_sigma, log_alpha]   (Core/cov.py:1304-1347)"""
+    _kind = _lib.COV_RQ
+    _WRONG_DER = "Wrong derivative index in covRQ"
+
+    def __init__(self, log_ell=0., log_sigma=0., log_alpha=0.):
+        self.hyp = [log_ell, log_sigma, log_alpha]
+        self.para = []
+
+
+class PiecePoly(_DeviceKernel):
+    """Piecewise polynomial kernel with compact support.  hyp = [log_ell, log_sigma], para = [v], v in {0,1,2,3}
+    (Core/cov.py:683-782)"""
+    _kind = _lib.COV_PIECEPOLY
+    _WRONG_DER = "Wrong derivative entry in PiecePoly"
+
+    def __init__(self, log_ell=0., v=2, log_sigma=0.):
+        self.hyp = [log_ell, log_sigma]
+        self.para = [v]
+
+    def _device_params(self):
+        v = self.para[0]
+        if np.abs(v - np.round(v)) < 1e-8:
+            v = int(round(v))
+        assert int(v) in range(4)                      # only degrees 0,1,2,3 (Core/cov.py:737)
+        return self._kind, int(v), 0
+
+
 # ---- composites: children are evaluated on the device, combined on the host (Core/cov.py:230-328) ----
 class _Pair(Kernel):
     def __init__(self, cov1, cov2):

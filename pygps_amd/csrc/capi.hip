@@ -163,6 +163,11 @@ int fill_scale(int kind, const double* hyp, int nhyp, int para, long d, std::vec
         if (nhyp != 2) return -10;
         const double ell = exp(hyp[0]);
         for (auto& s : sc) s = sqrt((double)matern_d(para)) / ell;
+    } else if (kind == PGP_COV_RBFUNIT || kind == PGP_COV_RQ || kind == PGP_COV_PIECEPOLY) {
+        if (nhyp != (kind == PGP_COV_RBFUNIT ? 1 : kind == PGP_COV_RQ ? 3 : 2)) return -10;
+        if (kind == PGP_COV_PIECEPOLY && (para < 0 || para > 3)) return -12;     // Core/cov.py:737 assert
+        const double ell = exp(hyp[0]);                                          // cov.py:847, 1318, 742
+        for (auto& s : sc) s = 1.0 / ell;
     } else {
         return -2;
     }
@@ -175,6 +180,10 @@ CovParams make_cp(int kind, const double* hyp, int nhyp, int para, int flags, in
     cp.ref_der = (flags & PGP_FLAG_MATERN_REFERENCE_DER) ? 1 : 0;
     cp.D = (int)d;
     cp.sf2 = exp(2.0 * hyp[nhyp - 1]);
+    cp.alpha = 1.0; cp.ppv = 0; cp.ppj = 1.0;
+    if (kind == PGP_COV_RBFUNIT) cp.sf2 = 1.0;
+    if (kind == PGP_COV_RQ) { cp.sf2 = exp(2.0 * hyp[1]); cp.alpha = exp(hyp[2]); }
+    if (kind == PGP_COV_PIECEPOLY) { cp.ppv = para; cp.ppj = floor(0.5 * (double)d) + para + 1.0; }
     return cp;
 }
 
@@ -532,7 +541,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
                   double* dnlZ_out, pgp_factor** factor_out) {
     if (!c) return -1;
     if (c->n <= 0) return -1;
-    if (kind < 0 || kind > 2) return -2;
+    if (kind < 0 || kind >= PGP_COV_NKIND) return -2;
     if (!covhyp) return -3;
     if (want < 1 || want > 3) return -11;
     HIP_TRY(hipSetDevice(c->device));
@@ -691,16 +700,19 @@ void pgp_factor_free(pgp_ctx* c, pgp_factor* f) {
 int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n, const double* z, int64_t m,
             int64_t d, const double* hyp, int nhyp, int para, int flags, double* out) {
     if (!c) return -1;
-    if (kind < 0 || kind > 2) return -2;
+    if (kind < 0 || kind >= PGP_COV_NKIND) return -2;
     if (mode < 0 || mode > 2) return -3;
     if (!hyp) return -10;
     if (!out) return -14;
     if (mode != PGP_MODE_SELF_TEST && !x) return -5;
     if (mode != PGP_MODE_TRAIN && !z) return -7;
     if (d <= 0) return -9;
-    if (kind == PGP_COV_RBFARD && nhyp != d + 1) return -11;
-    if (kind != PGP_COV_RBFARD && nhyp != 2) return -11;
-    const int nder = (kind == PGP_COV_MATERN) ? 3 : nhyp;           // Matern accepts der == 2 (cov.py:1178)
+    {
+        const int want_nhyp = kind == PGP_COV_RBFARD ? (int)d + 1 : kind == PGP_COV_RBFUNIT ? 1 : kind == PGP_COV_RQ ? 3 : 2;
+        if (nhyp != want_nhyp) return -11;
+    }
+    // Matern and PiecePoly accept der == 2 ("derivative w.r.t. the order" = zeros, cov.py:1178, 778)
+    const int nder = (kind == PGP_COV_MATERN || kind == PGP_COV_PIECEPOLY) ? 3 : nhyp;
     if (der >= nder) return -4;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->st;
@@ -708,19 +720,18 @@ int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n,
     if (mode == PGP_MODE_SELF_TEST) {
         // A = 0: value sf2*f(0); derivatives per Core/cov.py:815-817, 924-925, 1163-1177
         double val;
-        if (der < 0) val = cp.sf2;
-        else if (kind == PGP_COV_RBF) val = der == 0 ? 0.0 : 2.0 * cp.sf2;
-        else if (kind == PGP_COV_RBFARD) val = der < d ? 0.0 : 2.0 * cp.sf2;
-        else {
-            const double K = cp.sf2;   // matern at t = 0
-            if (der == 2) val = 0.0;
-            else if (cp.ref_der) {
-                auto poly = [&](double t) { switch (cp.md) { case 1: return 1.0; case 3: return 1.0 + t;
-                    case 5: return 1.0 + t + t * t / 3.0; default: return 1.0 + t + 2.0 * t * t / 5.0 + t * t * t / 15.0; } };
-                auto dpoly = [&](double t) { switch (cp.md) { case 1: return 1.0; case 3: return t;
-                    case 5: return (t + t * t) / 3.0; default: return (t + 3.0 * t * t + t * t * t) / 15.0; } };
-                val = der == 0 ? cp.sf2 * dpoly(K) * K * exp(-K) : 2.0 * cp.sf2 * poly(K) * exp(-K);
-            } else val = der == 0 ? 0.0 : 2.0 * cp.sf2;
+        if (der < 0) val = cp.sf2;                                        // every kernel here: k(x,x) = sf2
+        else if (kind == PGP_COV_MATERN && cp.ref_der && der < 2) {
+            const double K = cp.sf2;                                      // matern at t = 0, then the cov.py:1173 quirk
+            auto poly = [&](double t) { switch (cp.md) { case 1: return 1.0; case 3: return 1.0 + t;
+                case 5: return 1.0 + t + t * t / 3.0; default: return 1.0 + t + 2.0 * t * t / 5.0 + t * t * t / 15.0; } };
+            auto dpoly = [&](double t) { switch (cp.md) { case 1: return 1.0; case 3: return t;
+                case 5: return (t + t * t) / 3.0; default: return (t + 3.0 * t * t + t * t * t) / 15.0; } };
+            val = der == 0 ? cp.sf2 * dpoly(K) * K * exp(-K) : 2.0 * cp.sf2 * poly(K) * exp(-K);
+        } else {
+            // length-scale-type and shape derivatives vanish at zero distance; the magnitude derivative is 2 sf2
+            const int sf_index = kind == PGP_COV_RBFARD ? (int)d : kind == PGP_COV_RBFUNIT ? -1 : 1;
+            val = der == sf_index ? 2.0 * cp.sf2 : 0.0;
         }
         for (int64_t i = 0; i < m; ++i) out[i] = val;
         return PGP_OK;

@@ -160,7 +160,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                           pgp_factor** factor_out) {
     if (!c) return -1;
     if (c->n <= 0) return -1;
-    if (kind < 0 || kind > 2) return -2;
+    if (kind < 0 || kind >= PGP_COV_NKIND) return -2;
     if (!covhyp) return -3;
     if (!ttau_io || !tnu_io) return -12;
     HIP_TRY(hipSetDevice(c->device));

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
 
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     double w[4][4];                 // weight * Q_rc * K_rc   (ARD) -- or per-hyper accumulators below
-    double g0 = 0.0, g1 = 0.0, tq = 0.0;
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0, tq = 0.0;
     double ar[4], ac[4], wr[4], wc[4];        // Q_rc = Binv_rc * w_r w_c - alpha_r alpha_c  (Exact: w = 1/sn)
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -86,10 +86,11 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
                     w[a][bq] = wq * K;
                     g1 += 2.0 * wq * K;                                    // d/d log sf
                 } else {
-                    double d0, d1;
-                    cov_deriv01(cp, s[a][bq], d0, d1);
+                    double d0, d1, d2;
+                    cov_deriv_all(cp, s[a][bq], d0, d1, d2);
                     g0 = fma(wq, d0, g0);
                     g1 = fma(wq, d1, g1);
+                    g2 = fma(wq, d2, g2);
                     w[a][bq] = 0.0;
                 }
             }
@@ -141,8 +142,14 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
     } else {
         const double t0 = block_sum(g0, red);
         const double t1 = block_sum(g1, red);
-        const double t2 = block_sum(tq, red);
-        if (t == 0) { out[0] = t0; out[1] = t1; out[ncov] = t2; }
+        const double t2 = block_sum(g2, red);
+        const double t3 = block_sum(tq, red);
+        if (t == 0) {
+            out[0] = t0;
+            if (ncov > 1) out[1] = t1;
+            if (ncov > 2) out[2] = t2;
+            out[ncov] = t3;
+        }
     }
 }
 

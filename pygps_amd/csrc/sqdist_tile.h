@@ -18,7 +18,10 @@ struct CovParams {
     int md;          // Matern d (1,3,5,7)
     int ref_der;     // Matern: reproduce the reference's derivative-of-K quirk (Core/cov.py:1173-1177)
     int D;           // input dimension (ARD: der < D selects a length-scale)
-    double sf2;      // exp(2 log sf)
+    double sf2;      // exp(2 log sf)   (1 for RBFunit)
+    double alpha;    // RQ shape parameter exp(log alpha)
+    int ppv;         // PiecePoly degree v (0..3)
+    double ppj;      // PiecePoly j = floor(D/2) + v + 1
 };
 
 constexpr int ST = 64;      // tile edge
@@ -83,8 +86,41 @@ __device__ __forceinline__ double matern_dpoly(int d, double t) {
     }
 }
 
+// PiecePoly polynomial f(v, r, j) and "f - f'" companion (Core/cov.py:698-720)
+__device__ __forceinline__ double pp_func(int v, double r, double j) {
+    switch (v) {
+        case 0: return 1.0;
+        case 1: return 1.0 + (j + 1.0) * r;
+        case 2: return 1.0 + (j + 2.0) * r + (j * j + 4.0 * j + 3.0) / 3.0 * r * r;
+        default: return 1.0 + (j + 3.0) * r + (6.0 * j * j + 36.0 * j + 45.0) / 15.0 * r * r
+                        + (j * j * j + 9.0 * j * j + 23.0 * j + 15.0) / 15.0 * r * r * r;
+    }
+}
+__device__ __forceinline__ double pp_dfunc(int v, double r, double j) {
+    switch (v) {
+        case 0: return 0.0;
+        case 1: return j + 1.0;
+        case 2: return (j + 2.0) + 2.0 * (j * j + 4.0 * j + 3.0) / 3.0 * r;
+        default: return (j + 3.0) + 2.0 * (6.0 * j * j + 36.0 * j + 45.0) / 15.0 * r
+                        + (j * j * j + 9.0 * j * j + 23.0 * j + 15.0) / 5.0 * r * r;
+    }
+}
+__device__ __forceinline__ double ipow(double b, int n) {      // b^n, n >= 0, 0^0 = 1 like numpy
+    double r = 1.0;
+    while (n > 0) { if (n & 1) r *= b; b *= b; n >>= 1; }
+    return r;
+}
+
 // covariance value k(x,z) from the scaled squared distance s
 __device__ __forceinline__ double cov_value(const CovParams& p, double s) {
+    if (p.kind == 4) {                    // RQ: Core/cov.py:1323
+        return p.sf2 * exp(-p.alpha * log(1.0 + 0.5 * s / p.alpha));
+    }
+    if (p.kind == 5) {                    // PiecePoly: Core/cov.py:746 (compact support: 0 beyond r = 1)
+        const double r = sqrt(s);
+        const double pm = fmax(1.0 - r, 0.0);
+        return p.sf2 * pp_func(p.ppv, r, p.ppj) * ipow(pm, (int)p.ppj + p.ppv);
+    }
     if (p.kind == 2) {                    // Matern: t = sqrt(d) |x-z| / ell (scale folded into XsT)
         const double t = sqrt(s);
         return p.sf2 * matern_poly(p.md, t) * exp(-t);
@@ -94,6 +130,22 @@ __device__ __forceinline__ double cov_value(const CovParams& p, double s) {
 
 // derivative w.r.t. hyper p.der; dk2 = scaled squared difference in coordinate p.der (ARD only)
 __device__ __forceinline__ double cov_deriv(const CovParams& p, double s, double dk2) {
+    if (p.kind == 3) return exp(-0.5 * s) * s;        // RBFunit: Core/cov.py:865
+    if (p.kind == 4) {                    // RQ: Core/cov.py:1337-1345
+        const double Kp = 1.0 + 0.5 * s / p.alpha;
+        const double lk = log(Kp);
+        if (p.der == 0) return p.sf2 * exp((-p.alpha - 1.0) * lk) * s;
+        if (p.der == 1) return 2.0 * p.sf2 * exp(-p.alpha * lk);
+        return p.sf2 * exp(-p.alpha * lk) * (0.5 * s / Kp - p.alpha * lk);
+    }
+    if (p.kind == 5) {                    // PiecePoly: Core/cov.py:774-780
+        if (p.der == 2) return 0.0;
+        const double r = sqrt(s);
+        const double pm = fmax(1.0 - r, 0.0);
+        const int e = (int)p.ppj + p.ppv;
+        if (p.der == 1) return 2.0 * p.sf2 * pp_func(p.ppv, r, p.ppj) * ipow(pm, e);
+        return p.sf2 * ipow(pm, e - 1) * r * ((double)e * pp_func(p.ppv, r, p.ppj) - pm * pp_dfunc(p.ppv, r, p.ppj));
+    }
     if (p.kind == 0) {                    // RBF: Core/cov.py:823-825
         const double K = p.sf2 * exp(-0.5 * s);
         return p.der == 0 ? K * s : 2.0 * K;
@@ -113,8 +165,29 @@ __device__ __forceinline__ double cov_deriv(const CovParams& p, double s, double
                       : 2.0 * p.sf2 * matern_poly(p.md, t) * exp(-t);
 }
 
-// both derivatives (hyper 0 = log ell, hyper 1 = log sf) of the two-hyper kernels with ONE exp
-__device__ __forceinline__ void cov_deriv01(const CovParams& p, double s, double& d0, double& d1) {
+// every derivative (up to three hypers) of the non-ARD kernels, transcendental functions evaluated once
+__device__ __forceinline__ void cov_deriv_all(const CovParams& p, double s, double& d0, double& d1, double& d2) {
+    d2 = 0.0;
+    if (p.kind == 3) { d0 = exp(-0.5 * s) * s; d1 = 0.0; return; }
+    if (p.kind == 4) {
+        const double Kp = 1.0 + 0.5 * s / p.alpha;
+        const double lk = log(Kp);
+        const double Ka = p.sf2 * exp(-p.alpha * lk);
+        d0 = Ka / Kp * s;
+        d1 = 2.0 * Ka;
+        d2 = Ka * (0.5 * s / Kp - p.alpha * lk);
+        return;
+    }
+    if (p.kind == 5) {
+        const double r = sqrt(s);
+        const double pm = fmax(1.0 - r, 0.0);
+        const int e = (int)p.ppj + p.ppv;
+        const double f = pp_func(p.ppv, r, p.ppj);
+        const double pe1 = ipow(pm, e - 1);
+        d0 = p.sf2 * pe1 * r * ((double)e * f - pm * pp_dfunc(p.ppv, r, p.ppj));
+        d1 = 2.0 * p.sf2 * f * pe1 * pm;
+        return;
+    }
     if (p.kind == 0) {
         const double K = p.sf2 * exp(-0.5 * s);
         d0 = K * s;

@@ -180,7 +180,7 @@ class _Resident(object):
 def _device_kernel(covfunc):
     if not isinstance(covfunc, _cov.Kernel) or covfunc._kind is None:
         raise NotImplementedError(
-            "pygps_amd: only RBF, RBFard and Matern have a device covariance functor (got %s); "
+            "pygps_amd: only RBF, RBFard, Matern, RBFunit, RQ and PiecePoly have a device covariance functor (got %s); "
             "there is no CPU fallback" % type(covfunc).__name__)
     return covfunc._device_params()
 

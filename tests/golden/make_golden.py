@@ -310,8 +310,37 @@ def gmin():
     save("Gmin_minimize_trajectories", **out)
 
 
+# ----------------------------------------------------------------------------- G10: SURVEY 8(f) rank 2 kernels
+def g10():
+    np.random.seed(0)
+    x = np.random.normal(0, 1, (20, 3))
+    _ = np.random.random((20,))
+    z = np.random.normal(0, 1, (10, 3))
+    out = dict(x=x, z=z)
+    kernel_dump("rbfunit", pyGPs.cov.RBFunit(0.3), x, z, out)
+    kernel_dump("rq", pyGPs.cov.RQ(0.3, 0.2, -0.4), x, z, out)
+    for v in (0, 1, 2, 3):
+        kernel_dump("pp%d" % v, pyGPs.cov.PiecePoly(1.1, v, 0.2), x, z, out)
+    save("G10_kernels_rbfunit_rq_piecepoly", **out)
+    # a fit with each (synthetic recipe, N=300, d=4)
+    x, y = synth_reg(300, 4)
+    for nm, k in (("rbfunit", pyGPs.cov.RBFunit(np.log(2.0))), ("rq", pyGPs.cov.RQ(np.log(2.0), 0.1, 0.3)),
+                  ("pp2", pyGPs.cov.PiecePoly(np.log(6.0), 2, 0.1))):
+        m = pyGPs.GPR()
+        m.setPrior(kernel=k)
+        m.setNoise(np.log(0.1))
+        m.setData(x, y)
+        nlZ, dnlZ, post = m.getPosterior()
+        xs = x[:5] + 0.05
+        ym, ys2, fm, fs2, lp = m.predict(xs)
+        save("G10_fit_%s_N300" % nm, N=300, d=4, seed=0, nlZ=nlZ, alpha=post.alpha, L_diag=np.diag(post.L).copy(),
+             mean_hyp=np.array(m.meanfunc.hyp), cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp),
+             para=np.array(k.para if hasattr(k, "para") and k.para else [0]), pred_xs=xs, pred_ym=ym, pred_fs2=fs2,
+             **dn(dnlZ))
+
+
 CASES = {
-    "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
+    "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
     "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048),
 }

@@ -230,3 +230,42 @@ def test_G8_ep_classification_demo_and_synthetic(lib):
         assert relerr(dnlZ.cov, g["dnlZ_cov"]) < 1e-6
         assert relerr(post.alpha, g["alpha"]) < 1e-6 and relerr(post.sW, g["sW"]) < 1e-6
         assert relerr(np.diag(post.L), g["L_diag"]) < 1e-7
+
+
+def test_G10_rbfunit_rq_piecepoly_on_device(lib):
+    """the next stationary kernels as device functors (Core/cov.py:683-782, 832-869, 1304-1347)."""
+    import pygps_amd as pyGPs
+    g = golden("G10_kernels_rbfunit_rq_piecepoly")
+    x, z = g["x"], g["z"]
+    ks = {"rbfunit": pyGPs.cov.RBFunit(0.3), "rq": pyGPs.cov.RQ(0.3, 0.2, -0.4)}
+    for v in range(4):
+        ks["pp%d" % v] = pyGPs.cov.PiecePoly(1.1, v, 0.2)
+    for nm, k in ks.items():
+        assert relerr(k.hyp, g[nm + "_hyp"]) < 1e-15
+        for mode, kw in (("train", dict(x=x)), ("cross", dict(x=x, z=z)), ("self", dict(z=z))):
+            m = "self_test" if mode == "self" else mode
+            ref = g["%s_K_%s" % (nm, mode)]
+            assert np.max(np.abs(k.getCovMatrix(mode=m, **kw) - ref)) <= 1e-13 * max(1.0, np.max(np.abs(ref))), (nm, mode)
+            for i in range(len(k.hyp)):
+                ref = g["%s_dK%d_%s" % (nm, i, mode)]
+                got = k.getDerMatrix(mode=m, der=i, **kw)
+                assert np.max(np.abs(got - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), (nm, i, mode)
+    with pytest.raises(Exception, match="RDFunit"):
+        ks["rbfunit"].getDerMatrix(x=x, mode="train", der=1)
+    with pytest.raises(Exception, match="covRQ"):
+        ks["rq"].getDerMatrix(x=x, mode="train", der=3)
+    assert np.all(ks["pp2"].getDerMatrix(x=x, mode="train", der=2) == 0)
+    x, y = synth_reg(300, 4)
+    for nm, k in (("rbfunit", pyGPs.cov.RBFunit(np.log(2.0))), ("rq", pyGPs.cov.RQ(np.log(2.0), 0.1, 0.3)),
+                  ("pp2", pyGPs.cov.PiecePoly(np.log(6.0), 2, 0.1))):
+        g = golden("G10_fit_%s_N300" % nm)
+        m = pyGPs.GPR()
+        m.setPrior(kernel=k)
+        m.setNoise(np.log(0.1))
+        m.setData(x, y)
+        nlZ, dnlZ, post = m.getPosterior()
+        assert relerr(nlZ, g["nlZ"]) < 1e-9, nm
+        assert relerr(post.alpha, g["alpha"]) < 1e-7 and relerr(np.diag(post.L), g["L_diag"]) < 1e-9
+        assert relerr(_flat(dnlZ), np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7, nm
+        ym, ys2, fm, fs2, lp = m.predict(g["pred_xs"])
+        assert relerr(ym, g["pred_ym"]) < 1e-8 and relerr(fs2, g["pred_fs2"]) < 1e-6

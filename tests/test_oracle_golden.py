@@ -134,3 +134,27 @@ def test_non_pd_raises_linalgerror():
         O.jitchol(np.ones((4, 4)))
     with pytest.raises(Exception, match="Wrong sizes"):
         O.solve_chol(np.eye(3), np.ones((4, 1)))
+
+
+def test_G10_rbfunit_rq_piecepoly_kernels_and_fits():
+    """the next stationary kernels (Core/cov.py:683-782, 832-869, 1304-1347)."""
+    g = golden("G10_kernels_rbfunit_rq_piecepoly")
+    x, z = g["x"], g["z"]
+    kinds = {"rbfunit": (O.RBFUNIT, 0), "rq": (O.RQ, 0), "pp0": (O.PIECEPOLY, 0), "pp1": (O.PIECEPOLY, 1),
+             "pp2": (O.PIECEPOLY, 2), "pp3": (O.PIECEPOLY, 3)}
+    for nm, (kind, para) in kinds.items():
+        hyp = g[nm + "_hyp"]
+        for mode, kw in (("train", dict(x=x)), ("cross", dict(x=x, z=z)), ("self", dict(z=z))):
+            m = "self_test" if mode == "self" else mode
+            np.testing.assert_allclose(O.cov_matrix(kind, hyp, para, mode=m, **kw), g["%s_K_%s" % (nm, mode)], rtol=1e-13, atol=1e-300)
+            for i in range(len(hyp)):
+                np.testing.assert_allclose(O.der_matrix(kind, hyp, para, mode=m, der=i, **kw), g["%s_dK%d_%s" % (nm, i, mode)],
+                                           rtol=1e-12, atol=1e-300)
+    x, y = synth_reg(300, 4)
+    for nm, kind in (("rbfunit", O.RBFUNIT), ("rq", O.RQ), ("pp2", O.PIECEPOLY)):
+        g = golden("G10_fit_%s_N300" % nm)
+        c = g["mean_hyp"][0]
+        out = O.exact_fit(kind, g["cov_hyp"], int(g["para"][0]), g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y),
+                          faithful=False)
+        assert relerr(out["nlZ"], g["nlZ"]) < 1e-11 and relerr(out["alpha"], g["alpha"]) < 1e-9
+        assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-8 and relerr(out["dnlZ_lik"], g["dnlZ_lik"]) < 1e-8
