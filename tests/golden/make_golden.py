@@ -342,7 +342,7 @@ def g10():
 CASES = {
     "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
-    "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048),
+    "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384),
 }
 
 if __name__ == "__main__":
