@@ -33,13 +33,28 @@ typedef struct pgp_factor pgp_factor; /* device-resident posterior: factor R, al
 #define PGP_COV_RBFUNIT 3 /* Core/cov.py:832-869   hyp=[log ell]                                  */
 #define PGP_COV_RQ 4      /* Core/cov.py:1304-1347 hyp=[log ell, log sf, log alpha]               */
 #define PGP_COV_PIECEPOLY 5 /* Core/cov.py:683-782 hyp=[log ell, log sf], para=v in {0,1,2,3}      */
-#define PGP_COV_NKIND 6
+#define PGP_COV_RQARD 6   /* Core/cov.py:1356-1425 hyp=[log ell_1..log ell_D, log sf, log alpha]     */
+#define PGP_COV_GABOR 7   /* Core/cov.py:392-450   hyp=[log ell, log p]  (p = exp(2 hyp1), as the reference) */
+#define PGP_COV_PERIODIC 8 /* Core/cov.py:1186-1250 hyp=[log ell, log p, log sf], 1-d inputs only    */
+#define PGP_COV_NOISE 9   /* Core/cov.py:1254-1300 hyp=[log sf]                                      */
+#define PGP_COV_CONST 10  /* Core/cov.py:941-982   hyp=[log sf]  (sf2 = exp(hyp0), as the reference) */
+#define PGP_COV_NKIND 11
+/* Sum / Product / Scale tree over non-ARD primitives (Core/cov.py:230-328), registered with
+ * pgp_set_composite and selected by kind = PGP_COV_COMPOSITE in pgp_cov / pgp_exact_fit / pgp_ep_fit.
+ * hyp is the composite's flattened list in the reference's order (cov1.hyp + cov2.hyp; [scalar] + cov.hyp). */
+#define PGP_COV_COMPOSITE 100
+/* postfix program tokens */
+#define PGP_PROG_LEAF 1    /* LEAF kind para flags first_hyp_index */
+#define PGP_PROG_SUM 2
+#define PGP_PROG_PRODUCT 3
+#define PGP_PROG_SCALE 4   /* SCALE hyp_index */
 /* modes of getCovMatrix / getDerMatrix (Core/cov.py:81-111) */
 #define PGP_MODE_TRAIN 0
 #define PGP_MODE_CROSS 1
 #define PGP_MODE_SELF_TEST 2
 /* flags */
-#define PGP_FLAG_MATERN_REFERENCE_DER 1 /* reproduce Core/cov.py:1173-1177 (derivative of K, not t) */
+#define PGP_FLAG_MATERN_REFERENCE_DER 1 /* reproduce the reference's derivative quirks: Matern Core/cov.py:1173-1177
+                                         * (derivative of K, not t); RQard :1412-1418 (length-scale derivatives) */
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 int pgp_init(int device, pgp_ctx** ctx_out);
@@ -54,6 +69,11 @@ int pgp_device_info(pgp_ctx* ctx, int* n_cu, int* sclk_mhz, double* hbm_gib, cha
  * Error codes: -3 unknown mode, -4 derivative index does not exist, -5/-7 missing x / z.        */
 int pgp_cov(pgp_ctx* ctx, int kind, int mode, int der, const double* x, int64_t n, const double* z, int64_t m,
             int64_t d, const double* hyp, int nhyp, int para, int flags, double* out);
+
+/* Composite kernels: ProductOfKernel / SumOfKernel / ScaleOfKernel (Core/cov.py:230-328).  prog is the tree in
+ * postfix order (PGP_PROG_* tokens); it stays registered in the context until replaced.  Limits: 8 leaves, 8 Scale
+ * nodes, 8 products after distributing products over sums; ARD leaves are not allowed (-13).     */
+int pgp_set_composite(pgp_ctx* ctx, const int32_t* prog, int nprog);
 
 /* ---- data residency -------------------------------------------------------------------------
  * The optimiser calls the fit hundreds of times with identical (x, y) and only hyp changing

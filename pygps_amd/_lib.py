@@ -15,6 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygps_amd.so")
 
 COV_RBF, COV_RBFARD, COV_MATERN, COV_RBFUNIT, COV_RQ, COV_PIECEPOLY = 0, 1, 2, 3, 4, 5
+COV_RQARD, COV_GABOR, COV_PERIODIC, COV_NOISE, COV_CONST = 6, 7, 8, 9, 10
+COV_COMPOSITE = 100
+PROG_LEAF, PROG_SUM, PROG_PRODUCT, PROG_SCALE = 1, 2, 3, 4
+PROG_MAX = 8                      # leaves / Scale nodes / products per device program (csrc/sqdist_tile.h)
 MODE_TRAIN, MODE_CROSS, MODE_SELF_TEST = 0, 1, 2
 FLAG_MATERN_REFERENCE_DER = 1
 STAGES = ("assemble", "potrf", "solve", "trtri", "lauum", "grad", "total")
@@ -32,6 +36,7 @@ SIGNATURES = {
     "pgp_device_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_char_p, C.c_int]),
     "pgp_cov": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _i64, _dp, _i64, _i64, _dp, C.c_int, C.c_int,
                           C.c_int, _dp]),
+    "pgp_set_composite": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int]),
     "pgp_set_data": (C.c_int, [_vp, _dp, _i64, _i64, _dp]),
     "pgp_exact_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int,
                                 C.c_int, _dp, _dp, _dp, C.POINTER(_vp)]),

@@ -68,12 +68,28 @@ class Kernel(object):
         """(kind, para, flags) of the device functor."""
         return self._kind, 0, 0
 
+    def _program(self, h0):
+        """Postfix device program of this (sub)tree whose first hyper has flat index ``h0``:
+        ``(tokens, n_leaves, n_products, n_scales)`` -- or None when a leaf cannot be part of a program."""
+        if self._kind is None or self._kind in (_lib.COV_RBFARD, _lib.COV_RQARD):
+            return None
+        kind, para, flags = self._device_params()
+        return [_lib.PROG_LEAF, int(kind), int(para), int(flags), int(h0)], 1, 1, 0
+
+    def _bind(self, ctx):
+        """Select this kernel on context ``ctx``: returns (kind, para, flags) for the C entry points."""
+        if self._kind is None:
+            raise NotImplementedError(
+                "pygps_amd: %s has no device covariance functor; there is no CPU fallback" % type(self).__name__)
+        return self._device_params()
+
     _WRONG_DER = "Wrong derivative index"
+    _BAD_PARA = "invalid kernel parameter"
 
     def _device_eval(self, x, z, mode, der):
         if mode not in _MODES:
             raise Exception("Specify the mode: 'train' or 'cross'")
-        kind, para, flags = self._device_params()
+        kind, para, flags = self._bind(_lib.ctx())
         xa = None if x is None else _lib.f64(x)
         za = None if z is None else _lib.f64(z)
         if mode == "self_test":
@@ -89,7 +105,8 @@ class Kernel(object):
         out = np.empty(shape)
         rc = _lib.load().pgp_cov(_lib.ctx(), kind, _MODES[mode], -1 if der is None else int(der), _lib.ptr(xa), n,
                                  _lib.ptr(za), m, d, _lib.ptr(hyp), len(hyp), int(para), int(flags), _lib.ptr(out))
-        _lib.check(rc, "pgp_cov", {-4: self._WRONG_DER, -11: "number of hyperparameters does not match the input dimension"})
+        _lib.check(rc, "pgp_cov", {-4: self._WRONG_DER, -11: "number of hyperparameters does not match the input dimension",
+                                   -12: self._BAD_PARA})
         return out
 
 
@@ -216,8 +233,123 @@ class PiecePoly(_DeviceKernel):
         return self._kind, int(v), 0
 
 
-# ---- composites: children are evaluated on the device, combined on the host (Core/cov.py:230-328) ----
-class _Pair(Kernel):
+class RQard(_DeviceKernel):
+    """Rational quadratic with ARD.  hyp = log_ell_list + [log_sigma, log_alpha]   (Core/cov.py:1356-1425)
+
+    The length-scale derivatives are the mathematically correct ones by default.  ``reference_compat = True``
+    reproduces what the reference returns: all-zero matrices on 'train' (a missing transpose makes cdist see one
+    1 x n point, :1415-1416) and coordinates multiplied instead of divided by ell_k on 'cross' (:1418)."""
+    _kind = _lib.COV_RQARD
+    _WRONG_DER = "Wrong derivative index in covRQard"
+
+    def _device_params(self):
+        return self._kind, 0, (_lib.FLAG_MATERN_REFERENCE_DER if self.reference_compat else 0)
+
+    def __init__(self, D=None, log_ell_list=None, log_sigma=0., log_alpha=0.):
+        if log_ell_list is None:
+            self.hyp = [0. for _ in range(D)] + [log_sigma, log_alpha]
+        else:
+            self.hyp = list(log_ell_list) + [log_sigma, log_alpha]
+        self.para = []
+
+
+class Gabor(_DeviceKernel):
+    """Gabor kernel h(t) = exp(-t^2/(2 ell^2)) cos(2 pi t / p).  hyp = [log_ell, log_p]   (Core/cov.py:392-450).
+    Like the reference, the period is p = exp(2 * log_p) (:416) and the "derivatives" are dp*K and tan(dp)*dp*K
+    (:441-445)."""
+    _kind = _lib.COV_GABOR
+    _WRONG_DER = "Wrong derivative entry in Gabor"
+
+    def __init__(self, log_ell=0., log_p=0.):
+        self.hyp = [log_ell, log_p]
+        self.para = []
+
+
+class Periodic(_DeviceKernel):
+    """Smooth periodic kernel for 1-d inputs.  hyp = [log_ell, log_p, log_sigma]   (Core/cov.py:1186-1250)"""
+    _kind = _lib.COV_PERIODIC
+    _WRONG_DER = "Wrong derivative index in covPeriodic"
+    _BAD_PARA = "periodic covariance can only be used for 1d data"
+
+    def __init__(self, log_ell=0., log_p=0., log_sigma=0.):
+        self.hyp = [log_ell, log_p, log_sigma]
+        self.para = []
+
+    def _device_eval(self, x, z, mode, der):
+        for a in (x, z):                                   # Core/cov.py:1201-1204
+            if a is not None:
+                assert np.shape(a)[1] == 1, 'periodic covariance can only be used for 1d data'
+        return super(Periodic, self)._device_eval(x, z, mode, der)
+
+
+class Noise(_DeviceKernel):
+    """White noise.  hyp = [log_sigma]   (Core/cov.py:1254-1300): s2*I on 'train', s2 where |x-z|^2 < 1e-9 on
+    'cross', zeros on 'self_test'."""
+    _kind = _lib.COV_NOISE
+    _WRONG_DER = "Wrong derivative index in covNoise"
+
+    def __init__(self, log_sigma=0.):
+        self.hyp = [log_sigma]
+        self.para = []
+
+
+class Const(_DeviceKernel):
+    """Constant kernel.  hyp = [log_sigma]   (Core/cov.py:941-982).  As in the reference the variance is
+    exp(log_sigma) (:951, not squared), the training matrix carries a 1e-10 diagonal jitter (:957) and the
+    derivative is 2*sf2 (:979)."""
+    _kind = _lib.COV_CONST
+    _WRONG_DER = "Wrong derivative entry in covConst"
+
+    def __init__(self, log_sigma=0.):
+        self.hyp = [log_sigma]
+        self.para = []
+
+
+# ---- composites (Core/cov.py:230-328) ---------------------------------------------------------------------
+# A tree whose leaves all have isotropic device functors is evaluated in ONE pass of the tile kernel as a device
+# program (sum of products of leaf functors, csrc/sqdist_tile.h CovProgram) -- in getCovMatrix/getDerMatrix and,
+# more importantly, inside Exact/EP fits and predict.  Trees with ARD leaves (or more than 8 leaves / products)
+# still offer getCovMatrix/getDerMatrix by combining the children's device-built matrices.
+class _Composite(Kernel):
+    _kind = _lib.COV_COMPOSITE
+
+    def _tokens(self):
+        pr = self._program(0)
+        if pr is None or max(pr[1:]) > _lib.PROG_MAX:
+            return None
+        return pr[0]
+
+    def _bind(self, ctx):
+        tok = self._tokens()
+        if tok is None:
+            raise NotImplementedError(
+                "pygps_amd: this composite kernel cannot run as a device program (ARD leaf, unsupported leaf, or more "
+                "than %d leaves/products); there is no CPU fallback" % _lib.PROG_MAX)
+        arr = (_lib.C.c_int32 * len(tok))(*tok)
+        _lib.check(_lib.load().pgp_set_composite(ctx, arr, len(tok)), "pgp_set_composite")
+        return _lib.COV_COMPOSITE, 0, 0
+
+    def _on_device(self):
+        return self._tokens() is not None
+
+    def getCovMatrix(self, x=None, z=None, mode=None):
+        self.checkInputGetCovMatrix(x, z, mode)
+        if self._on_device():
+            return self._device_eval(x, z, mode, None)
+        return self._host_cov(x, z, mode)
+
+    def getDerMatrix(self, x=None, z=None, mode=None, der=None):
+        self.checkInputGetDerMatrix(x, z, mode, der)
+        if der >= len(self.hyp):
+            raise Exception(self._WRONG_DER)
+        if self._on_device():
+            return self._device_eval(x, z, mode, der)
+        return self._host_der(x, z, mode, der)
+
+
+class _Pair(_Composite):
+    _op = None
+
     def __init__(self, cov1, cov2):
         self.cov1, self.cov2 = cov1, cov2
         self.para = []
@@ -233,38 +365,54 @@ class _Pair(Kernel):
         self.cov1.hyp = list(value[:n1])
         self.cov2.hyp = list(value[n1:])
 
+    def _program(self, h0):
+        a = self.cov1._program(h0)
+        b = self.cov2._program(h0 + len(self.cov1.hyp))
+        if a is None or b is None:
+            return None
+        nprod = a[2] + b[2] if self._op == _lib.PROG_SUM else a[2] * b[2]
+        return a[0] + b[0] + [self._op], a[1] + b[1], nprod, a[3] + b[3]
+
 
 class SumOfKernel(_Pair):
-    def getCovMatrix(self, x=None, z=None, mode=None):
+    """Sum of two kernels (Core/cov.py:265-296)."""
+    _op = _lib.PROG_SUM
+    _WRONG_DER = "Error: der out of range for covSum"
+
+    def _host_cov(self, x, z, mode):
         return self.cov1.getCovMatrix(x, z, mode) + self.cov2.getCovMatrix(x, z, mode)
 
-    def getDerMatrix(self, x=None, z=None, mode=None, der=None):
+    def _host_der(self, x, z, mode, der):
         n1 = len(self.cov1.hyp)
         if der < n1:
             return self.cov1.getDerMatrix(x, z, mode, der)
-        if der < n1 + len(self.cov2.hyp):
-            return self.cov2.getDerMatrix(x, z, mode, der - n1)
-        raise Exception("Error: der out of range for covSum")
+        return self.cov2.getDerMatrix(x, z, mode, der - n1)
 
 
 class ProductOfKernel(_Pair):
-    def getCovMatrix(self, x=None, z=None, mode=None):
+    """Product of two kernels (Core/cov.py:230-261)."""
+    _op = _lib.PROG_PRODUCT
+    _WRONG_DER = "Error: der out of range for covProduct"
+
+    def _host_cov(self, x, z, mode):
         return self.cov1.getCovMatrix(x, z, mode) * self.cov2.getCovMatrix(x, z, mode)
 
-    def getDerMatrix(self, x=None, z=None, mode=None, der=None):
+    def _host_der(self, x, z, mode, der):
         n1 = len(self.cov1.hyp)
         if der < n1:
             return self.cov1.getDerMatrix(x, z, mode, der) * self.cov2.getCovMatrix(x, z, mode)
-        if der < n1 + len(self.cov2.hyp):
-            return self.cov2.getDerMatrix(x, z, mode, der - n1) * self.cov1.getCovMatrix(x, z, mode)
-        raise Exception("Error: der out of range for covProduct")
+        return self.cov2.getDerMatrix(x, z, mode, der - n1) * self.cov1.getCovMatrix(x, z, mode)
 
 
-class ScaleOfKernel(Kernel):
+class ScaleOfKernel(_Composite):
+    """Scaled kernel exp(h) * k (Core/cov.py:299-328).  As in the reference, the number given to ``k * number`` IS the
+    log-space hyper h (:303), and the derivative w.r.t. h is returned as 2 * exp(h) * k (:324)."""
+    _WRONG_DER = "Error: der out of range for covScale"
+
     def __init__(self, cov, scalar):
         self.cov = cov
         self.para = []
-        self._scale = [np.log(scalar)] if scalar else [-np.inf]
+        self._scale = [scalar]
 
     @property
     def hyp(self):
@@ -276,10 +424,16 @@ class ScaleOfKernel(Kernel):
         self._scale = [value[0]]
         self.cov.hyp = list(value[1:])
 
-    def getCovMatrix(self, x=None, z=None, mode=None):
+    def _program(self, h0):
+        a = self.cov._program(h0 + 1)
+        if a is None:
+            return None
+        return a[0] + [_lib.PROG_SCALE, int(h0)], a[1], a[2], a[3] + 1
+
+    def _host_cov(self, x, z, mode):
         return np.exp(self._scale[0]) * self.cov.getCovMatrix(x, z, mode)
 
-    def getDerMatrix(self, x=None, z=None, mode=None, der=None):
+    def _host_der(self, x, z, mode, der):
         if der == 0:
-            return np.exp(self._scale[0]) * self.cov.getCovMatrix(x, z, mode)
+            return 2. * np.exp(self._scale[0]) * self.cov.getCovMatrix(x, z, mode)
         return np.exp(self._scale[0]) * self.cov.getDerMatrix(x, z, mode, der - 1)

@@ -32,13 +32,20 @@ __global__ void scale_transpose_kernel(const double* __restrict__ x, long n, int
 
 enum { MODE_SYM = 0, MODE_RECT = 1, MODE_FACTOR = 2 };
 
-template <int MODE>
+template <class COV> struct is_program { static constexpr bool value = false; };
+template <> struct is_program<CovProgram> { static constexpr bool value = true; };
+
+// COV = CovParams (one functor, the hot path) or CovProgram (Sum/Product/Scale tree; elements are evaluated in a
+// rolled loop over LDS-staged distances so that the eight leaf functors are instantiated once, not 16 times)
+template <int MODE, class COV>
 __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict__ XrT, long ldr, long n,
                                                        const double* __restrict__ XcT, long ldc, long m, int dpad,
-                                                       CovParams cp, double inv_sn2, double* __restrict__ out,
+                                                       COV cp, double inv_sn2, double* __restrict__ out,
                                                        long ldo, long ntile_c) {
     constexpr int TS = ST + 2;                      // transpose-tile row stride (16-byte aligned rows)
-    __shared__ __attribute__((aligned(16))) double sm[MODE == MODE_SYM ? ST * TS : 2 * SKC * ST];
+    constexpr bool PROG = is_program<COV>::value;
+    constexpr int SMN = MODE == MODE_SYM ? ST * TS : (PROG ? 16 * 256 : 2 * SKC * ST);
+    __shared__ __attribute__((aligned(16))) double sm[SMN];
     long ti, tj;
     if (MODE == MODE_RECT) {
         ti = blockIdx.x / ntile_c;
@@ -60,6 +67,21 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict_
 
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     double v[4][4];
+    if (PROG) {                                     // sm is free: sqdist_tile ends with a barrier
+        double* sv = sm + t;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sv[e * 256] = s[e >> 2][e & 3];
+#pragma unroll 1
+        for (int e = 0; e < 16; ++e) {
+            const int a = e >> 2, b = e & 3;
+            const long r = r0 + 4 * tr + a;
+            const long c = c0 + 2 * tc + (b & 1) + 32 * (b >> 1);
+            sv[e * 256] = cov_elem(cp, sv[e * 256], 0.0, MODE != MODE_RECT && r == c);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e >> 2][e & 3] = sv[e * 256];
+    }
+    const int ard_der = cov_ard_der(cp);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -67,15 +89,15 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict_
             const long r = r0 + 4 * tr + a;
             const long c = c0 + 2 * tc + (b & 1) + 32 * (b >> 1);
             double val;
-            if (cp.der < 0) {
-                val = cov_value(cp, s[a][b]);
+            if (PROG) {
+                val = s[a][b];
             } else {
                 double dk2 = 0.0;
-                if (cp.kind == 1 && cp.der < cp.D) {
-                    const double dd = XrT[(long)cp.der * ldr + r] - XcT[(long)cp.der * ldc + c];
+                if (ard_der >= 0) {
+                    const double dd = XrT[(long)ard_der * ldr + r] - XcT[(long)ard_der * ldc + c];
                     dk2 = dd * dd;
                 }
-                val = cov_deriv(cp, s[a][b], dk2);
+                val = cov_elem(cp, s[a][b], dk2, MODE != MODE_RECT && r == c);
             }
             if (MODE == MODE_FACTOR) {
                 if (r < n && c < n) val = val * inv_sn2 + (r == c ? 1.0 : 0.0);
@@ -151,29 +173,64 @@ int scale_transpose_launch(const double* x, long n, int d, const double* scale_d
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
-int cov_sym_launch(const double* XT, long ldp, long n, int dpad, const CovParams& cp, double* out, hipStream_t st,
+template <int MODE>
+static int cov_tile_dispatch(const CovSpec& cs, int train, unsigned nblk, hipStream_t st, const double* XrT, long ldr,
+                             long n, const double* XcT, long ldc, long m, int dpad, double inv_sn2, double* out,
+                             long ldo, long ntile_c) {
+    if (cs.prog) {
+        CovProgram pg = cs.pg;
+        for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = train;
+        hipLaunchKernelGGL((cov_tile_kernel<MODE, CovProgram>), dim3(nblk), dim3(256), 0, st, XrT, ldr, n, XcT, ldc, m,
+                           dpad, pg, inv_sn2, out, ldo, ntile_c);
+    } else {
+        CovParams cp = cs.cp;
+        cp.train = train;
+        if (cp.kind == 6 && cp.ref_der) cp.gb = train == 1 ? 0.0 : cs.ell4;       // Core/cov.py:1415-1418 as returned
+        hipLaunchKernelGGL((cov_tile_kernel<MODE, CovParams>), dim3(nblk), dim3(256), 0, st, XrT, ldr, n, XcT, ldc, m,
+                           dpad, cp, inv_sn2, out, ldo, ntile_c);
+    }
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+int cov_sym_launch(const double* XT, long ldp, long n, int dpad, const CovSpec& cs, double* out, hipStream_t st,
                    long ldo) {
     const long nt = (n + ST - 1) / ST;
     const long nblk = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL((cov_tile_kernel<MODE_SYM>), dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, XT, ldp, n,
-                       dpad, cp, 0.0, out, ldo > 0 ? ldo : n, nt);
-    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+    return cov_tile_dispatch<MODE_SYM>(cs, 1, (unsigned)nblk, st, XT, ldp, n, XT, ldp, n, dpad, 0.0, out,
+                                       ldo > 0 ? ldo : n, nt);
 }
 
 int cov_rect_launch(const double* XrT, long ldr, long n, const double* XcT, long ldc, long m, int dpad,
-                    const CovParams& cp, double* out, long ldo, hipStream_t st) {
+                    const CovSpec& cs, double* out, long ldo, hipStream_t st) {
     const long ntr = (n + ST - 1) / ST, ntc = (m + ST - 1) / ST;
-    hipLaunchKernelGGL((cov_tile_kernel<MODE_RECT>), dim3((unsigned)(ntr * ntc)), dim3(256), 0, st, XrT, ldr, n, XcT,
-                       ldc, m, dpad, cp, 0.0, out, ldo, ntc);
-    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+    return cov_tile_dispatch<MODE_RECT>(cs, 0, (unsigned)(ntr * ntc), st, XrT, ldr, n, XcT, ldc, m, dpad, 0.0, out, ldo,
+                                        ntc);
 }
 
-int cov_factor_launch(const double* XT, long ldp, long n, long np, int dpad, const CovParams& cp, double inv_sn2,
+int cov_factor_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double inv_sn2,
                       double* Bf, long ldf, hipStream_t st) {
     const long nt = np / ST;
     const long nblk = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL((cov_tile_kernel<MODE_FACTOR>), dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, XT, ldp, n,
-                       dpad, cp, inv_sn2, Bf, ldf, nt);
+    return cov_tile_dispatch<MODE_FACTOR>(cs, 1, (unsigned)nblk, st, XT, ldp, n, XT, ldp, n, dpad, inv_sn2, Bf, ldf, nt);
+}
+
+// k(z,z) and its derivatives at zero distance ('self_test' mode): one evaluation of the functor
+template <class COV>
+__global__ void cov_self_kernel(COV cp, int same, double* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = cov_elem(cp, 0.0, 0.0, same != 0);
+}
+
+// train = 1: a diagonal entry of the training matrix; train = 2: 'self_test'
+int cov_self_launch(const CovSpec& cs, int train, double* out_dev, hipStream_t st) {
+    if (cs.prog) {
+        CovProgram pg = cs.pg;
+        for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = train;
+        hipLaunchKernelGGL((cov_self_kernel<CovProgram>), dim3(1), dim3(64), 0, st, pg, train == 1, out_dev);
+    } else {
+        CovParams cp = cs.cp;
+        cp.train = train;
+        hipLaunchKernelGGL((cov_self_kernel<CovParams>), dim3(1), dim3(64), 0, st, cp, train == 1, out_dev);
+    }
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 

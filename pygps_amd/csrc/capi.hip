@@ -148,43 +148,168 @@ int pgp_profile_reset(pgp_ctx* c) {
 
 static int matern_d(int para) { return (para == 1 || para == 3 || para == 5 || para == 7) ? para : 3; }
 
-// per-coordinate scales of the reference: RBF x/ell (cov.py:804); RBFard x*(1/ell_k) (:893-899);
-// Matern sqrt(d)*x/ell (:1141)
-int fill_scale(int kind, const double* hyp, int nhyp, int para, long d, std::vector<double>& sc) {
-    sc.assign(d, 1.0);
-    if (kind == PGP_COV_RBF) {
-        if (nhyp != 2) return -10;
-        const double ell = exp(hyp[0]);
-        for (auto& s : sc) s = 1.0 / ell;
-    } else if (kind == PGP_COV_RBFARD) {
-        if (nhyp != d + 1) return -10;
-        for (long k = 0; k < d; ++k) sc[k] = 1.0 / exp(hyp[k]);
-    } else if (kind == PGP_COV_MATERN) {
-        if (nhyp != 2) return -10;
-        const double ell = exp(hyp[0]);
-        for (auto& s : sc) s = sqrt((double)matern_d(para)) / ell;
-    } else if (kind == PGP_COV_RBFUNIT || kind == PGP_COV_RQ || kind == PGP_COV_PIECEPOLY) {
-        if (nhyp != (kind == PGP_COV_RBFUNIT ? 1 : kind == PGP_COV_RQ ? 3 : 2)) return -10;
-        if (kind == PGP_COV_PIECEPOLY && (para < 0 || para > 3)) return -12;     // Core/cov.py:737 assert
-        const double ell = exp(hyp[0]);                                          // cov.py:847, 1318, 742
-        for (auto& s : sc) s = 1.0 / ell;
-    } else {
-        return -2;
+// number of hyperparameters of a primitive kernel (-1: unknown kind)
+static int leaf_nhyp(int kind, long d) {
+    switch (kind) {
+        case PGP_COV_RBF: case PGP_COV_MATERN: case PGP_COV_PIECEPOLY: case PGP_COV_GABOR: return 2;
+        case PGP_COV_RBFARD: return (int)d + 1;
+        case PGP_COV_RQARD: return (int)d + 2;
+        case PGP_COV_RBFUNIT: case PGP_COV_NOISE: case PGP_COV_CONST: return 1;
+        case PGP_COV_RQ: case PGP_COV_PERIODIC: return 3;
+        default: return -1;
+    }
+}
+
+// One primitive functor.  iso = isotropic factor c with (scaled distance)^2 = c^2 |x-z|^2 of the reference:
+// RBF x/ell (cov.py:804); Matern sqrt(d) x/ell (:1141); RBFunit :847, RQ :1318, PiecePoly :742, Gabor :420 x/ell;
+// Periodic, Noise, Const take the raw distance.  ARD kinds (RBFard x*(1/ell_k) :893-899, RQard :1378) have no iso.
+static int make_leaf(int kind, const double* hyp, int nhyp, int para, int flags, long d, CovParams& cp, double& iso) {
+    const int want = leaf_nhyp(kind, d);
+    if (want < 0) return -2;
+    if (nhyp != want) return -11;
+    cp = CovParams{};
+    cp.kind = kind; cp.der = -1; cp.md = matern_d(para); cp.D = (int)d; cp.train = 1;
+    cp.ref_der = (flags & PGP_FLAG_MATERN_REFERENCE_DER) ? 1 : 0;
+    cp.sf2 = 1.0; cp.alpha = 1.0; cp.ppv = 0; cp.ppj = 1.0; cp.ga = 0.0; cp.gb = 0.0;
+    iso = 1.0;
+    switch (kind) {
+        case PGP_COV_RBF: iso = 1.0 / exp(hyp[0]); cp.sf2 = exp(2.0 * hyp[1]); break;
+        case PGP_COV_RBFARD: cp.sf2 = exp(2.0 * hyp[d]); break;
+        case PGP_COV_MATERN: iso = sqrt((double)cp.md) / exp(hyp[0]); cp.sf2 = exp(2.0 * hyp[1]); break;
+        case PGP_COV_RBFUNIT: iso = 1.0 / exp(hyp[0]); break;
+        case PGP_COV_RQ: iso = 1.0 / exp(hyp[0]); cp.sf2 = exp(2.0 * hyp[1]); cp.alpha = exp(hyp[2]); break;
+        case PGP_COV_PIECEPOLY:
+            if (para < 0 || para > 3) return -12;                                // Core/cov.py:737 assert
+            iso = 1.0 / exp(hyp[0]); cp.sf2 = exp(2.0 * hyp[1]);
+            cp.ppv = para; cp.ppj = floor(0.5 * (double)d) + para + 1.0;
+            break;
+        case PGP_COV_RQARD: cp.sf2 = exp(2.0 * hyp[d]); cp.alpha = exp(hyp[d + 1]); cp.gb = 1.0; break;
+        case PGP_COV_GABOR: {
+            const double ell = exp(hyp[0]), p = exp(2.0 * hyp[1]);               // cov.py:415-416
+            iso = 1.0 / ell; cp.ga = 2.0 * M_PI * ell / p;
+            break;
+        }
+        case PGP_COV_PERIODIC:
+            if (d != 1) return -12;                                              // cov.py:1201-1204 asserts
+            cp.gb = 1.0 / exp(hyp[0]); cp.ga = M_PI / exp(hyp[1]); cp.sf2 = exp(2.0 * hyp[2]);
+            break;
+        case PGP_COV_NOISE: cp.sf2 = exp(2.0 * hyp[0]); break;                   // cov.py:1268
+        case PGP_COV_CONST: cp.sf2 = exp(hyp[0]); break;                         // cov.py:951 (not squared)
     }
     return PGP_OK;
 }
 
-CovParams make_cp(int kind, const double* hyp, int nhyp, int para, int flags, int der, long d) {
-    CovParams cp;
-    cp.kind = kind; cp.der = der; cp.md = matern_d(para);
-    cp.ref_der = (flags & PGP_FLAG_MATERN_REFERENCE_DER) ? 1 : 0;
-    cp.D = (int)d;
-    cp.sf2 = exp(2.0 * hyp[nhyp - 1]);
-    cp.alpha = 1.0; cp.ppv = 0; cp.ppj = 1.0;
-    if (kind == PGP_COV_RBFUNIT) cp.sf2 = 1.0;
-    if (kind == PGP_COV_RQ) { cp.sf2 = exp(2.0 * hyp[1]); cp.alpha = exp(hyp[2]); }
-    if (kind == PGP_COV_PIECEPOLY) { cp.ppv = para; cp.ppj = floor(0.5 * (double)d) + para + 1.0; }
-    return cp;
+// Describe the covariance function of one call.  kind < PGP_COV_NKIND: a primitive; PGP_COV_COMPOSITE: the
+// postfix program registered with pgp_set_composite, expanded here into a sum of products.
+int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int flags, int der, long d, CovSpec& cs) {
+    cs = CovSpec{};
+    if (!hyp && nhyp > 0) return -10;
+    if (kind >= PGP_COV_GABOR && kind < PGP_COV_NKIND) {
+        // trigonometric / index-dependent primitives run as one-leaf programs (see sqdist_tile.h cov_value<EXT>)
+        CovProgram& P = cs.pg;
+        P = CovProgram{};
+        double iso;
+        CHK(make_leaf(kind, hyp, nhyp, para, flags, d, P.leaf[0], iso));
+        if (der >= nhyp) return -4;
+        P.nleaf = 1; P.nterm = 1; P.nscale = 0; P.is2[0] = iso * iso; P.hyp0[0] = 0; P.nh[0] = nhyp;
+        P.coef[0] = 1.0; P.tl[0] = 1u; P.ts[0] = 0u;
+        P.der = der; P.der_leaf = der >= 0 ? 0 : -1; P.der_j = der; P.der_scale = -1;
+        cs.prog = true; cs.scale.assign(d, 1.0); cs.ncov = nhyp; cs.nder = nhyp;
+        return PGP_OK;
+    }
+    if (kind != PGP_COV_COMPOSITE) {
+        double iso;
+        CHK(make_leaf(kind, hyp, nhyp, para, flags, d, cs.cp, iso));
+        cs.scale.assign(d, iso);
+        if (kind == PGP_COV_RBFARD || kind == PGP_COV_RQARD)
+            for (long k = 0; k < d; ++k) cs.scale[k] = 1.0 / exp(hyp[k]);
+        cs.ncov = nhyp;
+        // Matern and PiecePoly accept der == 2 ("derivative w.r.t. the order" = zeros, cov.py:1178, 778)
+        cs.nder = (kind == PGP_COV_MATERN || kind == PGP_COV_PIECEPOLY) ? 3 : nhyp;
+        if (der >= cs.nder) return -4;
+        cs.cp.der = der;
+        cs.ell4 = (kind == PGP_COV_RQARD && cs.cp.ref_der && der >= 0 && der < d) ? exp(4.0 * hyp[der]) : 1.0;
+        return PGP_OK;
+    }
+    const std::vector<int>& tok = c->composite;
+    if (tok.empty()) return -2;
+    struct Term { unsigned leaves, scales; };
+    std::vector<std::vector<Term>> stack;
+    CovProgram& P = cs.pg;
+    P = CovProgram{};
+    P.der = der; P.der_leaf = P.der_j = P.der_scale = -1;
+    int used = 0;
+    for (size_t i = 0; i < tok.size();) {
+        const int op = tok[i];
+        if (op == PGP_PROG_LEAF) {
+            if (i + 5 > tok.size()) return -2;
+            const int lk = tok[i + 1], lpara = tok[i + 2], lflags = tok[i + 3], h0 = tok[i + 4];
+            i += 5;
+            if (lk == PGP_COV_RBFARD || lk == PGP_COV_RQARD) return -13;          // ARD leaves need their own distance
+            const int nh = leaf_nhyp(lk, d);
+            if (nh < 0) return -2;
+            if (h0 < 0 || h0 + nh > nhyp) return -11;
+            if (P.nleaf >= CP_MAXLEAF) return -13;
+            double iso;
+            CHK(make_leaf(lk, hyp + h0, nh, lpara, lflags, d, P.leaf[P.nleaf], iso));
+            P.is2[P.nleaf] = iso * iso; P.hyp0[P.nleaf] = h0; P.nh[P.nleaf] = nh;
+            if (der >= h0 && der < h0 + nh) { P.der_leaf = P.nleaf; P.der_j = der - h0; }
+            stack.push_back({Term{1u << P.nleaf, 0u}});
+            ++P.nleaf; used += nh;
+        } else if (op == PGP_PROG_SUM || op == PGP_PROG_PRODUCT) {
+            ++i;
+            if (stack.size() < 2) return -2;
+            std::vector<Term> b = stack.back(); stack.pop_back();
+            std::vector<Term> a = stack.back(); stack.pop_back();
+            std::vector<Term> r;
+            if (op == PGP_PROG_SUM) { r = a; r.insert(r.end(), b.begin(), b.end()); }
+            else for (const Term& x : a) for (const Term& y : b) r.push_back(Term{x.leaves | y.leaves, x.scales | y.scales});
+            if (r.size() > (size_t)CP_MAXTERM) return -13;
+            stack.push_back(r);
+        } else if (op == PGP_PROG_SCALE) {
+            if (i + 1 >= tok.size()) return -2;
+            const int h = tok[i + 1];
+            i += 2;
+            if (stack.empty()) return -2;
+            if (h < 0 || h >= nhyp) return -11;
+            if (P.nscale >= CP_MAXSCALE) return -13;
+            for (Term& t : stack.back()) t.scales |= 1u << P.nscale;
+            P.shyp[P.nscale] = h;
+            if (der == h) P.der_scale = P.nscale;
+            ++P.nscale; ++used;
+        } else {
+            return -2;
+        }
+    }
+    if (stack.size() != 1 || used != nhyp) return -11;
+    P.nterm = (int)stack[0].size();
+    for (int t = 0; t < P.nterm; ++t) {
+        P.tl[t] = stack[0][t].leaves; P.ts[t] = stack[0][t].scales;
+        double cf = 1.0;
+        for (int k = 0; k < P.nscale; ++k)
+            if ((P.ts[t] >> k) & 1u) cf *= exp(hyp[P.shyp[k]]);                   // cov.py:315 sf2 = exp(hyp[0])
+        P.coef[t] = cf;
+    }
+    if (der >= nhyp) return -4;
+    cs.prog = true;
+    cs.scale.assign(d, 1.0);
+    cs.ncov = nhyp; cs.nder = nhyp;
+    cs.cp = CovParams{};
+    return PGP_OK;
+}
+
+// value of the functor at zero distance: train = 1 -> K_ii (training diagonal), train = 2 -> k(z,z) of 'self_test'
+int cov_point_value(pgp_ctx* c, const CovSpec& cs, int train, double* out) {
+    if (!cs.prog && cs.cp.der < 0) {          // every functor primitive has k(x,x) = sf2 (RBFunit: sf2 = 1)
+        (void)train;
+        *out = cs.cp.sf2;
+        return PGP_OK;
+    }
+    double* dv = c->scal + 6;
+    CHK(cov_self_launch(cs, train, dv, c->st));
+    HIP_TRY(hipMemcpyAsync(out, dv, sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    return PGP_OK;
 }
 
 // upload host x (n,d) scaled+transposed into a fresh device buffer XsT (dpad x ldp)
@@ -512,6 +637,13 @@ int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F) {
 
 extern "C" {
 
+int pgp_set_composite(pgp_ctx* c, const int32_t* prog, int nprog) {
+    if (!c) return -1;
+    if (nprog < 0 || (nprog > 0 && !prog)) return -2;
+    c->composite.assign(prog, prog + nprog);
+    return PGP_OK;
+}
+
 int pgp_set_data(pgp_ctx* c, const double* x, int64_t n, int64_t d, const double* y) {
     if (!c) return -1;
     if (!x) return -2;
@@ -541,14 +673,16 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
                   double* dnlZ_out, pgp_factor** factor_out) {
     if (!c) return -1;
     if (c->n <= 0) return -1;
-    if (kind < 0 || kind >= PGP_COV_NKIND) return -2;
     if (!covhyp) return -3;
     if (want < 1 || want > 3) return -11;
     HIP_TRY(hipSetDevice(c->device));
     const long n = c->n, d = c->d, np = c->np, ldf = c->ldf;
-    std::vector<double> sc;
-    CHK(fill_scale(kind, covhyp, ncov, para, d, sc));
+    CovSpec cp;
+    { const int rc = make_spec(c, kind, covhyp, ncov, para, flags, -1, d, cp); if (rc != PGP_OK) return rc == -11 ? -10 : rc; }
+    const std::vector<double>& sc = cp.scale;
     CHK(ensure_workspace(c, np));
+    double kss = 0.0;
+    if (factor_out) CHK(cov_point_value(c, cp, 2, &kss));
     const long need = std::max(hadamard_partial_count(np, ncov), 32L * np);       // also the partials of upper_matvec
     if (want >= 3 && c->partial_cap < need) {
         if (c->partial) (void)hipFree(c->partial);
@@ -556,7 +690,6 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         c->partial_cap = need;
     }
     const double sn2 = exp(2.0 * log_sn);
-    CovParams cp = make_cp(kind, covhyp, ncov, para, flags, -1, d);
     double* F = nullptr;
     CHK(alloc_factor_buffer(c, np, ldf, &F));
     FactorGuard fguard(c, F, (size_t)ldf * np * sizeof(double));       // back to the pool on every early return
@@ -655,8 +788,8 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     }
     if (factor_out) {
         pgp_factor* f = new pgp_factor();
-        f->n = n; f->np = np; f->ldf = ldf; f->F = fguard.release(); f->dpad = c->dpad; f->d = (int)d; f->cp = cp;
-        f->sn2 = sn2; f->sw = 1.0 / sqrt(sn2); f->scale = sc; f->Wd = nullptr;
+        f->n = n; f->np = np; f->ldf = ldf; f->F = fguard.release(); f->dpad = c->dpad; f->d = (int)d; f->cs = cp; f->kss = kss;
+        f->sn2 = sn2; f->sw = 1.0 / sqrt(sn2); f->Wd = nullptr;
         HIP_TRY(hipMalloc((void**)&f->alpha, np * sizeof(double)));
         HIP_TRY(hipMemsetAsync(f->alpha, 0, np * sizeof(double), st));
         HIP_TRY(hipMemcpyAsync(f->alpha, alpha_h.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
@@ -700,44 +833,26 @@ void pgp_factor_free(pgp_ctx* c, pgp_factor* f) {
 int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n, const double* z, int64_t m,
             int64_t d, const double* hyp, int nhyp, int para, int flags, double* out) {
     if (!c) return -1;
-    if (kind < 0 || kind >= PGP_COV_NKIND) return -2;
     if (mode < 0 || mode > 2) return -3;
     if (!hyp) return -10;
     if (!out) return -14;
     if (mode != PGP_MODE_SELF_TEST && !x) return -5;
     if (mode != PGP_MODE_TRAIN && !z) return -7;
     if (d <= 0) return -9;
-    {
-        const int want_nhyp = kind == PGP_COV_RBFARD ? (int)d + 1 : kind == PGP_COV_RBFUNIT ? 1 : kind == PGP_COV_RQ ? 3 : 2;
-        if (nhyp != want_nhyp) return -11;
-    }
-    // Matern and PiecePoly accept der == 2 ("derivative w.r.t. the order" = zeros, cov.py:1178, 778)
-    const int nder = (kind == PGP_COV_MATERN || kind == PGP_COV_PIECEPOLY) ? 3 : nhyp;
-    if (der >= nder) return -4;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->st;
-    CovParams cp = make_cp(kind, hyp, nhyp, para, flags, der, d);
+    CovSpec cp;
+    CHK(make_spec(c, kind, hyp, nhyp, para, flags, der, d, cp));
     if (mode == PGP_MODE_SELF_TEST) {
-        // A = 0: value sf2*f(0); derivatives per Core/cov.py:815-817, 924-925, 1163-1177
-        double val;
-        if (der < 0) val = cp.sf2;                                        // every kernel here: k(x,x) = sf2
-        else if (kind == PGP_COV_MATERN && cp.ref_der && der < 2) {
-            const double K = cp.sf2;                                      // matern at t = 0, then the cov.py:1173 quirk
-            auto poly = [&](double t) { switch (cp.md) { case 1: return 1.0; case 3: return 1.0 + t;
-                case 5: return 1.0 + t + t * t / 3.0; default: return 1.0 + t + 2.0 * t * t / 5.0 + t * t * t / 15.0; } };
-            auto dpoly = [&](double t) { switch (cp.md) { case 1: return 1.0; case 3: return t;
-                case 5: return (t + t * t) / 3.0; default: return (t + 3.0 * t * t + t * t * t) / 15.0; } };
-            val = der == 0 ? cp.sf2 * dpoly(K) * K * exp(-K) : 2.0 * cp.sf2 * poly(K) * exp(-K);
-        } else {
-            // length-scale-type and shape derivatives vanish at zero distance; the magnitude derivative is 2 sf2
-            const int sf_index = kind == PGP_COV_RBFARD ? (int)d : kind == PGP_COV_RBFUNIT ? -1 : 1;
-            val = der == sf_index ? 2.0 * cp.sf2 : 0.0;
-        }
+        // zero distance: the functor itself gives value and derivatives (Core/cov.py:815-817, 924-925, 1163-1177,
+        // SURVEY Q6), including the Matern derivative quirk and Noise = 0 on 'self_test' (cov.py:1271)
+        CHK(ensure_workspace(c, 128));
+        double val = 0.0;
+        CHK(cov_point_value(c, cp, 2, &val));
         for (int64_t i = 0; i < m; ++i) out[i] = val;
         return PGP_OK;
     }
-    std::vector<double> sc;
-    CHK(fill_scale(kind, hyp, nhyp, para, d, sc));
+    const std::vector<double>& sc = cp.scale;
     const int dpad = (int)round_up(d, SKC);
     const long ldr = round_up(n, 128), ldc = (mode == PGP_MODE_CROSS) ? round_up(m, 128) : 0;
     const long mm = (mode == PGP_MODE_CROSS) ? m : n;

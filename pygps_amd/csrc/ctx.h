@@ -23,15 +23,16 @@ struct pgp_factor {
     double* XsT;          // dpad x np scaled coordinates used for this fit
     double* Wd;           // np x 128 : inverted diagonal blocks (lazy, for predict)
     int dpad, d;
-    CovParams cp;
+    CovSpec cs;           // covariance functor / program of this fit (predict re-evaluates it in 'cross' mode)
+    double kss = 0.0;     // k(z,z) of 'self_test' mode
     double sn2;
     double sw;            // sW entries (1/sqrt(sn2)) for Exact
     double* sWv = nullptr; // per-point sW (EP); nullptr for Exact
-    std::vector<double> scale;
 };
 
 struct pgp_ctx {
     int device = 0;
+    std::vector<int> composite;         // postfix program of kind PGP_COV_COMPOSITE (pgp_set_composite)
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
@@ -138,8 +139,8 @@ struct FactorGuard {
 
 void prof_collect(pgp_ctx* c);
 static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
-int fill_scale(int kind, const double* hyp, int nhyp, int para, long d, std::vector<double>& sc);
-CovParams make_cp(int kind, const double* hyp, int nhyp, int para, int flags, int der, long d);
+int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int flags, int der, long d, CovSpec& cs);
+int cov_point_value(pgp_ctx* c, const CovSpec& cs, int train, double* out);
 int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse = false);
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);
 int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ldw, double* T, long np);

@@ -160,16 +160,19 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                           pgp_factor** factor_out) {
     if (!c) return -1;
     if (c->n <= 0) return -1;
-    if (kind < 0 || kind >= PGP_COV_NKIND) return -2;
     if (!covhyp) return -3;
     if (!ttau_io || !tnu_io) return -12;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->st;
     const long n = c->n, d = c->d, np = c->np, ldf = c->ldf;
-    std::vector<double> sc;
-    CHK(fill_scale(kind, covhyp, ncov, para, d, sc));
+    CovSpec cp;
+    { const int rc = make_spec(c, kind, covhyp, ncov, para, flags, -1, d, cp); if (rc != PGP_OK) return rc == -11 ? -10 : rc; }
+    const std::vector<double>& sc = cp.scale;
     CHK(ensure_workspace(c, np));
-    CovParams cp = make_cp(kind, covhyp, ncov, para, flags, -1, d);
+    double kdiag = 0.0;                               // K_ii, identical for every training point (stationary kernels)
+    CHK(cov_point_value(c, cp, 1, &kdiag));
+    double kss = 0.0;
+    CHK(cov_point_value(c, cp, 2, &kss));
     const long need = hadamard_partial_count(np, ncov);
     if (want >= 3 && c->partial_cap < need) {
         if (c->partial) (void)hipFree(c->partial);
@@ -200,16 +203,16 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     // ---- K (full symmetric, padded with zeros) --------------------------------------------------------
     EP_TRY(upload_scaled(c, c->x_dev, n, d, sc, c->XsT, np, c->dpad, c->scale_dev));
     EP_TRY(cov_sym_launch(c->XsT, np, n, c->dpad, cp, w.Kd, st, np));
-    std::vector<double> m(n, 0.0), y(n), ttau(n, 0.0), tnu(n, 0.0), mu(n, 0.0), dsig(n, cp.sf2);
+    std::vector<double> m(n, 0.0), y(n), ttau(n, 0.0), tnu(n, 0.0), mu(n, 0.0), dsig(n, kdiag);
     if (mvec) memcpy(m.data(), mvec, n * sizeof(double));
     HIP_TRY(hipMemcpyAsync(y.data(), c->y_dev, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(w.m_d, m.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    // nlZ0 = -sum lik(y, m, diag K)  (inf.py:737); diag K = sf2 for the three stationary kernels
+    // nlZ0 = -sum lik(y, m, diag K)  (inf.py:737)
     double nlZ0 = 0.0;
     for (long i = 0; i < n; ++i) {
         double lZ;
-        erf_ep_moments(y[i], m[i], cp.sf2, &lZ, nullptr, nullptr);
+        erf_ep_moments(y[i], m[i], kdiag, &lZ, nullptr, nullptr);
         nlZ0 -= lZ;
     }
     double nlZ = nlZ0;
@@ -301,8 +304,8 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     if (c->prof) prof_collect(c);
     if (factor_out) {
         pgp_factor* f = new pgp_factor();
-        f->n = n; f->np = np; f->ldf = ldf; f->F = w.F; f->dpad = c->dpad; f->d = (int)d; f->cp = cp; f->sn2 = 1.0;
-        f->sw = 1.0; f->scale = sc; f->Wd = nullptr;
+        f->n = n; f->np = np; f->ldf = ldf; f->F = w.F; f->dpad = c->dpad; f->d = (int)d; f->cs = cp; f->kss = kss; f->sn2 = 1.0;
+        f->sw = 1.0; f->Wd = nullptr;
         HIP_TRY(hipMalloc((void**)&f->alpha, np * sizeof(double)));
         HIP_TRY(hipMemsetAsync(f->alpha, 0, np * sizeof(double), st));
         HIP_TRY(hipMemcpyAsync(f->alpha, alpha.data(), n * sizeof(double), hipMemcpyHostToDevice, st));

@@ -85,9 +85,16 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
                     const double K = cov_value(cp, s[a][bq]);
                     w[a][bq] = wq * K;
                     g1 += 2.0 * wq * K;                                    // d/d log sf
+                } else if (cp.kind == 6) {                                 // RQard (Core/cov.py:1412-1425)
+                    const double Kp = 1.0 + 0.5 * s[a][bq] / cp.alpha;
+                    const double lk = log(Kp);
+                    const double Ka = cp.sf2 * exp(-cp.alpha * lk);
+                    w[a][bq] = cp.ref_der ? 0.0 : wq * Ka / Kp;         // compat: zero length-scale gradient (cov.py:1415)
+                    g1 = fma(wq, 2.0 * Ka, g1);
+                    g2 = fma(wq, Ka * (0.5 * s[a][bq] / Kp - cp.alpha * lk), g2);
                 } else {
                     double d0, d1, d2;
-                    cov_deriv_all(cp, s[a][bq], d0, d1, d2);
+                    cov_deriv_all(cp, s[a][bq], d0, d1, d2, cc == rr);
                     g0 = fma(wq, d0, g0);
                     g1 = fma(wq, d1, g1);
                     g2 = fma(wq, d2, g2);
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
         }
     }
     double* out = partial + b * (long)(ncov + 1);
-    if (cp.kind == 1) {
+    if (cov_is_ard(cp)) {
         // ARD length-scales: G_k = sum_rc w_rc (xs_rk - xs_ck)^2, 16 coordinates per staged slab
         double* xr = sm;
         double* xc = sm + SKC * ST;
@@ -138,7 +145,12 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
         }
         const double t1 = block_sum(g1, red);
         const double t2 = block_sum(tq, red);
-        if (t == 0) { out[cp.D] = t1; out[ncov] = t2; }
+        const double t3 = block_sum(g2, red);
+        if (t == 0) {
+            out[cp.D] = t1;
+            if (cp.kind == 6) out[cp.D + 1] = t3;
+            out[ncov] = t2;
+        }
     } else {
         const double t0 = block_sum(g0, red);
         const double t1 = block_sum(g1, red);
@@ -151,6 +163,106 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
             out[ncov] = t3;
         }
     }
+}
+
+// Same reduction for a composite program: per element the leaf values, their (up to three) derivatives and the
+// chain-rule weights through the Sum/Product/Scale tree.  Elements run in a rolled loop over LDS-staged distances
+// so that the leaf functors are instantiated once.
+__global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __restrict__ XT, long ldp, long n, int dpad,
+                                                            CovProgram P, int ncov, double inv_sn2, double sn2,
+                                                            const double* __restrict__ Binv, long ldb,
+                                                            const double* __restrict__ alpha,
+                                                            const double* __restrict__ wv,
+                                                            double* __restrict__ partial, long nt) {
+    __shared__ __attribute__((aligned(16))) double sm[16 * 256];
+    __shared__ double red[4];
+    const long b = blockIdx.x;
+    long r = (long)(((2.0 * nt + 1.0) - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)b)) * 0.5);
+    if (r < 0) r = 0;
+    while (r > 0 && r * nt - r * (r - 1) / 2 > b) --r;
+    while ((r + 1) * nt - (r + 1) * r / 2 <= b) ++r;
+    const long ti = r, tj = ti + (b - (r * nt - r * (r - 1) / 2));
+    const long r0 = ti * ST, c0 = tj * ST;
+    double s[4][4];
+    sqdist_tile(XT, ldp, r0, XT, ldp, c0, dpad, sm, s);
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    double* sv = sm + t;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sv[e * 256] = s[e >> 2][e & 3];
+
+    double gl[CP_MAXLEAF][3], gs[CP_MAXSCALE], tq = 0.0;
+#pragma unroll
+    for (int l = 0; l < CP_MAXLEAF; ++l) gl[l][0] = gl[l][1] = gl[l][2] = 0.0;
+#pragma unroll
+    for (int k = 0; k < CP_MAXSCALE; ++k) gs[k] = 0.0;
+
+#pragma unroll 1
+    for (int e = 0; e < 16; ++e) {
+        const int a = e >> 2, bq = e & 3;
+        const long rr = r0 + 4 * tr + a;
+        const long cc = c0 + 2 * tc + (bq & 1) + 32 * (bq >> 1);
+        double wt = (cc > rr) ? 2.0 : (cc == rr ? 1.0 : 0.0);
+        if (rr >= n || cc >= n) wt = 0.0;
+        if (wt == 0.0) continue;
+        const double wr = wv ? wv[rr] : inv_sn2, wc = wv ? wv[cc] : 1.0;
+        const double q = Binv[rr * ldb + cc] * (wr * wc) - alpha[rr] * alpha[cc];
+        const double wq = wt * q;
+        if (cc == rr) tq += sn2 * q;
+        const double r2 = sv[e * 256];
+        const bool same = cc == rr;
+        double v[CP_MAXLEAF], d[CP_MAXLEAF][3], T[CP_MAXTERM];
+#pragma unroll
+        for (int l = 0; l < CP_MAXLEAF; ++l) {
+            v[l] = 1.0; d[l][0] = d[l][1] = d[l][2] = 0.0;
+            if (l < P.nleaf) {
+                const double sl = r2 * P.is2[l];
+                v[l] = cov_value<true>(P.leaf[l], sl, same);
+                cov_deriv_all<true>(P.leaf[l], sl, d[l][0], d[l][1], d[l][2], same);
+            }
+        }
+        prog_terms(P, v, T);
+#pragma unroll
+        for (int l = 0; l < CP_MAXLEAF; ++l) {
+            if (l < P.nleaf) {
+                const double wl = wq * prog_leaf_weight(P, v, l);
+                gl[l][0] = fma(wl, d[l][0], gl[l][0]);
+                gl[l][1] = fma(wl, d[l][1], gl[l][1]);
+                gl[l][2] = fma(wl, d[l][2], gl[l][2]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CP_MAXSCALE; ++k) {
+            if (k < P.nscale) {
+                double acc = 0.0;
+#pragma unroll
+                for (int tt = 0; tt < CP_MAXTERM; ++tt)
+                    if ((P.ts[tt] >> k) & 1u) acc += T[tt];
+                gs[k] = fma(wq, 2.0 * acc, gs[k]);
+            }
+        }
+    }
+    double* out = partial + b * (long)(ncov + 1);
+#pragma unroll
+    for (int l = 0; l < CP_MAXLEAF; ++l) {
+        if (l < P.nleaf) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j < P.nh[l]) {
+                    const double tot = block_sum(gl[l][j], red);
+                    if (t == 0) out[P.hyp0[l] + j] = tot;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CP_MAXSCALE; ++k) {
+        if (k < P.nscale) {
+            const double tot = block_sum(gs[k], red);
+            if (t == 0) out[P.shyp[k]] = tot;
+        }
+    }
+    const double tt = block_sum(tq, red);
+    if (t == 0) out[ncov] = tt;
 }
 
 // out[h] = sum_b partial[b*nacc + h], fixed order; one block per h
@@ -329,13 +441,22 @@ int row_scale_launch(double* A, long lda, long nrows, long ncols, const double* 
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
-int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovParams& cp, int ncov,
+int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, int ncov,
                            double sn2, const double* Binv, long ldb, const double* alpha, double* partial,
                            double* out_dev, hipStream_t st, const double* wv) {
     const long nt = np / ST;
     const long nblk = nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(hadamard_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, cp, ncov,
-                       1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
+    if (cs.prog) {
+        CovProgram pg = cs.pg;
+        for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = 1;
+        hipLaunchKernelGGL(hadamard_prog_kernel, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
+                           1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
+    } else {
+        CovParams cp = cs.cp;
+        cp.train = 1;
+        hipLaunchKernelGGL(hadamard_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, cp, ncov,
+                           1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
+    }
     hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)(ncov + 1)), dim3(256), 0, st, partial, nblk, ncov + 1,
                        out_dev);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;

@@ -3,6 +3,7 @@
 #include "common.h"
 
 struct CovParams;
+struct CovSpec;
 
 // panel.hip
 constexpr long PACK_DOUBLES = 36 * 256;   // per-leaf packed operand image: 28 strictly-lower L blocks + 8 inverted pivot blocks
@@ -18,16 +19,17 @@ int gather_strided_launch(const double* src, long stride, long n, double* dst, h
 // assemble.hip
 int scale_transpose_launch(const double* x, long n, int d, const double* scale_dev, double* XsT, long ldp, int dpad,
                            hipStream_t st);
-int cov_sym_launch(const double* XT, long ldp, long n, int dpad, const CovParams& cp, double* out, hipStream_t st,
+int cov_sym_launch(const double* XT, long ldp, long n, int dpad, const CovSpec& cs, double* out, hipStream_t st,
                    long ldo = 0);
 int cov_rect_launch(const double* XrT, long ldr, long n, const double* XcT, long ldc, long m, int dpad,
-                    const CovParams& cp, double* out, long ldo, hipStream_t st);
-int cov_factor_launch(const double* XT, long ldp, long n, long np, int dpad, const CovParams& cp, double inv_sn2,
+                    const CovSpec& cs, double* out, long ldo, hipStream_t st);
+int cov_factor_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double inv_sn2,
                       double* Bf, long ldf, hipStream_t st);
+int cov_self_launch(const CovSpec& cs, int train, double* out_dev, hipStream_t st);
 int self_fill_launch(double* out, long m, double val, hipStream_t st);
 
 // grad.hip
-int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovParams& cp, int ncov,
+int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, int ncov,
                            double sn2, const double* Binv, long ldb, const double* alpha, double* partial,
                            double* out_dev, hipStream_t st, const double* wv = nullptr);
 long hadamard_partial_count(long np, int ncov);

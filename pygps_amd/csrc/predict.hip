@@ -71,9 +71,9 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     CHK(tmp.alloc(&msd, NSB * sizeof(double)));
     CHK(tmp.alloc(&o1, NSB * sizeof(double)));
     CHK(tmp.alloc(&o2, NSB * sizeof(double)));
-    HIP_TRY(hipMemcpyAsync(scd, f->scale.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
-    CovParams cp = f->cp;
-    cp.der = -1;
+    HIP_TRY(hipMemcpyAsync(scd, f->cs.scale.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
+    CovSpec cp = f->cs;
+    cp.cp.der = -1; cp.pg.der = -1;
     for (long a = 0; a < ns; a += NSB) {
         const long nb_ = std::min<long>(NSB, ns - a);
         const int nrhs = (int)round_up(nb_, 128);
@@ -87,7 +87,7 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
         CHK(col_dot_full_launch(Ks, np, n, nb_, f->alpha, msd, o1, st));                  // fmu = ms + Ks' alpha
         if (f->sWv) CHK(row_scale_launch(Ks, np, n, nrhs, f->sWv, st));                   // EP: sW o Ks
         CHK(solve_lower_multi(c, f->F, f->ldf, f->Wd, Ks, np, np, nrhs, false));
-        CHK(col_sumsq_launch(Ks, np, n, nb_, cp.sf2, f->sWv ? 1.0 : f->sw * f->sw, o2, st));
+        CHK(col_sumsq_launch(Ks, np, n, nb_, f->kss, f->sWv ? 1.0 : f->sw * f->sw, o2, st));
         HIP_TRY(hipMemcpyAsync(fmu + a, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(fs2 + a, o2, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -8,6 +8,8 @@
 // like scipy's cdist('sqeuclidean') that the reference calls (Core/cov.py:804) -- no |a|^2+|b|^2-2ab
 // cancellation, K(x,x) = sf2 exactly.
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -18,10 +20,32 @@ struct CovParams {
     int md;          // Matern d (1,3,5,7)
     int ref_der;     // Matern: reproduce the reference's derivative-of-K quirk (Core/cov.py:1173-1177)
     int D;           // input dimension (ARD: der < D selects a length-scale)
-    double sf2;      // exp(2 log sf)   (1 for RBFunit)
-    double alpha;    // RQ shape parameter exp(log alpha)
+    int train;       // 1: x against itself ('train'), 0: 'cross', 2: 'self_test' -- Noise and Const depend on it
+    double sf2;      // exp(2 log sf)   (1 for RBFunit and Gabor; exp(log sf) for Const, cov.py:951)
+    double alpha;    // RQ / RQard shape parameter exp(log alpha)
     int ppv;         // PiecePoly degree v (0..3)
     double ppj;      // PiecePoly j = floor(D/2) + v + 1
+    double ga;       // Gabor: 2 pi ell / p with p = exp(2 hyp1) (cov.py:416,425); Periodic: pi / p (cov.py:1212)
+    double gb;       // Periodic: 1 / ell (cov.py:1213); RQard: factor on the length-scale derivative (1, or the
+                     // reference's 0 on 'train' / ell_k^4 on 'cross' with PGP_FLAG_REFERENCE_DER, cov.py:1412-1418)
+};
+
+// A Sum / Product / Scale tree over non-ARD leaves (Core/cov.py:230-328), expanded on the host into a sum of
+// products:  K = sum_t coef_t * prod_{l in term t} k_l(r^2 * is2_l).  Every leaf is a function of the *raw*
+// squared distance r^2 (XsT is uploaded unscaled for programs), so one distance tile serves all leaves.
+constexpr int CP_MAXLEAF = 8, CP_MAXTERM = 8, CP_MAXSCALE = 8;
+struct CovProgram {
+    int nleaf, nterm, nscale;
+    int der;                         // flat hyper index for derivative matrices (-1: value)
+    int der_leaf, der_j, der_scale;  // der resolved: hyper j of leaf l, or Scale node s (other = -1)
+    CovParams leaf[CP_MAXLEAF];
+    double is2[CP_MAXLEAF];          // leaf's scaled squared distance = r^2 * is2
+    int hyp0[CP_MAXLEAF];            // flat index of the leaf's first hyper
+    int nh[CP_MAXLEAF];              // number of hypers of the leaf (<= 3)
+    double coef[CP_MAXTERM];         // product of exp(scale hyper) over the Scale nodes above the term (cov.py:315)
+    unsigned tl[CP_MAXTERM];         // leaves multiplied in term t (bit mask)
+    unsigned ts[CP_MAXTERM];         // Scale nodes above term t (bit mask)
+    int shyp[CP_MAXSCALE];           // flat hyper index of each Scale node
 };
 
 constexpr int ST = 64;      // tile edge
@@ -111,10 +135,27 @@ __device__ __forceinline__ double ipow(double b, int n) {      // b^n, n >= 0, 0
     return r;
 }
 
-// covariance value k(x,z) from the scaled squared distance s
-__device__ __forceinline__ double cov_value(const CovParams& p, double s) {
-    if (p.kind == 4) {                    // RQ: Core/cov.py:1323
+// covariance value k(x,z) from the scaled squared distance s; same = "row and column are the same training point"
+// EXT = false leaves out the trigonometric / index-dependent kinds (7..10): the primitive hot-path kernels are
+// instantiated without them (they run as one-leaf programs), which keeps their register count where it was.
+template <bool EXT = false>
+__device__ __forceinline__ double cov_value(const CovParams& p, double s, bool same = false) {
+    if (p.kind == 4 || p.kind == 6) {     // RQ: Core/cov.py:1323, RQard :1394
         return p.sf2 * exp(-p.alpha * log(1.0 + 0.5 * s / p.alpha));
+    }
+    if (EXT && p.kind == 7) {                    // Gabor: cov.py:424-426
+        return exp(-0.5 * s) * cos(sqrt(s) * p.ga);
+    }
+    if (EXT && p.kind == 8) {             // Periodic: cov.py:1212-1216 (s = raw |x-z|^2, 1-d inputs)
+        const double R = sin(sqrt(s) * p.ga) * p.gb;
+        return p.sf2 * exp(-2.0 * R * R);
+    }
+    if (EXT && p.kind == 9) {             // Noise: cov.py:1269-1280 (identity on 'train', |x-z|^2 < 1e-9 on 'cross', 0 on 'self_test')
+        const bool one = p.train == 1 ? same : (p.train == 0 ? s < 1e-9 : false);
+        return one ? p.sf2 : 0.0;
+    }
+    if (EXT && p.kind == 10) {            // Const: cov.py:951-962 (1e-10 jitter on the training diagonal)
+        return p.sf2 + ((p.train == 1 && same) ? 1e-10 : 0.0);
     }
     if (p.kind == 5) {                    // PiecePoly: Core/cov.py:746 (compact support: 0 beyond r = 1)
         const double r = sqrt(s);
@@ -129,8 +170,34 @@ __device__ __forceinline__ double cov_value(const CovParams& p, double s) {
 }
 
 // derivative w.r.t. hyper p.der; dk2 = scaled squared difference in coordinate p.der (ARD only)
-__device__ __forceinline__ double cov_deriv(const CovParams& p, double s, double dk2) {
+template <bool EXT = false>
+__device__ __forceinline__ double cov_deriv(const CovParams& p, double s, double dk2, bool same = false) {
     if (p.kind == 3) return exp(-0.5 * s) * s;        // RBFunit: Core/cov.py:865
+    if (p.kind == 6) {                    // RQard: cov.py:1412-1425
+        const double Kp = 1.0 + 0.5 * s / p.alpha;
+        const double lk = log(Kp);
+        if (p.der < p.D) return p.sf2 * exp((-p.alpha - 1.0) * lk) * dk2 * p.gb;   // gb = 1 (see make_leaf for compat)
+        if (p.der == p.D) return 2.0 * p.sf2 * exp(-p.alpha * lk);
+        return p.sf2 * exp(-p.alpha * lk) * (0.5 * s / Kp - p.alpha * lk);
+    }
+    if (EXT && p.kind == 7) {             // Gabor: cov.py:440-448 (as the reference returns them)
+        const double dp = sqrt(s) * p.ga;
+        const double K = exp(-0.5 * s) * cos(dp);
+        return p.der == 0 ? dp * K : tan(dp) * dp * K;
+    }
+    if (EXT && p.kind == 8) {             // Periodic: cov.py:1236-1249
+        const double A = sqrt(s) * p.ga;
+        const double R = sin(A) * p.gb;
+        const double e = p.sf2 * exp(-2.0 * R * R);
+        if (p.der == 0) return 4.0 * e * R * R;
+        if (p.der == 1) return 4.0 * p.gb * e * R * cos(A) * A;
+        return 2.0 * e;
+    }
+    if (EXT && p.kind == 9) {             // Noise: cov.py:1296-1297
+        const bool one = p.train == 1 ? same : (p.train == 0 ? s < 1e-9 : false);
+        return one ? 2.0 * p.sf2 : 0.0;
+    }
+    if (EXT && p.kind == 10) return 2.0 * p.sf2; // Const: cov.py:978-979 (no jitter in the derivative)
     if (p.kind == 4) {                    // RQ: Core/cov.py:1337-1345
         const double Kp = 1.0 + 0.5 * s / p.alpha;
         const double lk = log(Kp);
@@ -166,9 +233,33 @@ __device__ __forceinline__ double cov_deriv(const CovParams& p, double s, double
 }
 
 // every derivative (up to three hypers) of the non-ARD kernels, transcendental functions evaluated once
-__device__ __forceinline__ void cov_deriv_all(const CovParams& p, double s, double& d0, double& d1, double& d2) {
+template <bool EXT = false>
+__device__ __forceinline__ void cov_deriv_all(const CovParams& p, double s, double& d0, double& d1, double& d2,
+                                              bool same = false) {
     d2 = 0.0;
     if (p.kind == 3) { d0 = exp(-0.5 * s) * s; d1 = 0.0; return; }
+    if (EXT && p.kind == 7) {
+        const double dp = sqrt(s) * p.ga;
+        const double K = exp(-0.5 * s) * cos(dp);
+        d0 = dp * K;
+        d1 = tan(dp) * dp * K;
+        return;
+    }
+    if (EXT && p.kind == 8) {
+        const double A = sqrt(s) * p.ga;
+        const double R = sin(A) * p.gb;
+        const double e = p.sf2 * exp(-2.0 * R * R);
+        d0 = 4.0 * e * R * R;
+        d1 = 4.0 * p.gb * e * R * cos(A) * A;
+        d2 = 2.0 * e;
+        return;
+    }
+    if (EXT && p.kind == 9) {
+        const bool one = p.train == 1 ? same : (p.train == 0 ? s < 1e-9 : false);
+        d0 = one ? 2.0 * p.sf2 : 0.0; d1 = 0.0;
+        return;
+    }
+    if (EXT && p.kind == 10) { d0 = 2.0 * p.sf2; d1 = 0.0; return; }
     if (p.kind == 4) {
         const double Kp = 1.0 + 0.5 * s / p.alpha;
         const double lk = log(Kp);
@@ -206,3 +297,95 @@ __device__ __forceinline__ void cov_deriv_all(const CovParams& p, double s, doub
         d1 = 2.0 * p.sf2 * matern_poly(p.md, t) * e;
     }
 }
+
+// host-side description of the covariance function of one call: a primitive functor or a program
+struct CovSpec {
+    bool prog = false;
+    CovParams cp;
+    CovProgram pg;
+    std::vector<double> scale;      // per-coordinate scale folded into XsT (all ones for programs)
+    int ncov = 0;                   // number of hyperparameters (= gradient entries)
+    int nder = 0;                   // getDerMatrix accepts der in [0, nder)
+    double ell4 = 1.0;              // RQard reference-compat 'cross' derivative factor ell_der^4
+    double sf2() const { return cp.sf2; }
+};
+
+// ---- composite programs ----------------------------------------------------------------------------
+__device__ __forceinline__ bool cov_is_ard(const CovParams& p) { return p.kind == 1 || p.kind == 6; }
+
+// term products T_t = coef_t prod_{l in t} v_l
+__device__ __forceinline__ void prog_terms(const CovProgram& P, const double (&v)[CP_MAXLEAF], double (&T)[CP_MAXTERM]) {
+#pragma unroll
+    for (int t = 0; t < CP_MAXTERM; ++t) {
+        double pr = 0.0;
+        if (t < P.nterm) {
+            pr = P.coef[t];
+#pragma unroll
+            for (int l = 0; l < CP_MAXLEAF; ++l)
+                if ((P.tl[t] >> l) & 1u) pr *= v[l];
+        }
+        T[t] = pr;
+    }
+}
+
+// dK / d(leaf l's value) = sum_{t containing l} coef_t prod_{l' in t, l' != l} v_l'
+__device__ __forceinline__ double prog_leaf_weight(const CovProgram& P, const double (&v)[CP_MAXLEAF], int l) {
+    double w = 0.0;
+#pragma unroll
+    for (int t = 0; t < CP_MAXTERM; ++t) {
+        if (t < P.nterm && ((P.tl[t] >> l) & 1u)) {
+            double pr = P.coef[t];
+#pragma unroll
+            for (int l2 = 0; l2 < CP_MAXLEAF; ++l2)
+                if (l2 != l && ((P.tl[t] >> l2) & 1u)) pr *= v[l2];
+            w += pr;
+        }
+    }
+    return w;
+}
+
+__device__ __forceinline__ double prog_value(const CovProgram& P, double r2, bool same) {
+    double v[CP_MAXLEAF], T[CP_MAXTERM];
+#pragma unroll
+    for (int l = 0; l < CP_MAXLEAF; ++l) v[l] = l < P.nleaf ? cov_value<true>(P.leaf[l], r2 * P.is2[l], same) : 1.0;
+    prog_terms(P, v, T);
+    double K = 0.0;
+#pragma unroll
+    for (int t = 0; t < CP_MAXTERM; ++t) K += T[t];
+    return K;
+}
+
+// derivative matrix entry for the flat hyper index P.der (Product :246-256, Sum :281-291, Scale :320-328)
+__device__ __forceinline__ double prog_deriv(const CovProgram& P, double r2, bool same) {
+    double v[CP_MAXLEAF], T[CP_MAXTERM];
+#pragma unroll
+    for (int l = 0; l < CP_MAXLEAF; ++l) v[l] = l < P.nleaf ? cov_value<true>(P.leaf[l], r2 * P.is2[l], same) : 1.0;
+    if (P.der_scale >= 0) {               // 2 * exp(h) * child, through whatever sits above the Scale node
+        prog_terms(P, v, T);
+        double K = 0.0;
+#pragma unroll
+        for (int t = 0; t < CP_MAXTERM; ++t)
+            if ((P.ts[t] >> P.der_scale) & 1u) K += T[t];
+        return 2.0 * K;
+    }
+    double out = 0.0;
+#pragma unroll
+    for (int l = 0; l < CP_MAXLEAF; ++l) {
+        if (l == P.der_leaf) {
+            CovParams lp = P.leaf[l];
+            lp.der = P.der_j;
+            out = prog_leaf_weight(P, v, l) * cov_deriv<true>(lp, r2 * P.is2[l], 0.0, same);
+        }
+    }
+    return out;
+}
+
+// one element seen by the tile kernels, primitive functor or program
+__device__ __forceinline__ double cov_elem(const CovParams& p, double s, double dk2, bool same) {
+    return p.der < 0 ? cov_value(p, s, same) : cov_deriv(p, s, dk2, same);
+}
+__device__ __forceinline__ double cov_elem(const CovProgram& P, double s, double, bool same) {
+    return P.der < 0 ? prog_value(P, s, same) : prog_deriv(P, s, same);
+}
+__device__ __forceinline__ int cov_ard_der(const CovParams& p) { return (cov_is_ard(p) && p.der >= 0 && p.der < p.D) ? p.der : -1; }
+__device__ __forceinline__ int cov_ard_der(const CovProgram&) { return -1; }

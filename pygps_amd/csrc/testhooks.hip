@@ -139,9 +139,9 @@ int pgp_test_assemble(pgp_ctx* c, int kind, int mode, int64_t n, int64_t d, int 
     for (auto& v : x) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = ((double)(s >> 11) / 9007199254740992.0 - 0.5) * 3.4; }
     std::vector<double> hyp(kind == PGP_COV_RBFARD ? d + 1 : 2, 0.0);
     for (size_t i = 0; i + 1 < hyp.size(); ++i) hyp[i] = 0.5 * log((double)d);
-    std::vector<double> sc;
-    CHK(fill_scale(kind, hyp.data(), (int)hyp.size(), 3, d, sc));
-    CovParams cp = make_cp(kind, hyp.data(), (int)hyp.size(), 3, 0, -1, d);
+    CovSpec cp;
+    CHK(make_spec(c, kind, hyp.data(), (int)hyp.size(), 3, 0, -1, d, cp));
+    const std::vector<double>& sc = cp.scale;
     double *xd, *XT, *scd, *out;
     const long ldo = mode == 2 ? np + 128 : n;
     HIP_TRY(hipMalloc((void**)&xd, x.size() * 8)); HIP_TRY(hipMalloc((void**)&XT, (size_t)dpad * np * 8));

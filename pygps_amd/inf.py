@@ -177,12 +177,12 @@ class _Resident(object):
             cls.key.pop(k, None)
 
 
-def _device_kernel(covfunc):
-    if not isinstance(covfunc, _cov.Kernel) or covfunc._kind is None:
-        raise NotImplementedError(
-            "pygps_amd: only RBF, RBFard, Matern, RBFunit, RQ and PiecePoly have a device covariance functor (got %s); "
-            "there is no CPU fallback" % type(covfunc).__name__)
-    return covfunc._device_params()
+def _device_kernel(covfunc, ctx):
+    """(kind, para, flags) of ``covfunc`` on context ``ctx`` (composites register their device program there)."""
+    if not isinstance(covfunc, _cov.Kernel):
+        raise NotImplementedError("pygps_amd: covfunc must be a pygps_amd.cov.Kernel (got %s); there is no CPU fallback"
+                                  % type(covfunc).__name__)
+    return covfunc._bind(ctx)
 
 
 def _mean_inputs(meanfunc, x):
@@ -207,8 +207,8 @@ class Exact(Inference):
     def evaluate(self, meanfunc, covfunc, likfunc, x, y, nargout=1):
         if not isinstance(likfunc, _lik.Gauss):
             raise Exception("Exact inference only possible with Gaussian likelihood")
-        kind, para, flags = _device_kernel(covfunc)
         dev = _lib.default_device() if self.device is None else self.device
+        kind, para, flags = _device_kernel(covfunc, _lib.ctx(dev))
         x = _lib.f64(x)
         n, D = x.shape
         y = _lib.f64(y).reshape(n)
@@ -257,8 +257,8 @@ class EP(Inference):
     def evaluate(self, meanfunc, covfunc, likfunc, x, y, nargout=1):
         if not isinstance(likfunc, _lik.Erf):
             raise NotImplementedError("pygps_amd: EP runs on the device for lik.Erf only (no CPU fallback)")
-        kind, para, flags = _device_kernel(covfunc)
         dev = _lib.default_device() if self.device is None else self.device
+        kind, para, flags = _device_kernel(covfunc, _lib.ctx(dev))
         x = _lib.f64(x)
         n, D = x.shape
         y = _lib.f64(y).reshape(n)

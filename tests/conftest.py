@@ -46,3 +46,28 @@ def relerr(a, b):
 def lib():
     from pygps_amd import _lib
     return _lib.load()
+
+
+# ---- G11: remaining kernels and composites (oracle `kind` trees, see oracle/gp_oracle.py) -------------------
+def _leaf(kind, para=0):
+    return ("leaf", kind, para)
+
+
+def g11_trees():
+    from oracle import gp_oracle as O
+    L = _leaf
+    return {
+        "rqard": L(O.RQARD), "gabor": L(O.GABOR), "noise": L(O.NOISE), "const": L(O.CONST), "periodic": L(O.PERIODIC),
+        "sum": ("sum", L(O.RBF), L(O.MATERN, 5)),
+        "prod": ("prod", L(O.RQ), L(O.RBFUNIT)),
+        "scale": ("scale", L(O.PIECEPOLY, 2)),
+        "tree": ("sum", ("sum", ("prod", ("sum", L(O.RBF), ("scale", L(O.GABOR))), L(O.MATERN, 3)), L(O.NOISE)), L(O.CONST)),
+        "ardsum": ("sum", L(O.RBFARD), L(O.RBF)),
+        "maunaloa": ("sum", ("sum", ("sum", L(O.RBF), ("prod", L(O.PERIODIC), L(O.RBF))), L(O.RQ)),
+                     ("sum", L(O.RBF), L(O.NOISE))),
+        "scaled_sum": ("scale", ("sum", L(O.RBF), L(O.MATERN, 3))),
+        "ep_composite": ("sum", ("prod", L(O.RBF), L(O.RQ)), L(O.CONST)),
+    }
+
+
+G11_1D = ("periodic", "maunaloa")          # kernels dumped on the 1-d inputs x1 / z1

@@ -339,8 +339,85 @@ def g10():
              **dn(dnlZ))
 
 
+def g11():
+    """Remaining stationary kernels and Sum/Product/Scale composites."""
+    if not hasattr(np, "float"):
+        np.float = float        # Core/cov.py:1279 uses the alias numpy 2 removed; restore it so Noise 'cross' runs
+    cov = pyGPs.cov
+    np.random.seed(0)
+    x = np.random.normal(0, 1, (20, 3))
+    _ = np.random.random((20,))
+    z = np.random.normal(0, 1, (10, 3))
+    z[3] = x[5]                                   # one coincident point: Noise 'cross' has a non-zero entry
+    out = dict(x=x, z=z)
+    kernel_dump("rqard", cov.RQard(log_ell_list=[0.1, 0.4, -0.2], log_sigma=0.2, log_alpha=-0.3), x, z, out)
+    kernel_dump("gabor", cov.Gabor(0.3, 0.4), x, z, out)
+    kernel_dump("noise", cov.Noise(-0.7), x, z, out)
+    kernel_dump("const", cov.Const(0.4), x, z, out)
+    kernel_dump("sum", cov.RBF(0.3, 0.2) + cov.Matern(0.5, 5, -0.1), x, z, out)
+    kernel_dump("prod", cov.RQ(0.3, 0.2, -0.4) * cov.RBFunit(0.8), x, z, out)
+    kernel_dump("scale", cov.PiecePoly(1.1, 2, 0.2) * 0.7, x, z, out)
+    kernel_dump("tree", (cov.RBF(0.3, 0.2) + cov.Gabor(0.6, 0.5) * 0.3) * cov.Matern(0.9, 3, 0.1) + cov.Noise(-1.0)
+                + cov.Const(-0.5), x, z, out)
+    kernel_dump("ardsum", cov.RBFard(log_ell_list=[0.1, 0.4, -0.2], log_sigma=0.2) + cov.RBF(0.3, 0.2), x, z, out)
+    x1 = np.sort(np.random.uniform(-3, 3, (25, 1)), axis=0)
+    z1 = np.random.uniform(-3, 3, (9, 1))
+    out.update(x1=x1, z1=z1)
+    kernel_dump("periodic", cov.Periodic(0.3, 0.6, 0.2), x1, z1, out)
+    kernel_dump("maunaloa", cov.RBF(1.2, 0.9) + cov.Periodic(0.3, 0.1, 0.4) * cov.RBF(1.5, 0.4) + cov.RQ(0.2, -0.4, -0.2)
+                + (cov.RBF(-1.5, -1.0) + cov.Noise(-1.6)), x1, z1, out)
+    save("G11_kernels_rqard_gabor_periodic_noise_const_composites", **out)
+
+    # fits: MaunaLoa-shaped composite on 1-d data (doc/source/demoMaunaLoa.rst:104-108) and RQard, d = 4
+    rng = np.random.RandomState(3)
+    xt = np.sort(rng.uniform(0, 12, (300, 1)), axis=0)
+    yt = 0.4 * xt + np.sin(2 * np.pi * xt) * (1 + 0.05 * xt) + 0.3 * np.sin(0.7 * xt) + 0.1 * rng.randn(300, 1)
+    xs = np.linspace(11, 14, 7).reshape(-1, 1)
+
+    def mauna():
+        return (cov.RBF(np.log(6.), np.log(2.)) + cov.Periodic(np.log(1.3), np.log(1.0), np.log(1.1)) * cov.RBF(np.log(9.), np.log(1.1))
+                + cov.RQ(np.log(1.2), np.log(0.66), np.log(0.78)) + (cov.RBF(np.log(0.13), np.log(0.18)) + cov.Noise(np.log(0.19))))
+
+    m = pyGPs.GPR()
+    m.setPrior(kernel=mauna())
+    m.setNoise(np.log(0.1))
+    m.setData(xt, yt)
+    nlZ, dnlZ, post = m.getPosterior()
+    ym, ys2, fm, fs2, lp = m.predict(xs)
+    rec = dict(x=xt, y=yt, nlZ=nlZ, alpha=post.alpha, L_diag=np.diag(post.L).copy(), mean_hyp=np.array(m.meanfunc.hyp),
+               cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp), pred_xs=xs, pred_ym=ym, pred_ys2=ys2,
+               pred_fs2=fs2, **dn(dnlZ))
+    m.optimize(xt, yt, numIterations=15)
+    ym2, ys22, _, _, _ = m.predict(xs)
+    rec.update(opt_nlZ=m.nlZ, opt_hyp=np.array(m.meanfunc.hyp + m.covfunc.hyp + m.likfunc.hyp), opt_ym=ym2, opt_ys2=ys22)
+    save("G11_fit_maunaloa_N300", **rec)
+
+    x4, y4 = synth_reg(300, 4)
+    for nm, k in (("rqard", cov.RQard(log_ell_list=[np.log(2.0)] * 4, log_sigma=0.1, log_alpha=0.3)),
+                  ("scaled_sum", (cov.RBF(np.log(2.0), 0.1) + cov.Matern(np.log(3.0), 3, -0.5)) * 0.4)):
+        m = pyGPs.GPR()
+        m.setPrior(kernel=k)
+        m.setNoise(np.log(0.1))
+        m.setData(x4, y4)
+        nlZ, dnlZ, post = m.getPosterior()
+        xs4 = x4[:5] + 0.05
+        ym, ys2, fm, fs2, lp = m.predict(xs4)
+        save("G11_fit_%s_N300" % nm, N=300, d=4, seed=0, nlZ=nlZ, alpha=post.alpha, L_diag=np.diag(post.L).copy(),
+             mean_hyp=np.array(m.meanfunc.hyp), cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp),
+             pred_xs=xs4, pred_ym=ym, pred_fs2=fs2, **dn(dnlZ))
+
+    # EP with a composite kernel (GPC, classification recipe N=200, d=3)
+    xc, yc = synth_cls(200, 3)
+    m = pyGPs.GPC()
+    m.setPrior(kernel=cov.RBF(np.log(1.5), 0.3) * cov.RQ(0.6, 0.0, 0.2) + cov.Const(-1.0))
+    nlZ, dnlZ, post = m.getPosterior(xc, yc)
+    ym, ys2, fm, fs2, lp = m.predict(xc[:5] + 0.05, ys=np.ones((5, 1)))
+    save("G11_ep_composite_N200", x=xc, y=yc, nlZ=nlZ, alpha=post.alpha, sW=post.sW, cov_hyp=np.array(m.covfunc.hyp),
+         pred_xs=xc[:5] + 0.05, pred_ym=ym, pred_fs2=fs2, pred_lp=lp, **dn(dnlZ))
+
+
 CASES = {
-    "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
+    "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
     "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384),
 }

@@ -133,11 +133,11 @@ def test_kernel_classes_contract(lib):
     kk = pyGPs.cov.Matern(0.3, 3, 0.2)
     kk.reference_compat = True
     assert np.max(np.abs(kk.getDerMatrix(x=x, mode="train", der=0) - g["matern3_dK0_train"])) < 1e-13
-    # PSD-ness as unit_test_cov.py:53-59 checks it, composites through the host
+    # PSD-ness as unit_test_cov.py:53-59 checks it; `k * number`: the number is the log-space hyper (cov.py:303, 315)
     s = pyGPs.cov.RBF(0.3, 0.2) + pyGPs.cov.Matern(0.3, 5, 0.2) * 2.0
     K = s.getCovMatrix(x=x, mode="train")
     assert K.shape == (20, 20) and np.all(np.linalg.eigvalsh(K) > -1e-9)
-    assert relerr(K, g["rbf_K_train"] + 2.0 * g["matern5_K_train"]) < 1e-13
+    assert relerr(K, g["rbf_K_train"] + np.exp(2.0) * g["matern5_K_train"]) < 1e-13
     assert len(s.hyp) == 5
 
 
@@ -197,8 +197,10 @@ def test_exact_rejects_non_gaussian_and_unknown_kernel(lib):
     with pytest.raises(Exception, match="Exact inference only possible with Gaussian likelihood"):
         pyGPs.inf.Exact().evaluate(pyGPs.mean.Zero(), pyGPs.cov.RBF(), pyGPs.lik.Erf(), x, y, 2)
     with pytest.raises(NotImplementedError):
-        s = pyGPs.cov.RBF() + pyGPs.cov.RBF()
+        s = pyGPs.cov.RBFard(D=2) + pyGPs.cov.RBF()            # ARD leaf: no device program, and no CPU fallback
         pyGPs.inf.Exact().evaluate(pyGPs.mean.Zero(), s, pyGPs.lik.Gauss(), x, y, 2)
+    with pytest.raises(NotImplementedError):
+        pyGPs.inf.Exact().evaluate(pyGPs.mean.Zero(), object(), pyGPs.lik.Gauss(), x, y, 2)
 
 
 def test_G8_ep_classification_demo_and_synthetic(lib):

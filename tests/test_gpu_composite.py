@@ -1,0 +1,191 @@
+"""GPU: the remaining stationary kernels (RQard, Gabor, Periodic, Noise, Const) and Sum / Product / Scale trees
+running as ONE device program (Core/cov.py:230-328, 392-450, 941-982, 1186-1300, 1356-1425).
+Everything goes through the C ABI (pgp_set_composite + pgp_cov / pgp_exact_fit / pgp_predict / pgp_ep_fit) and is
+compared with the golden vectors recorded from the reference (G11) and with the oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, synth_reg, g11_trees, G11_1D
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def build(tree, hyp, D, compat=True):
+    """pygps_amd kernel object for an oracle `kind` tree with flattened hypers `hyp`."""
+    from pygps_amd import cov
+    hyp = [float(h) for h in hyp]
+    if tree[0] == "leaf":
+        kind, para = tree[1], tree[2]
+        k = {O.RBF: cov.RBF, O.RBFUNIT: cov.RBFunit, O.RQ: cov.RQ, O.GABOR: cov.Gabor, O.PERIODIC: cov.Periodic,
+             O.NOISE: cov.Noise, O.CONST: cov.Const}.get(kind)
+        if k is not None:
+            k = k()
+        elif kind == O.RBFARD:
+            k = cov.RBFard(D=D)
+        elif kind == O.RQARD:
+            k = cov.RQard(D=D)
+        elif kind == O.MATERN:
+            k = cov.Matern(d=para)
+        elif kind == O.PIECEPOLY:
+            k = cov.PiecePoly(v=para)
+        k.reference_compat = compat
+        assert len(k.hyp) == len(hyp)
+        k.hyp = hyp
+        return k
+    if tree[0] == "scale":
+        return build(tree[1], hyp[1:], D, compat) * hyp[0]
+    n1 = O.n_cov_hyp(tree[1] if tree[1][0] != "leaf" else tree[1][1], D)
+    a, b = build(tree[1], hyp[:n1], D, compat), build(tree[2], hyp[n1:], D, compat)
+    return a + b if tree[0] == "sum" else a * b
+
+
+def _close(a, b, tol=2e-12):
+    scale = max(1.0, float(np.max(np.abs(b))))
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol * scale)
+
+
+@pytest.mark.parametrize("nm", ["rqard", "gabor", "noise", "const", "periodic", "sum", "prod", "scale", "tree", "ardsum",
+                                "maunaloa"])
+def test_G11_kernel_matrices_all_modes(nm):
+    g = golden("G11_kernels_rqard_gabor_periodic_noise_const_composites")
+    x, z = (g["x1"], g["z1"]) if nm in G11_1D else (g["x"], g["z"])
+    hyp = g[nm + "_hyp"]
+    k = build(g11_trees()[nm], hyp, x.shape[1])
+    assert list(np.asarray(k.hyp, float)) == list(hyp)                  # reference flatten order
+    if nm not in ("rqard", "ardsum") and hasattr(k, "_on_device"):
+        assert k._on_device()                                            # runs as one device program
+    for mode, kw in (("train", dict(x=x)), ("cross", dict(x=x, z=z)), ("self", dict(z=z))):
+        m = "self_test" if mode == "self" else mode
+        K = k.getCovMatrix(mode=m, **kw)
+        assert K.shape == g["%s_K_%s" % (nm, mode)].shape
+        _close(K, g["%s_K_%s" % (nm, mode)])
+        for i in range(len(hyp)):
+            _close(k.getDerMatrix(mode=m, der=i, **kw), g["%s_dK%d_%s" % (nm, i, mode)], 1e-11)
+    with pytest.raises(Exception):
+        k.getDerMatrix(x=x, mode="train", der=len(hyp))
+
+
+def test_rqard_default_derivative_is_the_correct_one():
+    """reference_compat=False: analytic length-scale derivatives agree with central differences of K."""
+    from pygps_amd import cov
+    rng = np.random.RandomState(1)
+    x = rng.randn(40, 3)
+    k = cov.RQard(log_ell_list=[0.1, 0.4, -0.2], log_sigma=0.2, log_alpha=-0.3)
+    h0 = list(k.hyp)
+    for i in range(5):
+        dK = k.getDerMatrix(x=x, mode="train", der=i)
+        e = 1e-6
+        k.hyp = [h + (e if j == i else 0) for j, h in enumerate(h0)]
+        Kp = k.getCovMatrix(x=x, mode="train")
+        k.hyp = [h - (e if j == i else 0) for j, h in enumerate(h0)]
+        Km = k.getCovMatrix(x=x, mode="train")
+        k.hyp = h0
+        assert np.max(np.abs(dK - (Kp - Km) / (2 * e))) < 1e-8
+        _close(dK, O.der_matrix(O.RQARD, np.array(h0), 0, x=x, mode="train", der=i, matern_reference_compat=False), 1e-11)
+
+
+def test_G11_maunaloa_fit_predict_optimize():
+    """doc/source/demoMaunaLoa.rst:104-108 -- RBF + Periodic*RBF + RQ + (RBF + Noise), 11 hypers, in one program."""
+    import pygps_amd as pyGPs
+    g = golden("G11_fit_maunaloa_N300")
+    x, y = g["x"], g["y"]
+    m = pyGPs.GPR()
+    m.setPrior(kernel=build(g11_trees()["maunaloa"], g["cov_hyp"], 1))
+    m.setNoise(g["lik_hyp"][0])
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    assert relerr(nlZ, g["nlZ"]) < 1e-9
+    assert relerr(post.alpha, g["alpha"]) < 1e-6
+    assert relerr(np.diag(post.L), g["L_diag"]) < 1e-8
+    assert relerr(dnlZ.cov, g["dnlZ_cov"]) < 1e-7 and relerr(dnlZ.lik, g["dnlZ_lik"]) < 1e-7
+    assert relerr(dnlZ.mean, g["dnlZ_mean"]) < 1e-7
+    ym, ys2, fm, fs2, lp = m.predict(g["pred_xs"])
+    assert relerr(ym, g["pred_ym"]) < 1e-8 and relerr(fs2, g["pred_fs2"]) < 1e-6 and relerr(ys2, g["pred_ys2"]) < 1e-6
+    m.optimize(x, y, numIterations=15)
+    assert abs(m.nlZ - g["opt_nlZ"]) < 1e-4 * abs(g["opt_nlZ"])           # optimiser path amplifies rounding
+    ym2 = m.predict(g["pred_xs"])[0]
+    assert relerr(ym2, g["opt_ym"]) < 1e-3
+
+
+@pytest.mark.parametrize("nm", ["rqard", "scaled_sum"])
+def test_G11_fits(nm):
+    import pygps_amd as pyGPs
+    g = golden("G11_fit_%s_N300" % nm)
+    x, y = synth_reg(300, 4)
+    tree = g11_trees()[nm]
+    m = pyGPs.GPR()
+    m.setPrior(kernel=build(tree, g["cov_hyp"], 4))
+    m.setNoise(g["lik_hyp"][0])
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    assert relerr(nlZ, g["nlZ"]) < 1e-9 and relerr(post.alpha, g["alpha"]) < 1e-6
+    assert np.allclose(dnlZ.cov, g["dnlZ_cov"], rtol=1e-7, atol=1e-7 * np.max(np.abs(g["dnlZ_cov"])))
+    assert relerr(dnlZ.lik, g["dnlZ_lik"]) < 1e-7
+    ym, ys2, fm, fs2, lp = m.predict(g["pred_xs"])
+    assert relerr(ym, g["pred_ym"]) < 1e-8 and relerr(fs2, g["pred_fs2"]) < 1e-6
+    if nm == "rqard":        # default (correct) length-scale gradient against the oracle without the quirk + FD
+        k = build(tree, g["cov_hyp"], 4, compat=False)
+        m.setPrior(kernel=k)
+        m.setData(x, y)
+        nlZ2, dn2, _ = m.getPosterior()
+        c = m.meanfunc.hyp[0]
+        out = O.exact_fit(O.RQARD, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y), faithful=False,
+                          matern_reference_compat=False)
+        assert relerr(nlZ2, out["nlZ"]) < 1e-9 and relerr(dn2.cov, out["dnlZ_cov"]) < 1e-7
+        assert abs(dn2.cov[0]) > 1.0
+
+
+def test_G11_ep_with_a_composite_kernel():
+    import pygps_amd as pyGPs
+    g = golden("G11_ep_composite_N200")
+    m = pyGPs.GPC()
+    m.setPrior(kernel=build(g11_trees()["ep_composite"], g["cov_hyp"], 3))
+    nlZ, dnlZ, post = m.getPosterior(g["x"], g["y"])
+    assert relerr(nlZ, g["nlZ"]) < 1e-8 and relerr(post.alpha, g["alpha"]) < 1e-6 and relerr(post.sW, g["sW"]) < 1e-6
+    assert relerr(dnlZ.cov, g["dnlZ_cov"]) < 1e-6
+    ym, ys2, fm, fs2, lp = m.predict(g["pred_xs"], ys=np.ones((5, 1)))
+    assert relerr(ym, g["pred_ym"]) < 1e-7 and relerr(lp, g["pred_lp"]) < 1e-7
+
+
+def test_composite_limits_and_ard_leaves():
+    """More than 8 leaves, or an ARD leaf: getCovMatrix still works (children on the device, combined on the host);
+    fits refuse loudly -- there is no CPU fallback."""
+    import pygps_amd as pyGPs
+    from pygps_amd import cov
+    rng = np.random.RandomState(0)
+    x = rng.randn(30, 2)
+    y = rng.randn(30, 1)
+    big = cov.RBF(0.1, 0.0)
+    for i in range(8):
+        big = big + cov.RBF(0.1 * i, -0.2)
+    assert not big._on_device()
+    ref = sum(O.cov_matrix(O.RBF, [0.1 * i, -0.2], 0, x=x, mode="train") for i in range(8)) + O.cov_matrix(O.RBF, [0.1, 0.0], 0, x=x, mode="train")
+    _close(big.getCovMatrix(x=x, mode="train"), ref)
+    ard = cov.RBFard(D=2) * cov.RBF()
+    assert not ard._on_device()
+    for k in (big, ard):
+        m = pyGPs.GPR()
+        m.setPrior(kernel=k)
+        with pytest.raises(NotImplementedError):
+            m.getPosterior(x, y)
+    # exactly at the limit: 8 products from (a+b)*(c+d)*(e+f)
+    k8 = (cov.RBF(0.1, 0.) + cov.RQ(0.2, 0., 0.1)) * (cov.RBF(0.3, 0.) + cov.Matern(0.2, 3, 0.)) * (cov.RBFunit(0.5) + cov.Const(-1.))
+    assert k8._on_device()
+    t = ("prod", ("prod", ("sum", ("leaf", O.RBF, 0), ("leaf", O.RQ, 0)), ("sum", ("leaf", O.RBF, 0), ("leaf", O.MATERN, 3))),
+         ("sum", ("leaf", O.RBFUNIT, 0), ("leaf", O.CONST, 0)))
+    h = np.array(k8.hyp, float)
+    _close(k8.getCovMatrix(x=x, mode="train"), O.cov_matrix(t, h, 0, x=x, mode="train"))
+    for i in range(len(h)):
+        _close(k8.getDerMatrix(x=x, mode="train", der=i), O.der_matrix(t, h, 0, x=x, mode="train", der=i, matern_reference_compat=False), 1e-11)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=k8)
+    nlZ, dnlZ, post = m.getPosterior(x, y)
+    out = O.exact_fit(t, h, 0, m.likfunc.hyp[0], x, y, np.zeros_like(y), None, faithful=False, matern_reference_compat=False)
+    assert relerr(nlZ, out["nlZ"]) < 1e-10 and relerr(dnlZ.cov, out["dnlZ_cov"]) < 1e-8
+
+
+def test_periodic_needs_1d_inputs():
+    from pygps_amd import cov
+    with pytest.raises(AssertionError):
+        cov.Periodic().getCovMatrix(x=np.zeros((4, 2)), mode="train")

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import golden, relerr, synth_reg, synth_cls
+from conftest import golden, relerr, synth_reg, synth_cls, g11_trees, G11_1D
 from oracle import gp_oracle as O
 
 KINDS = {"rbf": (O.RBF, 0), "rbfard": (O.RBFARD, 0), "matern1": (O.MATERN, 1), "matern3": (O.MATERN, 3),
@@ -158,3 +158,43 @@ def test_G10_rbfunit_rq_piecepoly_kernels_and_fits():
                           faithful=False)
         assert relerr(out["nlZ"], g["nlZ"]) < 1e-11 and relerr(out["alpha"], g["alpha"]) < 1e-9
         assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-8 and relerr(out["dnlZ_lik"], g["dnlZ_lik"]) < 1e-8
+
+
+def test_G11_remaining_kernels_and_composites():
+    """RQard, Gabor, Periodic, Noise, Const and Sum/Product/Scale trees (Core/cov.py:230-328)."""
+    g = golden("G11_kernels_rqard_gabor_periodic_noise_const_composites")
+    trees = g11_trees()
+    for nm in ("rqard", "gabor", "noise", "const", "periodic", "sum", "prod", "scale", "tree", "ardsum", "maunaloa"):
+        x, z = (g["x1"], g["z1"]) if nm in G11_1D else (g["x"], g["z"])
+        tree = trees[nm]
+        kind, para = (tree[1], tree[2]) if tree[0] == "leaf" else (tree, 0)
+        hyp = g[nm + "_hyp"]
+        assert O.n_cov_hyp(kind, x.shape[1]) == len(hyp)
+        for mode, kw in (("train", dict(x=x)), ("cross", dict(x=x, z=z)), ("self", dict(z=z))):
+            m = "self_test" if mode == "self" else mode
+            np.testing.assert_allclose(O.cov_matrix(kind, hyp, para, mode=m, **kw), g["%s_K_%s" % (nm, mode)], rtol=1e-13,
+                                       atol=1e-300, err_msg=nm + mode)
+            for i in range(len(hyp)):
+                np.testing.assert_allclose(O.der_matrix(kind, hyp, para, mode=m, der=i, **kw), g["%s_dK%d_%s" % (nm, i, mode)],
+                                           rtol=1e-12, atol=1e-300, err_msg="%s d%d %s" % (nm, i, mode))
+
+
+def test_G11_fits_with_composites():
+    trees = g11_trees()
+    g = golden("G11_fit_maunaloa_N300")
+    x, y = g["x"], g["y"]
+    c = g["mean_hyp"][0]
+    out = O.exact_fit(trees["maunaloa"], g["cov_hyp"], 0, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y), faithful=False)
+    assert relerr(out["nlZ"], g["nlZ"]) < 1e-10 and relerr(out["alpha"], g["alpha"]) < 1e-8
+    assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-8 and relerr(out["dnlZ_lik"], g["dnlZ_lik"]) < 1e-8
+    x, y = synth_reg(300, 4)
+    for nm, kind in (("rqard", O.RQARD), ("scaled_sum", trees["scaled_sum"])):
+        g = golden("G11_fit_%s_N300" % nm)
+        c = g["mean_hyp"][0]
+        out = O.exact_fit(kind, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y), faithful=False)
+        assert relerr(out["nlZ"], g["nlZ"]) < 1e-11 and relerr(out["alpha"], g["alpha"]) < 1e-9
+        assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-8 and relerr(out["dnlZ_lik"], g["dnlZ_lik"]) < 1e-8
+    g = golden("G11_ep_composite_N200")
+    out = O.ep_fit(trees["ep_composite"], g["cov_hyp"], 0, g["x"], g["y"], np.zeros_like(g["y"]))
+    assert relerr(out["nlZ"], g["nlZ"]) < 1e-9 and relerr(out["alpha"], g["alpha"]) < 1e-7
+    assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-7
