@@ -58,6 +58,7 @@ SIGNATURES = {
     "pgp_test_gemm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                 C.c_double, _dp, _i64, _dp, _i64, _dp, _i64, C.c_int, C.c_int, C.c_int, C.c_int,
                                 _dp]),
+    "pgp_test_valu_peak": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "pgp_test_mfma_peak": (C.c_int, [_vp, C.c_int, _dp]),
     "pgp_test_mfma_cycles": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "pgp_test_leaf_ticks": (C.c_int, [_vp, _dp]),

@@ -13,6 +13,11 @@
 //        MODE_FACTOR fused assembly of B = K/sn2 + I straight into the (padded) factor buffer that
 //                    the Cholesky overwrites: only the row-major upper triangle (= column-major
 //                    lower) is written, padding rows/cols get the identity.
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "kernels.h"
 #include "sqdist_tile.h"
 
@@ -31,57 +36,23 @@ __global__ void scale_transpose_kernel(const double* __restrict__ x, long n, int
 }
 
 enum { MODE_SYM = 0, MODE_RECT = 1, MODE_FACTOR = 2 };
+#ifndef PGP_SUPER
+#define PGP_SUPER 8
+#endif
+constexpr int SUPER = PGP_SUPER;          // super-tile edge in tiles (0: plain packed-triangular order)
 
-template <class COV> struct is_program { static constexpr bool value = false; };
-template <> struct is_program<CovProgram> { static constexpr bool value = true; };
-
-// COV = CovParams (one functor, the hot path) or CovProgram (Sum/Product/Scale tree; elements are evaluated in a
-// rolled loop over LDS-staged distances so that the eight leaf functors are instantiated once, not 16 times)
-template <int MODE, class COV>
-__global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict__ XrT, long ldr, long n,
-                                                       const double* __restrict__ XcT, long ldc, long m, int dpad,
-                                                       COV cp, double inv_sn2, double* __restrict__ out,
-                                                       long ldo, long ntile_c) {
-    constexpr int TS = ST + 2;                      // transpose-tile row stride (16-byte aligned rows)
-    constexpr bool PROG = is_program<COV>::value;
-    constexpr int SMN = MODE == MODE_SYM ? ST * TS : (PROG ? 16 * 256 : 2 * SKC * ST);
-    __shared__ __attribute__((aligned(16))) double sm[SMN];
-    long ti, tj;
-    if (MODE == MODE_RECT) {
-        ti = blockIdx.x / ntile_c;
-        tj = blockIdx.x % ntile_c;
-    } else {                                       // packed upper-triangular tile index (tj >= ti)
-        const long b = blockIdx.x;
-        const long nt = ntile_c;
-        // row ti holds (nt - ti) tiles; invert the prefix sum b = ti*nt - ti(ti-1)/2 + (tj - ti)
-        long r = (long)(((2.0 * nt + 1.0) - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)b)) * 0.5);
-        if (r < 0) r = 0;
-        while (r > 0 && r * nt - r * (r - 1) / 2 > b) --r;
-        while ((r + 1) * nt - (r + 1) * r / 2 <= b) ++r;
-        ti = r;
-        tj = ti + (b - (r * nt - r * (r - 1) / 2));
-    }
-    const long r0 = ti * ST, c0 = tj * ST;
-    double s[4][4];
-    sqdist_tile(XrT, ldr, r0, XcT, ldc, c0, dpad, sm, s);
-
+// The scalar map of one 4x4 register tile with the kernel family and value/derivative choice fixed at compile time:
+// the run-time switch sits OUTSIDE the unrolled element loop, so the executed path is 16 short copies of one functor
+// (a few KB of code) instead of 16 copies of the whole kind chain (the unspecialised kernel was ~18k instructions,
+// larger than the instruction cache).
+template <int MODE, int KIND, bool DER>
+__device__ __forceinline__ void tile_values(const CovParams& cp0, const double (&s)[4][4], double (&v)[4][4],
+                                            const double* __restrict__ XrT, long ldr, const double* __restrict__ XcT,
+                                            long ldc, long r0, long c0, long n, double inv_sn2) {
+    CovParams cp = cp0;
+    cp.kind = KIND;                                 // constant-folds the kind chains of cov_value / cov_deriv
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
-    double v[4][4];
-    if (PROG) {                                     // sm is free: sqdist_tile ends with a barrier
-        double* sv = sm + t;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sv[e * 256] = s[e >> 2][e & 3];
-#pragma unroll 1
-        for (int e = 0; e < 16; ++e) {
-            const int a = e >> 2, b = e & 3;
-            const long r = r0 + 4 * tr + a;
-            const long c = c0 + 2 * tc + (b & 1) + 32 * (b >> 1);
-            sv[e * 256] = cov_elem(cp, sv[e * 256], 0.0, MODE != MODE_RECT && r == c);
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e >> 2][e & 3] = sv[e * 256];
-    }
-    const int ard_der = cov_ard_der(cp);
+    const int ard_der = DER ? cov_ard_der(cp) : -1;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -89,15 +60,15 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict_
             const long r = r0 + 4 * tr + a;
             const long c = c0 + 2 * tc + (b & 1) + 32 * (b >> 1);
             double val;
-            if (PROG) {
-                val = s[a][b];
+            if (!DER) {
+                val = cov_value(cp, s[a][b], MODE != MODE_RECT && r == c);
             } else {
                 double dk2 = 0.0;
-                if (ard_der >= 0) {
+                if ((KIND == 1 || KIND == 6) && ard_der >= 0) {
                     const double dd = XrT[(long)ard_der * ldr + r] - XcT[(long)ard_der * ldc + c];
                     dk2 = dd * dd;
                 }
-                val = cov_elem(cp, s[a][b], dk2, MODE != MODE_RECT && r == c);
+                val = cov_deriv(cp, s[a][b], dk2, MODE != MODE_RECT && r == c);
             }
             if (MODE == MODE_FACTOR) {
                 if (r < n && c < n) val = val * inv_sn2 + (r == c ? 1.0 : 0.0);
@@ -105,57 +76,253 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict_
             }
             v[a][b] = val;
         }
-    // direct store: row-major, double2 along c
+}
+
+// overload selection: programs never call the functor path
+template <int MODE, int KIND, bool DER>
+__device__ __forceinline__ void tile_values_sel(const CovProgram&, const double (&)[4][4], double (&)[4][4], const double*, long,
+                                                const double*, long, long, long, long, double) {}
+template <int MODE, int KIND, bool DER>
+__device__ __forceinline__ void tile_values_sel(const CovParams& cp, const double (&s)[4][4], double (&v)[4][4],
+                                                const double* __restrict__ XrT, long ldr, const double* __restrict__ XcT,
+                                                long ldc, long r0, long c0, long n, double inv_sn2) {
+    tile_values<MODE, KIND, DER>(cp, s, v, XrT, ldr, XcT, ldc, r0, c0, n, inv_sn2);
+}
+
+template <class COV> struct is_program { static constexpr bool value = false; };
+template <> struct is_program<CovProgram> { static constexpr bool value = true; };
+
+// first-slab share of one thread: 2 double2 of the row slab, 2 of the column slab (same split as sqdist_tile)
+struct SlabRegs { double2_t r[2], c[2]; };
+
+__device__ __forceinline__ void slab_fetch(const double* __restrict__ XrT, long ldr, long r0,
+                                           const double* __restrict__ XcT, long ldc, long c0, int k0, SlabRegs& g) {
+    const int t = threadIdx.x;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const long r = r0 + 4 * tr + a;
+    for (int p = 0; p < 2; ++p) {
+        const int v = t + p * 256;                 // 0..511 : k = v / 32, pair = v % 32
+        const int k = v >> 5, pr = v & 31;
+        g.r[p] = *(const double2_t*)(XrT + (long)(k0 + k) * ldr + r0 + 2 * pr);
+        g.c[p] = *(const double2_t*)(XcT + (long)(k0 + k) * ldc + c0 + 2 * pr);
+    }
+}
+
+__device__ __forceinline__ void slab_stage(double* __restrict__ smx, const SlabRegs& g) {
+    const int t = threadIdx.x;
 #pragma unroll
-        for (int bh = 0; bh < 2; ++bh) {
-            const long c = c0 + 2 * tc + 32 * bh;
-            if (MODE == MODE_FACTOR) {
-                if (ti != tj) {
-                    *(double2_t*)(out + r * ldo + c) = double2_t{v[a][2 * bh], v[a][2 * bh + 1]};
-                } else {                            // diagonal tile: keep exact zeros below the diagonal
-                    if (c >= r) out[r * ldo + c] = v[a][2 * bh];
-                    if (c + 1 >= r) out[r * ldo + c + 1] = v[a][2 * bh + 1];
+    for (int p = 0; p < 2; ++p) {
+        const int v = t + p * 256;
+        const int k = v >> 5, pr = v & 31;
+        *(double2_t*)(smx + k * ST + 2 * pr) = g.r[p];
+        *(double2_t*)(smx + SKC * ST + k * ST + 2 * pr) = g.c[p];
+    }
+}
+
+__device__ __forceinline__ void slab_accum(const double* __restrict__ smx, double (&s)[4][4]) {
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    const double* xr = smx;
+    const double* xc = smx + SKC * ST;
+#pragma unroll
+    for (int k = 0; k < SKC; ++k) {
+        const double2_t r01 = *(const double2_t*)(xr + k * ST + 4 * tr);
+        const double2_t r23 = *(const double2_t*)(xr + k * ST + 4 * tr + 2);
+        const double2_t c01 = *(const double2_t*)(xc + k * ST + 2 * tc);
+        const double2_t c23 = *(const double2_t*)(xc + k * ST + 2 * tc + 32);
+        const double rv[4] = {r01[0], r01[1], r23[0], r23[1]};
+        const double cv[4] = {c01[0], c01[1], c23[0], c23[1]};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double df = rv[a] - cv[b];
+                s[a][b] = fma(df, df, s[a][b]);
+            }
+    }
+}
+
+// COV = CovParams (one functor, the hot path) or CovProgram (Sum/Product/Scale tree; elements are evaluated in a
+// rolled loop over LDS-staged distances so that the eight leaf functors are instantiated once, not 16 times).
+//
+// Persistent workgroups, software-pipelined over tiles: the coordinates of tile i+1 are fetched into registers
+// BEFORE the stores of tile i are issued (vmcnt retires in order on gfx9, so a load queued behind 32 KB of stores
+// would wait for them), which lets the store bursts of one tile drain under the distance/exp arithmetic of the
+// next.  One workgroup per tile ran the phases load -> VALU -> store of all resident workgroups in lock-step:
+// HBM idle during the VALU phase, VALU idle (55 % busy by SQ_ACTIVE_INST_VALU) during the store phase.
+__device__ double2_t g_trash[1];       // out-of-range lanes of the FAST store path write here
+
+// FAST: ldo, n and m are even -> every store is an aligned, *unconditional* double2 store (lanes outside the matrix
+// are redirected to g_trash).  With a fixed number of stores per tile the compiler can wait for the prefetched
+// coordinates with vmcnt(#stores) instead of vmcnt(0), i.e. without waiting for the stores themselves.
+template <int MODE, class COV, int KIND, bool DER, bool FAST>
+__global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict__ XrT, long ldr, long n,
+                                                       const double* __restrict__ XcT, long ldc, long m, int dpad,
+                                                       COV cp, double inv_sn2, double* __restrict__ out,
+                                                       long ldo, const int2* __restrict__ tiles, long ntiles) {
+    constexpr int TS = ST + 2;                      // transpose-tile row stride (16-byte aligned rows)
+    constexpr bool PROG = is_program<COV>::value;
+    constexpr int SMT = MODE == MODE_SYM ? ST * TS : (PROG ? 16 * 256 : 2);
+    // coordinate slabs (2 x 16 x 64 doubles) and the mirror-transpose tile share one region: 33.8 KB -> 4 WGs per CU
+    constexpr int SMX = 2 * SKC * ST;
+    __shared__ __attribute__((aligned(16))) double sm[SMT > SMX ? SMT : SMX];
+    double* smx = sm;
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    // (ti, tj) come from a host-built table through scalar loads: no per-tile index arithmetic on the VALU
+    int2 tc2 = tiles[tile];
+    long ti = tc2.x, tj = tc2.y;
+    SlabRegs g;
+    slab_fetch(XrT, ldr, ti * ST, XcT, ldc, tj * ST, 0, g);
+    slab_stage(smx, g);
+    __syncthreads();
+    while (true) {
+        const long r0 = ti * ST, c0 = tj * ST;
+        const long next = tile + gridDim.x;
+        long nti = 0, ntj = 0;
+        if (next < ntiles) {
+            const int2 nx = tiles[next];
+            nti = nx.x; ntj = nx.y;
+            slab_fetch(XrT, ldr, nti * ST, XcT, ldc, ntj * ST, 0, g);
+        }
+        double s[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s[a][b] = 0.0;
+        slab_accum(smx, s);
+        for (int k0 = SKC; k0 < dpad; k0 += SKC) {          // d > 16: further slabs, loaded in place
+            SlabRegs h;
+            slab_fetch(XrT, ldr, r0, XcT, ldc, c0, k0, h);
+            __syncthreads();
+            slab_stage(smx, h);
+            __syncthreads();
+            slab_accum(smx, s);
+        }
+
+        double v[4][4];
+        if (PROG) {
+            __syncthreads();                            // slabs consumed; the staging area overlays them
+            double* sv = sm + t;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sv[e * 256] = s[e >> 2][e & 3];
+#pragma unroll 1
+            for (int e = 0; e < 16; ++e) {
+                const int a = e >> 2, b = e & 3;
+                const long r = r0 + 4 * tr + a;
+                const long c = c0 + 2 * tc + (b & 1) + 32 * (b >> 1);
+                sv[e * 256] = cov_elem(cp, sv[e * 256], 0.0, MODE != MODE_RECT && r == c);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e >> 2][e & 3] = sv[e * 256];
+        }
+        if (!PROG) tile_values_sel<MODE, KIND, DER>(cp, s, v, XrT, ldr, XcT, ldc, r0, c0, n, inv_sn2);
+        else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const long r = r0 + 4 * tr + a;
+                    const long c = c0 + 2 * tc + (b & 1) + 32 * (b >> 1);
+                    double val = s[a][b];
+                    if (MODE == MODE_FACTOR) {
+                        if (r < n && c < n) val = val * inv_sn2 + (r == c ? 1.0 : 0.0);
+                        else val = (r == c) ? 1.0 : 0.0;
+                    }
+                    v[a][b] = val;
                 }
-            } else {
-                if (r < n) {
-                    if (c + 1 < m && ((ldo & 1) == 0)) {
+        }
+        // direct store: row-major, double2 along c
+        if (FAST) {
+            // uniform 64-bit tile base + 32-bit per-thread byte offsets (64 rows x ldo x 8 B < 4 GiB)
+            char* base = (char*)(out + r0 * ldo + c0);
+            const unsigned ldb = (unsigned)ldo * 8u;
+            const unsigned off0 = (unsigned)(4 * tr) * ldb + (unsigned)(2 * tc) * 8u;
+            const bool edge = MODE != MODE_FACTOR && (r0 + ST > n || c0 + ST > m);      // uniform
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int bh = 0; bh < 2; ++bh) {
+                    double2_t val = double2_t{v[a][2 * bh], v[a][2 * bh + 1]};
+                    double2_t* dst = (double2_t*)(base + (off0 + (unsigned)a * ldb + (unsigned)bh * 256u));
+                    if (MODE == MODE_FACTOR) {      // padded buffer: every tile is full; exact zeros below the diagonal
+                        if (ti == tj) {
+                            const int rl = 4 * tr + a, cl = 2 * tc + 32 * bh;
+                            if (cl < rl) val[0] = 0.0;
+                            if (cl + 1 < rl) val[1] = 0.0;
+                        }
+                    } else if (edge) {
+                        const long r = r0 + 4 * tr + a, c = c0 + 2 * tc + 32 * bh;
+                        if (r >= n || c >= m) dst = g_trash;
+                    }
+                    *dst = val;
+                }
+            }
+        } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long r = r0 + 4 * tr + a;
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh) {
+                const long c = c0 + 2 * tc + 32 * bh;
+                if (MODE == MODE_FACTOR) {
+                    if (ti != tj) {
                         *(double2_t*)(out + r * ldo + c) = double2_t{v[a][2 * bh], v[a][2 * bh + 1]};
-                    } else {
-                        if (c < m) out[r * ldo + c] = v[a][2 * bh];
-                        if (c + 1 < m) out[r * ldo + c + 1] = v[a][2 * bh + 1];
+                    } else {                            // diagonal tile: keep exact zeros below the diagonal
+                        if (c >= r) out[r * ldo + c] = v[a][2 * bh];
+                        if (c + 1 >= r) out[r * ldo + c + 1] = v[a][2 * bh + 1];
+                    }
+                } else {
+                    if (r < n) {
+                        if (c + 1 < m && ((ldo & 1) == 0)) {
+                            *(double2_t*)(out + r * ldo + c) = double2_t{v[a][2 * bh], v[a][2 * bh + 1]};
+                        } else {
+                            if (c < m) out[r * ldo + c] = v[a][2 * bh];
+                            if (c + 1 < m) out[r * ldo + c + 1] = v[a][2 * bh + 1];
+                        }
                     }
                 }
             }
         }
-    }
-    if (MODE == MODE_SYM && ti != tj) {
-        // mirrored store out[c][r]: transpose the tile through LDS so that the global stores are 512-byte
-        // contiguous runs (32 lanes x 16 B) instead of 32-byte pieces with a row stride between lanes
-        __syncthreads();                            // sm is free again (sqdist_tile ends with a barrier)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int cl = 2 * tc + (b & 1) + 32 * (b >> 1);
-            *(double2_t*)(sm + cl * TS + 4 * tr) = double2_t{v[0][b], v[1][b]};
-            *(double2_t*)(sm + cl * TS + 4 * tr + 2) = double2_t{v[2][b], v[3][b]};
         }
-        __syncthreads();
-        const int pr = t & 31, rw = t >> 5;         // 8 tile rows per pass, 32 double2 per row
+        if (MODE == MODE_SYM && (FAST || ti != tj)) {     // FAST: diagonal tiles too (same values) -> fixed store count
+            // mirrored store out[c][r]: transpose the tile through LDS so that the global stores are 512-byte
+            // contiguous runs (32 lanes x 16 B) instead of 32-byte pieces with a row stride between lanes
+            __syncthreads();                            // the slabs (same LDS) have been consumed by every wave
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int cl = p * 8 + rw;
-            const long c = c0 + cl, r = r0 + 2 * pr;
-            if (c < m) {
-                const double2_t val = *(const double2_t*)(sm + cl * TS + 2 * pr);
-                if (r + 1 < n && ((ldo & 1) == 0)) *(double2_t*)(out + c * ldo + r) = val;
-                else {
-                    if (r < n) out[c * ldo + r] = val[0];
-                    if (r + 1 < n) out[c * ldo + r + 1] = val[1];
+            for (int b = 0; b < 4; ++b) {
+                const int cl = 2 * tc + (b & 1) + 32 * (b >> 1);
+                *(double2_t*)(sm + cl * TS + 4 * tr) = double2_t{v[0][b], v[1][b]};
+                *(double2_t*)(sm + cl * TS + 4 * tr + 2) = double2_t{v[2][b], v[3][b]};
+            }
+            __syncthreads();
+            const int pr = t & 31, rw = t >> 5;         // 8 tile rows per pass, 32 double2 per row
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int cl = p * 8 + rw;
+                const long c = c0 + cl, r = r0 + 2 * pr;
+                if (FAST) {
+                    const double2_t val = *(const double2_t*)(sm + cl * TS + 2 * pr);
+                    char* mbase = (char*)(out + c0 * ldo + r0);
+                    double2_t* dst = (double2_t*)(mbase + ((unsigned)cl * ((unsigned)ldo * 8u) + (unsigned)pr * 16u));
+                    if ((r0 + ST > n || c0 + ST > m) && (c >= m || r >= n)) dst = g_trash;
+                    *dst = val;
+                } else if (c < m) {
+                    const double2_t val = *(const double2_t*)(sm + cl * TS + 2 * pr);
+                    if (r + 1 < n && ((ldo & 1) == 0)) *(double2_t*)(out + c * ldo + r) = val;
+                    else {
+                        if (r < n) out[c * ldo + r] = val[0];
+                        if (r + 1 < n) out[c * ldo + r + 1] = val[1];
+                    }
                 }
             }
         }
+        if (next >= ntiles) break;
+        __syncthreads();                                // everyone is done reading smx / sm
+        // the wait for the prefetched coordinates sits right behind this tile's stores in straight-line code, so it
+        // is a vmcnt(#stores) -- the stores keep draining while the next tile computes
+        slab_stage(smx, g);
+        __syncthreads();
+        tile = next; ti = nti; tj = ntj;
     }
 }
 
@@ -173,21 +340,77 @@ int scale_transpose_launch(const double* x, long n, int d, const double* scale_d
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
+// (ti, tj) lists, cached per device and shape.  kind 0: row-major ntr x ntc ('cross'); kind 1: upper-triangular tiles of
+// an nt x nt grid walked in SUPER x SUPER super-tiles (tiles in flight together cover 512 x 512 blocks: both the direct
+// and the mirrored stores land in 4 KB runs per matrix row).
+static std::mutex g_tab_mu;
+static std::map<std::vector<long>, std::pair<int2*, long>> g_tabs;
+static int tile_table(int tri, long ntr, long ntc, const int2** tab, long* cnt) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PGP_ERR_HIP;
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    const std::vector<long> key = {dev, tri, ntr, ntc};
+    auto it = g_tabs.find(key);
+    if (it == g_tabs.end()) {
+        std::vector<int2> h;
+        if (!tri) {
+            for (long i = 0; i < ntr; ++i) for (long j = 0; j < ntc; ++j) h.push_back(make_int2((int)i, (int)j));
+        } else {
+            const long S = SUPER > 0 ? SUPER : 1, nst = (ntr + S - 1) / S;
+            for (long SI = 0; SI < nst; ++SI)
+                for (long SJ = SI; SJ < nst; ++SJ)
+                    for (long i = SI * S; i < std::min(ntr, SI * S + S); ++i)
+                        for (long j = std::max(i, SJ * S); j < std::min(ntr, SJ * S + S); ++j) h.push_back(make_int2((int)i, (int)j));
+        }
+        int2* d = nullptr;
+        if (hipMalloc((void**)&d, std::max<size_t>(1, h.size()) * sizeof(int2)) != hipSuccess) return PGP_ERR_HIP;
+        if (!h.empty() && hipMemcpy(d, h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) return PGP_ERR_HIP;
+        it = g_tabs.emplace(key, std::make_pair(d, (long)h.size())).first;
+    }
+    *tab = it->second.first; *cnt = it->second.second;
+    return PGP_OK;
+}
+
+static int g_tile_grid = 2048;                     // persistent workgroups (4 resident per CU, the rest queue: dynamic balance); option "asm_grid"
+void cov_tile_set_grid(int g) { g_tile_grid = g; }
+
 template <int MODE>
-static int cov_tile_dispatch(const CovSpec& cs, int train, unsigned nblk, hipStream_t st, const double* XrT, long ldr,
+static int cov_tile_dispatch(const CovSpec& cs, int train, long ntr, long ntc_, hipStream_t st, const double* XrT, long ldr,
                              long n, const double* XcT, long ldc, long m, int dpad, double inv_sn2, double* out,
-                             long ldo, long ntile_c) {
+                             long ldo) {
+    const int2* tiles = nullptr;
+    long ntiles = 0;
+    { const int rc = tile_table(MODE != MODE_RECT, ntr, ntc_, &tiles, &ntiles); if (rc != PGP_OK) return rc; }
+    if (ntiles == 0) return PGP_OK;
+    const unsigned nblk = g_tile_grid > 0 ? (unsigned)std::min<long>(ntiles, g_tile_grid) : (unsigned)ntiles;
     if (cs.prog) {
         CovProgram pg = cs.pg;
         for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = train;
-        hipLaunchKernelGGL((cov_tile_kernel<MODE, CovProgram>), dim3(nblk), dim3(256), 0, st, XrT, ldr, n, XcT, ldc, m,
-                           dpad, pg, inv_sn2, out, ldo, ntile_c);
+        hipLaunchKernelGGL((cov_tile_kernel<MODE, CovProgram, 0, false, false>), dim3(nblk), dim3(256), 0, st, XrT, ldr, n,
+                           XcT, ldc, m, dpad, pg, inv_sn2, out, ldo, tiles, ntiles);
     } else {
         CovParams cp = cs.cp;
         cp.train = train;
         if (cp.kind == 6 && cp.ref_der) cp.gb = train == 1 ? 0.0 : cs.ell4;       // Core/cov.py:1415-1418 as returned
-        hipLaunchKernelGGL((cov_tile_kernel<MODE, CovParams>), dim3(nblk), dim3(256), 0, st, XrT, ldr, n, XcT, ldc, m,
-                           dpad, cp, inv_sn2, out, ldo, ntile_c);
+        // kernel family and value/derivative choice are compile-time parameters of the kernel: one functor's code
+        // and constants per instantiation (the persistent tile loop keeps hoisted constants live)
+        const bool fast = ((ldo | n | m) & 1) == 0;
+#define LAUNCH(K, D, F) hipLaunchKernelGGL((cov_tile_kernel<MODE, CovParams, K, D, F>), dim3(nblk), dim3(256), 0, st, XrT, ldr, \
+                                           n, XcT, ldc, m, dpad, cp, inv_sn2, out, ldo, tiles, ntiles)
+#define LAUNCH_K(K) do { if (cp.der < 0) { if (fast) LAUNCH(K, false, true); else LAUNCH(K, false, false); } \
+                         else LAUNCH(K, true, false); } while (0)
+        switch (cp.kind) {
+            case 0: LAUNCH_K(0); break;
+            case 1: LAUNCH_K(1); break;
+            case 2: LAUNCH_K(2); break;
+            case 3: LAUNCH_K(3); break;
+            case 4: LAUNCH_K(4); break;
+            case 5: LAUNCH_K(5); break;
+            case 6: LAUNCH_K(6); break;
+            default: return -2;
+        }
+#undef LAUNCH_K
+#undef LAUNCH
     }
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
@@ -195,23 +418,19 @@ static int cov_tile_dispatch(const CovSpec& cs, int train, unsigned nblk, hipStr
 int cov_sym_launch(const double* XT, long ldp, long n, int dpad, const CovSpec& cs, double* out, hipStream_t st,
                    long ldo) {
     const long nt = (n + ST - 1) / ST;
-    const long nblk = nt * (nt + 1) / 2;
-    return cov_tile_dispatch<MODE_SYM>(cs, 1, (unsigned)nblk, st, XT, ldp, n, XT, ldp, n, dpad, 0.0, out,
-                                       ldo > 0 ? ldo : n, nt);
+    return cov_tile_dispatch<MODE_SYM>(cs, 1, nt, nt, st, XT, ldp, n, XT, ldp, n, dpad, 0.0, out, ldo > 0 ? ldo : n);
 }
 
 int cov_rect_launch(const double* XrT, long ldr, long n, const double* XcT, long ldc, long m, int dpad,
                     const CovSpec& cs, double* out, long ldo, hipStream_t st) {
     const long ntr = (n + ST - 1) / ST, ntc = (m + ST - 1) / ST;
-    return cov_tile_dispatch<MODE_RECT>(cs, 0, (unsigned)(ntr * ntc), st, XrT, ldr, n, XcT, ldc, m, dpad, 0.0, out, ldo,
-                                        ntc);
+    return cov_tile_dispatch<MODE_RECT>(cs, 0, ntr, ntc, st, XrT, ldr, n, XcT, ldc, m, dpad, 0.0, out, ldo);
 }
 
 int cov_factor_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double inv_sn2,
                       double* Bf, long ldf, hipStream_t st) {
     const long nt = np / ST;
-    const long nblk = nt * (nt + 1) / 2;
-    return cov_tile_dispatch<MODE_FACTOR>(cs, 1, (unsigned)nblk, st, XT, ldp, n, XT, ldp, n, dpad, inv_sn2, Bf, ldf, nt);
+    return cov_tile_dispatch<MODE_FACTOR>(cs, 1, nt, nt, st, XT, ldp, n, XT, ldp, n, dpad, inv_sn2, Bf, ldf);
 }
 
 // k(z,z) and its derivatives at zero distance ('self_test' mode): one evaluation of the functor

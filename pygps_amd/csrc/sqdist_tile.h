@@ -135,20 +135,45 @@ __device__ __forceinline__ double ipow(double b, int n) {      // b^n, n >= 0, 0
     return r;
 }
 
+// exp(x) for x <= 0 (the squared-exponential map).  Cody-Waite reduction x = k ln2 + r, |r| <= ln2/2, Taylor
+// polynomial of degree 13 (remainder < 5e-18 relative), 2^k applied by v_ldexp (underflows to 0 by itself): 19 VALU
+// instructions against ~26 for the library exp with its overflow / underflow selects; within 1-2 ulp of it.
+__device__ __forceinline__ double exp_nonpos(double x) {
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                 // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);               // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);              // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);              // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);             // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);               // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);              // 1/7!
+    p = fma(p, r, 1.3888888888888889e-03);             // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);              // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);             // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);             // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double kc = fmax(k, -1100.0);                // keep the int conversion in range; 2^-1100 is already 0
+    return ldexp(p, (int)kc);
+}
+
 // covariance value k(x,z) from the scaled squared distance s; same = "row and column are the same training point"
 // EXT = false leaves out the trigonometric / index-dependent kinds (7..10): the primitive hot-path kernels are
 // instantiated without them (they run as one-leaf programs), which keeps their register count where it was.
 template <bool EXT = false>
 __device__ __forceinline__ double cov_value(const CovParams& p, double s, bool same = false) {
     if (p.kind == 4 || p.kind == 6) {     // RQ: Core/cov.py:1323, RQard :1394
-        return p.sf2 * exp(-p.alpha * log(1.0 + 0.5 * s / p.alpha));
+        return p.sf2 *  exp_nonpos(-p.alpha * log(1.0 + 0.5 * s / p.alpha));
     }
     if (EXT && p.kind == 7) {                    // Gabor: cov.py:424-426
-        return exp(-0.5 * s) * cos(sqrt(s) * p.ga);
+        return  exp_nonpos(-0.5 * s) * cos(sqrt(s) * p.ga);
     }
     if (EXT && p.kind == 8) {             // Periodic: cov.py:1212-1216 (s = raw |x-z|^2, 1-d inputs)
         const double R = sin(sqrt(s) * p.ga) * p.gb;
-        return p.sf2 * exp(-2.0 * R * R);
+        return p.sf2 *  exp_nonpos(-2.0 * R * R);
     }
     if (EXT && p.kind == 9) {             // Noise: cov.py:1269-1280 (identity on 'train', |x-z|^2 < 1e-9 on 'cross', 0 on 'self_test')
         const bool one = p.train == 1 ? same : (p.train == 0 ? s < 1e-9 : false);
@@ -164,31 +189,31 @@ __device__ __forceinline__ double cov_value(const CovParams& p, double s, bool s
     }
     if (p.kind == 2) {                    // Matern: t = sqrt(d) |x-z| / ell (scale folded into XsT)
         const double t = sqrt(s);
-        return p.sf2 * matern_poly(p.md, t) * exp(-t);
+        return p.sf2 * matern_poly(p.md, t) *  exp_nonpos(-t);
     }
-    return p.sf2 * exp(-0.5 * s);         // RBF / RBFard
+    return p.sf2 * exp_nonpos(-0.5 * s);  // RBF / RBFard
 }
 
 // derivative w.r.t. hyper p.der; dk2 = scaled squared difference in coordinate p.der (ARD only)
 template <bool EXT = false>
 __device__ __forceinline__ double cov_deriv(const CovParams& p, double s, double dk2, bool same = false) {
-    if (p.kind == 3) return exp(-0.5 * s) * s;        // RBFunit: Core/cov.py:865
+    if (p.kind == 3) return  exp_nonpos(-0.5 * s) * s;        // RBFunit: Core/cov.py:865
     if (p.kind == 6) {                    // RQard: cov.py:1412-1425
         const double Kp = 1.0 + 0.5 * s / p.alpha;
         const double lk = log(Kp);
-        if (p.der < p.D) return p.sf2 * exp((-p.alpha - 1.0) * lk) * dk2 * p.gb;   // gb = 1 (see make_leaf for compat)
-        if (p.der == p.D) return 2.0 * p.sf2 * exp(-p.alpha * lk);
-        return p.sf2 * exp(-p.alpha * lk) * (0.5 * s / Kp - p.alpha * lk);
+        if (p.der < p.D) return p.sf2 *  exp_nonpos((-p.alpha - 1.0) * lk) * dk2 * p.gb;   // gb = 1 (see make_leaf for compat)
+        if (p.der == p.D) return 2.0 * p.sf2 *  exp_nonpos(-p.alpha * lk);
+        return p.sf2 *  exp_nonpos(-p.alpha * lk) * (0.5 * s / Kp - p.alpha * lk);
     }
     if (EXT && p.kind == 7) {             // Gabor: cov.py:440-448 (as the reference returns them)
         const double dp = sqrt(s) * p.ga;
-        const double K = exp(-0.5 * s) * cos(dp);
+        const double K =  exp_nonpos(-0.5 * s) * cos(dp);
         return p.der == 0 ? dp * K : tan(dp) * dp * K;
     }
     if (EXT && p.kind == 8) {             // Periodic: cov.py:1236-1249
         const double A = sqrt(s) * p.ga;
         const double R = sin(A) * p.gb;
-        const double e = p.sf2 * exp(-2.0 * R * R);
+        const double e = p.sf2 *  exp_nonpos(-2.0 * R * R);
         if (p.der == 0) return 4.0 * e * R * R;
         if (p.der == 1) return 4.0 * p.gb * e * R * cos(A) * A;
         return 2.0 * e;
@@ -201,9 +226,9 @@ __device__ __forceinline__ double cov_deriv(const CovParams& p, double s, double
     if (p.kind == 4) {                    // RQ: Core/cov.py:1337-1345
         const double Kp = 1.0 + 0.5 * s / p.alpha;
         const double lk = log(Kp);
-        if (p.der == 0) return p.sf2 * exp((-p.alpha - 1.0) * lk) * s;
-        if (p.der == 1) return 2.0 * p.sf2 * exp(-p.alpha * lk);
-        return p.sf2 * exp(-p.alpha * lk) * (0.5 * s / Kp - p.alpha * lk);
+        if (p.der == 0) return p.sf2 *  exp_nonpos((-p.alpha - 1.0) * lk) * s;
+        if (p.der == 1) return 2.0 * p.sf2 *  exp_nonpos(-p.alpha * lk);
+        return p.sf2 *  exp_nonpos(-p.alpha * lk) * (0.5 * s / Kp - p.alpha * lk);
     }
     if (p.kind == 5) {                    // PiecePoly: Core/cov.py:774-780
         if (p.der == 2) return 0.0;
@@ -214,22 +239,22 @@ __device__ __forceinline__ double cov_deriv(const CovParams& p, double s, double
         return p.sf2 * ipow(pm, e - 1) * r * ((double)e * pp_func(p.ppv, r, p.ppj) - pm * pp_dfunc(p.ppv, r, p.ppj));
     }
     if (p.kind == 0) {                    // RBF: Core/cov.py:823-825
-        const double K = p.sf2 * exp(-0.5 * s);
+        const double K = p.sf2 *  exp_nonpos(-0.5 * s);
         return p.der == 0 ? K * s : 2.0 * K;
     }
     if (p.kind == 1) {                    // RBFard: Core/cov.py:922-936
-        const double K = p.sf2 * exp(-0.5 * s);
+        const double K = p.sf2 *  exp_nonpos(-0.5 * s);
         return p.der < p.D ? K * dk2 : 2.0 * K;
     }
     const double t = sqrt(s);             // Matern
     if (p.der == 2) return 0.0;
     if (p.ref_der) {                      // Core/cov.py:1173-1177: dmfunc / mfunc applied to K, not t
-        const double K = p.sf2 * matern_poly(p.md, t) * exp(-t);
-        return p.der == 0 ? p.sf2 * matern_dpoly(p.md, K) * K * exp(-K)
-                          : 2.0 * p.sf2 * matern_poly(p.md, K) * exp(-K);
+        const double K = p.sf2 * matern_poly(p.md, t) *  exp_nonpos(-t);
+        return p.der == 0 ? p.sf2 * matern_dpoly(p.md, K) * K *  exp_nonpos(-K)
+                          : 2.0 * p.sf2 * matern_poly(p.md, K) *  exp_nonpos(-K);
     }
-    return p.der == 0 ? p.sf2 * matern_dpoly(p.md, t) * t * exp(-t)
-                      : 2.0 * p.sf2 * matern_poly(p.md, t) * exp(-t);
+    return p.der == 0 ? p.sf2 * matern_dpoly(p.md, t) * t *  exp_nonpos(-t)
+                      : 2.0 * p.sf2 * matern_poly(p.md, t) *  exp_nonpos(-t);
 }
 
 // every derivative (up to three hypers) of the non-ARD kernels, transcendental functions evaluated once
@@ -237,10 +262,10 @@ template <bool EXT = false>
 __device__ __forceinline__ void cov_deriv_all(const CovParams& p, double s, double& d0, double& d1, double& d2,
                                               bool same = false) {
     d2 = 0.0;
-    if (p.kind == 3) { d0 = exp(-0.5 * s) * s; d1 = 0.0; return; }
+    if (p.kind == 3) { d0 =  exp_nonpos(-0.5 * s) * s; d1 = 0.0; return; }
     if (EXT && p.kind == 7) {
         const double dp = sqrt(s) * p.ga;
-        const double K = exp(-0.5 * s) * cos(dp);
+        const double K =  exp_nonpos(-0.5 * s) * cos(dp);
         d0 = dp * K;
         d1 = tan(dp) * dp * K;
         return;
@@ -248,7 +273,7 @@ __device__ __forceinline__ void cov_deriv_all(const CovParams& p, double s, doub
     if (EXT && p.kind == 8) {
         const double A = sqrt(s) * p.ga;
         const double R = sin(A) * p.gb;
-        const double e = p.sf2 * exp(-2.0 * R * R);
+        const double e = p.sf2 *  exp_nonpos(-2.0 * R * R);
         d0 = 4.0 * e * R * R;
         d1 = 4.0 * p.gb * e * R * cos(A) * A;
         d2 = 2.0 * e;
@@ -263,7 +288,7 @@ __device__ __forceinline__ void cov_deriv_all(const CovParams& p, double s, doub
     if (p.kind == 4) {
         const double Kp = 1.0 + 0.5 * s / p.alpha;
         const double lk = log(Kp);
-        const double Ka = p.sf2 * exp(-p.alpha * lk);
+        const double Ka = p.sf2 *  exp_nonpos(-p.alpha * lk);
         d0 = Ka / Kp * s;
         d1 = 2.0 * Ka;
         d2 = Ka * (0.5 * s / Kp - p.alpha * lk);
@@ -280,16 +305,16 @@ __device__ __forceinline__ void cov_deriv_all(const CovParams& p, double s, doub
         return;
     }
     if (p.kind == 0) {
-        const double K = p.sf2 * exp(-0.5 * s);
+        const double K = p.sf2 *  exp_nonpos(-0.5 * s);
         d0 = K * s;
         d1 = 2.0 * K;
         return;
     }
     const double t = sqrt(s);                          // Matern
-    const double e = exp(-t);
+    const double e =  exp_nonpos(-t);
     if (p.ref_der) {
         const double K = p.sf2 * matern_poly(p.md, t) * e;
-        const double eK = exp(-K);
+        const double eK =  exp_nonpos(-K);
         d0 = p.sf2 * matern_dpoly(p.md, K) * K * eK;
         d1 = 2.0 * p.sf2 * matern_poly(p.md, K) * eK;
     } else {

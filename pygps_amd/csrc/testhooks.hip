@@ -79,6 +79,51 @@ int pgp_test_mfma_cycles(pgp_ctx* c, int iters, int nacc, int waves_per_simd, do
     return PGP_OK;
 }
 
+// fp64 VALU issue rate with the instruction mix of the distance loop: 16 x (v_add_f64, v_fma_f64) per step
+__global__ __launch_bounds__(256) void valu_peak_kernel(double* out, int iters, double a0, double b0) {
+    double s[16], a[4], b[4];
+    for (int i = 0; i < 16; ++i) s[i] = 0.0;
+    for (int i = 0; i < 4; ++i) { a[i] = a0 + threadIdx.x * 1e-3 + i; b[i] = b0 + i * 0.5; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double d = a[i] - b[j];
+                s[4 * i + j] = fma(d, d, s[4 * i + j]);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] += 1e-9; }
+    }
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += s[i];
+    if (t == 12345.678) out[0] = t;
+}
+
+// instr_rate_out[0] = fp64 VALU wave-instructions per ns over the chip; [1] = implied cycles per instruction at 2.4 GHz
+int pgp_test_valu_peak(pgp_ctx* c, int iters, int waves_per_simd, double* out2) {
+    if (!c || !out2) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    double* out = nullptr;
+    HIP_TRY(hipMalloc((void**)&out, 8));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const int blocks = c->prop.multiProcessorCount * waves_per_simd;
+    hipLaunchKernelGGL(valu_peak_kernel, dim3(blocks), dim3(256), 0, c->st, out, 64, 1.0, 1.0);
+    HIP_TRY(hipEventRecord(e0, c->st));
+    hipLaunchKernelGGL(valu_peak_kernel, dim3(blocks), dim3(256), 0, c->st, out, iters, 1.0, 1.0);
+    HIP_TRY(hipEventRecord(e1, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    const double winstr = (double)blocks * 4.0 * (double)iters * 36.0;           // 16 add + 16 fma + 4 add per step
+    const double per_simd = (double)waves_per_simd * (double)iters * 36.0;       // wave-instructions issued per SIMD
+    out2[0] = winstr / (ms * 1e6);
+    out2[1] = (ms * 1e-3) * 2.4e9 / per_simd;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+    return PGP_OK;
+}
+
 int pgp_test_mfma_peak(pgp_ctx* ctx, int iters, double* tflops_out) {
     if (!ctx || !tflops_out) return -1;
     pgp_ctx* c = ctx;

@@ -152,6 +152,9 @@ if __name__ == "__main__":
         assert lib.pgp_test_overlap(ctx, _lib.ptr(o)) == 0
         print("GEMM done at %.3f ms; leaf (other stream, issued after) done at %.3f ms; trsm done at %.3f ms; leaf alone %.3f ms" % tuple(o))
     if "asm" in what:
+      for grid in [int(a[5:]) for a in what if a.startswith("grid=")] or [2048]:
+        lib.pgp_set_option(ctx, b"asm_grid", grid)
+        print("asm_grid", grid)
         for (kind, n, d) in ((0, 8192, 16), (0, 16384, 16), (1, 16384, 64), (2, 16384, 16), (0, 16384, 4)):
             for mode in (0, 2):
                 ms = C.c_double()
