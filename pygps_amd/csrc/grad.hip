@@ -31,14 +31,18 @@ __device__ __forceinline__ double block_sum(double v, double* red /* 4 doubles *
 }
 
 // partial[blk * nacc + h]: h < ncov -> sum Q dK_h ; h == ncov -> sn2 * trace(Q)
+// KIND: the kernel family, a compile-time parameter (one functor's code and constants per instantiation)
+template <int KIND>
 __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __restrict__ XT, long ldp, long n, int dpad,
-                                                              CovParams cp, int ncov, double inv_sn2, double sn2,
+                                                              CovParams cp0, int ncov, double inv_sn2, double sn2,
                                                               const double* __restrict__ Binv, long ldb,
                                                               const double* __restrict__ alpha,
                                                               const double* __restrict__ wv,
                                                               double* __restrict__ partial, long nt) {
     __shared__ __attribute__((aligned(16))) double sm[2 * SKC * ST];
     __shared__ double red[4];
+    CovParams cp = cp0;
+    cp.kind = KIND;
     const long b = blockIdx.x;
     long r = (long)(((2.0 * nt + 1.0) - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)b)) * 0.5);
     if (r < 0) r = 0;
@@ -454,8 +458,19 @@ int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad
     } else {
         CovParams cp = cs.cp;
         cp.train = 1;
-        hipLaunchKernelGGL(hadamard_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, cp, ncov,
-                           1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
+#define HLAUNCH(K) hipLaunchKernelGGL(hadamard_reduce_kernel<K>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, cp, \
+                                      ncov, 1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt)
+        switch (cp.kind) {
+            case 0: HLAUNCH(0); break;
+            case 1: HLAUNCH(1); break;
+            case 2: HLAUNCH(2); break;
+            case 3: HLAUNCH(3); break;
+            case 4: HLAUNCH(4); break;
+            case 5: HLAUNCH(5); break;
+            case 6: HLAUNCH(6); break;
+            default: return -2;
+        }
+#undef HLAUNCH
     }
     hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)(ncov + 1)), dim3(256), 0, st, partial, nblk, ncov + 1,
                        out_dev);
