@@ -89,8 +89,8 @@ def cpu_baseline(N, d, budget_s=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--d", type=int, default=16)
     ap.add_argument("--prof-steps", type=int, default=3)
@@ -245,6 +245,17 @@ def main():
         if asm and asm["launches"]:
             roof["assembly_GBs"] = asm["bytes"] / asm["ms"] / 1e6
             roof["assembly_frac_of_hbm_peak"] = asm["bytes"] / asm["ms"] / 1e6 / PEAK_HBM_GBS
+        # the north-star assembly figure: full symmetric K (getCovMatrix 'train'), RBF, N=16384 d=16, device-resident
+        # coordinates, algorithmic bytes 8 N^2 + 8 N d, HIP-event time over 100 launches
+        try:
+            ms_a = ctypes.c_double()
+            na = 16384
+            if lib.pgp_test_assemble(ctx, _lib.COV_RBF, 0, na, 16, 100, ctypes.byref(ms_a)) == 0 and ms_a.value > 0:
+                ba = 8.0 * na * na + 8.0 * na * 16
+                roof["assembly_full_N16384"] = {"ms": ms_a.value, "GBs": ba / ms_a.value / 1e6, "bound": "hbm",
+                                                "frac_of_hbm_peak": ba / ms_a.value / 1e6 / PEAK_HBM_GBS}
+        except Exception:
+            pass
 
     if rank == 0:
         total_fits = world * args.steps

@@ -3,6 +3,7 @@
 // triangular inverse, W^T W, fused gradient reduce.  See DESIGN.md for the pipeline.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -25,6 +26,9 @@ void prof_collect(pgp_ctx* c) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);
         c->pc_ms[r.cls] += ms; c->pc_flops[r.cls] += r.flops; c->pc_bytes[r.cls] += r.bytes; c->pc_launch[r.cls]++;
+        if (getenv("PGP_PROF_DUMP"))
+            fprintf(stderr, "prof %-34s %8.4f ms %10.3f GF %7.2f TF\n", kProfNames[r.cls], ms, r.flops * 1e-9,
+                    ms > 0 ? r.flops / (ms * 1e-3) * 1e-12 : 0.0);
         c->ev_pool.push_back(r.e0); c->ev_pool.push_back(r.e1);
     }
     c->recs.clear();
