@@ -24,7 +24,9 @@ extern "C" {
 #endif
 
 typedef struct pgp_ctx pgp_ctx;
-typedef struct pgp_factor pgp_factor; /* device-resident posterior: factor R, alpha, sW, inputs */
+typedef struct pgp_factor pgp_factor;
+/* device-resident posterior: factor R, alpha, sW, inputs */
+typedef struct pgp_fitc pgp_fitc;     /* FITC posterior on the device (alpha, dense L, inducing coordinates) */
 
 /* covariance kinds            reference class                      */
 #define PGP_COV_RBF 0     /* Core/cov.py:786-828   hyp=[log ell, log sf]               */
@@ -105,6 +107,18 @@ int pgp_predict(pgp_ctx* ctx, pgp_factor* f, const double* xs, int64_t ns, const
 int pgp_ep_fit(pgp_ctx* ctx, int kind, const double* covhyp, int ncov, int para, int flags, const double* mvec,
                const double* dm, int nmean, int want, int warm, double* ttau, double* tnu, double* alpha_out,
                double* sW_out, double* nlZ_out, double* dnlZ_out, int* sweeps_out, pgp_factor** factor_out);
+
+/* ---- FITC sparse regression: FITC_Exact.evaluate (Core/inf.py:398-455) with FITCOfKernel (Core/cov.py:332-390)
+ * x, y of the last pgp_set_data; xu (nu,d) inducing inputs.  alpha_out (nu), L_out (nu,nu) = post.L (dense,
+ * symmetric; NULL to skip), dnlZ_out = [mean.., cov.., lik].  snu2 = 1e-6 sn2 like the reference (inf.py:410).
+ * Returns >0 when a Cholesky pivot is not positive.  handle_out (optional) feeds pgp_fitc_predict.               */
+int pgp_fitc_fit(pgp_ctx* ctx, int kind, const double* covhyp, int ncov, int para, int flags, double log_sn,
+                 const double* xu, int64_t nu, const double* mvec, const double* dm, int nmean, int want,
+                 double* alpha_out, double* L_out, double* nlZ_out, double* dnlZ_out, pgp_fitc** handle_out);
+/* the dense-L branch of GP.predict (Core/gp.py:404-417): fmu = ms + Ks'alpha, fs2 = max(kss + colsum(Ks o (L Ks)), 0) */
+int pgp_fitc_predict(pgp_ctx* ctx, pgp_fitc* f, const double* xs, int64_t ns, const double* ms, double* fmu,
+                     double* fs2);
+void pgp_fitc_free(pgp_ctx* ctx, pgp_fitc* f);
 
 /* ---- helper functions: tools.jitchol / tools.solve_chol (Core/tools.py:31-97) ----------------
  * pgp_potrf: A (n,n) symmetric row-major in -> lower Cholesky factor (row-major, zeros above) out.

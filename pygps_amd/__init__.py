@@ -7,6 +7,6 @@ gfx950 behind the C ABI in include/pygps_amd.h; importing the package does not n
 into it does (no CPU fallback).
 """
 from . import conf, cov, inf, lik, mean, minimize, opt, tools  # noqa: F401
-from .gp import GP, GPC, GPR  # noqa: F401
+from .gp import GP, GPC, GPR, GP_FITC, GPR_FITC  # noqa: F401
 
 __version__ = "0.1"

@@ -46,6 +46,10 @@ SIGNATURES = {
     "pgp_predict": (C.c_int, [_vp, _vp, _dp, _i64, _dp, _dp, _dp]),
     "pgp_ep_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
                              _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "pgp_fitc_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _i64, _dp, _dp, C.c_int,
+                               C.c_int, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
+    "pgp_fitc_predict": (C.c_int, [_vp, _vp, _dp, _i64, _dp, _dp, _dp]),
+    "pgp_fitc_free": (None, [_vp, _vp]),
     "pgp_potrf": (C.c_int, [_vp, _dp, _i64, _dp]),
     "pgp_potrs": (C.c_int, [_vp, _dp, _i64, _dp, _i64, _dp]),
     "pgp_last_timings": (C.c_int, [_vp, _dp]),

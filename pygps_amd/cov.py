@@ -63,6 +63,10 @@ class Kernel(object):
 
     __rmul__ = __mul__
 
+    def fitc(self, inducingInput):
+        """Covariance function for the FITC approximation (Core/cov.py:195-202)."""
+        return FITCOfKernel(self, inducingInput)
+
     # -- device dispatch ---------------------------------------------------------------------------
     def _device_params(self):
         """(kind, para, flags) of the device functor."""
@@ -437,3 +441,52 @@ class ScaleOfKernel(_Composite):
         if der == 0:
             return 2. * np.exp(self._scale[0]) * self.cov.getCovMatrix(x, z, mode)
         return np.exp(self._scale[0]) * self.cov.getDerMatrix(x, z, mode, der - 1)
+
+
+class FITCOfKernel(Kernel):
+    """Covariance "function" of the FITC approximation (Core/cov.py:332-390): instead of a full matrix it returns the
+    (cross-)covariances with the inducing inputs xu -- 'train': (diag K, Kuu, Ku), 'cross': k(xu, z), 'self_test':
+    k(z, z).  inf.FITC_Exact does not call these (the whole fit is one device call); they exist for API parity."""
+
+    def __init__(self, cov, inducingInput):
+        self.inducingInput = np.asarray(inducingInput, dtype=float)
+        self.covfunc = cov
+        self.para = []
+
+    @property
+    def hyp(self):
+        return self.covfunc.hyp
+
+    @hyp.setter
+    def hyp(self, value):
+        self.covfunc.hyp = value
+
+    def _bind(self, ctx):
+        return self.covfunc._bind(ctx)
+
+    def _check_dim(self, x):
+        if x is not None and self.inducingInput.shape[1] != np.shape(x)[1]:
+            raise Exception('Dimensionality of inducing inputs must match training inputs')
+
+    def getCovMatrix(self, x=None, z=None, mode=None):
+        self.checkInputGetCovMatrix(x, z, mode)
+        xu = self.inducingInput
+        self._check_dim(x)
+        if mode == 'self_test':
+            return self.covfunc.getCovMatrix(z=z, mode='self_test')
+        if mode == 'train':
+            return (self.covfunc.getCovMatrix(z=x, mode='self_test'), self.covfunc.getCovMatrix(x=xu, mode='train'),
+                    self.covfunc.getCovMatrix(x=xu, z=x, mode='cross'))
+        return self.covfunc.getCovMatrix(x=xu, z=z, mode='cross')
+
+    def getDerMatrix(self, x=None, z=None, mode=None, der=None):
+        self.checkInputGetDerMatrix(x, z, mode, der)
+        xu = self.inducingInput
+        self._check_dim(x)
+        if mode == 'self_test':
+            return self.covfunc.getDerMatrix(z=z, mode='self_test', der=der)
+        if mode == 'train':
+            return (self.covfunc.getDerMatrix(z=x, mode='self_test', der=der),
+                    self.covfunc.getDerMatrix(x=xu, mode='train', der=der),
+                    self.covfunc.getDerMatrix(x=xu, z=x, mode='cross', der=der))
+        return self.covfunc.getDerMatrix(x=xu, z=z, mode='cross', der=der)

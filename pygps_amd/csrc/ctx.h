@@ -129,6 +129,25 @@ struct DevScratch {
     }
 };
 
+// Scratch from the context's size-keyed pool: an optimiser calls with identical shapes hundreds of times, so after the
+// first call no hipMalloc / hipFree (both device-synchronising) remain on the path.  Buffers go back on scope exit.
+struct PoolScratch {
+    pgp_ctx* c;
+    std::vector<std::pair<size_t, void*>> held;
+    explicit PoolScratch(pgp_ctx* c_) : c(c_) {}
+    ~PoolScratch() { for (auto& h : held) pool_free(c, h.first, h.second); }
+    template <typename T>
+    int alloc(T** out, size_t bytes) {
+        void* p = nullptr;
+        if (!bytes) bytes = 8;
+        const int rc = pool_alloc(c, bytes, &p);
+        if (rc != PGP_OK) return rc;
+        held.push_back({bytes, p});
+        *out = (T*)p;
+        return PGP_OK;
+    }
+};
+
 // Returns a pooled factor buffer to the context unless ownership was handed on (release()).
 struct FactorGuard {
     pgp_ctx* c; double* F; size_t bytes;

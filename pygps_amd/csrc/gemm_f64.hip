@@ -15,8 +15,8 @@
 //   - the MFMA "row" index is mapped to our N (column) index and the MFMA "col" index to our M
 //     (contiguous) index, so each accumulator register is a 16-element contiguous run of C
 //     in memory (128-byte segments) for the C load / store.
-//   - C is pre-loaded into the accumulators (acc = alpha*beta*C) before the k-loop so its HBM
-//     latency overlaps the first operand tiles; out = alpha*acc.
+//   - C is pre-loaded into the accumulators (acc = (beta/alpha)*C) before the k-loop so its HBM
+//     latency overlaps the first operand tiles; out = alpha*acc = beta*C + alpha*A*B'.
 #include "common.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -78,9 +78,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     const int wm = (wave & 1) * (TM / 2), wn = (wave >> 1) * (TN / 2);
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // ---- accumulators, pre-loaded with alpha*beta*C -------------------------------------
+    // ---- accumulators, pre-loaded with (beta/alpha)*C (== alpha*beta*C for alpha = +-1) ------
     double4_t acc[FM][FN];
-    const double ab = g.alpha * g.beta;
+    const double ab = g.beta / g.alpha;
 #pragma unroll
     for (int im = 0; im < FM; ++im)
 #pragma unroll

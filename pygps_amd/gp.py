@@ -127,6 +127,16 @@ class GP(object):
     def _latent(self, post, xs):
         """fmu, fs2 for the (alpha, sW, L) parametrisation, on the device (Core/gp.py:395-417)."""
         L = post.L
+        fitc = getattr(post, "fitc", None)
+        if fitc is not None:                               # dense-L parametrisation of FITC (Core/gp.py:404-417)
+            xs = _lib.f64(xs)
+            ns = xs.shape[0]
+            ms = _lib.f64(self.meanfunc.getMean(xs)).reshape(ns)
+            fmu = np.empty(ns)
+            fs2 = np.empty(ns)
+            _lib.check(_lib.load().pgp_fitc_predict(fitc.ctx, fitc.handle, _lib.ptr(xs), ns, _lib.ptr(ms), _lib.ptr(fmu),
+                                                    _lib.ptr(fs2)), "pgp_fitc_predict")
+            return fmu.reshape(ns, 1), fs2.reshape(ns, 1)
         if not isinstance(L, inf.DeviceFactor):
             raise NotImplementedError("pygps_amd: predict needs a posterior produced by pygps_amd inference "
                                       "(device-resident factor); there is no CPU fallback")
@@ -200,3 +210,57 @@ class GPC(GP):
             self.inffunc = inf.EP()
         else:
             raise Exception('Possible inf values are "EP" (Laplace is out of scope of pygps_amd).')
+
+
+class GP_FITC(GP):
+    """Base class of the FITC models (Core/gp.py:934-1008)."""
+
+    def __init__(self):
+        super(GP_FITC, self).__init__()
+        self.u = None                                      # inducing points
+
+    def setData(self, x, y, value_per_axis=5):
+        """Training data; without user-given inducing points a regular grid with ``value_per_axis`` values per input
+        dimension is used (Core/gp.py:944-983)."""
+        import itertools
+        assert x.shape[0] == y.shape[0], "number of inputs and labels does not match"
+        self.x = _col(x)
+        self.y = _col(y)
+        if self.usingDefaultMean:
+            self.meanfunc = mean.Const(np.mean(y))
+        axes = [np.linspace(np.min(self.x[:, k]), np.max(self.x[:, k]), value_per_axis) for k in range(self.x.shape[1])]
+        if self.u is None:
+            self.u = np.array(list(itertools.product(*axes)))
+            self.covfunc = self.covfunc.fitc(self.u)
+
+    def setPrior(self, mean=None, kernel=None, inducing_points=None):
+        if kernel is not None:
+            if inducing_points is not None:
+                self.covfunc = kernel.fitc(inducing_points)
+                self.u = inducing_points
+            elif self.u is not None:
+                self.covfunc = kernel.fitc(self.u)
+            else:
+                raise Exception("To use default inducing points, please call setData() first!")
+        if mean is not None:
+            self.meanfunc = mean
+            self.usingDefaultMean = False
+
+
+class GPR_FITC(GP_FITC):
+    """Sparse GP regression with the FITC approximation (Core/gp.py:1010-1100)."""
+
+    def __init__(self):
+        super(GPR_FITC, self).__init__()
+        self.meanfunc = mean.Zero()
+        self.covfunc = cov.RBF()
+        self.likfunc = lik.Gauss()
+        self.inffunc = inf.FITC_Exact()
+        self.optimizer = opt.Minimize(self)
+        self.u = None
+
+    def setNoise(self, log_sigma):
+        self.likfunc = lik.Gauss(log_sigma)
+
+    def useInference(self, newInf):
+        raise Exception('FITC_Laplace / FITC_EP are out of scope of pygps_amd.')

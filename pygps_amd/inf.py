@@ -298,3 +298,80 @@ class EP(Inference):
             dnlZ.lik = []
             return post, np.float64(nlZ[0]), dnlZ
         return post, np.float64(nlZ[0])
+
+
+class FITCPosterior(object):
+    """Device handle of a FITC posterior (alpha, dense L, inducing coordinates) for predict; freed with the object."""
+
+    def __init__(self, handle, device, slot):
+        self.handle = handle
+        self._dev = device
+        self._slot = slot
+        self._fin = weakref.finalize(self, FITCPosterior._free, handle.value, device, slot)
+
+    @property
+    def ctx(self):
+        return _lib.ctx(self._dev, self._slot)
+
+    @staticmethod
+    def _free(h, device, slot):
+        try:
+            _lib.load().pgp_fitc_free(_lib.ctx(device, slot), C.c_void_p(h))
+        except Exception:
+            pass
+
+    def __deepcopy__(self, memo):
+        return self                                      # the device object is immutable; share it
+
+
+class FITC_Exact(Inference):
+    """FITC approximation to the posterior GP (Core/inf.py:386-455): exact inference with
+    Kt = Q + diag(K - Q), Q = Ku' inv(Kuu + snu2 I) Ku, snu2 = sn2 / 1e6.  One device call (csrc/fitc.hip)."""
+
+    def __init__(self):
+        self.name = 'FICT exact inference'
+        self.device = None
+
+    def evaluate(self, meanfunc, covfunc, likfunc, x, y, nargout=1):
+        if not isinstance(likfunc, _lik.Gauss):
+            raise Exception('Exact inference only possible with Gaussian likelihood')
+        if not isinstance(covfunc, _cov.FITCOfKernel):
+            raise Exception('Only covFITC supported.')
+        dev = _lib.default_device() if self.device is None else self.device
+        kind, para, flags = _device_kernel(covfunc.covfunc, _lib.ctx(dev))
+        x = _lib.f64(x)
+        n, D = x.shape
+        xu = _lib.f64(covfunc.inducingInput)
+        if xu.shape[1] != D:
+            raise Exception('Dimensionality of inducing inputs must match training inputs')
+        nu = xu.shape[0]
+        y = _lib.f64(y).reshape(n)
+        _Resident.ensure(x, y, dev)
+        m, dm, nm = _mean_inputs(meanfunc, x)
+        hyp = _lib.f64(np.asarray(covfunc.hyp, dtype=float))
+        nc = len(hyp)
+        log_sn = float(likfunc.hyp[0])
+        alpha = np.empty(nu)
+        Lm = np.empty((nu, nu))
+        nlZ = np.zeros(1)
+        g = np.zeros(nm + nc + 1)
+        fh = C.c_void_p()
+        rc = _lib.load().pgp_fitc_fit(_lib.ctx(dev), kind, _lib.ptr(hyp), nc, int(para), int(flags), log_sn, _lib.ptr(xu), nu,
+                                      _lib.ptr(m), _lib.ptr(dm), nm, int(min(max(nargout, 1), 3)), _lib.ptr(alpha),
+                                      _lib.ptr(Lm), _lib.ptr(nlZ), _lib.ptr(g), C.byref(fh))
+        _lib.check(rc, "pgp_fitc_fit")
+        post = postStruct()
+        post.alpha = alpha.reshape(nu, 1)
+        post.L = Lm                                       # Sigma - inv(Kuu): dense, not triangular (inf.py:424)
+        post.sW = np.ones((n, 1)) / np.sqrt(np.exp(2 * log_sn))
+        post.fitc = FITCPosterior(fh, dev, _lib.current_slot())
+        if nargout > 1:
+            nlz = np.float64(nlZ[0])
+            if nargout > 2:
+                dnlZ = dnlZStruct(meanfunc, covfunc, likfunc)
+                dnlZ.mean = [np.float64(v) for v in g[:nm]]
+                dnlZ.cov = [np.float64(v) for v in g[nm:nm + nc]]
+                dnlZ.lik = [np.float64(g[nm + nc])]
+                return post, nlz, dnlZ
+            return post, nlz
+        return post

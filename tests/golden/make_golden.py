@@ -416,8 +416,45 @@ def g11():
          pred_xs=xc[:5] + 0.05, pred_ym=ym, pred_fs2=fs2, pred_lp=lp, **dn(dnlZ))
 
 
+def g12():
+    """FITC sparse regression: Core/inf.py:386-455 through GPR_FITC (Core/gp.py:934-1100)."""
+    cov = pyGPs.cov
+    demo = np.load("/root/reference/pyGPs/Demo/Regression/regression_data.npz")
+    x, y, z = demo["x"], demo["y"], demo["xstar"]
+    # (i) the demo: default grid of 5 inducing points, default hypers, one posterior + predict
+    m = pyGPs.GPR_FITC()
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    ym, ys2, fm, fs2, lp = m.predict(z[:7])
+    save("G12_fitc_demo_default_u", x=x, y=y, u=m.u, nlZ=nlZ, alpha=post.alpha, L=post.L, sW=post.sW,
+         mean_hyp=np.array(m.meanfunc.hyp), cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp),
+         pred_xs=z[:7], pred_ym=ym, pred_ys2=ys2, pred_fm=fm, pred_fs2=fs2, **dn(dnlZ))
+    # (ii) synthetic recipe N=1500, d=4, 160 inducing points, three kernels; optimise the RBF one for 10 line searches
+    xs_, ys_ = synth_reg(1500, 4)
+    rng = np.random.RandomState(7)
+    u = xs_[rng.choice(1500, 160, replace=False)] + 0.01 * rng.randn(160, 4)
+    for nm, k in (("rbf", cov.RBF(np.log(2.0), 0.1)), ("matern5", cov.Matern(np.log(2.5), 5, 0.0)),
+                  ("rbfard", cov.RBFard(log_ell_list=[0.5, 0.7, 0.9, 0.6], log_sigma=0.2)),
+                  ("sum", cov.RBF(np.log(2.0), 0.1) + cov.RQ(0.3, -0.5, 0.2) * 0.3)):
+        m = pyGPs.GPR_FITC()
+        m.setData(xs_, ys_)
+        m.setPrior(kernel=k, inducing_points=u)
+        m.setNoise(np.log(0.1))
+        nlZ, dnlZ, post = m.getPosterior()
+        xt = xs_[:6] + 0.05
+        ym, ys2, fm, fs2, lp = m.predict(xt)
+        rec = dict(N=1500, d=4, seed=0, u=u, nlZ=nlZ, alpha=post.alpha, L=post.L, mean_hyp=np.array(m.meanfunc.hyp),
+                   cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp), pred_xs=xt, pred_ym=ym, pred_fs2=fs2,
+                   **dn(dnlZ))
+        if nm == "rbf":
+            m.optimize(xs_, ys_, numIterations=10)
+            ym2 = m.predict(xt)[0]
+            rec.update(opt_nlZ=m.nlZ, opt_hyp=np.array(m.meanfunc.hyp + m.covfunc.hyp + m.likfunc.hyp), opt_ym=ym2)
+        save("G12_fitc_%s_N1500_nu160" % nm, **rec)
+
+
 CASES = {
-    "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
+    "g12": g12, "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
     "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384),
 }

@@ -198,3 +198,26 @@ def test_G11_fits_with_composites():
     out = O.ep_fit(trees["ep_composite"], g["cov_hyp"], 0, g["x"], g["y"], np.zeros_like(g["y"]))
     assert relerr(out["nlZ"], g["nlZ"]) < 1e-9 and relerr(out["alpha"], g["alpha"]) < 1e-7
     assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-7
+
+
+def test_G12_fitc_sparse_regression():
+    """FITC_Exact (Core/inf.py:386-455) + FITCOfKernel (Core/cov.py:332-390) + predict."""
+    g = golden("G12_fitc_demo_default_u")
+    x, y = g["x"], g["y"]
+    c = g["mean_hyp"][0]
+    out = O.fitc_fit(O.RBF, g["cov_hyp"], 0, g["lik_hyp"][0], x, g["u"], y, c * np.ones_like(y), np.ones_like(y))
+    assert relerr(out["nlZ"], g["nlZ"]) < 1e-11 and relerr(out["alpha"], g["alpha"]) < 1e-9 and relerr(out["L"], g["L"]) < 1e-9
+    assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-8 and relerr(out["dnlZ_lik"], g["dnlZ_lik"]) < 1e-8
+    assert relerr(out["dnlZ_mean"], g["dnlZ_mean"]) < 1e-8
+    fm, fs2 = O.fitc_predict(O.RBF, g["cov_hyp"], 0, g["u"], out["alpha"], out["L"], g["pred_xs"], c * np.ones(7))
+    assert relerr(fm, g["pred_fm"]) < 1e-9 and relerr(fs2, g["pred_fs2"]) < 1e-8
+    x, y = synth_reg(1500, 4)
+    sum_tree = \
+        ("sum", ("leaf", O.RBF, 0), ("scale", ("leaf", O.RQ, 0)))
+    for nm, kind, para in (("rbf", O.RBF, 0), ("matern5", O.MATERN, 5), ("rbfard", O.RBFARD, 0), ("sum", sum_tree, 0)):
+        g = golden("G12_fitc_%s_N1500_nu160" % nm)
+        c = g["mean_hyp"][0]
+        out = O.fitc_fit(kind, g["cov_hyp"], para, g["lik_hyp"][0], x, g["u"], y, c * np.ones_like(y), np.ones_like(y))
+        assert relerr(out["nlZ"], g["nlZ"]) < 1e-10, nm
+        assert relerr(out["alpha"], g["alpha"]) < 1e-7 and relerr(out["L"], g["L"]) < 1e-7, nm
+        assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-7 and relerr(out["dnlZ_lik"], g["dnlZ_lik"]) < 1e-7, nm
