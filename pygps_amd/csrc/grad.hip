@@ -110,6 +110,8 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
     double* out = partial + b * (long)(ncov + 1);
     if (cov_is_ard(cp)) {
         // ARD length-scales: G_k = sum_rc w_rc (xs_rk - xs_ck)^2, 16 coordinates per staged slab
+        __shared__ double ardred[4][SKC];
+        const int lane_ = t & 63, wave_ = t >> 6;
         double* xr = sm;
         double* xc = sm + SKC * ST;
         for (int k0 = 0; k0 < dpad; k0 += SKC) {
@@ -141,11 +143,29 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
                     }
                 gk[k] = acc;
             }
+            // 16 sums over the 256 threads: butterfly transpose-reduce inside the wave (17 shuffles instead of
+            // 16 x 6: after the four halving steps lane l holds coordinate bitrev4(l & 15) summed over its 16-lane
+            // row, two more steps fold the four rows), then the four waves meet in LDS (fixed order)
 #pragma unroll
-            for (int k = 0; k < SKC; ++k) {
-                const double tot = block_sum(gk[k], red);
-                if (t == 0 && k0 + k < cp.D) out[k0 + k] = tot;
+            for (int st = 0; st < 4; ++st) {
+                const int m = 1 << st, cnt = SKC >> (st + 1);
+                const bool up = (lane_ & m) != 0;
+#pragma unroll
+                for (int i = 0; i < cnt; ++i) {
+                    const double keep = up ? gk[i + cnt] : gk[i];
+                    const double send = up ? gk[i] : gk[i + cnt];
+                    gk[i] = keep + __shfl_xor(send, m, 64);
+                }
             }
+            gk[0] += __shfl_xor(gk[0], 16, 64);
+            gk[0] += __shfl_xor(gk[0], 32, 64);
+            __syncthreads();                                        // ardred of the previous slab has been consumed
+            if (lane_ < 16) {
+                const int kk = ((lane_ & 1) << 3) | ((lane_ & 2) << 1) | ((lane_ & 4) >> 1) | ((lane_ & 8) >> 3);
+                ardred[wave_][kk] = gk[0];
+            }
+            __syncthreads();
+            if (t < SKC && k0 + t < cp.D) out[k0 + t] = ardred[0][t] + ardred[1][t] + ardred[2][t] + ardred[3][t];
         }
         const double t1 = block_sum(g1, red);
         const double t2 = block_sum(tq, red);
