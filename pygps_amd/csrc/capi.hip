@@ -89,6 +89,7 @@ void pgp_destroy(pgp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
+    for (auto& kv : c->spool) (void)hipFree(kv.second);
     for (auto& kv : c->orders) (void)hipFree(kv.second.first);
     void* bufs[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev, c->W, c->T, c->Binv, c->inv16, c->alpha_dev, c->m_dev,
                     c->rvec, c->zvec, c->partial, c->scal, c->info_dev};
@@ -651,7 +652,7 @@ int ensure_workspace(pgp_ctx* c, long np) {
 int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F) {
     const size_t bytes = (size_t)ldf * np * sizeof(double);
     auto it = c->pool.find(bytes);
-    if (it != c->pool.end()) { *F = (double*)it->second; c->pool.erase(it); return PGP_OK; }
+    if (it != c->pool.end()) { *F = (double*)it->second; c->pool.erase(it); c->pool_bytes -= bytes; return PGP_OK; }
     HIP_TRY(hipMalloc((void**)F, bytes));
     HIP_TRY(hipMemsetAsync(*F, 0, bytes, c->st));     // strict-upper tiles and augmented rows stay 0 forever
     return PGP_OK;

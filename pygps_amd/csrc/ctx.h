@@ -43,7 +43,10 @@ struct pgp_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     // pooled device buffers, keyed by byte size
-    std::multimap<size_t, void*> pool;
+    std::multimap<size_t, void*> pool;  // factor buffers only: strict-upper tiles and spare rhs rows are zero by contract
+    size_t pool_bytes = 0;
+    std::multimap<size_t, void*> spool; // general scratch (arbitrary contents)
+    size_t spool_bytes = 0;
     // data
     long n = 0, d = 0, np = 0, ldf = 0;
     int dpad = 0;
@@ -83,13 +86,23 @@ static inline int pool_alloc(pgp_ctx* c, size_t bytes, void** out) {
     if (it != c->pool.end()) {
         *out = it->second;
         c->pool.erase(it);
+        c->pool_bytes -= bytes;
         return PGP_OK;
     }
-    HIP_TRY(hipMalloc(out, bytes));
+    if (hipMalloc(out, bytes) != hipSuccess) {           // out of memory: drop the idle pool and retry once
+        (void)hipGetLastError();
+        for (auto& kv : c->pool) (void)hipFree(kv.second);
+        c->pool.clear(); c->pool_bytes = 0;
+        HIP_TRY(hipMalloc(out, bytes));
+    }
     return PGP_OK;
 }
+// idle buffers are kept for the next call with the same shape, up to a third of the device memory
 static inline void pool_free(pgp_ctx* c, size_t bytes, void* p) {
-    if (p) c->pool.insert({bytes, p});
+    if (!p) return;
+    if (c->pool_bytes + bytes > (size_t)c->prop.totalGlobalMem / 3) { (void)hipFree(p); return; }
+    c->pool.insert({bytes, p});
+    c->pool_bytes += bytes;
 }
 
 struct ProfScope {
@@ -135,13 +148,27 @@ struct PoolScratch {
     pgp_ctx* c;
     std::vector<std::pair<size_t, void*>> held;
     explicit PoolScratch(pgp_ctx* c_) : c(c_) {}
-    ~PoolScratch() { for (auto& h : held) pool_free(c, h.first, h.second); }
+    ~PoolScratch() {
+        for (auto& h : held) {
+            if (c->spool_bytes + h.first > (size_t)c->prop.totalGlobalMem / 3) { (void)hipFree(h.second); continue; }
+            c->spool.insert({h.first, h.second});
+            c->spool_bytes += h.first;
+        }
+    }
     template <typename T>
     int alloc(T** out, size_t bytes) {
         void* p = nullptr;
         if (!bytes) bytes = 8;
-        const int rc = pool_alloc(c, bytes, &p);
-        if (rc != PGP_OK) return rc;
+        auto it = c->spool.find(bytes);
+        if (it != c->spool.end()) {
+            p = it->second; c->spool.erase(it); c->spool_bytes -= bytes;
+        } else if (hipMalloc(&p, bytes) != hipSuccess) {      // out of memory: drop the idle scratch and retry once
+            (void)hipGetLastError();
+            for (auto& kv : c->spool) (void)hipFree(kv.second);
+            c->spool.clear(); c->spool_bytes = 0;
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) { pgp_set_last_hip_error(e, "hipMalloc(pool scratch)", __FILE__, __LINE__); return PGP_ERR_HIP; }
+        }
         held.push_back({bytes, p});
         *out = (T*)p;
         return PGP_OK;
