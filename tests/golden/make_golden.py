@@ -453,8 +453,34 @@ def g12():
         save("G12_fitc_%s_N1500_nu160" % nm, **rec)
 
 
+def g13():
+    """Mean-function composites (Core/mean.py:140-276): values and derivative columns."""
+    mean = pyGPs.mean
+    rng = np.random.RandomState(2)
+    x = rng.rand(15, 3) + 0.5
+    ms = {"sum": mean.Linear(alpha_list=[0.3, -0.2, 0.7]) + mean.Const(1.5),
+          "prod": mean.Linear(alpha_list=[0.3, 0.2, 0.7]) * mean.Const(1.5),
+          "scale": mean.Linear(alpha_list=[0.3, 0.2, 0.7]) * 2.5,
+          "power": (mean.Linear(alpha_list=[0.3, 0.2, 0.7]) + mean.One()) ** 3,
+          "tree": (mean.Linear(alpha_list=[0.3, 0.2, 0.7]) * 0.5 + mean.Const(0.4)) * mean.One() + mean.Zero()}
+    out = dict(x=x)
+    for nm, m in ms.items():
+        out[nm + "_hyp"] = np.array(m.hyp, dtype=float)
+        out[nm + "_m"] = m.getMean(x)
+        for i in range(len(m.hyp)):
+            out["%s_dm%d" % (nm, i)] = m.getDerMatrix(x, i)
+    # and through a fit: Linear + Const mean, RBF kernel, N=300, d=3
+    xs_, ys_ = synth_reg(300, 3)
+    m = pyGPs.GPR()
+    m.setPrior(mean=mean.Linear(alpha_list=[0.1, -0.3, 0.2]) + mean.Const(0.5), kernel=pyGPs.cov.RBF(0.4, 0.1))
+    m.setNoise(np.log(0.2))
+    nlZ, dnlZ, post = m.getPosterior(xs_, ys_)
+    out.update(fit_nlZ=nlZ, fit_alpha=post.alpha, **{"fit_" + k: v for k, v in dn(dnlZ).items()})
+    save("G13_mean_composites", **out)
+
+
 CASES = {
-    "g12": g12, "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
+    "g13": g13, "g12": g12, "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
     "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384),
 }

@@ -271,3 +271,17 @@ def test_G10_rbfunit_rq_piecepoly_on_device(lib):
         assert relerr(_flat(dnlZ), np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7, nm
         ym, ys2, fm, fs2, lp = m.predict(g["pred_xs"])
         assert relerr(ym, g["pred_ym"]) < 1e-8 and relerr(fs2, g["pred_fs2"]) < 1e-6
+
+
+def test_G13_fit_with_a_composite_mean(lib):
+    """Linear + Const mean through the device fit: m and the dm columns are host O(N) inputs (Core/inf.py:358, 378-381)."""
+    import pygps_amd as pyGPs
+    g = golden("G13_mean_composites")
+    x, y = synth_reg(300, 3)
+    m = pyGPs.GPR()
+    m.setPrior(mean=pyGPs.mean.Linear(alpha_list=[0.1, -0.3, 0.2]) + pyGPs.mean.Const(0.5), kernel=pyGPs.cov.RBF(0.4, 0.1))
+    m.setNoise(np.log(0.2))
+    nlZ, dnlZ, post = m.getPosterior(x, y)
+    assert relerr(nlZ, g["fit_nlZ"]) < 1e-10 and relerr(post.alpha, g["fit_alpha"]) < 1e-8
+    assert len(dnlZ.mean) == 4 and relerr(dnlZ.mean, g["fit_dnlZ_mean"]) < 1e-8
+    assert relerr(dnlZ.cov, g["fit_dnlZ_cov"]) < 1e-8 and relerr(dnlZ.lik, g["fit_dnlZ_lik"]) < 1e-8

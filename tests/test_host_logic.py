@@ -176,3 +176,24 @@ def test_no_gpu_fails_loudly_no_cpu_fallback():
         pyGPs.GPR().getPosterior(np.zeros((3, 1)), np.zeros(3))
     with pytest.raises(RuntimeError):
         pyGPs.cov.RBF().getCovMatrix(x=np.zeros((3, 1)), mode="train")
+
+
+def test_G13_mean_composites_match_the_reference():
+    """Sum / Product / Scale / Power of mean functions (Core/mean.py:140-276), values recorded from the reference."""
+    from conftest import golden
+    from pygps_amd import mean
+    g = golden("G13_mean_composites")
+    x = g["x"]
+    ms = {"sum": mean.Linear(alpha_list=[0.3, -0.2, 0.7]) + mean.Const(1.5),
+          "prod": mean.Linear(alpha_list=[0.3, 0.2, 0.7]) * mean.Const(1.5),
+          "scale": mean.Linear(alpha_list=[0.3, 0.2, 0.7]) * 2.5,
+          "power": (mean.Linear(alpha_list=[0.3, 0.2, 0.7]) + mean.One()) ** 3,
+          "tree": (mean.Linear(alpha_list=[0.3, 0.2, 0.7]) * 0.5 + mean.Const(0.4)) * mean.One() + mean.Zero()}
+    for nm, m in ms.items():
+        assert list(np.asarray(m.hyp, float)) == list(g[nm + "_hyp"]), nm
+        np.testing.assert_allclose(m.getMean(x), g[nm + "_m"], rtol=1e-14)
+        for i in range(len(m.hyp)):
+            np.testing.assert_allclose(m.getDerMatrix(x, i), g["%s_dm%d" % (nm, i)], rtol=1e-13, atol=1e-15)
+        h = [v + 0.01 for v in m.hyp]
+        m.hyp = h
+        assert list(m.hyp) == h                       # setter reaches the children
