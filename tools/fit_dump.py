@@ -5,6 +5,8 @@ sys.path.insert(0, "/root/repo")
 os.environ["PGP_PROF_DUMP"] = "1"
 from pygps_amd import _lib
 lib = _lib.load(); ctx = _lib.ctx()
+for o in sys.argv[1:]:
+    k, v = o.split('='); lib.pgp_set_option(ctx, k.encode(), int(v))
 N, d = 8192, 16
 rng = np.random.RandomState(0)
 x = rng.randn(N, d); w = rng.randn(d, 1)

@@ -28,7 +28,7 @@ def worker(ctx, steps, out, k):
 
 
 opts = [tuple(o.split("=")) for o in sys.argv[1:]]
-for S in (1, 2, 3, 4):
+for S in (1, 2):
     ctxs = []
     for k in range(S):
         h = C.c_void_p()
