@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, golden, relerr, synth_cls, synth_reg
+from oracle import gp_oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -133,3 +134,50 @@ def test_degenerate_inputs_fail_cleanly(lib):
     nlZ, dnlZ, post = m.getPosterior(np.array([[0.3]]), np.array([[1.2]]))
     sn2, sf2 = 0.01, 1.0
     assert abs(nlZ - (0.5 * 1.2 ** 2 / (sf2 + sn2) + 0.5 * np.log(2 * np.pi * (sf2 + sn2)))) < 1e-12
+
+
+def test_fitc_n32768_nu512_against_the_oracle():
+    """FITC at a size the reference algorithm still finishes on the host (numpy): nlZ, gradients, predictions."""
+    import pygps_amd as pyGPs
+    rng = np.random.RandomState(11)
+    n, nu, d = 32768, 512, 8
+    x = rng.randn(n, d); w = rng.randn(d, 1)
+    y = np.sin(x @ w / np.sqrt(d)) + 0.1 * rng.randn(n, 1)
+    u = x[rng.choice(n, nu, replace=False)] + 0.02 * rng.randn(nu, d)
+    hyp = np.array([np.log(2.0), 0.1])
+    m = pyGPs.GPR_FITC()
+    m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(hyp[0], hyp[1]), inducing_points=u)
+    m.setNoise(np.log(0.15))
+    nlZ, dnlZ, post = m.getPosterior(x, y)
+    out = O.fitc_fit(O.RBF, hyp, 0, np.log(0.15), x, u, y, np.zeros_like(y), None)
+    assert relerr(nlZ, out["nlZ"]) < 1e-8
+    assert relerr(dnlZ.cov, out["dnlZ_cov"]) < 1e-5 and relerr(dnlZ.lik, out["dnlZ_lik"]) < 1e-5
+    xs = x[:64] + 0.05
+    fm, fs2 = O.fitc_predict(O.RBF, hyp, 0, u, out["alpha"], out["L"], xs, np.zeros(64))
+    _, _, fm2, fs22, _ = m.predict(xs)
+    assert relerr(fm2, fm) < 1e-6 and relerr(fs22, fs2) < 1e-4
+
+
+def test_composite_program_N4096_against_the_oracle():
+    """MaunaLoa-shaped 11-hyper composite (one device program) at N=4096, d=1: nlZ, all gradients, predictions."""
+    import pygps_amd as pyGPs
+    from pygps_amd import cov
+    rng = np.random.RandomState(4)
+    N = 4096
+    x = np.sort(rng.uniform(0, 40, (N, 1)), axis=0)
+    y = 0.3 * x + np.sin(2 * np.pi * x) * (1 + 0.02 * x) + 0.4 * np.sin(0.5 * x) + 0.1 * rng.randn(N, 1)
+    k = (cov.RBF(np.log(20.), np.log(3.)) + cov.Periodic(np.log(1.3), 0.0, np.log(1.1)) * cov.RBF(np.log(30.), np.log(1.1))
+         + cov.RQ(np.log(1.2), np.log(0.66), np.log(0.78)) + (cov.RBF(np.log(0.13), np.log(0.18)) + cov.Noise(np.log(0.19))))
+    assert k._on_device()
+    L = ("leaf",)
+    tree = ("sum", ("sum", ("sum", L + (O.RBF, 0), ("prod", L + (O.PERIODIC, 0), L + (O.RBF, 0))), L + (O.RQ, 0)),
+            ("sum", L + (O.RBF, 0), L + (O.NOISE, 0)))
+    m = pyGPs.GPR()
+    m.setPrior(mean=pyGPs.mean.Zero(), kernel=k)
+    m.setNoise(np.log(0.1))
+    nlZ, dnlZ, post = m.getPosterior(x, y)
+    hyp = np.array(k.hyp, float)
+    out = O.exact_fit(tree, hyp, 0, np.log(0.1), x, y, np.zeros_like(y), None, faithful=False)
+    assert relerr(nlZ, out["nlZ"]) < 1e-8 and relerr(post.alpha, out["alpha"]) < 1e-6
+    assert np.max(np.abs(np.array(dnlZ.cov) - out["dnlZ_cov"])) < 1e-6 * np.max(np.abs(out["dnlZ_cov"]))
+    assert relerr(dnlZ.lik, out["dnlZ_lik"]) < 1e-6
