@@ -37,6 +37,7 @@ struct pgp_ctx {
     hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
+    int ep_block = 1;                   // EP: blocked site sweep (rank-1 updates folded every 128 sites); 0 = update Sigma per site
     int fused_inverse = 1;              // 1: L^-T falls out of the Cholesky sweep (appended identity rows); 0: recursive trtri
     hipStream_t st_masked = nullptr;    // main stream of the look-ahead Cholesky restricted to a CU subset (option cu_reserve)
     int cu_reserve = 0;                 // reserve every cu_reserve-th CU for the panel stream (0 = off)

@@ -76,6 +76,82 @@ __global__ __launch_bounds__(256) void ep_rank1_mu_kernel(double* __restrict__ S
     if (lane == 0) mu[r] = acc;
 }
 
+// ---- blocked ("lazy") site sweep ------------------------------------------------------------------------------
+// The reference updates the full Sigma and recomputes mu = Sigma tnu after every site (inf.py:769-770): 16 N^2 bytes per
+// site.  A site only ever reads column i of Sigma and mu_i, so the rank-1 updates of the last j < EPB sites are kept
+// as factors instead:   Sigma = Sigma_blk - sum_k c_k s_k s_k',   mu = mu_blk + sum_k q_k s_k
+// (mu' = (Sigma - c s s')(tnu + d e_i) = mu + s (d - c (mu_i + d Sigma_ii)), because s' tnu = (Sigma tnu)_i = mu_i).
+// One launch per site: every workgroup recomputes the (cheap, deterministic) scalar site update itself, so no
+// cross-workgroup synchronisation is needed; rows are spread over the workgroups.  After EPB sites the factors are
+// folded into Sigma_blk with one MFMA GEMM (K = EPB) and into mu_blk with one matvec.  Same site order, same
+// mathematics; only the floating-point summation order of the updates differs from the reference.
+constexpr int EPB = 128;
+
+__global__ __launch_bounds__(256) void ep_site_lazy_kernel(const double* __restrict__ Sig, long ld, long np, long i, int j,
+                                                           double* __restrict__ S, double* __restrict__ cvec,
+                                                           double* __restrict__ qvec, const double* __restrict__ mu_blk,
+                                                           const double* __restrict__ m, const double* __restrict__ y,
+                                                           const double* __restrict__ ttau_prev,
+                                                           const double* __restrict__ tnu_prev,
+                                                           double* __restrict__ ttau_cur, double* __restrict__ tnu_cur) {
+    __shared__ double g[EPB];            // c_k S(i,k)
+    __shared__ double red[2][4];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    if (t < j) {
+        const double sik = S[i + (long)t * ld];
+        g[t] = cvec[t] * sik;
+        a = g[t] * sik;                   // Sigma_ii correction
+        b = qvec[t] * sik;                // mu_i correction
+    }
+    a = wave_sum(a); b = wave_sum(b);
+    if ((t & 63) == 0) { red[0][t >> 6] = a; red[1][t >> 6] = b; }
+    __syncthreads();
+    const double sii = Sig[i + i * ld] - (red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    const double mui = mu_blk[i] + (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    // site update (inf.py:759-769), identical in every workgroup
+    const double tau_ni = 1.0 / sii - ttau_prev[i];
+    const double nu_ni = mui / sii + m[i] * tau_ni - tnu_prev[i];
+    double lZ, dlZ, d2lZ;
+    erf_ep_moments(y[i], nu_ni / tau_ni, 1.0 / tau_ni, &lZ, &dlZ, &d2lZ);
+    double t_new = -d2lZ / (1.0 + d2lZ / tau_ni);
+    t_new = fmax(t_new, 0.0);
+    const double nu_new = (dlZ + (m[i] - nu_ni / tau_ni) * d2lZ) / (1.0 + d2lZ / tau_ni);
+    const double ds2 = t_new - ttau_prev[i];
+    const double cj = ds2 / (1.0 + ds2 * sii);
+    const double dnu = nu_new - tnu_prev[i];
+    if (blockIdx.x == 0 && t == 0) {
+        ttau_cur[i] = t_new; tnu_cur[i] = nu_new;
+        cvec[j] = cj;
+        qvec[j] = dnu - cj * (mui + dnu * sii);
+    }
+    // column i of the current Sigma -> factor column j
+    const long r = (long)blockIdx.x * 256 + t;
+    if (r < np) {
+        double sr = Sig[r + i * ld];
+        for (int k = 0; k < j; ++k) sr = fma(-g[k], S[r + (long)k * ld], sr);
+        S[r + (long)j * ld] = sr;
+    }
+}
+
+// Sc(:,k) = c_k S(:,k)
+__global__ __launch_bounds__(256) void ep_colscale_kernel(const double* __restrict__ S, double* __restrict__ Sc, long ld,
+                                                          long np, const double* __restrict__ cvec) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (r < np) Sc[r + (long)k * ld] = cvec[k] * S[r + (long)k * ld];
+}
+
+// mu_r += sum_k q_k S(r,k)
+__global__ __launch_bounds__(256) void ep_mu_fold_kernel(const double* __restrict__ S, long ld, long np,
+                                                         const double* __restrict__ qvec, double* __restrict__ mu) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= np) return;
+    double acc = mu[r];
+    for (int k = 0; k < EPB; ++k) acc = fma(qvec[k], S[r + (long)k * ld], acc);
+    mu[r] = acc;
+}
+
 // F (column-major lower, ldf) = I + s s' o K ; Y (column-major, ld np) = diag(s) K     (K symmetric, ld np)
 __global__ __launch_bounds__(256) void ep_build_kernel(const double* __restrict__ K, long np,
                                                        const double* __restrict__ s, double* __restrict__ F, long ldf,
@@ -93,6 +169,7 @@ struct EpWork {
     long n, np, ldf;
     double *Kd, *Sig, *Vd, *F, *Wd, *rhs;
     double *ttau_d, *tnu_d, *mu_d, *m_d, *s_d, *sbuf, *coef, *diag_d, *tmp_d;
+    double *S, *Sc, *cq, *prev;          // blocked sweep: factor columns, scaled copy, (c, q) vectors, (ttau, tnu) snapshot
 };
 
 }  // namespace
@@ -198,6 +275,10 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     w.ttau_d = vecs; w.tnu_d = vecs + np; w.mu_d = vecs + 2 * np; w.m_d = vecs + 3 * np; w.s_d = vecs + 4 * np;
     w.sbuf = vecs + 5 * np; w.coef = vecs + 6 * np; w.diag_d = vecs + 7 * np; w.tmp_d = vecs + 8 * np;
     HIP_TRY(hipMemsetAsync(vecs, 0, (size_t)10 * np * sizeof(double), st));
+    EP_TRY(dalloc(&w.S, (size_t)EPB * np * sizeof(double)));
+    EP_TRY(dalloc(&w.Sc, (size_t)EPB * np * sizeof(double)));
+    EP_TRY(dalloc(&w.cq, (size_t)2 * EPB * sizeof(double)));
+    EP_TRY(dalloc(&w.prev, (size_t)2 * np * sizeof(double)));
     HIP_TRY(hipMemsetAsync(w.Kd, 0, nn, st));
     EP_TRY(alloc_factor_buffer(c, np, ldf, &w.F));
     // ---- K (full symmetric, padded with zeros) --------------------------------------------------------
@@ -242,6 +323,35 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     while ((fabs(nlZ - nlZ_old) > tol && sweep < max_sweep) || sweep < min_sweep) {
         nlZ_old = nlZ;
         ++sweep;
+        if (c->ep_block) {
+            // blocked sweep: site i reads the (ttau, tnu) it had at the start of the sweep (each site is visited once)
+            HIP_TRY(hipMemcpyAsync(w.prev, w.ttau_d, np * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(w.prev + np, w.tnu_d, np * sizeof(double), hipMemcpyDeviceToDevice, st));
+            auto fold = [&]() -> int {
+                hipLaunchKernelGGL(ep_colscale_kernel, dim3((unsigned)((np + 255) / 256), EPB), dim3(256), 0, st, w.S, w.Sc,
+                                   np, np, w.cq);
+                GemmArgs g{};                                                          // Sigma -= S diag(c) S'
+                g.A = w.Sc; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
+                g.C = w.Sig; g.ldc = np; g.M = (int)np; g.N = (int)np; g.K = EPB;
+                g.alpha = -1.0; g.beta = 1.0; g.tile = (np / 128) * (np / 128) < c->small_tile_below ? 64 : 128;
+                g.flops = 2.0 * (double)np * np * EPB;
+                CHK(gemm_prof(c, PC_GEMM_INNER, g));
+                hipLaunchKernelGGL(ep_mu_fold_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.S, np, np,
+                                   w.cq + EPB, w.mu_d);
+                HIP_TRY(hipMemsetAsync(w.S, 0, (size_t)EPB * np * sizeof(double), st));
+                HIP_TRY(hipMemsetAsync(w.cq, 0, (size_t)2 * EPB * sizeof(double), st));
+                return PGP_OK;
+            };
+            HIP_TRY(hipMemsetAsync(w.S, 0, (size_t)EPB * np * sizeof(double), st));
+            HIP_TRY(hipMemsetAsync(w.cq, 0, (size_t)2 * EPB * sizeof(double), st));
+            int j = 0;
+            for (long i = 0; i < n; ++i) {
+                hipLaunchKernelGGL(ep_site_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np, i,
+                                   j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d, w.tnu_d);
+                if (++j == EPB) { EP_TRY(fold()); j = 0; }
+            }
+            // Sigma / mu are rebuilt from (ttau, tnu) by ep_compute_params below: the last partial block need not be folded
+        } else
         for (long i = 0; i < n; ++i) {
             hipLaunchKernelGGL(ep_site_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np, i,
                                w.mu_d, w.m_d, c->y_dev, w.ttau_d, w.tnu_d, w.sbuf, w.coef);
