@@ -121,6 +121,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
     if (!strcmp(name, "ep_block")) { c->ep_block = value; return PGP_OK; }
+    if (!strcmp(name, "ep_graph")) { c->ep_graph = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { cov_tile_set_grid(value); return PGP_OK; }
     if (!strcmp(name, "cu_reserve")) {
         if (c->st_masked) { (void)hipStreamSynchronize(c->st_masked); (void)hipStreamDestroy(c->st_masked); c->st_masked = nullptr; }

@@ -13,6 +13,7 @@
 // Gradients reuse the triangular inverse, W'W and the Hadamard-reduce kernel with per-point weights sW.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -87,7 +88,12 @@ __global__ __launch_bounds__(256) void ep_rank1_mu_kernel(double* __restrict__ S
 // mathematics; only the floating-point summation order of the updates differs from the reference.
 constexpr int EPB = 128;
 
-__global__ __launch_bounds__(256) void ep_site_lazy_kernel(const double* __restrict__ Sig, long ld, long np, long i, int j,
+__global__ void ep_set_base_kernel(long* base, long v) { base[0] = v; }
+
+// site index i = base[0] + j: the 128 launches of one block are captured once into a hipGraph and replayed for every
+// block (only base[0] changes), instead of 128 separate kernel launches of ~5 us each
+__global__ __launch_bounds__(256) void ep_site_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
+                                                           const long* __restrict__ base, int j,
                                                            double* __restrict__ S, double* __restrict__ cvec,
                                                            double* __restrict__ qvec, const double* __restrict__ mu_blk,
                                                            const double* __restrict__ m, const double* __restrict__ y,
@@ -96,6 +102,7 @@ __global__ __launch_bounds__(256) void ep_site_lazy_kernel(const double* __restr
                                                            double* __restrict__ ttau_cur, double* __restrict__ tnu_cur) {
     __shared__ double g[EPB];            // c_k S(i,k)
     __shared__ double red[2][4];
+    const long i = base[0] + j;
     const int t = threadIdx.x;
     double a = 0.0, b = 0.0;
     if (t < j) {
@@ -170,6 +177,7 @@ struct EpWork {
     double *Kd, *Sig, *Vd, *F, *Wd, *rhs;
     double *ttau_d, *tnu_d, *mu_d, *m_d, *s_d, *sbuf, *coef, *diag_d, *tmp_d;
     double *S, *Sc, *cq, *prev;          // blocked sweep: factor columns, scaled copy, (c, q) vectors, (ttau, tnu) snapshot
+    long* base;                          // first site of the current block (device scalar read by the captured launches)
 };
 
 }  // namespace
@@ -279,6 +287,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     EP_TRY(dalloc(&w.Sc, (size_t)EPB * np * sizeof(double)));
     EP_TRY(dalloc(&w.cq, (size_t)2 * EPB * sizeof(double)));
     EP_TRY(dalloc(&w.prev, (size_t)2 * np * sizeof(double)));
+    { double* b8 = nullptr; EP_TRY(dalloc(&b8, 64)); w.base = (long*)b8; }
     HIP_TRY(hipMemsetAsync(w.Kd, 0, nn, st));
     EP_TRY(alloc_factor_buffer(c, np, ldf, &w.F));
     // ---- K (full symmetric, padded with zeros) --------------------------------------------------------
@@ -316,6 +325,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemsetAsync(w.ttau_d, 0, np * sizeof(double), st));
         HIP_TRY(hipMemsetAsync(w.tnu_d, 0, np * sizeof(double), st));
     }
+    hipGraphExec_t block_graph = nullptr;             // one block of the blocked sweep (128 site launches + fold)
     const double tol = 1e-4;
     const int max_sweep = 10, min_sweep = 2;
     double nlZ_old = INFINITY;
@@ -344,11 +354,36 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
             };
             HIP_TRY(hipMemsetAsync(w.S, 0, (size_t)EPB * np * sizeof(double), st));
             HIP_TRY(hipMemsetAsync(w.cq, 0, (size_t)2 * EPB * sizeof(double), st));
-            int j = 0;
-            for (long i = 0; i < n; ++i) {
-                hipLaunchKernelGGL(ep_site_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np, i,
-                                   j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d, w.tnu_d);
-                if (++j == EPB) { EP_TRY(fold()); j = 0; }
+            auto block_launches = [&](int nsite, bool do_fold) -> int {
+                for (int j = 0; j < nsite; ++j)
+                    hipLaunchKernelGGL(ep_site_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np,
+                                       w.base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
+                                       w.tnu_d);
+                if (do_fold) CHK(fold());
+                return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+            };
+            const long nfull = n / EPB;
+            if (nfull > 0 && !c->prof && c->ep_graph && !block_graph) {               // capture one full block once per fit
+                HIP_TRY(hipStreamSynchronize(st));
+                if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const int rc_cap = block_launches(EPB, true);
+                    hipGraph_t gr = nullptr;
+                    const hipError_t e_end = hipStreamEndCapture(st, &gr);
+                    if (rc_cap == PGP_OK && e_end == hipSuccess && gr &&
+                        hipGraphInstantiate(&block_graph, gr, nullptr, nullptr, 0) != hipSuccess) block_graph = nullptr;
+                    if (gr) (void)hipGraphDestroy(gr);
+                    (void)hipGetLastError();
+                }
+                if (c->ep_graph == 2) fprintf(stderr, "ep block graph %s\n", block_graph ? "captured" : "NOT captured (falling back to launches)");
+            }
+            for (long b = 0; b < nfull; ++b) {
+                hipLaunchKernelGGL(ep_set_base_kernel, dim3(1), dim3(1), 0, st, w.base, b * EPB);
+                if (block_graph) HIP_TRY(hipGraphLaunch(block_graph, st));
+                else EP_TRY(block_launches(EPB, true));
+            }
+            if (n % EPB) {
+                hipLaunchKernelGGL(ep_set_base_kernel, dim3(1), dim3(1), 0, st, w.base, nfull * EPB);
+                EP_TRY(block_launches((int)(n % EPB), false));
             }
             // Sigma / mu are rebuilt from (ttau, tnu) by ep_compute_params below: the last partial block need not be folded
         } else
@@ -364,6 +399,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // inf.py:772
         if (rc != PGP_OK) { pool_free(c, (size_t)ldf * np * sizeof(double), w.F); cleanup(); return rc; }
     }
+    if (block_graph) { (void)hipStreamSynchronize(st); (void)hipGraphExecDestroy(block_graph); block_graph = nullptr; }
     if (sweeps_out) *sweeps_out = sweep;
     memcpy(ttau_io, ttau.data(), n * sizeof(double));
     memcpy(tnu_io, tnu.data(), n * sizeof(double));

@@ -169,13 +169,14 @@ if __name__ == "__main__":
             d = 32
             x = rng.randn(N, d); w = rng.randn(d, 1)
             y = np.sign(x @ w / np.sqrt(d) + 0.3 * rng.randn(N, 1)); y[y == 0] = 1
-            for blk in (0, 1, 1):
+            for blk, gr in ((0, 0), (1, 0), (1, 1)):
                 lib.pgp_set_option(ctx, b"ep_block", blk)
+                lib.pgp_set_option(ctx, b"ep_graph", gr)
                 m = pyGPs.GPC()
                 m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
                 t = time.time()
                 nlZ, dnlZ, post = m.getPosterior(x, y)
-                print("EP N=%d d=%d ep_block=%d: %.3f s, %d sweeps, nlZ=%.12g dnlZ.cov=%s alpha[:2]=%s" % (
-                    N, d, blk, time.time() - t, m.inffunc.sweeps, nlZ, dnlZ.cov, post.alpha[:2, 0]))
+                print("EP N=%d d=%d ep_block=%d graph=%d: %.3f s, %d sweeps, nlZ=%.12g dnlZ.cov=%s alpha[:2]=%s" % (
+                    N, d, blk, gr, time.time() - t, m.inffunc.sweeps, nlZ, dnlZ.cov, post.alpha[:2, 0]))
     if "fit16k" in what:
         fit(16384, 64, kind=1, reps=1)
