@@ -37,7 +37,7 @@ struct pgp_ctx {
     hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
-    int ep_graph = 1;                   // EP: replay each 128-site block as a captured hipGraph
+    int ep_graph = 0;                   // EP: replay each 128-site block as a captured hipGraph (measured: no gain)
     int ep_block = 1;                   // EP: blocked site sweep (rank-1 updates folded every 128 sites); 0 = update Sigma per site
     int fused_inverse = 1;              // 1: L^-T falls out of the Cholesky sweep (appended identity rows); 0: recursive trtri
     hipStream_t st_masked = nullptr;    // main stream of the look-ahead Cholesky restricted to a CU subset (option cu_reserve)

@@ -141,6 +141,90 @@ __global__ __launch_bounds__(256) void ep_site_lazy_kernel(const double* __restr
     }
 }
 
+// EPT consecutive sites per launch.  The sites are sequentially dependent, but site t+1 only needs ROW i_(t+1) of the
+// factor columns, including the columns created by the sites before it in this launch -- single elements that any
+// workgroup can recompute in O(j) -- so every workgroup replays the EPT scalar site updates itself (wave 0, ~50
+// 64-lane reductions) and then computes its rows of all EPT new factor columns in one pass over S(r, 0..j0): the
+// chain of dependent kernel launches (~6 us each) gets EPT times shorter and S is read once instead of EPT times.
+constexpr int EPT = 8;
+
+__global__ __launch_bounds__(256) void ep_sites_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
+                                                            const long* __restrict__ base, int j0, double* __restrict__ S,
+                                                            double* __restrict__ cvec, double* __restrict__ qvec,
+                                                            const double* __restrict__ mu_blk, const double* __restrict__ m,
+                                                            const double* __restrict__ y,
+                                                            const double* __restrict__ ttau_prev,
+                                                            const double* __restrict__ tnu_prev,
+                                                            double* __restrict__ ttau_cur, double* __restrict__ tnu_cur) {
+    __shared__ double Srow[EPT][EPB + EPT];      // row i_t of the factor columns 0 .. j0+EPT-1
+    __shared__ double gv[EPT][EPB + EPT];        // g_t[k] = c_k Srow[t][k], k < j0 + t
+    __shared__ double cl[EPB + EPT], ql[EPB + EPT];
+    __shared__ double Sg[EPT][EPT];              // Sigma_blk(i_t, i_u)
+    const int t = threadIdx.x, lane = t & 63;
+    const long i0 = base[0] + j0;
+    for (int v = t; v < EPT * j0; v += 256) { const int tt = v / j0, k = v % j0; Srow[tt][k] = S[i0 + tt + (long)k * ld]; }
+    for (int k = t; k < j0; k += 256) { cl[k] = cvec[k]; ql[k] = qvec[k]; }
+    if (t < EPT * EPT) Sg[t / EPT][t % EPT] = Sig[i0 + t / EPT + (i0 + t % EPT) * ld];
+    __syncthreads();
+    if (t < 64) {                                // wave 0: the EPT scalar site updates, in order
+        for (int tt = 0; tt < EPT; ++tt) {
+            const long i = i0 + tt;
+            const int jt = j0 + tt;              // factor columns known so far for this site: k < jt
+            for (int u = 0; u < tt; ++u) {       // entries of the columns created in this launch, at row i
+                double a = 0.0;
+                for (int k = lane; k < j0 + u; k += 64) a = fma(gv[u][k], Srow[tt][k], a);
+                a = wave_sum(a);
+                a = __shfl(a, 0, 64);
+                if (lane == 0) Srow[tt][j0 + u] = Sg[tt][u] - a;
+                __builtin_amdgcn_wave_barrier();
+            }
+            double a = 0.0, b = 0.0;
+            for (int k = lane; k < jt; k += 64) { const double sk = Srow[tt][k]; a = fma(cl[k] * sk, sk, a); b = fma(ql[k], sk, b); }
+            a = wave_sum(a); b = wave_sum(b);
+            a = __shfl(a, 0, 64); b = __shfl(b, 0, 64);
+            const double sii = Sg[tt][tt] - a;
+            const double mui = mu_blk[i] + b;
+            const double tau_ni = 1.0 / sii - ttau_prev[i];                    // inf.py:759-769
+            const double nu_ni = mui / sii + m[i] * tau_ni - tnu_prev[i];
+            double lZ, dlZ, d2lZ;
+            erf_ep_moments(y[i], nu_ni / tau_ni, 1.0 / tau_ni, &lZ, &dlZ, &d2lZ);
+            double t_new = -d2lZ / (1.0 + d2lZ / tau_ni);
+            t_new = fmax(t_new, 0.0);
+            const double nu_new = (dlZ + (m[i] - nu_ni / tau_ni) * d2lZ) / (1.0 + d2lZ / tau_ni);
+            const double ds2 = t_new - ttau_prev[i];
+            const double cj = ds2 / (1.0 + ds2 * sii);
+            const double dnu = nu_new - tnu_prev[i];
+            const double qj = dnu - cj * (mui + dnu * sii);
+            if (lane == 0) {
+                cl[jt] = cj; ql[jt] = qj;
+                if (blockIdx.x == 0) { ttau_cur[i] = t_new; tnu_cur[i] = nu_new; cvec[jt] = cj; qvec[jt] = qj; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < jt; k += 64) gv[tt][k] = cl[k] * Srow[tt][k];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    // rows of the EPT new factor columns: one pass over S(r, 0..j0)
+    const long r = (long)blockIdx.x * 256 + t;
+    if (r < np) {
+        double acc[EPT];
+#pragma unroll
+        for (int tt = 0; tt < EPT; ++tt) acc[tt] = Sig[r + (i0 + tt) * ld];
+        for (int k = 0; k < j0; ++k) {
+            const double srk = S[r + (long)k * ld];
+#pragma unroll
+            for (int tt = 0; tt < EPT; ++tt) acc[tt] = fma(-gv[tt][k], srk, acc[tt]);
+        }
+#pragma unroll
+        for (int tt = 0; tt < EPT; ++tt) {           // column j0+tt also depends on the columns j0 .. j0+tt-1 of this launch
+#pragma unroll
+            for (int u = 0; u < tt; ++u) acc[tt] = fma(-gv[tt][j0 + u], acc[u], acc[tt]);
+            S[r + (long)(j0 + tt) * ld] = acc[tt];
+        }
+    }
+}
+
 // Sc(:,k) = c_k S(:,k)
 __global__ __launch_bounds__(256) void ep_colscale_kernel(const double* __restrict__ S, double* __restrict__ Sc, long ld,
                                                           long np, const double* __restrict__ cvec) {
@@ -355,7 +439,12 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
             HIP_TRY(hipMemsetAsync(w.S, 0, (size_t)EPB * np * sizeof(double), st));
             HIP_TRY(hipMemsetAsync(w.cq, 0, (size_t)2 * EPB * sizeof(double), st));
             auto block_launches = [&](int nsite, bool do_fold) -> int {
-                for (int j = 0; j < nsite; ++j)
+                int j = 0;
+                for (; j + EPT <= nsite; j += EPT)
+                    hipLaunchKernelGGL(ep_sites_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np,
+                                       w.base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
+                                       w.tnu_d);
+                for (; j < nsite; ++j)
                     hipLaunchKernelGGL(ep_site_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np,
                                        w.base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
                                        w.tnu_d);
