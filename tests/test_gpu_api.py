@@ -4,7 +4,8 @@ recorded from the reference, written the way the reference's own tests read
 import numpy as np
 import pytest
 
-from conftest import golden, relerr, synth_reg
+from conftest import golden, relerr, synth_cls, synth_reg
+from oracle import gp_oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -285,3 +286,17 @@ def test_G13_fit_with_a_composite_mean(lib):
     assert relerr(nlZ, g["fit_nlZ"]) < 1e-10 and relerr(post.alpha, g["fit_alpha"]) < 1e-8
     assert len(dnlZ.mean) == 4 and relerr(dnlZ.mean, g["fit_dnlZ_mean"]) < 1e-8
     assert relerr(dnlZ.cov, g["fit_dnlZ_cov"]) < 1e-8 and relerr(dnlZ.lik, g["fit_dnlZ_lik"]) < 1e-8
+
+
+def test_ep_ragged_sizes_against_the_oracle(lib):
+    """EP with n not a multiple of the 8-site launch / 128-site block of the blocked sweep (tails of both kinds)."""
+    import pygps_amd as pyGPs
+    for n in (203, 131, 7):
+        x, y = synth_cls(n, 3, seed=n)
+        hyp = np.array([np.log(1.5), 0.2])
+        m = pyGPs.GPC()
+        m.setPrior(kernel=pyGPs.cov.RBF(hyp[0], hyp[1]))
+        nlZ, dnlZ, post = m.getPosterior(x, y)
+        out = O.ep_fit(O.RBF, hyp, 0, x, y, np.zeros_like(y))
+        assert relerr(nlZ, out["nlZ"]) < 1e-9, n
+        assert relerr(post.alpha, out["alpha"]) < 1e-7 and relerr(dnlZ.cov, out["dnlZ_cov"]) < 1e-7, n
