@@ -74,7 +74,7 @@ int pgp_cov(pgp_ctx* ctx, int kind, int mode, int der, const double* x, int64_t 
 
 /* Composite kernels: ProductOfKernel / SumOfKernel / ScaleOfKernel (Core/cov.py:230-328).  prog is the tree in
  * postfix order (PGP_PROG_* tokens); it stays registered in the context until replaced.  Limits: 8 leaves, 8 Scale
- * nodes, 8 products after distributing products over sums; ARD leaves are not allowed (-13).     */
+ * nodes, 8 products after distributing products over sums; at most one ARD leaf (RBFard / RQard, D <= 64); else -13. */
 int pgp_set_composite(pgp_ctx* ctx, const int32_t* prog, int nprog);
 
 /* ---- data residency -------------------------------------------------------------------------

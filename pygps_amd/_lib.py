@@ -18,6 +18,7 @@ COV_RBF, COV_RBFARD, COV_MATERN, COV_RBFUNIT, COV_RQ, COV_PIECEPOLY = 0, 1, 2, 3
 COV_RQARD, COV_GABOR, COV_PERIODIC, COV_NOISE, COV_CONST = 6, 7, 8, 9, 10
 COV_COMPOSITE = 100
 PROG_LEAF, PROG_SUM, PROG_PRODUCT, PROG_SCALE = 1, 2, 3, 4
+PROG_MAX_ARD_DIM = 64             # input dimensions of the (single) ARD leaf of a device program
 PROG_MAX = 8                      # leaves / Scale nodes / products per device program (csrc/sqdist_tile.h)
 MODE_TRAIN, MODE_CROSS, MODE_SELF_TEST = 0, 1, 2
 FLAG_MATERN_REFERENCE_DER = 1

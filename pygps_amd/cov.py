@@ -75,10 +75,13 @@ class Kernel(object):
     def _program(self, h0):
         """Postfix device program of this (sub)tree whose first hyper has flat index ``h0``:
         ``(tokens, n_leaves, n_products, n_scales)`` -- or None when a leaf cannot be part of a program."""
-        if self._kind is None or self._kind in (_lib.COV_RBFARD, _lib.COV_RQARD):
+        if self._kind is None:
             return None
         kind, para, flags = self._device_params()
-        return [_lib.PROG_LEAF, int(kind), int(para), int(flags), int(h0)], 1, 1, 0
+        ard = 1 if self._kind in (_lib.COV_RBFARD, _lib.COV_RQARD) else 0
+        if ard and len(self.hyp) - (1 if self._kind == _lib.COV_RBFARD else 2) > _lib.PROG_MAX_ARD_DIM:
+            return None
+        return [_lib.PROG_LEAF, int(kind), int(para), int(flags), int(h0)], 1, 1, ard * 1000
 
     def _bind(self, ctx):
         """Select this kernel on context ``ctx``: returns (kind, para, flags) for the C entry points."""
@@ -312,15 +315,16 @@ class Const(_DeviceKernel):
 # ---- composites (Core/cov.py:230-328) ---------------------------------------------------------------------
 # A tree whose leaves all have isotropic device functors is evaluated in ONE pass of the tile kernel as a device
 # program (sum of products of leaf functors, csrc/sqdist_tile.h CovProgram) -- in getCovMatrix/getDerMatrix and,
-# more importantly, inside Exact/EP fits and predict.  Trees with ARD leaves (or more than 8 leaves / products)
+# more importantly, inside Exact/EP fits and predict.  One leaf may be an ARD kernel (RBFard / RQard, D <= 64): it gets its
+# own weighted distance, accumulated beside the shared one.  Trees with two ARD leaves (or more than 8 leaves / products)
 # still offer getCovMatrix/getDerMatrix by combining the children's device-built matrices.
 class _Composite(Kernel):
     _kind = _lib.COV_COMPOSITE
 
     def _tokens(self):
         pr = self._program(0)
-        if pr is None or max(pr[1:]) > _lib.PROG_MAX:
-            return None
+        if pr is None or pr[1] > _lib.PROG_MAX or pr[2] > _lib.PROG_MAX or pr[3] % 1000 > _lib.PROG_MAX or pr[3] >= 2000:
+            return None                                   # too many leaves / products / Scale nodes, or more than one ARD leaf
         return pr[0]
 
     def _bind(self, ctx):
@@ -375,7 +379,7 @@ class _Pair(_Composite):
         if a is None or b is None:
             return None
         nprod = a[2] + b[2] if self._op == _lib.PROG_SUM else a[2] * b[2]
-        return a[0] + b[0] + [self._op], a[1] + b[1], nprod, a[3] + b[3]
+        return a[0] + b[0] + [self._op], a[1] + b[1], nprod, a[3] + b[3]     # [3]: Scale nodes + 1000 per ARD leaf
 
 
 class SumOfKernel(_Pair):

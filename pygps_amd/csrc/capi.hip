@@ -236,7 +236,7 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
         double iso;
         CHK(make_leaf(kind, hyp, nhyp, para, flags, d, P.leaf[0], iso));
         if (der >= nhyp) return -4;
-        P.nleaf = 1; P.nterm = 1; P.nscale = 0; P.is2[0] = iso * iso; P.hyp0[0] = 0; P.nh[0] = nhyp;
+        P.nleaf = 1; P.nterm = 1; P.nscale = 0; P.is2[0] = iso * iso; P.hyp0[0] = 0; P.nh[0] = nhyp; P.ard_leaf = -1;
         P.coef[0] = 1.0; P.tl[0] = 1u; P.ts[0] = 0u;
         P.der = der; P.der_leaf = der >= 0 ? 0 : -1; P.der_j = der; P.der_scale = -1;
         cs.prog = true; cs.scale.assign(d, 1.0); cs.ncov = nhyp; cs.nder = nhyp;
@@ -263,6 +263,7 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
     CovProgram& P = cs.pg;
     P = CovProgram{};
     P.der = der; P.der_leaf = P.der_j = P.der_scale = -1;
+    P.ard_leaf = -1;
     int used = 0;
     for (size_t i = 0; i < tok.size();) {
         const int op = tok[i];
@@ -270,7 +271,8 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
             if (i + 5 > tok.size()) return -2;
             const int lk = tok[i + 1], lpara = tok[i + 2], lflags = tok[i + 3], h0 = tok[i + 4];
             i += 5;
-            if (lk == PGP_COV_RBFARD || lk == PGP_COV_RQARD) return -13;          // ARD leaves need their own distance
+            const bool ard = lk == PGP_COV_RBFARD || lk == PGP_COV_RQARD;
+            if (ard && (P.ard_leaf >= 0 || d > CP_MAXARD)) return -13;            // one ARD leaf (own weighted distance), D <= 64
             const int nh = leaf_nhyp(lk, d);
             if (nh < 0) return -2;
             if (h0 < 0 || h0 + nh > nhyp) return -11;
@@ -278,6 +280,11 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
             double iso;
             CHK(make_leaf(lk, hyp + h0, nh, lpara, lflags, d, P.leaf[P.nleaf], iso));
             P.is2[P.nleaf] = iso * iso; P.hyp0[P.nleaf] = h0; P.nh[P.nleaf] = nh;
+            if (ard) {
+                P.ard_leaf = P.nleaf;
+                for (long k = 0; k < d; ++k) P.ardw[k] = exp(-2.0 * hyp[h0 + k]);  // 1 / ell_k^2 (cov.py:893, 1378)
+                if (lk == PGP_COV_RQARD && P.leaf[P.nleaf].ref_der && der >= h0 && der < h0 + d) cs.ell4 = exp(4.0 * hyp[der]);
+            }
             if (der >= h0 && der < h0 + nh) { P.der_leaf = P.nleaf; P.der_j = der - h0; }
             stack.push_back({Term{1u << P.nleaf, 0u}});
             ++P.nleaf; used += nh;

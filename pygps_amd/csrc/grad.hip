@@ -30,6 +30,71 @@ __device__ __forceinline__ double block_sum(double v, double* red /* 4 doubles *
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// ARD length-scale sums of one 64x64 tile: out[k] = sum_rc w_rc wk[k] (x_rk - x_ck)^2 for k < D, 16 coordinates per
+// staged slab (wk == nullptr: the weights are already folded into the scaled coordinates).  sm: 2*SKC*ST doubles.
+__device__ __forceinline__ void ard_dim_reduce(const double* __restrict__ XT, long ldp, long r0, long c0, int dpad,
+                                               double* __restrict__ sm, const double (&w)[4][4],
+                                               const double* __restrict__ wk, int D, double* __restrict__ out) {
+    __shared__ double ardred[4][SKC];
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    const int lane_ = t & 63, wave_ = t >> 6;
+    double* xr = sm;
+    double* xc = sm + SKC * ST;
+    for (int k0 = 0; k0 < dpad; k0 += SKC) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int v = t + p * 256;
+            const int k = v >> 5, pr = v & 31;
+            *(double2_t*)(xr + k * ST + 2 * pr) = *(const double2_t*)(XT + (long)(k0 + k) * ldp + r0 + 2 * pr);
+            *(double2_t*)(xc + k * ST + 2 * pr) = *(const double2_t*)(XT + (long)(k0 + k) * ldp + c0 + 2 * pr);
+        }
+        __syncthreads();
+        double gk[SKC];
+#pragma unroll
+        for (int k = 0; k < SKC; ++k) {
+            const double2_t r01 = *(const double2_t*)(xr + k * ST + 4 * tr);
+            const double2_t r23 = *(const double2_t*)(xr + k * ST + 4 * tr + 2);
+            const double2_t c01 = *(const double2_t*)(xc + k * ST + 2 * tc);
+            const double2_t c23 = *(const double2_t*)(xc + k * ST + 2 * tc + 32);
+            const double rv[4] = {r01[0], r01[1], r23[0], r23[1]};
+            const double cv[4] = {c01[0], c01[1], c23[0], c23[1]};
+            double acc = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq) {
+                    const double df = rv[a] - cv[bq];
+                    acc = fma(w[a][bq], df * df, acc);
+                }
+            gk[k] = wk ? acc * ((k0 + k) < CP_MAXARD ? wk[k0 + k] : 0.0) : acc;
+        }
+        // 16 sums over the 256 threads: butterfly transpose-reduce inside the wave (17 shuffles instead of
+        // 16 x 6: after the four halving steps lane l holds coordinate bitrev4(l & 15) summed over its 16-lane
+        // row, two more steps fold the four rows), then the four waves meet in LDS (fixed order)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int m = 1 << st, cnt = SKC >> (st + 1);
+            const bool up = (lane_ & m) != 0;
+#pragma unroll
+            for (int i = 0; i < cnt; ++i) {
+                const double keep = up ? gk[i + cnt] : gk[i];
+                const double send = up ? gk[i] : gk[i + cnt];
+                gk[i] = keep + __shfl_xor(send, m, 64);
+            }
+        }
+        gk[0] += __shfl_xor(gk[0], 16, 64);
+        gk[0] += __shfl_xor(gk[0], 32, 64);
+        __syncthreads();                                        // ardred of the previous slab has been consumed
+        if (lane_ < 16) {
+            const int kk = ((lane_ & 1) << 3) | ((lane_ & 2) << 1) | ((lane_ & 4) >> 1) | ((lane_ & 8) >> 3);
+            ardred[wave_][kk] = gk[0];
+        }
+        __syncthreads();
+        if (t < SKC && k0 + t < D) out[k0 + t] = ardred[0][t] + ardred[1][t] + ardred[2][t] + ardred[3][t];
+    }
+}
+
 // partial[blk * nacc + h]: h < ncov -> sum Q dK_h ; h == ncov -> sn2 * trace(Q)
 // KIND: the kernel family, a compile-time parameter (one functor's code and constants per instantiation)
 template <int KIND>
@@ -109,64 +174,7 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
     }
     double* out = partial + b * (long)(ncov + 1);
     if (cov_is_ard(cp)) {
-        // ARD length-scales: G_k = sum_rc w_rc (xs_rk - xs_ck)^2, 16 coordinates per staged slab
-        __shared__ double ardred[4][SKC];
-        const int lane_ = t & 63, wave_ = t >> 6;
-        double* xr = sm;
-        double* xc = sm + SKC * ST;
-        for (int k0 = 0; k0 < dpad; k0 += SKC) {
-            __syncthreads();
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int v = t + p * 256;
-                const int k = v >> 5, pr = v & 31;
-                *(double2_t*)(xr + k * ST + 2 * pr) = *(const double2_t*)(XT + (long)(k0 + k) * ldp + r0 + 2 * pr);
-                *(double2_t*)(xc + k * ST + 2 * pr) = *(const double2_t*)(XT + (long)(k0 + k) * ldp + c0 + 2 * pr);
-            }
-            __syncthreads();
-            double gk[SKC];
-#pragma unroll
-            for (int k = 0; k < SKC; ++k) {
-                const double2_t r01 = *(const double2_t*)(xr + k * ST + 4 * tr);
-                const double2_t r23 = *(const double2_t*)(xr + k * ST + 4 * tr + 2);
-                const double2_t c01 = *(const double2_t*)(xc + k * ST + 2 * tc);
-                const double2_t c23 = *(const double2_t*)(xc + k * ST + 2 * tc + 32);
-                const double rv[4] = {r01[0], r01[1], r23[0], r23[1]};
-                const double cv[4] = {c01[0], c01[1], c23[0], c23[1]};
-                double acc = 0.0;
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int bq = 0; bq < 4; ++bq) {
-                        const double df = rv[a] - cv[bq];
-                        acc = fma(w[a][bq], df * df, acc);
-                    }
-                gk[k] = acc;
-            }
-            // 16 sums over the 256 threads: butterfly transpose-reduce inside the wave (17 shuffles instead of
-            // 16 x 6: after the four halving steps lane l holds coordinate bitrev4(l & 15) summed over its 16-lane
-            // row, two more steps fold the four rows), then the four waves meet in LDS (fixed order)
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int m = 1 << st, cnt = SKC >> (st + 1);
-                const bool up = (lane_ & m) != 0;
-#pragma unroll
-                for (int i = 0; i < cnt; ++i) {
-                    const double keep = up ? gk[i + cnt] : gk[i];
-                    const double send = up ? gk[i] : gk[i + cnt];
-                    gk[i] = keep + __shfl_xor(send, m, 64);
-                }
-            }
-            gk[0] += __shfl_xor(gk[0], 16, 64);
-            gk[0] += __shfl_xor(gk[0], 32, 64);
-            __syncthreads();                                        // ardred of the previous slab has been consumed
-            if (lane_ < 16) {
-                const int kk = ((lane_ & 1) << 3) | ((lane_ & 2) << 1) | ((lane_ & 4) >> 1) | ((lane_ & 8) >> 3);
-                ardred[wave_][kk] = gk[0];
-            }
-            __syncthreads();
-            if (t < SKC && k0 + t < cp.D) out[k0 + t] = ardred[0][t] + ardred[1][t] + ardred[2][t] + ardred[3][t];
-        }
+        ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, nullptr, cp.D, out);
         const double t1 = block_sum(g1, red);
         const double t2 = block_sum(tq, red);
         const double t3 = block_sum(g2, red);
@@ -192,13 +200,15 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
 // Same reduction for a composite program: per element the leaf values, their (up to three) derivatives and the
 // chain-rule weights through the Sum/Product/Scale tree.  Elements run in a rolled loop over LDS-staged distances
 // so that the leaf functors are instantiated once.
+// PARD: the program has an ARD leaf (own weighted distance; per-dimension length-scale sums in a second pass)
+template <bool PARD>
 __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __restrict__ XT, long ldp, long n, int dpad,
                                                             CovProgram P, int ncov, double inv_sn2, double sn2,
                                                             const double* __restrict__ Binv, long ldb,
                                                             const double* __restrict__ alpha,
                                                             const double* __restrict__ wv,
                                                             double* __restrict__ partial, long nt) {
-    __shared__ __attribute__((aligned(16))) double sm[16 * 256];
+    __shared__ __attribute__((aligned(16))) double sm[(PARD ? 2 : 1) * 16 * 256];
     __shared__ double red[4];
     const long b = blockIdx.x;
     long r = (long)(((2.0 * nt + 1.0) - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)b)) * 0.5);
@@ -207,12 +217,14 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
     while ((r + 1) * nt - (r + 1) * r / 2 <= b) ++r;
     const long ti = r, tj = ti + (b - (r * nt - r * (r - 1) / 2));
     const long r0 = ti * ST, c0 = tj * ST;
-    double s[4][4];
-    sqdist_tile(XT, ldp, r0, XT, ldp, c0, dpad, sm, s);
+    double s[4][4], s1[PARD ? 4 : 1][4];
+    if constexpr (PARD) sqdist_tile2(XT, ldp, r0, XT, ldp, c0, dpad, P.ardw, sm, s, s1);
+    else sqdist_tile(XT, ldp, r0, XT, ldp, c0, dpad, sm, s);
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     double* sv = sm + t;
+    double* sv1 = sm + 16 * 256 + t;       // PARD: the ARD distance going in, the length-scale weight omega coming out
 #pragma unroll
-    for (int e = 0; e < 16; ++e) sv[e * 256] = s[e >> 2][e & 3];
+    for (int e = 0; e < 16; ++e) { sv[e * 256] = s[e >> 2][e & 3]; if (PARD) sv1[e * 256] = s1[e >> 2][e & 3]; }
 
     double gl[CP_MAXLEAF][3], gs[CP_MAXSCALE], tq = 0.0;
 #pragma unroll
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
         const long cc = c0 + 2 * tc + (bq & 1) + 32 * (bq >> 1);
         double wt = (cc > rr) ? 2.0 : (cc == rr ? 1.0 : 0.0);
         if (rr >= n || cc >= n) wt = 0.0;
-        if (wt == 0.0) continue;
+        if (wt == 0.0) { if (PARD) sv1[e * 256] = 0.0; continue; }
         const double wr = wv ? wv[rr] : inv_sn2, wc = wv ? wv[cc] : 1.0;
         const double q = Binv[rr * ldb + cc] * (wr * wc) - alpha[rr] * alpha[cc];
         const double wq = wt * q;
@@ -235,13 +247,32 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
         const double r2 = sv[e * 256];
         const bool same = cc == rr;
         double v[CP_MAXLEAF], d[CP_MAXLEAF][3], T[CP_MAXTERM];
+        double ardfac = 0.0;                  // dK_l / d log ell_k = ardfac * (scaled squared difference in coordinate k)
 #pragma unroll
         for (int l = 0; l < CP_MAXLEAF; ++l) {
             v[l] = 1.0; d[l][0] = d[l][1] = d[l][2] = 0.0;
             if (l < P.nleaf) {
-                const double sl = r2 * P.is2[l];
-                v[l] = cov_value<true>(P.leaf[l], sl, same);
-                cov_deriv_all<true>(P.leaf[l], sl, d[l][0], d[l][1], d[l][2], same);
+                if (PARD && l == P.ard_leaf) {
+                    // d[l][0]: magnitude hyper, d[l][1]: RQard shape hyper (Core/cov.py:922-936, 1412-1425)
+                    const double sl = sv1[e * 256];
+                    const CovParams& lp = P.leaf[l];
+                    if (lp.kind == 1) {
+                        v[l] = lp.sf2 * exp_nonpos(-0.5 * sl);
+                        d[l][0] = 2.0 * v[l];
+                        ardfac = v[l];
+                    } else {
+                        const double Kp = 1.0 + 0.5 * sl / lp.alpha;
+                        const double lk = log(Kp);
+                        v[l] = lp.sf2 * exp_nonpos(-lp.alpha * lk);
+                        d[l][0] = 2.0 * v[l];
+                        d[l][1] = v[l] * (0.5 * sl / Kp - lp.alpha * lk);
+                        ardfac = lp.ref_der ? 0.0 : v[l] / Kp;
+                    }
+                } else {
+                    const double sl = r2 * P.is2[l];
+                    v[l] = cov_value<true>(P.leaf[l], sl, same);
+                    cov_deriv_all<true>(P.leaf[l], sl, d[l][0], d[l][1], d[l][2], same);
+                }
             }
         }
         prog_terms(P, v, T);
@@ -252,6 +283,7 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
                 gl[l][0] = fma(wl, d[l][0], gl[l][0]);
                 gl[l][1] = fma(wl, d[l][1], gl[l][1]);
                 gl[l][2] = fma(wl, d[l][2], gl[l][2]);
+                if (PARD && l == P.ard_leaf) sv1[e * 256] = wl * ardfac;
             }
         }
 #pragma unroll
@@ -269,6 +301,13 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
 #pragma unroll
     for (int l = 0; l < CP_MAXLEAF; ++l) {
         if (l < P.nleaf) {
+            if (PARD && l == P.ard_leaf) {      // hypers of the ARD leaf: D length-scales (below), magnitude, [shape]
+                const int D = P.leaf[l].D;
+                const double t0 = block_sum(gl[l][0], red);
+                const double t1 = block_sum(gl[l][1], red);
+                if (t == 0) { out[P.hyp0[l] + D] = t0; if (P.leaf[l].kind == 6) out[P.hyp0[l] + D + 1] = t1; }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 if (j < P.nh[l]) {
@@ -277,6 +316,14 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
                 }
             }
         }
+    }
+    if constexpr (PARD) {
+        double w[4][4];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w[e >> 2][e & 3] = sv1[e * 256];
+        const int la = P.ard_leaf & 7;
+        ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, P.ardw, P.leaf[la].D, out + P.hyp0[la]);
     }
 #pragma unroll
     for (int k = 0; k < CP_MAXSCALE; ++k) {
@@ -473,8 +520,12 @@ int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad
     if (cs.prog) {
         CovProgram pg = cs.pg;
         for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = 1;
-        hipLaunchKernelGGL(hadamard_prog_kernel, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
-                           1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
+        if (pg.ard_leaf >= 0)
+            hipLaunchKernelGGL(hadamard_prog_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
+                               1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
+        else
+            hipLaunchKernelGGL(hadamard_prog_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
+                               1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
     } else {
         CovParams cp = cs.cp;
         cp.train = 1;

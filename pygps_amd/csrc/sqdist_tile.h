@@ -33,7 +33,7 @@ struct CovParams {
 // A Sum / Product / Scale tree over non-ARD leaves (Core/cov.py:230-328), expanded on the host into a sum of
 // products:  K = sum_t coef_t * prod_{l in term t} k_l(r^2 * is2_l).  Every leaf is a function of the *raw*
 // squared distance r^2 (XsT is uploaded unscaled for programs), so one distance tile serves all leaves.
-constexpr int CP_MAXLEAF = 8, CP_MAXTERM = 8, CP_MAXSCALE = 8;
+constexpr int CP_MAXLEAF = 8, CP_MAXTERM = 8, CP_MAXSCALE = 8, CP_MAXARD = 64;
 struct CovProgram {
     int nleaf, nterm, nscale;
     int der;                         // flat hyper index for derivative matrices (-1: value)
@@ -46,6 +46,8 @@ struct CovProgram {
     unsigned tl[CP_MAXTERM];         // leaves multiplied in term t (bit mask)
     unsigned ts[CP_MAXTERM];         // Scale nodes above term t (bit mask)
     int shyp[CP_MAXSCALE];           // flat hyper index of each Scale node
+    int ard_leaf;                    // index of the (at most one) ARD leaf (RBFard / RQard), -1: none.  Its distance is the
+    double ardw[CP_MAXARD];          // weighted sum_k ardw[k] (x_k - z_k)^2, ardw[k] = 1 / ell_k^2, accumulated beside r^2
 };
 
 constexpr int ST = 64;      // tile edge
@@ -87,6 +89,50 @@ __device__ __forceinline__ void sqdist_tile(const double* __restrict__ XrT, long
                 for (int b = 0; b < 4; ++b) {
                     const double df = rv[a] - cv[b];
                     s[a][b] = fma(df, df, s[a][b]);
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// the same tile with a second, per-coordinate weighted distance s1 = sum_k w[k] (a_k - b_k)^2 (ARD leaf of a program)
+__device__ __forceinline__ void sqdist_tile2(const double* __restrict__ XrT, long ldr, long r0,
+                                             const double* __restrict__ XcT, long ldc, long c0, int dpad,
+                                             const double* __restrict__ w /* uniform, >= dpad entries */,
+                                             double* __restrict__ sm, double (&s)[4][4], double (&s1)[4][4]) {
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    double* xr = sm;
+    double* xc = sm + SKC * ST;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { s[a][b] = 0.0; s1[a][b] = 0.0; }
+    for (int k0 = 0; k0 < dpad; k0 += SKC) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int v = t + p * 256;
+            const int k = v >> 5, pr = v & 31;
+            *(double2_t*)(xr + k * ST + 2 * pr) = *(const double2_t*)(XrT + (long)(k0 + k) * ldr + r0 + 2 * pr);
+            *(double2_t*)(xc + k * ST + 2 * pr) = *(const double2_t*)(XcT + (long)(k0 + k) * ldc + c0 + 2 * pr);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SKC; ++k) {
+            const double wk = (k0 + k) < CP_MAXARD ? w[k0 + k] : 0.0;
+            const double2_t r01 = *(const double2_t*)(xr + k * ST + 4 * tr);
+            const double2_t r23 = *(const double2_t*)(xr + k * ST + 4 * tr + 2);
+            const double2_t c01 = *(const double2_t*)(xc + k * ST + 2 * tc);
+            const double2_t c23 = *(const double2_t*)(xc + k * ST + 2 * tc + 32);
+            const double rv[4] = {r01[0], r01[1], r23[0], r23[1]};
+            const double cv[4] = {c01[0], c01[1], c23[0], c23[1]};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double df = rv[a] - cv[b];
+                    const double d2 = df * df;
+                    s[a][b] += d2;
+                    s1[a][b] = fma(wk, d2, s1[a][b]);
                 }
         }
         __syncthreads();
@@ -369,10 +415,15 @@ __device__ __forceinline__ double prog_leaf_weight(const CovProgram& P, const do
     return w;
 }
 
-__device__ __forceinline__ double prog_value(const CovProgram& P, double r2, bool same) {
+// scaled squared distance of leaf l: the shared raw distance times the leaf's 1/ell^2, or the ARD-weighted one
+__device__ __forceinline__ double prog_leaf_dist(const CovProgram& P, int l, double r2, double s1) {
+    return l == P.ard_leaf ? s1 : r2 * P.is2[l];
+}
+
+__device__ __forceinline__ double prog_value(const CovProgram& P, double r2, bool same, double s1 = 0.0) {
     double v[CP_MAXLEAF], T[CP_MAXTERM];
 #pragma unroll
-    for (int l = 0; l < CP_MAXLEAF; ++l) v[l] = l < P.nleaf ? cov_value<true>(P.leaf[l], r2 * P.is2[l], same) : 1.0;
+    for (int l = 0; l < CP_MAXLEAF; ++l) v[l] = l < P.nleaf ? cov_value<true>(P.leaf[l], prog_leaf_dist(P, l, r2, s1), same) : 1.0;
     prog_terms(P, v, T);
     double K = 0.0;
 #pragma unroll
@@ -381,10 +432,11 @@ __device__ __forceinline__ double prog_value(const CovProgram& P, double r2, boo
 }
 
 // derivative matrix entry for the flat hyper index P.der (Product :246-256, Sum :281-291, Scale :320-328)
-__device__ __forceinline__ double prog_deriv(const CovProgram& P, double r2, bool same) {
+// dk2: ARD-weighted squared difference in coordinate der_j (only when the derivative is w.r.t. an ARD length-scale)
+__device__ __forceinline__ double prog_deriv(const CovProgram& P, double r2, bool same, double s1 = 0.0, double dk2 = 0.0) {
     double v[CP_MAXLEAF], T[CP_MAXTERM];
 #pragma unroll
-    for (int l = 0; l < CP_MAXLEAF; ++l) v[l] = l < P.nleaf ? cov_value<true>(P.leaf[l], r2 * P.is2[l], same) : 1.0;
+    for (int l = 0; l < CP_MAXLEAF; ++l) v[l] = l < P.nleaf ? cov_value<true>(P.leaf[l], prog_leaf_dist(P, l, r2, s1), same) : 1.0;
     if (P.der_scale >= 0) {               // 2 * exp(h) * child, through whatever sits above the Scale node
         prog_terms(P, v, T);
         double K = 0.0;
@@ -399,7 +451,7 @@ __device__ __forceinline__ double prog_deriv(const CovProgram& P, double r2, boo
         if (l == P.der_leaf) {
             CovParams lp = P.leaf[l];
             lp.der = P.der_j;
-            out = prog_leaf_weight(P, v, l) * cov_deriv<true>(lp, r2 * P.is2[l], 0.0, same);
+            out = prog_leaf_weight(P, v, l) * cov_deriv<true>(lp, prog_leaf_dist(P, l, r2, s1), dk2, same);
         }
     }
     return out;
@@ -409,8 +461,10 @@ __device__ __forceinline__ double prog_deriv(const CovProgram& P, double r2, boo
 __device__ __forceinline__ double cov_elem(const CovParams& p, double s, double dk2, bool same) {
     return p.der < 0 ? cov_value(p, s, same) : cov_deriv(p, s, dk2, same);
 }
-__device__ __forceinline__ double cov_elem(const CovProgram& P, double s, double, bool same) {
-    return P.der < 0 ? prog_value(P, s, same) : prog_deriv(P, s, same);
+__device__ __forceinline__ double cov_elem(const CovProgram& P, double s, double dk2, bool same, double s1 = 0.0) {
+    return P.der < 0 ? prog_value(P, s, same, s1) : prog_deriv(P, s, same, s1, dk2);
 }
 __device__ __forceinline__ int cov_ard_der(const CovParams& p) { return (cov_is_ard(p) && p.der >= 0 && p.der < p.D) ? p.der : -1; }
-__device__ __forceinline__ int cov_ard_der(const CovProgram&) { return -1; }
+__device__ __forceinline__ int cov_ard_der(const CovProgram& P) {
+    return (P.ard_leaf >= 0 && P.der_leaf == P.ard_leaf && P.der_j >= 0 && P.der_j < P.leaf[P.ard_leaf & 7].D) ? P.der_j : -1;
+}

@@ -71,3 +71,15 @@ def g11_trees():
 
 
 G11_1D = ("periodic", "maunaloa")          # kernels dumped on the 1-d inputs x1 / z1
+
+
+def g14_trees():
+    """Composites with one ARD leaf (G14 fixtures)."""
+    from oracle import gp_oracle as O
+    L = _leaf
+    return {
+        "ard_noise": ("sum", L(O.RBFARD), L(O.NOISE)),
+        "ard_scaled_prod": ("sum", ("prod", ("scale", L(O.RBFARD)), L(O.RQ)), L(O.CONST)),
+        "rqard_sum": ("sum", L(O.RQARD), L(O.MATERN, 3)),
+        "ep_ard_const": ("sum", L(O.RBFARD), L(O.CONST)),
+    }

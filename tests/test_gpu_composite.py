@@ -5,7 +5,7 @@ compared with the golden vectors recorded from the reference (G11) and with the 
 import numpy as np
 import pytest
 
-from conftest import golden, relerr, synth_reg, g11_trees, G11_1D
+from conftest import golden, relerr, synth_cls, synth_reg, g11_trees, g14_trees, G11_1D
 from oracle import gp_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -53,8 +53,8 @@ def test_G11_kernel_matrices_all_modes(nm):
     hyp = g[nm + "_hyp"]
     k = build(g11_trees()[nm], hyp, x.shape[1])
     assert list(np.asarray(k.hyp, float)) == list(hyp)                  # reference flatten order
-    if nm not in ("rqard", "ardsum") and hasattr(k, "_on_device"):
-        assert k._on_device()                                            # runs as one device program
+    if hasattr(k, "_on_device"):
+        assert k._on_device()                                            # runs as one device program (ardsum: one ARD leaf)
     for mode, kw in (("train", dict(x=x)), ("cross", dict(x=x, z=z)), ("self", dict(z=z))):
         m = "self_test" if mode == "self" else mode
         K = k.getCovMatrix(mode=m, **kw)
@@ -162,8 +162,8 @@ def test_composite_limits_and_ard_leaves():
     assert not big._on_device()
     ref = sum(O.cov_matrix(O.RBF, [0.1 * i, -0.2], 0, x=x, mode="train") for i in range(8)) + O.cov_matrix(O.RBF, [0.1, 0.0], 0, x=x, mode="train")
     _close(big.getCovMatrix(x=x, mode="train"), ref)
-    ard = cov.RBFard(D=2) * cov.RBF()
-    assert not ard._on_device()
+    ard = cov.RBFard(D=2) * cov.RQard(D=2)                       # two ARD leaves: no device program
+    assert not ard._on_device() and (cov.RBFard(D=2) * cov.RBF())._on_device()
     for k in (big, ard):
         m = pyGPs.GPR()
         m.setPrior(kernel=k)
@@ -189,3 +189,51 @@ def test_periodic_needs_1d_inputs():
     from pygps_amd import cov
     with pytest.raises(AssertionError):
         cov.Periodic().getCovMatrix(x=np.zeros((4, 2)), mode="train")
+
+
+@pytest.mark.parametrize("nm", ["ard_noise", "ard_scaled_prod", "rqard_sum"])
+def test_G14_fit_with_an_ard_leaf_inside_the_program(nm):
+    """One ARD leaf (own weighted distance) inside a Sum/Product/Scale tree: kernel matrices in all modes with every
+    derivative, fit with all gradients (per-dimension length-scale sums in the second pass), predict."""
+    import pygps_amd as pyGPs
+    g = golden("G14_fit_%s_N300" % nm)
+    tree = g14_trees()[nm]
+    hyp = g["cov_hyp"]
+    k = build(tree, hyp, 4)
+    assert k._on_device() and list(np.asarray(k.hyp, float)) == list(hyp)
+    kx, kz = g["kx"], g["kz"]
+    for mode, kw in (("train", dict(x=kx)), ("cross", dict(x=kx, z=kz)), ("self", dict(z=kz))):
+        mm = "self_test" if mode == "self" else mode
+        _close(k.getCovMatrix(mode=mm, **kw), g["k_K_%s" % mode])
+        for i in range(len(hyp)):
+            _close(k.getDerMatrix(mode=mm, der=i, **kw), g["k_dK%d_%s" % (i, mode)], 1e-11)
+    x, y = synth_reg(300, 4)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=k)
+    m.setNoise(g["lik_hyp"][0])
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    assert relerr(nlZ, g["nlZ"]) < 1e-9 and relerr(post.alpha, g["alpha"]) < 1e-6
+    assert np.allclose(dnlZ.cov, g["dnlZ_cov"], rtol=1e-7, atol=1e-7 * np.max(np.abs(g["dnlZ_cov"])))
+    assert relerr(dnlZ.lik, g["dnlZ_lik"]) < 1e-7 and relerr(dnlZ.mean, g["dnlZ_mean"]) < 1e-7
+    ym, ys2, fm, fs2, lp = m.predict(g["pred_xs"])
+    assert relerr(ym, g["pred_ym"]) < 1e-8 and relerr(fs2, g["pred_fs2"]) < 1e-6
+    if nm == "rqard_sum":                # default (correct) RQard length-scale gradient vs the oracle without the quirk
+        m.setPrior(kernel=build(tree, hyp, 4, compat=False))
+        m.setData(x, y)
+        nlZ2, dn2, _ = m.getPosterior()
+        c = m.meanfunc.hyp[0]
+        out = O.exact_fit(tree, hyp, 0, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y), faithful=False,
+                          matern_reference_compat=False)
+        assert relerr(dn2.cov, out["dnlZ_cov"]) < 1e-7 and abs(dn2.cov[0]) > 1e-3
+
+
+def test_G14_ep_with_an_ard_leaf():
+    import pygps_amd as pyGPs
+    g = golden("G14_ep_ard_const_N200")
+    m = pyGPs.GPC()
+    m.setPrior(kernel=build(g14_trees()["ep_ard_const"], g["cov_hyp"], 3))
+    nlZ, dnlZ, post = m.getPosterior(g["x"], g["y"])
+    assert relerr(nlZ, g["nlZ"]) < 1e-8 and relerr(post.alpha, g["alpha"]) < 1e-6 and relerr(dnlZ.cov, g["dnlZ_cov"]) < 1e-6
+    ym, ys2, fm, fs2, lp = m.predict(g["pred_xs"], ys=np.ones((5, 1)))
+    assert relerr(ym, g["pred_ym"]) < 1e-7 and relerr(lp, g["pred_lp"]) < 1e-7
