@@ -218,3 +218,20 @@ def test_mfma_peak_reported(lib):
     assert lib.pgp_test_mfma_peak(_lib.ctx(), 20000, C.byref(tf)) == 0
     print("fp64 MFMA issue-rate peak: %.1f TFLOP/s" % tf.value, _lib.device_info())
     assert tf.value > 20
+
+
+def test_exp_nonpos_accuracy_over_the_whole_range(lib):
+    """The device exp for non-positive arguments (Cody-Waite + degree-13 Taylor, csrc/sqdist_tile.h) against numpy over
+    [-745, 0]: RBF values from 1 down to the denormals, and exact zeros beyond."""
+    import pygps_amd as pyGPs
+    n = 4000
+    x = np.zeros((n, 1))
+    x[:, 0] = np.sqrt(np.linspace(0.0, 1600.0, n))          # s = x_i^2 against the origin: 0 .. 1600
+    z = np.zeros((1, 1))
+    K = pyGPs.cov.RBF(0.0, 0.0).getCovMatrix(x=x, z=z, mode="cross")[:, 0]
+    s = x[:, 0] ** 2
+    ref = np.exp(-0.5 * s)
+    normal = ref > 1e-300
+    assert np.max(np.abs(K[normal] / ref[normal] - 1.0)) < 1e-15
+    assert np.all(K[~normal] >= 0.0) and np.all(np.abs(K[~normal] - ref[~normal]) < 1e-300)
+    assert K[0] == 1.0 and K[-1] == 0.0
