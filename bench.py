@@ -256,6 +256,35 @@ def main():
                                                 "frac_of_hbm_peak": ba / ms_a.value / 1e6 / PEAK_HBM_GBS}
         except Exception:
             pass
+        # the north-star Cholesky figure at N=16384: one extra context, RBF d=16, the factorisation stage of a full fit
+        # (with the fused triangular inverse riding along: 2 N^3 / 3 flops in that stage), HIP-event stage time
+        try:
+            hb = ctypes.c_void_p()
+            nb_ = 16384
+            if lib.pgp_init(local, ctypes.byref(hb)) == 0:
+                xb, yb = synth_reg(nb_, d)
+                ybv = np.ascontiguousarray(yb).ravel()
+                mb, dmb = np.full(nb_, ybv.mean()), np.ones((1, nb_))
+                ab, nzb, gb = np.empty(nb_), np.zeros(1), np.zeros(4)
+                if lib.pgp_set_data(hb, _lib.ptr(np.ascontiguousarray(xb)), nb_, d, _lib.ptr(ybv)) == 0:
+                    tb = []
+                    for it in range(3):
+                        hyp_b, lsn_b = hyp_for(it, 0, d)
+                        if lib.pgp_exact_fit(hb, _lib.COV_RBF, _lib.ptr(hyp_b), 2, 0, 0, lsn_b, _lib.ptr(mb), _lib.ptr(dmb), 1, 3,
+                                             _lib.ptr(ab), _lib.ptr(nzb), _lib.ptr(gb), None) != 0:
+                            break
+                        st_b = np.zeros(len(_lib.STAGES))
+                        lib.pgp_last_timings(hb, _lib.ptr(st_b))
+                        tb.append(dict(zip(_lib.STAGES, st_b.tolist())))
+                    if len(tb) == 3:
+                        pm = tb[-1]["potrf"]
+                        roof["cholesky_sweep_N16384"] = {
+                            "ms": pm, "TFLOPs": (2.0 * nb_ ** 3 / 3.0) / (pm * 1e-3) / 1e12, "bound": "mfma",
+                            "frac_of_peak": (2.0 * nb_ ** 3 / 3.0) / (pm * 1e-3) / 1e12 / PEAK_FP64_MFMA_TF,
+                            "fit_ms": tb[-1]["total"], "fit_TFLOPs": float(nb_) ** 3 / (tb[-1]["total"] * 1e-3) / 1e12}
+                lib.pgp_destroy(hb)
+        except Exception:
+            pass
 
     if rank == 0:
         total_fits = world * args.steps
