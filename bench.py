@@ -98,6 +98,7 @@ def main():
                     help="independent fit streams per GPU (one pgp_ctx + one host thread each); the K timed steps are "
                          "split over them.  2 overlaps one fit's latency-bound panel phases with the other's GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the N=16384 assembly / Cholesky figures (used by the PMC passes)")
     args = ap.parse_args()
 
     import torch
@@ -246,8 +247,11 @@ def main():
             roof["assembly_GBs"] = asm["bytes"] / asm["ms"] / 1e6
             roof["assembly_frac_of_hbm_peak"] = asm["bytes"] / asm["ms"] / 1e6 / PEAK_HBM_GBS
         # the north-star assembly figure: full symmetric K (getCovMatrix 'train'), RBF, N=16384 d=16, device-resident
+        # (both N=16384 extras are skipped with --no-extras)
         # coordinates, algorithmic bytes 8 N^2 + 8 N d, HIP-event time over 100 launches
         try:
+            if args.no_extras:
+                raise RuntimeError("skipped")
             ms_a = ctypes.c_double()
             na = 16384
             if lib.pgp_test_assemble(ctx, _lib.COV_RBF, 0, na, 16, 100, ctypes.byref(ms_a)) == 0 and ms_a.value > 0:
@@ -259,6 +263,8 @@ def main():
         # the north-star Cholesky figure at N=16384: one extra context, RBF d=16, the factorisation stage of a full fit
         # (with the fused triangular inverse riding along: 2 N^3 / 3 flops in that stage), HIP-event stage time
         try:
+            if args.no_extras:
+                raise RuntimeError("skipped")
             hb = ctypes.c_void_p()
             nb_ = 16384
             if lib.pgp_init(local, ctypes.byref(hb)) == 0:
