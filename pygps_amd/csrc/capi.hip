@@ -17,6 +17,7 @@
 static thread_local char g_err[512] = "";
 void pgp_set_last_hip_error(hipError_t e, const char* what, const char* file, int line) {
     snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    (void)hipGetLastError();      // clear the runtime's sticky "last error": the launch wrappers test hipGetLastError()
 }
 
 void prof_collect(pgp_ctx* c) {

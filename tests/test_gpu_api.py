@@ -300,3 +300,16 @@ def test_ep_ragged_sizes_against_the_oracle(lib):
         out = O.ep_fit(O.RBF, hyp, 0, x, y, np.zeros_like(y))
         assert relerr(nlZ, out["nlZ"]) < 1e-9, n
         assert relerr(post.alpha, out["alpha"]) < 1e-7 and relerr(dnlZ.cov, out["dnlZ_cov"]) < 1e-7, n
+
+
+def test_device_out_of_memory_raises_and_the_context_recovers(lib):
+    """A fit whose N x N workspaces exceed the HBM fails with RuntimeError (status <= -100), and the next fit works."""
+    import pygps_amd as pyGPs
+    rng = np.random.RandomState(0)
+    n = 150000                                    # three 180 GB workspaces: more than 288 GB; the host side stays tiny
+    with pytest.raises(RuntimeError, match="out of memory"):
+        pyGPs.GPR().getPosterior(rng.randn(n, 2), rng.randn(n, 1))
+    x, y = synth_reg(300, 3)
+    nlZ, dnlZ, post = pyGPs.GPR().getPosterior(x, y)
+    out = O.exact_fit(O.RBF, np.array([0.0, 0.0]), 0, np.log(0.1), x, y, np.zeros_like(y), None, faithful=False)
+    assert relerr(nlZ, out["nlZ"]) < 1e-10
