@@ -179,6 +179,18 @@ def device_info(device=None):
     return dict(name=name.value.decode(), n_cu=ncu.value, sclk_mhz=clk.value, hbm_gib=gib.value)
 
 
+_devmem = {}
+
+
+def device_memory_bytes(device=None):
+    """HBM capacity of the device (cached)."""
+    if device is None:
+        device = default_device()
+    if device not in _devmem:
+        _devmem[device] = device_info(device)["hbm_gib"] * 2.0 ** 30
+    return _devmem[device]
+
+
 def last_timings(device=None):
     out = np.zeros(len(STAGES))
     check(load().pgp_last_timings(ctx(device), ptr(out)))

@@ -78,6 +78,11 @@ class DeviceFactor(object):
     ``predict`` uses the handle directly and never materialises it."""
     ndim = 2
     dtype = np.dtype(np.float64)
+    #: bytes of factor buffers (2 n^2 doubles each, with the fused-inverse rows) held by live DeviceFactor objects.
+    #: Models sit in reference cycles (model <-> optimizer), so a dropped model frees its factor only when the cyclic
+    #: garbage collector runs; `reserve` forces a collection before the device fills up with unreachable factors.
+    live_bytes = 0
+    _live_lock = __import__("threading").Lock()
 
     def __init__(self, handle, n, device, slot=0):
         self._h = handle
@@ -85,10 +90,27 @@ class DeviceFactor(object):
         self._dev = device
         self._slot = slot
         self._host = None
-        self._fin = weakref.finalize(self, DeviceFactor._release, handle, device, slot)
+        nbytes = DeviceFactor.nbytes_for(n)
+        with DeviceFactor._live_lock:
+            DeviceFactor.live_bytes += nbytes
+        self._fin = weakref.finalize(self, DeviceFactor._release, handle, device, slot, nbytes)
 
     @staticmethod
-    def _release(handle, device, slot):
+    def nbytes_for(n):
+        np_ = (int(n) + 127) // 128 * 128
+        return (2 * np_ + 128) * np_ * 8
+
+    @staticmethod
+    def reserve(n, device):
+        """Called before a fit: collect unreachable models when their factors hold more than a quarter of the HBM."""
+        if DeviceFactor.live_bytes + DeviceFactor.nbytes_for(n) > 0.25 * _lib.device_memory_bytes(device):
+            import gc
+            gc.collect()
+
+    @staticmethod
+    def _release(handle, device, slot, nbytes=0):
+        with DeviceFactor._live_lock:
+            DeviceFactor.live_bytes -= nbytes
         try:
             _lib.load().pgp_factor_free(_lib.ctx(device, slot), handle)
         except Exception:       # interpreter shutdown
@@ -212,6 +234,7 @@ class Exact(Inference):
         x = _lib.f64(x)
         n, D = x.shape
         y = _lib.f64(y).reshape(n)
+        DeviceFactor.reserve(n, dev)
         _Resident.ensure(x, y, dev)
         m, dm, nm = _mean_inputs(meanfunc, x)
         hyp = _lib.f64(np.asarray(covfunc.hyp, dtype=float))
@@ -262,6 +285,7 @@ class EP(Inference):
         x = _lib.f64(x)
         n, D = x.shape
         y = _lib.f64(y).reshape(n)
+        DeviceFactor.reserve(n, dev)
         _Resident.ensure(x, y, dev)
         m, dm, nm = _mean_inputs(meanfunc, x)
         hyp = _lib.f64(np.asarray(covfunc.hyp, dtype=float))
