@@ -661,8 +661,11 @@ int ensure_workspace(pgp_ctx* c, long np) {
 
 int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F) {
     const size_t bytes = (size_t)ldf * np * sizeof(double);
-    auto it = c->pool.find(bytes);
-    if (it != c->pool.end()) { *F = (double*)it->second; c->pool.erase(it); c->pool_bytes -= bytes; return PGP_OK; }
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mu);
+        auto it = c->pool.find(bytes);
+        if (it != c->pool.end()) { *F = (double*)it->second; c->pool.erase(it); c->pool_bytes -= bytes; return PGP_OK; }
+    }
     HIP_TRY(hipMalloc((void**)F, bytes));
     HIP_TRY(hipMemsetAsync(*F, 0, bytes, c->st));     // strict-upper tiles and augmented rows stay 0 forever
     return PGP_OK;

@@ -1,6 +1,7 @@
 // Internal: context / factor structs shared by the host-side drivers (capi.hip, predict.hip, ep.hip).
 #pragma once
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/pygps_amd.h"
@@ -45,6 +46,7 @@ struct pgp_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     // pooled device buffers, keyed by byte size
+    std::mutex pool_mu;                 // pgp_factor_free may run on another thread (Python finalizers / cyclic GC)
     std::multimap<size_t, void*> pool;  // factor buffers only: strict-upper tiles and spare rhs rows are zero by contract
     size_t pool_bytes = 0;
     std::multimap<size_t, void*> spool; // general scratch (arbitrary contents)
@@ -84,6 +86,7 @@ struct pgp_ctx {
     } while (0)
 
 static inline int pool_alloc(pgp_ctx* c, size_t bytes, void** out) {
+    std::lock_guard<std::mutex> lk(c->pool_mu);
     auto it = c->pool.find(bytes);
     if (it != c->pool.end()) {
         *out = it->second;
@@ -102,6 +105,7 @@ static inline int pool_alloc(pgp_ctx* c, size_t bytes, void** out) {
 // idle buffers are kept for the next call with the same shape, up to a third of the device memory
 static inline void pool_free(pgp_ctx* c, size_t bytes, void* p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
     if (c->pool_bytes + bytes > (size_t)c->prop.totalGlobalMem / 3) { (void)hipFree(p); return; }
     c->pool.insert({bytes, p});
     c->pool_bytes += bytes;
@@ -151,6 +155,7 @@ struct PoolScratch {
     std::vector<std::pair<size_t, void*>> held;
     explicit PoolScratch(pgp_ctx* c_) : c(c_) {}
     ~PoolScratch() {
+        std::lock_guard<std::mutex> lk(c->pool_mu);
         for (auto& h : held) {
             if (c->spool_bytes + h.first > (size_t)c->prop.totalGlobalMem / 3) { (void)hipFree(h.second); continue; }
             c->spool.insert({h.first, h.second});
@@ -161,6 +166,7 @@ struct PoolScratch {
     int alloc(T** out, size_t bytes) {
         void* p = nullptr;
         if (!bytes) bytes = 8;
+        std::lock_guard<std::mutex> lk(c->pool_mu);
         auto it = c->spool.find(bytes);
         if (it != c->spool.end()) {
             p = it->second; c->spool.erase(it); c->spool_bytes -= bytes;
