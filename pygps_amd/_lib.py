@@ -71,7 +71,7 @@ SIGNATURES = {
     "pgp_test_assemble": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _i64, C.c_int, _dp]),
 }
 
-_lock = threading.Lock()
+_lock = threading.RLock()
 _dll = None
 _ctx = {}
 
@@ -79,6 +79,8 @@ _ctx = {}
 def load():
     """dlopen the library and attach the prototypes.  Raises if it is not built."""
     global _dll
+    if _dll is not None:                    # lock-free fast path
+        return _dll
     with _lock:
         if _dll is None:
             if not os.path.exists(LIB_PATH):
@@ -157,6 +159,9 @@ def ctx(device=None, slot=None):
         device = default_device()
     if slot is None:
         slot = current_slot()
+    h = _ctx.get((device, slot))            # lock-free fast path (dict reads are atomic under the GIL)
+    if h is not None:
+        return h
     dll = load()
     with _lock:
         h = _ctx.get((device, slot))

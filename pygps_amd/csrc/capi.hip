@@ -642,6 +642,7 @@ int ensure_workspace(pgp_ctx* c, long np) {
     void* olds[] = {c->W, c->T, c->Binv, c->inv16, c->alpha_dev, c->m_dev, c->rvec, c->zvec};
     for (void* b : olds) if (b) (void)hipFree(b);
     c->W = c->T = c->Binv = c->inv16 = c->alpha_dev = c->m_dev = c->rvec = c->zvec = nullptr;
+    c->ws_np = 0;          // committed again only once EVERY allocation below has succeeded
     const size_t nn = (size_t)np * np * sizeof(double);
     HIP_TRY(hipMalloc((void**)&c->W, nn));
     HIP_TRY(hipMemsetAsync(c->W, 0, nn, c->st));
@@ -690,17 +691,20 @@ int pgp_set_data(pgp_ctx* c, const double* x, int64_t n, int64_t d, const double
     void* olds[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev};
     for (void* b : olds) if (b) (void)hipFree(b);
     c->x_dev = c->y_dev = c->XsT = c->scale_dev = nullptr;
-    c->n = n; c->d = d; c->np = round_up(n, 128); c->ldf = 2 * c->np + 128;
-    // ^ factor rows | 128 augmented rhs rows | np rows of the fused inverse (E region)
-    c->dpad = (int)round_up(d, SKC);
+    c->n = 0;              // "no data" until every allocation and copy below has succeeded
+    const long np = round_up(n, 128);
+    const int dpad = (int)round_up(d, SKC);
     HIP_TRY(hipMalloc((void**)&c->x_dev, n * d * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->y_dev, c->np * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->XsT, (size_t)c->dpad * c->np * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->scale_dev, c->dpad * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->y_dev, np * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->XsT, (size_t)dpad * np * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->scale_dev, dpad * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(c->x_dev, x, n * d * sizeof(double), hipMemcpyHostToDevice, c->st));
-    HIP_TRY(hipMemsetAsync(c->y_dev, 0, c->np * sizeof(double), c->st));
+    HIP_TRY(hipMemsetAsync(c->y_dev, 0, np * sizeof(double), c->st));
     if (y) HIP_TRY(hipMemcpyAsync(c->y_dev, y, n * sizeof(double), hipMemcpyHostToDevice, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
+    c->n = n; c->d = d; c->np = np; c->ldf = 2 * np + 128;
+    // ^ factor rows | 128 augmented rhs rows | np rows of the fused inverse (E region)
+    c->dpad = dpad;
     return PGP_OK;
 }
 
@@ -722,6 +726,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     const long need = std::max(hadamard_partial_count(np, ncov), 32L * np);       // also the partials of upper_matvec
     if (want >= 3 && c->partial_cap < need) {
         if (c->partial) (void)hipFree(c->partial);
+        c->partial = nullptr; c->partial_cap = 0;      // a failed realloc must not leave a dangling pointer behind
         HIP_TRY(hipMalloc((void**)&c->partial, need * sizeof(double)));
         c->partial_cap = need;
     }
@@ -882,8 +887,7 @@ int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n,
     if (mode == PGP_MODE_SELF_TEST) {
         // zero distance: the functor itself gives value and derivatives (Core/cov.py:815-817, 924-925, 1163-1177,
         // SURVEY Q6), including the Matern derivative quirk and Noise = 0 on 'self_test' (cov.py:1271)
-        CHK(ensure_workspace(c, 128));
-        double val = 0.0;
+        double val = 0.0;                              // cov_point_value only needs c->scal: the fit workspace stays as it is
         CHK(cov_point_value(c, cp, 2, &val));
         for (int64_t i = 0; i < m; ++i) out[i] = val;
         return PGP_OK;

@@ -183,12 +183,26 @@ struct PoolScratch {
     }
 };
 
-// Returns a pooled factor buffer to the context unless ownership was handed on (release()).
+// Returns a pooled factor buffer to the context unless ownership was handed on (release()).  The pool's contract is
+// "strict-upper tiles and spare rhs rows are zero": with scrub set, a buffer abandoned half-way (non-PD pivot -> NaNs,
+// HIP failure) is zeroed before it goes back.
 struct FactorGuard {
-    pgp_ctx* c; double* F; size_t bytes;
-    FactorGuard(pgp_ctx* c_, double* F_, size_t b) : c(c_), F(F_), bytes(b) {}
-    ~FactorGuard() { if (F) pool_free(c, bytes, F); }
+    pgp_ctx* c; double* F; size_t bytes; bool scrub;
+    FactorGuard(pgp_ctx* c_, double* F_, size_t b, bool scrub_ = false) : c(c_), F(F_), bytes(b), scrub(scrub_) {}
+    ~FactorGuard() {
+        if (!F) return;
+        if (scrub) { (void)hipMemsetAsync(F, 0, bytes, c->st); (void)hipStreamSynchronize(c->st); }
+        pool_free(c, bytes, F);
+    }
     double* release() { double* p = F; F = nullptr; return p; }
+};
+
+// A factor handle under construction: freed (with everything it owns) on an early return.
+struct FactorHandleGuard {
+    pgp_ctx* c; pgp_factor* f;
+    FactorHandleGuard(pgp_ctx* c_, pgp_factor* f_) : c(c_), f(f_) {}
+    ~FactorHandleGuard() { if (f) pgp_factor_free(c, f); }
+    pgp_factor* release() { pgp_factor* p = f; f = nullptr; return p; }
 };
 
 void prof_collect(pgp_ctx* c);

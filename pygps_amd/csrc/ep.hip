@@ -345,20 +345,18 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     const long need = hadamard_partial_count(np, ncov);
     if (want >= 3 && c->partial_cap < need) {
         if (c->partial) (void)hipFree(c->partial);
+        c->partial = nullptr; c->partial_cap = 0;      // a failed realloc must not leave a dangling pointer behind
         HIP_TRY(hipMalloc((void**)&c->partial, need * sizeof(double)));
         c->partial_cap = need;
     }
     EpWork w{};
     w.n = n; w.np = np; w.ldf = ldf;
     const size_t nn = (size_t)np * np * sizeof(double);
-    std::vector<void*> owned;
-    auto dalloc = [&](double** p, size_t bytes) -> int {
-        HIP_TRY(hipMalloc((void**)p, bytes));
-        owned.push_back(*p);
-        return PGP_OK;
-    };
-    auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
-#define EP_TRY(x) do { int rc__ = (x); if (rc__ != PGP_OK) { cleanup(); return rc__; } } while (0)
+    // RAII: every early return (HIP_TRY / EP_TRY / CHK) gives the scratch back to the context's pool, scrubs + returns the
+    // factor buffer and frees a half-built handle -- no hipMalloc / hipFree (device-synchronising) on the steady-state path
+    PoolScratch pscr(c);
+    auto dalloc = [&](double** p, size_t bytes) -> int { return pscr.alloc(p, bytes); };
+#define EP_TRY(x) CHK(x)
     EP_TRY(dalloc(&w.Kd, nn)); EP_TRY(dalloc(&w.Sig, nn)); EP_TRY(dalloc(&w.Vd, nn));
     EP_TRY(dalloc(&w.Wd, (size_t)128 * np * sizeof(double)));
     EP_TRY(dalloc(&w.rhs, (size_t)128 * np * sizeof(double)));
@@ -374,6 +372,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     { double* b8 = nullptr; EP_TRY(dalloc(&b8, 64)); w.base = (long*)b8; }
     HIP_TRY(hipMemsetAsync(w.Kd, 0, nn, st));
     EP_TRY(alloc_factor_buffer(c, np, ldf, &w.F));
+    FactorGuard fguard(c, w.F, (size_t)ldf * np * sizeof(double), /*scrub=*/true);
     // ---- K (full symmetric, padded with zeros) --------------------------------------------------------
     EP_TRY(upload_scaled(c, c->x_dev, n, d, sc, c->XsT, np, c->dpad, c->scale_dev));
     EP_TRY(cov_sym_launch(c->XsT, np, n, c->dpad, cp, w.Kd, st, np));
@@ -398,7 +397,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);
         if (rc == PGP_OK && !(nlZ > nlZ0)) fresh = false;
         if (rc > 0) rc = PGP_OK;                                                      // bad warm start: fall back to zeros
-        if (rc != PGP_OK) { pool_free(c, (size_t)ldf * np * sizeof(double), w.F); cleanup(); return rc; }
+        if (rc != PGP_OK) return rc;
     }
     if (fresh) {
         std::fill(ttau.begin(), ttau.end(), 0.0);
@@ -486,7 +485,10 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // inf.py:772
-        if (rc != PGP_OK) { pool_free(c, (size_t)ldf * np * sizeof(double), w.F); cleanup(); return rc; }
+        if (rc != PGP_OK) {
+            if (block_graph) { (void)hipStreamSynchronize(st); (void)hipGraphExecDestroy(block_graph); }
+            return rc;
+        }
     }
     if (block_graph) { (void)hipStreamSynchronize(st); (void)hipGraphExecDestroy(block_graph); block_graph = nullptr; }
     if (sweeps_out) *sweeps_out = sweep;
@@ -538,9 +540,10 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     }
     if (c->prof) prof_collect(c);
     if (factor_out) {
-        pgp_factor* f = new pgp_factor();
-        f->n = n; f->np = np; f->ldf = ldf; f->F = w.F; f->dpad = c->dpad; f->d = (int)d; f->cs = cp; f->kss = kss; f->sn2 = 1.0;
-        f->sw = 1.0; f->Wd = nullptr;
+        FactorHandleGuard hg(c, new pgp_factor());
+        pgp_factor* f = hg.f;
+        f->n = n; f->np = np; f->ldf = ldf; f->F = fguard.release(); f->dpad = c->dpad; f->d = (int)d; f->cs = cp; f->kss = kss;
+        f->sn2 = 1.0; f->sw = 1.0; f->Wd = nullptr;
         HIP_TRY(hipMalloc((void**)&f->alpha, np * sizeof(double)));
         HIP_TRY(hipMemsetAsync(f->alpha, 0, np * sizeof(double), st));
         HIP_TRY(hipMemcpyAsync(f->alpha, alpha.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
@@ -549,12 +552,11 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMalloc((void**)&f->XsT, (size_t)c->dpad * np * sizeof(double)));
         HIP_TRY(hipMemcpyAsync(f->XsT, c->XsT, (size_t)c->dpad * np * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
-        *factor_out = f;
+        *factor_out = hg.release();
     } else {
         HIP_TRY(hipStreamSynchronize(st));
-        pool_free(c, (size_t)ldf * np * sizeof(double), w.F);
+        fguard.scrub = false;                         // a finished factor honours the pool contract (zeros above the diagonal)
     }
-    cleanup();
     return PGP_OK;
 #undef EP_TRY
 }

@@ -82,7 +82,8 @@ class DeviceFactor(object):
     #: Models sit in reference cycles (model <-> optimizer), so a dropped model frees its factor only when the cyclic
     #: garbage collector runs; `reserve` forces a collection before the device fills up with unreachable factors.
     live_bytes = 0
-    _live_lock = __import__("threading").Lock()
+    # RLock: the finalizer below can run from the cyclic GC on the very thread that is inside `with _live_lock`
+    _live_lock = __import__("threading").RLock()
 
     def __init__(self, handle, n, device, slot=0):
         self._h = handle
@@ -93,7 +94,10 @@ class DeviceFactor(object):
         nbytes = DeviceFactor.nbytes_for(n)
         with DeviceFactor._live_lock:
             DeviceFactor.live_bytes += nbytes
-        self._fin = weakref.finalize(self, DeviceFactor._release, handle, device, slot, nbytes)
+        # the context handle and the entry point are captured NOW: a finalizer may fire (cyclic GC) while this thread
+        # holds _lib's module lock inside ctx()/load(), so it must not look either of them up again
+        self._ctx = _lib.ctx(device, slot)
+        self._fin = weakref.finalize(self, DeviceFactor._release, _lib.load().pgp_factor_free, self._ctx, handle, nbytes)
 
     @staticmethod
     def nbytes_for(n):
@@ -108,18 +112,18 @@ class DeviceFactor(object):
             gc.collect()
 
     @staticmethod
-    def _release(handle, device, slot, nbytes=0):
+    def _release(free_fn, ctx_handle, handle, nbytes=0):
         with DeviceFactor._live_lock:
             DeviceFactor.live_bytes -= nbytes
         try:
-            _lib.load().pgp_factor_free(_lib.ctx(device, slot), handle)
+            free_fn(ctx_handle, handle)     # pgp_factor_free: takes the context's own pool mutex, no Python lock
         except Exception:       # interpreter shutdown
             pass
 
     @property
     def ctx(self):
         """The context that owns the device buffers of this factor."""
-        return _lib.ctx(self._dev, self._slot)
+        return self._ctx
 
     @property
     def handle(self):
@@ -331,16 +335,17 @@ class FITCPosterior(object):
         self.handle = handle
         self._dev = device
         self._slot = slot
-        self._fin = weakref.finalize(self, FITCPosterior._free, handle.value, device, slot)
+        self._ctx = _lib.ctx(device, slot)                # captured now: the finalizer must not take _lib's lock
+        self._fin = weakref.finalize(self, FITCPosterior._free, _lib.load().pgp_fitc_free, self._ctx, handle.value)
 
     @property
     def ctx(self):
-        return _lib.ctx(self._dev, self._slot)
+        return self._ctx
 
     @staticmethod
-    def _free(h, device, slot):
+    def _free(free_fn, ctx_handle, h):
         try:
-            _lib.load().pgp_fitc_free(_lib.ctx(device, slot), C.c_void_p(h))
+            free_fn(ctx_handle, C.c_void_p(h))
         except Exception:
             pass
 

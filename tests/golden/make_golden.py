@@ -215,19 +215,42 @@ def g8():
          cov_hyp=np.array(m.covfunc.hyp), ttau=m.inffunc.last_ttau, tnu=m.inffunc.last_tnu,
          pred_ym=ym, pred_ys2=ys2, pred_fm=fm, pred_fs2=fs2, **dn(dnlZ))
     for N in (128, 512):
-        d = 32
-        x, y = synth_cls(N, d)
-        m = pyGPs.GPC()
-        m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+        g8ii(N)
+
+
+def g8ii(N):
+    """cfg 5 recipe at size N; the number of EP sweeps is recorded by counting the
+    reference's own _epComputeParams calls (one per sweep on a cold start, inf.py:771)."""
+    d = 32
+    x, y = synth_cls(N, d)
+    m = pyGPs.GPC()
+    m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+    calls = []
+    orig = type(m.inffunc)._epComputeParams
+
+    def spy(self, *a, **k):
+        out = orig(self, *a, **k)
+        calls.append(float(out[2]))
+        print("   sweep %d nlZ %.12g  (%.0fs)" % (len(calls), calls[-1], time.time() - t0), flush=True)
+        return out
+    t0 = time.time()
+    type(m.inffunc)._epComputeParams = spy
+    try:
         nlZ, dnlZ, post = m.getPosterior(x, y)
-        save("G8ii_ep_d32_N%d" % N, N=N, d=d, seed=0, nlZ=nlZ, alpha=post.alpha, sW=post.sW,
-             L_diag=np.diag(post.L).copy(), cov_hyp=np.array(m.covfunc.hyp),
-             ttau=m.inffunc.last_ttau, tnu=m.inffunc.last_tnu, **dn(dnlZ))
+    finally:
+        type(m.inffunc)._epComputeParams = orig
+    extra = {}
+    if N > 512:     # strided L sample (every 257th entry of the flattened upper factor), like G6
+        extra = dict(L_stride=257, L_sample=np.asarray(post.L).ravel()[::257].copy())
+    save("G8ii_ep_d32_N%d" % N, N=N, d=d, seed=0, nlZ=nlZ, alpha=post.alpha, sW=post.sW,
+         L_diag=np.diag(post.L).copy(), cov_hyp=np.array(m.covfunc.hyp),
+         ttau=m.inffunc.last_ttau, tnu=m.inffunc.last_tnu, n_sweeps=len(calls),
+         sweep_nlZ=np.array(calls), **extra, **dn(dnlZ))
 
 
 # ----------------------------------------------------------------------------- G9 (cfg 4, restarts)
-def g9():
-    N, d = 512, 16
+def g9(N=512):
+    d = 16
     x, y = synth_reg(N, d)
     m = pyGPs.GPR()
     m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
@@ -261,7 +284,7 @@ def g9():
     fopt = np.array([r.get("f", np.nan) for r in runs])
     nls = np.array([r.get("nls", -1) for r in runs])
     final = np.array(m.meanfunc.hyp + m.covfunc.hyp + m.likfunc.hyp)
-    save("G9_restarts_N512", N=N, d=d, seed=0, np_seed=123, num_restarts=8, numIterations=40,
+    save("G9_restarts_N%d" % N, N=N, d=d, seed=0, np_seed=123, num_restarts=8, numIterations=40,
          hyp0=hyp0, run_X0=X0, run_ok=ok, run_Xopt=Xopt, run_f=fopt, run_nls=nls, n_runs=R,
          best_hyp=final, best_nlZ=m.nlZ)
 
@@ -516,6 +539,7 @@ def g14():
 CASES = {
     "g14": g14, "g13": g13, "g12": g12, "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
+    "g8ii_2048": lambda: g8ii(2048), "g8ii_4096": lambda: g8ii(4096), "g9_2048": lambda: g9(2048),
     "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384),
 }
 
