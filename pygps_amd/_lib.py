@@ -67,6 +67,7 @@ SIGNATURES = {
     "pgp_test_mfma_peak": (C.c_int, [_vp, C.c_int, _dp]),
     "pgp_test_mfma_cycles": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "pgp_test_leaf_ticks": (C.c_int, [_vp, _dp]),
+    "pgp_test_ds_ticks": (C.c_int, [_vp, _dp, C.c_int]),
     "pgp_test_overlap": (C.c_int, [_vp, _dp]),
     "pgp_test_assemble": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _i64, C.c_int, _dp]),
 }

@@ -74,6 +74,7 @@ int pgp_init(int device, pgp_ctx** ctx_out) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         HIP_TRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, hi));   // panel chain = critical path
+        HIP_TRY(hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, hi));   // panel solves (sweep v2 with the server)
     }
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     memset(c->last_ms, 0, sizeof(c->last_ms));
@@ -81,6 +82,14 @@ int pgp_init(int device, pgp_ctx** ctx_out) {
     memset(c->pc_bytes, 0, sizeof(c->pc_bytes)); memset(c->pc_launch, 0, sizeof(c->pc_launch));
     HIP_TRY(hipMalloc((void**)&c->scal, 256 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->info_dev, sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&c->Dk, (size_t)2048 * 1024 * sizeof(double)));       // 2w x w, w <= 1024
+    HIP_TRY(hipMalloc((void**)&c->dpack, (size_t)8 * PACK_DOUBLES * sizeof(double)));
+    HIP_TRY(hipMemset(c->Dk, 0, (size_t)2048 * 1024 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->Yn, (size_t)512 * 512 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->dflags, diag_server_flag_bytes()));
+    HIP_TRY(hipMemset(c->dflags, 0, diag_server_flag_bytes()));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_ds, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_ds2, hipEventDisableTiming));
     *ctx_out = c;
     return PGP_OK;
 }
@@ -93,12 +102,13 @@ void pgp_destroy(pgp_ctx* c) {
     for (auto& kv : c->spool) (void)hipFree(kv.second);
     for (auto& kv : c->orders) (void)hipFree(kv.second.first);
     void* bufs[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev, c->W, c->T, c->Binv, c->inv16, c->alpha_dev, c->m_dev,
-                    c->rvec, c->zvec, c->partial, c->scal, c->info_dev};
+                    c->rvec, c->zvec, c->partial, c->scal, c->info_dev, c->Dk, c->dpack, c->Xs, c->dflags, c->ds_ticks, c->Yn};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->st);
     if (c->st2) (void)hipStreamDestroy(c->st2);
+    if (c->st3) (void)hipStreamDestroy(c->st3);
     for (auto& e : c->la_ev) (void)hipEventDestroy(e);
     delete c;
 }
@@ -120,6 +130,17 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "xcd_order")) { c->xcd_order = value; return PGP_OK; }
     if (!strcmp(name, "gemm_dbg")) { c->gemm_dbg = value; return PGP_OK; }
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
+    if (!strcmp(name, "potrf_v1")) { c->potrf_v1 = value; return PGP_OK; }
+    if (!strcmp(name, "dserver")) { c->dserver = value; return PGP_OK; }
+    if (!strcmp(name, "ds_exclusive")) { c->ds_exclusive = value; return PGP_OK; }
+    if (!strcmp(name, "ds_timeout_ms")) { c->ds_timeout_s = 1e-3 * value; return PGP_OK; }
+    if (!strcmp(name, "ds_ticks")) {            // record wall-clock stamps of the server phases (16 per panel)
+        if (value && !c->ds_ticks) {
+            HIP_TRY(hipMalloc((void**)&c->ds_ticks, (size_t)diag_server_max_panels() * 16 * sizeof(long long)));
+            HIP_TRY(hipMemset(c->ds_ticks, 0, (size_t)diag_server_max_panels() * 16 * sizeof(long long)));
+        } else if (!value && c->ds_ticks) { (void)hipFree(c->ds_ticks); c->ds_ticks = nullptr; }
+        return PGP_OK;
+    }
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
     if (!strcmp(name, "ep_block")) { c->ep_block = value; return PGP_OK; }
     if (!strcmp(name, "ep_graph")) { c->ep_graph = value; return PGP_OK; }
@@ -440,13 +461,15 @@ int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
 // rows_end(nb) = one past the last row that takes part once nb column blocks are factored
 struct RowEnd { long eoff; bool winv; long operator()(int nb) const { return winv ? eoff + (long)nb * 128 : eoff; } };
 
-static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s1, hipStream_t st) {
+static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s1, hipStream_t st,
+                        double* packs = nullptr, int info_base = 0) {
+    if (!packs) packs = c->inv16;
     for (int cb = s0; cb < s1; ++cb) {
         double* Acc = F + (long)cb * 128 + (long)cb * 128 * ld;
-        double* pack = c->inv16 + (long)cb * PACK_DOUBLES;
+        double* pack = packs + (long)cb * PACK_DOUBLES;
         {
             ProfScope ps(c, PC_LEAF, 128.0 * 128.0 * 128.0 / 3.0, 0.0, st);
-            CHK(leaf_potrf_launch(Acc, ld, pack, c->info_dev, cb * 128, st));
+            CHK(leaf_potrf_launch(Acc, ld, pack, c->info_dev, info_base + cb * 128, st));
         }
         const long rows_below = re(cb + 1) - (long)(cb + 1) * 128;
         if (rows_below > 0) {
@@ -491,7 +514,7 @@ static int trailing_update(pgp_ctx* c, double* F, long ld, RowEnd re, int k0, in
 // exactly a triangular inverse -- but it runs inside the big K=512 trailing-update launches, which it also keeps
 // large when the Cholesky's own trailing matrix shrinks (tiles per launch ~ constant), instead of a separate
 // recursion of 12 small clipped GEMM launches.
-int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse) {
+static int potrf_blocked_v1(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse) {
     const RowEnd re{mrows, with_inverse};
     const int nblk = (int)(np / 128);
     const int q = c->nb_outer;
@@ -536,6 +559,268 @@ int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with
         HIP_TRY(hipStreamWaitEvent(c->st, c->ev_join, 0));
     }
     return PGP_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Cholesky sweep, version 2 ("diagonal-panel" schedule; the default).
+//
+// The v1 sweep above keeps EVERY row below a leaf (Cholesky rows, rhs rows, fused-inverse rows: ~np rows) in the
+// latency-bound leaf-level chain: 64 x (leaf_potrf -> trsm_rows over ~np rows -> K=128 inner update) at 5-11 TF, and
+// those launches queue behind 150 us trailing-update workgroups.  Here only the w x w DIAGONAL block of an outer panel
+// (w = 128 q = 512) goes through the leaf chain, in a small scratch with identity rows appended so that E_D = L_D^-T
+// falls out with it (diag_factor: D(p)).  Everything below the block is then ONE MFMA GEMM per panel
+//        Y = X E_D        (solve_below: S(p);  K clipped to the triangle, k < j0 + T)
+// instead of 4 trsm + 3 inner-update launches, and the trailing update TU(p) is unchanged.  The critical chain per panel
+// is D(p) only (~13 tiny launches on <= 8 CUs); S and TU are bulk MFMA work on the main stream:
+//
+//   main :  S(p) -> TU_a(p) [next panel's columns, written to the staging buffer Xs] -> TU_b(p) [rest, in place] -> ...
+//   panel:                       D(p+1) (reads its diagonal block from Xs)  ..................^ joined before S(p+1)
+//
+// S is out of place (reads Xs, writes the factor / inverse rows), which is free: TU_a already reads and writes those
+// columns once, it just writes them to Xs instead.  The matrix lives in two pieces: logical rows [0, mrows) in F
+// (factor + rhs rows, what a posterior handle keeps) and rows [mrows, mrows + np) in E (fused inverse, scratch).
+struct SweepMat { double* F; long ldf; long mrows; double* E; long lde; long np; };
+
+static int ensure_stage(pgp_ctx* c, long rows, int w) {
+    const size_t need = (size_t)rows * w * sizeof(double);
+    if (c->Xs_bytes >= need) return PGP_OK;
+    (void)hipStreamSynchronize(c->st);
+    if (c->Xs) (void)hipFree(c->Xs);
+    c->Xs = nullptr; c->Xs_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&c->Xs, need));
+    c->Xs_bytes = need;
+    return PGP_OK;
+}
+
+// D(p): factor the diagonal block of columns [s0, s1) (block units), src = its (updated) image with leading dim lds
+static int diag_factor(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* src, long lds, hipStream_t st) {
+    const int w = (s1 - s0) * 128;
+    const long ldd = 2L * w;
+    { ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
+      CHK(diag_in_launch(src, lds, c->Dk, ldd, w, st)); }
+    CHK(factor_panel(c, c->Dk, ldd, RowEnd{(long)w, true}, 0, s1 - s0, st, c->dpack, s0 * 128));
+    { ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
+      CHK(diag_out_launch(c->Dk, ldd, w, m.F + (long)s0 * 128 * (1 + m.ldf), m.ldf,
+                          m.E ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, st)); }
+    return PGP_OK;
+}
+
+// S(p): rows below the diagonal block of panel [s0, s1):  Y = X E_D, X read from the staging buffer (logical rows, ldx)
+static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* Xs, long ldx, hipStream_t st,
+                       const double* Dk = nullptr) {
+    if (!Dk) Dk = c->Dk;
+    const int w = (s1 - s0) * 128;
+    const long r0 = (long)s1 * 128, r1 = m.mrows + (m.E ? (long)s0 * 128 : 0);
+    if (r1 <= r0) return PGP_OK;
+    GemmArgs g{};
+    g.A = Xs + r0; g.lda = ldx; g.a_kc = 0;
+    g.B = Dk + w; g.ldb = 2L * w; g.b_kc = 1;                 // B(n,k) = E_D(k,n): K-contiguous
+    g.C = m.F + r0 + (long)s0 * 128 * m.ldf; g.ldc = m.ldf;
+    if (m.E && r1 > m.mrows) { g.C2 = m.E + (long)s0 * 128 * m.lde; g.ldc2 = m.lde; g.c_split = (int)(m.mrows - r0); }
+    g.M = (int)(r1 - r0); g.N = w; g.K = w; g.alpha = 1.0; g.beta = 0.0;
+    g.kmode = KM_LT_J; g.koff = 0;
+    const long t128 = (long)(g.M / 128) * (w / 128);
+    g.tile = t128 < c->small_tile_below ? 64 : 128;
+    const double nt = (double)(w / g.tile);
+    g.flops = 2.0 * (double)g.M * g.tile * g.tile * nt * (nt + 1.0) * 0.5;
+    return gemm_prof(c, PC_GEMM_SOLVE, g, st);
+}
+
+// TU: C[rows >= c0, cols c0..c1) -= P P^T, P = solved columns [k0, k1); out != nullptr: result goes to the staging buffer
+static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c0, int c1, double* out, long ldx,
+                            hipStream_t st, int stage_blocks = 0, unsigned* sig_counter = nullptr,
+                            unsigned* sig_flag = nullptr, int sig_blocks = 0, bool skip_stage_diag = false,
+                            unsigned* stg_counter = nullptr, unsigned* stg_flag = nullptr) {
+    if (c1 <= c0) return PGP_OK;
+    const long r0 = (long)c0 * 128, r1 = m.mrows + (m.E ? (long)k1 * 128 : 0);
+    GemmArgs g{};
+    g.A = m.F + r0 + (long)k0 * 128 * m.ldf; g.lda = m.ldf; g.a_kc = 0;
+    g.B = g.A; g.ldb = m.ldf; g.b_kc = 0;
+    double* Cf = m.F + r0 + (long)c0 * 128 * m.ldf;
+    const bool split = m.E && r1 > m.mrows;
+    const int sp = (int)(m.mrows - r0);
+    double* Ce = split ? m.E + (long)c0 * 128 * m.lde : nullptr;
+    if (split) { g.A2 = m.E + (long)k0 * 128 * m.lde; g.lda2 = m.lde; g.a_split = sp; }
+    if (out) {
+        g.Cin = Cf; g.ldcin = m.ldf; g.Cin2 = Ce; g.ldcin2 = m.lde;
+        g.C = out + r0; g.ldc = ldx;
+        if (split) { g.C2 = out + r0 + sp; g.ldc2 = ldx; g.c_split = sp; }
+    } else {
+        g.C = Cf; g.ldc = m.ldf;
+        if (split) { g.C2 = Ce; g.ldc2 = m.lde; g.c_split = sp; }
+    }
+    g.M = (int)(r1 - r0); g.N = (c1 - c0) * 128; g.K = (k1 - k0) * 128;
+    g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
+    if (split) g.zero_from = (int)(m.mrows + (long)k0 * 128 - r0);     // this panel's own inverse rows: first touch
+    const long t128 = (long)(g.M / 128) * (g.N / 128) - (long)(g.N / 128) * (g.N / 128 - 1) / 2;
+    g.tile = t128 < c->small_tile_below ? 64 : 128;
+    if (out && stage_blocks > 0) {                    // one launch: the first stage_blocks column blocks -> staging, rest in place
+        g.stage_cols = stage_blocks * 128;
+        g.skip_stage_diag = skip_stage_diag ? 1 : 0;
+        const int T = g.tile, mt = g.M / T, nst = g.stage_cols / T;
+        auto count = [&](int ns) {                                     // active tiles of the first ns tile columns
+            long tot = 0;
+            for (int tj = 0; tj < ns; ++tj)
+                for (int ti = tj; ti < mt; ++ti)
+                    if (!(skip_stage_diag && ti < nst && tj < nst)) ++tot;
+            return (unsigned)tot;
+        };
+        if (sig_counter) {
+            if (sig_blocks <= 0) sig_blocks = stage_blocks;
+            g.sig_counter = sig_counter; g.sig_flag = sig_flag; g.sig_cols = sig_blocks * 128;
+            g.sig_total = count(sig_blocks * 128 / T);
+        }
+        if (stg_counter) {                                             // "the staged columns are complete" (for the next S)
+            g.sig2_counter = stg_counter; g.sig2_flag = stg_flag; g.sig2_cols = g.stage_cols; g.sig2_total = count(nst);
+        }
+        // no active tile carries the signal (e.g. the last update of a sweep without rhs rows: only the skipped diagonal
+        // block is left): post the flag from the stream instead
+        unsigned* late[2] = {nullptr, nullptr};
+        if (g.sig_counter && g.sig_total == 0) { late[0] = g.sig_flag; g.sig_counter = nullptr; }
+        if (g.sig2_counter && g.sig2_total == 0) { late[1] = g.sig2_flag; g.sig2_counter = nullptr; }
+        if (late[0] || late[1]) {
+            g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
+            CHK(gemm_prof(c, PC_GEMM_TRAIL, g, st));
+            for (unsigned* f : late) if (f) CHK(diag_server_post(f, st));
+            return PGP_OK;
+        }
+    }
+    g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
+    return gemm_prof(c, PC_GEMM_TRAIL, g, st);
+}
+
+static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
+    const int nblk = (int)(m.np / 128);
+    const int q = std::min(c->nb_outer, 8);
+    const int npanel = (nblk + q - 1) / q;
+    const int wmax = q * 128;
+    const long ldx = m.mrows + m.np;                              // staging buffer indexed by logical row
+    const bool la = c->lookahead && npanel >= 3;
+    // the resident server only pays when there is a trailing update to overlap with
+    const bool server = la && c->dserver && q <= 4 && npanel <= diag_server_max_panels();
+    const long xs_stride = ldx * wmax;                            // server mode: two staging buffers (panel parity)
+    CHK(ensure_stage(c, server ? 2 * ldx : ldx, wmax));
+    double* Xs = c->Xs;
+    const long dk_stride = 1024L * 1024L;                         // two scratch images inside c->Dk (server mode)
+    if (la && !server)
+        while ((int)c->la_ev.size() < 2 * npanel + 2) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->la_ev.push_back(e);
+        }
+    hipStream_t main = c->st, pan = la ? c->st2 : c->st;
+    if (la && c->st_masked) {                 // bulk work on a CU subset, the reserved CUs belong to the panel chain
+        HIP_TRY(hipEventRecord(c->ev_fork, c->st));
+        HIP_TRY(hipStreamWaitEvent(c->st_masked, c->ev_fork, 0));
+        main = c->st_masked;
+    }
+    if (server) {
+        // flags zeroed, then the server goes resident on the panel stream BEFORE any bulk work is queued
+        HIP_TRY(hipMemsetAsync(c->dflags, 0, diag_server_flag_bytes(), main));
+        HIP_TRY(hipEventRecord(c->ev_ds, main));
+        HIP_TRY(hipStreamWaitEvent(pan, c->ev_ds, 0));
+        CHK(diag_server_launch(c->Dk, dk_stride, c->dpack, m.F, m.ldf, m.E, m.lde, Xs, ldx, xs_stride, c->Yn, nblk, q,
+                               c->dflags, c->info_dev, c->ds_timeout_s, c->ds_ticks, pan, c->ds_exclusive != 0));
+        c->ds_used = true;
+    }
+    // panel 0: its columns go to the staging buffer by a plain copy (later panels get there through TU_a)
+    {
+        const int s1 = std::min(q, nblk);
+        const long r0 = (long)s1 * 128;
+        if (m.mrows > r0)
+            HIP_TRY(hipMemcpy2DAsync(Xs + r0, ldx * sizeof(double), m.F + r0, m.ldf * sizeof(double),
+                                     (m.mrows - r0) * sizeof(double), (size_t)s1 * 128, hipMemcpyDeviceToDevice, main));
+        if (server) CHK(diag_server_go(c->dflags, 0, main));
+        else CHK(diag_factor(c, m, 0, s1, m.F, m.ldf, main));
+    }
+    if (server) {
+        // server: the whole critical path, left-looking -- it brings the next diagonal block up to date itself and
+        //         factors it, one to two panels ahead of the bulk work (see diag_server_kernel)
+        // side  : S(p) as soon as the server has posted done[p]; overlaps the tail of TU(p-1)
+        // main  : TU(p) as ONE launch -- the next panel's columns first (into staging buffer (p+1)&1; the next panel's
+        //         diagonal block is the server's and skipped), then the rest in place; the tile that completes the first two
+        //         column panels releases go[p+2] from inside the kernel
+        hipStream_t side = c->st3;
+        while ((int)c->la_ev.size() < npanel + 2) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->la_ev.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(c->ev_ds, main));                      // panel-0 copy before the first S
+        HIP_TRY(hipStreamWaitEvent(side, c->ev_ds, 0));
+        for (int p = 0; p < npanel; ++p) {
+            const int s0 = p * q, s1 = std::min(s0 + q, nblk);
+            CHK(diag_server_wait(c->dflags, p, c->ds_timeout_s, side));
+            // the server may be ahead of the bulk: S(p) also needs panel p's staged columns, i.e. the head of TU(p-1)
+            if (p > 0) CHK(diag_server_wait_staged(c->dflags, p, c->ds_timeout_s, side));
+            CHK(solve_below(c, m, s0, s1, Xs + (p & 1) * xs_stride, ldx, side, c->Dk + (p & 1) * dk_stride));
+            HIP_TRY(hipEventRecord(c->la_ev[p], side));
+            HIP_TRY(hipStreamWaitEvent(main, c->la_ev[p], 0));
+            if (s1 >= nblk) break;
+            const int n1 = std::min(s1 + q, nblk), n2 = std::min(n1 + q, nblk);
+            const bool sig = p + 2 < npanel;
+            CHK(trailing_update2(c, m, s0, s1, s1, nblk, Xs + ((p + 1) & 1) * xs_stride, ldx, main, n1 - s1,
+                                 sig ? diag_server_counter(c->dflags, p + 2) : nullptr,
+                                 sig ? diag_server_go_flag(c->dflags, p + 2) : nullptr, n2 - s1, true,
+                                 diag_server_counter2(c->dflags, p + 1), diag_server_stage_flag(c->dflags, p + 1)));
+        }
+        HIP_TRY(hipEventRecord(c->ev_ds2, pan));                      // the server has exited (or is about to)
+        HIP_TRY(hipStreamWaitEvent(main, c->ev_ds2, 0));
+        return PGP_OK;
+    }
+    for (int p = 0; p < npanel; ++p) {
+        const int s0 = p * q, s1 = std::min(s0 + q, nblk);
+        CHK(solve_below(c, m, s0, s1, Xs, ldx, main));
+        if (s1 >= nblk) break;
+        const int n0 = s1, n1 = std::min(s1 + q, nblk);              // next panel's columns
+        CHK(trailing_update2(c, m, s0, s1, n0, n1, Xs, ldx, main));  // TU_a -> staging
+        if (la) {
+            HIP_TRY(hipEventRecord(c->la_ev[2 * p], main));
+            HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
+        }
+        CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan));
+        if (la) HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
+        CHK(trailing_update2(c, m, s0, s1, n1, nblk, nullptr, 0, main));   // TU_b in place, concurrent with D(p+1)
+        if (la) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
+    }
+    if (main != c->st) {
+        HIP_TRY(hipEventRecord(c->ev_join, main));
+        HIP_TRY(hipStreamWaitEvent(c->st, c->ev_join, 0));
+    }
+    return PGP_OK;
+}
+
+// after the stream has been synchronised: did the resident server of the last sweep post an error (timeout)?
+int potrf_server_status(pgp_ctx* c) {
+    if (!c->ds_used) return PGP_OK;
+    c->ds_used = false;
+    unsigned err = 0;
+    HIP_TRY(hipMemcpy(&err, c->dflags + diag_server_err_index(), sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (err != 0) {
+        char msg[128];
+        snprintf(msg, sizeof(msg), "diagonal-panel server timed out (code %u)", err);
+        pgp_set_last_hip_error(hipErrorLaunchTimeOut, msg, __FILE__, __LINE__);
+        return PGP_ERR_HIP;
+    }
+    return PGP_OK;
+}
+
+// Entry point.  with_inverse: the np rows [mrows, mrows + np) end up holding E = L^-T (upper triangular).  They live at
+// E (leading dimension lde) or, when E is null, directly below the factor's rows in the same buffer (F + mrows, ld).
+// The v2 sweep writes EVERY entry of the inverse rows it later reads, so E needs no initialisation; v1 (option potrf_v1)
+// wants an identity there on entry and a single buffer.
+int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse, double* E, long lde) {
+    if (with_inverse && !E) { E = F + mrows; lde = ld; }
+    if (c->potrf_v1) {
+        if (with_inverse) {
+            if (E != F + mrows || lde != ld) return -1;
+            CHK(identity_upper_launch(E, ld, np, c->st));
+        }
+        return potrf_blocked_v1(c, F, ld, np, mrows, with_inverse);
+    }
+    SweepMat m{F, ld, mrows, with_inverse ? E : nullptr, lde, np};
+    return potrf_blocked_v2(c, m);
 }
 
 // W = L^-1 (column-major lower, np x np).  Level 0: batched inversion of the 128-blocks; then the
@@ -702,8 +987,9 @@ int pgp_set_data(pgp_ctx* c, const double* x, int64_t n, int64_t d, const double
     HIP_TRY(hipMemsetAsync(c->y_dev, 0, np * sizeof(double), c->st));
     if (y) HIP_TRY(hipMemcpyAsync(c->y_dev, y, n * sizeof(double), hipMemcpyHostToDevice, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
-    c->n = n; c->d = d; c->np = np; c->ldf = 2 * np + 128;
-    // ^ factor rows | 128 augmented rhs rows | np rows of the fused inverse (E region)
+    c->n = n; c->d = d; c->np = np; c->ldf = np + 128;
+    // ^ factor rows | 128 augmented rhs rows.  (The np rows of the fused inverse live in pooled scratch, not in the
+    //   factor buffer: a posterior handle keeps (np + 128) np doubles, not (2 np + 128) np.)
     c->dpad = dpad;
     return PGP_OK;
 }
@@ -716,7 +1002,10 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     if (!covhyp) return -3;
     if (want < 1 || want > 3) return -11;
     HIP_TRY(hipSetDevice(c->device));
-    const long n = c->n, d = c->d, np = c->np, ldf = c->ldf;
+    const long n = c->n, d = c->d, np = c->np;
+    const bool fused = want >= 3 && c->fused_inverse;
+    // v1 sweep (A/B option): inverse rows inside the factor buffer; v2: factor buffer = factor + rhs rows only
+    const long ldf = (c->potrf_v1 && fused) ? 2 * np + 128 : c->ldf;
     CovSpec cp;
     { const int rc = make_spec(c, kind, covhyp, ncov, para, flags, -1, d, cp); if (rc != PGP_OK) return rc == -11 ? -10 : rc; }
     const std::vector<double>& sc = cp.scale;
@@ -733,7 +1022,14 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     const double sn2 = exp(2.0 * log_sn);
     double* F = nullptr;
     CHK(alloc_factor_buffer(c, np, ldf, &F));
-    FactorGuard fguard(c, F, (size_t)ldf * np * sizeof(double));       // back to the pool on every early return
+    FactorGuard fguard(c, F, (size_t)ldf * np * sizeof(double), /*scrub=*/true);   // back to the pool on every early return
+    PoolScratch pscr(c);
+    double* E = nullptr;                             // E(i,j) at E[i + j*lde]: ends up as W^T = L^-T (upper triangular)
+    long lde = np;
+    if (fused) {
+        if (c->potrf_v1) { E = F + np + 128; lde = ldf; }
+        else CHK(pscr.alloc(&E, (size_t)np * np * sizeof(double)));
+    }
     hipStream_t st = c->st;
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
     if (mvec) HIP_TRY(hipMemcpyAsync(c->m_dev, mvec, n * sizeof(double), hipMemcpyHostToDevice, st));
@@ -747,12 +1043,9 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         CHK(cov_factor_launch(c->XsT, np, n, np, c->dpad, cp, 1.0 / sn2, F, ldf, st));
     }
     CHK(aug_rhs_launch(c->y_dev, c->m_dev, n, F, ldf, np, c->rvec, st));
-    const bool fused = want >= 3 && c->fused_inverse;
-    double* E = F + np + 128;                        // E(i,j) at E[i + j*ldf]: ends up as W^T = L^-T (upper triangular)
-    if (fused) CHK(identity_upper_launch(E, ldf, np, st));
     // ---- S2: Cholesky (forward substitution of the augmented row -- and L^-T -- ride along) ----------
     HIP_TRY(hipEventRecord(c->ev[1], st));
-    CHK(potrf_blocked(c, F, ldf, np, np + 128, fused));
+    CHK(potrf_blocked(c, F, ldf, np, np + 128, fused, E, lde));
     HIP_TRY(hipEventRecord(c->ev[2], st));
     int info = 0;
     // ---- S5a/S3: W = L^-1, alpha = W^T z / sn2 (or blocked back-substitution when W is not needed)
@@ -760,7 +1053,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     if (fused) {
         HIP_TRY(hipEventRecord(c->ev[3], st));
         { ProfScope ps(c, PC_SMALL, 0.0, 4.0 * (double)np * np);                      // alpha = W^T z / sn2 = E z / sn2
-          CHK(upper_matvec_launch(E, ldf, np, c->zvec, 1.0 / sn2, c->partial, c->alpha_dev, st)); }
+          CHK(upper_matvec_launch(E, lde, np, c->zvec, 1.0 / sn2, c->partial, c->alpha_dev, st)); }
     } else if (want >= 3) {
         CHK(trtri_lower(c, F, ldf, c->W, np, c->T, np));
         HIP_TRY(hipEventRecord(c->ev[3], st));
@@ -778,7 +1071,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     HIP_TRY(hipEventRecord(c->ev[4], st));
     // ---- S5b: B^-1 = W^T W ; S6: gradient reduce ------------------------------------------------
     if (want >= 3) {
-        if (fused) CHK(eet_lower(c, E, ldf, c->Binv, np, np));                        // B^-1 = W^T W = E E^T
+        if (fused) CHK(eet_lower(c, E, lde, c->Binv, np, np));                        // B^-1 = W^T W = E E^T
         else CHK(lauum_lower(c, c->W, np, c->Binv, np, np));
         HIP_TRY(hipEventRecord(c->ev[5], st));
         // alpha currently holds W^T z / sn2 = B^-1 r / sn2  (already the final alpha)
@@ -799,6 +1092,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     std::vector<double> alpha_h(n);
     HIP_TRY(hipMemcpyAsync(alpha_h.data(), c->alpha_dev, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    CHK(potrf_server_status(c));
     if (want < 3) for (auto& a : alpha_h) a /= sn2;
     {
         float ms;
@@ -807,11 +1101,9 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[6]); c->last_ms[PGP_STAGE_TOTAL] = ms;
     }
     if (c->prof) prof_collect(c);
-    if (info != 0) {
-        // the buffer now holds NaNs: scrub it before it goes back to the pool (fguard)
-        (void)hipMemsetAsync(F, 0, (size_t)ldf * np * sizeof(double), st);
-        (void)hipStreamSynchronize(st);
-        return info > (int)n ? (int)n : info;
+    if (info != 0) return info > (int)n ? (int)n : info;     // the buffer now holds NaNs: fguard scrubs it for the pool
+    if (c->potrf_v1 && fused) {                       // v1 leaves E in the spare rows: honour the pool contract (zeros)
+        CHK(zero_strip_launch(F, ldf, np, np + 128, np, st));
     }
     if (alpha_out) memcpy(alpha_out, alpha_h.data(), n * sizeof(double));
     if (want >= 2 && nlZ_out) {
@@ -828,7 +1120,8 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         dnlZ_out[nmean + ncov] = sc_host[8 + ncov];                                     // inf.py:374
     }
     if (factor_out) {
-        pgp_factor* f = new pgp_factor();
+        FactorHandleGuard hg(c, new pgp_factor());
+        pgp_factor* f = hg.f;
         f->n = n; f->np = np; f->ldf = ldf; f->F = fguard.release(); f->dpad = c->dpad; f->d = (int)d; f->cs = cp; f->kss = kss;
         f->sn2 = sn2; f->sw = 1.0 / sqrt(sn2); f->Wd = nullptr;
         HIP_TRY(hipMalloc((void**)&f->alpha, np * sizeof(double)));
@@ -837,8 +1130,9 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         HIP_TRY(hipMalloc((void**)&f->XsT, (size_t)c->dpad * np * sizeof(double)));
         HIP_TRY(hipMemcpyAsync(f->XsT, c->XsT, (size_t)c->dpad * np * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
-        *factor_out = f;
+        *factor_out = hg.release();
     }
+    fguard.scrub = false;                             // a finished factor honours the pool contract as it is
     return PGP_OK;
 }
 
@@ -950,6 +1244,7 @@ int pgp_potrf(pgp_ctx* c, const double* A, int64_t n, double* L_out) {
     int info = 0;
     HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    CHK(potrf_server_status(c));
     if (c->prof) prof_collect(c);
     if (info != 0) return info > (int)n ? (int)n : info;
     // device holds column-major lower L; numpy wants row-major lower => transpose on the host

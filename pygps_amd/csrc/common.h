@@ -34,6 +34,7 @@ enum GemmKMode {
     KM_GE_I = 1,     // k in [i0 + koff, K)        (i0 = first row of the tile)
     KM_GE_J = 2,     // k in [j0 + koff, K)        (j0 = first column of the tile)
     KM_LT_I = 3,     // k in [0, i0 + TM + koff)
+    KM_LT_J = 4,     // k in [0, j0 + TN + koff)
 };
 
 struct GemmArgs {
@@ -52,6 +53,24 @@ struct GemmArgs {
     int norder;
     int dbg;                // experiments only: 1 = no global->LDS restaging in the k-loop, 2 = no barrier, 4 = no C load/store
     double flops;           // algorithmic flops of this launch (for profiling; filled by caller)
+    // Two-piece row spaces (the factor rows and the fused-inverse rows of a Cholesky sweep live in separate buffers so
+    // that a posterior handle only keeps the factor).  Tile rows i0 >= *_split (relative to the operand's row 0, a
+    // multiple of the tile size; 0 = single piece) are addressed at  X2[(i - split) + k*ldx2].  M-contiguous A only.
+    const double* A2; long lda2; int a_split;
+    double* C2; long ldc2; int c_split;
+    // Optional separate source of the beta*C term (same shape and split point as C): out-of-place updates
+    // C = beta*Cin + alpha*A*B' (the look-ahead Cholesky redirects the next panel's columns into a staging buffer).
+    const double* Cin; long ldcin; const double* Cin2; long ldcin2;
+    int zero_from;          // > 0: tile rows i0 >= zero_from take beta = 0 (rows touched for the first time: never read)
+    // Staged columns (look-ahead Cholesky): with Cin set, only tiles with j0 < stage_cols write to C / C2 (the staging
+    // buffer); the other tiles update Cin / Cin2 in place.  stage_cols == 0 with Cin set: every tile goes to C.
+    int stage_cols;
+    int skip_stage_diag;    // 1: tiles with i0 < stage_cols and j0 < stage_cols are not computed (the next panel's diagonal
+                            //    block belongs to the resident server, which updates its private copy itself)
+    // Device-side completion signal: every tile with j0 < sig_cols releases its stores and bumps *sig_counter; the
+    // tile that brings it to sig_total stores 1 to *sig_flag (what the resident diagonal-panel server polls).
+    unsigned* sig_counter; unsigned* sig_flag; int sig_cols; unsigned sig_total;
+    unsigned* sig2_counter; unsigned* sig2_flag; int sig2_cols; unsigned sig2_total;      // a second, independent signal
 };
 
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st);

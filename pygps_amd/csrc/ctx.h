@@ -9,11 +9,11 @@
 #include "sqdist_tile.h"
 
 enum ProfClass { PC_ASSEMBLE = 0, PC_GEMM_TRAIL, PC_GEMM_INNER, PC_LEAF, PC_TRSM, PC_LEAFINV, PC_GEMM_TRTRI,
-                 PC_GEMM_LAUUM, PC_HADAMARD, PC_SMALL, PC_COUNT };
+                 PC_GEMM_LAUUM, PC_HADAMARD, PC_SMALL, PC_GEMM_SOLVE, PC_DIAG, PC_COUNT };
 static const char* const kProfNames[PC_COUNT] = {
     "cov_tile_kernel(assemble)", "gemm_f64(potrf trailing syrk)", "gemm_f64(potrf inner update)",
     "leaf_potrf_kernel", "trsm_rows_kernel", "leaf_inv_kernel", "gemm_f64(trtri)", "gemm_f64(lauum W^T W)",
-    "hadamard_reduce_kernel", "small/O(N) kernels"};
+    "hadamard_reduce_kernel", "small/O(N) kernels", "gemm_f64(panel solve X E_D)", "diag_in/out staging"};
 
 struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
 
@@ -36,6 +36,7 @@ struct pgp_ctx {
     std::vector<int> composite;         // postfix program of kind PGP_COV_COMPOSITE (pgp_set_composite)
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky
+    hipStream_t st3 = nullptr;          // panel-solve stream (sweep v2 with the resident server)
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
     int ep_graph = 0;                   // EP: replay each 128-site block as a captured hipGraph (measured: no gain)
@@ -61,6 +62,19 @@ struct pgp_ctx {
            *rvec = nullptr, *zvec = nullptr, *partial = nullptr, *scal = nullptr;
     long partial_cap = 0;
     int* info_dev = nullptr;
+    // Cholesky sweep v2: diagonal-panel scratch (2w x w, w <= 1024), its leaf operand images, column staging buffer
+    double *Dk = nullptr, *dpack = nullptr, *Xs = nullptr, *Yn = nullptr;
+    size_t Xs_bytes = 0;
+    unsigned* dflags = nullptr;         // barrier counter / error word / go[p] / done[p] of the resident diagonal-panel server
+    hipEvent_t ev_ds = nullptr, ev_ds2 = nullptr;
+    int dserver = 0;                    // 1: diagonal panels factored by the resident server kernel (left-looking, runs ahead of the
+                                        //    bulk); 0: by 13 launches each on the panel stream.  Measured equal single-stream (13.5 ms
+                                        //    at N=8192), the launch chain is better with two fit streams per GPU (91 vs 81 fits/s)
+    int ds_exclusive = 1;               // 1: server workgroups claim a whole CU each (LDS padding)
+    double ds_timeout_s = 10.0;         // every spin of the server (and of the main stream's wait kernel) is bounded
+    long long* ds_ticks = nullptr;      // optional per-phase wall-clock stamps (option ds_ticks)
+    bool ds_used = false;
+    int potrf_v1 = 0;                   // 1: the round-1 sweep (every row in the leaf chain), kept for A/B measurements
     hipEvent_t ev[PGP_NSTAGE + 2];
     double last_ms[PGP_NSTAGE];
     // profiling
@@ -209,7 +223,9 @@ void prof_collect(pgp_ctx* c);
 static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int flags, int der, long d, CovSpec& cs);
 int cov_point_value(pgp_ctx* c, const CovSpec& cs, int train, double* out);
-int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse = false);
+int potrf_server_status(pgp_ctx* c);
+int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse = false, double* E = nullptr,
+                  long lde = 0);
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);
 int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ldw, double* T, long np);
 int lauum_lower(pgp_ctx* c, const double* W, long ldw, double* Binv, long ldb, long np);

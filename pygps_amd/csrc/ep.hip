@@ -305,6 +305,7 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     HIP_TRY(hipMemcpyAsync(dsig_h.data(), w.diag_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(sc, c->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    CHK(potrf_server_status(c));
     // -log marginal likelihood (inf.py:184-188)
     double slZ = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0, t6 = 0.0;
     for (long i = 0; i < n; ++i) {

@@ -1,0 +1,220 @@
+// fp64 MFMA GEMM tile body shared by gemm_f64_kernel (gemm_f64.hip) and the resident diagonal-panel server
+// (panel.hip): one workgroup (256 threads) computes one TM x TN tile of  C = alpha * A B' + beta * Cin.
+#pragma once
+#include "common.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+namespace gemm_tile_ns {
+
+constexpr int BK = 16;
+
+template <int TM, int TN, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, long bz, double* __restrict__ smem) {
+    constexpr int SA = TM + 16, SB = TN + 16, SK = BK + 2;
+    constexpr int ASZ = AKC ? TM * SK : BK * SA;
+    constexpr int BSZ = BKC ? TN * SK : BK * SB;
+    constexpr int STAGE = ASZ + BSZ;
+    constexpr int FM = TM / 32, FN = TN / 32;      // 16x16 fragments per wave in M and N
+    constexpr int AV = TM * BK / 2 / 256;          // double2 vectors staged per thread
+    constexpr int BV = TN * BK / 2 / 256;
+
+    const int i0 = ti * TM, j0 = tj * TN;
+    if (g.skip_stage_diag && i0 < g.stage_cols && j0 < g.stage_cols) return;
+    bool diag = false;
+    if (g.tri) {
+        if (i0 + g.tri_off < j0) return;
+        diag = g.mask_diag && (i0 + g.tri_off == j0);
+    }
+    int k0 = 0, k1 = g.K;
+    if (g.kmode == KM_GE_I) k0 = i0 + g.koff;
+    else if (g.kmode == KM_GE_J) k0 = j0 + g.koff;
+    else if (g.kmode == KM_LT_I) k1 = i0 + TM + g.koff;
+    else if (g.kmode == KM_LT_J) k1 = j0 + TN + g.koff;
+    if (k0 < 0) k0 = 0;
+    if (k1 > g.K) k1 = g.K;
+    k0 &= ~(BK - 1);
+
+    // two-piece row spaces: pick the piece this tile's rows live in (workgroup-uniform)
+    const bool a_hi = g.a_split && i0 >= g.a_split;
+    const bool c_hi = g.c_split && i0 >= g.c_split;
+    const double* __restrict__ A = (a_hi ? g.A2 - g.a_split : g.A) + bz * g.sA;
+    const long lda = a_hi ? g.lda2 : g.lda;
+    const double* __restrict__ B = g.B + bz * g.sB;
+    const bool inplace = g.Cin && g.stage_cols && j0 >= g.stage_cols;        // not a staged column: update Cin in place
+    double* __restrict__ C = inplace ? (double*)(c_hi ? g.Cin2 - g.c_split : g.Cin)
+                                     : (c_hi ? g.C2 - g.c_split : g.C) + bz * g.sC;
+    const long ldc = inplace ? (c_hi ? g.ldcin2 : g.ldcin) : (c_hi ? g.ldc2 : g.ldc);
+    const double* __restrict__ Cin = g.Cin ? (c_hi ? g.Cin2 - g.c_split : g.Cin) : C;
+    const long ldcin = g.Cin ? (c_hi ? g.ldcin2 : g.ldcin) : ldc;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = (wave & 1) * (TM / 2), wn = (wave >> 1) * (TN / 2);
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    // ---- accumulators, pre-loaded with (beta/alpha)*C (== alpha*beta*C for alpha = +-1) ------
+    double4_t acc[FM][FN];
+    const double ab = g.beta / g.alpha;
+    const bool preload = g.beta != 0.0 && !(g.dbg & 4) && !(g.zero_from && i0 >= g.zero_from);
+#pragma unroll
+    for (int im = 0; im < FM; ++im)
+#pragma unroll
+        for (int in = 0; in < FN; ++in) {
+            if (preload) {
+                const double* cp = Cin + (long)(i0 + wm + im * 16 + l15) + (long)(j0 + wn + in * 16 + l4) * ldcin;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[im][in][r] = ab * cp[(long)(4 * r) * ldcin];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[im][in][r] = 0.0;
+            }
+        }
+
+    // ---- staging helpers ----------------------------------------------------------------
+    double2_t ra[AV], rb[BV];
+    // per-thread source pointers of the staging loads, bumped by one k-tile per iteration (no 64-bit address
+    // arithmetic inside the k-loop: those VALU ops would sit un-overlapped at the loop head)
+    const double* pa[AV];
+    const double* pb[BV];
+    long astep, bstep;
+    if (!AKC) {
+        constexpr int VPR = TM / 2, RPP = 256 / VPR;
+#pragma unroll
+        for (int p = 0; p < AV; ++p) pa[p] = A + (long)(i0 + 2 * (t % VPR)) + (long)(k0 + t / VPR + p * RPP) * lda;
+        astep = (long)BK * lda;
+    } else {
+#pragma unroll
+        for (int p = 0; p < AV; ++p) pa[p] = A + (long)(k0 + 2 * (t & 7)) + (long)(i0 + (t >> 3) + p * 32) * lda;
+        astep = BK;
+    }
+    if (!BKC) {
+        constexpr int VPR = TN / 2, RPP = 256 / VPR;
+#pragma unroll
+        for (int p = 0; p < BV; ++p) pb[p] = B + (long)(j0 + 2 * (t % VPR)) + (long)(k0 + t / VPR + p * RPP) * g.ldb;
+        bstep = (long)BK * g.ldb;
+    } else {
+#pragma unroll
+        for (int p = 0; p < BV; ++p) pb[p] = B + (long)(k0 + 2 * (t & 7)) + (long)(j0 + (t >> 3) + p * 32) * g.ldb;
+        bstep = BK;
+    }
+    auto gload = [&](int) {
+#pragma unroll
+        for (int p = 0; p < AV; ++p) { ra[p] = *(const double2_t*)pa[p]; pa[p] += astep; }
+#pragma unroll
+        for (int p = 0; p < BV; ++p) { rb[p] = *(const double2_t*)pb[p]; pb[p] += bstep; }
+    };
+    auto sstore = [&](int buf) {
+        double* sa = smem + buf * STAGE;
+        double* sb = sa + ASZ;
+        if (!AKC) {
+            constexpr int VPR = TM / 2;
+            constexpr int RPP = 256 / VPR;
+#pragma unroll
+            for (int p = 0; p < AV; ++p) {
+                const int mv = t % VPR, kr = t / VPR + p * RPP;
+                *(double2_t*)(sa + kr * SA + 2 * mv) = ra[p];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < AV; ++p) {
+                const int kp = t & 7, m = (t >> 3) + p * 32;
+                *(double2_t*)(sa + m * SK + 2 * kp) = ra[p];
+            }
+        }
+        if (!BKC) {
+            constexpr int VPR = TN / 2;
+            constexpr int RPP = 256 / VPR;
+#pragma unroll
+            for (int p = 0; p < BV; ++p) {
+                const int nv = t % VPR, kr = t / VPR + p * RPP;
+                *(double2_t*)(sb + kr * SB + 2 * nv) = rb[p];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < BV; ++p) {
+                const int kp = t & 7, n = (t >> 3) + p * 32;
+                *(double2_t*)(sb + n * SK + 2 * kp) = rb[p];
+            }
+        }
+    };
+
+    if (k0 < k1) {
+        gload(k0);
+        sstore(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = k0; kt < k1; kt += BK) {
+            const bool more = kt + BK < k1;
+            if (more && !(g.dbg & 1)) gload(kt + BK);
+            const double* sa = smem + buf * STAGE;
+            const double* sb = sa + ASZ;
+            // fragments are double-buffered in registers: the LDS reads of k-step ks+1 are issued BEFORE the 16
+            // MFMAs of k-step ks, so their latency hides behind 1024 cycles of matrix work instead of stalling
+            // the (in-order) wave once per k-step
+            double fa[2][FM], fb[2][FN];
+            auto ldfrag = [&](int ks, int slot) {
+                const int k = ks * 4 + l4;
+#pragma unroll
+                for (int im = 0; im < FM; ++im) {
+                    const int m = wm + im * 16 + l15;
+                    fa[slot][im] = AKC ? sa[m * SK + k] : sa[k * SA + m];
+                }
+#pragma unroll
+                for (int in = 0; in < FN; ++in) {
+                    const int n = wn + in * 16 + l15;
+                    fb[slot][in] = BKC ? sb[n * SK + k] : sb[k * SB + n];
+                }
+            };
+            ldfrag(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                if (ks + 1 < BK / 4) ldfrag(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int in = 0; in < FN; ++in)
+#pragma unroll
+                    for (int im = 0; im < FM; ++im)
+                        acc[im][in] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ks & 1][in], fa[ks & 1][im], acc[im][in], 0, 0, 0);
+            }
+            if (more && !(g.dbg & 1)) sstore(buf ^ 1);
+            if (!(g.dbg & 2)) __syncthreads();
+            if (!(g.dbg & 1)) buf ^= 1;
+        }
+    }
+
+    // ---- epilogue: C = alpha * acc ---------------------------------------------------------
+#pragma unroll
+    for (int im = 0; im < FM; ++im)
+#pragma unroll
+        for (int in = 0; in < FN; ++in) {
+            const int m = wm + im * 16 + l15;
+            const int nb = wn + in * 16 + l4;
+            double* cp = C + (long)(i0 + m) + (long)(j0 + nb) * ldc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb + 4 * r;
+                if ((!diag || m >= n) && (!(g.dbg & 4) || acc[im][in][r] == 12345.678)) cp[(long)(4 * r) * ldc] = g.alpha * acc[im][in][r];
+            }
+        }
+    // ---- completion signal for the resident diagonal-panel server (cdna guide G16: drain, barrier, ONE release) ----
+    const bool s1 = g.sig_counter && j0 < g.sig_cols, s2 = g.sig2_counter && j0 < g.sig2_cols;
+    if (s1 || s2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (s1) {
+                const unsigned prev = __hip_atomic_fetch_add(g.sig_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (prev + 1 == g.sig_total) __hip_atomic_store(g.sig_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (s2) {
+                const unsigned prev = __hip_atomic_fetch_add(g.sig2_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (prev + 1 == g.sig2_total) __hip_atomic_store(g.sig2_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+}  // namespace gemm_tile_ns

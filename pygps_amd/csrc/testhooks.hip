@@ -172,6 +172,16 @@ int pgp_test_leaf_ticks(pgp_ctx* c, double* ticks_out) {
     return PGP_OK;
 }
 
+// wall-clock stamps (100 MHz) of the resident diagonal-panel server's last sweep (option ds_ticks=1): 16 per panel
+int pgp_test_ds_ticks(pgp_ctx* c, double* ticks_out, int npanel) {
+    if (!c || !ticks_out || !c->ds_ticks) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<long long> h((size_t)npanel * 16);
+    HIP_TRY(hipMemcpy(h.data(), c->ds_ticks, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); ++i) ticks_out[i] = (double)h[i];
+    return PGP_OK;
+}
+
 // device-only timing of the kernel-assembly tile kernel on synthetic resident coordinates:
 // mode 0 = full symmetric (n,n) output ('train'), 2 = fused lower-triangle B = K/sn2 + I.  ms_out = avg per launch.
 int pgp_test_assemble(pgp_ctx* c, int kind, int mode, int64_t n, int64_t d, int iters, double* ms_out) {

@@ -78,7 +78,7 @@ class DeviceFactor(object):
     ``predict`` uses the handle directly and never materialises it."""
     ndim = 2
     dtype = np.dtype(np.float64)
-    #: bytes of factor buffers (2 n^2 doubles each, with the fused-inverse rows) held by live DeviceFactor objects.
+    #: bytes of factor buffers ((n + 128) n doubles each: factor + rhs rows) held by live DeviceFactor objects.
     #: Models sit in reference cycles (model <-> optimizer), so a dropped model frees its factor only when the cyclic
     #: garbage collector runs; `reserve` forces a collection before the device fills up with unreachable factors.
     live_bytes = 0
@@ -102,7 +102,7 @@ class DeviceFactor(object):
     @staticmethod
     def nbytes_for(n):
         np_ = (int(n) + 127) // 128 * 128
-        return (2 * np_ + 128) * np_ * 8
+        return (np_ + 128) * np_ * 8
 
     @staticmethod
     def reserve(n, device):
