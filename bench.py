@@ -13,12 +13,16 @@ broadcast of (x, y) before and the all-gather of results after the timed region 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (gemm_f64_kernel, the fp64 MFMA
-GEMM behind the Cholesky trailing updates, the triangular inverse and W'W): algorithmic flops of all
-its launches in a fit / their summed duration, measured with HIP events on the library's stream in a
-profiled pass over the same steps.  `cpu_baseline` (N=1 only) times the oracle's reference-faithful
-CPU path (scipy cdist + LAPACK dpotrf + general-LU solve_chol + one derivative matrix per hyper,
-call-for-call what pyGPs does) on this host's cores, on a bounded sample.
+Rank 0 prints ONE JSON line.  The K-step window is timed `--windows` times (each bracketed by barrier +
+synchronize); `value` is K / (median window time), every window is listed.  `roofline` is for the dominant
+kernel (gemm_f64_kernel, the fp64 MFMA GEMM behind the Cholesky trailing updates, the panel solves, the
+fused triangular inverse and E E'): ALGORITHMIC flops of a fit that run in it (N^3: Cholesky N^3/3 +
+inverse N^3/3 + E E' N^3/3) / its launches / their average duration, measured with HIP events on the
+library's own stream in a single-stream profiled pass over the same steps (profiles/README.md says which
+rocprofv3 CSV reproduces it); the executed/algorithmic flop ratio and the aggregate rate of the timed
+(multi-stream) window are reported beside it.  `cpu_baseline` (N=1 only) times the oracle's
+reference-faithful CPU path (scipy cdist + LAPACK dpotrf + general-LU solve_chol + one derivative matrix
+per hyper, call-for-call what pyGPs does) on this host's cores: ONE full fit at the benchmark size.
 """
 import argparse
 import json
@@ -49,8 +53,10 @@ def hyp_for(step, rank, d):
     return np.array([np.log(np.sqrt(d)) + eps, 0.0 - eps]), float(np.log(0.1) + 0.5 * eps)
 
 
-def cpu_baseline(N, d, budget_s=40.0):
-    """Reference-faithful CPU path (oracle) on the host cores.  Returns the cpu_baseline object."""
+def cpu_baseline(N, d, budget_s=150.0):
+    """Reference-faithful CPU path (oracle) on the host cores: ONE full fit at (N, d) unless a half-size fit predicts more
+    than budget_s (then the half-size time is scaled and labelled as such).  Also returns the measured exponent between
+    N/2 and N (SURVEY section 6 measured x5.5 for 4096 -> 8192 on 8 cores, i.e. not a clean N^3)."""
     from oracle import gp_oracle as O
     try:
         from threadpoolctl import threadpool_info
@@ -67,38 +73,158 @@ def cpu_baseline(N, d, budget_s=40.0):
         return time.perf_counter() - t
 
     one(512)                                            # warm the BLAS threads
-    t2k = one(2048)
-    if t2k * 64 <= budget_s:
+    th = one(N // 2)
+    out = {"unit": "fits/s", "cores": int(thr), "kind": "port", "host_cpu_count": os.cpu_count(),
+           "half_size_fit_s": th}
+    if th * 8 <= budget_s:
         t = one(N)
-        sample = "1 full fit at N=%d d=%d (%.1f s), oracle reference-faithful path" % (N, d, t)
-        t_sane = one(N, faithful=False) if t * 0.4 <= budget_s else None
+        out["sample"] = ("1 full fit at N=%d d=%d (%.1f s), oracle reference-faithful path (cdist + dpotrf + LU solve_chol x2 + "
+                         "one derivative matrix per hyper); N=%d took %.1f s" % (N, d, t, N // 2, th))
+        out["exponent_N_half_to_N"] = float(np.log(t / th) / np.log(2.0))
     else:
-        n_s = 4096 if t2k * 8 <= budget_s else 2048
-        ts = one(n_s) if n_s != 2048 else t2k
-        t = ts * (N / n_s) ** 3
-        sample = ("1 fit at N=%d d=%d took %.1f s; scaled by (N/%d)^3 to N=%d (the fit is O(N^3): LU/Cholesky "
-                  "dominated)" % (n_s, d, ts, n_s, N))
-        t_sane = one(n_s, faithful=False) * (N / n_s) ** 3
-    out = {"value": 1.0 / t, "unit": "fits/s", "cores": int(thr), "kind": "port", "sample": sample,
-           "host_cpu_count": os.cpu_count()}
-    if t_sane:
-        out["value_sane_linear_algebra"] = 1.0 / t_sane       # same maths with triangular solves + potri
+        t = th * 8
+        out["sample"] = ("1 fit at N=%d d=%d took %.1f s; scaled by 2^3 to N=%d because the full fit would exceed the %.0f s "
+                         "budget (EXTRAPOLATED, not measured)" % (N // 2, d, th, N, budget_s))
+    out["value"] = 1.0 / t
+    ts = one(N // 2, faithful=False)                    # same maths with triangular solves + potri, half size, scaled
+    out["value_sane_linear_algebra"] = 1.0 / (ts * 8)
+    out["sane_sample"] = "N=%d in %.1f s, scaled by 2^3" % (N // 2, ts)
     return out
+
+
+def _fit_args(lib, _lib, h, kind, hyp, log_sn, m, dm, out):
+    alpha, nlZ, g = out
+    return lib.pgp_exact_fit(h, kind, _lib.ptr(hyp), len(hyp), 0, 0, log_sn, _lib.ptr(m), _lib.ptr(dm), 1, 3,
+                             _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(g), None)
+
+
+def extras(lib, _lib, local, d, roof):
+    """Driver-run figures of the other single-GPU configs, OUTSIDE the timed region, a few seconds in total."""
+    import ctypes
+    # ---- north-star assembly figure: full symmetric K (getCovMatrix 'train'), N=16384, device-resident coordinates,
+    #      algorithmic bytes 8 N^2 + 8 N d (SURVEY 8d S1), HIP-event time over 100 launches: RBF d=16 and SEard d=64
+    ctx = _lib.ctx(local)
+    na = 16384
+    for key, kind, dd in (("assembly_full_N16384", _lib.COV_RBF, 16), ("assembly_full_N16384_SEard_d64", _lib.COV_RBFARD, 64)):
+        ms_a = ctypes.c_double()
+        if lib.pgp_test_assemble(ctx, kind, 0, na, dd, 100, ctypes.byref(ms_a)) == 0 and ms_a.value > 0:
+            ba = 8.0 * na * na + 8.0 * na * dd
+            roof[key] = {"ms": ms_a.value, "GBs": ba / ms_a.value / 1e6, "bound": "hbm",
+                         "frac_of_hbm_peak": ba / ms_a.value / 1e6 / PEAK_HBM_GBS}
+            if dd == 64:        # VALU-bound at d=64: 3 d + 25 fp64 operations per output (SURVEY 8d) against the fp64 vector peak
+                fl = (3.0 * dd + 25.0) * na * na
+                roof[key].update({"bound": "fp64-valu", "valu_TFLOPs": fl / ms_a.value / 1e9,
+                                  "frac_of_fp64_vector_peak": fl / ms_a.value / 1e9 / PEAK_FP64_MFMA_TF})
+    out = {}
+    # ---- cfg 3 (GPR + SEard, N=16384 d=64, nlZ + 67 gradients) and the N=16384 RBF Cholesky figure ----------------
+    for key, kind, dd in (("cholesky_sweep_N16384", _lib.COV_RBF, d), ("cfg3_seard_N16384_d64", _lib.COV_RBFARD, 64)):
+        hb = ctypes.c_void_p()
+        nb_ = 16384
+        if lib.pgp_init(local, ctypes.byref(hb)) != 0:
+            continue
+        try:
+            xb, yb = synth_reg(nb_, dd)
+            ybv = np.ascontiguousarray(yb).ravel()
+            mb, dmb = np.full(nb_, ybv.mean()), np.ones((1, nb_))
+            nh = 2 if kind == _lib.COV_RBF else dd + 1
+            bufs = (np.empty(nb_), np.zeros(1), np.zeros(nh + 2))
+            if lib.pgp_set_data(hb, _lib.ptr(np.ascontiguousarray(xb)), nb_, dd, _lib.ptr(ybv)) != 0:
+                continue
+            tb = []
+            for it in range(3):
+                eps = 1e-3 * it
+                hyp_b = (np.array([np.log(np.sqrt(dd)) + eps, -eps]) if kind == _lib.COV_RBF
+                         else np.concatenate([np.full(dd, np.log(np.sqrt(dd)) + eps), [-eps]]))
+                if _fit_args(lib, _lib, hb, kind, hyp_b, float(np.log(0.1)), mb, dmb, bufs) != 0:
+                    break
+                st_b = np.zeros(len(_lib.STAGES))
+                lib.pgp_last_timings(hb, _lib.ptr(st_b))
+                tb.append(dict(zip(_lib.STAGES, st_b.tolist())))
+            if len(tb) == 3:
+                pm = min(t["potrf"] for t in tb[1:])
+                ft = min(t["total"] for t in tb[1:])
+                rec = {"ms": pm, "TFLOPs": (2.0 * nb_ ** 3 / 3.0) / (pm * 1e-3) / 1e12, "bound": "mfma",
+                       "frac_of_peak": (2.0 * nb_ ** 3 / 3.0) / (pm * 1e-3) / 1e12 / PEAK_FP64_MFMA_TF,
+                       "fit_ms": ft, "fit_TFLOPs": float(nb_) ** 3 / (ft * 1e-3) / 1e12,
+                       "stage_ms": tb[-1]}
+                if kind == _lib.COV_RBF:
+                    roof[key] = rec
+                else:
+                    rec = {"fit_ms": ft, "fit_TFLOPs": rec["fit_TFLOPs"], "fits_per_s": 1e3 / ft, "n_gradients": dd + 3,
+                           "cholesky_sweep_ms": pm, "cholesky_sweep_frac_of_peak": rec["frac_of_peak"],
+                           "assembly_fused_ms": tb[-1]["assemble"], "hadamard_reduce_ms": tb[-1]["grad"],
+                           "EEt_ms": tb[-1]["lauum"], "stage_ms": tb[-1],
+                           "workload": "BASELINE configs[2]: GPR + SEard, N=16384 d=64 fp64 synthetic, infExact nlZ + all hyper-gradients"}
+                    out[key] = rec
+        finally:
+            lib.pgp_destroy(hb)
+    # ---- cfg 5 (GPC + RBF, infEP, N=4096 d=32) through the drop-in API ------------------------------------------------
+    try:
+        import pygps_amd as pyGPs
+        n5, d5 = 4096, 32
+        rng = np.random.RandomState(0)
+        x5 = rng.randn(n5, d5); w5 = rng.randn(d5, 1)
+        y5 = np.sign(x5 @ w5 / np.sqrt(d5) + 0.3 * rng.randn(n5, 1)); y5[y5 == 0] = 1
+        ts, sw = [], 0
+        for it in range(2):
+            m5 = pyGPs.GPC()
+            m5.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(d5)), 0.0))
+            t = time.perf_counter()
+            nlz5 = m5.getPosterior(x5, y5)[0]
+            ts.append(time.perf_counter() - t)
+            sw = int(m5.inffunc.sweeps)
+        t5 = min(ts)
+        # blocked sweep: per site one column of S (8 N B written) + the <=128 pending factor columns re-read by the 8-site
+        # kernel once per 8 sites (8 N 128 / 8 B), per 128 sites one K=128 fold of Sigma (read + write 16 N^2 B)
+        bytes_sweep = n5 * (8.0 * n5 + 8.0 * n5 * 128 / 8.0) + (n5 / 128.0) * 16.0 * n5 * n5
+        out["cfg5_ep_N4096_d32"] = {
+            "fit_ms": t5 * 1e3, "sweeps": sw, "ms_per_sweep_incl_params": t5 * 1e3 / max(sw, 1), "nlZ": float(nlz5),
+            "algorithmic_bytes_per_sweep_blocked": bytes_sweep,
+            "reference_algorithm_bytes_per_sweep": 16.0 * n5 ** 3,
+            "epComputeParams_flops_per_sweep": 7.0 * n5 ** 3 / 3.0,
+            "workload": "BASELINE configs[4]: GPC + RBF, infEP, N=4096 d=32 (cold start, nlZ + gradients, through model.getPosterior)"}
+    except Exception as e:           # pragma: no cover
+        out["cfg5_ep_N4096_d32"] = {"error": repr(e)}
+    return out
+
+
+def api_rate(N, d, x, y, steps):
+    """fits/s through the drop-in API, the way minimize.run drives it: model.getPosterior() with hyp changing every call
+    (hashes x / y for the residency check, builds postStruct / dnlZStruct, keeps post.L as a device handle)."""
+    import pygps_amd as pyGPs
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+    m.setNoise(np.log(0.1))
+    m.setData(x, y)
+    for s in range(2):
+        m.getPosterior()
+    t = time.perf_counter()
+    for s in range(steps):
+        hyp, log_sn = hyp_for(s, 0, d)
+        m.covfunc.hyp = [float(hyp[0]), float(hyp[1])]
+        m.likfunc.hyp = [log_sn]
+        m.getPosterior()
+    dt = time.perf_counter() - t
+    return {"fits_per_s": steps / dt, "ms_per_fit": dt / steps * 1e3, "steps": steps,
+            "what": "loop of model.getPosterior() (nlZ, dnlZ, post with device-resident L), one fit stream"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--windows", type=int, default=5, help="the K-step window is timed this many times; value = K / median")
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--d", type=int, default=16)
-    ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--prof-steps", type=int, default=6)
     ap.add_argument("--streams", type=int, default=2,
                     help="independent fit streams per GPU (one pgp_ctx + one host thread each); the K timed steps are "
                          "split over them.  2 overlaps one fit's latency-bound panel phases with the other's GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the N=16384 assembly / Cholesky figures (used by the PMC passes)")
+    ap.add_argument("--cpu-budget", type=float, default=150.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip cfg 3 / cfg 5 / N=16384 figures (used by the rocprof passes)")
+    ap.add_argument("--option", action="append", default=[], help="library option name=value (experiments)")
     args = ap.parse_args()
 
     import torch
@@ -113,14 +239,23 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     cdev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # The process group is created at EVERY world size, 1 included: the RCCL broadcast / all-reduce / all-gather below
+    # are then the same code on one GPU as on eight.
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    rccl_note = None
+    try:
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))    # RCCL over xGMI
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))              # RCCL (over xGMI for N > 1)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    except Exception as e:
+        if world > 1:
+            raise
+        rccl_note = "process group not available at world size 1: %r" % (e,)
+        dist = None
     assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
 
     from pygps_amd import _lib
@@ -154,6 +289,9 @@ def main():
         ctxs.append(h)
     for h in ctxs:
         _lib.check(lib.pgp_set_data(h, _lib.ptr(x), N, d, _lib.ptr(yv)))
+        for o in args.option:
+            k_, v_ = o.split("=")
+            _lib.check(lib.pgp_set_option(h, k_.encode(), int(v_)), "pgp_set_option")
     bufs = [(np.empty(N), np.zeros(1), np.zeros(4)) for _ in range(S)]
 
     def fit(step, k=0):
@@ -186,111 +324,94 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(0, max(args.warmup, S))
-    fence()
-    t0 = time.perf_counter()
-    vals = run_steps(args.warmup, args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    # single-stream latency of one fit (not the headline: reported alongside)
+    windows = []
+    vals = None
+    for wdw in range(max(1, args.windows)):           # EXACTLY K steps per window, barrier + synchronize on both sides
+        fence()
+        t0 = time.perf_counter()
+        vals = run_steps(args.warmup, args.steps)
+        fence()
+        wt = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([wt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)                                # slowest rank defines the window
+            wt = float(tt.item())
+        windows.append(wt)
+    dt = float(np.median(windows))
+    # single-stream latency of one fit in a dependent chain (what cfg 4's one-restart-per-GPU minimize.run sees)
     t1 = time.perf_counter()
-    for s in range(3):
+    for s in range(6):
         fit(args.warmup + s)
-    lat_ms = (time.perf_counter() - t1) / 3 * 1e3
+    lat_ms = (time.perf_counter() - t1) / 6 * 1e3
     if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
         res = torch.tensor(vals, dtype=torch.float64, device=cdev)
         parts = [torch.empty_like(res) for _ in range(world)]
         dist.all_gather(parts, res)                                              # RCCL gather of results
         vals_all = torch.stack(parts).cpu().numpy()
-        assert np.all(np.isfinite(vals_all))
+        assert np.all(np.isfinite(vals_all)) and vals_all.shape == (world, args.steps)
     stages = _lib.last_timings(local)
 
-    # ---- roofline of the dominant kernel: profiled pass over the same steps (HIP events per launch) ----
+    # ---- roofline of the dominant kernel: single-stream profiled pass over the same steps (HIP events per launch,
+    #      recorded on the library's own stream) -------------------------------------------------------------------
     roof = None
     classes = {}
+    extra = {}
     if rank == 0:
         lib.pgp_profile_reset(ctx)
         lib.pgp_set_profiling(ctx, 1)
+        prof_stage = []
         for s in range(args.prof_steps):
             fit(args.warmup + s)
+            prof_stage.append(_lib.last_timings(local))
         lib.pgp_set_profiling(ctx, 0)
         prof = _lib.profile(local)
+        nfit = float(args.prof_steps)
         gl = gm = gf = 0.0
         for name, v in prof.items():
             if v["launches"]:
-                classes[name] = {"launches_per_fit": v["launches"] / args.prof_steps,
-                                 "ms_per_fit": v["ms"] / args.prof_steps,
-                                 "TFLOPs": v["flops"] / max(v["ms"], 1e-12) / 1e9 if v["flops"] else None,
+                classes[name] = {"launches_per_fit": v["launches"] / nfit, "ms_per_fit": v["ms"] / nfit,
+                                 "us_per_launch": v["ms"] / v["launches"] * 1e3,
+                                 "executed_TFLOPs": v["flops"] / max(v["ms"], 1e-12) / 1e9 if v["flops"] else None,
                                  "GBs": v["bytes"] / max(v["ms"], 1e-12) / 1e6 if v["bytes"] else None}
             if name.startswith("gemm_f64"):
                 gl += v["launches"]; gm += v["ms"]; gf += v["flops"]
-        achieved = gf / max(gm, 1e-12) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "gemm_f64_hbm_traffic.json")
+        alg = float(N) ** 3                                    # algorithmic flops of one fit that run in gemm_f64_kernel
+        achieved = alg * nfit / max(gm, 1e-12) / 1e9
+        potrf_ms = float(np.median([t["potrf"] for t in prof_stage]))
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_gemm_f64_hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic, tsrc = tj.get("bytes_per_launch"), "profiles/r02_gemm_f64_hbm_traffic.json (rocprofv3 --pmc passes of this command line, not re-measured in this run)"
             except Exception:
                 traffic = None
-        roof = {"kernel": "gemm_f64_kernel (fp64 MFMA: Cholesky trailing/inner updates incl. the fused inverse, E E^T)",
-                "bound": "mfma",
-                "achieved": achieved, "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TF,
-                "traffic": traffic, "launches_per_fit": gl / args.prof_steps,
-                "flops_per_launch": gf / max(gl, 1), "avg_launch_ms": gm / max(gl, 1),
-                # the Cholesky sweep also produces L^-T (fused triangular inverse): 2 N^3 / 3 flops in that stage
-                "cholesky_sweep_TFLOPs": (2.0 * N ** 3 / 3.0) / (stages["potrf"] * 1e-3) / 1e12,
-                "cholesky_sweep_frac_of_peak": (2.0 * N ** 3 / 3.0) / (stages["potrf"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TF}
+        roof = {"kernel": "gemm_f64_kernel (fp64 MFMA: Cholesky trailing updates + panel solves incl. the fused inverse, E E^T)",
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP64_MFMA_TF, "traffic": traffic, "traffic_source": tsrc,
+                "how": "N^3 algorithmic flops per fit / summed HIP-event durations of every gemm_f64 launch, %d single-stream fits" % args.prof_steps,
+                "launches_per_fit": gl / nfit, "flops_per_launch": alg * nfit / max(gl, 1), "avg_launch_ms": gm / max(gl, 1),
+                "executed_over_algorithmic_flops": gf / (alg * nfit),
+                "timed_window": {"streams": S, "TFLOPs_end_to_end": alg / (dt / args.steps) / 1e12,
+                                 "frac_of_peak": alg / (dt / args.steps) / 1e12 / PEAK_FP64_MFMA_TF,
+                                 "what": "N^3 x K fits / window time: every kernel and every gap of the timed region included"},
+                # the Cholesky sweep also produces L^-T (fused triangular inverse): 2 N^3 / 3 algorithmic flops in that stage
+                "cholesky_sweep_ms": potrf_ms,
+                "cholesky_sweep_TFLOPs": (2.0 * N ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12,
+                "cholesky_sweep_frac_of_peak": (2.0 * N ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TF}
         asm = prof.get("cov_tile_kernel(assemble)")
         if asm and asm["launches"]:
-            roof["assembly_GBs"] = asm["bytes"] / asm["ms"] / 1e6
-            roof["assembly_frac_of_hbm_peak"] = asm["bytes"] / asm["ms"] / 1e6 / PEAK_HBM_GBS
-        # the north-star assembly figure: full symmetric K (getCovMatrix 'train'), RBF, N=16384 d=16, device-resident
-        # (both N=16384 extras are skipped with --no-extras)
-        # coordinates, algorithmic bytes 8 N^2 + 8 N d, HIP-event time over 100 launches
-        try:
-            if args.no_extras:
-                raise RuntimeError("skipped")
-            ms_a = ctypes.c_double()
-            na = 16384
-            if lib.pgp_test_assemble(ctx, _lib.COV_RBF, 0, na, 16, 100, ctypes.byref(ms_a)) == 0 and ms_a.value > 0:
-                ba = 8.0 * na * na + 8.0 * na * 16
-                roof["assembly_full_N16384"] = {"ms": ms_a.value, "GBs": ba / ms_a.value / 1e6, "bound": "hbm",
-                                                "frac_of_hbm_peak": ba / ms_a.value / 1e6 / PEAK_HBM_GBS}
-        except Exception:
-            pass
-        # the north-star Cholesky figure at N=16384: one extra context, RBF d=16, the factorisation stage of a full fit
-        # (with the fused triangular inverse riding along: 2 N^3 / 3 flops in that stage), HIP-event stage time
-        try:
-            if args.no_extras:
-                raise RuntimeError("skipped")
-            hb = ctypes.c_void_p()
-            nb_ = 16384
-            if lib.pgp_init(local, ctypes.byref(hb)) == 0:
-                xb, yb = synth_reg(nb_, d)
-                ybv = np.ascontiguousarray(yb).ravel()
-                mb, dmb = np.full(nb_, ybv.mean()), np.ones((1, nb_))
-                ab, nzb, gb = np.empty(nb_), np.zeros(1), np.zeros(4)
-                if lib.pgp_set_data(hb, _lib.ptr(np.ascontiguousarray(xb)), nb_, d, _lib.ptr(ybv)) == 0:
-                    tb = []
-                    for it in range(3):
-                        hyp_b, lsn_b = hyp_for(it, 0, d)
-                        if lib.pgp_exact_fit(hb, _lib.COV_RBF, _lib.ptr(hyp_b), 2, 0, 0, lsn_b, _lib.ptr(mb), _lib.ptr(dmb), 1, 3,
-                                             _lib.ptr(ab), _lib.ptr(nzb), _lib.ptr(gb), None) != 0:
-                            break
-                        st_b = np.zeros(len(_lib.STAGES))
-                        lib.pgp_last_timings(hb, _lib.ptr(st_b))
-                        tb.append(dict(zip(_lib.STAGES, st_b.tolist())))
-                    if len(tb) == 3:
-                        pm = tb[-1]["potrf"]
-                        roof["cholesky_sweep_N16384"] = {
-                            "ms": pm, "TFLOPs": (2.0 * nb_ ** 3 / 3.0) / (pm * 1e-3) / 1e12, "bound": "mfma",
-                            "frac_of_peak": (2.0 * nb_ ** 3 / 3.0) / (pm * 1e-3) / 1e12 / PEAK_FP64_MFMA_TF,
-                            "fit_ms": tb[-1]["total"], "fit_TFLOPs": float(nb_) ** 3 / (tb[-1]["total"] * 1e-3) / 1e12}
-                lib.pgp_destroy(hb)
-        except Exception:
-            pass
+            roof["assembly_fused_GBs"] = asm["bytes"] / asm["ms"] / 1e6
+            roof["assembly_fused_frac_of_hbm_peak"] = asm["bytes"] / asm["ms"] / 1e6 / PEAK_HBM_GBS
+        if not args.no_extras:
+            try:
+                extra = extras(lib, _lib, local, d, roof)
+            except Exception as e:         # pragma: no cover
+                extra = {"error": repr(e)}
+            try:
+                extra["api"] = api_rate(N, d, x, y, 20)
+            except Exception as e:         # pragma: no cover
+                extra["api"] = {"error": repr(e)}
 
     if rank == 0:
         total_fits = world * args.steps
@@ -304,16 +425,24 @@ def main():
                                    "nlZ, dnlZ(4), alpha(N) to host per step" % (N, d),
                        "fits_per_rank": args.steps, "fit_streams_per_gpu": S,
                        "parallelism": "independent fits (restart evaluations) per GPU, %d concurrent fit streams per "
-                                      "GPU; RCCL broadcast+gather only" % S},
-            "single_stream_ms_per_fit": lat_ms,
+                                      "GPU; RCCL broadcast + all-reduce(max) + all-gather only%s"
+                                      % (S, "" if dist else " (no process group at world size 1)")},
+            "timed_windows_s": windows, "window_spread": (max(windows) - min(windows)) / dt,
+            "single_stream_ms_per_fit": lat_ms, "single_stream_fits_per_s": 1e3 / lat_ms,
             "stage_ms_last_fit": stages,
             "flops_per_fit": float(N) ** 3,
             "fit_TFLOPs": float(N) ** 3 / (dt / args.steps) / 1e12,
             "roofline": roof, "kernel_classes": classes,
             "device": _lib.device_info(local),
         }
+        if rccl_note:
+            out["rccl_note"] = rccl_note
+        out.update({k: v for k, v in extra.items() if k != "api"})
+        if "api" in extra:
+            out["api_fits_per_s"] = extra["api"].get("fits_per_s")
+            out["api"] = extra["api"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, d)
+            out["cpu_baseline"] = cpu_baseline(N, d, args.cpu_budget)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist:

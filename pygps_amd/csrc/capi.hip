@@ -74,7 +74,6 @@ int pgp_init(int device, pgp_ctx** ctx_out) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         HIP_TRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, hi));   // panel chain = critical path
-        HIP_TRY(hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, hi));   // panel solves (sweep v2 with the server)
     }
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     memset(c->last_ms, 0, sizeof(c->last_ms));
@@ -741,6 +740,11 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         // main  : TU(p) as ONE launch -- the next panel's columns first (into staging buffer (p+1)&1; the next panel's
         //         diagonal block is the server's and skipped), then the rest in place; the tile that completes the first two
         //         column panels releases go[p+2] from inside the kernel
+        if (!c->st3) {        // created on first use only: every extra stream shifts the hardware-queue placement of the others
+            int lo = 0, hi = 0;   // (two fit contexts per GPU: 91.7 fits/s with two streams each, 80.3 with a third one idle)
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_TRY(hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, hi));
+        }
         hipStream_t side = c->st3;
         while ((int)c->la_ev.size() < npanel + 2) {
             hipEvent_t e;

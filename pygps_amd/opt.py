@@ -216,7 +216,9 @@ class ShardedMinimize(Minimize):
             for t in range(1, R):
                 for i in range(nh):
                     table[t, i] = np.random.uniform(low=ranges[i][0], high=ranges[i][1])
-        if dist and world > 1:
+        # the collectives run whenever a process group exists, world size 1 included: the RCCL path of a one-GPU job is
+        # then the same code that runs on eight (and is exercised by the one-GPU test tier)
+        if dist:
             tt = torch.from_numpy(table).to(dev)
             dist.broadcast(tt, src=0, group=self.group)                  # RCCL broadcast #1: init table
             table = tt.cpu().numpy()
@@ -225,6 +227,7 @@ class ShardedMinimize(Minimize):
             dist.broadcast(xt, src=0, group=self.group)                  # RCCL broadcast #2: X, y (~1 MB)
             dist.broadcast(yt, src=0, group=self.group)
             self.model.x, self.model.y = xt.cpu().numpy(), yt.cpu().numpy()
+        self.init_table = table.copy()                                   # per-restart initial points (row 0 = current hyps)
         # local share
         rec = np.zeros((R, nh + 3))
         rec[:, 0] = np.inf
@@ -236,7 +239,7 @@ class ShardedMinimize(Minimize):
                 rec[t, 1:1 + nh] = r.hyp
                 rec[t, nh + 1] = r.nls
                 rec[t, nh + 2] = 0.0
-        if dist and world > 1:
+        if dist:
             mt = torch.from_numpy(rec).to(dev)
             # each restart is owned by exactly one rank and the others hold (inf, 0.., failed):
             # gather all shares, then pick the owner's row

@@ -165,6 +165,32 @@ def test_exact_fit_golden_G6_cfg2_scale(lib):
         assert relerr(got["dnlZ"], np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7
 
 
+@pytest.mark.parametrize("opts", [dict(dserver=1), dict(dserver=1, ds_exclusive=0), dict(potrf_v1=1), dict(lookahead=0)])
+def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
+    """Every schedule of the Cholesky sweep -- the default diagonal-panel chain, the resident diagonal-panel server
+    (left-looking, in-kernel go signals), the round-1 leaf chain and the serial order -- against the reference's own
+    numbers (G6: Core/inf.py:353-384 at N=2048 and at the benchmark size N=8192)."""
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    try:
+        for k, v in opts.items():
+            _lib.check(lib.pgp_set_option(ctx, k.encode(), v))
+        for N in (2048, 8192):
+            g = golden("G6_rbf_d16_N%d" % N)
+            x, y = synth_reg(N, 16)
+            for rep in range(2):
+                got = _fit(lib, 0, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, g["mean_hyp"][0] * np.ones(N), np.ones((1, N)),
+                           factor=rep == 0)
+                assert relerr(got["nlZ"], g["nlZ"]) < 1e-9
+                assert relerr(got["alpha"][g["alpha_idx"], 0], g["alpha_sample"]) < 1e-7
+                assert relerr(got["dnlZ"], np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7
+                if rep == 0:
+                    assert relerr(got["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-8
+    finally:
+        for k in opts:
+            lib.pgp_set_option(ctx, k.encode(), 1 if k in ("lookahead", "ds_exclusive") else 0)
+
+
 def test_exact_fit_golden_G7_ard_d64(lib):
     g = golden("G7_rbfard_d64_N1024")
     x, y = synth_reg(1024, 64)

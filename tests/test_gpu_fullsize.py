@@ -83,6 +83,29 @@ def test_cfg3_scale_golden_N4096_if_recorded(lib):
     assert relerr(np.diag(post.L), g["L_diag"]) < 1e-9
 
 
+@pytest.mark.parametrize("N", [2048, 4096])
+def test_cfg5_ep_reference_fixture_at_stated_size(lib, N):
+    """BASELINE configs[4] (GPC + RBF, infEP, d=32) against fixtures recorded from the reference itself at N=2048 and at
+    the stated N=4096 (tests/golden/make_golden.py g8ii_N; Core/inf.py:731-806: 4 sweeps each, 43 min of reference run
+    time at N=4096).  The blocked 8-site sweep changes the summation order exactly where N is large, so this is the
+    parity evidence for it: north-star tolerances nlZ 1e-8, alpha / sW / L 1e-6, and the sweep count must be identical."""
+    import pygps_amd as pyGPs
+    g = golden("G8ii_ep_d32_N%d" % N)
+    x, y = synth_cls(N, 32)
+    m = pyGPs.GPC()
+    m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(32.0)), 0.0))
+    nlZ, dnlZ, post = m.getPosterior(x, y)
+    assert m.inffunc.sweeps == int(g["n_sweeps"])
+    assert relerr(nlZ, g["nlZ"]) < 1e-8
+    assert relerr(dnlZ.cov, g["dnlZ_cov"]) < 1e-6
+    assert relerr(post.alpha, g["alpha"]) < 1e-6 and relerr(post.sW, g["sW"]) < 1e-6
+    assert relerr(m.inffunc.last_ttau, g["ttau"]) < 1e-6 and relerr(m.inffunc.last_tnu, g["tnu"]) < 1e-6
+    L = np.asarray(post.L)
+    assert relerr(np.diag(L), g["L_diag"]) < 1e-6
+    assert relerr(L.ravel()[::int(g["L_stride"])], g["L_sample"]) < 1e-6
+    assert np.all(np.tril(L[:400, :400], -1) == 0)
+
+
 def test_cfg5_ep_N4096_d32_properties(lib):
     import pygps_amd as pyGPs
     N, d = 4096, 32
