@@ -1,22 +1,21 @@
 #!/bin/bash
-# Regenerate profiles/r01_* on the GPU box:  gpurun -- 'bash tools/make_profiles.sh'
+# Regenerate profiles/r02_* on the GPU box:  gpurun -- 'bash tools/make_profiles.sh'
 # (kernel-trace stats and PMC counters in SEPARATE rocprofv3 runs; PMC runs use --kernel-trace only)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/prof_r01
+O=$R/gpurun_out/prof_r02
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-# 1. the bench line itself (with cpu_baseline)
+# 1. the bench line itself (with cpu_baseline, extras)
 timeout 900 python $R/bench.py > $O/bench.json 2> $O/bench.err
-# 2. kernel-trace stats of the same command (no cpu baseline: host time only)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> $O/stats.err
-# 3. PMC traffic of gemm_f64 (separate passes)
+# 2a. kernel-trace stats of the SINGLE-STREAM command: this is the run whose per-kernel averages reproduce roofline.frac
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python $R/bench.py --streams 1 --no-cpu-baseline --no-extras > $O/bench_streams1_under_rocprof.json 2> $O/stats1.err
+# 2b. the same for the timed (two fit streams) configuration: kernel time sums overlap there
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python $R/bench.py --no-cpu-baseline --no-extras > $O/bench_streams2_under_rocprof.json 2> $O/stats2.err
+# 3. PMC traffic of gemm_f64 (separate passes, single stream)
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -- python $R/bench.py --steps 3 --streams 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_$d.err
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -- python $R/bench.py --steps 3 --windows 1 --prof-steps 1 --streams 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_$d.err
 done
-# 4. assembly kernel counters at N=16384
-for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "WRITE_SIZE" "FETCH_SIZE"; do
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/asm/$(echo $set | cut -c1-14 | tr " " _) -- python $R/tools/asm_only.py > $O/asm_only.out 2>> $O/asm.err
-done
-ls -R $O | head -50
+python $R/tools/pmc_traffic.py $O/pmc $O/r02_gemm_f64_hbm_traffic.json > /dev/null 2>> $O/pmc.err
+find $O -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head

@@ -31,7 +31,7 @@ if __name__ == "__main__":
     json.dump({"kernel": "gemm_f64_kernel", "launches_sampled": nf,
                "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
                "bytes_per_launch": fetch_b + write_b,
-               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python bench.py --steps 3 --streams 1 "
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python bench.py --steps 3 --windows 1 --prof-steps 1 --streams 1 "
                        "--warmup 1 --no-cpu-baseline`, all gemm_f64_kernel dispatches averaged; FETCH_SIZE x2 "
                        "(gfx950 wide-load correction, MI355X_MICROARCH.md HBM section), KiB -> bytes"},
               open(out, "w"), indent=1)
