@@ -12,7 +12,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpygps_amd.so")
+# PYGPS_AMD_LIB: another build of the same library (the host-side AddressSanitizer build, csrc/Makefile target `asan`)
+LIB_PATH = os.environ.get("PYGPS_AMD_LIB") or os.path.join(_HERE, "libpygps_amd.so")
 
 COV_RBF, COV_RBFARD, COV_MATERN, COV_RBFUNIT, COV_RQ, COV_PIECEPOLY = 0, 1, 2, 3, 4, 5
 COV_RQARD, COV_GABOR, COV_PERIODIC, COV_NOISE, COV_CONST = 6, 7, 8, 9, 10

@@ -20,6 +20,9 @@ void pgp_set_last_hip_error(hipError_t e, const char* what, const char* file, in
     (void)hipGetLastError();      // clear the runtime's sticky "last error": the launch wrappers test hipGetLastError()
 }
 
+static void ctx_register(pgp_ctx* c);
+static void ctx_unregister(pgp_ctx* c);
+
 void prof_collect(pgp_ctx* c) {
     if (c->recs.empty()) return;
     (void)hipStreamSynchronize(c->st);
@@ -89,12 +92,14 @@ int pgp_init(int device, pgp_ctx** ctx_out) {
     HIP_TRY(hipMemset(c->dflags, 0, diag_server_flag_bytes()));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_ds, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_ds2, hipEventDisableTiming));
+    ctx_register(c);
     *ctx_out = c;
     return PGP_OK;
 }
 
 void pgp_destroy(pgp_ctx* c) {
     if (!c) return;
+    ctx_unregister(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
@@ -951,14 +956,36 @@ int ensure_workspace(pgp_ctx* c, long np) {
 
 int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F) {
     const size_t bytes = (size_t)ldf * np * sizeof(double);
-    {
-        std::lock_guard<std::mutex> lk(c->pool_mu);
-        auto it = c->pool.find(bytes);
-        if (it != c->pool.end()) { *F = (double*)it->second; c->pool.erase(it); c->pool_bytes -= bytes; return PGP_OK; }
-    }
-    HIP_TRY(hipMalloc((void**)F, bytes));
-    HIP_TRY(hipMemsetAsync(*F, 0, bytes, c->st));     // strict-upper tiles and augmented rows stay 0 forever
+    bool fresh = false;
+    CHK(pool_alloc(c, bytes, (void**)F, &fresh));
+    if (fresh) HIP_TRY(hipMemsetAsync(*F, 0, bytes, c->st));     // strict-upper tiles and augmented rows stay 0 forever
     return PGP_OK;
+}
+
+// ---- registry of live contexts (per-device idle caps, cross-context eviction on out-of-memory) ------------------
+static std::mutex g_ctx_mu;
+static std::vector<pgp_ctx*> g_ctxs;
+int pgp_ctx_count_on_device(int device) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    int n = 0;
+    for (pgp_ctx* c : g_ctxs) n += c->device == device;
+    return n;
+}
+void pgp_drop_idle_pools(int device) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (pgp_ctx* c : g_ctxs) {
+        if (c->device != device) continue;
+        std::lock_guard<std::mutex> lp(c->pool_mu);
+        for (auto& kv : c->pool) (void)hipFree(kv.second);
+        for (auto& kv : c->spool) (void)hipFree(kv.second);
+        c->pool.clear(); c->pool_bytes = 0;
+        c->spool.clear(); c->spool_bytes = 0;
+    }
+}
+static void ctx_register(pgp_ctx* c) { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.push_back(c); }
+static void ctx_unregister(pgp_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end());
 }
 
 extern "C" {

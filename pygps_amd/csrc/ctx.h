@@ -1,5 +1,6 @@
 // Internal: context / factor structs shared by the host-side drivers (capi.hip, predict.hip, ep.hip).
 #pragma once
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -99,28 +100,42 @@ struct pgp_ctx {
         if (rc__ != PGP_OK) return rc__; \
     } while (0)
 
-static inline int pool_alloc(pgp_ctx* c, size_t bytes, void** out) {
-    std::lock_guard<std::mutex> lk(c->pool_mu);
-    auto it = c->pool.find(bytes);
-    if (it != c->pool.end()) {
-        *out = it->second;
-        c->pool.erase(it);
-        c->pool_bytes -= bytes;
-        return PGP_OK;
+// Every live context, so that an out-of-memory allocation can drop the idle pools of ALL contexts on the device (two fit
+// streams per GPU = two contexts, each with its own pools) and so that the idle caps are per device, not per context.
+int pgp_ctx_count_on_device(int device);
+void pgp_drop_idle_pools(int device);
+
+static inline size_t pool_idle_cap(pgp_ctx* c) {
+    return (size_t)c->prop.totalGlobalMem / 3 / (size_t)std::max(1, pgp_ctx_count_on_device(c->device));
+}
+
+// factor buffers: strict-upper tiles and spare rhs rows are zero by contract; *fresh = true when the caller must zero it
+static inline int pool_alloc(pgp_ctx* c, size_t bytes, void** out, bool* fresh = nullptr) {
+    if (fresh) *fresh = false;
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mu);
+        auto it = c->pool.find(bytes);
+        if (it != c->pool.end()) {
+            *out = it->second;
+            c->pool.erase(it);
+            c->pool_bytes -= bytes;
+            return PGP_OK;
+        }
     }
-    if (hipMalloc(out, bytes) != hipSuccess) {           // out of memory: drop the idle pool and retry once
+    if (fresh) *fresh = true;
+    if (hipMalloc(out, bytes) != hipSuccess) {           // out of memory: drop every idle pool on this device, retry once
         (void)hipGetLastError();
-        for (auto& kv : c->pool) (void)hipFree(kv.second);
-        c->pool.clear(); c->pool_bytes = 0;
+        pgp_drop_idle_pools(c->device);
         HIP_TRY(hipMalloc(out, bytes));
     }
     return PGP_OK;
 }
-// idle buffers are kept for the next call with the same shape, up to a third of the device memory
+// idle buffers are kept for the next call with the same shape, up to a third of the device memory over all contexts
 static inline void pool_free(pgp_ctx* c, size_t bytes, void* p) {
     if (!p) return;
+    const size_t cap = pool_idle_cap(c);
     std::lock_guard<std::mutex> lk(c->pool_mu);
-    if (c->pool_bytes + bytes > (size_t)c->prop.totalGlobalMem / 3) { (void)hipFree(p); return; }
+    if (c->pool_bytes + bytes > cap) { (void)hipFree(p); return; }
     c->pool.insert({bytes, p});
     c->pool_bytes += bytes;
 }
@@ -169,9 +184,10 @@ struct PoolScratch {
     std::vector<std::pair<size_t, void*>> held;
     explicit PoolScratch(pgp_ctx* c_) : c(c_) {}
     ~PoolScratch() {
+        const size_t cap = pool_idle_cap(c);
         std::lock_guard<std::mutex> lk(c->pool_mu);
         for (auto& h : held) {
-            if (c->spool_bytes + h.first > (size_t)c->prop.totalGlobalMem / 3) { (void)hipFree(h.second); continue; }
+            if (c->spool_bytes + h.first > cap) { (void)hipFree(h.second); continue; }
             c->spool.insert({h.first, h.second});
             c->spool_bytes += h.first;
         }
@@ -180,14 +196,14 @@ struct PoolScratch {
     int alloc(T** out, size_t bytes) {
         void* p = nullptr;
         if (!bytes) bytes = 8;
-        std::lock_guard<std::mutex> lk(c->pool_mu);
-        auto it = c->spool.find(bytes);
-        if (it != c->spool.end()) {
-            p = it->second; c->spool.erase(it); c->spool_bytes -= bytes;
-        } else if (hipMalloc(&p, bytes) != hipSuccess) {      // out of memory: drop the idle scratch and retry once
+        {
+            std::lock_guard<std::mutex> lk(c->pool_mu);
+            auto it = c->spool.find(bytes);
+            if (it != c->spool.end()) { p = it->second; c->spool.erase(it); c->spool_bytes -= bytes; }
+        }
+        if (!p && hipMalloc(&p, bytes) != hipSuccess) {       // out of memory: drop every idle pool on this device, retry once
             (void)hipGetLastError();
-            for (auto& kv : c->spool) (void)hipFree(kv.second);
-            c->spool.clear(); c->spool_bytes = 0;
+            pgp_drop_idle_pools(c->device);
             hipError_t e = hipMalloc(&p, bytes);
             if (e != hipSuccess) { pgp_set_last_hip_error(e, "hipMalloc(pool scratch)", __FILE__, __LINE__); return PGP_ERR_HIP; }
         }

@@ -414,3 +414,14 @@ def test_device_out_of_memory_raises_and_the_context_recovers(lib):
     nlZ, dnlZ, post = pyGPs.GPR().getPosterior(x, y)
     out = O.exact_fit(O.RBF, np.array([0.0, 0.0]), 0, np.log(0.1), x, y, np.zeros_like(y), None, faithful=False)
     assert relerr(nlZ, out["nlZ"]) < 1e-10
+    # same padded size before and after the failure: the workspace of the last good size must not be taken for valid
+    # (the failed fit freed it), and EP shares the same context state
+    with pytest.raises(RuntimeError, match="out of memory"):
+        pyGPs.GPR().getPosterior(rng.randn(n, 2), rng.randn(n, 1))
+    nlZ2, _, _ = pyGPs.GPR().getPosterior(x, y)
+    assert nlZ2 == nlZ
+    xc, yc = synth_cls(300, 3)
+    with pytest.raises(RuntimeError, match="out of memory"):
+        pyGPs.GPC().getPosterior(rng.randn(n, 2), np.sign(rng.randn(n, 1)))
+    assert np.isfinite(pyGPs.GPC().getPosterior(xc, yc)[0])
+    assert pyGPs.GPR().getPosterior(x, y)[0] == nlZ
