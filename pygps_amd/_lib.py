@@ -155,6 +155,27 @@ class fit_stream(object):
         return False
 
 
+_torch_checked = False
+
+
+def _torch_first():
+    """PyTorch's ROCm wheels bundle their own copy of the HIP / HSA runtime.  Measured on the round-2 GPU boxes: when THIS
+    library (linked against /opt/rocm) brings its runtime up first, a later torch.cuda initialisation in the same process
+    fails with "No HIP GPUs are available"; the other order works.  ShardedMinimize and bench.py use torch.distributed
+    (RCCL) beside the library, so the first context creation lets torch initialise first when torch is installed
+    (PYGPS_AMD_NO_TORCH=1 skips this; torch is never needed for a fit)."""
+    global _torch_checked
+    if _torch_checked or os.environ.get("PYGPS_AMD_NO_TORCH"):
+        return
+    _torch_checked = True
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def ctx(device=None, slot=None):
     """Context (one device + its HIP streams + one workspace pool) of (device, fit-stream slot); created on first use."""
     if device is None:
@@ -165,6 +186,7 @@ def ctx(device=None, slot=None):
     if h is not None:
         return h
     dll = load()
+    _torch_first()
     with _lock:
         h = _ctx.get((device, slot))
         if h is None:

@@ -315,24 +315,24 @@ class Const(_DeviceKernel):
 # ---- composites (Core/cov.py:230-328) ---------------------------------------------------------------------
 # A tree whose leaves all have isotropic device functors is evaluated in ONE pass of the tile kernel as a device
 # program (sum of products of leaf functors, csrc/sqdist_tile.h CovProgram) -- in getCovMatrix/getDerMatrix and,
-# more importantly, inside Exact/EP fits and predict.  One leaf may be an ARD kernel (RBFard / RQard, D <= 64): it gets its
-# own weighted distance, accumulated beside the shared one.  Trees with two ARD leaves (or more than 8 leaves / products)
-# still offer getCovMatrix/getDerMatrix by combining the children's device-built matrices.
+# more importantly, inside Exact/EP fits and predict.  Up to TWO leaves may be ARD kernels (RBFard / RQard, D <= 64): each
+# gets its own weighted distance, accumulated beside the shared one.  Trees with three ARD leaves (or more than 8 leaves /
+# products) still offer getCovMatrix/getDerMatrix by combining the children's device-built matrices.
 class _Composite(Kernel):
     _kind = _lib.COV_COMPOSITE
 
     def _tokens(self):
         pr = self._program(0)
-        if pr is None or pr[1] > _lib.PROG_MAX or pr[2] > _lib.PROG_MAX or pr[3] % 1000 > _lib.PROG_MAX or pr[3] >= 2000:
-            return None                                   # too many leaves / products / Scale nodes, or more than one ARD leaf
+        if pr is None or pr[1] > _lib.PROG_MAX or pr[2] > _lib.PROG_MAX or pr[3] % 1000 > _lib.PROG_MAX or pr[3] >= 3000:
+            return None                                   # too many leaves / products / Scale nodes, or more than two ARD leaves
         return pr[0]
 
     def _bind(self, ctx):
         tok = self._tokens()
         if tok is None:
             raise NotImplementedError(
-                "pygps_amd: this composite kernel cannot run as a device program (ARD leaf, unsupported leaf, or more "
-                "than %d leaves/products); there is no CPU fallback" % _lib.PROG_MAX)
+                "pygps_amd: this composite kernel cannot run as a device program (more than two ARD leaves, an unsupported "
+                "leaf, or more than %d leaves/products); there is no CPU fallback" % _lib.PROG_MAX)
         arr = (_lib.C.c_int32 * len(tok))(*tok)
         _lib.check(_lib.load().pgp_set_composite(ctx, arr, len(tok)), "pgp_set_composite")
         return _lib.COV_COMPOSITE, 0, 0

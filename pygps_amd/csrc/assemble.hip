@@ -91,8 +91,12 @@ __device__ __forceinline__ void tile_values_sel(const CovParams& cp, const doubl
 
 __device__ __forceinline__ const double* prog_ardw(const CovProgram& P) { return P.ardw; }
 __device__ __forceinline__ const double* prog_ardw(const CovParams&) { return nullptr; }
-__device__ __forceinline__ double prog_elem(const CovProgram& P, double s, double dk2, bool same, double s1) { return cov_elem(P, s, dk2, same, s1); }
-__device__ __forceinline__ double prog_elem(const CovParams& p, double s, double dk2, bool same, double) { return cov_elem(p, s, dk2, same); }
+__device__ __forceinline__ const double* prog_ardw2(const CovProgram& P) { return P.ardw2; }
+__device__ __forceinline__ const double* prog_ardw2(const CovParams&) { return nullptr; }
+__device__ __forceinline__ const double* prog_der_w(const CovProgram& P) { return cov_ard_der_w(P); }
+__device__ __forceinline__ const double* prog_der_w(const CovParams&) { return nullptr; }
+__device__ __forceinline__ double prog_elem(const CovProgram& P, double s, double dk2, bool same, double s1, double s2) { return cov_elem(P, s, dk2, same, s1, s2); }
+__device__ __forceinline__ double prog_elem(const CovParams& p, double s, double dk2, bool same, double, double) { return cov_elem(p, s, dk2, same); }
 
 template <class COV> struct is_program { static constexpr bool value = false; };
 template <> struct is_program<CovProgram> { static constexpr bool value = true; };
@@ -150,6 +154,36 @@ __device__ __forceinline__ void slab_accum2(const double* __restrict__ smx, doub
     }
 }
 
+// two ARD leaves: s1 += w[k] d^2, s2 += w2[k] d^2
+__device__ __forceinline__ void slab_accum3(const double* __restrict__ smx, double (&s)[4][4], double (&s1)[4][4],
+                                            double (&s2)[4][4], const double* __restrict__ w,
+                                            const double* __restrict__ w2, int k0) {
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    const double* xr = smx;
+    const double* xc = smx + SKC * ST;
+#pragma unroll
+    for (int k = 0; k < SKC; ++k) {
+        const double wk = (k0 + k) < CP_MAXARD ? w[k0 + k] : 0.0;
+        const double wk2 = (k0 + k) < CP_MAXARD ? w2[k0 + k] : 0.0;
+        const double2_t r01 = *(const double2_t*)(xr + k * ST + 4 * tr);
+        const double2_t r23 = *(const double2_t*)(xr + k * ST + 4 * tr + 2);
+        const double2_t c01 = *(const double2_t*)(xc + k * ST + 2 * tc);
+        const double2_t c23 = *(const double2_t*)(xc + k * ST + 2 * tc + 32);
+        const double rv[4] = {r01[0], r01[1], r23[0], r23[1]};
+        const double cv[4] = {c01[0], c01[1], c23[0], c23[1]};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double df = rv[a] - cv[b];
+                const double d2 = df * df;
+                s[a][b] += d2;
+                s1[a][b] = fma(wk, d2, s1[a][b]);
+                s2[a][b] = fma(wk2, d2, s2[a][b]);
+            }
+    }
+}
+
 __device__ __forceinline__ void slab_accum(const double* __restrict__ smx, double (&s)[4][4]) {
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     const double* xr = smx;
@@ -192,7 +226,8 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict_
                                                        long ldo, const int2* __restrict__ tiles, long ntiles) {
     constexpr int TS = ST + 2;                      // transpose-tile row stride (16-byte aligned rows)
     constexpr bool PROG = is_program<COV>::value;
-    constexpr bool PARD = PROG && KIND == 1;        // program with an ARD leaf: second (weighted) distance
+    constexpr bool PARD = PROG && KIND >= 1;        // program with an ARD leaf: second (weighted) distance
+    constexpr bool PARD2 = PROG && KIND == 2;       // two ARD leaves: a third distance, kept in registers
     constexpr int SMT = PARD ? 2 * 16 * 256 : (MODE == MODE_SYM ? ST * TS : (PROG ? 16 * 256 : 2));
     // coordinate slabs (2 x 16 x 64 doubles) and the mirror-transpose tile share one region: 33.8 KB -> 4 WGs per CU
     constexpr int SMX = 2 * SKC * ST;
@@ -217,19 +252,21 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict_
             nti = nx.x; ntj = nx.y;
             slab_fetch(XrT, ldr, nti * ST, XcT, ldc, ntj * ST, 0, g);
         }
-        double s[4][4], s1[PARD ? 4 : 1][4];
+        double s[4][4], s1[PARD ? 4 : 1][4], s2[PARD2 ? 4 : 1][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) { s[a][b] = 0.0; if (PARD) s1[a][b] = 0.0; }
-        if constexpr (PARD) slab_accum2(smx, s, s1, prog_ardw(cp), 0); else slab_accum(smx, s);
+            for (int b = 0; b < 4; ++b) { s[a][b] = 0.0; if (PARD) s1[a][b] = 0.0; if (PARD2) s2[a][b] = 0.0; }
+        if constexpr (PARD2) slab_accum3(smx, s, s1, s2, prog_ardw(cp), prog_ardw2(cp), 0);
+        else if constexpr (PARD) slab_accum2(smx, s, s1, prog_ardw(cp), 0); else slab_accum(smx, s);
         for (int k0 = SKC; k0 < dpad; k0 += SKC) {          // d > 16: further slabs, loaded in place
             SlabRegs h;
             slab_fetch(XrT, ldr, r0, XcT, ldc, c0, k0, h);
             __syncthreads();
             slab_stage(smx, h);
             __syncthreads();
-            if constexpr (PARD) slab_accum2(smx, s, s1, prog_ardw(cp), k0); else slab_accum(smx, s);
+            if constexpr (PARD2) slab_accum3(smx, s, s1, s2, prog_ardw(cp), prog_ardw2(cp), k0);
+            else if constexpr (PARD) slab_accum2(smx, s, s1, prog_ardw(cp), k0); else slab_accum(smx, s);
         }
 
         double v[4][4];
@@ -248,9 +285,11 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict_
                 double dk2 = 0.0;
                 if (PARD && pder >= 0) {
                     const double dd = XrT[(long)pder * ldr + r] - XcT[(long)pder * ldc + c];
-                    dk2 = prog_ardw(cp)[pder] * dd * dd;
+                    dk2 = prog_der_w(cp)[pder] * dd * dd;
                 }
-                sv[e * 256] = prog_elem(cp, sv[e * 256], dk2, MODE != MODE_RECT && r == c, PARD ? sv1[e * 256] : 0.0);
+                double s2e = 0.0;
+                if constexpr (PARD2) s2e = sel16(s2, e);
+                sv[e * 256] = prog_elem(cp, sv[e * 256], dk2, MODE != MODE_RECT && r == c, PARD ? sv1[e * 256] : 0.0, s2e);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e >> 2][e & 3] = sv[e * 256];
@@ -426,9 +465,13 @@ static int cov_tile_dispatch(const CovSpec& cs, int train, long ntr, long ntc_, 
     if (cs.prog) {
         CovProgram pg = cs.pg;
         for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = train;
-        if (pg.ard_leaf >= 0 && pg.leaf[pg.ard_leaf].kind == 6 && pg.leaf[pg.ard_leaf].ref_der)
-            pg.leaf[pg.ard_leaf].gb = train == 1 ? 0.0 : cs.ell4;                 // Core/cov.py:1415-1418 as returned
-        if (pg.ard_leaf >= 0)
+        for (int la : {pg.ard_leaf, pg.ard_leaf2})
+            if (la >= 0 && pg.leaf[la].kind == 6 && pg.leaf[la].ref_der)
+                pg.leaf[la].gb = train == 1 ? 0.0 : cs.ell4;                      // Core/cov.py:1415-1418 as returned
+        if (pg.ard_leaf2 >= 0)
+            hipLaunchKernelGGL((cov_tile_kernel<MODE, CovProgram, 2, false, false>), dim3(nblk), dim3(256), 0, st, XrT, ldr, n,
+                               XcT, ldc, m, dpad, pg, inv_sn2, out, ldo, tiles, ntiles);
+        else if (pg.ard_leaf >= 0)
             hipLaunchKernelGGL((cov_tile_kernel<MODE, CovProgram, 1, false, false>), dim3(nblk), dim3(256), 0, st, XrT, ldr, n,
                                XcT, ldc, m, dpad, pg, inv_sn2, out, ldo, tiles, ntiles);
         else

@@ -137,6 +137,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "potrf_v1")) { c->potrf_v1 = value; return PGP_OK; }
     if (!strcmp(name, "dserver")) { c->dserver = value; return PGP_OK; }
     if (!strcmp(name, "ds_exclusive")) { c->ds_exclusive = value; return PGP_OK; }
+    if (!strcmp(name, "ds_fake")) { c->ds_fake = value; return PGP_OK; }
     if (!strcmp(name, "ds_timeout_ms")) { c->ds_timeout_s = 1e-3 * value; return PGP_OK; }
     if (!strcmp(name, "ds_ticks")) {            // record wall-clock stamps of the server phases (16 per panel)
         if (value && !c->ds_ticks) {
@@ -262,7 +263,7 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
         double iso;
         CHK(make_leaf(kind, hyp, nhyp, para, flags, d, P.leaf[0], iso));
         if (der >= nhyp) return -4;
-        P.nleaf = 1; P.nterm = 1; P.nscale = 0; P.is2[0] = iso * iso; P.hyp0[0] = 0; P.nh[0] = nhyp; P.ard_leaf = -1;
+        P.nleaf = 1; P.nterm = 1; P.nscale = 0; P.is2[0] = iso * iso; P.hyp0[0] = 0; P.nh[0] = nhyp; P.ard_leaf = -1; P.ard_leaf2 = -1;
         P.coef[0] = 1.0; P.tl[0] = 1u; P.ts[0] = 0u;
         P.der = der; P.der_leaf = der >= 0 ? 0 : -1; P.der_j = der; P.der_scale = -1;
         cs.prog = true; cs.scale.assign(d, 1.0); cs.ncov = nhyp; cs.nder = nhyp;
@@ -289,7 +290,7 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
     CovProgram& P = cs.pg;
     P = CovProgram{};
     P.der = der; P.der_leaf = P.der_j = P.der_scale = -1;
-    P.ard_leaf = -1;
+    P.ard_leaf = -1; P.ard_leaf2 = -1;
     int used = 0;
     for (size_t i = 0; i < tok.size();) {
         const int op = tok[i];
@@ -298,7 +299,7 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
             const int lk = tok[i + 1], lpara = tok[i + 2], lflags = tok[i + 3], h0 = tok[i + 4];
             i += 5;
             const bool ard = lk == PGP_COV_RBFARD || lk == PGP_COV_RQARD;
-            if (ard && (P.ard_leaf >= 0 || d > CP_MAXARD)) return -13;            // one ARD leaf (own weighted distance), D <= 64
+            if (ard && (P.ard_leaf2 >= 0 || d > CP_MAXARD)) return -13;           // at most two ARD leaves (own weighted distances), D <= 64
             const int nh = leaf_nhyp(lk, d);
             if (nh < 0) return -2;
             if (h0 < 0 || h0 + nh > nhyp) return -11;
@@ -307,8 +308,9 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
             CHK(make_leaf(lk, hyp + h0, nh, lpara, lflags, d, P.leaf[P.nleaf], iso));
             P.is2[P.nleaf] = iso * iso; P.hyp0[P.nleaf] = h0; P.nh[P.nleaf] = nh;
             if (ard) {
-                P.ard_leaf = P.nleaf;
-                for (long k = 0; k < d; ++k) P.ardw[k] = exp(-2.0 * hyp[h0 + k]);  // 1 / ell_k^2 (cov.py:893, 1378)
+                double* aw = P.ard_leaf < 0 ? P.ardw : P.ardw2;
+                (P.ard_leaf < 0 ? P.ard_leaf : P.ard_leaf2) = P.nleaf;
+                for (long k = 0; k < d; ++k) aw[k] = exp(-2.0 * hyp[h0 + k]);      // 1 / ell_k^2 (cov.py:893, 1378)
                 if (lk == PGP_COV_RQARD && P.leaf[P.nleaf].ref_der && der >= h0 && der < h0 + d) cs.ell4 = exp(4.0 * hyp[der]);
             }
             if (der >= h0 && der < h0 + nh) { P.der_leaf = P.nleaf; P.der_j = der - h0; }
@@ -725,7 +727,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         HIP_TRY(hipEventRecord(c->ev_ds, main));
         HIP_TRY(hipStreamWaitEvent(pan, c->ev_ds, 0));
         CHK(diag_server_launch(c->Dk, dk_stride, c->dpack, m.F, m.ldf, m.E, m.lde, Xs, ldx, xs_stride, c->Yn, nblk, q,
-                               c->dflags, c->info_dev, c->ds_timeout_s, c->ds_ticks, pan, c->ds_exclusive != 0));
+                               c->dflags, c->info_dev, c->ds_timeout_s, c->ds_ticks, pan, c->ds_exclusive != 0, c->ds_fake));
         c->ds_used = true;
     }
     // panel 0: its columns go to the staging buffer by a plain copy (later panels get there through TU_a)

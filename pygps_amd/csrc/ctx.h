@@ -71,6 +71,7 @@ struct pgp_ctx {
     int dserver = 0;                    // 1: diagonal panels factored by the resident server kernel (left-looking, runs ahead of the
                                         //    bulk); 0: by 13 launches each on the panel stream.  Measured equal single-stream (13.5 ms
                                         //    at N=8192), the launch chain is better with two fit streams per GPU (91 vs 81 fits/s)
+    int ds_fake = 0;                    // experiment only: the server posts done[p] without factoring (WRONG results)
     int ds_exclusive = 1;               // 1: server workgroups claim a whole CU each (LDS padding)
     double ds_timeout_s = 10.0;         // every spin of the server (and of the main stream's wait kernel) is bounded
     long long* ds_ticks = nullptr;      // optional per-phase wall-clock stamps (option ds_ticks)

@@ -57,7 +57,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
     // ---- accumulators, pre-loaded with (beta/alpha)*C (== alpha*beta*C for alpha = +-1) ------
     double4_t acc[FM][FN];
     const double ab = g.beta / g.alpha;
-    const bool preload = g.beta != 0.0 && !(g.dbg & 4) && !(g.zero_from && i0 >= g.zero_from);
+    // in-place tiles with beta = 1 may skip the C pre-load entirely: acc starts at zero and the epilogue adds alpha*acc
+    // to C with fire-and-forget global_atomic_add_f64 (ONE add per element per launch: bitwise deterministic)
+    const bool atomic_c = (g.dbg & 16) && g.beta == 1.0 && (!g.Cin || inplace) && !(g.zero_from && i0 >= g.zero_from);
+    const bool preload = g.beta != 0.0 && !(g.dbg & 4) && !(g.zero_from && i0 >= g.zero_from) && !atomic_c;
 #pragma unroll
     for (int im = 0; im < FM; ++im)
 #pragma unroll
@@ -194,7 +197,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = nb + 4 * r;
-                if ((!diag || m >= n) && (!(g.dbg & 4) || acc[im][in][r] == 12345.678)) cp[(long)(4 * r) * ldc] = g.alpha * acc[im][in][r];
+                if ((!diag || m >= n) && (!(g.dbg & 4) || acc[im][in][r] == 12345.678)) {
+                    if (atomic_c) unsafeAtomicAdd(cp + (long)(4 * r) * ldc, g.alpha * acc[im][in][r]);
+                    else cp[(long)(4 * r) * ldc] = g.alpha * acc[im][in][r];
+                }
             }
         }
     // ---- completion signal for the resident diagonal-panel server (cdna guide G16: drain, barrier, ONE release) ----

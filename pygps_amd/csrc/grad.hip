@@ -200,14 +200,16 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
 // Same reduction for a composite program: per element the leaf values, their (up to three) derivatives and the
 // chain-rule weights through the Sum/Product/Scale tree.  Elements run in a rolled loop over LDS-staged distances
 // so that the leaf functors are instantiated once.
-// PARD: the program has an ARD leaf (own weighted distance; per-dimension length-scale sums in a second pass)
-template <bool PARD>
+// NARD: number of ARD leaves of the program (own weighted distances; per-dimension length-scale sums in a second pass
+// per leaf).  The second leaf's distance and weights stay in registers (sel16 / put16): static LDS ends at 64 KB.
+template <int NARD>
 __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __restrict__ XT, long ldp, long n, int dpad,
                                                             CovProgram P, int ncov, double inv_sn2, double sn2,
                                                             const double* __restrict__ Binv, long ldb,
                                                             const double* __restrict__ alpha,
                                                             const double* __restrict__ wv,
                                                             double* __restrict__ partial, long nt) {
+    constexpr bool PARD = NARD >= 1, PARD2 = NARD == 2;
     __shared__ __attribute__((aligned(16))) double sm[(PARD ? 2 : 1) * 16 * 256];
     __shared__ double red[4];
     const long b = blockIdx.x;
@@ -217,9 +219,14 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
     while ((r + 1) * nt - (r + 1) * r / 2 <= b) ++r;
     const long ti = r, tj = ti + (b - (r * nt - r * (r - 1) / 2));
     const long r0 = ti * ST, c0 = tj * ST;
-    double s[4][4], s1[PARD ? 4 : 1][4];
-    if constexpr (PARD) sqdist_tile2(XT, ldp, r0, XT, ldp, c0, dpad, P.ardw, sm, s, s1);
+    double s[4][4], s1[PARD ? 4 : 1][4], s2[PARD2 ? 4 : 1][4], w2[PARD2 ? 4 : 1][4];
+    if constexpr (PARD2) sqdist_tile3(XT, ldp, r0, XT, ldp, c0, dpad, P.ardw, P.ardw2, sm, s, s1, s2);
+    else if constexpr (PARD) sqdist_tile2(XT, ldp, r0, XT, ldp, c0, dpad, P.ardw, sm, s, s1);
     else sqdist_tile(XT, ldp, r0, XT, ldp, c0, dpad, sm, s);
+    if constexpr (PARD2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w2[e >> 2][e & 3] = 0.0;
+    }
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     double* sv = sm + t;
     double* sv1 = sm + 16 * 256 + t;       // PARD: the ARD distance going in, the length-scale weight omega coming out
@@ -247,27 +254,31 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
         const double r2 = sv[e * 256];
         const bool same = cc == rr;
         double v[CP_MAXLEAF], d[CP_MAXLEAF][3], T[CP_MAXTERM];
-        double ardfac = 0.0;                  // dK_l / d log ell_k = ardfac * (scaled squared difference in coordinate k)
+        double ardfac = 0.0, ardfac2 = 0.0;   // dK_l / d log ell_k = ardfac * (scaled squared difference in coordinate k)
 #pragma unroll
         for (int l = 0; l < CP_MAXLEAF; ++l) {
             v[l] = 1.0; d[l][0] = d[l][1] = d[l][2] = 0.0;
             if (l < P.nleaf) {
-                if (PARD && l == P.ard_leaf) {
+                const bool a1 = PARD && l == P.ard_leaf, a2 = PARD2 && l == P.ard_leaf2;
+                if (a1 || a2) {
                     // d[l][0]: magnitude hyper, d[l][1]: RQard shape hyper (Core/cov.py:922-936, 1412-1425)
-                    const double sl = sv1[e * 256];
+                    double sl = sv1[e * 256];
+                    if constexpr (PARD2) { if (a2) sl = sel16(s2, e); }
                     const CovParams& lp = P.leaf[l];
+                    double af;
                     if (lp.kind == 1) {
                         v[l] = lp.sf2 * exp_nonpos(-0.5 * sl);
                         d[l][0] = 2.0 * v[l];
-                        ardfac = v[l];
+                        af = v[l];
                     } else {
                         const double Kp = 1.0 + 0.5 * sl / lp.alpha;
                         const double lk = log(Kp);
                         v[l] = lp.sf2 * exp_nonpos(-lp.alpha * lk);
                         d[l][0] = 2.0 * v[l];
                         d[l][1] = v[l] * (0.5 * sl / Kp - lp.alpha * lk);
-                        ardfac = lp.ref_der ? 0.0 : v[l] / Kp;
+                        af = lp.ref_der ? 0.0 : v[l] / Kp;
                     }
+                    if (a2) ardfac2 = af; else ardfac = af;
                 } else {
                     const double sl = r2 * P.is2[l];
                     v[l] = cov_value<true>(P.leaf[l], sl, same);
@@ -284,6 +295,7 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
                 gl[l][1] = fma(wl, d[l][1], gl[l][1]);
                 gl[l][2] = fma(wl, d[l][2], gl[l][2]);
                 if (PARD && l == P.ard_leaf) sv1[e * 256] = wl * ardfac;
+                if constexpr (PARD2) { if (l == P.ard_leaf2) put16(w2, e, wl * ardfac2); }
             }
         }
 #pragma unroll
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
 #pragma unroll
     for (int l = 0; l < CP_MAXLEAF; ++l) {
         if (l < P.nleaf) {
-            if (PARD && l == P.ard_leaf) {      // hypers of the ARD leaf: D length-scales (below), magnitude, [shape]
+            if ((PARD && l == P.ard_leaf) || (PARD2 && l == P.ard_leaf2)) {      // ARD leaf: D length-scales (below), magnitude, [shape]
                 const int D = P.leaf[l].D;
                 const double t0 = block_sum(gl[l][0], red);
                 const double t1 = block_sum(gl[l][1], red);
@@ -324,6 +336,11 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
         for (int e = 0; e < 16; ++e) w[e >> 2][e & 3] = sv1[e * 256];
         const int la = P.ard_leaf & 7;
         ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, P.ardw, P.leaf[la].D, out + P.hyp0[la]);
+        if constexpr (PARD2) {
+            const int lb = P.ard_leaf2 & 7;
+            __syncthreads();
+            ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w2, P.ardw2, P.leaf[lb].D, out + P.hyp0[lb]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < CP_MAXSCALE; ++k) {
@@ -520,11 +537,14 @@ int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad
     if (cs.prog) {
         CovProgram pg = cs.pg;
         for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = 1;
-        if (pg.ard_leaf >= 0)
-            hipLaunchKernelGGL(hadamard_prog_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
+        if (pg.ard_leaf2 >= 0)
+            hipLaunchKernelGGL(hadamard_prog_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
+                               1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
+        else if (pg.ard_leaf >= 0)
+            hipLaunchKernelGGL(hadamard_prog_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
                                1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
         else
-            hipLaunchKernelGGL(hadamard_prog_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
+            hipLaunchKernelGGL(hadamard_prog_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
                                1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
     } else {
         CovParams cp = cs.cp;

@@ -26,7 +26,7 @@ int diag_server_wait_staged(unsigned* flags, int p, double timeout_s, hipStream_
 int diag_server_err_index();
 int diag_server_launch(double* Dk, long dk_stride, double* dpack, double* F, long ldf, double* E, long lde,
                        const double* Xs, long ldx, long xs_stride, double* Yn, int nblk, int q, unsigned* flags, int* info,
-                       double timeout_s, long long* ticks, hipStream_t st, bool exclusive = true);
+                       double timeout_s, long long* ticks, hipStream_t st, bool exclusive = true, int fake = 0);
 int diag_server_go(unsigned* flags, int p, hipStream_t st);
 int diag_server_post(unsigned* flag, hipStream_t st);
 int diag_server_wait(unsigned* flags, int p, double timeout_s, hipStream_t st);

@@ -484,6 +484,7 @@ struct DiagServerArgs {
     const double* Xs; long ldx; long xs_stride;    // two staging buffers (panel p's columns live in buffer p & 1)
     double* Yn;                       // w x w scratch of the next-diagonal-block update
     int nblk, q;
+    int fake;                         // experiment: post done[p] at once (no factorisation): times the bulk schedule alone
     unsigned* flags; int* info;
     long long timeout_ticks;          // wall_clock64 ticks (100 MHz)
     long long* ticks;                 // optional: per panel, per phase wall-clock stamps (16 per panel)
@@ -669,6 +670,12 @@ __global__ __launch_bounds__(256, 2) void diag_server_kernel(DiagServerArgs a) {
         const long ldd = 2L * w;
         double* Dc = a.Dk + (long)(p & 1) * a.dk_stride;
         STAMP(0);
+        if (a.fake) {
+            if (p == 0 && !ds_wait(a.flags, DS_GO, 1u, a.timeout_ticks, s_ok)) return;
+            if (p >= 2 && !ds_wait(a.flags, DS_GO + p, 1u, a.timeout_ticks, s_ok)) return;
+            if (wg == 0 && t == 0) __hip_atomic_store(a.flags + DS_DONE + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
         if (p == 0) {
             if (!ds_wait(a.flags, DS_GO, 1u, a.timeout_ticks, s_ok)) return;
             STAMP(1);
@@ -778,8 +785,8 @@ int diag_server_max_panels() { return (int)DS_MAXP; }
 
 int diag_server_launch(double* Dk, long dk_stride, double* dpack, double* F, long ldf, double* E, long lde,
                        const double* Xs, long ldx, long xs_stride, double* Yn, int nblk, int q, unsigned* flags, int* info,
-                       double timeout_s, long long* ticks, hipStream_t st, bool exclusive) {
-    DiagServerArgs a{Dk, dk_stride, dpack, F, ldf, E, lde, Xs, ldx, xs_stride, Yn, nblk, q, flags, info,
+                       double timeout_s, long long* ticks, hipStream_t st, bool exclusive, int fake) {
+    DiagServerArgs a{Dk, dk_stride, dpack, F, ldf, E, lde, Xs, ldx, xs_stride, Yn, nblk, q, fake, flags, info,
                      (long long)(timeout_s * 1e8), ticks};
     // 96 KB of LDS although the phases need 74: a server workgroup then has its CU to itself (a 74 KB trailing-update
     // workgroup no longer fits beside it).  Sharing the CU slowed every phase 2-2.7x (leaf 34 -> 90 us): LDS + MFMA pipe.

@@ -46,8 +46,10 @@ struct CovProgram {
     unsigned tl[CP_MAXTERM];         // leaves multiplied in term t (bit mask)
     unsigned ts[CP_MAXTERM];         // Scale nodes above term t (bit mask)
     int shyp[CP_MAXSCALE];           // flat hyper index of each Scale node
-    int ard_leaf;                    // index of the (at most one) ARD leaf (RBFard / RQard), -1: none.  Its distance is the
+    int ard_leaf;                    // index of the first ARD leaf (RBFard / RQard), -1: none.  Its distance is the
     double ardw[CP_MAXARD];          // weighted sum_k ardw[k] (x_k - z_k)^2, ardw[k] = 1 / ell_k^2, accumulated beside r^2
+    int ard_leaf2;                   // a second ARD leaf with its own weights (-1: none): at most two per program
+    double ardw2[CP_MAXARD];
 };
 
 constexpr int ST = 64;      // tile edge
@@ -137,6 +139,66 @@ __device__ __forceinline__ void sqdist_tile2(const double* __restrict__ XrT, lon
         }
         __syncthreads();
     }
+}
+
+// and with two weighted distances (programs with two ARD leaves)
+__device__ __forceinline__ void sqdist_tile3(const double* __restrict__ XrT, long ldr, long r0,
+                                             const double* __restrict__ XcT, long ldc, long c0, int dpad,
+                                             const double* __restrict__ w, const double* __restrict__ w2,
+                                             double* __restrict__ sm, double (&s)[4][4], double (&s1)[4][4],
+                                             double (&s2)[4][4]) {
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    double* xr = sm;
+    double* xc = sm + SKC * ST;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { s[a][b] = 0.0; s1[a][b] = 0.0; s2[a][b] = 0.0; }
+    for (int k0 = 0; k0 < dpad; k0 += SKC) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int v = t + p * 256;
+            const int k = v >> 5, pr = v & 31;
+            *(double2_t*)(xr + k * ST + 2 * pr) = *(const double2_t*)(XrT + (long)(k0 + k) * ldr + r0 + 2 * pr);
+            *(double2_t*)(xc + k * ST + 2 * pr) = *(const double2_t*)(XcT + (long)(k0 + k) * ldc + c0 + 2 * pr);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SKC; ++k) {
+            const double wk = (k0 + k) < CP_MAXARD ? w[k0 + k] : 0.0;
+            const double wk2 = (k0 + k) < CP_MAXARD ? w2[k0 + k] : 0.0;
+            const double2_t r01 = *(const double2_t*)(xr + k * ST + 4 * tr);
+            const double2_t r23 = *(const double2_t*)(xr + k * ST + 4 * tr + 2);
+            const double2_t c01 = *(const double2_t*)(xc + k * ST + 2 * tc);
+            const double2_t c23 = *(const double2_t*)(xc + k * ST + 2 * tc + 32);
+            const double rv[4] = {r01[0], r01[1], r23[0], r23[1]};
+            const double cv[4] = {c01[0], c01[1], c23[0], c23[1]};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double df = rv[a] - cv[b];
+                    const double d2 = df * df;
+                    s[a][b] += d2;
+                    s1[a][b] = fma(wk, d2, s1[a][b]);
+                    s2[a][b] = fma(wk2, d2, s2[a][b]);
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// s[e >> 2][e & 3] for a run-time e without dynamic register indexing (the second ARD distance stays in registers:
+// three 32 KB staging arrays would not fit the 64 KB of static LDS)
+__device__ __forceinline__ double sel16(const double (&s)[4][4], int e) {
+    double v = s[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) v = (e == i) ? s[i >> 2][i & 3] : v;
+    return v;
+}
+__device__ __forceinline__ void put16(double (&s)[4][4], int e, double val) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i >> 2][i & 3] = (e == i) ? val : s[i >> 2][i & 3];
 }
 
 __device__ __forceinline__ double matern_poly(int d, double t) {
@@ -416,14 +478,14 @@ __device__ __forceinline__ double prog_leaf_weight(const CovProgram& P, const do
 }
 
 // scaled squared distance of leaf l: the shared raw distance times the leaf's 1/ell^2, or the ARD-weighted one
-__device__ __forceinline__ double prog_leaf_dist(const CovProgram& P, int l, double r2, double s1) {
-    return l == P.ard_leaf ? s1 : r2 * P.is2[l];
+__device__ __forceinline__ double prog_leaf_dist(const CovProgram& P, int l, double r2, double s1, double s2 = 0.0) {
+    return l == P.ard_leaf ? s1 : (l == P.ard_leaf2 ? s2 : r2 * P.is2[l]);
 }
 
-__device__ __forceinline__ double prog_value(const CovProgram& P, double r2, bool same, double s1 = 0.0) {
+__device__ __forceinline__ double prog_value(const CovProgram& P, double r2, bool same, double s1 = 0.0, double s2 = 0.0) {
     double v[CP_MAXLEAF], T[CP_MAXTERM];
 #pragma unroll
-    for (int l = 0; l < CP_MAXLEAF; ++l) v[l] = l < P.nleaf ? cov_value<true>(P.leaf[l], prog_leaf_dist(P, l, r2, s1), same) : 1.0;
+    for (int l = 0; l < CP_MAXLEAF; ++l) v[l] = l < P.nleaf ? cov_value<true>(P.leaf[l], prog_leaf_dist(P, l, r2, s1, s2), same) : 1.0;
     prog_terms(P, v, T);
     double K = 0.0;
 #pragma unroll
@@ -433,10 +495,11 @@ __device__ __forceinline__ double prog_value(const CovProgram& P, double r2, boo
 
 // derivative matrix entry for the flat hyper index P.der (Product :246-256, Sum :281-291, Scale :320-328)
 // dk2: ARD-weighted squared difference in coordinate der_j (only when the derivative is w.r.t. an ARD length-scale)
-__device__ __forceinline__ double prog_deriv(const CovProgram& P, double r2, bool same, double s1 = 0.0, double dk2 = 0.0) {
+__device__ __forceinline__ double prog_deriv(const CovProgram& P, double r2, bool same, double s1 = 0.0, double dk2 = 0.0,
+                                             double s2 = 0.0) {
     double v[CP_MAXLEAF], T[CP_MAXTERM];
 #pragma unroll
-    for (int l = 0; l < CP_MAXLEAF; ++l) v[l] = l < P.nleaf ? cov_value<true>(P.leaf[l], prog_leaf_dist(P, l, r2, s1), same) : 1.0;
+    for (int l = 0; l < CP_MAXLEAF; ++l) v[l] = l < P.nleaf ? cov_value<true>(P.leaf[l], prog_leaf_dist(P, l, r2, s1, s2), same) : 1.0;
     if (P.der_scale >= 0) {               // 2 * exp(h) * child, through whatever sits above the Scale node
         prog_terms(P, v, T);
         double K = 0.0;
@@ -451,7 +514,7 @@ __device__ __forceinline__ double prog_deriv(const CovProgram& P, double r2, boo
         if (l == P.der_leaf) {
             CovParams lp = P.leaf[l];
             lp.der = P.der_j;
-            out = prog_leaf_weight(P, v, l) * cov_deriv<true>(lp, prog_leaf_dist(P, l, r2, s1), dk2, same);
+            out = prog_leaf_weight(P, v, l) * cov_deriv<true>(lp, prog_leaf_dist(P, l, r2, s1, s2), dk2, same);
         }
     }
     return out;
@@ -461,10 +524,14 @@ __device__ __forceinline__ double prog_deriv(const CovProgram& P, double r2, boo
 __device__ __forceinline__ double cov_elem(const CovParams& p, double s, double dk2, bool same) {
     return p.der < 0 ? cov_value(p, s, same) : cov_deriv(p, s, dk2, same);
 }
-__device__ __forceinline__ double cov_elem(const CovProgram& P, double s, double dk2, bool same, double s1 = 0.0) {
-    return P.der < 0 ? prog_value(P, s, same, s1) : prog_deriv(P, s, same, s1, dk2);
+__device__ __forceinline__ double cov_elem(const CovProgram& P, double s, double dk2, bool same, double s1 = 0.0,
+                                           double s2 = 0.0) {
+    return P.der < 0 ? prog_value(P, s, same, s1, s2) : prog_deriv(P, s, same, s1, dk2, s2);
 }
 __device__ __forceinline__ int cov_ard_der(const CovParams& p) { return (cov_is_ard(p) && p.der >= 0 && p.der < p.D) ? p.der : -1; }
 __device__ __forceinline__ int cov_ard_der(const CovProgram& P) {
-    return (P.ard_leaf >= 0 && P.der_leaf == P.ard_leaf && P.der_j >= 0 && P.der_j < P.leaf[P.ard_leaf & 7].D) ? P.der_j : -1;
+    const bool ard = P.der_leaf >= 0 && (P.der_leaf == P.ard_leaf || P.der_leaf == P.ard_leaf2);
+    return (ard && P.der_j >= 0 && P.der_j < P.leaf[P.der_leaf & 7].D) ? P.der_j : -1;
 }
+// 1 / ell_k^2 of the ARD leaf the derivative is taken in
+__device__ __forceinline__ const double* cov_ard_der_w(const CovProgram& P) { return P.der_leaf == P.ard_leaf2 ? P.ardw2 : P.ardw; }

@@ -83,3 +83,15 @@ def g14_trees():
         "rqard_sum": ("sum", L(O.RQARD), L(O.MATERN, 3)),
         "ep_ard_const": ("sum", L(O.RBFARD), L(O.CONST)),
     }
+
+
+def g15_trees():
+    """Composites with TWO ARD leaves (G15 fixtures)."""
+    from oracle import gp_oracle as O
+    L = _leaf
+    return {
+        "ard_plus_rqard": ("sum", L(O.RBFARD), L(O.RQARD)),
+        "ard_times_ard": ("sum", ("prod", L(O.RBFARD), L(O.RBFARD)), L(O.NOISE)),
+        "scaled_ard_rq_ard": ("sum", ("prod", ("scale", L(O.RBFARD)), L(O.RQ)), L(O.RQARD)),
+        "ep_ard_times_ard": ("prod", L(O.RBFARD), L(O.RBFARD)),
+    }

@@ -536,8 +536,45 @@ def g14():
          pred_xs=xc[:5] + 0.05, pred_ym=ym, pred_lp=lp, **dn(dnlZ))
 
 
+def g15():
+    """Composites with TWO ARD leaves: each ARD leaf has its own weighted distance inside the device
+    program.  Core/cov.py:230-296 composes anything; these are the two shapes the verdict names plus an EP case."""
+    if not hasattr(np, "float"):
+        np.float = float
+    cov = pyGPs.cov
+    x4, y4 = synth_reg(300, 4)
+    ks = {"ard_plus_rqard": lambda: cov.RBFard(log_ell_list=[0.5, 0.7, 0.9, 0.6], log_sigma=0.2)
+          + cov.RQard(log_ell_list=[0.9, 0.6, 0.8, 1.0], log_sigma=-0.3, log_alpha=0.4),
+          "ard_times_ard": lambda: cov.RBFard(log_ell_list=[0.8, 0.7, 1.1, 0.9], log_sigma=0.1)
+          * cov.RBFard(log_ell_list=[1.2, 1.0, 0.9, 1.3], log_sigma=-0.2) + cov.Noise(-1.5),
+          "scaled_ard_rq_ard": lambda: (cov.RBFard(log_ell_list=[0.7, 0.9, 0.8, 1.0], log_sigma=0.0) * 0.2) * cov.RQ(0.9, 0.0, 0.2)
+          + cov.RQard(log_ell_list=[1.1, 0.9, 1.0, 0.8], log_sigma=-0.5, log_alpha=0.1)}
+    for nm, mk in ks.items():
+        m = pyGPs.GPR()
+        m.setPrior(kernel=mk())
+        m.setNoise(np.log(0.1))
+        m.setData(x4, y4)
+        nlZ, dnlZ, post = m.getPosterior()
+        xs4 = x4[:5] + 0.05
+        ym, ys2, fm, fs2, lp = m.predict(xs4)
+        k = mk()
+        z = x4[300 - 7:] * 0.9
+        out = {}
+        kernel_dump("k", k, x4[:12], z, out)
+        save("G15_fit_%s_N300" % nm, N=300, d=4, seed=0, nlZ=nlZ, alpha=post.alpha, mean_hyp=np.array(m.meanfunc.hyp),
+             cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp), pred_xs=xs4, pred_ym=ym, pred_fs2=fs2,
+             kx=x4[:12], kz=z, **out, **dn(dnlZ))
+    xc, yc = synth_cls(200, 3)
+    m = pyGPs.GPC()
+    m.setPrior(kernel=cov.RBFard(log_ell_list=[0.4, 0.6, 0.5], log_sigma=0.3) * cov.RBFard(log_ell_list=[0.9, 0.8, 1.0], log_sigma=0.0))
+    nlZ, dnlZ, post = m.getPosterior(xc, yc)
+    ym, ys2, fm, fs2, lp = m.predict(xc[:5] + 0.05, ys=np.ones((5, 1)))
+    save("G15_ep_ard_times_ard_N200", x=xc, y=yc, nlZ=nlZ, alpha=post.alpha, sW=post.sW, cov_hyp=np.array(m.covfunc.hyp),
+         pred_xs=xc[:5] + 0.05, pred_ym=ym, pred_lp=lp, **dn(dnlZ))
+
+
 CASES = {
-    "g14": g14, "g13": g13, "g12": g12, "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
+    "g15": g15, "g14": g14, "g13": g13, "g12": g12, "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
     "g8ii_2048": lambda: g8ii(2048), "g8ii_4096": lambda: g8ii(4096), "g9_2048": lambda: g9(2048),
     "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384),

@@ -299,7 +299,7 @@ def test_exact_rejects_non_gaussian_and_unknown_kernel(lib):
     with pytest.raises(Exception, match="Exact inference only possible with Gaussian likelihood"):
         pyGPs.inf.Exact().evaluate(pyGPs.mean.Zero(), pyGPs.cov.RBF(), pyGPs.lik.Erf(), x, y, 2)
     with pytest.raises(NotImplementedError):
-        s = pyGPs.cov.RBFard(D=2) + pyGPs.cov.RQard(D=2)       # two ARD leaves: no device program, and no CPU fallback
+        s = pyGPs.cov.RBFard(D=2) + pyGPs.cov.RQard(D=2) + pyGPs.cov.RBFard(D=2)   # three ARD leaves: no device program, no CPU fallback
         pyGPs.inf.Exact().evaluate(pyGPs.mean.Zero(), s, pyGPs.lik.Gauss(), x, y, 2)
     with pytest.raises(NotImplementedError):
         pyGPs.inf.Exact().evaluate(pyGPs.mean.Zero(), object(), pyGPs.lik.Gauss(), x, y, 2)

@@ -5,7 +5,7 @@ compared with the golden vectors recorded from the reference (G11) and with the 
 import numpy as np
 import pytest
 
-from conftest import golden, relerr, synth_cls, synth_reg, g11_trees, g14_trees, G11_1D
+from conftest import golden, relerr, synth_cls, synth_reg, g11_trees, g14_trees, g15_trees, G11_1D
 from oracle import gp_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -149,8 +149,8 @@ def test_G11_ep_with_a_composite_kernel():
 
 
 def test_composite_limits_and_ard_leaves():
-    """More than 8 leaves, or an ARD leaf: getCovMatrix still works (children on the device, combined on the host);
-    fits refuse loudly -- there is no CPU fallback."""
+    """More than 8 leaves, or more than two ARD leaves: getCovMatrix still works (children on the device, combined on the
+    host); fits refuse loudly -- there is no CPU fallback."""
     import pygps_amd as pyGPs
     from pygps_amd import cov
     rng = np.random.RandomState(0)
@@ -162,8 +162,10 @@ def test_composite_limits_and_ard_leaves():
     assert not big._on_device()
     ref = sum(O.cov_matrix(O.RBF, [0.1 * i, -0.2], 0, x=x, mode="train") for i in range(8)) + O.cov_matrix(O.RBF, [0.1, 0.0], 0, x=x, mode="train")
     _close(big.getCovMatrix(x=x, mode="train"), ref)
-    ard = cov.RBFard(D=2) * cov.RQard(D=2)                       # two ARD leaves: no device program
-    assert not ard._on_device() and (cov.RBFard(D=2) * cov.RBF())._on_device()
+    ard = cov.RBFard(D=2) * cov.RQard(D=2) + cov.RBFard(D=2)      # three ARD leaves: no device program
+    assert not ard._on_device() and (cov.RBFard(D=2) * cov.RBF())._on_device() and (cov.RBFard(D=2) * cov.RQard(D=2))._on_device()
+    t3 = ("sum", ("prod", ("leaf", O.RBFARD, 0), ("leaf", O.RQARD, 0)), ("leaf", O.RBFARD, 0))
+    _close(ard.getCovMatrix(x=x, mode="train"), O.cov_matrix(t3, np.array(ard.hyp, float), 0, x=x, mode="train"))
     for k in (big, ard):
         m = pyGPs.GPR()
         m.setPrior(kernel=k)
@@ -237,3 +239,69 @@ def test_G14_ep_with_an_ard_leaf():
     assert relerr(nlZ, g["nlZ"]) < 1e-8 and relerr(post.alpha, g["alpha"]) < 1e-6 and relerr(dnlZ.cov, g["dnlZ_cov"]) < 1e-6
     ym, ys2, fm, fs2, lp = m.predict(g["pred_xs"], ys=np.ones((5, 1)))
     assert relerr(ym, g["pred_ym"]) < 1e-7 and relerr(lp, g["pred_lp"]) < 1e-7
+
+
+@pytest.mark.parametrize("nm", ["ard_plus_rqard", "ard_times_ard", "scaled_ard_rq_ard"])
+def test_G15_fit_with_two_ard_leaves_inside_the_program(nm):
+    """Two ARD leaves (each with its own weighted distance) inside a Sum/Product/Scale tree, against the reference's
+    composition (Core/cov.py:230-296): kernel matrices in all modes with every derivative, fit with all gradients (one
+    per-dimension length-scale pass per ARD leaf), predict."""
+    import pygps_amd as pyGPs
+    g = golden("G15_fit_%s_N300" % nm)
+    tree = g15_trees()[nm]
+    hyp = g["cov_hyp"]
+    k = build(tree, hyp, 4)
+    assert k._on_device() and list(np.asarray(k.hyp, float)) == list(hyp)
+    kx, kz = g["kx"], g["kz"]
+    for mode, kw in (("train", dict(x=kx)), ("cross", dict(x=kx, z=kz)), ("self", dict(z=kz))):
+        mm = "self_test" if mode == "self" else mode
+        _close(k.getCovMatrix(mode=mm, **kw), g["k_K_%s" % mode])
+        for i in range(len(hyp)):
+            _close(k.getDerMatrix(mode=mm, der=i, **kw), g["k_dK%d_%s" % (i, mode)], 1e-11)
+    x, y = synth_reg(300, 4)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=k)
+    m.setNoise(g["lik_hyp"][0])
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    assert relerr(nlZ, g["nlZ"]) < 1e-9 and relerr(post.alpha, g["alpha"]) < 1e-6
+    assert np.allclose(dnlZ.cov, g["dnlZ_cov"], rtol=1e-7, atol=1e-7 * np.max(np.abs(g["dnlZ_cov"])))
+    assert relerr(dnlZ.lik, g["dnlZ_lik"]) < 1e-7 and relerr(dnlZ.mean, g["dnlZ_mean"]) < 1e-7
+    ym, ys2, fm, fs2, lp = m.predict(g["pred_xs"])
+    assert relerr(ym, g["pred_ym"]) < 1e-8 and relerr(fs2, g["pred_fs2"]) < 1e-6
+    # the default (mathematically correct) RQard length-scale gradient against the oracle without the reference's quirk
+    m.setPrior(kernel=build(tree, hyp, 4, compat=False))
+    m.setData(x, y)
+    nlZ2, dn2, _ = m.getPosterior()
+    c = m.meanfunc.hyp[0]
+    out = O.exact_fit(tree, hyp, 0, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y), faithful=False,
+                      matern_reference_compat=False)
+    assert relerr(dn2.cov, out["dnlZ_cov"]) < 1e-7
+
+
+def test_G15_ep_with_two_ard_leaves_and_larger_sizes_vs_oracle():
+    import pygps_amd as pyGPs
+    g = golden("G15_ep_ard_times_ard_N200")
+    tree = g15_trees()["ep_ard_times_ard"]
+    m = pyGPs.GPC()
+    m.setPrior(kernel=build(tree, g["cov_hyp"], 3))
+    nlZ, dnlZ, post = m.getPosterior(g["x"], g["y"])
+    assert relerr(nlZ, g["nlZ"]) < 1e-8 and relerr(post.alpha, g["alpha"]) < 1e-6 and relerr(dnlZ.cov, g["dnlZ_cov"]) < 1e-6
+    ym, ys2, fm, fs2, lp = m.predict(g["pred_xs"], ys=np.ones((5, 1)))
+    assert relerr(ym, g["pred_ym"]) < 1e-7 and relerr(lp, g["pred_lp"]) < 1e-7
+    # d > 16 (several coordinate slabs) and a ragged n, against the oracle
+    n, d = 700, 37
+    x, y = synth_reg(n, d, seed=3)
+    tr = g15_trees()["ard_plus_rqard"]
+    rng = np.random.RandomState(1)
+    hyp = np.concatenate([np.log(np.sqrt(d)) + 0.3 * rng.randn(d), [0.1], np.log(np.sqrt(d)) + 0.3 * rng.randn(d), [-0.2, 0.3]])
+    mm = pyGPs.GPR()
+    mm.setPrior(kernel=build(tr, hyp, d, compat=False))
+    mm.setNoise(np.log(0.1))
+    mm.setData(x, y)
+    nlZ, dnlZ, post = mm.getPosterior()
+    c = mm.meanfunc.hyp[0]
+    out = O.exact_fit(tr, hyp, 0, np.log(0.1), x, y, c * np.ones_like(y), np.ones_like(y), faithful=False,
+                      matern_reference_compat=False)
+    assert relerr(nlZ, out["nlZ"]) < 1e-9 and relerr(post.alpha, out["alpha"]) < 1e-7
+    assert np.allclose(dnlZ.cov, out["dnlZ_cov"], rtol=1e-6, atol=1e-7 * np.max(np.abs(out["dnlZ_cov"])))

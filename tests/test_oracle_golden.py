@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import golden, relerr, synth_reg, synth_cls, g11_trees, g14_trees, G11_1D
+from conftest import golden, relerr, synth_reg, synth_cls, g11_trees, g14_trees, g15_trees, G11_1D
 from oracle import gp_oracle as O
 
 KINDS = {"rbf": (O.RBF, 0), "rbfard": (O.RBFARD, 0), "matern1": (O.MATERN, 1), "matern3": (O.MATERN, 3),
@@ -242,4 +242,26 @@ def test_G14_composites_with_an_ard_leaf():
                                            rtol=1e-12, atol=1e-300)
     g = golden("G14_ep_ard_const_N200")
     out = O.ep_fit(trees["ep_ard_const"], g["cov_hyp"], 0, g["x"], g["y"], np.zeros_like(g["y"]))
+    assert relerr(out["nlZ"], g["nlZ"]) < 1e-9 and relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-7
+
+
+def test_G15_composites_with_two_ard_leaves():
+    trees = g15_trees()
+    x, y = synth_reg(300, 4)
+    for nm in ("ard_plus_rqard", "ard_times_ard", "scaled_ard_rq_ard"):
+        g = golden("G15_fit_%s_N300" % nm)
+        c = g["mean_hyp"][0]
+        hyp = g["cov_hyp"]
+        out = O.exact_fit(trees[nm], hyp, 0, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y), faithful=False)
+        assert relerr(out["nlZ"], g["nlZ"]) < 1e-11 and relerr(out["alpha"], g["alpha"]) < 1e-9, nm
+        assert np.allclose(out["dnlZ_cov"], g["dnlZ_cov"], rtol=1e-8, atol=1e-8 * np.max(np.abs(g["dnlZ_cov"]))), nm
+        kx, kz = g["kx"], g["kz"]
+        for mode, kw in (("train", dict(x=kx)), ("cross", dict(x=kx, z=kz)), ("self", dict(z=kz))):
+            mm = "self_test" if mode == "self" else mode
+            np.testing.assert_allclose(O.cov_matrix(trees[nm], hyp, 0, mode=mm, **kw), g["k_K_%s" % mode], rtol=1e-13, atol=1e-300)
+            for i in range(len(hyp)):
+                np.testing.assert_allclose(O.der_matrix(trees[nm], hyp, 0, mode=mm, der=i, **kw), g["k_dK%d_%s" % (i, mode)],
+                                           rtol=1e-12, atol=1e-300)
+    g = golden("G15_ep_ard_times_ard_N200")
+    out = O.ep_fit(trees["ep_ard_times_ard"], g["cov_hyp"], 0, g["x"], g["y"], np.zeros_like(g["y"]))
     assert relerr(out["nlZ"], g["nlZ"]) < 1e-9 and relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-7

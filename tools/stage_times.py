@@ -1,0 +1,19 @@
+"""Stage times of N=8192 fits under library options (results may be WRONG with experiment options such as ds_fake)."""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+from pygps_amd import _lib
+lib = _lib.load(); ctx = _lib.ctx()
+for o in sys.argv[1:]:
+    k, v = o.split('='); lib.pgp_set_option(ctx, k.encode(), int(v))
+N, d = 8192, 16
+rng = np.random.RandomState(0)
+x = rng.randn(N, d); w = rng.randn(d, 1)
+y = (np.sin(x @ w / np.sqrt(d)) + 0.1 * rng.randn(N, 1)).ravel()
+assert lib.pgp_set_data(ctx, _lib.ptr(x), N, d, _lib.ptr(y)) == 0
+hyp = np.array([np.log(np.sqrt(d)), 0.0]); m = np.full(N, y.mean()); dm = np.ones((1, N))
+alpha = np.zeros(N); nlZ = np.zeros(1); g = np.zeros(4)
+for it in range(4):
+    rc = lib.pgp_exact_fit(ctx, 0, _lib.ptr(hyp), 2, 0, 0, float(np.log(0.1)), _lib.ptr(m), _lib.ptr(dm), 1, 3,
+                           _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(g), None)
+    print(sys.argv[1:], "rc", rc, {k: round(v, 3) for k, v in _lib.last_timings().items()})
