@@ -78,6 +78,22 @@ _dll = None
 _ctx = {}
 
 
+def _torch_first():
+    """PyTorch's ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64 (same sonames as /opt/rocm's).  Whichever
+    copy is loaded first serves the whole process.  Measured on the round-2 GPU boxes: with THIS library loaded first
+    (runtime from /opt/rocm) and torch imported afterwards, one of the two then fails to see the GPU ("No HIP GPUs are
+    available" / "no ROCm-capable device is detected", node dependent); with torch imported first both run on torch's
+    copy and every order of initialisation works.  ShardedMinimize and bench.py use torch.distributed (RCCL) beside the
+    library, so torch is imported before the dlopen when it is installed (PYGPS_AMD_NO_TORCH=1 skips this; torch is
+    never needed for a fit)."""
+    if os.environ.get("PYGPS_AMD_NO_TORCH"):
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load():
     """dlopen the library and attach the prototypes.  Raises if it is not built."""
     global _dll
@@ -85,6 +101,7 @@ def load():
         return _dll
     with _lock:
         if _dll is None:
+            _torch_first()
             if not os.path.exists(LIB_PATH):
                 raise RuntimeError(
                     "pygps_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -155,27 +172,6 @@ class fit_stream(object):
         return False
 
 
-_torch_checked = False
-
-
-def _torch_first():
-    """PyTorch's ROCm wheels bundle their own copy of the HIP / HSA runtime.  Measured on the round-2 GPU boxes: when THIS
-    library (linked against /opt/rocm) brings its runtime up first, a later torch.cuda initialisation in the same process
-    fails with "No HIP GPUs are available"; the other order works.  ShardedMinimize and bench.py use torch.distributed
-    (RCCL) beside the library, so the first context creation lets torch initialise first when torch is installed
-    (PYGPS_AMD_NO_TORCH=1 skips this; torch is never needed for a fit)."""
-    global _torch_checked
-    if _torch_checked or os.environ.get("PYGPS_AMD_NO_TORCH"):
-        return
-    _torch_checked = True
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:
-        pass
-
-
 def ctx(device=None, slot=None):
     """Context (one device + its HIP streams + one workspace pool) of (device, fit-stream slot); created on first use."""
     if device is None:
@@ -186,7 +182,6 @@ def ctx(device=None, slot=None):
     if h is not None:
         return h
     dll = load()
-    _torch_first()
     with _lock:
         h = _ctx.get((device, slot))
         if h is None:

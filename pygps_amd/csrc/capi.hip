@@ -136,6 +136,8 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     if (!strcmp(name, "potrf_v1")) { c->potrf_v1 = value; return PGP_OK; }
     if (!strcmp(name, "dserver")) { c->dserver = value; return PGP_OK; }
+    if (!strcmp(name, "s_side")) { c->s_side = value; return PGP_OK; }
+    if (!strcmp(name, "la2")) { c->la2 = value; return PGP_OK; }
     if (!strcmp(name, "ds_exclusive")) { c->ds_exclusive = value; return PGP_OK; }
     if (!strcmp(name, "ds_fake")) { c->ds_fake = value; return PGP_OK; }
     if (!strcmp(name, "ds_timeout_ms")) { c->ds_timeout_s = 1e-3 * value; return PGP_OK; }
@@ -151,14 +153,27 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "ep_graph")) { c->ep_graph = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { cov_tile_set_grid(value); return PGP_OK; }
     if (!strcmp(name, "cu_reserve")) {
+        // value > 1: every value-th CU is kept free of bulk work; value < 0: the LAST -value CUs of the mask enumeration;
+        // value in (1000, 2000): the first value - 1000 CUs
         if (c->st_masked) { (void)hipStreamSynchronize(c->st_masked); (void)hipStreamDestroy(c->st_masked); c->st_masked = nullptr; }
         c->cu_reserve = value;
-        if (value > 1) {
+        if (value > 1 || value < 0) {
             const int ncu = c->prop.multiProcessorCount;
             std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            for (int i = 0; i < ncu; ++i)
-                if (i % value != value - 1) mask[i / 32] |= (1u << (i % 32));
+            for (int i = 0; i < ncu; ++i) {
+                bool keep;
+                if (value > 1000) keep = i >= value - 1000;
+                else if (value > 1) keep = i % value != value - 1;
+                else keep = i < ncu + value;
+                if (keep) mask[i / 32] |= (1u << (i % 32));
+            }
             HIP_TRY(hipExtStreamCreateWithCUMask(&c->st_masked, (uint32_t)mask.size(), mask.data()));
+            // the panel chain gets the complement: its kernels can only land on the CUs the bulk stream never uses
+            if (c->st_pan_masked) { (void)hipStreamSynchronize(c->st_pan_masked); (void)hipStreamDestroy(c->st_pan_masked); c->st_pan_masked = nullptr; }
+            std::vector<uint32_t> inv(mask.size(), 0u);
+            for (int i = 0; i < ncu; ++i)
+                if (!((mask[i / 32] >> (i % 32)) & 1u)) inv[i / 32] |= (1u << (i % 32));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&c->st_pan_masked, (uint32_t)inv.size(), inv.data()));
             if (!c->ev_fork) { HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
                                HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
         }
@@ -720,6 +735,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         HIP_TRY(hipEventRecord(c->ev_fork, c->st));
         HIP_TRY(hipStreamWaitEvent(c->st_masked, c->ev_fork, 0));
         main = c->st_masked;
+        if (c->st_pan_masked && !server) pan = c->st_pan_masked;
     }
     if (server) {
         // flags zeroed, then the server goes resident on the panel stream BEFORE any bulk work is queued
@@ -780,20 +796,94 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         HIP_TRY(hipStreamWaitEvent(main, c->ev_ds2, 0));
         return PGP_OK;
     }
+    if (la && c->la2 && !server) {
+        // Depth-2 look-ahead on three streams.  The critical chain  D(p) -> S(p) -> TU_a(p) -> D(p+1)  runs on the panel
+        // and side streams; the main stream only carries the big in-place updates TU_b(p), split so that the columns the
+        // NEXT chain step reads (panel p+2: TU_b1) come first.  The half-wave launches of the chain (S, TU_a: ~254 tiles on
+        // 512 slots) then overlap the previous panel's TU_b2 instead of running alone:
+        //   side : S(p) <- D(p);  TU_a(p) <- S(p), TU_b1(p-1);  [-> panel stream: D(p+1)]
+        //   main : TU_b1(p) <- S(p) (and TU_b2(p-1) by stream order);  TU_b2(p)
+        if (!c->st3) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_TRY(hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, hi));
+        }
+        hipStream_t side = c->st3;
+        std::vector<hipEvent_t>& e2 = c->la_ev;
+        while ((int)e2.size() < 6 * npanel + 6) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            e2.push_back(e);
+        }
+        auto EV = [&](int kind, int p) { return e2[kind * (npanel + 1) + p]; };   // 0: D done, 1: S done, 2: TU_a done, 3: TU_b1 done
+        HIP_TRY(hipEventRecord(EV(0, 0), main));                      // D(0) ran on main above
+        for (int p = 0; p < npanel; ++p) {
+            const int s0 = p * q, s1 = std::min(s0 + q, nblk);
+            HIP_TRY(hipStreamWaitEvent(side, EV(0, p), 0));
+            CHK(solve_below(c, m, s0, s1, Xs, ldx, side));
+            HIP_TRY(hipEventRecord(EV(1, p), side));
+            HIP_TRY(hipStreamWaitEvent(main, EV(1, p), 0));
+            if (s1 >= nblk) break;
+            const int n0 = s1, n1 = std::min(s1 + q, nblk), n2 = std::min(n1 + q, nblk);
+            if (p > 0) HIP_TRY(hipStreamWaitEvent(side, EV(3, p - 1), 0));          // panel p+1's columns carry update p-1
+            CHK(trailing_update2(c, m, s0, s1, n0, n1, Xs, ldx, side));            // TU_a -> staging
+            HIP_TRY(hipEventRecord(EV(2, p), side));
+            HIP_TRY(hipStreamWaitEvent(pan, EV(2, p), 0));
+            CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan));
+            HIP_TRY(hipEventRecord(EV(0, p + 1), pan));
+            CHK(trailing_update2(c, m, s0, s1, n1, n2, nullptr, 0, main));          // TU_b1: the next-next panel's columns
+            HIP_TRY(hipEventRecord(EV(3, p), main));
+            CHK(trailing_update2(c, m, s0, s1, n2, nblk, nullptr, 0, main));        // TU_b2: the rest
+        }
+        HIP_TRY(hipEventRecord(EV(4, 0), side));
+        HIP_TRY(hipStreamWaitEvent(main, EV(4, 0), 0));
+        HIP_TRY(hipEventRecord(EV(4, 1), pan));
+        HIP_TRY(hipStreamWaitEvent(main, EV(4, 1), 0));
+        if (main != c->st) {
+            HIP_TRY(hipEventRecord(c->ev_join, main));
+            HIP_TRY(hipStreamWaitEvent(c->st, c->ev_join, 0));
+        }
+        return PGP_OK;
+    }
+    const SweepMat& mc = m;
+    std::vector<hipEvent_t>& ev = c->la_ev;
+    // side stream: S(p+1) starts as soon as D(p+1) is done and overlaps the tail of TU_b(p) on the main stream
+    hipStream_t side = nullptr;
+    if (la && c->s_side) {
+        if (!c->st3) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_TRY(hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, hi));
+        }
+        side = c->st3;
+        while ((int)ev.size() < 4 * npanel + 4) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev.push_back(e);
+        }
+    }
     for (int p = 0; p < npanel; ++p) {
         const int s0 = p * q, s1 = std::min(s0 + q, nblk);
-        CHK(solve_below(c, m, s0, s1, Xs, ldx, main));
+        if (side && p > 0) {
+            // D(p) finished on the panel stream (la_ev[2(p-1)+1]): solve on the side stream, the main stream joins after it
+            HIP_TRY(hipStreamWaitEvent(side, c->la_ev[2 * (p - 1) + 1], 0));
+            CHK(solve_below(c, mc, s0, s1, Xs, ldx, side));
+            HIP_TRY(hipEventRecord(ev[2 * npanel + 3 + p], side));
+            HIP_TRY(hipStreamWaitEvent(main, ev[2 * npanel + 3 + p], 0));
+        } else {
+            CHK(solve_below(c, mc, s0, s1, Xs, ldx, main));
+        }
         if (s1 >= nblk) break;
         const int n0 = s1, n1 = std::min(s1 + q, nblk);              // next panel's columns
-        CHK(trailing_update2(c, m, s0, s1, n0, n1, Xs, ldx, main));  // TU_a -> staging
+        CHK(trailing_update2(c, mc, s0, s1, n0, n1, Xs, ldx, main));  // TU_a -> staging
         if (la) {
             HIP_TRY(hipEventRecord(c->la_ev[2 * p], main));
             HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
         }
         CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan));
         if (la) HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
-        CHK(trailing_update2(c, m, s0, s1, n1, nblk, nullptr, 0, main));   // TU_b in place, concurrent with D(p+1)
-        if (la) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
+        CHK(trailing_update2(c, mc, s0, s1, n1, nblk, nullptr, 0, main));   // TU_b in place, concurrent with D(p+1)
+        if (la && !side) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
     }
     if (main != c->st) {
         HIP_TRY(hipEventRecord(c->ev_join, main));

@@ -43,6 +43,7 @@ struct pgp_ctx {
     int ep_graph = 0;                   // EP: replay each 128-site block as a captured hipGraph (measured: no gain)
     int ep_block = 1;                   // EP: blocked site sweep (rank-1 updates folded every 128 sites); 0 = update Sigma per site
     int fused_inverse = 1;              // 1: L^-T falls out of the Cholesky sweep (appended identity rows); 0: recursive trtri
+    hipStream_t st_pan_masked = nullptr;  // panel stream restricted to the reserved CUs (complement of st_masked's mask)
     hipStream_t st_masked = nullptr;    // main stream of the look-ahead Cholesky restricted to a CU subset (option cu_reserve)
     int cu_reserve = 0;                 // reserve every cu_reserve-th CU for the panel stream (0 = off)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -71,6 +72,8 @@ struct pgp_ctx {
     int dserver = 0;                    // 1: diagonal panels factored by the resident server kernel (left-looking, runs ahead of the
                                         //    bulk); 0: by 13 launches each on the panel stream.  Measured equal single-stream (13.5 ms
                                         //    at N=8192), the launch chain is better with two fit streams per GPU (91 vs 81 fits/s)
+    int la2 = 0;                        // 1: depth-2 look-ahead on three streams (see potrf_blocked_v2)
+    int s_side = 0;                     // 1: the panel solves S(p) run on a side stream (overlap the tail of the previous trailing update)
     int ds_fake = 0;                    // experiment only: the server posts done[p] without factoring (WRONG results)
     int ds_exclusive = 1;               // 1: server workgroups claim a whole CU each (LDS padding)
     double ds_timeout_s = 10.0;         // every spin of the server (and of the main stream's wait kernel) is bounded

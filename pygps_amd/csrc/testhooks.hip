@@ -284,16 +284,17 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
     g.A = Ad; g.lda = lda; g.a_kc = a_kc; g.B = Bd; g.ldb = ldb; g.b_kc = b_kc; g.C = Cd; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.tri = tri; g.tri_off = 0; g.mask_diag = mask_diag;
     g.kmode = kmode; g.koff = koff; g.batch = 1; g.tile = tile; g.dbg = c->gemm_dbg;
-    int rc = gemm_f64_launch(g, c->st);
-    HIP_TRY(hipStreamSynchronize(c->st));
+    hipStream_t ts = c->st_masked ? c->st_masked : c->st;         // option cu_reserve: time the CU-masked stream
+    int rc = gemm_f64_launch(g, ts);
+    HIP_TRY(hipStreamSynchronize(ts));
     if (rc == PGP_OK) HIP_TRY(hipMemcpy(C, Cd, cn * 8, hipMemcpyDeviceToHost));
     if (rc == PGP_OK && iters > 0 && ms_out) {
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, c->st));
-        for (int i = 0; i < iters; ++i) rc = gemm_f64_launch(g, c->st);
-        HIP_TRY(hipEventRecord(e1, c->st));
-        HIP_TRY(hipStreamSynchronize(c->st));
+        HIP_TRY(hipEventRecord(e0, ts));
+        for (int i = 0; i < iters; ++i) rc = gemm_f64_launch(g, ts);
+        HIP_TRY(hipEventRecord(e1, ts));
+        HIP_TRY(hipStreamSynchronize(ts));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         *ms_out = ms / iters;

@@ -165,11 +165,14 @@ def test_exact_fit_golden_G6_cfg2_scale(lib):
         assert relerr(got["dnlZ"], np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7
 
 
-@pytest.mark.parametrize("opts", [dict(dserver=1), dict(dserver=1, ds_exclusive=0), dict(potrf_v1=1), dict(lookahead=0)])
+@pytest.mark.parametrize("opts", [dict(dserver=1), dict(dserver=1, ds_exclusive=0), dict(potrf_v1=1), dict(lookahead=0),
+                                  dict(la2=1), dict(s_side=1), dict(cu_reserve=-8), dict(cu_reserve=-8, s_side=1)])
 def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
     """Every schedule of the Cholesky sweep -- the default diagonal-panel chain, the resident diagonal-panel server
-    (left-looking, in-kernel go signals), the round-1 leaf chain and the serial order -- against the reference's own
-    numbers (G6: Core/inf.py:353-384 at N=2048 and at the benchmark size N=8192)."""
+    (left-looking, in-kernel go signals), the round-1 leaf chain, the serial order, and the measured-and-rejected
+    variants kept as options (depth-2 look-ahead, solves on a side stream, CU
+    reservation for the panel chain) -- against the reference's own numbers (G6: Core/inf.py:353-384 at N=2048 and
+    at the benchmark size N=8192)."""
     from pygps_amd import _lib
     ctx = _lib.ctx()
     try:
@@ -189,6 +192,7 @@ def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
     finally:
         for k in opts:
             lib.pgp_set_option(ctx, k.encode(), 1 if k in ("lookahead", "ds_exclusive") else 0)
+        lib.pgp_set_option(ctx, b"cu_reserve", 0)
 
 
 def test_exact_fit_golden_G7_ard_d64(lib):

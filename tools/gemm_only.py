@@ -17,6 +17,8 @@ tile = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 if len(sys.argv) > 7:
     lib.pgp_set_option(ctx, b"gemm_dbg", int(sys.argv[7]))
+if len(sys.argv) > 8:
+    lib.pgp_set_option(ctx, b"cu_reserve", int(sys.argv[8]))
 rng = np.random.RandomState(0)
 A = np.asfortranarray(rng.randn(M, K))
 B = np.asfortranarray(rng.randn(N, K))
@@ -24,4 +26,4 @@ Cm = np.asfortranarray(rng.randn(M, N))
 ms = C.c_double()
 rc = lib.pgp_test_gemm(ctx, tile, 0, 0, tri, 1 if tri else 0, 0, 0, -1.0, beta, _lib.ptr(A), M, _lib.ptr(B), N, _lib.ptr(Cm),
                        M, M, N, K, iters, C.byref(ms))
-print("rc", rc, "ms", ms.value, "TF", 2.0 * M * N * K * (0.5 if tri else 1) / ms.value / 1e9)
+print(sys.argv[1:], "rc", rc, "ms", ms.value, "TF", 2.0 * M * N * K * (0.5 if tri else 1) / ms.value / 1e9)
