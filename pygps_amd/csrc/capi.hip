@@ -138,6 +138,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "dserver")) { c->dserver = value; return PGP_OK; }
     if (!strcmp(name, "s_side")) { c->s_side = value; return PGP_OK; }
     if (!strcmp(name, "la2")) { c->la2 = value; return PGP_OK; }
+    if (!strcmp(name, "merge_tu")) { c->merge_tu = value; return PGP_OK; }
     if (!strcmp(name, "ds_exclusive")) { c->ds_exclusive = value; return PGP_OK; }
     if (!strcmp(name, "ds_fake")) { c->ds_fake = value; return PGP_OK; }
     if (!strcmp(name, "ds_timeout_ms")) { c->ds_timeout_s = 1e-3 * value; return PGP_OK; }
@@ -794,6 +795,39 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         }
         HIP_TRY(hipEventRecord(c->ev_ds2, pan));                      // the server has exited (or is about to)
         HIP_TRY(hipStreamWaitEvent(main, c->ev_ds2, 0));
+        return PGP_OK;
+    }
+    if (la && c->merge_tu && !server) {
+        // One trailing-update launch per panel (next panel's columns first, into the staging buffer); the tile that
+        // completes them releases stg[p+1] from inside the kernel and the panel stream -- parked on that flag -- factors
+        // the next diagonal block while the rest of the update runs.  No half-wave TU_a launch; the price is that the
+        // staged tiles share the first wave with everybody else (flag ~250 us after the launch instead of ~100).
+        HIP_TRY(hipMemsetAsync(c->dflags, 0, diag_server_flag_bytes(), main));
+        std::vector<hipEvent_t>& e2 = c->la_ev;
+        while ((int)e2.size() < 2 * npanel + 4) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            e2.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(e2[2 * npanel + 2], main));            // flags zeroed, D(0) done (main)
+        HIP_TRY(hipStreamWaitEvent(pan, e2[2 * npanel + 2], 0));
+        for (int p = 0; p < npanel; ++p) {
+            const int s0 = p * q, s1 = std::min(s0 + q, nblk);
+            CHK(solve_below(c, m, s0, s1, Xs, ldx, main));
+            if (s1 >= nblk) break;
+            const int n1 = std::min(s1 + q, nblk);
+            CHK(trailing_update2(c, m, s0, s1, s1, nblk, Xs, ldx, main, n1 - s1, nullptr, nullptr, 0, false,
+                                 diag_server_counter2(c->dflags, p + 1), diag_server_stage_flag(c->dflags, p + 1)));
+            CHK(diag_server_wait_staged(c->dflags, p + 1, c->ds_timeout_s, pan));
+            CHK(diag_factor(c, m, s1, n1, Xs + (long)s1 * 128, ldx, pan));
+            HIP_TRY(hipEventRecord(e2[2 * p + 1], pan));
+            HIP_TRY(hipStreamWaitEvent(main, e2[2 * p + 1], 0));      // S(p+1) needs D(p+1); TU(p) is done by then too
+        }
+        c->ds_used = true;
+        if (main != c->st) {
+            HIP_TRY(hipEventRecord(c->ev_join, main));
+            HIP_TRY(hipStreamWaitEvent(c->st, c->ev_join, 0));
+        }
         return PGP_OK;
     }
     if (la && c->la2 && !server) {

@@ -72,6 +72,7 @@ struct pgp_ctx {
     int dserver = 0;                    // 1: diagonal panels factored by the resident server kernel (left-looking, runs ahead of the
                                         //    bulk); 0: by 13 launches each on the panel stream.  Measured equal single-stream (13.5 ms
                                         //    at N=8192), the launch chain is better with two fit streams per GPU (91 vs 81 fits/s)
+    int merge_tu = 0;                   // 1: one trailing-update launch per panel, next diagonal block released by an in-kernel signal
     int la2 = 0;                        // 1: depth-2 look-ahead on three streams (see potrf_blocked_v2)
     int s_side = 0;                     // 1: the panel solves S(p) run on a side stream (overlap the tail of the previous trailing update)
     int ds_fake = 0;                    // experiment only: the server posts done[p] without factoring (WRONG results)

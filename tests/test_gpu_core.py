@@ -166,11 +166,11 @@ def test_exact_fit_golden_G6_cfg2_scale(lib):
 
 
 @pytest.mark.parametrize("opts", [dict(dserver=1), dict(dserver=1, ds_exclusive=0), dict(potrf_v1=1), dict(lookahead=0),
-                                  dict(la2=1), dict(s_side=1), dict(cu_reserve=-8), dict(cu_reserve=-8, s_side=1)])
+                                  dict(la2=1), dict(s_side=1), dict(merge_tu=1), dict(cu_reserve=-8), dict(cu_reserve=-8, s_side=1)])
 def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
     """Every schedule of the Cholesky sweep -- the default diagonal-panel chain, the resident diagonal-panel server
     (left-looking, in-kernel go signals), the round-1 leaf chain, the serial order, and the measured-and-rejected
-    variants kept as options (depth-2 look-ahead, solves on a side stream, CU
+    variants kept as options (depth-2 look-ahead, solves on a side stream, one merged update launch, CU
     reservation for the panel chain) -- against the reference's own numbers (G6: Core/inf.py:353-384 at N=2048 and
     at the benchmark size N=8192)."""
     from pygps_amd import _lib

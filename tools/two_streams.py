@@ -27,8 +27,9 @@ def worker(ctx, steps, out, k):
     out[k] = nlZ[0]
 
 
+import os
 opts = [tuple(o.split("=")) for o in sys.argv[1:]]
-for S in (1, 2):
+for S in tuple(int(v) for v in os.environ.get("NSTREAMS", "1,2").split(",")):
     ctxs = []
     for k in range(S):
         h = C.c_void_p()
