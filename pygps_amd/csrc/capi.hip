@@ -460,6 +460,7 @@ static int tri_tile_list(pgp_ctx* c, int mt, int nt, int off_tiles, const int** 
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
     if (!st) st = c->st;
     if (g.batch < 1) g.batch = 1;
+    g.dbg |= c->gemm_dbg;
     if (g.tri == 1 && !g.order && !c->xcd_order) {
         const int T = g.tile == 64 ? 64 : 128;
         CHK(tri_tile_list(c, g.M / T, g.N / T, g.tri_off / T, &g.order, &g.norder));

@@ -25,7 +25,7 @@ namespace {
 
 using gemm_tile_ns::BK;
 
-template <int TM, int TN, bool AKC, bool BKC>
+template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int mt = g.M / TM;
@@ -45,10 +45,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         ti = blockIdx.x % mt;
         tj = blockIdx.x / mt;
     }
-    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC>(g, ti, tj, blockIdx.z, smem);
+    if ((g.dbg & 32) && blockIdx.x >= 256 && blockIdx.x < 512) {      // experiment: de-phase the second workgroup of every CU
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < 7000) __builtin_amdgcn_s_sleep(10);                // ~70 us = half a K=512 tile
+    }
+    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA>(g, ti, tj, blockIdx.z, smem);
 }
 
-template <int T, bool AKC, bool BKC>
+template <int T, bool AKC, bool BKC, bool DMA = false>
 int launch_t(const GemmArgs& g, hipStream_t st) {
     constexpr int SK = BK + 2;
     constexpr int ASZ = AKC ? T * SK : BK * (T + 16);
@@ -60,11 +64,11 @@ int launch_t(const GemmArgs& g, hipStream_t st) {
     dim3 grid(nblk, 1, g.batch > 0 ? g.batch : 1);
     static std::atomic<size_t> attr_set{0};          // two fit streams (host threads) launch concurrently
     if (attr_set.load(std::memory_order_acquire) < shm) {
-        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC>,
+        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC, DMA>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set.store(shm, std::memory_order_release);
     }
-    hipLaunchKernelGGL((gemm_f64_kernel<T, T, AKC, BKC>), grid, dim3(256), shm, st, g);
+    hipLaunchKernelGGL((gemm_f64_kernel<T, T, AKC, BKC, DMA>), grid, dim3(256), shm, st, g);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
@@ -81,5 +85,8 @@ int launch_l(const GemmArgs& g, hipStream_t st) {
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PGP_OK;
     if (g.tile == 64) return launch_l<64>(g, st);
+    // LDS-DMA staging (dbg bit 64): 128 x 128 tiles of M-contiguous operands, whole 16-deep k-tiles
+    if ((g.dbg & 64) && !g.a_kc && !g.b_kc && (g.K % 16) == 0 && (g.koff % 16) == 0)
+        return launch_t<128, false, false, true>(g, st);
     return launch_l<128>(g, st);
 }

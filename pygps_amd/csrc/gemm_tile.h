@@ -10,8 +10,18 @@ namespace gemm_tile_ns {
 
 constexpr int BK = 16;
 
-template <int TM, int TN, bool AKC, bool BKC>
+// One 1 KiB LDS-DMA piece: every lane of the wave names 16 bytes of global memory, the 64 x 16 B land contiguously at
+// the (wave-uniform) LDS byte address in M0 -- no staging VGPRs, no ds_write.  Issued through asm so that hipcc does not
+// serialise it against the LDS reads of the other buffer (it cannot prove the two stages disjoint); completion is the
+// issuing wave's vmcnt, visibility to the other waves the barrier that follows (cdna guide, LDS-DMA).
+__device__ __forceinline__ void lds_dma_1k(const double* gptr, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(gptr), "s"(lds_byte_addr) : "memory");
+}
+
+template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, long bz, double* __restrict__ smem) {
+    static_assert(!DMA || (!AKC && !BKC && TM == 128 && TN == 128), "LDS-DMA staging: 128-wide M-contiguous operands only");
     constexpr int SA = TM + 16, SB = TN + 16, SK = BK + 2;
     constexpr int ASZ = AKC ? TM * SK : BK * SA;
     constexpr int BSZ = BKC ? TN * SK : BK * SB;
@@ -102,6 +112,28 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         for (int p = 0; p < BV; ++p) pb[p] = B + (long)(k0 + 2 * (t & 7)) + (long)(j0 + (t >> 3) + p * 32) * g.ldb;
         bstep = BK;
     }
+    // LDS-DMA variant: wave w stages k-rows w, w+4, w+8, w+12 of both operands (one 1 KiB piece = one k-row of 128 doubles)
+    const double* da[4];
+    const double* db[4];
+    if constexpr (DMA) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            da[p] = A + (long)(i0 + 2 * lane) + (long)(k0 + wave + 4 * p) * lda;
+            db[p] = B + (long)(j0 + 2 * lane) + (long)(k0 + wave + 4 * p) * g.ldb;
+        }
+    }
+    const unsigned smem_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem;
+    auto dma_stage = [&](int buf) {
+        const unsigned sa_b = smem_lds + (unsigned)(buf * STAGE) * 8u, sb_b = sa_b + (unsigned)ASZ * 8u;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned kr = (unsigned)(wave + 4 * p);
+            lds_dma_1k(da[p], __builtin_amdgcn_readfirstlane(sa_b + kr * (unsigned)(SA * 8)));
+            lds_dma_1k(db[p], __builtin_amdgcn_readfirstlane(sb_b + kr * (unsigned)(SB * 8)));
+            da[p] += (long)BK * lda;
+            db[p] += (long)BK * g.ldb;
+        }
+    };
     auto gload = [&](int) {
 #pragma unroll
         for (int p = 0; p < AV; ++p) { ra[p] = *(const double2_t*)pa[p]; pa[p] += astep; }
@@ -144,13 +176,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
     };
 
     if (k0 < k1) {
-        gload(k0);
-        sstore(0);
+        if constexpr (DMA) {
+            dma_stage(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            gload(k0);
+            sstore(0);
+        }
         __syncthreads();
         int buf = 0;
         for (int kt = k0; kt < k1; kt += BK) {
             const bool more = kt + BK < k1;
-            if (more && !(g.dbg & 1)) gload(kt + BK);
+            if constexpr (DMA) { if (more) dma_stage(buf ^ 1); }     // the other stage was last read before the previous barrier
+            else if (more && !(g.dbg & 1)) gload(kt + BK);
             const double* sa = smem + buf * STAGE;
             const double* sb = sa + ASZ;
             // fragments are double-buffered in registers: the LDS reads of k-step ks+1 are issued BEFORE the 16
@@ -180,7 +218,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
                     for (int im = 0; im < FM; ++im)
                         acc[im][in] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ks & 1][in], fa[ks & 1][im], acc[im][in], 0, 0, 0);
             }
-            if (more && !(g.dbg & 1)) sstore(buf ^ 1);
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (more && !(g.dbg & 1)) sstore(buf ^ 1);
             if (!(g.dbg & 2)) __syncthreads();
             if (!(g.dbg & 1)) buf ^= 1;
         }
