@@ -71,6 +71,7 @@ struct GemmArgs {
     // tile that brings it to sig_total stores 1 to *sig_flag (what the resident diagonal-panel server polls).
     unsigned* sig_counter; unsigned* sig_flag; int sig_cols; unsigned sig_total;
     unsigned* sig2_counter; unsigned* sig2_flag; int sig2_cols; unsigned sig2_total;      // a second, independent signal
+    long long* stamps;      // experiments: 4 wall-clock stamps per workgroup (start, first MFMA, loop end, stores done)
 };
 
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st);

@@ -141,13 +141,68 @@ __global__ __launch_bounds__(256) void ep_site_lazy_kernel(const double* __restr
     }
 }
 
-// EPT consecutive sites per launch.  The sites are sequentially dependent, but site t+1 only needs ROW i_(t+1) of the
-// factor columns, including the columns created by the sites before it in this launch -- single elements that any
-// workgroup can recompute in O(j) -- so every workgroup replays the EPT scalar site updates itself (wave 0, ~50
-// 64-lane reductions) and then computes its rows of all EPT new factor columns in one pass over S(r, 0..j0): the
-// chain of dependent kernel launches (~6 us each) gets EPT times shorter and S is read once instead of EPT times.
-constexpr int EPT = 8;
+// Latency-trimmed site update for the replay chain (4096 sequentially dependent evaluations per sweep: every cycle of
+// this function is on the critical path).  Same formulas as Core/inf.py:759-769 + lik.py:295-311, but: reciprocals by
+// v_rcp_f64 + one Newton step instead of IEEE division sequences (10 divisions per site), 1/sqrt by v_rsq_f64 + Newton, and
+// for z > -5 (the branch without asymptotics) N(z)/Phi(z) straight from Phi -- the reference's exp(log Phi) round trip and
+// log Phi itself are not needed for the derivatives.  Differences to the scalar path: a few ulp (parity tests: 1e-8).
+// value of lane `src` (compile-time constant after unrolling) in every lane: two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    r = r * fma(-h * r, r, 1.5);
+    r = r * fma(-h * r, r, 1.5);
+    return r;
+}
+__device__ __forceinline__ void ep_site_update(double sii, double mui, double tp, double np_, double mi, double yi,
+                                               double& t_new, double& nu_new, double& cj, double& qj) {
+    const double inv_sii = fast_rcp(sii);
+    const double tau_ni = inv_sii - tp;                                        // inf.py:759-760
+    const double nu_ni = fma(mui, inv_sii, mi * tau_ni) - np_;
+    const double inv_tau = fast_rcp(tau_ni);
+    const double mu_c = nu_ni * inv_tau, s2 = inv_tau;
+    const double ys = (yi < 0.0) ? -1.0 : 1.0;
+    const double rden = fast_rsqrt(1.0 + s2);
+    const double z = ys * mu_c * rden;
+    double n_p;
+    if (z > -5.0) {                                                            // lik.py:340-343 (naive ratio)
+        const double p = 0.5 * (1.0 + erf(z * 0.70710678118654752440));
+        n_p = exp(-0.5 * z * z) * 0.39894228040143267794 * fast_rcp(p);
+    } else {
+        n_p = erf_ratio(z, exp(erf_logphi(z)));
+    }
+    const double dlZ = ys * n_p * rden;                                        // lik.py:304-309
+    const double d2lZ = -n_p * (z + n_p) * (rden * rden);
+    const double w = fast_rcp(fma(d2lZ, inv_tau, 1.0));
+    t_new = fmax(-d2lZ * w, 0.0);                                              // inf.py:764-765
+    nu_new = (dlZ + (mi - mu_c) * d2lZ) * w;
+    const double ds2 = t_new - tp;
+    cj = ds2 * fast_rcp(fma(ds2, sii, 1.0));
+    const double dnu = nu_new - np_;
+    qj = dnu - cj * fma(dnu, sii, mui);
+}
 
+// EPT consecutive sites per launch.  The sites are sequentially dependent, but site t+1 only needs ROW i_(t+1) of the
+// factor columns, including those created by the sites before it in the same launch -- single elements any
+// workgroup can recompute -- so every workgroup replays the EPT scalar site updates itself and then computes its rows of
+// all EPT new factor columns in one pass over S(r, 0..j0): the chain of dependent kernel launches gets EPT times
+// shorter and S is read once instead of EPT times.
+// Round 2: the replay is split into (i) everything that only involves the j0 columns that existed before the launch --
+// the EPT x EPT Gram matrix G = Srow diag(c) Srow', the weighted rows gv and b0 = Srow q -- computed by all 256 threads
+// at once, and (ii) the EPT x EPT triangular recurrence over the columns created inside the launch, run by ONE wave with
+// lane = site and the in-launch entries in registers (shuffles instead of LDS round trips).  The serial part per launch
+// fell from ~40 wave reductions of length j0 to ~EPT probit evaluations: EPT = 16 (was 8), 14 -> 4 ms per sweep at N=4096.
+constexpr int EPT = 16;
 __global__ __launch_bounds__(256) void ep_sites_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
                                                             const long* __restrict__ base, int j0, double* __restrict__ S,
                                                             double* __restrict__ cvec, double* __restrict__ qvec,
@@ -156,52 +211,66 @@ __global__ __launch_bounds__(256) void ep_sites_lazy_kernel(const double* __rest
                                                             const double* __restrict__ ttau_prev,
                                                             const double* __restrict__ tnu_prev,
                                                             double* __restrict__ ttau_cur, double* __restrict__ tnu_cur) {
-    __shared__ double Srow[EPT][EPB + EPT];      // row i_t of the factor columns 0 .. j0+EPT-1
-    __shared__ double gv[EPT][EPB + EPT];        // g_t[k] = c_k Srow[t][k], k < j0 + t
-    __shared__ double cl[EPB + EPT], ql[EPB + EPT];
+    __shared__ double Srow[EPT][EPB + 1];        // row i_t of the factor columns 0 .. j0-1 (+1: bank spread)
+    __shared__ double gv[EPT][EPB + EPT];        // g_t[k] = c_k S(i_t, k), k < j0 + t
+    __shared__ double cl[EPB], ql[EPB];
     __shared__ double Sg[EPT][EPT];              // Sigma_blk(i_t, i_u)
+    __shared__ double G[EPT][EPT];               // sum_{k<j0} c_k S(i_t,k) S(i_u,k)
+    __shared__ double b0[EPT];                   // sum_{k<j0} q_k S(i_t,k)
     const int t = threadIdx.x, lane = t & 63;
     const long i0 = base[0] + j0;
     for (int v = t; v < EPT * j0; v += 256) { const int tt = v / j0, k = v % j0; Srow[tt][k] = S[i0 + tt + (long)k * ld]; }
     for (int k = t; k < j0; k += 256) { cl[k] = cvec[k]; ql[k] = qvec[k]; }
     if (t < EPT * EPT) Sg[t / EPT][t % EPT] = Sig[i0 + t / EPT + (i0 + t % EPT) * ld];
     __syncthreads();
-    if (t < 64) {                                // wave 0: the EPT scalar site updates, in order
-        for (int tt = 0; tt < EPT; ++tt) {
-            const long i = i0 + tt;
-            const int jt = j0 + tt;              // factor columns known so far for this site: k < jt
-            for (int u = 0; u < tt; ++u) {       // entries of the columns created in this launch, at row i
-                double a = 0.0;
-                for (int k = lane; k < j0 + u; k += 64) a = fma(gv[u][k], Srow[tt][k], a);
-                a = wave_sum(a);
-                a = __shfl(a, 0, 64);
-                if (lane == 0) Srow[tt][j0 + u] = Sg[tt][u] - a;
-                __builtin_amdgcn_wave_barrier();
-            }
+    for (int v = t; v < EPT * j0; v += 256) { const int tt = v / j0, k = v % j0; gv[tt][k] = cl[k] * Srow[tt][k]; }
+    __syncthreads();
+    {   // (i) Gram matrix (lower part) and b0: EPT (EPT+1) / 2 + EPT dots of length j0, one per thread
+        constexpr int NG = EPT * (EPT + 1) / 2;
+        if (t < NG) {
+            int tt = 0, rem = t;
+            while (rem > tt) { rem -= tt + 1; ++tt; }
+            const int u = rem;
+            double a = 0.0;
+            for (int k = 0; k < j0; ++k) a = fma(gv[u][k], Srow[tt][k], a);
+            G[tt][u] = a;
+        } else if (t < NG + EPT) {
+            const int tt = t - NG;
+            double a = 0.0;
+            for (int k = 0; k < j0; ++k) a = fma(ql[k], Srow[tt][k], a);
+            b0[tt] = a;
+        }
+    }
+    __syncthreads();
+    if (t < 64) {                                // (ii) one wave, lane L = site L (lanes >= EPT idle along)
+        const int L = lane < EPT ? lane : EPT - 1;
+        const long i = i0 + L;
+        double e[EPT], cN[EPT], qN[EPT];         // e[u] = S(i_L, j0 + u) for u < L; cN / qN: the sites' new (c, q), wave-uniform
+        const double Sgd = Sg[L][L] - G[L][L], mub = mu_blk[i] + b0[L];
+        const double tp = ttau_prev[i], np_ = tnu_prev[i], mi = m[i], yi = y[i];
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            // site u's scalar update, evaluated by every lane on its own row; lane u's result is the one that counts
             double a = 0.0, b = 0.0;
-            for (int k = lane; k < jt; k += 64) { const double sk = Srow[tt][k]; a = fma(cl[k] * sk, sk, a); b = fma(ql[k], sk, b); }
-            a = wave_sum(a); b = wave_sum(b);
-            a = __shfl(a, 0, 64); b = __shfl(b, 0, 64);
-            const double sii = Sg[tt][tt] - a;
-            const double mui = mu_blk[i] + b;
-            const double tau_ni = 1.0 / sii - ttau_prev[i];                    // inf.py:759-769
-            const double nu_ni = mui / sii + m[i] * tau_ni - tnu_prev[i];
-            double lZ, dlZ, d2lZ;
-            erf_ep_moments(y[i], nu_ni / tau_ni, 1.0 / tau_ni, &lZ, &dlZ, &d2lZ);
-            double t_new = -d2lZ / (1.0 + d2lZ / tau_ni);
-            t_new = fmax(t_new, 0.0);
-            const double nu_new = (dlZ + (m[i] - nu_ni / tau_ni) * d2lZ) / (1.0 + d2lZ / tau_ni);
-            const double ds2 = t_new - ttau_prev[i];
-            const double cj = ds2 / (1.0 + ds2 * sii);
-            const double dnu = nu_new - tnu_prev[i];
-            const double qj = dnu - cj * (mui + dnu * sii);
-            if (lane == 0) {
-                cl[jt] = cj; ql[jt] = qj;
-                if (blockIdx.x == 0) { ttau_cur[i] = t_new; tnu_cur[i] = nu_new; cvec[jt] = cj; qvec[jt] = qj; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (int k = lane; k < jt; k += 64) gv[tt][k] = cl[k] * Srow[tt][k];
-            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int v = 0; v < u; ++v) { a = fma(cN[v] * e[v], e[v], a); b = fma(qN[v], e[v], b); }
+            const double sii = Sgd - a;
+            const double mui = mub + b;
+            double t_new, nu_new, cj, qj;
+            ep_site_update(sii, mui, tp, np_, mi, yi, t_new, nu_new, cj, qj);
+            cN[u] = bcast_lane(cj, u);
+            qN[u] = bcast_lane(qj, u);
+            if (lane == u && blockIdx.x == 0) { ttau_cur[i] = t_new; tnu_cur[i] = nu_new; cvec[j0 + u] = cj; qvec[j0 + u] = qj; }
+            // column j0 + u at the rows of the later sites:  e_L[u] = Sigma_blk(i_L, i_u) - G[L][u] - sum_{v<u} c_v e_u[v] e_L[v]
+            double acc = Sg[L][u] - G[L > u ? L : u][L > u ? u : L];
+#pragma unroll
+            for (int v = 0; v < u; ++v) acc = fma(-cN[v] * bcast_lane(e[v], u), e[v], acc);
+            e[u] = acc;
+        }
+        if (lane < EPT) {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u)
+                if (u < L) gv[L][j0 + u] = cN[u] * e[u];
         }
     }
     __syncthreads();

@@ -25,6 +25,8 @@ namespace {
 
 using gemm_tile_ns::BK;
 
+__device__ int g_cu_arrivals[4096];       // de-phasing experiment (gemm_dbg & 32): arrivals per CU
+
 template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -45,9 +47,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         ti = blockIdx.x % mt;
         tj = blockIdx.x / mt;
     }
-    if ((g.dbg & 32) && blockIdx.x >= 256 && blockIdx.x < 512) {      // experiment: de-phase the second workgroup of every CU
-        const long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < 7000) __builtin_amdgcn_s_sleep(10);                // ~70 us = half a K=512 tile
+    if ((g.dbg & 32) && blockIdx.x < 512) {          // experiment: de-phase the two workgroups that share a CU (first wave only)
+        __shared__ int s_par;
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, 32 bits
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u; // HW_REG_XCC_ID
+            const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);                                  // cu_id, sh_id, se_id
+            s_par = atomicAdd(&g_cu_arrivals[key & 4095u], 1) & 1;
+        }
+        __syncthreads();
+        if (s_par) {
+            const long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < 7000) __builtin_amdgcn_s_sleep(10);                        // ~70 us = half a K=512 tile
+        }
     }
     gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA>(g, ti, tj, blockIdx.z, smem);
 }

@@ -61,6 +61,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
+#define GT_STAMP(i) do { if (g.stamps && t == 0) g.stamps[4L * blockIdx.x + (i)] = wall_clock64(); } while (0)
+    GT_STAMP(0);
     const int wm = (wave & 1) * (TM / 2), wn = (wave >> 1) * (TN / 2);
     const int l15 = lane & 15, l4 = lane >> 4;
 
@@ -184,6 +186,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             sstore(0);
         }
         __syncthreads();
+        if (g.stamps) {                       // the C pre-load has landed when its first use can issue
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GT_STAMP(1);
+        }
         int buf = 0;
         for (int kt = k0; kt < k1; kt += BK) {
             const bool more = kt + BK < k1;
@@ -225,6 +231,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         }
     }
 
+    GT_STAMP(2);
     // ---- epilogue: C = alpha * acc ---------------------------------------------------------
 #pragma unroll
     for (int im = 0; im < FM; ++im)
@@ -242,6 +249,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
                 }
             }
         }
+    if (g.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GT_STAMP(3); }
+#undef GT_STAMP
     // ---- completion signal for the resident diagonal-panel server (cdna guide G16: drain, barrier, ONE release) ----
     const bool s1 = g.sig_counter && j0 < g.sig_cols, s2 = g.sig2_counter && j0 < g.sig2_cols;
     if (s1 || s2) {

@@ -285,6 +285,9 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.tri = tri; g.tri_off = 0; g.mask_diag = mask_diag;
     g.kmode = kmode; g.koff = koff; g.batch = 1; g.tile = tile; g.dbg = c->gemm_dbg;
     hipStream_t ts = c->st_masked ? c->st_masked : c->st;         // option cu_reserve: time the CU-masked stream
+    long long* stamps = nullptr;
+    const long nwg = (long)(M / tile) * (N / tile);
+    if (c->gemm_dbg & 128) { HIP_TRY(hipMalloc((void**)&stamps, nwg * 4 * sizeof(long long))); g.stamps = stamps; }
     int rc = gemm_f64_launch(g, ts);
     HIP_TRY(hipStreamSynchronize(ts));
     if (rc == PGP_OK) HIP_TRY(hipMemcpy(C, Cd, cn * 8, hipMemcpyDeviceToHost));
@@ -299,6 +302,20 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         *ms_out = ms / iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    if (stamps) {                 // per-tile phase times of the LAST launch (wall clock, 100 MHz)
+        std::vector<long long> h((size_t)nwg * 4);
+        HIP_TRY(hipMemcpy(h.data(), stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        double a = 0, b = 0, d = 0, e = 0; long long tmin = h[0], tmax = 0;
+        for (long w = 0; w < nwg; ++w) {
+            a += (double)(h[4 * w + 1] - h[4 * w]); b += (double)(h[4 * w + 2] - h[4 * w + 1]); d += (double)(h[4 * w + 3] - h[4 * w + 2]);
+            e += (double)(h[4 * w + 3] - h[4 * w]);
+            tmin = std::min(tmin, h[4 * w]); tmax = std::max(tmax, h[4 * w + 3]);
+        }
+        fprintf(stderr, "gemm stamps: %ld tiles; per tile us: prologue (C pre-load + first stage) %.1f, k-loop %.1f, stores %.1f, total %.1f; "
+                        "kernel span %.1f us, sum(tile time)/512 slots = %.1f us\n", nwg, a / nwg / 100, b / nwg / 100, d / nwg / 100,
+                e / nwg / 100, (double)(tmax - tmin) / 100, e / 100 / 512);
+        (void)hipFree(stamps);
     }
     (void)hipFree(Ad); (void)hipFree(Bd); (void)hipFree(Cd);
     return rc;
