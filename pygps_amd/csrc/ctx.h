@@ -91,7 +91,10 @@ struct pgp_ctx {
     int64_t pc_launch[PC_COUNT];
     // cached tile-order tables (device), keyed by (mt, nt, tri, tri_off_tiles)
     std::map<std::vector<int>, std::pair<int*, int>> orders;
-    int gemm_dbg = 0;
+    // GEMM variant bits (also the experiment switches of gemm_f64 / gemm_tile.h): 64 LDS-DMA operand staging, 256 lazy C
+    // (fetched during the k-loop into the registers the DMA frees), 512 16-byte epilogue stores -- the measured-best set;
+    // 1/2/4/8 ablations, 16 atomic epilogue, 32 de-phased workgroups, 128 phase stamps
+    int gemm_dbg = 64 | 256 | 512;
     int xcd_order = 0;    // 1: XCD-aware super-tile order (measured slower on MI355X for these shapes: off)
     // options
     int nb_outer = 4;     // leaves (128 columns each) per outer panel -> trailing update K = 512

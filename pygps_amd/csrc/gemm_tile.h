@@ -19,6 +19,13 @@ __device__ __forceinline__ void lds_dma_1k(const double* gptr, unsigned lds_byte
                  :: "v"(gptr), "s"(lds_byte_addr) : "memory");
 }
 
+// value of the neighbouring lane (l ^ 1): DPP quad_perm [1,0,3,2] on both halves
+__device__ __forceinline__ double swap_adjacent(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, long bz, double* __restrict__ smem) {
     static_assert(!DMA || (!AKC && !BKC && TM == 128 && TN == 128), "LDS-DMA staging: 128-wide M-contiguous operands only");
@@ -72,7 +79,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
     // in-place tiles with beta = 1 may skip the C pre-load entirely: acc starts at zero and the epilogue adds alpha*acc
     // to C with fire-and-forget global_atomic_add_f64 (ONE add per element per launch: bitwise deterministic)
     const bool atomic_c = (g.dbg & 16) && g.beta == 1.0 && (!g.Cin || inplace) && !(g.zero_from && i0 >= g.zero_from);
-    const bool preload = g.beta != 0.0 && !(g.dbg & 4) && !(g.zero_from && i0 >= g.zero_from) && !atomic_c;
+    const bool wantc = g.beta != 0.0 && !(g.dbg & 4) && !(g.zero_from && i0 >= g.zero_from) && !atomic_c;
+    // LDS-DMA variant: the staging registers it frees hold one quarter of the C tile at a time, fetched DURING the k-loop
+    // and folded into the accumulators two k-steps later ("lazy C": the pre-load no longer delays the first MFMA)
+    const bool lazyc = DMA && wantc && (g.dbg & 256) && (k1 - k0) >= (FN * FM + 2) * BK;
+    const bool preload = wantc && !lazyc;
 #pragma unroll
     for (int im = 0; im < FM; ++im)
 #pragma unroll
@@ -191,7 +202,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             GT_STAMP(1);
         }
         int buf = 0;
-        for (int kt = k0; kt < k1; kt += BK) {
+        auto kstep = [&](int kt) {
             const bool more = kt + BK < k1;
             if constexpr (DMA) { if (more) dma_stage(buf ^ 1); }     // the other stage was last read before the previous barrier
             else if (more && !(g.dbg & 1)) gload(kt + BK);
@@ -228,11 +239,58 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             else if (more && !(g.dbg & 1)) sstore(buf ^ 1);
             if (!(g.dbg & 2)) __syncthreads();
             if (!(g.dbg & 1)) buf ^= 1;
+        };
+        int kt = k0;
+        if constexpr (DMA) {
+            if (lazyc) {          // first 2 FM FN / 2 k-steps, fully unrolled: chunk c = two accumulator tiles, fetched at step 2c,
+                double4_t creg[2];   // folded in at step 2c + 1 (16 VGPRs in flight; every accumulator index is a constant)
+#pragma unroll
+                for (int st = 0; st < FN * FM; ++st) {
+                    const int chunk = st >> 1, in = chunk / (FM / 2), hf = chunk % (FM / 2);
+                    if (!(st & 1)) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const double* cp = Cin + (long)(i0 + wm + (2 * hf + q) * 16 + l15) + (long)(j0 + wn + in * 16 + l4) * ldcin;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) creg[q][r] = cp[(long)(4 * r) * ldcin];
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[2 * hf + q][in][r] = fma(ab, creg[q][r], acc[2 * hf + q][in][r]);
+                    }
+                    kstep(kt);
+                    kt += BK;
+                }
+            }
         }
+        for (; kt < k1; kt += BK) kstep(kt);
     }
 
     GT_STAMP(2);
     // ---- epilogue: C = alpha * acc ---------------------------------------------------------
+    if (!diag && !atomic_c && !(g.dbg & 4) && (g.dbg & 512) && !(ldc & 1) && !((unsigned long)C & 15ul)) {
+        // 16-byte stores: adjacent lanes (rows m, m+1) trade one value each by a DPP quad_perm, then the even lane stores
+        // rows {m, m+1} of column n(r), the odd lane rows {m-1, m} of column n(r+1): half the store instructions (the
+        // epilogue is store-ISSUE bound: 64 global_store_dwordx2 per lane otherwise).  C is 16-byte aligned at even rows.
+        const bool odd = l15 & 1;
+#pragma unroll
+        for (int im = 0; im < FM; ++im)
+#pragma unroll
+            for (int in = 0; in < FN; ++in) {
+                const int m = wm + im * 16 + l15;
+                const int nb = wn + in * 16 + l4;
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const double x = g.alpha * acc[im][in][r], yv = g.alpha * acc[im][in][r + 1];
+                    const double nx = swap_adjacent(x), ny = swap_adjacent(yv);
+                    const double2_t val = odd ? double2_t{ny, yv} : double2_t{x, nx};
+                    double* cp = C + (long)(i0 + (odd ? m - 1 : m)) + (long)(j0 + nb + 4 * (odd ? r + 1 : r)) * ldc;
+                    *(double2_t*)cp = val;
+                }
+            }
+    } else {
 #pragma unroll
     for (int im = 0; im < FM; ++im)
 #pragma unroll
@@ -249,6 +307,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
                 }
             }
         }
+    }
     if (g.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GT_STAMP(3); }
 #undef GT_STAMP
     // ---- completion signal for the resident diagonal-panel server (cdna guide G16: drain, barrier, ONE release) ----
