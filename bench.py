@@ -227,6 +227,13 @@ def main():
     ap.add_argument("--option", action="append", default=[], help="library option name=value (experiments)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON).  Native libraries print there too (RCCL writes its version banner to
+    # the C stdout when the first communicator is made), so fd 1 is pointed at stderr for the life of the process and
+    # the JSON line goes out through a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -447,7 +454,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, d, args.cpu_budget)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -280,8 +280,9 @@ def test_bench_line_contract_small(lib):
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--n", "1024", "--steps", "4", "--warmup", "2",
                           "--windows", "2", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, lines        # ONE line on stdout: RCCL's banner and anything else native goes to stderr
+    j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in j, k
