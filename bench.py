@@ -352,6 +352,14 @@ def main():
         fit(args.warmup + s)
         lat_stage.append(_lib.last_timings(local))
     lat_ms = (time.perf_counter() - t1) / 6 * 1e3
+    # the same with E E^T kept OUT of the sweep (option eet_overlap=0): the stage time of the sweep + fused inverse alone,
+    # the figure rounds 1-2 quote as cholesky_sweep_* (2 N^3 / 3 flops); the default schedule folds E E^T into the sweep
+    sweep_stage = []
+    if lib.pgp_set_option(ctxs[0], b"eet_overlap", 0) == 0:
+        for s in range(6):
+            fit(args.warmup + s)
+            sweep_stage.append(_lib.last_timings(local))
+        lib.pgp_set_option(ctxs[0], b"eet_overlap", 3)
     if dist:
         res = torch.tensor(vals, dtype=torch.float64, device=cdev)
         parts = [torch.empty_like(res) for _ in range(world)]
@@ -385,9 +393,21 @@ def main():
             if name.startswith("gemm_f64"):
                 gl += v["launches"]; gm += v["ms"]; gf += v["flops"]
         alg = float(N) ** 3                                    # algorithmic flops of one fit that run in gemm_f64_kernel
-        achieved = alg * nfit / max(gm, 1e-12) / 1e9
+        achieved_all = alg * nfit / max(gm, 1e-12) / 1e9
+        # the dominant kernel = ONE instantiation (one row of the rocprofv3 kernel-stats CSV): the LDS-DMA 128 x 128 tile
+        # kernel that runs every trailing update and E E^T product.  Its algorithmic flops: N^3 per fit minus everything
+        # the OTHER gemm_f64 instantiations execute (panel solves, 64-tile updates of the leaf chain; executed >= algorithmic
+        # there, so this is a lower bound)
+        kd = next((v for k_, v in prof.items() if k_.startswith("kernel gemm_f64_kernel<128,128,false,false,true>")), None)
+        if kd and kd["launches"]:
+            alg_dom = alg * nfit - (gf - kd["flops"])
+            dom_ms, dom_l = kd["ms"], kd["launches"]
+        else:
+            alg_dom, dom_ms, dom_l = alg * nfit, gm, gl
+        achieved = alg_dom / max(dom_ms, 1e-12) / 1e9
         # stage time of the UN-profiled single-stream fits (the per-launch HIP events of the profiled pass stretch the chain)
-        potrf_ms = float(np.median([t["potrf"] for t in lat_stage]))
+        potrf_ms = float(np.median([t["potrf"] for t in (sweep_stage or lat_stage)]))
+        fact_ms = float(np.median([t["potrf"] + t["lauum"] for t in lat_stage]))
         traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", "r02_gemm_f64_hbm_traffic.json")
         if os.path.exists(tpath):
@@ -396,17 +416,30 @@ def main():
                 traffic, tsrc = tj.get("bytes_per_launch"), "profiles/r02_gemm_f64_hbm_traffic.json (rocprofv3 --pmc passes of this command line, not re-measured in this run)"
             except Exception:
                 traffic = None
-        roof = {"kernel": "gemm_f64_kernel (fp64 MFMA: Cholesky trailing updates + panel solves incl. the fused inverse, E E^T)",
+        roof = {"kernel": "gemm_f64_kernel<128,128,false,false,true> (fp64 MFMA, LDS-DMA operand staging: every trailing update of "
+                          "the Cholesky sweep incl. the fused inverse, and the E E^T products)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_MFMA_TF, "traffic": traffic, "traffic_source": tsrc,
-                "how": "N^3 algorithmic flops per fit / summed HIP-event durations of every gemm_f64 launch, %d single-stream fits" % args.prof_steps,
-                "launches_per_fit": gl / nfit, "flops_per_launch": alg * nfit / max(gl, 1), "avg_launch_ms": gm / max(gl, 1),
+                "how": "algorithmic flops of this instantiation's launches (N^3 per fit minus what the other gemm_f64 "
+                       "instantiations execute) / summed HIP-event durations of its launches, %d single-stream fits" % args.prof_steps,
+                "launches_per_fit": dom_l / nfit, "flops_per_launch": alg_dom / max(dom_l, 1), "avg_launch_ms": dom_ms / max(dom_l, 1),
+                "algorithmic_flops_per_fit": alg_dom / nfit,
+                "all_gemm_f64_instantiations": {
+                    "achieved": achieved_all, "frac": achieved_all / PEAK_FP64_MFMA_TF, "launches_per_fit": gl / nfit,
+                    "avg_launch_ms": gm / max(gl, 1),
+                    "what": "rounds 1-2 definition: N^3 per fit / summed durations of EVERY gemm_f64 launch, the 64-tile "
+                            "updates of the latency-bound leaf chain included (their event durations overlap the bulk kernels)"},
                 "executed_over_algorithmic_flops": gf / (alg * nfit),
                 "timed_window": {"streams": S, "TFLOPs_end_to_end": alg / (dt / args.steps) / 1e12,
                                  "frac_of_peak": alg / (dt / args.steps) / 1e12 / PEAK_FP64_MFMA_TF,
                                  "what": "N^3 x K fits / window time: every kernel and every gap of the timed region included"},
                 # the Cholesky sweep also produces L^-T (fused triangular inverse): 2 N^3 / 3 algorithmic flops in that stage
-                "cholesky_sweep_ms": potrf_ms, "cholesky_sweep_ms_profiled_pass": float(np.median([t["potrf"] for t in prof_stage])),
+                "factor_inverse_EEt": {"ms": fact_ms, "TFLOPs": alg / (fact_ms * 1e-3) / 1e12,
+                                       "frac_of_peak": alg / (fact_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TF,
+                                       "what": "default schedule, one fit stream: Cholesky sweep + fused inverse + E E^T (accumulated "
+                                               "panel by panel under the sweep) = N^3 flops / (potrf + lauum stage time)"},
+                "cholesky_sweep_what": "sweep + fused inverse alone (2 N^3 / 3 flops), 6 single-stream fits with option eet_overlap=0",
+                "cholesky_sweep_ms": potrf_ms,
                 "cholesky_sweep_TFLOPs": (2.0 * N ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12,
                 "cholesky_sweep_frac_of_peak": (2.0 * N ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TF}
         asm = prof.get("cov_tile_kernel(assemble)")

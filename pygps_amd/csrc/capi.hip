@@ -2,6 +2,7 @@
 // panel (outer K = 512 trailing updates on the fp64 MFMA GEMM, inner 128-wide leaves), recursive
 // triangular inverse, W^T W, fused gradient reduce.  See DESIGN.md for the pipeline.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,7 @@ void prof_collect(pgp_ctx* c) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);
         c->pc_ms[r.cls] += ms; c->pc_flops[r.cls] += r.flops; c->pc_bytes[r.cls] += r.bytes; c->pc_launch[r.cls]++;
+        if (r.shadow >= 0) { c->pc_ms[r.shadow] += ms; c->pc_flops[r.shadow] += r.flops; c->pc_launch[r.shadow]++; }
         if (getenv("PGP_PROF_DUMP"))
             fprintf(stderr, "prof %-34s %8.4f ms %10.3f GF %7.2f TF\n", kProfNames[r.cls], ms, r.flops * 1e-9,
                     ms > 0 ? r.flops / (ms * 1e-3) * 1e-12 : 0.0);
@@ -139,6 +141,11 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "s_side")) { c->s_side = value; return PGP_OK; }
     if (!strcmp(name, "la2")) { c->la2 = value; return PGP_OK; }
     if (!strcmp(name, "merge_tu")) { c->merge_tu = value; return PGP_OK; }
+    if (!strcmp(name, "eet_overlap")) { if (value < 0 || value > 3) return -2; c->eet_overlap = value; return PGP_OK; }
+    if (!strcmp(name, "eet_max_panels")) { c->eet_max_panels = value; return PGP_OK; }
+    if (!strcmp(name, "eet_merge")) { c->eet_merge = value; return PGP_OK; }
+    if (!strcmp(name, "eet_tail")) { if (value < 1) return -2; c->eet_tail = value; return PGP_OK; }
+    if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
     if (!strcmp(name, "ds_exclusive")) { c->ds_exclusive = value; return PGP_OK; }
     if (!strcmp(name, "ds_fake")) { c->ds_fake = value; return PGP_OK; }
     if (!strcmp(name, "ds_timeout_ms")) { c->ds_timeout_s = 1e-3 * value; return PGP_OK; }
@@ -469,8 +476,24 @@ int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
         const int T = g.tile == 64 ? 64 : 128;
         CHK(tile_order(c, g.M / T, g.N / T, g.tri, g.tri ? g.tri_off / T : 0, &g.order, &g.norder));
     }
-    ProfScope ps(c, cls, g.flops, 0.0, st);
+    ProfScope ps(c, cls, g.flops, 0.0, st, gemm_f64_uses_dma128(g) ? PC_KERNEL_DMA128 : -1);
     return gemm_f64_launch(g, st);
+}
+
+// a and b in ONE grid when both qualify for the merged 128-tile kernel, else one after the other
+static int gemm_prof_pair(pgp_ctx* c, int cls_a, GemmArgs a, int cls_b, GemmArgs b, hipStream_t st) {
+    if (!st) st = c->st;
+    a.dbg |= c->gemm_dbg; b.dbg |= c->gemm_dbg;
+    if (a.batch < 1) a.batch = 1;
+    if (b.batch < 1) b.batch = 1;
+    if (c->xcd_order || !gemm_f64_dual_ok(a, b)) {
+        CHK(gemm_prof(c, cls_a, a, st));
+        return gemm_prof(c, cls_b, b, st);
+    }
+    if (a.tri == 1 && !a.order) CHK(tri_tile_list(c, a.M / 128, a.N / 128, a.tri_off / 128, &a.order, &a.norder));
+    if (b.tri == 1 && !b.order) CHK(tri_tile_list(c, b.M / 128, b.N / 128, b.tri_off / 128, &b.order, &b.norder));
+    ProfScope ps(c, cls_a, a.flops + b.flops, 0.0, st, PC_KERNEL_DMA128);
+    return gemm_f64_dual_launch(a, b, st);
 }
 
 // Blocked right-looking Cholesky of the (mrows x np) column-major lower matrix F (mrows >= np; rows
@@ -654,8 +677,9 @@ static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const doub
 static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c0, int c1, double* out, long ldx,
                             hipStream_t st, int stage_blocks = 0, unsigned* sig_counter = nullptr,
                             unsigned* sig_flag = nullptr, int sig_blocks = 0, bool skip_stage_diag = false,
-                            unsigned* stg_counter = nullptr, unsigned* stg_flag = nullptr) {
-    if (c1 <= c0) return PGP_OK;
+                            unsigned* stg_counter = nullptr, unsigned* stg_flag = nullptr,
+                            const GemmArgs* extra = nullptr) {
+    if (c1 <= c0) return extra ? gemm_prof(c, PC_GEMM_LAUUM, *extra, st) : PGP_OK;
     const long r0 = (long)c0 * 128, r1 = m.mrows + (m.E ? (long)k1 * 128 : 0);
     GemmArgs g{};
     g.A = m.F + r0 + (long)k0 * 128 * m.ldf; g.lda = m.ldf; g.a_kc = 0;
@@ -710,7 +734,29 @@ static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c
         }
     }
     g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
+    if (extra) return gemm_prof_pair(c, PC_GEMM_TRAIL, g, PC_GEMM_LAUUM, *extra, st);
     return gemm_prof(c, PC_GEMM_TRAIL, g, st);
+}
+
+// Filler: B^-1 (lower) += E_p E_p^T with E_p = columns [s0, s1) of E = L^-T, which are FINAL once S(p) has run (right-
+// looking sweep).  E_p is non-zero in rows < 128 s1 only, so the product covers the leading 128 s1 square; its rows
+// >= 128 s0 are touched for the first time (zero_from), and inside the diagonal block k starts at the row (KM_GE_I).
+static GemmArgs eet_panel_args(pgp_ctx* c, const SweepMat& m, int s0, int s1, double* Binv, long ldb) {
+    GemmArgs g{};
+    g.A = m.E + (long)s0 * 128 * m.lde; g.lda = m.lde; g.a_kc = 0;
+    g.B = g.A; g.ldb = m.lde; g.b_kc = 0;
+    g.C = Binv; g.ldc = ldb;
+    g.M = s1 * 128; g.N = s1 * 128; g.K = (s1 - s0) * 128; g.alpha = 1.0; g.beta = s0 > 0 ? 1.0 : 0.0;
+    g.tri = 2; g.mask_diag = 1; g.kmode = KM_GE_I; g.koff = -s0 * 128;
+    if (s0 > 0) g.zero_from = s0 * 128;
+    const long t128 = (long)s1 * (s1 + 1) / 2;
+    g.tile = (t128 < c->small_tile_below || c->eet_tile == 64) ? 64 : 128;
+    const double w = (double)g.K, r0 = 128.0 * s0;
+    g.flops = w * r0 * r0 + w * w * r0 + w * w * w / 3.0;      // old x old (lower) + new x old (k >= row) + new x new
+    return g;
+}
+static int eet_panel(pgp_ctx* c, const SweepMat& m, int s0, int s1, double* Binv, long ldb, hipStream_t st) {
+    return gemm_prof(c, PC_GEMM_LAUUM, eet_panel_args(c, m, s0, s1, Binv, ldb), st);
 }
 
 static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
@@ -897,6 +943,28 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
             ev.push_back(e);
         }
     }
+    // filler stream: panel p's share of B^-1 = E E^T is queued as soon as S(p) has produced the final columns p of E; it
+    // fills the slots the dependent chain leaves idle (lowest priority), instead of one long product after the sweep
+    hipStream_t fill = nullptr;
+    c->eet_join = nullptr;
+    // eet_overlap: 1 = filler stream, 2 = inline (behind / inside TU_b on the main stream), 3 = inline up to
+    // eet_max_panels panels (default: beyond that the chain is amortised and the one-shot long-K product is faster)
+    const bool fill_inline = la && m.E && c->eet_out &&
+                             (c->eet_overlap == 2 || (c->eet_overlap == 3 && npanel <= c->eet_max_panels));
+    c->eet_inline_done = false;
+    if (la && c->eet_overlap == 1 && m.E && c->eet_out) {
+        if (!c->st_fill) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_TRY(hipStreamCreateWithPriority(&c->st_fill, hipStreamNonBlocking, lo));
+        }
+        fill = c->st_fill;
+        while ((int)c->fill_ev.size() < npanel + 1) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->fill_ev.push_back(e);
+        }
+    }
     for (int p = 0; p < npanel; ++p) {
         const int s0 = p * q, s1 = std::min(s0 + q, nblk);
         if (side && p > 0) {
@@ -908,6 +976,15 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         } else {
             CHK(solve_below(c, mc, s0, s1, Xs, ldx, main));
         }
+        if (fill && (p < npanel - c->eet_tail || s1 >= nblk)) {
+            // the last eet_tail panels are folded into ONE product after the last solve (K = eet_tail w: the filler is
+            // starved while trailing updates are queued, so the end of the sweep finds a backlog anyway)
+            const int f0 = s1 >= nblk ? std::max(0, npanel - c->eet_tail) * q : s0;
+            HIP_TRY(hipEventRecord(c->fill_ev[p], main));
+            HIP_TRY(hipStreamWaitEvent(fill, c->fill_ev[p], 0));
+            CHK(eet_panel(c, mc, std::min(f0, s0), s1, c->eet_out, c->eet_ld, fill));
+            if (s1 >= nblk) { HIP_TRY(hipEventRecord(c->fill_ev[npanel], fill)); c->eet_join = c->fill_ev[npanel]; }
+        }
         if (s1 >= nblk) break;
         const int n0 = s1, n1 = std::min(s1 + q, nblk);              // next panel's columns
         CHK(trailing_update2(c, mc, s0, s1, n0, n1, Xs, ldx, main));  // TU_a -> staging
@@ -917,8 +994,24 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         }
         CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan));
         if (la) HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
-        CHK(trailing_update2(c, mc, s0, s1, n1, nblk, nullptr, 0, main));   // TU_b in place, concurrent with D(p+1)
+        // inline filler: panel p's share of E E^T in the SAME grid as TU_b(p) (or right behind it when the shapes do not
+        // qualify) -- the main stream stays busy until D(p+1) is done instead of waiting for it, no third stream
+        if (fill_inline) {
+            const GemmArgs fa = eet_panel_args(c, mc, s0, s1, c->eet_out, c->eet_ld);
+            if (c->eet_merge)
+                CHK(trailing_update2(c, mc, s0, s1, n1, nblk, nullptr, 0, main, 0, nullptr, nullptr, 0, false, nullptr, nullptr, &fa));
+            else {
+                CHK(trailing_update2(c, mc, s0, s1, n1, nblk, nullptr, 0, main));
+                CHK(gemm_prof(c, PC_GEMM_LAUUM, fa, main));
+            }
+        } else
+            CHK(trailing_update2(c, mc, s0, s1, n1, nblk, nullptr, 0, main));   // TU_b in place, concurrent with D(p+1)
         if (la && !side) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
+    }
+    if (fill_inline) {
+        const int s0 = (npanel - 1) * q;
+        CHK(eet_panel(c, mc, s0, nblk, c->eet_out, c->eet_ld, main));
+        c->eet_inline_done = true;
     }
     if (main != c->st) {
         HIP_TRY(hipEventRecord(c->ev_join, main));
@@ -1203,7 +1296,13 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     CHK(aug_rhs_launch(c->y_dev, c->m_dev, n, F, ldf, np, c->rvec, st));
     // ---- S2: Cholesky (forward substitution of the augmented row -- and L^-T -- ride along) ----------
     HIP_TRY(hipEventRecord(c->ev[1], st));
-    CHK(potrf_blocked(c, F, ldf, np, np + 128, fused, E, lde));
+    c->eet_inline_done = false;
+    if (fused && !c->potrf_v1) { c->eet_out = c->Binv; c->eet_ld = np; }
+    c->eet_join = nullptr;
+    const int prc = potrf_blocked(c, F, ldf, np, np + 128, fused, E, lde);
+    c->eet_out = nullptr;
+    if (prc != PGP_OK && c->st_fill) (void)hipStreamSynchronize(c->st_fill);     // queued products still read the scratch E
+    CHK(prc);
     HIP_TRY(hipEventRecord(c->ev[2], st));
     int info = 0;
     // ---- S5a/S3: W = L^-1, alpha = W^T z / sn2 (or blocked back-substitution when W is not needed)
@@ -1229,7 +1328,9 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     HIP_TRY(hipEventRecord(c->ev[4], st));
     // ---- S5b: B^-1 = W^T W ; S6: gradient reduce ------------------------------------------------
     if (want >= 3) {
-        if (fused) CHK(eet_lower(c, E, lde, c->Binv, np, np));                        // B^-1 = W^T W = E E^T
+        if (fused && c->eet_inline_done) { }                                           // accumulated inside the sweep
+        else if (fused && c->eet_join) HIP_TRY(hipStreamWaitEvent(st, c->eet_join, 0));   // accumulated under the sweep
+        else if (fused) CHK(eet_lower(c, E, lde, c->Binv, np, np));                   // B^-1 = W^T W = E E^T
         else CHK(lauum_lower(c, c->W, np, c->Binv, np, np));
         HIP_TRY(hipEventRecord(c->ev[5], st));
         // alpha currently holds W^T z / sn2 = B^-1 r / sn2  (already the final alpha)

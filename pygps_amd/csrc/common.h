@@ -75,3 +75,7 @@ struct GemmArgs {
 };
 
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st);
+// two independent products in one grid (both must qualify for the 128-tile LDS-DMA form: gemm_f64_dual_ok)
+bool gemm_f64_uses_dma128(const GemmArgs& g);       // would gemm_f64_launch pick the LDS-DMA 128-tile instantiation?
+bool gemm_f64_dual_ok(const GemmArgs& a, const GemmArgs& b);
+int gemm_f64_dual_launch(const GemmArgs& a, const GemmArgs& b, hipStream_t st);

@@ -10,13 +10,16 @@
 #include "sqdist_tile.h"
 
 enum ProfClass { PC_ASSEMBLE = 0, PC_GEMM_TRAIL, PC_GEMM_INNER, PC_LEAF, PC_TRSM, PC_LEAFINV, PC_GEMM_TRTRI,
-                 PC_GEMM_LAUUM, PC_HADAMARD, PC_SMALL, PC_GEMM_SOLVE, PC_DIAG, PC_COUNT };
+                 PC_GEMM_LAUUM, PC_HADAMARD, PC_SMALL, PC_GEMM_SOLVE, PC_DIAG, PC_KERNEL_DMA128, PC_COUNT };
 static const char* const kProfNames[PC_COUNT] = {
     "cov_tile_kernel(assemble)", "gemm_f64(potrf trailing syrk)", "gemm_f64(potrf inner update)",
     "leaf_potrf_kernel", "trsm_rows_kernel", "leaf_inv_kernel", "gemm_f64(trtri)", "gemm_f64(lauum W^T W)",
-    "hadamard_reduce_kernel", "small/O(N) kernels", "gemm_f64(panel solve X E_D)", "diag_in/out staging"};
+    "hadamard_reduce_kernel", "small/O(N) kernels", "gemm_f64(panel solve X E_D)", "diag_in/out staging",
+    // shadow class: every launch of the dominant kernel INSTANTIATION (one row of a rocprofv3 kernel-stats CSV), whatever
+    // its purpose class above -- each such launch is counted here AND in its purpose class
+    "kernel gemm_f64_kernel<128,128,false,false,true> (+ dual)"};
 
-struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
+struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; int shadow; };
 
 struct pgp_factor {
     long n, np, ldf;
@@ -38,6 +41,18 @@ struct pgp_ctx {
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky
     hipStream_t st3 = nullptr;          // panel-solve stream (sweep v2 with the resident server)
+    hipStream_t st_fill = nullptr;      // low-priority filler stream: B^-1 accumulated panel by panel under the sweep (eet_overlap)
+    std::vector<hipEvent_t> fill_ev;
+    double* eet_out = nullptr;          // set by the fit for the duration of one sweep: where the filler accumulates B^-1
+    long eet_ld = 0;
+    hipEvent_t eet_join = nullptr;      // non-null: the sweep queued every panel product; the fit joins st_fill on this event
+    int eet_tail = 1;                   // the last eet_tail panels go into ONE final product (longer K, after the sweep)
+    int eet_tile = 128;                 // tile size of the filler products (64: shorter workgroups in the way of the chain)
+    bool eet_inline_done = false;
+    int eet_merge = 0;                  // inline filler: 1 = same grid as TU_b (gemm_f64_dual_kernel), 0 = its own launch behind it
+    int eet_overlap = 3;                // B^-1 = sum_p E_p E_p^T accumulated under the sweep: 0 off (one product after it), 1 on a
+                                        // low-priority filler stream, 2 inline on the main stream, 3 inline when npanel <= eet_max_panels
+    int eet_max_panels = 16;
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
     int ep_graph = 0;                   // EP: replay each 128-site block as a captured hipGraph (measured: no gain)
@@ -149,9 +164,9 @@ static inline void pool_free(pgp_ctx* c, size_t bytes, void* p) {
 }
 
 struct ProfScope {
-    pgp_ctx* c; int cls; double flops, bytes; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t s;
-    ProfScope(pgp_ctx* c_, int cls_, double f, double b, hipStream_t s_ = nullptr)
-        : c(c_), cls(cls_), flops(f), bytes(b), s(s_ ? s_ : c_->st) {
+    pgp_ctx* c; int cls; double flops, bytes; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t s; int shadow;
+    ProfScope(pgp_ctx* c_, int cls_, double f, double b, hipStream_t s_ = nullptr, int shadow_ = -1)
+        : c(c_), cls(cls_), flops(f), bytes(b), s(s_ ? s_ : c_->st), shadow(shadow_) {
         if (!c->prof) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -165,7 +180,7 @@ struct ProfScope {
     ~ProfScope() {
         if (!c->prof) return;
         (void)hipEventRecord(e1, s);
-        c->recs.push_back({cls, e0, e1, flops, bytes});
+        c->recs.push_back({cls, e0, e1, flops, bytes, shadow});
     }
 };
 

@@ -27,26 +27,47 @@ using gemm_tile_ns::BK;
 
 __device__ int g_cu_arrivals[4096];       // de-phasing experiment (gemm_dbg & 32): arrivals per CU
 
-template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int mt = g.M / TM;
-    int ti, tj;
+// tile (ti, tj) of workgroup number b of a launch described by g; false: padding entry, nothing to do
+__device__ __forceinline__ bool decode_tile(const GemmArgs& g, int b, int T, int& ti, int& tj) {
     if (g.order) {                                  // host-built tile order (see tile_order() in capi.hip)
-        ti = g.order[2 * blockIdx.x];
-        tj = g.order[2 * blockIdx.x + 1];
-        if (ti < 0) return;                         // padding entry
-    } else if (g.tri == 2) {                               // packed lower-triangular tile index
-        const int b = blockIdx.x;
+        ti = g.order[2 * b];
+        tj = g.order[2 * b + 1];
+        return ti >= 0;
+    }
+    if (g.tri == 2) {                               // packed lower-triangular tile index
         int r = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
         while ((long)(r + 1) * (r + 2) / 2 <= b) ++r;
         while ((long)r * (r + 1) / 2 > b) --r;
         ti = r;
         tj = b - r * (r + 1) / 2;
-    } else {
-        ti = blockIdx.x % mt;
-        tj = blockIdx.x / mt;
+        return true;
     }
+    const int mt = g.M / T;
+    ti = b % mt;
+    tj = b / mt;
+    return true;
+}
+
+// Two independent products in ONE grid: workgroups [0, na) work on `a`, the rest on `b`.  Used by the Cholesky sweep to
+// append panel p's share of B^-1 = E E^T to the trailing update TU_b(p): consecutive launches on one stream drain the
+// chip at every boundary (the partial last wave of one kernel runs alone), a merged grid has one tail instead of two.
+struct GemmArgsPair { GemmArgs g[2]; int na; };
+template <int TM, int TN, bool AKC, bool BKC, bool DMA>
+__global__ __launch_bounds__(256, 2) void gemm_f64_dual_kernel(GemmArgsPair p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int na = p.na;
+    const bool second = (int)blockIdx.x >= na;
+    const GemmArgs& g = p.g[second ? 1 : 0];        // uniform index into the kernarg segment: scalar loads, no private copy
+    int ti, tj;
+    if (!decode_tile(g, second ? (int)blockIdx.x - na : (int)blockIdx.x, TM, ti, tj)) return;
+    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA>(g, ti, tj, 0, smem);
+}
+
+template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int ti, tj;
+    if (!decode_tile(g, (int)blockIdx.x, TM, ti, tj)) return;
     if ((g.dbg & 32) && blockIdx.x < 512) {          // experiment: de-phase the two workgroups that share a CU (first wave only)
         __shared__ int s_par;
         if (threadIdx.x == 0) {
@@ -84,6 +105,16 @@ int launch_t(const GemmArgs& g, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
+static unsigned grid_blocks(const GemmArgs& g, int T) {
+    const int mt = g.M / T, nt = g.N / T;
+    if (g.order) return (unsigned)g.norder;
+    return (g.tri == 2) ? (unsigned)((long)mt * (mt + 1) / 2) : (unsigned)(mt * nt);
+}
+
+static bool dma_ok(const GemmArgs& g) {
+    return g.tile != 64 && (g.dbg & 64) && !g.a_kc && !g.b_kc && (g.K % 16) == 0 && (g.koff % 16) == 0;
+}
+
 template <int T>
 int launch_l(const GemmArgs& g, hipStream_t st) {
     if (!g.a_kc && !g.b_kc) return launch_t<T, false, false>(g, st);
@@ -94,11 +125,34 @@ int launch_l(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
+bool gemm_f64_uses_dma128(const GemmArgs& g) { return dma_ok(g); }
+
+bool gemm_f64_dual_ok(const GemmArgs& a, const GemmArgs& b) {
+    return dma_ok(a) && dma_ok(b) && a.batch <= 1 && b.batch <= 1 && a.M > 0 && a.N > 0 && b.M > 0 && b.N > 0 &&
+           !b.sig_counter && !b.sig2_counter && !a.stamps && !b.stamps;
+}
+
+int gemm_f64_dual_launch(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+    if (!gemm_f64_dual_ok(a, b)) return -1;
+    constexpr int T = 128;
+    const size_t shm = 2 * 2 * BK * (T + 16) * sizeof(double);
+    const unsigned na = grid_blocks(a, T), nb = grid_blocks(b, T);
+    static std::atomic<size_t> attr_set{0};
+    if (attr_set.load(std::memory_order_acquire) < shm) {
+        (void)hipFuncSetAttribute((const void*)gemm_f64_dual_kernel<T, T, false, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr_set.store(shm, std::memory_order_release);
+    }
+    GemmArgsPair pr;
+    pr.g[0] = a; pr.g[1] = b; pr.na = (int)na;
+    hipLaunchKernelGGL((gemm_f64_dual_kernel<T, T, false, false, true>), dim3(na + nb), dim3(256), shm, st, pr);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PGP_OK;
     if (g.tile == 64) return launch_l<64>(g, st);
     // LDS-DMA staging (dbg bit 64): 128 x 128 tiles of M-contiguous operands, whole 16-deep k-tiles
-    if ((g.dbg & 64) && !g.a_kc && !g.b_kc && (g.K % 16) == 0 && (g.koff % 16) == 0)
-        return launch_t<128, false, false, true>(g, st);
+    if (dma_ok(g)) return launch_t<128, false, false, true>(g, st);
     return launch_l<128>(g, st);
 }

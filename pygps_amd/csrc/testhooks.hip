@@ -321,4 +321,33 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
     return rc;
 }
 
+// Two products in one grid (gemm_f64_dual_launch): a = trailing-update shape (C1 -= A1 A1^T, lower trapezoid), b = the
+// E E^T filler shape (C2 = [rows < zero_from: C2] + A2 A2^T, packed lower tiles, k >= row + koff).  Results back to the host.
+int pgp_test_gemm_dual(pgp_ctx* ctx, const double* A1, int64_t lda1, double* C1, int64_t ldc1, int M1, int K1,
+                       const double* A2, int64_t lda2, double* C2, int64_t ldc2, int M2, int K2, int koff2, int zero_from2) {
+    if (!ctx) return -1;
+    pgp_ctx* c = ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    DevScratch scr;
+    double *a1, *c1, *a2, *c2;
+    CHK(scr.alloc(&a1, (size_t)lda1 * K1 * 8)); CHK(scr.alloc(&c1, (size_t)ldc1 * M1 * 8));
+    CHK(scr.alloc(&a2, (size_t)lda2 * K2 * 8)); CHK(scr.alloc(&c2, (size_t)ldc2 * M2 * 8));
+    HIP_TRY(hipMemcpy(a1, A1, (size_t)lda1 * K1 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c1, C1, (size_t)ldc1 * M1 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(a2, A2, (size_t)lda2 * K2 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c2, C2, (size_t)ldc2 * M2 * 8, hipMemcpyHostToDevice));
+    GemmArgs a{}, b{};
+    a.A = a1; a.lda = lda1; a.B = a1; a.ldb = lda1; a.C = c1; a.ldc = ldc1; a.M = M1; a.N = M1; a.K = K1;
+    a.alpha = -1.0; a.beta = 1.0; a.tri = 1; a.mask_diag = 1; a.kmode = KM_FULL; a.batch = 1; a.tile = 128; a.dbg = c->gemm_dbg;
+    b.A = a2; b.lda = lda2; b.B = a2; b.ldb = lda2; b.C = c2; b.ldc = ldc2; b.M = M2; b.N = M2; b.K = K2;
+    b.alpha = 1.0; b.beta = 1.0; b.tri = 2; b.mask_diag = 1; b.kmode = KM_GE_I; b.koff = koff2; b.zero_from = zero_from2;
+    b.batch = 1; b.tile = 128; b.dbg = c->gemm_dbg;
+    if (!gemm_f64_dual_ok(a, b)) return -2;
+    CHK(gemm_f64_dual_launch(a, b, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    HIP_TRY(hipMemcpy(C1, c1, (size_t)ldc1 * M1 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(C2, c2, (size_t)ldc2 * M2 * 8, hipMemcpyDeviceToHost));
+    return PGP_OK;
+}
+
 }  // extern "C"

@@ -165,13 +165,38 @@ def test_exact_fit_golden_G6_cfg2_scale(lib):
         assert relerr(got["dnlZ"], np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7
 
 
+def test_two_products_in_one_grid(lib):
+    """gemm_f64_dual_kernel: a trailing-update-shaped product and an E E^T-filler-shaped product (packed lower tiles,
+    k clipped to k >= row + koff, first-touch rows from zero_from) launched as ONE grid, against numpy."""
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    rng = np.random.RandomState(5)
+    M1, K1, M2, K2, s0 = 1024, 512, 1536, 512, 1024
+    A1 = np.asfortranarray(rng.randn(M1, K1)); C1 = np.asfortranarray(rng.randn(M1, M1))
+    # columns [s0, s0 + K2) of an upper-triangular E: rows <= s0 + k non-zero
+    A2 = np.asfortranarray(np.triu(rng.randn(M2, M2))[:, s0:s0 + K2]); C2 = np.asfortranarray(rng.randn(M2, M2))
+    want1 = C1 - A1 @ A1.T
+    base = C2.copy(); base[s0:, :] = 0.0
+    want2 = base + A2 @ A2.T
+    g1, g2 = C1.copy(order="F"), C2.copy(order="F")
+    _lib.check(lib.pgp_test_gemm_dual(ctx, _lib.ptr(A1), M1, _lib.ptr(g1), M1, M1, K1, _lib.ptr(A2), M2, _lib.ptr(g2), M2,
+                                      M2, K2, -s0, s0))
+    lo1, lo2 = np.tril_indices(M1), np.tril_indices(M2)
+    assert np.abs(g1[lo1] - want1[lo1]).max() < 1e-11
+    assert np.abs(g2[lo2] - want2[lo2]).max() < 1e-11
+    assert np.array_equal(np.triu(g1, 129), np.triu(C1, 129)) and np.array_equal(np.triu(g2, 129), np.triu(C2, 129))
+
+
 @pytest.mark.parametrize("opts", [dict(dserver=1), dict(dserver=1, ds_exclusive=0), dict(potrf_v1=1), dict(lookahead=0),
-                                  dict(la2=1), dict(s_side=1), dict(merge_tu=1), dict(cu_reserve=-8), dict(cu_reserve=-8, s_side=1)])
+                                  dict(la2=1), dict(s_side=1), dict(merge_tu=1), dict(cu_reserve=-8), dict(cu_reserve=-8, s_side=1),
+                                  dict(eet_overlap=0), dict(eet_overlap=1), dict(eet_overlap=1, eet_tile=64), dict(eet_overlap=2, eet_merge=1)])
 def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
     """Every schedule of the Cholesky sweep -- the default diagonal-panel chain, the resident diagonal-panel server
     (left-looking, in-kernel go signals), the round-1 leaf chain, the serial order, and the measured-and-rejected
     variants kept as options (depth-2 look-ahead, solves on a side stream, one merged update launch, CU
-    reservation for the panel chain) -- against the reference's own numbers (G6: Core/inf.py:353-384 at N=2048 and
+    reservation for the panel chain), and the ways B^-1 = E E^T is produced (one product after the sweep, panel products
+    on a filler stream, panel products in the same grid as the trailing update; the default runs them behind the
+    trailing update) -- against the reference's own numbers (G6: Core/inf.py:353-384 at N=2048 and
     at the benchmark size N=8192)."""
     from pygps_amd import _lib
     ctx = _lib.ctx()
@@ -191,7 +216,7 @@ def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
                     assert relerr(got["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-8
     finally:
         for k in opts:
-            lib.pgp_set_option(ctx, k.encode(), 1 if k in ("lookahead", "ds_exclusive") else 0)
+            lib.pgp_set_option(ctx, k.encode(), {"lookahead": 1, "ds_exclusive": 1, "eet_overlap": 3, "eet_tile": 128}.get(k, 0))
         lib.pgp_set_option(ctx, b"cu_reserve", 0)
 
 

@@ -1,12 +1,15 @@
-"""Stage times of N=8192 fits under library options (results may be WRONG with experiment options such as ds_fake)."""
+"""Stage times of N=8192 (or N=<n>) fits under library options (results may be WRONG with experiment options such as ds_fake)."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
 from pygps_amd import _lib
 lib = _lib.load(); ctx = _lib.ctx()
+N = 8192
 for o in sys.argv[1:]:
-    k, v = o.split('='); lib.pgp_set_option(ctx, k.encode(), int(v))
-N, d = 8192, 16
+    k, v = o.split('=')
+    if k == "N": N = int(v)
+    else: lib.pgp_set_option(ctx, k.encode(), int(v))
+d = 16
 rng = np.random.RandomState(0)
 x = rng.randn(N, d); w = rng.randn(d, 1)
 y = (np.sin(x @ w / np.sqrt(d)) + 0.1 * rng.randn(N, 1)).ravel()
