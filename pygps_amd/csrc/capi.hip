@@ -89,6 +89,8 @@ int pgp_init(int device, pgp_ctx** ctx_out) {
     HIP_TRY(hipMalloc((void**)&c->Dk, (size_t)2048 * 1024 * sizeof(double)));       // 2w x w, w <= 1024
     HIP_TRY(hipMalloc((void**)&c->dpack, (size_t)8 * PACK_DOUBLES * sizeof(double)));
     HIP_TRY(hipMemset(c->Dk, 0, (size_t)2048 * 1024 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->Dt, (size_t)1024 * 1024 * sizeof(double)));
+    HIP_TRY(hipMemset(c->Dt, 0, (size_t)1024 * 1024 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->Yn, (size_t)512 * 512 * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->dflags, diag_server_flag_bytes()));
     HIP_TRY(hipMemset(c->dflags, 0, diag_server_flag_bytes()));
@@ -108,7 +110,7 @@ void pgp_destroy(pgp_ctx* c) {
     for (auto& kv : c->spool) (void)hipFree(kv.second);
     for (auto& kv : c->orders) (void)hipFree(kv.second.first);
     void* bufs[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev, c->W, c->T, c->Binv, c->inv16, c->alpha_dev, c->m_dev,
-                    c->rvec, c->zvec, c->partial, c->scal, c->info_dev, c->Dk, c->dpack, c->Xs, c->dflags, c->ds_ticks, c->Yn};
+                    c->rvec, c->zvec, c->partial, c->scal, c->info_dev, c->Dk, c->Dt, c->dpack, c->Xs, c->dflags, c->ds_ticks, c->Yn};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
@@ -140,9 +142,13 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "dserver")) { c->dserver = value; return PGP_OK; }
     if (!strcmp(name, "s_side")) { c->s_side = value; return PGP_OK; }
     if (!strcmp(name, "la2")) { c->la2 = value; return PGP_OK; }
+    if (!strcmp(name, "half_wave")) { c->half_wave = value; return PGP_OK; }
+    if (!strcmp(name, "s_tile")) { if (value != 0 && value != 64 && value != 128) return -2; c->s_tile = value; return PGP_OK; }
+    if (!strcmp(name, "s_dma")) { c->s_dma = value; return PGP_OK; }
     if (!strcmp(name, "merge_tu")) { c->merge_tu = value; return PGP_OK; }
     if (!strcmp(name, "eet_overlap")) { if (value < 0 || value > 3) return -2; c->eet_overlap = value; return PGP_OK; }
     if (!strcmp(name, "eet_max_panels")) { c->eet_max_panels = value; return PGP_OK; }
+    if (!strcmp(name, "eet_first")) { if (value < -1) return -2; c->eet_first = value; return PGP_OK; }
     if (!strcmp(name, "eet_merge")) { c->eet_merge = value; return PGP_OK; }
     if (!strcmp(name, "eet_tail")) { if (value < 1) return -2; c->eet_tail = value; return PGP_OK; }
     if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
@@ -648,13 +654,14 @@ static int diag_factor(pgp_ctx* c, const SweepMat& m, int s0, int s1, const doub
     CHK(factor_panel(c, c->Dk, ldd, RowEnd{(long)w, true}, 0, s1 - s0, st, c->dpack, s0 * 128));
     { ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
       CHK(diag_out_launch(c->Dk, ldd, w, m.F + (long)s0 * 128 * (1 + m.ldf), m.ldf,
-                          m.E ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, st)); }
+                          m.E ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, st, c->s_dma ? c->Dt : nullptr, w)); }
     return PGP_OK;
 }
 
 // S(p): rows below the diagonal block of panel [s0, s1):  Y = X E_D, X read from the staging buffer (logical rows, ldx)
 static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* Xs, long ldx, hipStream_t st,
                        const double* Dk = nullptr) {
+    const bool own = !Dk;                                     // the launch chain's own scratch: diag_factor also left E_D^T in c->Dt
     if (!Dk) Dk = c->Dk;
     const int w = (s1 - s0) * 128;
     const long r0 = (long)s1 * 128, r1 = m.mrows + (m.E ? (long)s0 * 128 : 0);
@@ -662,12 +669,16 @@ static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const doub
     GemmArgs g{};
     g.A = Xs + r0; g.lda = ldx; g.a_kc = 0;
     g.B = Dk + w; g.ldb = 2L * w; g.b_kc = 1;                 // B(n,k) = E_D(k,n): K-contiguous
+    if (own && c->s_dma) { g.B = c->Dt; g.ldb = w; g.b_kc = 0; }   // ... or n-contiguous from the transposed copy
     g.C = m.F + r0 + (long)s0 * 128 * m.ldf; g.ldc = m.ldf;
     if (m.E && r1 > m.mrows) { g.C2 = m.E + (long)s0 * 128 * m.lde; g.ldc2 = m.lde; g.c_split = (int)(m.mrows - r0); }
     g.M = (int)(r1 - r0); g.N = w; g.K = w; g.alpha = 1.0; g.beta = 0.0;
     g.kmode = KM_LT_J; g.koff = 0;
     const long t128 = (long)(g.M / 128) * (w / 128);
-    g.tile = t128 < c->small_tile_below ? 64 : 128;
+    // fewer 128-tiles than workgroup slots: the launch lasts as long as its longest (k = w) tile while the short-k tiles'
+    // CUs idle -- 64-tiles, long-k columns first, balance it (option s_tile: 0 = this rule, 64 / 128 = forced)
+    g.tile = c->s_tile ? c->s_tile : ((t128 < c->small_tile_below || t128 < 512) ? 64 : 128);
+    g.rev_cols = 1;
     const double nt = (double)(w / g.tile);
     g.flops = 2.0 * (double)g.M * g.tile * g.tile * nt * (nt + 1.0) * 0.5;
     return gemm_prof(c, PC_GEMM_SOLVE, g, st);
@@ -702,6 +713,11 @@ static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c
     if (split) g.zero_from = (int)(m.mrows + (long)k0 * 128 - r0);     // this panel's own inverse rows: first touch
     const long t128 = (long)(g.M / 128) * (g.N / 128) - (long)(g.N / 128) * (g.N / 128 - 1) / 2;
     g.tile = t128 < c->small_tile_below ? 64 : 128;
+    // at most one 128-tile per CU (TU_a at N = 8192: 254 tiles): the dispatcher still packs two workgroups onto one CU
+    // and leaves the next CU empty, so each pair runs at half speed.  half_wave 1: pad the LDS request so that only ONE
+    // workgroup fits a CU; 2: 64-tiles instead
+    if (g.tile == 128 && t128 <= 256 && c->half_wave == 1) g.dbg |= 8;
+    if (g.tile == 128 && t128 <= 256 && c->half_wave == 2) g.tile = 64;
     if (out && stage_blocks > 0) {                    // one launch: the first stage_blocks column blocks -> staging, rest in place
         g.stage_cols = stage_blocks * 128;
         g.skip_stage_diag = skip_stage_diag ? 1 : 0;
@@ -996,8 +1012,11 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         if (la) HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
         // inline filler: panel p's share of E E^T in the SAME grid as TU_b(p) (or right behind it when the shapes do not
         // qualify) -- the main stream stays busy until D(p+1) is done instead of waiting for it, no third stream
-        if (fill_inline) {
-            const GemmArgs fa = eet_panel_args(c, mc, s0, s1, c->eet_out, c->eet_ld);
+        // the first products are small (few tiles, short k) and the early trailing updates are long enough to hide D by
+        // themselves: panels 0 .. eet_first go into ONE product (k = (eet_first + 1) w) behind TU_b(eet_first)
+        const int pf = std::min(c->eet_first >= 0 ? c->eet_first : npanel / 4, npanel - 2);
+        if (fill_inline && p >= pf) {
+            const GemmArgs fa = eet_panel_args(c, mc, p == pf ? 0 : s0, s1, c->eet_out, c->eet_ld);
             if (c->eet_merge)
                 CHK(trailing_update2(c, mc, s0, s1, n1, nblk, nullptr, 0, main, 0, nullptr, nullptr, 0, false, nullptr, nullptr, &fa));
             else {
@@ -1009,7 +1028,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         if (la && !side) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
     }
     if (fill_inline) {
-        const int s0 = (npanel - 1) * q;
+        const int s0 = npanel >= 2 ? (npanel - 1) * q : 0;
         CHK(eet_panel(c, mc, s0, nblk, c->eet_out, c->eet_ld, main));
         c->eet_inline_done = true;
     }

@@ -61,6 +61,7 @@ struct GemmArgs {
     // Optional separate source of the beta*C term (same shape and split point as C): out-of-place updates
     // C = beta*Cin + alpha*A*B' (the look-ahead Cholesky redirects the next panel's columns into a staging buffer).
     const double* Cin; long ldcin; const double* Cin2; long ldcin2;
+    int rev_cols;           // rectangular grids: tile columns enumerated last-to-first (KM_LT_J: the long-k tiles start first)
     int zero_from;          // > 0: tile rows i0 >= zero_from take beta = 0 (rows touched for the first time: never read)
     // Staged columns (look-ahead Cholesky): with Cin set, only tiles with j0 < stage_cols write to C / C2 (the staging
     // buffer); the other tiles update Cin / Cin2 in place.  stage_cols == 0 with Cin set: every tile goes to C.

@@ -49,6 +49,7 @@ struct pgp_ctx {
     int eet_tail = 1;                   // the last eet_tail panels go into ONE final product (longer K, after the sweep)
     int eet_tile = 128;                 // tile size of the filler products (64: shorter workgroups in the way of the chain)
     bool eet_inline_done = false;
+    int eet_first = -1;                 // inline filler: panels 0 .. eet_first are folded into one product (-1: a quarter of the panels)
     int eet_merge = 0;                  // inline filler: 1 = same grid as TU_b (gemm_f64_dual_kernel), 0 = its own launch behind it
     int eet_overlap = 3;                // B^-1 = sum_p E_p E_p^T accumulated under the sweep: 0 off (one product after it), 1 on a
                                         // low-priority filler stream, 2 inline on the main stream, 3 inline when npanel <= eet_max_panels
@@ -81,6 +82,10 @@ struct pgp_ctx {
     int* info_dev = nullptr;
     // Cholesky sweep v2: diagonal-panel scratch (2w x w, w <= 1024), its leaf operand images, column staging buffer
     double *Dk = nullptr, *dpack = nullptr, *Xs = nullptr, *Yn = nullptr;
+    double* Dt = nullptr;               // E_D transposed (w x w): B operand of the panel solve in the LDS-DMA GEMM's layout
+    int half_wave = 0;                  // trailing updates with <= 256 tiles: 1 = one workgroup per CU, 2 = 64-tiles
+    int s_tile = 0;                     // tile size of the panel solves: 0 = automatic
+    int s_dma = 0;                      // 1: panel solves read a transposed copy of E_D (n-contiguous, the LDS-DMA GEMM form; measured neutral); 0: K-contiguous E_D
     size_t Xs_bytes = 0;
     unsigned* dflags = nullptr;         // barrier counter / error word / go[p] / done[p] of the resident diagonal-panel server
     hipEvent_t ev_ds = nullptr, ev_ds2 = nullptr;
@@ -114,7 +119,7 @@ struct pgp_ctx {
     // options
     int nb_outer = 4;     // leaves (128 columns each) per outer panel -> trailing update K = 512
     int trtri_small_tile_below = 2049;   // measured: 64x64 tiles win on every recursion level at N=8192 (more, shorter tiles)
-    int small_tile_below = 256;   // use 64x64 tiles when a GEMM has fewer 128-tiles than this
+    int small_tile_below = 200;   // use 64x64 tiles when a GEMM has fewer 128-tiles than this
 };
 
 #define CHK(x)                      \

@@ -45,6 +45,7 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs& g, int b, int T, int
     const int mt = g.M / T;
     ti = b % mt;
     tj = b / mt;
+    if (g.rev_cols) tj = g.N / T - 1 - tj;
     return true;
 }
 

@@ -15,7 +15,8 @@ int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, long wstride
 int trsv_bwd_launch(const double* L, long ldl, const double* W, long ldw, double* z, double* a_out, int nblk,
                     hipStream_t st);
 int diag_in_launch(const double* src, long lds, double* D, long ldd, int w, hipStream_t st);
-int diag_out_launch(const double* D, long ldd, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st);
+int diag_out_launch(const double* D, long ldd, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st,
+                    double* Dt = nullptr, long ldt = 0);
 size_t diag_server_flag_bytes();
 int diag_server_max_panels();
 unsigned* diag_server_counter(unsigned* flags, int p);

@@ -450,9 +450,21 @@ __global__ __launch_bounds__(256) void diag_in_kernel(const double* __restrict__
 }
 // L_D (lower part) -> the factor's diagonal block; E_D (whole w x w block, zeros below its diagonal included) -> the
 // fused-inverse rows of this panel (E may be null: no global inverse wanted)
+// Blocks >= w (present when Dt != null): 64 x 64 tiles of E_D transposed through LDS into Dt(n, k) = E_D(k, n), ld ldt --
+// the panel solve Y = X E_D then reads its B operand n-contiguous like every other operand of the LDS-DMA GEMM.
 __global__ __launch_bounds__(256) void diag_out_kernel(const double* __restrict__ D, long ldd, int w,
                                                        double* __restrict__ Fd, long ldf, double* __restrict__ Ed,
-                                                       long lde) {
+                                                       long lde, double* __restrict__ Dt, long ldt) {
+    if ((int)blockIdx.x >= w) {
+        __shared__ double tile[64][65];
+        const int tb = blockIdx.x - w, nt = w / 64;
+        const int k0 = (tb % nt) * 64, n0 = (tb / nt) * 64;
+        const int a = threadIdx.x & 63, b = threadIdx.x >> 6;
+        for (int r = b; r < 64; r += 4) tile[r][a] = D[w + k0 + a + (long)(n0 + r) * ldd];      // tile[n][k], k contiguous
+        __syncthreads();
+        for (int r = b; r < 64; r += 4) Dt[n0 + a + (long)(k0 + r) * ldt] = tile[a][r];         // n contiguous
+        return;
+    }
     const int j = blockIdx.x;
     for (int i = threadIdx.x; i < 2 * w; i += 256) {
         const double v = D[i + (long)j * ldd];
@@ -825,8 +837,10 @@ int diag_in_launch(const double* src, long lds, double* D, long ldd, int w, hipS
     hipLaunchKernelGGL(diag_in_kernel, dim3(w), dim3(256), 0, st, src, lds, D, ldd, w);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
-int diag_out_launch(const double* D, long ldd, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st) {
-    hipLaunchKernelGGL(diag_out_kernel, dim3(w), dim3(256), 0, st, D, ldd, w, Fd, ldf, Ed, lde);
+int diag_out_launch(const double* D, long ldd, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st,
+                    double* Dt, long ldt) {
+    const int extra = Dt ? (w / 64) * (w / 64) : 0;
+    hipLaunchKernelGGL(diag_out_kernel, dim3(w + extra), dim3(256), 0, st, D, ldd, w, Fd, ldf, Ed, lde, Dt, ldt);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
