@@ -407,7 +407,7 @@ def main():
         achieved = alg_dom / max(dom_ms, 1e-12) / 1e9
         # stage time of the UN-profiled single-stream fits (the per-launch HIP events of the profiled pass stretch the chain)
         potrf_ms = float(np.median([t["potrf"] for t in (sweep_stage or lat_stage)]))
-        fact_ms = float(np.median([t["potrf"] + t["lauum"] for t in lat_stage]))
+        fact_ms = float(np.median([t["potrf"] + t["solve"] + t["trtri"] + t["lauum"] for t in lat_stage]))
         traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", "r02_gemm_f64_hbm_traffic.json")
         if os.path.exists(tpath):
@@ -437,7 +437,8 @@ def main():
                 "factor_inverse_EEt": {"ms": fact_ms, "TFLOPs": alg / (fact_ms * 1e-3) / 1e12,
                                        "frac_of_peak": alg / (fact_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TF,
                                        "what": "default schedule, one fit stream: Cholesky sweep + fused inverse + E E^T (accumulated "
-                                               "panel by panel under the sweep) = N^3 flops / (potrf + lauum stage time)"},
+                                               "panel by panel under the sweep; the last product overlaps the O(N^2) alpha / log det "
+                                               "kernels) = N^3 flops / (potrf + solve + lauum stage times)"},
                 "cholesky_sweep_what": "sweep + fused inverse alone (2 N^3 / 3 flops), 6 single-stream fits with option eet_overlap=0",
                 "cholesky_sweep_ms": potrf_ms,
                 "cholesky_sweep_TFLOPs": (2.0 * N ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12,

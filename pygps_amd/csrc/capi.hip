@@ -967,7 +967,6 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // eet_max_panels panels (default: beyond that the chain is amortised and the one-shot long-K product is faster)
     const bool fill_inline = la && m.E && c->eet_out &&
                              (c->eet_overlap == 2 || (c->eet_overlap == 3 && npanel <= c->eet_max_panels));
-    c->eet_inline_done = false;
     if (la && c->eet_overlap == 1 && m.E && c->eet_out) {
         if (!c->st_fill) {
             int lo = 0, hi = 0;
@@ -1028,9 +1027,19 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         if (la && !side) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
     }
     if (fill_inline) {
+        // the last product has nothing of the sweep left to hide: it goes to the (now idle) panel stream so that the O(N^2)
+        // kernels that follow the sweep on the main stream (alpha = E z, log det) run beside it; the fit joins on eet_join
         const int s0 = npanel >= 2 ? (npanel - 1) * q : 0;
-        CHK(eet_panel(c, mc, s0, nblk, c->eet_out, c->eet_ld, main));
-        c->eet_inline_done = true;
+        while ((int)c->fill_ev.size() < 2) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->fill_ev.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(c->fill_ev[0], main));
+        HIP_TRY(hipStreamWaitEvent(pan, c->fill_ev[0], 0));
+        CHK(eet_panel(c, mc, s0, nblk, c->eet_out, c->eet_ld, pan));
+        HIP_TRY(hipEventRecord(c->fill_ev[1], pan));
+        c->eet_join = c->fill_ev[1];
     }
     if (main != c->st) {
         HIP_TRY(hipEventRecord(c->ev_join, main));
@@ -1315,12 +1324,11 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     CHK(aug_rhs_launch(c->y_dev, c->m_dev, n, F, ldf, np, c->rvec, st));
     // ---- S2: Cholesky (forward substitution of the augmented row -- and L^-T -- ride along) ----------
     HIP_TRY(hipEventRecord(c->ev[1], st));
-    c->eet_inline_done = false;
     if (fused && !c->potrf_v1) { c->eet_out = c->Binv; c->eet_ld = np; }
     c->eet_join = nullptr;
     const int prc = potrf_blocked(c, F, ldf, np, np + 128, fused, E, lde);
     c->eet_out = nullptr;
-    if (prc != PGP_OK && c->st_fill) (void)hipStreamSynchronize(c->st_fill);     // queued products still read the scratch E
+    if (prc != PGP_OK) (void)hipDeviceSynchronize();                              // queued products still read the scratch E
     CHK(prc);
     HIP_TRY(hipEventRecord(c->ev[2], st));
     int info = 0;
@@ -1347,8 +1355,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     HIP_TRY(hipEventRecord(c->ev[4], st));
     // ---- S5b: B^-1 = W^T W ; S6: gradient reduce ------------------------------------------------
     if (want >= 3) {
-        if (fused && c->eet_inline_done) { }                                           // accumulated inside the sweep
-        else if (fused && c->eet_join) HIP_TRY(hipStreamWaitEvent(st, c->eet_join, 0));   // accumulated under the sweep
+        if (fused && c->eet_join) HIP_TRY(hipStreamWaitEvent(st, c->eet_join, 0));        // accumulated under the sweep   // accumulated under the sweep
         else if (fused) CHK(eet_lower(c, E, lde, c->Binv, np, np));                   // B^-1 = W^T W = E E^T
         else CHK(lauum_lower(c, c->W, np, c->Binv, np, np));
         HIP_TRY(hipEventRecord(c->ev[5], st));
