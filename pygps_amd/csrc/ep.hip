@@ -90,6 +90,25 @@ constexpr int EPB = 128;
 
 __global__ void ep_set_base_kernel(long* base, long v) { base[0] = v; }
 
+// Sigma_blk is kept current in its LOWER triangle only (the folds and Sigma = K - V'V are symmetric rank-k updates: half
+// the tiles); element (r, c) of the symmetric matrix:
+__device__ __forceinline__ double sym_at(const double* __restrict__ Sig, long ld, long r, long c) {
+    return r >= c ? Sig[r + c * ld] : Sig[c + r * ld];
+}
+
+// upper triangle <- transpose of the lower one, 64 x 64 tiles through LDS (blockIdx = (tile row, tile column), row >= column)
+__global__ __launch_bounds__(256) void ep_mirror_kernel(double* __restrict__ A, long ld) {
+    if (blockIdx.x < blockIdx.y) return;
+    __shared__ double tile[64][65];
+    const long r0 = 64L * blockIdx.x, c0 = 64L * blockIdx.y;
+    const int a = threadIdx.x & 63, b = threadIdx.x >> 6;
+    const bool diag = blockIdx.x == blockIdx.y;      // diagonal tiles: only the entries above the diagonal are rewritten
+    for (int q = b; q < 64; q += 4) tile[q][a] = A[r0 + a + (c0 + q) * ld];
+    __syncthreads();
+    for (int q = b; q < 64; q += 4)
+        if (!diag || a < q) A[c0 + a + (r0 + q) * ld] = tile[a][q];
+}
+
 // site index i = base[0] + j: the 128 launches of one block are captured once into a hipGraph and replayed for every
 // block (only base[0] changes), instead of 128 separate kernel launches of ~5 us each
 __global__ __launch_bounds__(256) void ep_site_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
@@ -135,7 +154,7 @@ __global__ __launch_bounds__(256) void ep_site_lazy_kernel(const double* __restr
     // column i of the current Sigma -> factor column j
     const long r = (long)blockIdx.x * 256 + t;
     if (r < np) {
-        double sr = Sig[r + i * ld];
+        double sr = sym_at(Sig, ld, r, i);
         for (int k = 0; k < j; ++k) sr = fma(-g[k], S[r + (long)k * ld], sr);
         S[r + (long)j * ld] = sr;
     }
@@ -203,7 +222,8 @@ __device__ __forceinline__ void ep_site_update(double sii, double mui, double tp
 // lane = site and the in-launch entries in registers (shuffles instead of LDS round trips).  The serial part per launch
 // fell from ~40 wave reductions of length j0 to ~EPT probit evaluations: EPT = 16 (was 8), 14 -> 4 ms per sweep at N=4096.
 constexpr int EPT = 16;
-__global__ __launch_bounds__(256) void ep_sites_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
+constexpr int EPS_THREADS = 320;          // wave 0: the in-launch recurrence; waves 1-4: 256 rows of the new factor columns
+__global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
                                                             const long* __restrict__ base, int j0, double* __restrict__ S,
                                                             double* __restrict__ cvec, double* __restrict__ qvec,
                                                             const double* __restrict__ mu_blk, const double* __restrict__ m,
@@ -219,11 +239,11 @@ __global__ __launch_bounds__(256) void ep_sites_lazy_kernel(const double* __rest
     __shared__ double b0[EPT];                   // sum_{k<j0} q_k S(i_t,k)
     const int t = threadIdx.x, lane = t & 63;
     const long i0 = base[0] + j0;
-    for (int v = t; v < EPT * j0; v += 256) { const int tt = v / j0, k = v % j0; Srow[tt][k] = S[i0 + tt + (long)k * ld]; }
-    for (int k = t; k < j0; k += 256) { cl[k] = cvec[k]; ql[k] = qvec[k]; }
-    if (t < EPT * EPT) Sg[t / EPT][t % EPT] = Sig[i0 + t / EPT + (i0 + t % EPT) * ld];
+    for (int v = t; v < EPT * j0; v += EPS_THREADS) { const int tt = v / j0, k = v % j0; Srow[tt][k] = S[i0 + tt + (long)k * ld]; }
+    for (int k = t; k < j0; k += EPS_THREADS) { cl[k] = cvec[k]; ql[k] = qvec[k]; }
+    if (t < EPT * EPT) Sg[t / EPT][t % EPT] = sym_at(Sig, ld, i0 + t / EPT, i0 + t % EPT);
     __syncthreads();
-    for (int v = t; v < EPT * j0; v += 256) { const int tt = v / j0, k = v % j0; gv[tt][k] = cl[k] * Srow[tt][k]; }
+    for (int v = t; v < EPT * j0; v += EPS_THREADS) { const int tt = v / j0, k = v % j0; gv[tt][k] = cl[k] * Srow[tt][k]; }
     __syncthreads();
     {   // (i) Gram matrix (lower part) and b0: EPT (EPT+1) / 2 + EPT dots of length j0, one per thread
         constexpr int NG = EPT * (EPT + 1) / 2;
@@ -273,18 +293,30 @@ __global__ __launch_bounds__(256) void ep_sites_lazy_kernel(const double* __rest
                 if (u < L) gv[L][j0 + u] = cN[u] * e[u];
         }
     }
-    __syncthreads();
-    // rows of the EPT new factor columns: one pass over S(r, 0..j0)
-    const long r = (long)blockIdx.x * 256 + t;
-    if (r < np) {
-        double acc[EPT];
+    // rows of the EPT new factor columns (waves 1-4), one pass over S(r, 0..j0).  The pass over the columns that existed
+    // before the launch needs nothing from the recurrence, so it runs BESIDE it; only the short in-launch correction waits.
+    const long r = (long)blockIdx.x * 256 + (t - 64);
+    double acc[EPT];
+    if (t >= 64 && r < np) {
+        if (r >= i0 + EPT) {                         // below the launch's sites: column reads, coalesced over the rows
 #pragma unroll
-        for (int tt = 0; tt < EPT; ++tt) acc[tt] = Sig[r + (i0 + tt) * ld];
+            for (int tt = 0; tt < EPT; ++tt) acc[tt] = Sig[r + (i0 + tt) * ld];
+        } else if (r < i0) {                         // above: row r of the lower triangle, EPT contiguous doubles per thread
+            const double2_t* src = reinterpret_cast<const double2_t*>(Sig + i0 + r * ld);     // i0 % EPT == 0, ld even
+#pragma unroll
+            for (int tt = 0; tt < EPT; tt += 2) { const double2_t v = src[tt / 2]; acc[tt] = v[0]; acc[tt + 1] = v[1]; }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < EPT; ++tt) acc[tt] = sym_at(Sig, ld, r, i0 + tt);
+        }
         for (int k = 0; k < j0; ++k) {
             const double srk = S[r + (long)k * ld];
 #pragma unroll
             for (int tt = 0; tt < EPT; ++tt) acc[tt] = fma(-gv[tt][k], srk, acc[tt]);
         }
+    }
+    __syncthreads();                                 // gv[.][j0 ..] of the recurrence
+    if (t >= 64 && r < np) {
 #pragma unroll
         for (int tt = 0; tt < EPT; ++tt) {           // column j0+tt also depends on the columns j0 .. j0+tt-1 of this launch
 #pragma unroll
@@ -312,6 +344,28 @@ __global__ __launch_bounds__(256) void ep_mu_fold_kernel(const double* __restric
     mu[r] = acc;
 }
 
+// Both of the above in one pass over S: 64 rows per workgroup, the EPB columns split over the 4 waves; the 4 partial sums
+// of a row meet in LDS and are added in a fixed order (bitwise reproducible)
+__global__ __launch_bounds__(256) void ep_fold_prep_kernel(const double* __restrict__ S, double* __restrict__ Sc, long ld,
+                                                           long np, const double* __restrict__ cvec,
+                                                           const double* __restrict__ qvec, double* __restrict__ mu) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * 64 + lane;
+    double acc = 0.0;
+    if (r < np) {
+#pragma unroll 4
+        for (int k = grp * (EPB / 4); k < (grp + 1) * (EPB / 4); ++k) {
+            const double v = S[r + (long)k * ld];
+            Sc[r + (long)k * ld] = cvec[k] * v;
+            acc = fma(qvec[k], v, acc);
+        }
+    }
+    part[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && r < np) mu[r] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+
 // F (column-major lower, ldf) = I + s s' o K ; Y (column-major, ld np) = diag(s) K     (K symmetric, ld np)
 __global__ __launch_bounds__(256) void ep_build_kernel(const double* __restrict__ K, long np,
                                                        const double* __restrict__ s, double* __restrict__ F, long ldf,
@@ -331,6 +385,7 @@ struct EpWork {
     double *ttau_d, *tnu_d, *mu_d, *m_d, *s_d, *sbuf, *coef, *diag_d, *tmp_d;
     double *S, *Sc, *cq, *prev;          // blocked sweep: factor columns, scaled copy, (c, q) vectors, (ttau, tnu) snapshot
     long* base;                          // first site of the current block (device scalar read by the captured launches)
+    long* bases;                         // bases[b] = b * EPB: the launches of block b read their offset from here
 };
 
 }  // namespace
@@ -364,7 +419,10 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
         g.C = w.Sig; g.ldc = np; g.M = (int)np; g.N = (int)np; g.K = (int)np;
         g.alpha = -1.0; g.beta = 1.0; g.tile = (np / 128) * (np / 128) < c->small_tile_below ? 64 : 128;
         g.flops = 2.0 * (double)np * np * np;
+        if (c->ep_sym) { g.tri = 2; g.mask_diag = 1; g.flops *= 0.5; }                  // lower tiles only, then mirrored
         CHK(gemm_prof(c, PC_GEMM_INNER, g));
+        if (c->ep_sym)
+            hipLaunchKernelGGL(ep_mirror_kernel, dim3((unsigned)(np / 64), (unsigned)(np / 64)), dim3(256), 0, st, w.Sig, np);
     }
     CHK(col_dot_full_launch(w.Sig, np, np, np, w.tnu_d, nullptr, w.mu_d, st));           // mu = Sigma tnu
     CHK(gather_strided_launch(w.Sig, np + 1, np, w.diag_d, st));
@@ -440,6 +498,16 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     EP_TRY(dalloc(&w.cq, (size_t)2 * EPB * sizeof(double)));
     EP_TRY(dalloc(&w.prev, (size_t)2 * np * sizeof(double)));
     { double* b8 = nullptr; EP_TRY(dalloc(&b8, 64)); w.base = (long*)b8; }
+    {
+        double* bb = nullptr;
+        const long nb = np / EPB + 1;
+        EP_TRY(dalloc(&bb, (size_t)nb * sizeof(long)));
+        w.bases = (long*)bb;
+        std::vector<long> hb(nb);
+        for (long b = 0; b < nb; ++b) hb[b] = b * EPB;
+        HIP_TRY(hipMemcpyAsync(w.bases, hb.data(), (size_t)nb * sizeof(long), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));                       // hb goes out of scope
+    }
     HIP_TRY(hipMemsetAsync(w.Kd, 0, nn, st));
     EP_TRY(alloc_factor_buffer(c, np, ldf, &w.F));
     FactorGuard fguard(c, w.F, (size_t)ldf * np * sizeof(double), /*scrub=*/true);
@@ -491,31 +559,32 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
             HIP_TRY(hipMemcpyAsync(w.prev, w.ttau_d, np * sizeof(double), hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.prev + np, w.tnu_d, np * sizeof(double), hipMemcpyDeviceToDevice, st));
             auto fold = [&]() -> int {
-                hipLaunchKernelGGL(ep_colscale_kernel, dim3((unsigned)((np + 255) / 256), EPB), dim3(256), 0, st, w.S, w.Sc,
-                                   np, np, w.cq);
+                hipLaunchKernelGGL(ep_fold_prep_kernel, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, st, w.S, w.Sc, np, np,
+                                   w.cq, w.cq + EPB, w.mu_d);                          // Sc = S diag(c) ; mu += S q
                 GemmArgs g{};                                                          // Sigma -= S diag(c) S'
                 g.A = w.Sc; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
                 g.C = w.Sig; g.ldc = np; g.M = (int)np; g.N = (int)np; g.K = EPB;
                 g.alpha = -1.0; g.beta = 1.0; g.tile = (np / 128) * (np / 128) < c->small_tile_below ? 64 : 128;
                 g.flops = 2.0 * (double)np * np * EPB;
+                // symmetric rank-EPB update: only the lower tiles (the site kernels read Sigma_blk through its lower triangle)
+                if (c->ep_sym) { g.tri = 2; g.mask_diag = 1; g.flops *= 0.5; }
                 CHK(gemm_prof(c, PC_GEMM_INNER, g));
-                hipLaunchKernelGGL(ep_mu_fold_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.S, np, np,
-                                   w.cq + EPB, w.mu_d);
-                HIP_TRY(hipMemsetAsync(w.S, 0, (size_t)EPB * np * sizeof(double), st));
-                HIP_TRY(hipMemsetAsync(w.cq, 0, (size_t)2 * EPB * sizeof(double), st));
+                // no re-zeroing of S / c / q: every site launch of the next block writes its columns (all rows) and its c, q
+                // entries before anything reads them, and a fold only follows a full block
                 return PGP_OK;
             };
             HIP_TRY(hipMemsetAsync(w.S, 0, (size_t)EPB * np * sizeof(double), st));
             HIP_TRY(hipMemsetAsync(w.cq, 0, (size_t)2 * EPB * sizeof(double), st));
-            auto block_launches = [&](int nsite, bool do_fold) -> int {
+            auto block_launches = [&](int nsite, bool do_fold, const long* base = nullptr) -> int {
+                if (!base) base = w.base;
                 int j = 0;
                 for (; j + EPT <= nsite; j += EPT)
-                    hipLaunchKernelGGL(ep_sites_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np,
-                                       w.base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
+                    hipLaunchKernelGGL(ep_sites_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(EPS_THREADS), 0, st, w.Sig, np, np,
+                                       base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
                                        w.tnu_d);
                 for (; j < nsite; ++j)
                     hipLaunchKernelGGL(ep_site_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np,
-                                       w.base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
+                                       base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
                                        w.tnu_d);
                 if (do_fold) CHK(fold());
                 return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
@@ -535,14 +604,12 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                 if (c->ep_graph == 2) fprintf(stderr, "ep block graph %s\n", block_graph ? "captured" : "NOT captured (falling back to launches)");
             }
             for (long b = 0; b < nfull; ++b) {
-                hipLaunchKernelGGL(ep_set_base_kernel, dim3(1), dim3(1), 0, st, w.base, b * EPB);
-                if (block_graph) HIP_TRY(hipGraphLaunch(block_graph, st));
-                else EP_TRY(block_launches(EPB, true));
+                if (block_graph) {                                   // the captured launches read the offset from base[0]
+                    hipLaunchKernelGGL(ep_set_base_kernel, dim3(1), dim3(1), 0, st, w.base, b * EPB);
+                    HIP_TRY(hipGraphLaunch(block_graph, st));
+                } else EP_TRY(block_launches(EPB, true, w.bases + b));
             }
-            if (n % EPB) {
-                hipLaunchKernelGGL(ep_set_base_kernel, dim3(1), dim3(1), 0, st, w.base, nfull * EPB);
-                EP_TRY(block_launches((int)(n % EPB), false));
-            }
+            if (n % EPB) EP_TRY(block_launches((int)(n % EPB), false, w.bases + nfull));
             // Sigma / mu are rebuilt from (ttau, tnu) by ep_compute_params below: the last partial block need not be folded
         } else
         for (long i = 0; i < n; ++i) {
