@@ -143,6 +143,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "s_side")) { c->s_side = value; return PGP_OK; }
     if (!strcmp(name, "la2")) { c->la2 = value; return PGP_OK; }
     if (!strcmp(name, "half_wave")) { c->half_wave = value; return PGP_OK; }
+    if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
     if (!strcmp(name, "ep_sym")) { c->ep_sym = value; return PGP_OK; }
     if (!strcmp(name, "s_tile")) { if (value != 0 && value != 64 && value != 128) return -2; c->s_tile = value; return PGP_OK; }
     if (!strcmp(name, "s_dma")) { c->s_dma = value; return PGP_OK; }
@@ -1077,6 +1078,9 @@ int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with
         }
         return potrf_blocked_v1(c, F, ld, np, mrows, with_inverse);
     }
+    // two-piece row space: the panel solves / updates address "rows >= mrows" through a split that must be positive for
+    // every panel, i.e. at least one spare row block between the factor's rows and the inverse rows
+    if (with_inverse && E != F + mrows && mrows < np + 128) return -1;
     SweepMat m{F, ld, mrows, with_inverse ? E : nullptr, lde, np};
     return potrf_blocked_v2(c, m);
 }

@@ -56,6 +56,7 @@ struct pgp_ctx {
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
     int ep_graph = 0;                   // EP: replay each 128-site block as a captured hipGraph (measured: no gain)
+    int ep_fused = 1;                   // EP: parameter recomputation through the fused inverse (V' = K diag(sW) L^-T as one product)
     int ep_sym = 1;                     // EP: Sigma kept current in its lower triangle only (folds and K - V'V on the lower tiles)
     int ep_block = 1;                   // EP: blocked site sweep (rank-1 updates folded every 128 sites); 0 = update Sigma per site
     int fused_inverse = 1;              // 1: L^-T falls out of the Cholesky sweep (appended identity rows); 0: recursive trtri

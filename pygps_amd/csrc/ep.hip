@@ -222,6 +222,7 @@ __device__ __forceinline__ void ep_site_update(double sii, double mui, double tp
 // lane = site and the in-launch entries in registers (shuffles instead of LDS round trips).  The serial part per launch
 // fell from ~40 wave reductions of length j0 to ~EPT probit evaluations: EPT = 16 (was 8), 14 -> 4 ms per sweep at N=4096.
 constexpr int EPT = 16;
+constexpr size_t EPS_LDS_BYTES = (size_t)(16 * (EPB + 1) + 16 * (EPB + 16) + 2 * EPB) * sizeof(double);
 constexpr int EPS_THREADS = 320;          // wave 0: the in-launch recurrence; waves 1-4: 256 rows of the new factor columns
 __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
                                                             const long* __restrict__ base, int j0, double* __restrict__ S,
@@ -231,9 +232,11 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
                                                             const double* __restrict__ ttau_prev,
                                                             const double* __restrict__ tnu_prev,
                                                             double* __restrict__ ttau_cur, double* __restrict__ tnu_cur) {
-    __shared__ double Srow[EPT][EPB + 1];        // row i_t of the factor columns 0 .. j0-1 (+1: bank spread)
-    __shared__ double gv[EPT][EPB + EPT];        // g_t[k] = c_k S(i_t, k), k < j0 + t
-    __shared__ double cl[EPB], ql[EPB];
+    extern __shared__ __attribute__((aligned(16))) double eps_lds[];   // EPS_LDS_BYTES: more than the 64 KB static limit at EPB = 256
+    double (*Srow)[EPB + 1] = reinterpret_cast<double (*)[EPB + 1]>(eps_lds);                         // row i_t of the factor columns 0 .. j0-1
+    double (*gv)[EPB + EPT] = reinterpret_cast<double (*)[EPB + EPT]>(eps_lds + EPT * (EPB + 1));     // g_t[k] = c_k S(i_t, k), k < j0 + t
+    double* cl = eps_lds + EPT * (EPB + 1) + EPT * (EPB + EPT);
+    double* ql = cl + EPB;
     __shared__ double Sg[EPT][EPT];              // Sigma_blk(i_t, i_u)
     __shared__ double G[EPT][EPT];               // sum_{k<j0} c_k S(i_t,k) S(i_u,k)
     __shared__ double b0[EPT];                   // sum_{k<j0} q_k S(i_t,k)
@@ -268,14 +271,12 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
         double e[EPT], cN[EPT], qN[EPT];         // e[u] = S(i_L, j0 + u) for u < L; cN / qN: the sites' new (c, q), wave-uniform
         const double Sgd = Sg[L][L] - G[L][L], mub = mu_blk[i] + b0[L];
         const double tp = ttau_prev[i], np_ = tnu_prev[i], mi = m[i], yi = y[i];
+        double sa = 0.0, sb = 0.0;               // running sum_{v<u} c_v e_L[v]^2 and sum_{v<u} q_v e_L[v] of this lane's row
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
             // site u's scalar update, evaluated by every lane on its own row; lane u's result is the one that counts
-            double a = 0.0, b = 0.0;
-#pragma unroll
-            for (int v = 0; v < u; ++v) { a = fma(cN[v] * e[v], e[v], a); b = fma(qN[v], e[v], b); }
-            const double sii = Sgd - a;
-            const double mui = mub + b;
+            const double sii = Sgd - sa;
+            const double mui = mub + sb;
             double t_new, nu_new, cj, qj;
             ep_site_update(sii, mui, tp, np_, mi, yi, t_new, nu_new, cj, qj);
             cN[u] = bcast_lane(cj, u);
@@ -286,6 +287,8 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
 #pragma unroll
             for (int v = 0; v < u; ++v) acc = fma(-cN[v] * bcast_lane(e[v], u), e[v], acc);
             e[u] = acc;
+            sa = fma(cN[u] * acc, acc, sa);
+            sb = fma(qN[u], acc, sb);
         }
         if (lane < EPT) {
 #pragma unroll
@@ -375,12 +378,20 @@ __global__ __launch_bounds__(256) void ep_build_kernel(const double* __restrict_
     if (i >= np) return;
     const double k = K[i + j * np];
     const double si = s[i];
-    Y[i + j * np] = si * k;
+    if (Y) Y[i + j * np] = si * k;
     if (i >= j) F[i + j * ldf] = (i == j ? 1.0 : 0.0) + si * s[j] * k;
+}
+
+// E'(k, m) = s_k E(k, m) on the block-upper part of E = L^-T (everything the sweep wrote: k < 128 (m / 128 + 1))
+__global__ __launch_bounds__(256) void ep_rowscale_upper_kernel(double* __restrict__ E, long lde, const double* __restrict__ s) {
+    const long m = blockIdx.y;
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k < (m / 128 + 1) * 128) E[k + m * lde] *= s[k];
 }
 
 struct EpWork {
     long n, np, ldf;
+    double* Ed;                          // fused path: E = L^-T from the sweep, then diag(sW) E
     double *Kd, *Sig, *Vd, *F, *Wd, *rhs;
     double *ttau_d, *tnu_d, *mu_d, *m_d, *s_d, *sbuf, *coef, *diag_d, *tmp_d;
     double *S, *Sc, *cq, *prev;          // blocked sweep: factor columns, scaled copy, (c, q) vectors, (ttau, tnu) snapshot
@@ -402,20 +413,41 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     HIP_TRY(hipMemcpyAsync(w.ttau_d, ttau.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(w.tnu_d, tnu.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
+    const bool fusedp = c->ep_fused && w.Ed;
     hipLaunchKernelGGL(ep_build_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Kd, np,
-                       w.s_d, w.F, w.ldf, w.Vd);
-    CHK(potrf_blocked(c, w.F, w.ldf, np, np));
+                       w.s_d, w.F, w.ldf, fusedp ? nullptr : w.Vd);
+    // fused path: the sweep also yields E = L^-T, so V' = (K diag(sW)) E is ONE clipped MFMA product (no blocked multi-rhs
+    // solve, no leaf inverses) and Sigma = K - V'V'^T an NT product in the LDS-DMA form
+    // (the sweep's two-piece row space wants the factor's 128 spare rows between the factor and the inverse rows, like the
+    //  exact fit's rhs rows: they are zeroed and ride along)
+    if (fusedp) {
+        CHK(zero_strip_launch(w.F, w.ldf, np, np, 128, st));
+        CHK(potrf_blocked(c, w.F, w.ldf, np, np + 128, true, w.Ed, np));
+    }
+    else CHK(potrf_blocked(c, w.F, w.ldf, np, np));
     int info = 0;
     HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (info != 0) return info > (int)n ? (int)n : info;
-    CHK(leaf_inv_launch(w.F, w.ldf, w.Wd, 128, 128L * 128L, (int)(np / 128), st));
-    CHK(solve_lower_multi(c, w.F, w.ldf, w.Wd, w.Vd, np, np, (int)np, false));        // V = L^-1 (sW o K)
+    if (fusedp) {
+        hipLaunchKernelGGL(ep_rowscale_upper_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Ed, np, w.s_d);
+        GemmArgs g{};                                                                   // V'(n, m) = sum_{k <= m} K(n, k) sW_k E(k, m)
+        g.A = w.Kd; g.lda = np; g.a_kc = 0;
+        g.B = w.Ed; g.ldb = np; g.b_kc = 1;
+        g.C = w.Vd; g.ldc = np; g.M = (int)np; g.N = (int)np; g.K = (int)np;
+        g.alpha = 1.0; g.beta = 0.0; g.kmode = KM_LT_J; g.koff = 0; g.rev_cols = 1;
+        g.tile = (np / 128) * (np / 128) < c->small_tile_below ? 64 : 128;
+        g.flops = (double)np * np * np;
+        CHK(gemm_prof(c, PC_GEMM_SOLVE, g));
+    } else {
+        CHK(leaf_inv_launch(w.F, w.ldf, w.Wd, 128, 128L * 128L, (int)(np / 128), st));
+        CHK(solve_lower_multi(c, w.F, w.ldf, w.Wd, w.Vd, np, np, (int)np, false));    // V = L^-1 (sW o K)
+    }
     HIP_TRY(hipMemcpyAsync(w.Sig, w.Kd, (size_t)np * np * sizeof(double), hipMemcpyDeviceToDevice, st));
     {
         GemmArgs g{};                                                                   // Sigma = K - V'V
-        g.A = w.Vd; g.lda = np; g.a_kc = 1;
-        g.B = w.Vd; g.ldb = np; g.b_kc = 1;
+        g.A = w.Vd; g.lda = np; g.a_kc = fusedp ? 0 : 1;                                // fused path: Vd holds V' (n-contiguous)
+        g.B = w.Vd; g.ldb = np; g.b_kc = fusedp ? 0 : 1;
         g.C = w.Sig; g.ldc = np; g.M = (int)np; g.N = (int)np; g.K = (int)np;
         g.alpha = -1.0; g.beta = 1.0; g.tile = (np / 128) * (np / 128) < c->small_tile_below ? 64 : 128;
         g.flops = 2.0 * (double)np * np * np;
@@ -486,6 +518,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     auto dalloc = [&](double** p, size_t bytes) -> int { return pscr.alloc(p, bytes); };
 #define EP_TRY(x) CHK(x)
     EP_TRY(dalloc(&w.Kd, nn)); EP_TRY(dalloc(&w.Sig, nn)); EP_TRY(dalloc(&w.Vd, nn));
+    if (c->ep_fused) EP_TRY(dalloc(&w.Ed, nn));
     EP_TRY(dalloc(&w.Wd, (size_t)128 * np * sizeof(double)));
     EP_TRY(dalloc(&w.rhs, (size_t)128 * np * sizeof(double)));
     double* vecs = nullptr;
@@ -546,7 +579,8 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemsetAsync(w.ttau_d, 0, np * sizeof(double), st));
         HIP_TRY(hipMemsetAsync(w.tnu_d, 0, np * sizeof(double), st));
     }
-    hipGraphExec_t block_graph = nullptr;             // one block of the blocked sweep (128 site launches + fold)
+    HIP_TRY(hipFuncSetAttribute((const void*)ep_sites_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EPS_LDS_BYTES));
+    hipGraphExec_t block_graph = nullptr;             // one block of the blocked sweep (EPB / EPT site launches + fold)
     const double tol = 1e-4;
     const int max_sweep = 10, min_sweep = 2;
     double nlZ_old = INFINITY;
@@ -579,7 +613,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                 if (!base) base = w.base;
                 int j = 0;
                 for (; j + EPT <= nsite; j += EPT)
-                    hipLaunchKernelGGL(ep_sites_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(EPS_THREADS), 0, st, w.Sig, np, np,
+                    hipLaunchKernelGGL(ep_sites_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(EPS_THREADS), EPS_LDS_BYTES, st, w.Sig, np, np,
                                        base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
                                        w.tnu_d);
                 for (; j < nsite; ++j)
@@ -640,6 +674,8 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     for (long i = 0; i < n; ++i) b[i] *= sW[i];
     HIP_TRY(hipMemsetAsync(w.rhs, 0, (size_t)128 * np * sizeof(double), st));
     HIP_TRY(hipMemcpyAsync(w.rhs, b.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+    if (c->ep_fused && w.Ed)        // the fused parameter recomputation does not produce the leaf inverses of the blocked solve
+        EP_TRY(leaf_inv_launch(w.F, ldf, w.Wd, 128, 128L * 128L, (int)(np / 128), st));
     EP_TRY(solve_lower_multi(c, w.F, ldf, w.Wd, w.rhs, np, np, 128, false));
     EP_TRY(solve_lower_multi(c, w.F, ldf, w.Wd, w.rhs, np, np, 128, true));
     HIP_TRY(hipMemcpyAsync(b.data(), w.rhs, n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -653,11 +689,18 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     if (want >= 3 && dnlZ_out) {
         HIP_TRY(hipMemsetAsync(c->alpha_dev, 0, np * sizeof(double), st));
         HIP_TRY(hipMemcpyAsync(c->alpha_dev, alpha.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-        EP_TRY(trtri_lower(c, w.F, ldf, c->W, np, c->T, np));
-        EP_TRY(lauum_lower(c, c->W, np, c->Binv, np, np));
         // F = alpha alpha' - sW sW' o B^-1 ; dnlZ.cov[j] = -sum(F o dK_j)/2 = sum((sW sW' o B^-1 - alpha alpha') o dK_j)/2
-        EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
-                                      c->scal + 8, st, w.s_d));
+        if (c->ep_fused && w.Ed) {
+            // Ed holds diag(sW) L^-T of the final parameters: (diag(sW) E)(diag(sW) E)' = sW sW' o B^-1 in one product
+            EP_TRY(eet_lower(c, w.Ed, np, c->Binv, np, np));
+            EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
+                                          c->scal + 8, st, nullptr));
+        } else {
+            EP_TRY(trtri_lower(c, w.F, ldf, c->W, np, c->T, np));
+            EP_TRY(lauum_lower(c, c->W, np, c->Binv, np, np));
+            EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
+                                          c->scal + 8, st, w.s_d));
+        }
         std::vector<double> g(ncov + 1);
         HIP_TRY(hipMemcpyAsync(g.data(), c->scal + 8, (ncov + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
