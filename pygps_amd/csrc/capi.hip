@@ -143,6 +143,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "s_side")) { c->s_side = value; return PGP_OK; }
     if (!strcmp(name, "la2")) { c->la2 = value; return PGP_OK; }
     if (!strcmp(name, "half_wave")) { c->half_wave = value; return PGP_OK; }
+    if (!strcmp(name, "ep_dbg")) { return ep_set_dbg(value); }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
     if (!strcmp(name, "ep_sym")) { c->ep_sym = value; return PGP_OK; }
     if (!strcmp(name, "s_tile")) { if (value != 0 && value != 64 && value != 128) return -2; c->s_tile = value; return PGP_OK; }

@@ -280,4 +280,5 @@ int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F);
 int ensure_workspace(pgp_ctx* c, long np);
 int solve_lower_multi(pgp_ctx* c, const double* L, long ldl, const double* Wd, double* Y, long ldy, long np, int nrhs,
                       bool trans);
+int ep_set_dbg(int v);
 int eet_lower(pgp_ctx* c, const double* E, long lde, double* Binv, long ldb, long np);

@@ -222,7 +222,8 @@ __device__ __forceinline__ void ep_site_update(double sii, double mui, double tp
 // lane = site and the in-launch entries in registers (shuffles instead of LDS round trips).  The serial part per launch
 // fell from ~40 wave reductions of length j0 to ~EPT probit evaluations: EPT = 16 (was 8), 14 -> 4 ms per sweep at N=4096.
 constexpr int EPT = 16;
-constexpr size_t EPS_LDS_BYTES = (size_t)(16 * (EPB + 1) + 16 * (EPB + 16) + 2 * EPB) * sizeof(double);
+__device__ int g_ep_dbg = 0;            // timing experiments only (option ep_dbg): 1 skip the recurrence, 2 skip the Gram phase, 4 skip the rows loop
+constexpr size_t EPS_LDS_BYTES = (size_t)(EPT * (EPB + 1) + EPT * (EPB + EPT) + 2 * EPB) * sizeof(double);
 constexpr int EPS_THREADS = 320;          // wave 0: the in-launch recurrence; waves 1-4: 256 rows of the new factor columns
 __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
                                                             const long* __restrict__ base, int j0, double* __restrict__ S,
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
     __shared__ double Sg[EPT][EPT];              // Sigma_blk(i_t, i_u)
     __shared__ double G[EPT][EPT];               // sum_{k<j0} c_k S(i_t,k) S(i_u,k)
     __shared__ double b0[EPT];                   // sum_{k<j0} q_k S(i_t,k)
+    __shared__ double sv[4][EPT];                // the sites' (ttau, tnu) of the previous sweep, m, y
     const int t = threadIdx.x, lane = t & 63;
     const long i0 = base[0] + j0;
     for (int v = t; v < EPT * j0; v += EPS_THREADS) { const int tt = v / j0, k = v % j0; Srow[tt][k] = S[i0 + tt + (long)k * ld]; }
@@ -248,6 +250,8 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
     __syncthreads();
     for (int v = t; v < EPT * j0; v += EPS_THREADS) { const int tt = v / j0, k = v % j0; gv[tt][k] = cl[k] * Srow[tt][k]; }
     __syncthreads();
+    const int dbg = g_ep_dbg;
+    if (!(dbg & 2))
     {   // (i) Gram matrix (lower part) and b0: EPT (EPT+1) / 2 + EPT dots of length j0, one per thread
         constexpr int NG = EPT * (EPT + 1) / 2;
         if (t < NG) {
@@ -265,23 +269,25 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
         }
     }
     __syncthreads();
-    if (t < 64) {                                // (ii) one wave, lane L = site L (lanes >= EPT idle along)
+    if (t < 64 && !(dbg & 1)) {                  // (ii) one wave, lane L = site L (lanes >= EPT idle along)
         const int L = lane < EPT ? lane : EPT - 1;
         const long i = i0 + L;
         double e[EPT], cN[EPT], qN[EPT];         // e[u] = S(i_L, j0 + u) for u < L; cN / qN: the sites' new (c, q), wave-uniform
         const double Sgd = Sg[L][L] - G[L][L], mub = mu_blk[i] + b0[L];
-        const double tp = ttau_prev[i], np_ = tnu_prev[i], mi = m[i], yi = y[i];
+        if (lane < EPT) { sv[0][lane] = ttau_prev[i]; sv[1][lane] = tnu_prev[i]; sv[2][lane] = m[i]; sv[3][lane] = y[i]; }
+        __builtin_amdgcn_wave_barrier();
         double sa = 0.0, sb = 0.0;               // running sum_{v<u} c_v e_L[v]^2 and sum_{v<u} q_v e_L[v] of this lane's row
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
-            // site u's scalar update, evaluated by every lane on its own row; lane u's result is the one that counts
-            const double sii = Sgd - sa;
-            const double mui = mub + sb;
+            // site u's scalar update on lane u's row, evaluated wave-UNIFORMLY (inputs broadcast first): the branches of the
+            // probit moments are then taken once, not once per distinct lane value
+            const double sii = bcast_lane(Sgd - sa, u);
+            const double mui = bcast_lane(mub + sb, u);
             double t_new, nu_new, cj, qj;
-            ep_site_update(sii, mui, tp, np_, mi, yi, t_new, nu_new, cj, qj);
-            cN[u] = bcast_lane(cj, u);
-            qN[u] = bcast_lane(qj, u);
-            if (lane == u && blockIdx.x == 0) { ttau_cur[i] = t_new; tnu_cur[i] = nu_new; cvec[j0 + u] = cj; qvec[j0 + u] = qj; }
+            ep_site_update(sii, mui, sv[0][u], sv[1][u], sv[2][u], sv[3][u], t_new, nu_new, cj, qj);
+            cN[u] = cj;
+            qN[u] = qj;
+            if (lane == 0 && blockIdx.x == 0) { ttau_cur[i0 + u] = t_new; tnu_cur[i0 + u] = nu_new; cvec[j0 + u] = cj; qvec[j0 + u] = qj; }
             // column j0 + u at the rows of the later sites:  e_L[u] = Sigma_blk(i_L, i_u) - G[L][u] - sum_{v<u} c_v e_u[v] e_L[v]
             double acc = Sg[L][u] - G[L > u ? L : u][L > u ? u : L];
 #pragma unroll
@@ -312,6 +318,7 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
 #pragma unroll
             for (int tt = 0; tt < EPT; ++tt) acc[tt] = sym_at(Sig, ld, r, i0 + tt);
         }
+        if (!(dbg & 4))
         for (int k = 0; k < j0; ++k) {
             const double srk = S[r + (long)k * ld];
 #pragma unroll
@@ -482,6 +489,8 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     *nlZ_out = sc[0] - slZ - 0.5 * t3 - 0.5 * t4 + 0.5 * t5 - 0.5 * t6;
     return PGP_OK;
 }
+
+int ep_set_dbg(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ep_dbg), &v, sizeof(int)) == hipSuccess ? PGP_OK : PGP_ERR_HIP; }
 
 extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para, int flags, const double* mvec,
                           const double* dm, int nmean, int want, int warm, double* ttau_io, double* tnu_io,
