@@ -52,7 +52,7 @@ struct pgp_ctx {
     int eet_merge = 0;                  // inline filler: 1 = same grid as TU_b (gemm_f64_dual_kernel), 0 = its own launch behind it
     int eet_overlap = 3;                // B^-1 = sum_p E_p E_p^T accumulated under the sweep: 0 off (one product after it), 1 on a
                                         // low-priority filler stream, 2 inline on the main stream, 3 inline when npanel <= eet_max_panels
-    int eet_max_panels = 16;
+    int eet_max_panels = 32;
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
     int ep_graph = 0;                   // EP: replay each 128-site block as a captured hipGraph (measured: no gain)
@@ -118,7 +118,7 @@ struct pgp_ctx {
     int gemm_dbg = 64 | 256 | 512;
     int xcd_order = 0;    // 1: XCD-aware super-tile order (measured slower on MI355X for these shapes: off)
     // options
-    int nb_outer = 4;     // leaves (128 columns each) per outer panel -> trailing update K = 512
+    int nb_outer = 0;     // leaves (128 columns each) per outer panel -> trailing update K = 128 nb_outer; 0 = automatic (4, or 8 from N = 12288)
     int trtri_small_tile_below = 2049;   // measured: 64x64 tiles win on every recursion level at N=8192 (more, shorter tiles)
     int small_tile_below = 200;   // use 64x64 tiles when a GEMM has fewer 128-tiles than this
 };
