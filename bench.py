@@ -194,7 +194,7 @@ def extras(lib, _lib, local, d, roof):
             "fit_ms": t5 * 1e3, "sweeps": sw, "ms_per_sweep_incl_params": t5 * 1e3 / max(sw, 1), "nlZ": float(nlz5),
             "algorithmic_bytes_per_sweep_blocked": bytes_sweep,
             "reference_algorithm_bytes_per_sweep": 16.0 * n5 ** 3,
-            "site_sweep_GBs": bytes_sweep / 1e9,
+            "site_sweep_GB_per_sweep": bytes_sweep / 1e9,
             # sweep + fused inverse 2 N^3 / 3, V' = K diag(sW) L^-T N^3 (clipped), Sigma = K - V'V'^T N^3 (lower tiles)
             "epComputeParams_flops_per_sweep": 8.0 * n5 ** 3 / 3.0,
             "workload": "BASELINE configs[4]: GPC + RBF, infEP, N=4096 d=32 (cold start, nlZ + gradients, through model.getPosterior)"}

@@ -146,6 +146,9 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "ep_dbg")) { return ep_set_dbg(value); }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
     if (!strcmp(name, "ep_sym")) { c->ep_sym = value; return PGP_OK; }
+    if (!strcmp(name, "xcd_max_k")) { c->xcd_max_k = value; return PGP_OK; }
+    if (!strcmp(name, "xcd_min_tiles")) { c->xcd_min_tiles = value; return PGP_OK; }
+    if (!strcmp(name, "xcd_super")) { c->xcd_super = value; return PGP_OK; }
     if (!strcmp(name, "s_tile")) { if (value != 0 && value != 64 && value != 128) return -2; c->s_tile = value; return PGP_OK; }
     if (!strcmp(name, "s_dma")) { c->s_dma = value; return PGP_OK; }
     if (!strcmp(name, "merge_tu")) { c->merge_tu = value; return PGP_OK; }
@@ -418,25 +421,39 @@ int upload_scaled(pgp_ctx* c, const double* x_dev, long n, long d, const std::ve
 // private 4 MiB L2 instead of streaming 64 + 8 distinct slabs through all eight L2s.  Speed only: any
 // placement computes the same result.
 static int tile_order(pgp_ctx* c, int mt, int nt, int tri, int off_tiles, const int** out, int* n) {
-    std::vector<int> key = {mt, nt, tri ? 1 : 0, off_tiles};
+    std::vector<int> key = {mt, nt, tri ? 1 : 0, off_tiles, c->xcd_super};
     auto it = c->orders.find(key);
     if (it != c->orders.end()) { *out = it->second.first; *n = it->second.second; return PGP_OK; }
-    // super-tiles in row-major order (long-K rows first), dealt round-robin to the 8 XCDs so that every XCD
-    // sees the same cost profile; exhausted XCD sequences are padded with (-1,-1) no-op entries
-    const int S = 8;
-    std::vector<std::vector<int>> seq(8);
-    int sidx = 0;
+    // super-tiles (S x S tiles: S A slabs + S B slabs serve S^2 tiles out of one XCD's L2), biggest first, each handed to
+    // the XCD with the least work so far (LPT): the triangular edge makes partial super-tiles, and a plain round-robin
+    // left one XCD up to a whole super-tile = one full round of its 64 slots behind (measured: -46 % FETCH but +13 % time)
+    const int S = c->xcd_super > 0 ? c->xcd_super : 8;
+    std::vector<std::vector<int>> sts;
     for (int SI = 0; SI * S < mt; ++SI)
         for (int SJ = 0; SJ * S < nt; ++SJ) {
             std::vector<int> st;
             for (int ti = SI * S; ti < std::min(mt, SI * S + S); ++ti)
                 for (int tj = SJ * S; tj < std::min(nt, SJ * S + S); ++tj)
                     if (!tri || ti + off_tiles >= tj) { st.push_back(ti); st.push_back(tj); }
-            if (st.empty()) continue;
-            auto& dst = seq[sidx % 8];
-            dst.insert(dst.end(), st.begin(), st.end());
-            ++sidx;
+            if (!st.empty()) sts.push_back(std::move(st));
         }
+    std::stable_sort(sts.begin(), sts.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a.size() > b.size(); });
+    std::vector<std::vector<int>> seq(8);
+    for (auto& st : sts) {
+        int best = 0;
+        for (int x = 1; x < 8; ++x) if (seq[x].size() < seq[best].size()) best = x;
+        seq[best].insert(seq[best].end(), st.begin(), st.end());
+    }
+    // level the eight sequences to within one tile: single tiles move from the end of the longest to the shortest (a few
+    // tiles per launch lose their super-tile's locality; an XCD that is a partial super-tile behind costs a whole tail)
+    for (;;) {
+        int lo = 0, hi = 0;
+        for (int x = 1; x < 8; ++x) { if (seq[x].size() < seq[lo].size()) lo = x; if (seq[x].size() > seq[hi].size()) hi = x; }
+        if (seq[hi].size() < seq[lo].size() + 4) break;
+        const int tj = seq[hi].back(); seq[hi].pop_back();
+        const int ti = seq[hi].back(); seq[hi].pop_back();
+        seq[lo].push_back(ti); seq[lo].push_back(tj);
+    }
     size_t maxlen = 0;
     for (auto& q : seq) maxlen = std::max(maxlen, q.size() / 2);
     const int nb = (int)maxlen * 8;
@@ -477,14 +494,20 @@ int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
     if (!st) st = c->st;
     if (g.batch < 1) g.batch = 1;
     g.dbg |= c->gemm_dbg;
-    if (g.tri == 1 && !g.order && !c->xcd_order) {
+    // XCD-aware order only for bulk launches (>= xcd_min_tiles 128-tiles, unbatched): a latency-bound grid of a few
+    // tiles would be serialised on one or two XCDs by it; and only up to K = xcd_max_k (measured: N = 8192, K = 512:
+    // same speed, -40 % FETCH_SIZE per launch; N = 16384, K = 1024: 6 % slower)
+    bool xcd = false;
+    if (c->xcd_order && !g.order && g.tile != 64 && g.batch == 1 && g.K <= c->xcd_max_k) {
+        const long mt = g.M / 128, nt = g.N / 128;
+        const long tiles = g.tri == 2 ? mt * (mt + 1) / 2 : (g.tri == 1 ? mt * nt - nt * (nt - 1) / 2 : mt * nt);
+        xcd = tiles >= c->xcd_min_tiles;
+    }
+    if (g.tri == 1 && !g.order && !xcd) {
         const int T = g.tile == 64 ? 64 : 128;
         CHK(tri_tile_list(c, g.M / T, g.N / T, g.tri_off / T, &g.order, &g.norder));
     }
-    if (c->xcd_order && !g.order) {
-        const int T = g.tile == 64 ? 64 : 128;
-        CHK(tile_order(c, g.M / T, g.N / T, g.tri, g.tri ? g.tri_off / T : 0, &g.order, &g.norder));
-    }
+    if (xcd) CHK(tile_order(c, g.M / 128, g.N / 128, g.tri, g.tri ? g.tri_off / 128 : 0, &g.order, &g.norder));
     ProfScope ps(c, cls, g.flops, 0.0, st, gemm_f64_uses_dma128(g) ? PC_KERNEL_DMA128 : -1);
     return gemm_f64_launch(g, st);
 }

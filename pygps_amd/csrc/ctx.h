@@ -85,6 +85,9 @@ struct pgp_ctx {
     double *Dk = nullptr, *dpack = nullptr, *Xs = nullptr, *Yn = nullptr;
     double* Dt = nullptr;               // E_D transposed (w x w): B operand of the panel solve in the LDS-DMA GEMM's layout
     int half_wave = 0;                  // trailing updates with <= 256 tiles: 1 = one workgroup per CU, 2 = 64-tiles
+    int xcd_max_k = 512;                // ... and a k extent of at most this
+    int xcd_min_tiles = 256;            // xcd_order applies to launches with at least this many 128-tiles
+    int xcd_super = 8;                  // xcd_order: super-tile edge in tiles
     int s_tile = 0;                     // tile size of the panel solves: 0 = automatic
     int s_dma = 0;                      // 1: panel solves read a transposed copy of E_D (n-contiguous, the LDS-DMA GEMM form; measured neutral); 0: K-contiguous E_D
     size_t Xs_bytes = 0;
@@ -116,7 +119,7 @@ struct pgp_ctx {
     // (fetched during the k-loop into the registers the DMA frees), 512 16-byte epilogue stores -- the measured-best set;
     // 1/2/4/8 ablations, 16 atomic epilogue, 32 de-phased workgroups, 128 phase stamps
     int gemm_dbg = 64 | 256 | 512;
-    int xcd_order = 0;    // 1: XCD-aware super-tile order (measured slower on MI355X for these shapes: off)
+    int xcd_order = 0;    // 1: XCD-aware super-tile order for bulk launches (see gemm_prof): -40 % FETCH per launch, 1-3 % slower
     // options
     int nb_outer = 0;     // leaves (128 columns each) per outer panel -> trailing update K = 128 nb_outer; 0 = automatic (4, or 8 from N = 12288)
     int trtri_small_tile_below = 2049;   // measured: 64x64 tiles win on every recursion level at N=8192 (more, shorter tiles)

@@ -189,7 +189,7 @@ def test_two_products_in_one_grid(lib):
 
 @pytest.mark.parametrize("opts", [dict(dserver=1), dict(dserver=1, ds_exclusive=0), dict(potrf_v1=1), dict(lookahead=0),
                                   dict(la2=1), dict(s_side=1), dict(merge_tu=1), dict(cu_reserve=-8), dict(cu_reserve=-8, s_side=1),
-                                  dict(eet_overlap=0), dict(eet_overlap=1), dict(eet_overlap=1, eet_tile=64), dict(eet_overlap=2, eet_merge=1), dict(s_dma=1, s_tile=128), dict(s_tile=128), dict(eet_first=0), dict(small_tile_below=256)])
+                                  dict(eet_overlap=0), dict(eet_overlap=1), dict(eet_overlap=1, eet_tile=64), dict(eet_overlap=2, eet_merge=1), dict(s_dma=1, s_tile=128), dict(s_tile=128), dict(eet_first=0), dict(small_tile_below=256), dict(xcd_order=1), dict(xcd_order=1, xcd_super=4, xcd_min_tiles=64)])
 def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
     """Every schedule of the Cholesky sweep -- the default diagonal-panel chain, the resident diagonal-panel server
     (left-looking, in-kernel go signals), the round-1 leaf chain, the serial order, and the measured-and-rejected
@@ -216,7 +216,7 @@ def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
                     assert relerr(got["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-8
     finally:
         for k in opts:
-            lib.pgp_set_option(ctx, k.encode(), {"lookahead": 1, "ds_exclusive": 1, "eet_overlap": 3, "eet_tile": 128, "s_dma": 0, "s_tile": 0, "eet_first": -1, "small_tile_below": 200}.get(k, 0))
+            lib.pgp_set_option(ctx, k.encode(), {"lookahead": 1, "ds_exclusive": 1, "eet_overlap": 3, "eet_tile": 128, "s_dma": 0, "s_tile": 0, "eet_first": -1, "small_tile_below": 200, "xcd_order": 0, "xcd_super": 8, "xcd_min_tiles": 256}.get(k, 0))
         lib.pgp_set_option(ctx, b"cu_reserve", 0)
 
 

@@ -4,7 +4,8 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_r02
-mkdir -p $O
+rm -rf $O/stats1 $O/stats2 $O/pmc $O/final
+mkdir -p $O $O/final
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line itself (with cpu_baseline, extras)
 timeout 900 python $R/bench.py > $O/bench.json 2> $O/bench.err
@@ -18,4 +19,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -- python $R/bench.py --steps 3 --windows 1 --prof-steps 1 --streams 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_$d.err
 done
 python $R/tools/pmc_traffic.py $O/pmc $O/r02_gemm_f64_hbm_traffic.json > /dev/null 2>> $O/pmc.err
-find $O -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
+# 4. the files profiles/ tracks, under their tracked names (copy gpurun_out/prof_r02/final/* to profiles/)
+grep '^{' $O/bench.json > $O/final/r02_bench.json
+grep '^{' $O/bench_streams1_under_rocprof.json > $O/final/r02_bench_streams1_under_rocprof.json
+grep '^{' $O/bench_streams2_under_rocprof.json > $O/final/r02_bench_streams2_under_rocprof.json
+cp $(ls -t $O/stats1/*/*_kernel_stats.csv | head -1) $O/final/r02_bench_streams1_kernel_stats.csv
+cp $(ls -t $O/stats2/*/*_kernel_stats.csv | head -1) $O/final/r02_bench_streams2_kernel_stats.csv
+cp $(ls -t $O/pmc/fetch/*/*_counter_collection.csv | head -1) $O/final/r02_pmc_fetch_counter_collection.csv
+cp $(ls -t $O/pmc/write/*/*_counter_collection.csv | head -1) $O/final/r02_pmc_write_counter_collection.csv
+cp $O/r02_gemm_f64_hbm_traffic.json $O/final/
+ls -la $O/final

@@ -23,16 +23,20 @@ def load(pattern, counter, match):
 if __name__ == "__main__":
     root = sys.argv[1]
     out = sys.argv[2]
-    f, nf = load(root + "/fetch/**/*counter_collection.csv", "FETCH_SIZE", "gemm_f64_kernel")
-    w, nw = load(root + "/write/**/*counter_collection.csv", "WRITE_SIZE", "gemm_f64_kernel")
+    DOM = "gemm_f64_kernel<128, 128, false, false, true>"        # the dominant instantiation (LDS-DMA 128-tile kernel)
+    f, nf = load(root + "/fetch/**/*counter_collection.csv", "FETCH_SIZE", DOM)
+    w, nw = load(root + "/write/**/*counter_collection.csv", "WRITE_SIZE", DOM)
+    fa, nfa = load(root + "/fetch/**/*counter_collection.csv", "FETCH_SIZE", "gemm_f64_kernel")
+    wa, nwa = load(root + "/write/**/*counter_collection.csv", "WRITE_SIZE", "gemm_f64_kernel")
     assert nf and nw, (nf, nw)
     fetch_b = f * 1024.0 * 2.0 / nf
     write_b = w * 1024.0 / nw
-    json.dump({"kernel": "gemm_f64_kernel", "launches_sampled": nf,
+    json.dump({"kernel": DOM, "launches_sampled": nf,
                "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
                "bytes_per_launch": fetch_b + write_b,
+               "all_gemm_f64_instantiations": {"launches_sampled": nfa, "bytes_per_launch": fa * 2048.0 / nfa + wa * 1024.0 / nwa},
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python bench.py --steps 3 --windows 1 --prof-steps 1 --streams 1 "
-                       "--warmup 1 --no-cpu-baseline`, all gemm_f64_kernel dispatches averaged; FETCH_SIZE x2 "
+                       "--warmup 1 --no-cpu-baseline --no-extras`, dispatches of that instantiation averaged; FETCH_SIZE x2 "
                        "(gfx950 wide-load correction, MI355X_MICROARCH.md HBM section), KiB -> bytes"},
               open(out, "w"), indent=1)
     print(open(out).read())
