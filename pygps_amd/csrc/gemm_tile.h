@@ -202,43 +202,51 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             GT_STAMP(1);
         }
         int buf = 0;
+        // fragments are double-buffered in registers: the LDS reads of k-substep ks+1 are issued BEFORE the 16 MFMAs of
+        // substep ks, so their latency hides behind 1024 cycles of matrix work.  The same holds ACROSS the stage barrier:
+        // the last substep's MFMAs of a stage are held back until after the barrier and issued behind the first fragment
+        // reads of the next stage (they only need registers), so the wave does not restart each stage with an exposed
+        // LDS round trip (measured: the per-stage barrier + restart cost 5.7 % of the K = 512 kernel)
+        double fa[2][FM], fb[2][FN];
+        auto ldfrag = [&](int b, int ks, int slot) {
+            const double* sa = smem + b * STAGE;
+            const double* sb = sa + ASZ;
+            const int k = ks * 4 + l4;
+#pragma unroll
+            for (int im = 0; im < FM; ++im) {
+                const int m = wm + im * 16 + l15;
+                fa[slot][im] = AKC ? sa[m * SK + k] : sa[k * SA + m];
+            }
+#pragma unroll
+            for (int in = 0; in < FN; ++in) {
+                const int n = wn + in * 16 + l15;
+                fb[slot][in] = BKC ? sb[n * SK + k] : sb[k * SB + n];
+            }
+        };
+        auto mfmas = [&](int slot) {
+#pragma unroll
+            for (int in = 0; in < FN; ++in)
+#pragma unroll
+                for (int im = 0; im < FM; ++im)
+                    acc[im][in] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[slot][in], fa[slot][im], acc[im][in], 0, 0, 0);
+        };
+        constexpr int NS = BK / 4;                // k-substeps per stage
+        ldfrag(0, 0, 0);
         auto kstep = [&](int kt) {
             const bool more = kt + BK < k1;
             if constexpr (DMA) { if (more) dma_stage(buf ^ 1); }     // the other stage was last read before the previous barrier
             else if (more && !(g.dbg & 1)) gload(kt + BK);
-            const double* sa = smem + buf * STAGE;
-            const double* sb = sa + ASZ;
-            // fragments are double-buffered in registers: the LDS reads of k-step ks+1 are issued BEFORE the 16
-            // MFMAs of k-step ks, so their latency hides behind 1024 cycles of matrix work instead of stalling
-            // the (in-order) wave once per k-step
-            double fa[2][FM], fb[2][FN];
-            auto ldfrag = [&](int ks, int slot) {
-                const int k = ks * 4 + l4;
 #pragma unroll
-                for (int im = 0; im < FM; ++im) {
-                    const int m = wm + im * 16 + l15;
-                    fa[slot][im] = AKC ? sa[m * SK + k] : sa[k * SA + m];
-                }
-#pragma unroll
-                for (int in = 0; in < FN; ++in) {
-                    const int n = wn + in * 16 + l15;
-                    fb[slot][in] = BKC ? sb[n * SK + k] : sb[k * SB + n];
-                }
-            };
-            ldfrag(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < BK / 4; ++ks) {
-                if (ks + 1 < BK / 4) ldfrag(ks + 1, (ks + 1) & 1);
-#pragma unroll
-                for (int in = 0; in < FN; ++in)
-#pragma unroll
-                    for (int im = 0; im < FM; ++im)
-                        acc[im][in] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ks & 1][in], fa[ks & 1][im], acc[im][in], 0, 0, 0);
+            for (int ks = 0; ks + 1 < NS; ++ks) {
+                ldfrag(buf, ks + 1, (ks + 1) & 1);
+                mfmas(ks & 1);
             }
-            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (DMA) { if (!(g.dbg & 1024)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // dbg 1024: timing experiment (wrong results)
             else if (more && !(g.dbg & 1)) sstore(buf ^ 1);
             if (!(g.dbg & 2)) __syncthreads();
             if (!(g.dbg & 1)) buf ^= 1;
+            if (more) ldfrag(buf, 0, NS & 1);     // first fragments of the next stage, behind ...
+            mfmas((NS - 1) & 1);                  // ... the held-back last substep of this one
         };
         int kt = k0;
         if constexpr (DMA) {
