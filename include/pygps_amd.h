@@ -125,13 +125,16 @@ void pgp_fitc_free(pgp_ctx* ctx, pgp_fitc* f);
  * pgp_potrs: R (n,n) UPPER factor row-major, Bm (n,nrhs) row-major in -> X = (R'R)^-1 Bm out.   */
 /* Device-pointer primitives of the single-fit multi-GPU Cholesky (no reference counterpart -- the
  * reference's tools.jitchol, Core/tools.py:31-77, factors on one host).  pygps_amd/multigpu.py drives them: one column panel
- * per call, caller-owned device memory, torch.distributed (RCCL) broadcasts in between.  Both return after the work is done.
+ * per call, caller-owned device memory, torch.distributed (RCCL) broadcasts in between.  The work runs on the context's
+ * stream: pgp_dev_panel_factor returns after everything queued so far is done, pgp_dev_panel_update only queues its launch,
+ * pgp_dev_sync waits for the stream.
  *   pgp_dev_panel_factor: factor the w x w block on top of `panel` (rows x w, column-major, ld), solve the rows below it.
  *                         Returns k > 0 when pivot k of the block is not positive.
  *   pgp_dev_panel_update: C (M x w, ldc) -= Y Y[0:w,:]' over the lower trapezoid, Y (M x k, ldy) = the broadcast panel's
  *                         rows facing C. */
 int pgp_dev_panel_factor(pgp_ctx* ctx, double* panel_dev, int64_t ld, int64_t rows, int w);
 int pgp_dev_panel_update(pgp_ctx* ctx, double* C_dev, int64_t ldc, int64_t M, int w, const double* Y_dev, int64_t ldy, int k);
+int pgp_dev_sync(pgp_ctx* ctx);
 int pgp_potrf(pgp_ctx* ctx, const double* A, int64_t n, double* L_out);
 int pgp_potrs(pgp_ctx* ctx, const double* R, int64_t n, const double* Bm, int64_t nrhs, double* X_out);
 

@@ -1534,8 +1534,9 @@ int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n,
 // ---- helper functions ------------------------------------------------------------------------------
 // ---- device-pointer primitives of the multi-GPU (1-D block-cyclic) Cholesky executor, pygps_amd/multigpu.py --------
 // The caller owns the device memory (one column panel per call, column-major, leading dimension ld); the work runs on
-// the context's stream and the call returns after it has finished (the executor interleaves these calls with
-// torch.distributed broadcasts on torch's stream).
+// the context's stream (the executor interleaves these calls with torch.distributed broadcasts on torch's stream):
+// pgp_dev_panel_factor returns after everything queued so far has finished, pgp_dev_panel_update only queues its
+// launch, pgp_dev_sync waits for the stream.
 
 // Panel step of the right-looking sweep on ONE column panel: the w x w block at the top of `panel` is factored
 // (lower Cholesky), the rows - w rows below it are solved against it in place (X <- X L_D^-T): D(p) and S(p) of
@@ -1582,7 +1583,12 @@ int pgp_dev_panel_update(pgp_ctx* c, double* C, int64_t ldc, int64_t M, int w, c
     const long t128 = (M / 128) * (w / 128) - (long)(w / 128) * (w / 128 - 1) / 2;
     g.tile = t128 < c->small_tile_below ? 64 : 128;
     g.flops = 2.0 * (double)k * ((double)M * w - 0.5 * (double)w * w);
-    CHK(gemm_prof(c, PC_GEMM_TRAIL, g, c->st));
+    return gemm_prof(c, PC_GEMM_TRAIL, g, c->st);       // asynchronous: pgp_dev_sync / the next pgp_dev_panel_factor waits
+}
+
+int pgp_dev_sync(pgp_ctx* c) {
+    if (!c) return -1;
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->st));
     return PGP_OK;
 }

@@ -10,9 +10,9 @@ executes that plan on the device:
     all ranks:  pgp_dev_panel_update   -- C_j -= Y_p Y_p[j]' on the fp64-MFMA GEMM for every OWNED panel j > p,
                 the next panel first (it is the next owner's look-ahead target)
 
-Status: correct by construction and tested (world 1 over RCCL, world 2 sharing one GPU over gloo, against LAPACK); every
-step is synchronous -- the broadcast of step p+1 is not yet overlapped with the trailing update of step p (the plan's
-look-ahead) -- and it has never been timed on more than one GPU.  Product rule as everywhere: no CPU fallback, the
+Status: correct by construction and tested (world 1 over RCCL, world 2 sharing one GPU over gloo, against LAPACK); the
+steps are synchronous (the updates of a step are queued without waiting, but the broadcast of step p+1 is not yet
+overlapped with the trailing update of step p -- the plan's look-ahead) and it has never been timed on more than one GPU.  Product rule as everywhere: no CPU fallback, the
 primitives raise without the HIP library.
 """
 import numpy as np
@@ -86,6 +86,7 @@ class ShardedCholesky(object):
 
     def factor(self):
         torch, lib, plan, w, npd = self.torch, self.lib, self.plan, self.w, self.np
+        pending = []
         for s in plan.steps():
             p = s.p
             rows = npd - p * w                              # panel p from its diagonal block down
@@ -111,4 +112,10 @@ class ShardedCholesky(object):
                 cptr = self.local.data_ptr() + 8 * (cj * npd + j * w)
                 yptr = ybuf.data_ptr() + 8 * ((j - p - 1) * w)
                 _lib.check(lib.pgp_dev_panel_update(self.ctx, cptr, npd, m, w, yptr, below, w), "pgp_dev_panel_update")
+            # the queued updates read ybuf: it must outlive them (torch's caching allocator would hand the block out again)
+            pending.append(ybuf)
+            if len(pending) > 1:
+                _lib.check(lib.pgp_dev_sync(self.ctx), "pgp_dev_sync")
+                del pending[:-1]
+        _lib.check(lib.pgp_dev_sync(self.ctx), "pgp_dev_sync")
         return self
