@@ -187,9 +187,9 @@ def extras(lib, _lib, local, d, roof):
             sw = int(m5.inffunc.sweeps)
         t5 = min(ts)
         # blocked sweep: per site one column of S (8 N B written) + the <=128 (64 on average) pending factor columns re-read
-        # by the 16-site kernel once per 16 sites (8 N 64 / 16 B per site), per 128 sites one K=128 fold of the LOWER
-        # triangle of Sigma (read + write 8 N^2 B)
-        bytes_sweep = n5 * (8.0 * n5 + 8.0 * n5 * 64 / 16.0) + (n5 / 128.0) * 8.0 * n5 * n5
+        # by the 16-site kernel once per 16 sites (8 N 64 / 16 B per site); per 128 sites one K=128 fold of the rows >= r0
+        # of the LOWER triangle of Sigma (r0 = first site still to come: read + write 8 (N^2 - r0^2) B)
+        bytes_sweep = n5 * (8.0 * n5 + 8.0 * n5 * 64 / 16.0) + sum(8.0 * (n5 * n5 - float(r0) ** 2) for r0 in range(128, n5, 128))
         out["cfg5_ep_N4096_d32"] = {
             "fit_ms": t5 * 1e3, "sweeps": sw, "ms_per_sweep_incl_params": t5 * 1e3 / max(sw, 1), "nlZ": float(nlz5),
             "algorithmic_bytes_per_sweep_blocked": bytes_sweep,

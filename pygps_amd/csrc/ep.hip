@@ -601,7 +601,13 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
             // blocked sweep: site i reads the (ttau, tnu) it had at the start of the sweep (each site is visited once)
             HIP_TRY(hipMemcpyAsync(w.prev, w.ttau_d, np * sizeof(double), hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.prev + np, w.tnu_d, np * sizeof(double), hipMemcpyDeviceToDevice, st));
-            auto fold = [&]() -> int {
+            // r0 >= 0: only the rows >= r0 of the lower triangle are brought up to date -- the sites still to come in this
+            // sweep are i >= r0 and read column i of the symmetric matrix = row i of its lower triangle (left of the
+            // diagonal) and column i below it; rows < r0 are never read again before _epComputeParams rebuilds Sigma from
+            // scratch.  Halves the fold work once more and ends the 528-tiles-on-512-slots second round.  r0 < 0: everything
+            // (the captured-graph path replays one fold for every block).
+            auto fold = [&](long r0) -> int {
+                if (r0 >= np) return PGP_OK;                                           // nothing of this sweep reads it any more
                 hipLaunchKernelGGL(ep_fold_prep_kernel, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, st, w.S, w.Sc, np, np,
                                    w.cq, w.cq + EPB, w.mu_d);                          // Sc = S diag(c) ; mu += S q
                 GemmArgs g{};                                                          // Sigma -= S diag(c) S'
@@ -611,6 +617,12 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                 g.flops = 2.0 * (double)np * np * EPB;
                 // symmetric rank-EPB update: only the lower tiles (the site kernels read Sigma_blk through its lower triangle)
                 if (c->ep_sym) { g.tri = 2; g.mask_diag = 1; g.flops *= 0.5; }
+                if (c->ep_sym && r0 > 0) {                                             // rows >= r0: lower trapezoid, tri_off = r0
+                    g.A = w.Sc + r0; g.C = w.Sig + r0; g.M = (int)(np - r0);
+                    g.tri = 1; g.tri_off = (int)r0;
+                    g.flops = (double)EPB * ((double)np * np - (double)r0 * r0);
+                    g.tile = 128;
+                }
                 CHK(gemm_prof(c, PC_GEMM_INNER, g));
                 // no re-zeroing of S / c / q: every site launch of the next block writes its columns (all rows) and its c, q
                 // entries before anything reads them, and a fold only follows a full block
@@ -618,7 +630,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
             };
             HIP_TRY(hipMemsetAsync(w.S, 0, (size_t)EPB * np * sizeof(double), st));
             HIP_TRY(hipMemsetAsync(w.cq, 0, (size_t)2 * EPB * sizeof(double), st));
-            auto block_launches = [&](int nsite, bool do_fold, const long* base = nullptr) -> int {
+            auto block_launches = [&](int nsite, bool do_fold, const long* base = nullptr, long fold_r0 = -1) -> int {
                 if (!base) base = w.base;
                 int j = 0;
                 for (; j + EPT <= nsite; j += EPT)
@@ -629,7 +641,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                     hipLaunchKernelGGL(ep_site_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np,
                                        base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
                                        w.tnu_d);
-                if (do_fold) CHK(fold());
+                if (do_fold) CHK(fold(fold_r0));
                 return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
             };
             const long nfull = n / EPB;
@@ -650,7 +662,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                 if (block_graph) {                                   // the captured launches read the offset from base[0]
                     hipLaunchKernelGGL(ep_set_base_kernel, dim3(1), dim3(1), 0, st, w.base, b * EPB);
                     HIP_TRY(hipGraphLaunch(block_graph, st));
-                } else EP_TRY(block_launches(EPB, true, w.bases + b));
+                } else EP_TRY(block_launches(EPB, true, w.bases + b, c->ep_sym ? (b + 1) * EPB : -1));
             }
             if (n % EPB) EP_TRY(block_launches((int)(n % EPB), false, w.bases + nfull));
             // Sigma / mu are rebuilt from (ttau, tnu) by ep_compute_params below: the last partial block need not be folded
