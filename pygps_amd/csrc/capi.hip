@@ -658,7 +658,10 @@ static int potrf_blocked_v1(pgp_ctx* c, double* F, long ld, long np, long mrows,
 // S is out of place (reads Xs, writes the factor / inverse rows), which is free: TU_a already reads and writes those
 // columns once, it just writes them to Xs instead.  The matrix lives in two pieces: logical rows [0, mrows) in F
 // (factor + rhs rows, what a posterior handle keeps) and rows [mrows, mrows + np) in E (fused inverse, scratch).
-struct SweepMat { double* F; long ldf; long mrows; double* E; long lde; long np; };
+// dense2 > 0: the second piece is NOT the fused inverse but dense2 extra right-hand-side rows (all of them take part from
+// the first panel on: they receive the forward substitution X <- X L^-T, like the rhs rows inside F)
+struct SweepMat { double* F; long ldf; long mrows; double* E; long lde; long np; long dense2 = 0;
+                  long rows2(int blocks) const { return !E ? 0 : (dense2 > 0 ? dense2 : (long)blocks * 128); } };
 
 static int ensure_stage(pgp_ctx* c, long rows, int w) {
     const size_t need = (size_t)rows * w * sizeof(double);
@@ -680,7 +683,7 @@ static int diag_factor(pgp_ctx* c, const SweepMat& m, int s0, int s1, const doub
     CHK(factor_panel(c, c->Dk, ldd, RowEnd{(long)w, true}, 0, s1 - s0, st, c->dpack, s0 * 128));
     { ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
       CHK(diag_out_launch(c->Dk, ldd, w, m.F + (long)s0 * 128 * (1 + m.ldf), m.ldf,
-                          m.E ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, st, c->s_dma ? c->Dt : nullptr, w)); }
+                          (m.E && !m.dense2) ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, st, c->s_dma ? c->Dt : nullptr, w)); }
     return PGP_OK;
 }
 
@@ -690,7 +693,7 @@ static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const doub
     const bool own = !Dk;                                     // the launch chain's own scratch: diag_factor also left E_D^T in c->Dt
     if (!Dk) Dk = c->Dk;
     const int w = (s1 - s0) * 128;
-    const long r0 = (long)s1 * 128, r1 = m.mrows + (m.E ? (long)s0 * 128 : 0);
+    const long r0 = (long)s1 * 128, r1 = m.mrows + m.rows2(s0);
     if (r1 <= r0) return PGP_OK;
     GemmArgs g{};
     g.A = Xs + r0; g.lda = ldx; g.a_kc = 0;
@@ -717,7 +720,7 @@ static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c
                             unsigned* stg_counter = nullptr, unsigned* stg_flag = nullptr,
                             const GemmArgs* extra = nullptr) {
     if (c1 <= c0) return extra ? gemm_prof(c, PC_GEMM_LAUUM, *extra, st) : PGP_OK;
-    const long r0 = (long)c0 * 128, r1 = m.mrows + (m.E ? (long)k1 * 128 : 0);
+    const long r0 = (long)c0 * 128, r1 = m.mrows + m.rows2(k1);
     GemmArgs g{};
     g.A = m.F + r0 + (long)k0 * 128 * m.ldf; g.lda = m.ldf; g.a_kc = 0;
     g.B = g.A; g.ldb = m.ldf; g.b_kc = 0;
@@ -736,7 +739,7 @@ static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c
     }
     g.M = (int)(r1 - r0); g.N = (c1 - c0) * 128; g.K = (k1 - k0) * 128;
     g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
-    if (split) g.zero_from = (int)(m.mrows + (long)k0 * 128 - r0);     // this panel's own inverse rows: first touch
+    if (split && !m.dense2) g.zero_from = (int)(m.mrows + (long)k0 * 128 - r0);     // this panel's own inverse rows: first touch
     const long t128 = (long)(g.M / 128) * (g.N / 128) - (long)(g.N / 128) * (g.N / 128 - 1) / 2;
     g.tile = t128 < c->small_tile_below ? 64 : 128;
     // at most one 128-tile per CU (TU_a at N = 8192: 254 tiles): the dispatcher still packs two workgroups onto one CU
@@ -808,10 +811,10 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     const int q = c->nb_outer > 0 ? std::min(c->nb_outer, 8) : (nblk >= 96 ? 8 : 4);
     const int npanel = (nblk + q - 1) / q;
     const int wmax = q * 128;
-    const long ldx = m.mrows + m.np;                              // staging buffer indexed by logical row
+    const long ldx = m.mrows + (m.dense2 > 0 ? m.dense2 : m.np);   // staging buffer indexed by logical row
     const bool la = c->lookahead && npanel >= 3;
     // the resident server only pays when there is a trailing update to overlap with
-    const bool server = la && c->dserver && q <= 4 && npanel <= diag_server_max_panels();
+    const bool server = la && c->dserver && q <= 4 && npanel <= diag_server_max_panels() && !m.dense2;
     const long xs_stride = ldx * wmax;                            // server mode: two staging buffers (panel parity)
     CHK(ensure_stage(c, server ? 2 * ldx : ldx, wmax));
     double* Xs = c->Xs;
@@ -845,6 +848,9 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         if (m.mrows > r0)
             HIP_TRY(hipMemcpy2DAsync(Xs + r0, ldx * sizeof(double), m.F + r0, m.ldf * sizeof(double),
                                      (m.mrows - r0) * sizeof(double), (size_t)s1 * 128, hipMemcpyDeviceToDevice, main));
+        if (m.E && m.dense2 > 0)                                  // the dense second piece takes part from panel 0 on
+            HIP_TRY(hipMemcpy2DAsync(Xs + m.mrows, ldx * sizeof(double), m.E, m.lde * sizeof(double),
+                                     m.dense2 * sizeof(double), (size_t)s1 * 128, hipMemcpyDeviceToDevice, main));
         if (server) CHK(diag_server_go(c->dflags, 0, main));
         else CHK(diag_factor(c, m, 0, s1, m.F, m.ldf, main));
     }
@@ -888,7 +894,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         HIP_TRY(hipStreamWaitEvent(main, c->ev_ds2, 0));
         return PGP_OK;
     }
-    if (la && c->merge_tu && !server) {
+    if (la && c->merge_tu && !server && !m.dense2) {
         // One trailing-update launch per panel (next panel's columns first, into the staging buffer); the tile that
         // completes them releases stg[p+1] from inside the kernel and the panel stream -- parked on that flag -- factors
         // the next diagonal block while the rest of the update runs.  No half-wave TU_a launch; the price is that the
@@ -921,7 +927,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         }
         return PGP_OK;
     }
-    if (la && c->la2 && !server) {
+    if (la && c->la2 && !server && !m.dense2) {
         // Depth-2 look-ahead on three streams.  The critical chain  D(p) -> S(p) -> TU_a(p) -> D(p+1)  runs on the panel
         // and side streams; the main stream only carries the big in-place updates TU_b(p), split so that the columns the
         // NEXT chain step reads (panel p+2: TU_b1) come first.  The half-wave launches of the chain (S, TU_a: ~254 tiles on
@@ -993,9 +999,9 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     c->eet_join = nullptr;
     // eet_overlap: 1 = filler stream, 2 = inline (behind / inside TU_b on the main stream), 3 = inline up to
     // eet_max_panels panels (default: beyond that the chain is amortised and the one-shot long-K product is faster)
-    const bool fill_inline = la && m.E && c->eet_out &&
+    const bool fill_inline = la && m.E && !m.dense2 && c->eet_out &&
                              (c->eet_overlap == 2 || (c->eet_overlap == 3 && npanel <= c->eet_max_panels));
-    if (la && c->eet_overlap == 1 && m.E && c->eet_out) {
+    if (la && c->eet_overlap == 1 && m.E && !m.dense2 && c->eet_out) {
         if (!c->st_fill) {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -1108,6 +1114,16 @@ int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with
     // every panel, i.e. at least one spare row block between the factor's rows and the inverse rows
     if (with_inverse && E != F + mrows && mrows < np + 128) return -1;
     SweepMat m{F, ld, mrows, with_inverse ? E : nullptr, lde, np};
+    return potrf_blocked_v2(c, m);
+}
+
+// The same sweep with a SECOND piece of nrhs2 dense right-hand-side rows in their own buffer R (leading dimension ldr; row n,
+// column k at R[n + k ldr]): on return R = R L^-T, i.e. row n of R holds (L^-1 r_n)' for the right-hand side r_n = R(n, :)'.
+// The rows ride along in the panel solves and trailing updates of the sweep (N^2 flops per row inside the bulk MFMA launches).
+int potrf_blocked_rhs(pgp_ctx* c, double* F, long ld, long np, long mrows, double* R, long ldr, long nrhs2) {
+    if (c->potrf_v1 || !R || nrhs2 <= 0 || nrhs2 % 128 || mrows < np + 128) return -1;
+    SweepMat m{F, ld, mrows, R, ldr, np};
+    m.dense2 = nrhs2;
     return potrf_blocked_v2(c, m);
 }
 

@@ -56,7 +56,8 @@ struct pgp_ctx {
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
     int ep_graph = 0;                   // EP: replay each 128-site block as a captured hipGraph (measured: no gain)
-    int ep_fused = 1;                   // EP: parameter recomputation through the fused inverse (V' = K diag(sW) L^-T as one product)
+    int ep_fused = 2;                   // EP parameter recomputation: 0 blocked multi-rhs solve, 1 through the fused inverse (V' = K diag(sW)
+                                        // L^-T as one product), 2 K diag(sW) as dense right-hand-side rows of the sweep
     int ep_sym = 1;                     // EP: Sigma kept current in its lower triangle only (folds and K - V'V on the lower tiles)
     int ep_block = 1;                   // EP: blocked site sweep (rank-1 updates folded every 128 sites); 0 = update Sigma per site
     int fused_inverse = 1;              // 1: L^-T falls out of the Cholesky sweep (appended identity rows); 0: recursive trtri
@@ -284,4 +285,5 @@ int ensure_workspace(pgp_ctx* c, long np);
 int solve_lower_multi(pgp_ctx* c, const double* L, long ldl, const double* Wd, double* Y, long ldy, long np, int nrhs,
                       bool trans);
 int ep_set_dbg(int v);
+int potrf_blocked_rhs(pgp_ctx* c, double* F, long ld, long np, long mrows, double* R, long ldr, long nrhs2);
 int eet_lower(pgp_ctx* c, const double* E, long lde, double* Binv, long ldb, long np);

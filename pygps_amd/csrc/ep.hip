@@ -379,13 +379,13 @@ __global__ __launch_bounds__(256) void ep_fold_prep_kernel(const double* __restr
 // F (column-major lower, ldf) = I + s s' o K ; Y (column-major, ld np) = diag(s) K     (K symmetric, ld np)
 __global__ __launch_bounds__(256) void ep_build_kernel(const double* __restrict__ K, long np,
                                                        const double* __restrict__ s, double* __restrict__ F, long ldf,
-                                                       double* __restrict__ Y) {
+                                                       double* __restrict__ Y, int colscale) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long j = blockIdx.y;
     if (i >= np) return;
     const double k = K[i + j * np];
     const double si = s[i];
-    if (Y) Y[i + j * np] = si * k;
+    if (Y) Y[i + j * np] = (colscale ? s[j] : si) * k;        // colscale: Y = K diag(s) (= (diag(s) K)' : the rhs ROWS of the sweep)
     if (i >= j) F[i + j * ldf] = (i == j ? 1.0 : 0.0) + si * s[j] * k;
 }
 
@@ -420,9 +420,10 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     HIP_TRY(hipMemcpyAsync(w.ttau_d, ttau.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(w.tnu_d, tnu.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
-    const bool fusedp = c->ep_fused && w.Ed;
+    const bool fusedp = c->ep_fused == 1 && w.Ed;
+    const bool rhsp = c->ep_fused == 2;             // V' = (K diag(sW)) L^-T as dense right-hand-side ROWS of the sweep itself
     hipLaunchKernelGGL(ep_build_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Kd, np,
-                       w.s_d, w.F, w.ldf, fusedp ? nullptr : w.Vd);
+                       w.s_d, w.F, w.ldf, fusedp ? nullptr : w.Vd, rhsp ? 1 : 0);
     // fused path: the sweep also yields E = L^-T, so V' = (K diag(sW)) E is ONE clipped MFMA product (no blocked multi-rhs
     // solve, no leaf inverses) and Sigma = K - V'V'^T an NT product in the LDS-DMA form
     // (the sweep's two-piece row space wants the factor's 128 spare rows between the factor and the inverse rows, like the
@@ -430,6 +431,12 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     if (fusedp) {
         CHK(zero_strip_launch(w.F, w.ldf, np, np, 128, st));
         CHK(potrf_blocked(c, w.F, w.ldf, np, np + 128, true, w.Ed, np));
+    } else if (rhsp) {
+        // the np rows of K diag(sW) ride along in the panel solves and trailing updates (np^3 flops inside the bulk MFMA
+        // launches, which at N = 4096 also gives the chain of diagonal blocks enough work to hide behind): no inverse
+        // rows (np^3 / 3 less) and no separate product
+        CHK(zero_strip_launch(w.F, w.ldf, np, np, 128, st));
+        CHK(potrf_blocked_rhs(c, w.F, w.ldf, np, np + 128, w.Vd, np, np));
     }
     else CHK(potrf_blocked(c, w.F, w.ldf, np, np));
     int info = 0;
@@ -446,15 +453,15 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
         g.tile = (np / 128) * (np / 128) < c->small_tile_below ? 64 : 128;
         g.flops = (double)np * np * np;
         CHK(gemm_prof(c, PC_GEMM_SOLVE, g));
-    } else {
+    } else if (!rhsp) {
         CHK(leaf_inv_launch(w.F, w.ldf, w.Wd, 128, 128L * 128L, (int)(np / 128), st));
         CHK(solve_lower_multi(c, w.F, w.ldf, w.Wd, w.Vd, np, np, (int)np, false));    // V = L^-1 (sW o K)
     }
     HIP_TRY(hipMemcpyAsync(w.Sig, w.Kd, (size_t)np * np * sizeof(double), hipMemcpyDeviceToDevice, st));
     {
         GemmArgs g{};                                                                   // Sigma = K - V'V
-        g.A = w.Vd; g.lda = np; g.a_kc = fusedp ? 0 : 1;                                // fused path: Vd holds V' (n-contiguous)
-        g.B = w.Vd; g.ldb = np; g.b_kc = fusedp ? 0 : 1;
+        g.A = w.Vd; g.lda = np; g.a_kc = (fusedp || rhsp) ? 0 : 1;                      // fused paths: Vd holds V' (n-contiguous)
+        g.B = w.Vd; g.ldb = np; g.b_kc = (fusedp || rhsp) ? 0 : 1;
         g.C = w.Sig; g.ldc = np; g.M = (int)np; g.N = (int)np; g.K = (int)np;
         g.alpha = -1.0; g.beta = 1.0; g.tile = (np / 128) * (np / 128) < c->small_tile_below ? 64 : 128;
         g.flops = 2.0 * (double)np * np * np;
@@ -527,7 +534,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     auto dalloc = [&](double** p, size_t bytes) -> int { return pscr.alloc(p, bytes); };
 #define EP_TRY(x) CHK(x)
     EP_TRY(dalloc(&w.Kd, nn)); EP_TRY(dalloc(&w.Sig, nn)); EP_TRY(dalloc(&w.Vd, nn));
-    if (c->ep_fused) EP_TRY(dalloc(&w.Ed, nn));
+    if (c->ep_fused == 1) EP_TRY(dalloc(&w.Ed, nn));
     EP_TRY(dalloc(&w.Wd, (size_t)128 * np * sizeof(double)));
     EP_TRY(dalloc(&w.rhs, (size_t)128 * np * sizeof(double)));
     double* vecs = nullptr;
@@ -695,7 +702,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     for (long i = 0; i < n; ++i) b[i] *= sW[i];
     HIP_TRY(hipMemsetAsync(w.rhs, 0, (size_t)128 * np * sizeof(double), st));
     HIP_TRY(hipMemcpyAsync(w.rhs, b.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-    if (c->ep_fused && w.Ed)        // the fused parameter recomputation does not produce the leaf inverses of the blocked solve
+    if (c->ep_fused)                // the fused parameter recomputations do not produce the leaf inverses of the blocked solve
         EP_TRY(leaf_inv_launch(w.F, ldf, w.Wd, 128, 128L * 128L, (int)(np / 128), st));
     EP_TRY(solve_lower_multi(c, w.F, ldf, w.Wd, w.rhs, np, np, 128, false));
     EP_TRY(solve_lower_multi(c, w.F, ldf, w.Wd, w.rhs, np, np, 128, true));
@@ -711,7 +718,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemsetAsync(c->alpha_dev, 0, np * sizeof(double), st));
         HIP_TRY(hipMemcpyAsync(c->alpha_dev, alpha.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
         // F = alpha alpha' - sW sW' o B^-1 ; dnlZ.cov[j] = -sum(F o dK_j)/2 = sum((sW sW' o B^-1 - alpha alpha') o dK_j)/2
-        if (c->ep_fused && w.Ed) {
+        if (c->ep_fused == 1 && w.Ed) {
             // Ed holds diag(sW) L^-T of the final parameters: (diag(sW) E)(diag(sW) E)' = sW sW' o B^-1 in one product
             EP_TRY(eet_lower(c, w.Ed, np, c->Binv, np, np));
             EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
