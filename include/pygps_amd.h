@@ -163,6 +163,7 @@ int pgp_set_option(pgp_ctx* ctx, const char* name, int value);
 int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_diag, int kmode, int koff,
                   double alpha, double beta, const double* A, int64_t lda, const double* B, int64_t ldb,
                   double* C, int64_t ldc, int M, int N, int K, int iters, double* ms_out);
+int pgp_test_probit_hazard(pgp_ctx* ctx, const double* z, double* out, int n);
 int pgp_test_gemm_dual(pgp_ctx* ctx, const double* A1, int64_t lda1, double* C1, int64_t ldc1, int M1, int K1,
                        const double* A2, int64_t lda2, double* C2, int64_t ldc2, int M2, int K2, int koff2, int zero_from2);
 int pgp_test_valu_peak(pgp_ctx* ctx, int iters, int waves_per_simd, double* out2);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pgp_dev_panel_factor": (C.c_int, [_vp, C.c_void_p, _i64, _i64, C.c_int]),
     "pgp_dev_panel_update": (C.c_int, [_vp, C.c_void_p, _i64, _i64, C.c_int, C.c_void_p, _i64, C.c_int]),
     "pgp_dev_sync": (C.c_int, [_vp]),
+    "pgp_test_probit_hazard": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "pgp_test_gemm_dual": (C.c_int, [_vp, _dp, _i64, _dp, _i64, C.c_int, C.c_int, _dp, _i64, _dp, _i64, C.c_int, C.c_int,
                                      C.c_int, C.c_int]),
     "pgp_test_valu_peak": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),

@@ -19,6 +19,7 @@
 
 #include "ctx.h"
 #include "erf_lik.h"
+#include "erfcx_poly.h"
 
 namespace {
 
@@ -183,26 +184,52 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     r = r * fma(-h * r, r, 1.5);
     return r;
 }
+// erfcx(u) = exp(u^2) erfc(u) for 0 <= u <= 6: ONE polynomial of degree 20 in the mapped variable y = 4 / (4 + u)
+// (csrc/erfcx_poly.h, generated with mpmath; 1.2e-15 relative) in Estrin form -- depth ~12 from u including the reciprocal,
+// branch-free (piecewise versions were built: six degree-16 pieces in u get if-converted into all six evaluations, and a
+// scalar switch on the piece stops the unroller of the site recurrence), against the library's erf + exp + division
+__device__ __forceinline__ double erfcx_0_6(double u) {
+    using namespace erfcx_poly;
+    const double y = C0 * fast_rcp(C0 + u);
+    const double t = (y - MID) * INV_HALF;
+    const double t2 = t * t, t4 = t2 * t2, t8 = t4 * t4, t16 = t8 * t8;
+    double p[NC / 2];
+#pragma unroll
+    for (int i = 0; i < NC / 2; ++i) p[i] = fma(COEF[2 * i + 1], t, COEF[2 * i]);
+    double q[NC / 4];
+#pragma unroll
+    for (int i = 0; i < NC / 4; ++i) q[i] = fma(p[2 * i + 1], t2, p[2 * i]);
+    const double r0 = fma(q[1], t4, q[0]), r1 = fma(q[3], t4, q[2]), r2 = fma(q[5], t4, q[4]);
+    return fma(r2, t16, fma(r1, t8, r0));
+}
+// N(z) / Phi(z) for z > -5 (the branch of lik.py:340-343 without asymptotics).  z <= 0: Phi = exp(-z^2/2) erfcx(-z/sqrt 2) / 2,
+// so the ratio is sqrt(2/pi) / erfcx(-z/sqrt 2) -- no exponential at all; z > 0: Phi = 1 - exp(-u^2) erfcx(u) / 2, u = z/sqrt 2
+// (beyond u = 6 exp(-u^2) < 2.4e-16 makes Phi = 1 whatever the clamped polynomial returns).
+__device__ __forceinline__ double probit_hazard(double z) {
+    const double u = fabs(z) * 0.70710678118654752440;
+    const double gx = erfcx_0_6(fmin(u, erfcx_poly::UMAX));
+    const double e = exp(-u * u);                                              // only used for z > 0: off the z <= 0 chain
+    const double neg = 0.79788456080286535588 * fast_rcp(gx);
+    const double pos = e * 0.39894228040143267794 * fast_rcp(fma(-0.5 * e, gx, 1.0));
+    return z <= 0.0 ? neg : pos;
+}
+
 __device__ __forceinline__ void ep_site_update(double sii, double mui, double tp, double np_, double mi, double yi,
                                                double& t_new, double& nu_new, double& cj, double& qj) {
-    const double inv_sii = fast_rcp(sii);
-    const double tau_ni = inv_sii - tp;                                        // inf.py:759-760
-    const double nu_ni = fma(mui, inv_sii, mi * tau_ni) - np_;
-    const double inv_tau = fast_rcp(tau_ni);
-    const double mu_c = nu_ni * inv_tau, s2 = inv_tau;
+    // cavity (inf.py:759-760) with ONE reciprocal: tau_ni = 1/sii - tp = d1/sii, d1 = 1 - tp sii
+    const double d1 = fma(-tp, sii, 1.0);
+    const double r1 = fast_rcp(d1);
+    const double s2 = sii * r1;                                                // 1 / tau_ni
+    const double mu_c = fma(mi, d1, fma(-np_, sii, mui)) * r1;                 // nu_ni / tau_ni
     const double ys = (yi < 0.0) ? -1.0 : 1.0;
     const double rden = fast_rsqrt(1.0 + s2);
     const double z = ys * mu_c * rden;
     double n_p;
-    if (z > -5.0) {                                                            // lik.py:340-343 (naive ratio)
-        const double p = 0.5 * (1.0 + erf(z * 0.70710678118654752440));
-        n_p = exp(-0.5 * z * z) * 0.39894228040143267794 * fast_rcp(p);
-    } else {
-        n_p = erf_ratio(z, exp(erf_logphi(z)));
-    }
+    if (z > -5.0) n_p = probit_hazard(z);                                      // lik.py:340-343 (naive ratio)
+    else n_p = erf_ratio(z, exp(erf_logphi(z)));
     const double dlZ = ys * n_p * rden;                                        // lik.py:304-309
     const double d2lZ = -n_p * (z + n_p) * (rden * rden);
-    const double w = fast_rcp(fma(d2lZ, inv_tau, 1.0));
+    const double w = fast_rcp(fma(d2lZ, s2, 1.0));
     t_new = fmax(-d2lZ * w, 0.0);                                              // inf.py:764-765
     nu_new = (dlZ + (mi - mu_c) * d2lZ) * w;
     const double ds2 = t_new - tp;
@@ -494,6 +521,27 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
         t6 += log(1.0 + ttau[i] / tau_n);
     }
     *nlZ_out = sc[0] - slZ - 0.5 * t3 - 0.5 * t4 + 0.5 * t5 - 0.5 * t6;
+    return PGP_OK;
+}
+
+namespace {
+__global__ void probit_hazard_test_kernel(const double* __restrict__ z, double* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = probit_hazard(z[i]);
+}
+}  // namespace
+
+// self-test hook: N(z) / Phi(z) of the latency-trimmed site update for host values z > -5 (tests compare with mpmath)
+extern "C" int pgp_test_probit_hazard(pgp_ctx* c, const double* z, double* out, int n) {
+    if (!c || !z || !out || n <= 0) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    DevScratch scr;
+    double *zd, *od;
+    CHK(scr.alloc(&zd, (size_t)n * 8)); CHK(scr.alloc(&od, (size_t)n * 8));
+    HIP_TRY(hipMemcpy(zd, z, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(probit_hazard_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st, zd, od, n);
+    HIP_TRY(hipStreamSynchronize(c->st));
+    HIP_TRY(hipMemcpy(out, od, (size_t)n * 8, hipMemcpyDeviceToHost));
     return PGP_OK;
 }
 

@@ -165,6 +165,27 @@ def test_exact_fit_golden_G6_cfg2_scale(lib):
         assert relerr(got["dnlZ"], np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7
 
 
+def test_probit_hazard_of_the_site_update(lib):
+    """N(z) / Phi(z) of the latency-trimmed EP site update (erfcx polynomial in Estrin form, csrc/erfcx_poly.h) against
+    50-digit mpmath over the whole branch z > -5 of Core/lik.py:340-343 -- including z << 0, where the reference's own
+    0.5 (1 + erf) loses digits."""
+    mp = pytest.importorskip("mpmath")
+    from pygps_amd import _lib
+    mp.mp.dps = 40
+    ctx = _lib.ctx()
+    rng = np.random.RandomState(2)
+    z = np.concatenate([np.linspace(-4.999, 9.0, 3001), rng.uniform(-4.999, 0.0, 2000), [0.0, -0.0, 1e-300, 8.4852, 8.49, 30.0]])
+    out = np.empty_like(z)
+    _lib.check(lib.pgp_test_probit_hazard(ctx, _lib.ptr(z), _lib.ptr(out), len(z)))
+    worst, zw = 0.0, None
+    for zi, oi in zip(z, out):
+        ex = mp.npdf(zi) / mp.ncdf(zi)
+        err = float(abs((mp.mpf(float(oi)) - ex) / ex))
+        if err > worst:
+            worst, zw = err, float(zi)
+    assert worst < 2e-13, (worst, zw)          # v_rcp_f64 + one Newton step (fast_rcp) is good to ~6e-14
+
+
 def test_two_products_in_one_grid(lib):
     """gemm_f64_dual_kernel: a trailing-update-shaped product and an E E^T-filler-shaped product (packed lower tiles,
     k clipped to k >= row + koff, first-touch rows from zero_from) launched as ONE grid, against numpy."""
