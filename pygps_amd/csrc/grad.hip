@@ -35,7 +35,7 @@ __device__ __forceinline__ double block_sum(double v, double* red /* 4 doubles *
 __device__ __forceinline__ void ard_dim_reduce(const double* __restrict__ XT, long ldp, long r0, long c0, int dpad,
                                                double* __restrict__ sm, const double (&w)[4][4],
                                                const double* __restrict__ wk, int D, double* __restrict__ out) {
-    __shared__ double ardred[4][SKC];
+    __shared__ double ardred[4][CP_MAXARD];     // per-wave sums of every coordinate: the four waves meet ONCE, after the last slab
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     const int lane_ = t & 63, wave_ = t >> 6;
     double* xr = sm;
@@ -85,14 +85,14 @@ __device__ __forceinline__ void ard_dim_reduce(const double* __restrict__ XT, lo
         }
         gk[0] += __shfl_xor(gk[0], 16, 64);
         gk[0] += __shfl_xor(gk[0], 32, 64);
-        __syncthreads();                                        // ardred of the previous slab has been consumed
         if (lane_ < 16) {
             const int kk = ((lane_ & 1) << 3) | ((lane_ & 2) << 1) | ((lane_ & 4) >> 1) | ((lane_ & 8) >> 3);
-            ardred[wave_][kk] = gk[0];
+            if (k0 + kk < CP_MAXARD) ardred[wave_][k0 + kk] = gk[0];
         }
-        __syncthreads();
-        if (t < SKC && k0 + t < D) out[k0 + t] = ardred[0][t] + ardred[1][t] + ardred[2][t] + ardred[3][t];
     }
+    __syncthreads();
+    for (int k = t; k < D && k < CP_MAXARD; k += 256) out[k] = ardred[0][k] + ardred[1][k] + ardred[2][k] + ardred[3][k];
+    __syncthreads();                                            // a second call (second ARD leaf) reuses ardred
 }
 
 // partial[blk * nacc + h]: h < ncov -> sum Q dK_h ; h == ncov -> sn2 * trace(Q)
