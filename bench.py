@@ -200,6 +200,41 @@ def extras(lib, _lib, local, d, roof):
             "workload": "BASELINE configs[4]: GPC + RBF, infEP, N=4096 d=32 (cold start, nlZ + gradients, through model.getPosterior)"}
     except Exception as e:           # pragma: no cover
         out["cfg5_ep_N4096_d32"] = {"error": repr(e)}
+    # ---- SURVEY 8(f) rows 1 and 3 through the drop-in API: predict throughput on the cfg-2 posterior, one FITC fit -----
+    try:
+        import pygps_amd as pyGPs
+        n6, d6, ns = 8192, 16, 65536
+        x6, y6 = synth_reg(n6, d6)
+        m6 = pyGPs.GPR()
+        m6.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d6)), 0.0)); m6.setNoise(np.log(0.1))
+        m6.getPosterior(x6, y6)
+        xs6 = np.random.RandomState(1).randn(ns, d6)
+        m6.predict(xs6[:4096])
+        t = time.perf_counter(); m6.predict(xs6); tp = time.perf_counter() - t
+        out["predict_N8192_ns65536"] = {
+            "ms": tp * 1e3, "test_points_per_s": ns / tp,
+            "TFLOPs": (2.0 * n6 * n6 * ns) / tp / 1e12,     # fs2 needs V = L^-1 Ks: N^2 flops per test point (x2 for fma)
+            "what": "GP.predict (ym, ys2, fm, fs2, lp) of 65536 test points on the N=8192 posterior; host arrays in and out"}
+        nf, nuf, df = 131072, 1024, 16
+        rng = np.random.RandomState(0)
+        xf = rng.randn(nf, df); wf = rng.randn(df, 1)
+        yf = np.sin(xf @ wf / np.sqrt(df)) + 0.1 * rng.randn(nf, 1)
+        uf = xf[rng.choice(nf, nuf, replace=False)] + 0.01 * rng.randn(nuf, df)
+        mf = pyGPs.GPR_FITC()
+        mf.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(df)), 0.0), inducing_points=uf)
+        mf.setNoise(np.log(0.1))
+        mf.getPosterior(xf, yf)
+        tsf = []
+        for it in range(3):
+            mf.covfunc.hyp = [np.log(np.sqrt(df)) + 1e-3 * it, 0.0]
+            t = time.perf_counter(); mf.getPosterior(xf, yf); tsf.append(time.perf_counter() - t)
+        tf = min(tsf)
+        out["fitc_n131072_nu1024"] = {
+            "fit_ms": tf * 1e3, "TFLOPs_on_nu2n_products": 2.0 * nuf * nuf * nf * 8 / tf / 1e12,
+            "what": "GPR_FITC.getPosterior (nlZ + 3 gradients), n=131072, 1024 inducing points, d=16; "
+                    "flop model: 8 products of 2 nu^2 n (V, V V', B, W, B W' and two per hyper)"}
+    except Exception as e:           # pragma: no cover
+        out["predict_fitc_error"] = repr(e)
     return out
 
 
