@@ -39,7 +39,7 @@ for S in tuple(int(v) for v in os.environ.get("NSTREAMS", "1,2").split(",")):
             assert lib.pgp_set_option(h, k_.encode(), int(v_)) == 0
         ctxs.append(h)
     out = [0] * S
-    for steps in (2, 600):
+    for steps in (2, int(os.environ.get("STEPS", "600"))):
         ths = [threading.Thread(target=worker, args=(ctxs[k], steps, out, k)) for k in range(S)]
         t = time.time()
         [th.start() for th in ths]
