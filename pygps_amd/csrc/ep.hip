@@ -251,7 +251,8 @@ __device__ __forceinline__ void ep_site_update(double sii, double mui, double tp
 constexpr int EPT = 16;
 __device__ int g_ep_dbg = 0;            // timing experiments only (option ep_dbg): 1 skip the recurrence, 2 skip the Gram phase, 4 skip the rows loop
 constexpr size_t EPS_LDS_BYTES = (size_t)(EPT * (EPB + 1) + EPT * (EPB + EPT) + 2 * EPB) * sizeof(double);
-constexpr int EPS_THREADS = 320;          // wave 0: the in-launch recurrence; waves 1-4: 256 rows of the new factor columns
+constexpr int EPS_THREADS = 256;          // wave 0: the in-launch recurrence, alone on its SIMD; waves 1-3: EPS_ROWS rows of the new factor columns
+constexpr int EPS_ROWS = EPS_THREADS - 64;
 __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
                                                             const long* __restrict__ base, int j0, double* __restrict__ S,
                                                             double* __restrict__ cvec, double* __restrict__ qvec,
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
     }
     // rows of the EPT new factor columns (waves 1-4), one pass over S(r, 0..j0).  The pass over the columns that existed
     // before the launch needs nothing from the recurrence, so it runs BESIDE it; only the short in-launch correction waits.
-    const long r = (long)blockIdx.x * 256 + (t - 64);
+    const long r = (long)blockIdx.x * EPS_ROWS + (t - 64);
     double acc[EPT];
     if (t >= 64 && r < np) {
         if (r >= i0 + EPT) {                         // below the launch's sites: column reads, coalesced over the rows
@@ -689,7 +690,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                 if (!base) base = w.base;
                 int j = 0;
                 for (; j + EPT <= nsite; j += EPT)
-                    hipLaunchKernelGGL(ep_sites_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(EPS_THREADS), EPS_LDS_BYTES, st, w.Sig, np, np,
+                    hipLaunchKernelGGL(ep_sites_lazy_kernel, dim3((unsigned)((np + EPS_ROWS - 1) / EPS_ROWS)), dim3(EPS_THREADS), EPS_LDS_BYTES, st, w.Sig, np, np,
                                        base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
                                        w.tnu_d);
                 for (; j < nsite; ++j)
