@@ -145,6 +145,8 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "half_wave")) { c->half_wave = value; return PGP_OK; }
     if (!strcmp(name, "ep_dbg")) { return ep_set_dbg(value); }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
+    if (!strcmp(name, "ep_r_direct")) { c->ep_r_direct = value; return PGP_OK; }
+    if (!strcmp(name, "ep_alpha_direct")) { c->ep_alpha_direct = value; return PGP_OK; }
     if (!strcmp(name, "ep_sym")) { c->ep_sym = value; return PGP_OK; }
     if (!strcmp(name, "xcd_max_k")) { c->xcd_max_k = value; return PGP_OK; }
     if (!strcmp(name, "xcd_min_tiles")) { c->xcd_min_tiles = value; return PGP_OK; }

@@ -58,6 +58,8 @@ struct pgp_ctx {
     int ep_graph = 0;                   // EP: replay each 128-site block as a captured hipGraph (measured: no gain)
     int ep_fused = 2;                   // EP parameter recomputation: 0 blocked multi-rhs solve, 1 through the fused inverse (V' = K diag(sW)
                                         // L^-T as one product), 2 K diag(sW) as dense right-hand-side rows of the sweep
+    int ep_r_direct = 1;                // EP gradient: sW sW' o B^-1 = S - S Sigma S from the rebuilt Sigma; 0 = triangular inverse + W'W
+    int ep_alpha_direct = 1;            // EP: alpha = tnu - ttau o mu (identity, no solve); 0 = the reference's two triangular solves
     int ep_sym = 1;                     // EP: Sigma kept current in its lower triangle only (folds and K - V'V on the lower tiles)
     int ep_block = 1;                   // EP: blocked site sweep (rank-1 updates folded every 128 sites); 0 = update Sigma per site
     int fused_inverse = 1;              // 1: L^-T falls out of the Cholesky sweep (appended identity rows); 0: recursive trtri

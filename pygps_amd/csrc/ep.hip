@@ -12,6 +12,7 @@
 //   the MFMA GEMM) -> Sigma = K - V'V (MFMA GEMM, TN) -> mu = Sigma tnu.
 // Gradients reuse the triangular inverse, W'W and the Hadamard-reduce kernel with per-point weights sW.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -27,6 +28,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
+}
+__device__ __forceinline__ double block_sum(double v, double* red /* 4 doubles */) {      // 256 threads, fixed order
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
 }
 
 __global__ __launch_bounds__(256) void ep_site_kernel(const double* __restrict__ Sig, long ld, long np, long i,
@@ -417,6 +426,50 @@ __global__ __launch_bounds__(256) void ep_build_kernel(const double* __restrict_
     if (i >= j) F[i + j * ldf] = (i == j ? 1.0 : 0.0) + si * s[j] * k;
 }
 
+// Per-site terms of the EP marginal likelihood (inf.py:184-188) and, optionally, d lZ_i / d mu (inf.py:788-790) on the device:
+// the host loop over n sites (probit moments in double, ~0.3 us each) sat between every sweep and the next one -- 1.2 ms of
+// idle GPU per parameter recomputation at N = 4096.  Block partials [blk][5] = (sum lZ, t3, t4, t5, t6) in a fixed order.
+__global__ __launch_bounds__(256) void ep_site_terms_kernel(long n, const double* __restrict__ y, const double* __restrict__ m,
+                                                            const double* __restrict__ mu, const double* __restrict__ dsig,
+                                                            double dsig_const, const double* __restrict__ ttau,
+                                                            const double* __restrict__ tnu, int with_m,
+                                                            double* __restrict__ partial, double* __restrict__ dlz) {
+    __shared__ double red[4];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (i < n) {
+        const double ds = dsig ? dsig[i] : dsig_const, mui = mu ? mu[i] : 0.0;
+        const double tt = ttau ? ttau[i] : 0.0, tn = tnu ? tnu[i] : 0.0;
+        const double tau_n = 1.0 / ds - tt;
+        const double nu_n = mui / ds - tn + (with_m ? m[i] * tau_n : 0.0);
+        double lZ, dl;
+        erf_ep_moments(y[i], nu_n / tau_n, 1.0 / tau_n, &lZ, &dl, nullptr);
+        if (dlz) dlz[i] = dl;
+        const double a = nu_n - (with_m ? m[i] * tau_n : 0.0);
+        v[0] = lZ;
+        v[1] = tn * mui;
+        v[2] = a * ((tt / tau_n * a - 2.0 * tn) / (tt + tau_n));
+        v[3] = tn * tn / (tau_n + tt);
+        v[4] = log(1.0 + tt / tau_n);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const double sres = block_sum(v[q], red);
+        if (threadIdx.x == 0) partial[5L * blockIdx.x + q] = sres;
+    }
+}
+
+// R = sW sW' o B^-1 without B^-1: sW (I + sW K sW)^-1 sW = (S^-1 + K)^-1 = S - S Sigma S with S = diag(ttau) and the
+// Sigma = (K^-1 + S)^-1 that _epComputeParams has just rebuilt (matrix inversion lemma); lower triangle, column-major
+__global__ __launch_bounds__(256) void ep_r_from_sigma_kernel(const double* __restrict__ Sig, long ld, long np,
+                                                              const double* __restrict__ ttau, double* __restrict__ R, long ldr) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long j = blockIdx.y;
+    if (i >= np || i < j) return;
+    const double ti = ttau[i];
+    R[i + j * ldr] = (i == j ? ti : 0.0) - ti * ttau[j] * Sig[i + j * ld];
+}
+
 // E'(k, m) = s_k E(k, m) on the block-upper part of E = L^-T (everything the sweep wrote: k < 128 (m / 128 + 1))
 __global__ __launch_bounds__(256) void ep_rowscale_upper_kernel(double* __restrict__ E, long lde, const double* __restrict__ s) {
     const long m = blockIdx.y;
@@ -501,25 +554,22 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     CHK(col_dot_full_launch(w.Sig, np, np, np, w.tnu_d, nullptr, w.mu_d, st));           // mu = Sigma tnu
     CHK(gather_strided_launch(w.Sig, np + 1, np, w.diag_d, st));
     CHK(logdet_ztz_launch(w.F, w.ldf, n, w.F, 0, c->scal, st));
+    const long nblk_terms = (n + 255) / 256;
+    std::vector<double> part_h(5 * nblk_terms);
+    hipLaunchKernelGGL(ep_site_terms_kernel, dim3((unsigned)nblk_terms), dim3(256), 0, st, n, c->y_dev, w.m_d, w.mu_d, w.diag_d, 0.0,
+                       w.ttau_d, w.tnu_d, 1, w.tmp_d, (double*)nullptr);
+    HIP_TRY(hipMemcpyAsync(part_h.data(), w.tmp_d, part_h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     double sc[2];
     HIP_TRY(hipMemcpyAsync(mu_h.data(), w.mu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(dsig_h.data(), w.diag_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(sc, c->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     CHK(potrf_server_status(c));
-    // -log marginal likelihood (inf.py:184-188)
+    // -log marginal likelihood (inf.py:184-188): the per-site terms were reduced on the device (ep_site_terms_kernel, queued
+    // before the copies above); the block partials are added here in block order
     double slZ = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0, t6 = 0.0;
-    for (long i = 0; i < n; ++i) {
-        const double tau_n = 1.0 / dsig_h[i] - ttau[i];
-        const double nu_n = mu_h[i] / dsig_h[i] - tnu[i] + m[i] * tau_n;
-        double lZ;
-        erf_ep_moments(y[i], nu_n / tau_n, 1.0 / tau_n, &lZ, nullptr, nullptr);
-        slZ += lZ;
-        t3 += tnu[i] * mu_h[i];
-        const double a = nu_n - m[i] * tau_n;
-        t4 += a * ((ttau[i] / tau_n * a - 2.0 * tnu[i]) / (ttau[i] + tau_n));
-        t5 += tnu[i] * tnu[i] / (tau_n + ttau[i]);
-        t6 += log(1.0 + ttau[i] / tau_n);
+    for (long b = 0; b < nblk_terms; ++b) {
+        slZ += part_h[5 * b]; t3 += part_h[5 * b + 1]; t4 += part_h[5 * b + 2]; t5 += part_h[5 * b + 3]; t6 += part_h[5 * b + 4];
     }
     *nlZ_out = sc[0] - slZ - 0.5 * t3 - 0.5 * t4 + 0.5 * t5 - 0.5 * t6;
     return PGP_OK;
@@ -574,6 +624,11 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMalloc((void**)&c->partial, need * sizeof(double)));
         c->partial_cap = need;
     }
+    static const bool ep_timing = getenv("PGP_EP_TIMING") != nullptr;      // host wall-clock stamps of the phases (stderr)
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (ep_timing) fprintf(stderr, "[ep] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+    };
     EpWork w{};
     w.n = n; w.np = np; w.ldf = ldf;
     const size_t nn = (size_t)np * np * sizeof(double);
@@ -609,6 +664,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     HIP_TRY(hipMemsetAsync(w.Kd, 0, nn, st));
     EP_TRY(alloc_factor_buffer(c, np, ldf, &w.F));
     FactorGuard fguard(c, w.F, (size_t)ldf * np * sizeof(double), /*scrub=*/true);
+    stamp("scratch acquired");
     // ---- K (full symmetric, padded with zeros) --------------------------------------------------------
     EP_TRY(upload_scaled(c, c->x_dev, n, d, sc, c->XsT, np, c->dpad, c->scale_dev));
     EP_TRY(cov_sym_launch(c->XsT, np, n, c->dpad, cp, w.Kd, st, np));
@@ -619,10 +675,14 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     HIP_TRY(hipStreamSynchronize(st));
     // nlZ0 = -sum lik(y, m, diag K)  (inf.py:737)
     double nlZ0 = 0.0;
-    for (long i = 0; i < n; ++i) {
-        double lZ;
-        erf_ep_moments(y[i], m[i], kdiag, &lZ, nullptr, nullptr);
-        nlZ0 -= lZ;
+    {   // the same per-site kernel with mu = 0, Sigma_ii = K_ii, zero site parameters: lZ_i = lik(y_i, m_i, K_ii)
+        const long nbt = (n + 255) / 256;
+        std::vector<double> ph(5 * nbt);
+        hipLaunchKernelGGL(ep_site_terms_kernel, dim3((unsigned)nbt), dim3(256), 0, st, n, c->y_dev, w.m_d, (const double*)nullptr,
+                           (const double*)nullptr, kdiag, (const double*)nullptr, (const double*)nullptr, 1, w.tmp_d, (double*)nullptr);
+        HIP_TRY(hipMemcpyAsync(ph.data(), w.tmp_d, ph.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (long b = 0; b < nbt; ++b) nlZ0 -= ph[5 * b];
     }
     double nlZ = nlZ0;
     bool fresh = true;
@@ -645,6 +705,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemsetAsync(w.tnu_d, 0, np * sizeof(double), st));
     }
     HIP_TRY(hipFuncSetAttribute((const void*)ep_sites_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EPS_LDS_BYTES));
+    stamp("K built, nlZ0");
     hipGraphExec_t block_graph = nullptr;             // one block of the blocked sweep (EPB / EPT site launches + fold)
     const double tol = 1e-4;
     const int max_sweep = 10, min_sweep = 2;
@@ -732,7 +793,9 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemcpyAsync(ttau.data(), w.ttau_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        stamp("sweep done (synced)");
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // inf.py:772
+        stamp("params recomputed");
         if (rc != PGP_OK) {
             if (block_graph) { (void)hipStreamSynchronize(st); (void)hipGraphExecDestroy(block_graph); }
             return rc;
@@ -745,6 +808,12 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     // ---- alpha = tnu - sW o B^-1 (sW o K tnu)   (inf.py:777) ----------------------------------------------
     std::vector<double> sW(np, 0.0), b(n), alpha(n);
     for (long i = 0; i < n; ++i) sW[i] = sqrt(ttau[i]);
+    if (c->ep_alpha_direct) {
+        // The same vector without any solve: Sigma = (K^-1 + S)^-1, S = diag(ttau), and mu = Sigma tnu (inf.py:183), so
+        // K^-1 mu = tnu - S mu; and K alpha = mu for the reference's alpha (Sigma tnu = K (tnu - sW B^-1 sW K tnu), because
+        // sW K sW = B - I).  mu is the one _epComputeParams just produced from the final site parameters.
+        for (long i = 0; i < n; ++i) alpha[i] = tnu[i] - ttau[i] * mu[i];
+    } else {
     EP_TRY(col_dot_full_launch(w.Kd, np, np, np, w.tnu_d, nullptr, w.tmp_d, st));
     HIP_TRY(hipMemcpyAsync(b.data(), w.tmp_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -758,10 +827,12 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     HIP_TRY(hipMemcpyAsync(b.data(), w.rhs, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (long i = 0; i < n; ++i) alpha[i] = tnu[i] - sW[i] * b[i];
+    }
     if (alpha_out) memcpy(alpha_out, alpha.data(), n * sizeof(double));
     if (sW_out) memcpy(sW_out, sW.data(), n * sizeof(double));
     if (nlZ_out) *nlZ_out = nlZ;
     HIP_TRY(hipMemcpyAsync(w.s_d, sW.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
+    stamp("alpha");
     // ---- derivatives (inf.py:780-803) ------------------------------------------------------------------------
     if (want >= 3 && dnlZ_out) {
         HIP_TRY(hipMemsetAsync(c->alpha_dev, 0, np * sizeof(double), st));
@@ -770,6 +841,11 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         if (c->ep_fused == 1 && w.Ed) {
             // Ed holds diag(sW) L^-T of the final parameters: (diag(sW) E)(diag(sW) E)' = sW sW' o B^-1 in one product
             EP_TRY(eet_lower(c, w.Ed, np, c->Binv, np, np));
+            EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
+                                          c->scal + 8, st, nullptr));
+        } else if (c->ep_r_direct) {
+            hipLaunchKernelGGL(ep_r_from_sigma_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Sig, np, np,
+                               w.ttau_d, c->Binv, np);
             EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
                                           c->scal + 8, st, nullptr));
         } else {
@@ -781,21 +857,23 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         std::vector<double> g(ncov + 1);
         HIP_TRY(hipMemcpyAsync(g.data(), c->scal + 8, (ncov + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        for (int i = 0; i < nmean; ++i) {
-            double s = 0.0;
-            for (long j = 0; j < n; ++j) {
-                const double tau_n = 1.0 / dsig[j] - ttau[j];
-                const double nu_n = mu[j] / dsig[j] - tnu[j];                           // inf.py:788 (no m term)
-                double lZ, dlZ;
-                erf_ep_moments(y[j], nu_n / tau_n, 1.0 / tau_n, &lZ, &dlZ, nullptr);
-                s += dlZ * dm[(long)i * n + j];
+        if (nmean > 0) {                              // d lZ_j / d mu on the device (inf.py:788-790: no m term in nu_n), dot with dm on the host
+            std::vector<double> dl(n);
+            hipLaunchKernelGGL(ep_site_terms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, c->y_dev, w.m_d, w.mu_d,
+                               w.diag_d, 0.0, w.ttau_d, w.tnu_d, 0, w.tmp_d, w.sbuf);
+            HIP_TRY(hipMemcpyAsync(dl.data(), w.sbuf, n * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (int i = 0; i < nmean; ++i) {
+                double sacc = 0.0;
+                for (long j = 0; j < n; ++j) sacc += dl[j] * dm[(long)i * n + j];
+                dnlZ_out[i] = -sacc;
             }
-            dnlZ_out[i] = -s;
         }
         for (int h = 0; h < ncov; ++h) dnlZ_out[nmean + h] = 0.5 * g[h];
         dnlZ_out[nmean + ncov] = 0.0;                                                   // lik.Erf has no hyper
     }
     if (c->prof) prof_collect(c);
+    stamp("gradients");
     if (factor_out) {
         FactorHandleGuard hg(c, new pgp_factor());
         pgp_factor* f = hg.f;
