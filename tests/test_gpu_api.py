@@ -337,6 +337,37 @@ def test_G8_ep_classification_demo_and_synthetic(lib):
         assert relerr(np.diag(post.L), g["L_diag"]) < 1e-7
 
 
+@pytest.mark.parametrize("opts", [dict(ep_fused=0), dict(ep_fused=1), dict(ep_sym=0), dict(ep_alpha_direct=0, ep_r_direct=0),
+                                  dict(ep_fused=0, ep_alpha_direct=0, ep_r_direct=0, ep_sym=0), dict(ep_block=0)])
+def test_ep_variants_agree_with_the_reference(lib, opts):
+    """Every kept variant of the EP path -- parameter recomputation by the blocked solve / through the fused inverse /
+    as right-hand-side rows of the sweep (default), full or lower-triangle Sigma, alpha and sW sW' o B^-1 by the
+    reference's solves or by the identities, per-site or blocked sweeps -- against the reference's own numbers (G8ii)."""
+    import pygps_amd as pyGPs
+    from pygps_amd import _lib
+    from conftest import synth_cls
+    ctx = _lib.ctx()
+    defaults = dict(ep_fused=2, ep_sym=1, ep_alpha_direct=1, ep_r_direct=1, ep_block=1)
+    try:
+        for k, v in opts.items():
+            _lib.check(lib.pgp_set_option(ctx, k.encode(), v))
+        for N in (128, 512):
+            if opts.get("ep_block", 1) == 0 and N > 128:
+                continue                                   # the per-site path is the slow reference-order one
+            g = golden("G8ii_ep_d32_N%d" % N)
+            x, y = synth_cls(N, 32)
+            m = pyGPs.GPC()
+            m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(32.0)), 0.0))
+            nlZ, dnlZ, post = m.getPosterior(x, y)
+            assert relerr(nlZ, g["nlZ"]) < 1e-8, N
+            assert relerr(dnlZ.cov, g["dnlZ_cov"]) < 1e-6
+            assert relerr(post.alpha, g["alpha"]) < 1e-6 and relerr(post.sW, g["sW"]) < 1e-6
+            assert relerr(np.diag(post.L), g["L_diag"]) < 1e-7
+    finally:
+        for k in opts:
+            lib.pgp_set_option(ctx, k.encode(), defaults[k])
+
+
 def test_G10_rbfunit_rq_piecepoly_on_device(lib):
     """the next stationary kernels as device functors (Core/cov.py:683-782, 832-869, 1304-1347)."""
     import pygps_amd as pyGPs
