@@ -213,7 +213,7 @@ def extras(lib, _lib, local, d, roof):
         t = time.perf_counter(); m6.predict(xs6); tp = time.perf_counter() - t
         out["predict_N8192_ns65536"] = {
             "ms": tp * 1e3, "test_points_per_s": ns / tp,
-            "TFLOPs": (2.0 * n6 * n6 * ns) / tp / 1e12,     # fs2 needs V = L^-1 Ks: N^2 flops per test point (x2 for fma)
+            "TFLOPs": (1.0 * n6 * n6 * ns) / tp / 1e12,     # fs2 needs V = L^-1 Ks: a triangular solve, N^2 flops per test point
             "what": "GP.predict (ym, ys2, fm, fs2, lp) of 65536 test points on the N=8192 posterior; host arrays in and out"}
         nf, nuf, df = 131072, 1024, 16
         rng = np.random.RandomState(0)

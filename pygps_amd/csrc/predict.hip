@@ -61,8 +61,8 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     const long np = f->np, n = f->n;
     const int d = f->d, dpad = f->dpad;
     // test points per batch (the reference uses 1000): up to predict_batch = 16384, so that the K = 128 updates of the
-    // blocked solve are whole waves of tiles (measured at N=8192, 65536 test points, warm: batch 1024 -> 27.7 TF on the
-    // 2 N^2 flops per point, 4096 -> 39.9, 8192 -> 45.9, 16384 -> 51.5)
+    // blocked solve are whole waves of tiles (measured at N=8192, 65536 test points, warm: batch 1024 -> 318 ms = 13.8 TF on
+    // the N^2 flops per point of the triangular solve, 4096 -> 220 ms, 8192 -> 192 ms, 16384 -> 171 ms = 25.8 TF)
     const long NSB = std::max<long>(128, std::min<long>(c->predict_batch, round_up(ns, 128)));
     const long ldc = NSB;
     DevScratch tmp;
