@@ -151,6 +151,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "xcd_max_k")) { c->xcd_max_k = value; return PGP_OK; }
     if (!strcmp(name, "xcd_min_tiles")) { c->xcd_min_tiles = value; return PGP_OK; }
     if (!strcmp(name, "xcd_super")) { c->xcd_super = value; return PGP_OK; }
+    if (!strcmp(name, "solve_outer")) { if (value < 1) return -2; c->solve_outer = value; return PGP_OK; }
     if (!strcmp(name, "predict_batch")) { if (value < 128 || value % 128) return -2; c->predict_batch = value; return PGP_OK; }
     if (!strcmp(name, "s_tile")) { if (value != 0 && value != 64 && value != 128) return -2; c->s_tile = value; return PGP_OK; }
     if (!strcmp(name, "s_dma")) { c->s_dma = value; return PGP_OK; }

@@ -91,6 +91,7 @@ struct pgp_ctx {
     int xcd_max_k = 512;                // ... and a k extent of at most this
     int xcd_min_tiles = 256;            // xcd_order applies to launches with at least this many 128-tiles
     int xcd_super = 8;                  // xcd_order: super-tile edge in tiles
+    int solve_outer = 8;                // leaves per outer panel of the blocked multi-rhs triangular solve (K = 128 solve_outer)
     int predict_batch = 16384;          // test points per batch of pgp_predict (scratch: np x batch doubles)
     int s_tile = 0;                     // tile size of the panel solves: 0 = automatic
     int s_dma = 0;                      // 1: panel solves read a transposed copy of E_D (n-contiguous, the LDS-DMA GEMM form; measured neutral); 0: K-contiguous E_D

@@ -17,25 +17,43 @@ int solve_lower_multi(pgp_ctx* c, const double* L, long ldl, const double* Wd /*
                              long ldy, long np, int nrhs, bool trans) {
     const int nb = (int)(np / 128);
     const int tile = (nrhs % 128 == 0 && (long)nrhs / 128 * (np / 128) >= c->small_tile_below) ? 128 : 64;
-    for (int s = 0; s < nb; ++s) {
-        const int kb = trans ? nb - 1 - s : s;
-        const long o = (long)kb * 128;
-        GemmArgs g{};                                   // diagonal solve, in place (one WG column-tile owns its rows)
-        g.A = Wd + o * 128; g.lda = 128; g.a_kc = trans ? 1 : 0;
-        g.B = Y + o; g.ldb = ldy; g.b_kc = 1;
-        g.C = Y + o; g.ldc = ldy;
-        g.M = 128; g.N = nrhs; g.K = 128; g.alpha = 1.0; g.beta = 0.0; g.tile = 128;
-        g.flops = 128.0 * 128.0 * nrhs;
-        CHK(gemm_prof(c, PC_GEMM_INNER, g));
-        const long rest = trans ? o : np - o - 128;
-        if (rest <= 0) continue;
+    // Two-level blocking: inside an outer panel of Q leaves the updates have K = 128 and stay inside the panel; the rows
+    // outside the panel are updated ONCE per panel with K = 128 Q (C is read and written once per panel instead of once
+    // per leaf, and the k-loop is four times longer: the product that carries ~all the flops runs at the K = 512 rate)
+    const int Q = std::max(1, std::min(c->solve_outer, 8));
+    auto update = [&](long o, long kw, long r0, long rows) -> int {        // Y[r0 .. r0+rows) -= L-part(.., o..o+kw) V[o..o+kw)
+        if (rows <= 0) return PGP_OK;
         GemmArgs h{};
-        if (!trans) { h.A = L + o + 128 + o * ldl; h.lda = ldl; h.a_kc = 0; h.C = Y + o + 128; }
-        else        { h.A = L + o; h.lda = ldl; h.a_kc = 1; h.C = Y; }       // A(m,k) = L(o+k, m)
+        if (!trans) { h.A = L + r0 + o * ldl; h.lda = ldl; h.a_kc = 0; }
+        else        { h.A = L + o + r0 * ldl; h.lda = ldl; h.a_kc = 1; }   // A(m,k) = L(o+k, r0+m)
+        h.C = Y + r0;
         h.B = Y + o; h.ldb = ldy; h.b_kc = 1;
-        h.ldc = ldy; h.M = (int)rest; h.N = nrhs; h.K = 128; h.alpha = -1.0; h.beta = 1.0; h.tile = tile;
-        h.flops = 2.0 * 128.0 * (double)rest * nrhs;
-        CHK(gemm_prof(c, PC_GEMM_INNER, h));
+        h.ldc = ldy; h.M = (int)rows; h.N = nrhs; h.K = (int)kw; h.alpha = -1.0; h.beta = 1.0; h.tile = tile;
+        h.flops = 2.0 * (double)kw * (double)rows * nrhs;
+        return gemm_prof(c, PC_GEMM_INNER, h);
+    };
+    for (int p0 = 0; p0 < nb; p0 += Q) {
+        const int p1 = std::min(p0 + Q, nb);
+        // leaves of this panel in solve order: forward p0 .. p1-1 (global blocks kb), backward the mirrored blocks
+        for (int s = p0; s < p1; ++s) {
+            const int kb = trans ? nb - 1 - s : s;
+            const long o = (long)kb * 128;
+            GemmArgs g{};                               // diagonal solve, in place (one WG column-tile owns its rows)
+            g.A = Wd + o * 128; g.lda = 128; g.a_kc = trans ? 1 : 0;
+            g.B = Y + o; g.ldb = ldy; g.b_kc = 1;
+            g.C = Y + o; g.ldc = ldy;
+            g.M = 128; g.N = nrhs; g.K = 128; g.alpha = 1.0; g.beta = 0.0; g.tile = 128;
+            g.flops = 128.0 * 128.0 * nrhs;
+            CHK(gemm_prof(c, PC_GEMM_INNER, g));
+            // the leaves still to come INSIDE the panel
+            const long in_rows = (long)(p1 - 1 - s) * 128;
+            if (!trans) CHK(update(o, 128, o + 128, in_rows));
+            else        CHK(update(o, 128, o - in_rows, in_rows));
+        }
+        // everything outside the panel, once, with K = 128 (p1 - p0)
+        const long kw = (long)(p1 - p0) * 128;
+        if (!trans) { const long o = (long)p0 * 128; CHK(update(o, kw, o + kw, np - o - kw)); }
+        else        { const long o = (long)(nb - p1) * 128; CHK(update(o, kw, 0, o)); }
     }
     return PGP_OK;
 }

@@ -13,4 +13,4 @@ xs = np.random.RandomState(1).randn(ns, d)
 m.predict(xs)
 m.predict(xs)
 t = time.perf_counter(); out = m.predict(xs); dt = time.perf_counter() - t
-print(sys.argv[1:], "%.1f ms, %.0f points/s, %.1f TF, fs2[0] %.12f" % (dt * 1e3, ns / dt, 2.0 * n * n * ns / dt / 1e12, out[3][0, 0]))
+print(sys.argv[1:], "%.1f ms, %.0f points/s, %.1f TF, fs2[0] %.12f" % (dt * 1e3, ns / dt, 1.0 * n * n * ns / dt / 1e12, out[3][0, 0]))
