@@ -30,6 +30,22 @@ __device__ __forceinline__ double block_sum(double v, double* red /* 4 doubles *
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// four block sums with ONE barrier pair (block_sum x 4 costs eight barriers: the 64 x 64-tile reduce kernels do one tile per
+// workgroup and were bound by them); fixed order: waves 0..3
+__device__ __forceinline__ void block_sum4(double (&v)[4], double* red16 /* 16 doubles */) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red16[4 * wave + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = red16[q] + red16[4 + q] + red16[8 + q] + red16[12 + q];
+}
+
 // ARD length-scale sums of one 64x64 tile: out[k] = sum_rc w_rc wk[k] (x_rk - x_ck)^2 for k < D, 16 coordinates per
 // staged slab (wk == nullptr: the weights are already folded into the scaled coordinates).  sm: 2*SKC*ST doubles.
 __device__ __forceinline__ void ard_dim_reduce(const double* __restrict__ XT, long ldp, long r0, long c0, int dpad,
@@ -105,7 +121,6 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
                                                               const double* __restrict__ wv,
                                                               double* __restrict__ partial, long nt) {
     __shared__ __attribute__((aligned(16))) double sm[2 * SKC * ST];
-    __shared__ double red[4];
     CovParams cp = cp0;
     cp.kind = KIND;
     const long b = blockIdx.x;
@@ -173,26 +188,24 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
         }
     }
     double* out = partial + b * (long)(ncov + 1);
+    __shared__ double red16[16];
     if (cov_is_ard(cp)) {
         ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, nullptr, cp.D, out);
-        const double t1 = block_sum(g1, red);
-        const double t2 = block_sum(tq, red);
-        const double t3 = block_sum(g2, red);
+        double v4[4] = {g1, tq, g2, 0.0};
+        block_sum4(v4, red16);
         if (t == 0) {
-            out[cp.D] = t1;
-            if (cp.kind == 6) out[cp.D + 1] = t3;
-            out[ncov] = t2;
+            out[cp.D] = v4[0];
+            if (cp.kind == 6) out[cp.D + 1] = v4[2];
+            out[ncov] = v4[1];
         }
     } else {
-        const double t0 = block_sum(g0, red);
-        const double t1 = block_sum(g1, red);
-        const double t2 = block_sum(g2, red);
-        const double t3 = block_sum(tq, red);
+        double v4[4] = {g0, g1, g2, tq};
+        block_sum4(v4, red16);
         if (t == 0) {
-            out[0] = t0;
-            if (ncov > 1) out[1] = t1;
-            if (ncov > 2) out[2] = t2;
-            out[ncov] = t3;
+            out[0] = v4[0];
+            if (ncov > 1) out[1] = v4[1];
+            if (ncov > 2) out[2] = v4[2];
+            out[ncov] = v4[3];
         }
     }
 }
