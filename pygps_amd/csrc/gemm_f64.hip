@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_dual_kernel(GemmArgsPair p) {
     gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA>(g, ti, tj, 0, smem);
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
+template <int TM, int TN, bool AKC, bool BKC, bool DMA = false, bool EXP = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int ti, tj;
@@ -83,10 +83,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             while (wall_clock64() - t0 < 7000) __builtin_amdgcn_s_sleep(10);                        // ~70 us = half a K=512 tile
         }
     }
-    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA>(g, ti, tj, blockIdx.z, smem);
+    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, EXP>(g, ti, tj, blockIdx.z, smem);
 }
 
-template <int T, bool AKC, bool BKC, bool DMA = false>
+template <int T, bool AKC, bool BKC, bool DMA = false, bool EXP = false>
 int launch_t(const GemmArgs& g, hipStream_t st) {
     constexpr int SK = BK + 2;
     constexpr int ASZ = AKC ? T * SK : BK * (T + 16);
@@ -98,11 +98,11 @@ int launch_t(const GemmArgs& g, hipStream_t st) {
     dim3 grid(nblk, 1, g.batch > 0 ? g.batch : 1);
     static std::atomic<size_t> attr_set{0};          // two fit streams (host threads) launch concurrently
     if (attr_set.load(std::memory_order_acquire) < shm) {
-        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC, DMA>,
+        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC, DMA, EXP>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set.store(shm, std::memory_order_release);
     }
-    hipLaunchKernelGGL((gemm_f64_kernel<T, T, AKC, BKC, DMA>), grid, dim3(256), shm, st, g);
+    hipLaunchKernelGGL((gemm_f64_kernel<T, T, AKC, BKC, DMA, EXP>), grid, dim3(256), shm, st, g);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
@@ -154,6 +154,8 @@ int gemm_f64_launch(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PGP_OK;
     if (g.tile == 64) return launch_l<64>(g, st);
     // LDS-DMA staging (dbg bit 64): 128 x 128 tiles of M-contiguous operands, whole 16-deep k-tiles
-    if (dma_ok(g)) return launch_t<128, false, false, true>(g, st);
+    const bool ablate = (g.dbg & (1 | 2 | 1024)) != 0;        // timing experiments: the instantiations that test those bits
+    if (dma_ok(g)) return ablate ? launch_t<128, false, false, true, true>(g, st) : launch_t<128, false, false, true>(g, st);
+    if (ablate && !g.a_kc && !g.b_kc) return launch_t<128, false, false, false, true>(g, st);
     return launch_l<128>(g, st);
 }

@@ -26,7 +26,10 @@ __device__ __forceinline__ double swap_adjacent(double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
+// EXP: the instantiation that honours the k-loop ablation bits of GemmArgs::dbg (1 no restaging, 2 no barrier, 1024 no DMA
+// wait -- all give wrong results and exist for timing only); the production instantiations compile those tests away, so that
+// a stage of the k-loop is one basic block
+template <int TM, int TN, bool AKC, bool BKC, bool DMA = false, bool EXP = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, long bz, double* __restrict__ smem) {
     static_assert(!DMA || (!AKC && !BKC && TM == 128 && TN == 128), "LDS-DMA staging: 128-wide M-contiguous operands only");
     constexpr int SA = TM + 16, SB = TN + 16, SK = BK + 2;
@@ -68,6 +71,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
+    const int xdbg = EXP ? g.dbg : 0;              // ablation bits, only in the EXP instantiation
 #define GT_STAMP(i) do { if (g.stamps && t == 0) g.stamps[4L * blockIdx.x + (i)] = wall_clock64(); } while (0)
     GT_STAMP(0);
     const int wm = (wave & 1) * (TM / 2), wn = (wave >> 1) * (TN / 2);
@@ -235,16 +239,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         auto kstep = [&](int kt) {
             const bool more = kt + BK < k1;
             if constexpr (DMA) { if (more) dma_stage(buf ^ 1); }     // the other stage was last read before the previous barrier
-            else if (more && !(g.dbg & 1)) gload(kt + BK);
+            else if (more && !(xdbg & 1)) gload(kt + BK);
 #pragma unroll
             for (int ks = 0; ks + 1 < NS; ++ks) {
                 ldfrag(buf, ks + 1, (ks + 1) & 1);
                 mfmas(ks & 1);
             }
-            if constexpr (DMA) { if (!(g.dbg & 1024)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // dbg 1024: timing experiment (wrong results)
-            else if (more && !(g.dbg & 1)) sstore(buf ^ 1);
-            if (!(g.dbg & 2)) __syncthreads();
-            if (!(g.dbg & 1)) buf ^= 1;
+            if constexpr (DMA) { if (!(xdbg & 1024)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // dbg 1024: timing experiment (wrong results)
+            else if (more && !(xdbg & 1)) sstore(buf ^ 1);
+            if (!(xdbg & 2)) __syncthreads();
+            if (!(xdbg & 1)) buf ^= 1;
             if (more) ldfrag(buf, 0, NS & 1);     // first fragments of the next stage, behind ...
             mfmas((NS - 1) & 1);                  // ... the held-back last substep of this one
         };
