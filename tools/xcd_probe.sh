@@ -8,7 +8,7 @@ import csv,glob,sys
 tot=n=0
 for f in glob.glob("/tmp/pm/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"]=="FETCH_SIZE" and "gemm_f64_kernel<128, 128, false, false, true>" in r["Kernel_Name"]:
+        if r["Counter_Name"]=="FETCH_SIZE" and "gemm_f64_kernel<128, 128, false, false, true, false>" in r["Kernel_Name"]:
             tot+=float(r["Counter_Value"]); n+=1
 print(sys.argv[1], "FETCH per launch (x2, MB):", tot*2048/n/1e6, "launches", n)
 PY
