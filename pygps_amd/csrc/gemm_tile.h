@@ -250,6 +250,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             if (!(xdbg & 2)) __syncthreads();
             if (!(xdbg & 1)) buf ^= 1;
             if (more) ldfrag(buf, 0, NS & 1);     // first fragments of the next stage, behind ...
+            __builtin_amdgcn_sched_barrier(0);    // (keep the reads AHEAD of the MFMAs: the scheduler sinks them behind otherwise)
             mfmas((NS - 1) & 1);                  // ... the held-back last substep of this one
         };
         int kt = k0;
