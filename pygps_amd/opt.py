@@ -151,7 +151,7 @@ class ShardedMinimize(Minimize):
 
     #: concurrent fit streams per GPU.  A single fit leaves the GPU under-used while its Cholesky panel chain
     #: runs; a second, independent restart on the same GPU (own context, own host thread) fills those gaps:
-    #: 12.3 instead of 15.2 ms per fit at N=8192 on MI355X.  Results do not depend on this number.
+    #: 10.0 instead of 12.6 ms per fit at N=8192 on MI355X (round 2).  Results do not depend on this number.
     streams_per_gpu = 2
 
     def __init__(self, model, searchConfig=None, group=None, streams_per_gpu=None):
