@@ -1460,10 +1460,10 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         pgp_factor* f = hg.f;
         f->n = n; f->np = np; f->ldf = ldf; f->F = fguard.release(); f->dpad = c->dpad; f->d = (int)d; f->cs = cp; f->kss = kss;
         f->sn2 = sn2; f->sw = 1.0 / sqrt(sn2); f->Wd = nullptr;
-        HIP_TRY(hipMalloc((void**)&f->alpha, np * sizeof(double)));
+        CHK(spool_take(c, np * sizeof(double), (void**)&f->alpha));
         HIP_TRY(hipMemsetAsync(f->alpha, 0, np * sizeof(double), st));
         HIP_TRY(hipMemcpyAsync(f->alpha, alpha_h.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMalloc((void**)&f->XsT, (size_t)c->dpad * np * sizeof(double)));
+        CHK(spool_take(c, (size_t)c->dpad * np * sizeof(double), (void**)&f->XsT));
         HIP_TRY(hipMemcpyAsync(f->XsT, c->XsT, (size_t)c->dpad * np * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         *factor_out = hg.release();
@@ -1493,10 +1493,10 @@ void pgp_factor_free(pgp_ctx* c, pgp_factor* f) {
         // wrote the lower triangle + row np, and row np is rewritten by every fit, so it can go back as is.
         pool_free(c, (size_t)f->ldf * f->np * sizeof(double), f->F);
     }
-    if (f->alpha) (void)hipFree(f->alpha);
-    if (f->XsT) (void)hipFree(f->XsT);
-    if (f->Wd) (void)hipFree(f->Wd);
-    if (f->sWv) (void)hipFree(f->sWv);
+    spool_give(c, (size_t)f->np * sizeof(double), f->alpha);
+    spool_give(c, (size_t)f->dpad * f->np * sizeof(double), f->XsT);
+    spool_give(c, (size_t)128 * f->np * sizeof(double), f->Wd);
+    spool_give(c, (size_t)f->np * sizeof(double), f->sWv);
     delete f;
 }
 

@@ -177,6 +177,34 @@ static inline void pool_free(pgp_ctx* c, size_t bytes, void* p) {
     c->pool_bytes += bytes;
 }
 
+// Small device buffers owned by a posterior handle (alpha, scaled coordinates, leaf inverses): through the scratch pool, not
+// hipMalloc / hipFree -- hipFree synchronises the whole device, so releasing a posterior on one fit stream stalled the
+// other (API restart search on two streams: 88 instead of 100 fits/s).  No content contract: the owner writes every byte.
+static inline int spool_take(pgp_ctx* c, size_t bytes, void** out) {
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mu);
+        auto it = c->spool.find(bytes);
+        if (it != c->spool.end()) {
+            *out = it->second;
+            c->spool.erase(it);
+            c->spool_bytes -= bytes;
+            return PGP_OK;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    if (e != hipSuccess) { pgp_set_last_hip_error(e, "hipMalloc(handle buffer)", __FILE__, __LINE__); return PGP_ERR_HIP; }
+    return PGP_OK;
+}
+static inline void spool_give(pgp_ctx* c, size_t bytes, void* p) {
+    if (!p) return;
+    if (!c) { (void)hipFree(p); return; }
+    const size_t cap = pool_idle_cap(c);
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    if (c->spool_bytes + bytes > cap) { (void)hipFree(p); return; }
+    c->spool.insert({bytes, p});
+    c->spool_bytes += bytes;
+}
+
 struct ProfScope {
     pgp_ctx* c; int cls; double flops, bytes; hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t s; int shadow;
     ProfScope(pgp_ctx* c_, int cls_, double f, double b, hipStream_t s_ = nullptr, int shadow_ = -1)

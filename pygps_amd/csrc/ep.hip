@@ -879,12 +879,12 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         pgp_factor* f = hg.f;
         f->n = n; f->np = np; f->ldf = ldf; f->F = fguard.release(); f->dpad = c->dpad; f->d = (int)d; f->cs = cp; f->kss = kss;
         f->sn2 = 1.0; f->sw = 1.0; f->Wd = nullptr;
-        HIP_TRY(hipMalloc((void**)&f->alpha, np * sizeof(double)));
+        CHK(spool_take(c, np * sizeof(double), (void**)&f->alpha));
         HIP_TRY(hipMemsetAsync(f->alpha, 0, np * sizeof(double), st));
         HIP_TRY(hipMemcpyAsync(f->alpha, alpha.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMalloc((void**)&f->sWv, np * sizeof(double)));
+        CHK(spool_take(c, np * sizeof(double), (void**)&f->sWv));
         HIP_TRY(hipMemcpyAsync(f->sWv, sW.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMalloc((void**)&f->XsT, (size_t)c->dpad * np * sizeof(double)));
+        CHK(spool_take(c, (size_t)c->dpad * np * sizeof(double), (void**)&f->XsT));
         HIP_TRY(hipMemcpyAsync(f->XsT, c->XsT, (size_t)c->dpad * np * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         *factor_out = hg.release();

@@ -376,9 +376,9 @@ int pgp_fitc_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para,
     if (handle_out) {
         pgp_fitc* f = new pgp_fitc();
         f->nu = nu; f->nup = nup; f->d = (int)d; f->dpad = dpad; f->cs = cs; f->kss = kss;
-        HIP_TRY(hipMalloc((void**)&f->XuT, (size_t)dpad * nup * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&f->alpha, nup * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&f->Lpost, sq));
+        CHK(spool_take(c, (size_t)dpad * nup * sizeof(double), (void**)&f->XuT));      // pooled: hipFree would synchronise the device
+        CHK(spool_take(c, nup * sizeof(double), (void**)&f->alpha));
+        CHK(spool_take(c, (size_t)nup * nup * sizeof(double), (void**)&f->Lpost));
         HIP_TRY(hipMemcpyAsync(f->XuT, XuT, (size_t)dpad * nup * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(f->alpha, alpha_d, nup * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(f->Lpost, Lp, sq, hipMemcpyDeviceToDevice, st));
@@ -439,9 +439,9 @@ int pgp_fitc_predict(pgp_ctx* c, pgp_fitc* f, const double* xs, int64_t ns, cons
 void pgp_fitc_free(pgp_ctx* c, pgp_fitc* f) {
     if (!f) return;
     if (c) (void)hipSetDevice(c->device);
-    if (f->XuT) (void)hipFree(f->XuT);
-    if (f->alpha) (void)hipFree(f->alpha);
-    if (f->Lpost) (void)hipFree(f->Lpost);
+    spool_give(c, (size_t)f->dpad * f->nup * sizeof(double), f->XuT);
+    spool_give(c, (size_t)f->nup * sizeof(double), f->alpha);
+    spool_give(c, (size_t)f->nup * f->nup * sizeof(double), f->Lpost);
     delete f;
 }
 

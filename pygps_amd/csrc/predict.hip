@@ -60,7 +60,7 @@ int solve_lower_multi(pgp_ctx* c, const double* L, long ldl, const double* Wd /*
 
 static int ensure_wd(pgp_ctx* c, pgp_factor* f) {
     if (f->Wd) return PGP_OK;
-    HIP_TRY(hipMalloc((void**)&f->Wd, (size_t)128 * f->np * sizeof(double)));
+    CHK(spool_take(c, (size_t)128 * f->np * sizeof(double), (void**)&f->Wd));
     return leaf_inv_launch(f->F, f->ldf, f->Wd, 128, 128L * 128L, (int)(f->np / 128), c->st);
 }
 

@@ -173,12 +173,19 @@ class ShardedMinimize(Minimize):
         from . import _lib
         out = {}
 
+        todo = list(mine)
+        lock = threading.Lock()
+
         def work(k):
             with _lib.fit_stream(k):
                 clone = Minimize(_dc(self.model), None)
                 clone.model.optimizer = clone
                 clone.logger = self.logger
-                for t in mine[k::S]:
+                while True:                       # restarts are taken from a shared queue: line searches differ in length, a
+                    with lock:                    # static deal can leave one stream idle at the end (results do not depend on it)
+                        if not todo:
+                            return
+                        t = todo.pop(0)
                     out[t] = clone._one(table[t].copy(), numIters)
         ths = [threading.Thread(target=work, args=(k,)) for k in range(S)]
         [th.start() for th in ths]
