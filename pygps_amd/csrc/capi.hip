@@ -1526,7 +1526,7 @@ int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n,
     const int dpad = (int)round_up(d, SKC);
     const long ldr = round_up(n, 128), ldc = (mode == PGP_MODE_CROSS) ? round_up(m, 128) : 0;
     const long mm = (mode == PGP_MODE_CROSS) ? m : n;
-    DevScratch tmp;
+    PoolScratch tmp(c);
     double *xd = nullptr, *zd = nullptr, *XrT = nullptr, *XcT = nullptr, *scd = nullptr, *od = nullptr;
     CHK(tmp.alloc(&xd, n * d * sizeof(double)));
     CHK(tmp.alloc(&XrT, (size_t)dpad * ldr * sizeof(double)));
@@ -1621,7 +1621,7 @@ int pgp_potrf(pgp_ctx* c, const double* A, int64_t n, double* L_out) {
     HIP_TRY(hipSetDevice(c->device));
     const long np = round_up(n, 128);
     hipStream_t st = c->st;
-    DevScratch tmp;
+    PoolScratch tmp(c);
     double *F = nullptr, *pack = nullptr;
     CHK(tmp.alloc(&F, (size_t)np * np * sizeof(double)));
     CHK(tmp.alloc(&pack, (size_t)(np / 128) * PACK_DOUBLES * sizeof(double)));

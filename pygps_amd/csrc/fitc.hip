@@ -401,7 +401,7 @@ int pgp_fitc_predict(pgp_ctx* c, pgp_fitc* f, const double* xs, int64_t ns, cons
     const long nup = f->nup, nu = f->nu;
     const int d = f->d, dpad = f->dpad;
     const long NSB = 1024;
-    DevScratch tmp;
+    PoolScratch tmp(c);
     double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *LKs = nullptr, *msd = nullptr, *o1 = nullptr, *o2 = nullptr;
     CHK(tmp.alloc(&xd, NSB * d * sizeof(double)));
     CHK(tmp.alloc(&XcT, (size_t)dpad * NSB * sizeof(double)));

@@ -83,7 +83,7 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     // the N^2 flops per point of the triangular solve, 4096 -> 220 ms, 8192 -> 192 ms, 16384 -> 171 ms = 25.8 TF)
     const long NSB = std::max<long>(128, std::min<long>(c->predict_batch, round_up(ns, 128)));
     const long ldc = NSB;
-    DevScratch tmp;
+    PoolScratch tmp(c);
     double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *o2 = nullptr;
     CHK(tmp.alloc(&xd, NSB * d * sizeof(double)));
     CHK(tmp.alloc(&XcT, (size_t)dpad * ldc * sizeof(double)));
@@ -128,7 +128,7 @@ int pgp_potrs(pgp_ctx* c, const double* R, int64_t n, const double* Bm, int64_t 
     hipStream_t st = c->st;
     const long np = round_up(n, 128);
     const int nr = (int)round_up(nrhs, 128);
-    DevScratch tmp;
+    PoolScratch tmp(c);
     double *L = nullptr, *Wd = nullptr, *Y = nullptr;
     CHK(tmp.alloc(&L, (size_t)np * np * sizeof(double)));
     CHK(tmp.alloc(&Wd, (size_t)128 * np * sizeof(double)));
