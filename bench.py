@@ -296,6 +296,64 @@ def api_rate(N, d, x, y, steps):
             "what": "loop of model.getPosterior() (nlZ, dnlZ, post with device-resident L), one fit stream"}
 
 
+def sharded_cholesky_extra(torch, dist, n, w=512):
+    """SURVEY 8(f) row 4, measured: ONE Cholesky factorisation of an (n x n) RBF kernel matrix spread over all ranks
+    (pygps_amd.multigpu.ShardedCholesky: 1-D block-cyclic column panels, panel broadcasts over RCCL, trailing updates on
+    the fp64-MFMA GEMM).  The matrix is generated on the device panel by panel (torch: input generation only) and the
+    factor is checked in place with a distributed residual ||L L' v - A v|| / ||A v|| (no gather, no oracle).
+    Collective: every rank calls this."""
+    from pygps_amd.multigpu import ShardedCholesky
+    sc = ShardedCholesky(n, w=w)
+    dev, rank, world, plan = sc.device, sc.rank, sc.world, sc.plan
+    gen = torch.Generator().manual_seed(11)
+    X = torch.rand((n, 8), generator=gen, dtype=torch.float64).to(dev) * 4.0
+    v = torch.randn((n,), generator=gen, dtype=torch.float64).to(dev)
+    x2 = (X * X).sum(1)
+    times = []
+    for rep in range(2):                                                     # the first pass also warms pools, kernels, RCCL
+        Av = torch.zeros(n, dtype=torch.float64, device=dev)
+        for p in plan.owned(rank):
+            c = plan.local_index(p) * w
+            cols = slice(p * w, (p + 1) * w)
+            blk = sc.local[c:c + w]                                         # row a = column p w + a of the matrix
+            torch.mm(X[cols], X.T, out=blk)
+            blk.mul_(-2.0).add_(x2[cols, None]).add_(x2[None, :]).clamp_(min=0.0).mul_(-0.5).exp_()
+            blk[:, cols].diagonal().add_(0.1)
+            Av += blk.T @ v[cols]
+        dist.all_reduce(Av)
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sc.factor()
+        torch.cuda.synchronize(); dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        times.append(float(tt.item()))
+    dt = times[-1]
+    u = torch.zeros(n, dtype=torch.float64, device=dev)                     # u = L' v, each rank its own columns
+    masked = {}
+    for p in plan.owned(rank):
+        c = plan.local_index(p) * w
+        cols = slice(p * w, (p + 1) * w)
+        Lp = sc.local[c:c + w].clone()
+        Lp[:, :p * w] = 0.0
+        Lp[:, cols] = torch.triu(Lp[:, cols])                               # [a, b] = L[p w + b, p w + a], b >= a
+        u[cols] = Lp @ v
+        masked[p] = Lp
+    dist.all_reduce(u)
+    LLv = torch.zeros(n, dtype=torch.float64, device=dev)
+    for p, Lp in masked.items():
+        LLv += Lp.T @ u[p * w:(p + 1) * w]
+    dist.all_reduce(LLv)
+    res = float(((LLv - Av).norm() / Av.norm()).item())
+    fl = float(n) ** 3 / 3.0
+    return {"what": "ONE (n x n) fp64 Cholesky over all ranks: 1-D block-cyclic column panels of %d, depth-1 look-ahead, panel "
+                    "broadcast over RCCL (pygps_amd.multigpu.ShardedCholesky); matrix generated on the device" % w,
+            "n": n, "world": world, "panels": plan.npanel, "seconds": dt, "seconds_first_pass": times[0], "TFLOPs": fl / dt / 1e12,
+            "TFLOPs_per_gpu": fl / dt / 1e12 / world, "frac_of_peak_per_gpu": fl / dt / 1e12 / world / PEAK_FP64_MFMA_TF,
+            "residual_LLtv_vs_Av": res, "bytes_broadcast": float(sum(s.bcast_bytes for s in plan.steps())),
+            "imbalance": plan.imbalance()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,6 +370,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=150.0)
     ap.add_argument("--no-extras", action="store_true", help="skip cfg 3 / cfg 5 / N=16384 figures (used by the rocprof passes)")
     ap.add_argument("--option", action="append", default=[], help="library option name=value (experiments)")
+    ap.add_argument("--sharded-n", type=int, default=-1,
+                    help="size of the one-Cholesky-over-all-ranks extra (SURVEY 8(f)4); -1 = 32768 on one GPU, 65536 on "
+                         "more; 0 = skip")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON).  Native libraries print there too (RCCL writes its version banner to
@@ -572,6 +633,28 @@ def main():
         if "api" in extra:
             out["api_fits_per_s"] = extra["api"].get("fits_per_s")
             out["api"] = extra["api"]
+    # ---- one factorisation over ALL ranks (collective; after the timed region, outside `value`).  A
+    #      watchdog keeps the contract if the collective path stalls on a node this code has never run on: the JSON line
+    #      goes out without the figure and the process leaves.
+    sn = args.sharded_n if args.sharded_n >= 0 else (32768 if world == 1 else 65536)
+    if dist and sn > 0 and not args.no_extras and backend == "nccl":
+        def bail():                                          # pragma: no cover
+            if rank == 0:
+                out["sharded_cholesky"] = {"error": "no result within 240 s", "n": sn, "world": world}
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        dist.barrier()                                       # rank 0 arrives after its single-GPU extras; the clock starts here
+        dog = threading.Timer(240.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            shard = sharded_cholesky_extra(torch, dist, sn)
+        except Exception as e:                               # pragma: no cover
+            shard = {"error": repr(e), "n": sn, "world": world}
+        dog.cancel()
+        if rank == 0:
+            out["sharded_cholesky"] = shard
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, d, args.cpu_budget)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -10,10 +10,15 @@ executes that plan on the device:
     all ranks:  pgp_dev_panel_update   -- C_j -= Y_p Y_p[j]' on the fp64-MFMA GEMM for every OWNED panel j > p,
                 the next panel first (it is the next owner's look-ahead target)
 
-Status: correct by construction and tested (world 1 over RCCL, world 2 sharing one GPU over gloo, against LAPACK); the
-steps are synchronous (the updates of a step are queued without waiting, but the broadcast of step p+1 is not yet
-overlapped with the trailing update of step p -- the plan's look-ahead) and it has never been timed on more than one GPU.  Product rule as everywhere: no CPU fallback, the
-primitives raise without the HIP library.
+Look-ahead (depth 1): in step p the owner of panel p+1 updates that panel first, factors it and posts its broadcast
+(`async_op`), so Y_{p+1} travels while every rank works through the rest of step p's trailing updates; two receive
+buffers alternate.  A non-positive pivot is marked in the broadcast panel (the last panel: a final status all-reduce), so
+every rank raises `LinAlgError` at the same step instead of waiting in a collective.
+
+Status: tested against LAPACK (world 1 over RCCL, world 2 sharing one GPU over gloo, non-PD input at both); timed on ONE
+GPU only (N = 32768: 0.27 s = 43.5 TF, the Python-driven panel loop included) -- `bench.py` runs it over all ranks as the
+`sharded_cholesky` extra, which is where the first multi-GPU figure comes from.  Product rule as everywhere: no CPU
+fallback, the primitives raise without the HIP library.
 """
 import numpy as np
 
@@ -75,47 +80,111 @@ class ShardedCholesky(object):
 
     # ---- the sweep ------------------------------------------------------------------------------------------------
     def _bcast(self, t, src):
+        self._bcast_start(t, src)()
+
+    def _bcast_start(self, t, src):
+        """Post the broadcast of `t`; the returned callable blocks the host until `t` holds the data."""
         if self.world == 1 and self.backend is None:
-            return
-        if self.backend == "gloo":                         # self-test transport: through host memory
-            h = t.cpu()
-            self.dist.broadcast(h, src=src, group=self.group)
-            t.copy_(h)
-        else:                                              # RCCL (xGMI ring for world > 1)
-            self.dist.broadcast(t, src=src, group=self.group)
+            return lambda: None
+        if self.backend == "gloo":                         # self-test transport: through host memory, at wait time
+            def wait():
+                h = t.cpu()
+                self.dist.broadcast(h, src=src, group=self.group)
+                t.copy_(h)
+                self.torch.cuda.current_stream(self.device).synchronize()
+            return wait
+        work = self.dist.broadcast(t, src=src, group=self.group, async_op=True)    # RCCL (xGMI ring for world > 1)
+
+        def wait():
+            work.wait()                                    # torch's stream waits for the collective ...
+            self.torch.cuda.current_stream(self.device).synchronize()              # ... and the host for torch's stream
+        return wait
+
+    def _panel_ptr(self, p):
+        """Device address of panel p's diagonal block inside the local storage."""
+        return self.local.data_ptr() + 8 * (self.plan.local_index(p) * self.w * self.np + p * self.w)
+
+    def _factor_owned(self, p, ybuf):
+        """D(p) + S(p) on the owned panel p; the solved rows below go to `ybuf` (contiguous, what the broadcast sends).
+        A non-positive pivot does not raise here: it is marked in the buffer (NaN, pivot index) so that EVERY rank sees it
+        after the broadcast and leaves the sweep at the same step."""
+        torch, w, npd = self.torch, self.w, self.np
+        rc = self.lib.pgp_dev_panel_factor(self.ctx, self._panel_ptr(p), npd, npd - p * w, w)
+        if rc < 0:
+            _lib.check(rc, "pgp_dev_panel_factor")
+        c = self.plan.local_index(p) * w
+        if ybuf is not None:
+            ybuf.copy_(self.local[c:c + w, (p + 1) * w:])
+            if rc > 0:
+                ybuf.view(-1)[:2] = torch.tensor([float("nan"), float(p * w + rc)], dtype=torch.float64, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()
+        return rc
 
     def factor(self):
+        """Right-looking sweep with a depth-1 look-ahead: in step p the owner of panel p+1 updates that panel first,
+        factors it and posts its broadcast; the broadcast of Y_{p+1} then travels while every rank (the owner included)
+        works through the rest of step p's trailing updates (multigpu_plan: "Look-ahead")."""
         torch, lib, plan, w, npd = self.torch, self.lib, self.plan, self.w, self.np
-        pending = []
-        for s in plan.steps():
+        steps = plan.steps()
+        store = [torch.empty(w * max(npd - w, 1), dtype=torch.float64, device=self.device) for _ in range(2)]
+
+        def ybuf_of(p):                                    # Y_p: column-major below x w, ld = below
+            below = steps[p].bcast_rows
+            return store[p & 1][:w * below].view(w, below) if below else None
+
+        def update(j, p, y):
+            m = npd - j * w
+            yptr = y.data_ptr() + 8 * ((j - p - 1) * w)
+            _lib.check(lib.pgp_dev_panel_update(self.ctx, self._panel_ptr(j), npd, m, w, yptr, steps[p].bcast_rows, w),
+                       "pgp_dev_panel_update")
+
+        def bad_pivot(piv):
+            raise np.linalg.LinAlgError("Matrix is not positive definite (pivot %d)" % piv)
+
+        torch.cuda.synchronize(self.device)                 # torch's copies into `local` precede the library's stream
+        y = ybuf_of(0)
+        rc = self._factor_owned(0, y) if steps[0].owner == self.rank else 0
+        if y is None:                                       # a single panel
+            if rc > 0:
+                bad_pivot(rc)
+            return self
+        arrived = self._bcast_start(y, steps[0].owner)
+        for s in steps:
             p = s.p
-            rows = npd - p * w                              # panel p from its diagonal block down
-            below = s.bcast_rows                            # = rows - w: what the other panels need of it
-            ybuf = torch.empty((w, max(below, 1)), dtype=torch.float64, device=self.device)   # column-major below x w, ld = below
-            if s.owner == self.rank:
-                c = plan.local_index(p) * w
-                torch.cuda.synchronize(self.device)         # torch's copies into `local` precede the library's stream
-                ptr = self.local.data_ptr() + 8 * (c * npd + p * w)
-                rc = lib.pgp_dev_panel_factor(self.ctx, ptr, npd, rows, w)
-                if rc > 0:
-                    raise np.linalg.LinAlgError("Matrix is not positive definite (pivot %d)" % (p * w + rc))
-                _lib.check(rc, "pgp_dev_panel_factor")
-                if below:
-                    ybuf.copy_(self.local[c:c + w, (p + 1) * w:])
-            if not below:
+            if not s.bcast_rows:
                 break
-            self._bcast(ybuf, s.owner)
-            torch.cuda.synchronize(self.device)
-            for j in s.updates[self.rank]:                  # ascending: the next panel (look-ahead target) first
-                cj = plan.local_index(j) * w
-                m = npd - j * w
-                cptr = self.local.data_ptr() + 8 * (cj * npd + j * w)
-                yptr = ybuf.data_ptr() + 8 * ((j - p - 1) * w)
-                _lib.check(lib.pgp_dev_panel_update(self.ctx, cptr, npd, m, w, yptr, below, w), "pgp_dev_panel_update")
-            # the queued updates read ybuf: it must outlive them (torch's caching allocator would hand the block out again)
-            pending.append(ybuf)
-            if len(pending) > 1:
+            arrived()                                       # Y_p is here
+            head = y.view(-1)[:2].cpu().numpy()
+            if head[0] != head[0]:
                 _lib.check(lib.pgp_dev_sync(self.ctx), "pgp_dev_sync")
-                del pending[:-1]
+                bad_pivot(int(head[1]))
+            mine = list(s.updates[self.rank])
+            nxt = p + 1
+            ynext = ybuf_of(nxt)
+            rc = 0
+            if steps[nxt].owner == self.rank:
+                update(nxt, p, y)                           # look-ahead target first ...
+                mine.remove(nxt)
+                rc = self._factor_owned(nxt, ynext)         # ... waits for the stream (my step p-1 updates are behind it)
+            else:
+                # the buffer Y_{p+1} lands in was Y_{p-1}: the updates that read it must have left the stream
+                _lib.check(lib.pgp_dev_sync(self.ctx), "pgp_dev_sync")
+            if ynext is not None:
+                arrived = self._bcast_start(ynext, steps[nxt].owner)
+            elif rc > 0:                                    # the last panel has nothing to send: status by all-reduce below
+                pass
+            for j in mine:                                  # the rest of step p, queued; it runs under the broadcast
+                update(j, p, y)
+            y = ynext
+            last_rc = rc
         _lib.check(lib.pgp_dev_sync(self.ctx), "pgp_dev_sync")
+        # the last panel's pivot status reaches everybody through one small all-reduce
+        piv = torch.tensor([float((plan.npanel - 1) * w + last_rc) if last_rc > 0 else 0.0], dtype=torch.float64,
+                           device=self.device)
+        if not (self.world == 1 and self.backend is None):
+            t = piv.cpu() if self.backend == "gloo" else piv
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+            piv = t
+        if float(piv.item()) > 0:
+            bad_pivot(int(piv.item()))
         return self

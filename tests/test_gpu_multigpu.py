@@ -45,13 +45,14 @@ def _worker(rank, world, port, backend, n, w, out_dir):
         sc.factor()
         L = sc.gather_host()
         np.save(os.path.join(out_dir, "L%d.npy" % rank), L)
-        # a non-PD matrix: every rank must see the owner's failure... the owner raises, the others would wait in the
-        # broadcast -- so only a single-rank world checks the error path here
-        if world == 1:
+        # a non-PD matrix: the owner of the failing panel marks the panel it broadcasts (or, for the last panel, the final
+        # status all-reduce), so EVERY rank raises at the same step instead of waiting in a broadcast
+        for bad in (700, n - 3):
             B = A.copy()
-            B[700, 700] = -1.0
-            with pytest.raises(np.linalg.LinAlgError):
+            B[bad, bad] = -1.0
+            with pytest.raises(np.linalg.LinAlgError) as ei:
                 ShardedCholesky(n, w=w).load_host(B).factor()
+            assert "pivot %d" % (bad + 1) in str(ei.value)
     finally:
         dist.destroy_process_group()
 
