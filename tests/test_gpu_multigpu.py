@@ -66,3 +66,33 @@ def test_block_cyclic_cholesky_on_device(tmp_path, world, backend, n, w):
         L = np.load(os.path.join(str(tmp_path), "L%d.npy" % r))
         assert np.abs(L - ref).max() < 1e-11 * np.abs(ref).max() * n ** 0.5
         assert np.array_equal(np.triu(L, 1), np.zeros_like(L))
+
+
+def _extra_worker(rank, world, port, backend, n, out_dir):
+    import json
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        import bench
+        out = bench.sharded_cholesky_extra(torch, dist, n, w=256)
+        if rank == 0:
+            json.dump(out, open(os.path.join(out_dir, "extra.json"), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+def test_bench_extra_one_factorisation_over_all_ranks(tmp_path, world, backend):
+    """bench.py's `sharded_cholesky` extra: device-generated kernel matrix, factor, distributed residual check."""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_extra_worker, args=(world, _free_port(), backend, 2048, str(tmp_path)), nprocs=world, join=True)
+    out = json.load(open(os.path.join(str(tmp_path), "extra.json")))
+    assert out["world"] == world and out["n"] == 2048 and out["panels"] == 8
+    assert out["residual_LLtv_vs_Av"] < 1e-13 and out["seconds"] > 0
