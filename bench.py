@@ -235,43 +235,6 @@ def extras(lib, _lib, local, d, roof):
                     "flop model: 8 products of 2 nu^2 n (V, V V', B, W, B W' and two per hyper)"}
     except Exception as e:           # pragma: no cover
         out["predict_fitc_error"] = repr(e)
-    # ---- cfg 4 on ONE GPU: the restart search through the drop-in optimiser (two restarts at a time, one fit stream each) ----
-    try:
-        import pygps_amd as pyGPs
-        n4, d4 = 8192, 16
-        x4, y4 = synth_reg(n4, d4)
-        m4 = pyGPs.GPR()
-        m4.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d4)), 0.0)); m4.setNoise(np.log(0.1))
-        m4.setData(x4, y4)
-        m4.setOptimizer("ShardedMinimize", num_restarts=8)
-        np.random.seed(7)
-        import threading
-        calls, lock, orig = [0], threading.Lock(), pyGPs.inf.Exact.evaluate
-
-        def counted(self_, *a, **k):                      # count the fits the optimiser asks for (all restart threads)
-            with lock:
-                calls[0] += 1
-            return orig(self_, *a, **k)
-        pyGPs.inf.Exact.evaluate = counted
-        try:
-            m4.optimize(x4, y4, numIterations=2)          # builds the two fit-stream contexts and their workspaces (one-off cost)
-            calls[0] = 0
-            np.random.seed(7)
-            t = time.perf_counter()
-            m4.optimize(x4, y4, numIterations=10)
-            t4 = time.perf_counter() - t
-        finally:
-            pyGPs.inf.Exact.evaluate = orig
-        runs = m4.optimizer.runs or []
-        nls = int(sum(r.nls for r in runs))
-        out["cfg4_restarts_N8192_1gpu"] = {
-            "restarts": 8, "line_searches_per_restart": 10, "wall_s": t4, "line_searches_total": nls, "fits": calls[0],
-            "fits_per_s": calls[0] / t4, "nlZ_best": float(m4.nlZ),
-            "what": "BASELINE configs[3] on one GPU: GPR.optimize with ShardedMinimize, 8 restarts x 10 line searches of "
-                    "minimize.run at N=8192 d=16, restarts dealt to two fit streams; fits = Exact.evaluate calls "
-                    "(nlZ + gradients each), wall time of the whole optimize() call of a warmed-up model"}
-    except Exception as e:           # pragma: no cover
-        out["cfg4_error"] = repr(e)
     return out
 
 
@@ -294,6 +257,55 @@ def api_rate(N, d, x, y, steps):
     dt = time.perf_counter() - t
     return {"fits_per_s": steps / dt, "ms_per_fit": dt / steps * 1e3, "steps": steps,
             "what": "loop of model.getPosterior() (nlZ, dnlZ, post with device-resident L), one fit stream"}
+
+
+def cfg4_extra(torch, dist, world, n4=8192):
+    """BASELINE configs[3] through the drop-in optimiser: GPR.optimize with ShardedMinimize, 8 restarts x 10 line searches of
+    minimize.run at N=8192 d=16, restart r on rank r % world (one broadcast of the start table + data, one all-gather of the
+    results: pygps_amd/opt.py).  On one GPU the 8 restarts are dealt to two fit streams; on 8 GPUs it is one restart per
+    GPU, one fit stream each.  Collective: every rank calls this."""
+    import threading
+    import pygps_amd as pyGPs
+    d4 = 16
+    x4, y4 = synth_reg(n4, d4)
+    m4 = pyGPs.GPR()
+    m4.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d4)), 0.0)); m4.setNoise(np.log(0.1))
+    m4.setData(x4, y4)
+    m4.setOptimizer("ShardedMinimize", num_restarts=8)
+    calls, lock, orig = [0], threading.Lock(), pyGPs.inf.Exact.evaluate
+
+    def counted(self_, *a, **k):                          # count the fits the optimiser asks for (all restart threads)
+        with lock:
+            calls[0] += 1
+        return orig(self_, *a, **k)
+    pyGPs.inf.Exact.evaluate = counted
+    try:
+        np.random.seed(7)
+        m4.optimize(x4, y4, numIterations=2)              # builds the fit-stream contexts and their workspaces (one-off cost)
+        calls[0] = 0
+        np.random.seed(7)
+        if dist:
+            dist.barrier()
+        t = time.perf_counter()
+        m4.optimize(x4, y4, numIterations=10)
+        t4 = time.perf_counter() - t
+    finally:
+        pyGPs.inf.Exact.evaluate = orig
+    fits = float(calls[0])
+    if dist:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        tt = torch.tensor([t4], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ft = torch.tensor([fits], dtype=torch.float64, device=dev)
+        dist.all_reduce(ft)
+        t4, fits = float(tt.item()), float(ft.item())
+    runs = m4.optimizer.runs or []
+    return {"n_gpus": world, "N": n4, "restarts": 8, "line_searches_per_restart": 10, "wall_s": t4,
+            "line_searches_total": int(sum(r.nls for r in runs)), "fits": int(fits), "fits_per_s": fits / t4,
+            "nlZ_best": float(m4.nlZ), "fit_streams_per_gpu": min(2, -(-8 // world)),
+            "what": "BASELINE configs[3]: GPR.optimize with ShardedMinimize, 8 restarts x 10 line searches of minimize.run at "
+                    "N=8192 d=16, restart r on rank r % n_gpus over RCCL; fits = Exact.evaluate calls on all ranks (nlZ + "
+                    "gradients each), wall time of the whole optimize() call of a warmed-up model (max over ranks)"}
 
 
 def sharded_cholesky_extra(torch, dist, n, w=512):
@@ -370,6 +382,10 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=150.0)
     ap.add_argument("--no-extras", action="store_true", help="skip cfg 3 / cfg 5 / N=16384 figures (used by the rocprof passes)")
     ap.add_argument("--option", action="append", default=[], help="library option name=value (experiments)")
+    ap.add_argument("--collective-extras-only", action="store_true",
+                    help="skip rank 0's single-GPU extras but run the collective ones (cfg 4 over the ranks, one Cholesky over "
+                         "the ranks): the 2-rank self-test")
+    ap.add_argument("--cfg4-n", type=int, default=8192, help="N of the cfg-4 restart-search extra")
     ap.add_argument("--sharded-n", type=int, default=-1,
                     help="size of the one-Cholesky-over-all-ranks extra (SURVEY 8(f)4); -1 = 32768 on one GPU, 65536 on "
                          "more; 0 = skip")
@@ -392,6 +408,7 @@ def main():
     backend = os.environ.get("PYGPS_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = local % torch.cuda.device_count()
+        os.environ["LOCAL_RANK"] = str(local)              # pygps_amd._lib.default_device() reads it
     torch.cuda.set_device(local)
     cdev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
     # The process group is created at EVERY world size, 1 included: the RCCL broadcast / all-reduce / all-gather below
@@ -595,7 +612,7 @@ def main():
         if asm and asm["launches"]:
             roof["assembly_fused_GBs"] = asm["bytes"] / asm["ms"] / 1e6
             roof["assembly_fused_frac_of_hbm_peak"] = asm["bytes"] / asm["ms"] / 1e6 / PEAK_HBM_GBS
-        if not args.no_extras:
+        if not args.no_extras and not args.collective_extras_only:
             try:
                 extra = extras(lib, _lib, local, d, roof)
             except Exception as e:         # pragma: no cover
@@ -633,27 +650,36 @@ def main():
         if "api" in extra:
             out["api_fits_per_s"] = extra["api"].get("fits_per_s")
             out["api"] = extra["api"]
-    # ---- one factorisation over ALL ranks (collective; after the timed region, outside `value`).  A
-    #      watchdog keeps the contract if the collective path stalls on a node this code has never run on: the JSON line
-    #      goes out without the figure and the process leaves.
+    # ---- collective extras, after the timed region and outside `value`: BASELINE configs[3] through the drop-in optimiser
+    #      (restarts sharded over the ranks) and SURVEY 8(f) row 4 (one factorisation over ALL ranks).  A watchdog keeps
+    #      the contract if the collective path stalls on a node this code has never run on: the JSON line goes out without
+    #      the figures and the process leaves.
     sn = args.sharded_n if args.sharded_n >= 0 else (32768 if world == 1 else 65536)
-    if dist and sn > 0 and not args.no_extras and backend == "nccl":
+    if dist and not args.no_extras:
+        dist.barrier()                                       # rank 0 arrives after its single-GPU extras; the clock starts here
+        partial = {}
+
         def bail():                                          # pragma: no cover
             if rank == 0:
-                out["sharded_cholesky"] = {"error": "no result within 240 s", "n": sn, "world": world}
+                out.update(partial)
+                out["collective_extras_error"] = "no result within 300 s (world %d)" % world
                 os.write(json_fd, (json.dumps(out) + "\n").encode())
             os._exit(0)
-        dist.barrier()                                       # rank 0 arrives after its single-GPU extras; the clock starts here
-        dog = threading.Timer(240.0, bail)
+        dog = threading.Timer(300.0, bail)
         dog.daemon = True
         dog.start()
         try:
-            shard = sharded_cholesky_extra(torch, dist, sn)
+            partial["cfg4_restarts_N8192"] = cfg4_extra(torch, dist, world, args.cfg4_n)
         except Exception as e:                               # pragma: no cover
-            shard = {"error": repr(e), "n": sn, "world": world}
+            partial["cfg4_restarts_N8192"] = {"error": repr(e), "n_gpus": world}
+        if sn > 0:
+            try:
+                partial["sharded_cholesky"] = sharded_cholesky_extra(torch, dist, sn)
+            except Exception as e:                           # pragma: no cover
+                partial["sharded_cholesky"] = {"error": repr(e), "n": sn, "world": world}
         dog.cancel()
         if rank == 0:
-            out["sharded_cholesky"] = shard
+            out.update(partial)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, d, args.cpu_budget)
