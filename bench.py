@@ -387,8 +387,8 @@ def main():
                          "the ranks): the 2-rank self-test")
     ap.add_argument("--cfg4-n", type=int, default=8192, help="N of the cfg-4 restart-search extra")
     ap.add_argument("--sharded-n", type=int, default=-1,
-                    help="size of the one-Cholesky-over-all-ranks extra (SURVEY 8(f)4); -1 = 32768 on one GPU, 65536 on "
-                         "more; 0 = skip")
+                    help="size of the one-Cholesky-over-all-ranks extra (SURVEY 8(f)4); -1 = 65536 (34 GB over the ranks); "
+                         "0 = skip")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON).  Native libraries print there too (RCCL writes its version banner to
@@ -654,7 +654,7 @@ def main():
     #      (restarts sharded over the ranks) and SURVEY 8(f) row 4 (one factorisation over ALL ranks).  A watchdog keeps
     #      the contract if the collective path stalls on a node this code has never run on: the JSON line goes out without
     #      the figures and the process leaves.
-    sn = args.sharded_n if args.sharded_n >= 0 else (32768 if world == 1 else 65536)
+    sn = args.sharded_n if args.sharded_n >= 0 else 65536     # the same size at every world size: a strong-scaling series
     if dist and not args.no_extras:
         dist.barrier()                                       # rank 0 arrives after its single-GPU extras; the clock starts here
         partial = {}
