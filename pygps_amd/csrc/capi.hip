@@ -175,6 +175,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
     if (!strcmp(name, "ep_block")) { c->ep_block = value; return PGP_OK; }
     if (!strcmp(name, "ep_graph")) { c->ep_graph = value; return PGP_OK; }
+    if (!strcmp(name, "ep_resident")) { c->ep_resident = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { cov_tile_set_grid(value); return PGP_OK; }
     if (!strcmp(name, "cu_reserve")) {
         // value > 1: every value-th CU is kept free of bulk work; value < 0: the LAST -value CUs of the mask enumeration;

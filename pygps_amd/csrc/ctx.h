@@ -55,6 +55,9 @@ struct pgp_ctx {
     int eet_max_panels = 32;
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
+    int ep_resident = 0;                // EP: one resident kernel per 128-site block (grid barrier between its 8 steps) instead of 8 dependent
+                                        // launches.  Measured: 52.7 against 50.7 ms per cfg-5 fit -- a counter barrier over 22 workgroups through
+                                        // memory-side atomics costs as much as the launch gap it replaces; kept as an option (parity-tested)
     int ep_graph = 0;                   // EP: replay each 128-site block as a captured hipGraph (measured: no gain)
     int ep_fused = 2;                   // EP parameter recomputation: 0 blocked multi-rhs solve, 1 through the fused inverse (V' = K diag(sW)
                                         // L^-T as one product), 2 K diag(sW) as dense right-hand-side rows of the sweep

@@ -262,15 +262,25 @@ __device__ int g_ep_dbg = 0;            // timing experiments only (option ep_db
 constexpr size_t EPS_LDS_BYTES = (size_t)(EPT * (EPB + 1) + EPT * (EPB + EPT) + 2 * EPB) * sizeof(double);
 constexpr int EPS_THREADS = 256;          // wave 0: the in-launch recurrence, alone on its SIMD; waves 1-3: EPS_ROWS rows of the new factor columns
 constexpr int EPS_ROWS = EPS_THREADS - 64;
-__global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
-                                                            const long* __restrict__ base, int j0, double* __restrict__ S,
-                                                            double* __restrict__ cvec, double* __restrict__ qvec,
-                                                            const double* __restrict__ mu_blk, const double* __restrict__ m,
-                                                            const double* __restrict__ y,
-                                                            const double* __restrict__ ttau_prev,
-                                                            const double* __restrict__ tnu_prev,
-                                                            double* __restrict__ ttau_cur, double* __restrict__ tnu_cur) {
-    extern __shared__ __attribute__((aligned(16))) double eps_lds[];   // EPS_LDS_BYTES: more than the 64 KB static limit at EPB = 256
+// COH: what other workgroups wrote earlier in the SAME kernel (rows i_t of the factor columns, the (c, q) entries) is read with
+// agent-scope loads, and the factor columns / (c, q) are written with agent-scope stores (coherent across the XCD L2s without
+// cache-wide write-back / invalidate); false for the one-step-per-launch kernel, where the launch boundary does that.
+__device__ __forceinline__ double coh_ld(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coh_st(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH>
+__device__ __forceinline__ void ep_sites_lazy_body(const double* __restrict__ Sig, long ld, long np,
+                                                   const long* __restrict__ base, int j0, double* __restrict__ S,
+                                                   double* __restrict__ cvec, double* __restrict__ qvec,
+                                                   const double* __restrict__ mu_blk, const double* __restrict__ m,
+                                                   const double* __restrict__ y,
+                                                   const double* __restrict__ ttau_prev,
+                                                   const double* __restrict__ tnu_prev,
+                                                   double* __restrict__ ttau_cur, double* __restrict__ tnu_cur,
+                                                   double* __restrict__ eps_lds /* EPS_LDS_BYTES of dynamic LDS */) {
     double (*Srow)[EPB + 1] = reinterpret_cast<double (*)[EPB + 1]>(eps_lds);                         // row i_t of the factor columns 0 .. j0-1
     double (*gv)[EPB + EPT] = reinterpret_cast<double (*)[EPB + EPT]>(eps_lds + EPT * (EPB + 1));     // g_t[k] = c_k S(i_t, k), k < j0 + t
     double* cl = eps_lds + EPT * (EPB + 1) + EPT * (EPB + EPT);
@@ -281,8 +291,11 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
     __shared__ double sv[4][EPT];                // the sites' (ttau, tnu) of the previous sweep, m, y
     const int t = threadIdx.x, lane = t & 63;
     const long i0 = base[0] + j0;
-    for (int v = t; v < EPT * j0; v += EPS_THREADS) { const int tt = v / j0, k = v % j0; Srow[tt][k] = S[i0 + tt + (long)k * ld]; }
-    for (int k = t; k < j0; k += EPS_THREADS) { cl[k] = cvec[k]; ql[k] = qvec[k]; }
+    for (int v = t; v < EPT * j0; v += EPS_THREADS) {
+        const int tt = v / j0, k = v % j0;
+        Srow[tt][k] = COH ? coh_ld(S + i0 + tt + (long)k * ld) : S[i0 + tt + (long)k * ld];
+    }
+    for (int k = t; k < j0; k += EPS_THREADS) { cl[k] = COH ? coh_ld(cvec + k) : cvec[k]; ql[k] = COH ? coh_ld(qvec + k) : qvec[k]; }
     if (t < EPT * EPT) Sg[t / EPT][t % EPT] = sym_at(Sig, ld, i0 + t / EPT, i0 + t % EPT);
     __syncthreads();
     for (int v = t; v < EPT * j0; v += EPS_THREADS) { const int tt = v / j0, k = v % j0; gv[tt][k] = cl[k] * Srow[tt][k]; }
@@ -324,7 +337,11 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
             ep_site_update(sii, mui, sv[0][u], sv[1][u], sv[2][u], sv[3][u], t_new, nu_new, cj, qj);
             cN[u] = cj;
             qN[u] = qj;
-            if (lane == 0 && blockIdx.x == 0) { ttau_cur[i0 + u] = t_new; tnu_cur[i0 + u] = nu_new; cvec[j0 + u] = cj; qvec[j0 + u] = qj; }
+            if (lane == 0 && blockIdx.x == 0) {
+                ttau_cur[i0 + u] = t_new; tnu_cur[i0 + u] = nu_new;
+                if (COH) { coh_st(cvec + j0 + u, cj); coh_st(qvec + j0 + u, qj); }
+                else { cvec[j0 + u] = cj; qvec[j0 + u] = qj; }
+            }
             // column j0 + u at the rows of the later sites:  e_L[u] = Sigma_blk(i_L, i_u) - G[L][u] - sum_{v<u} c_v e_u[v] e_L[v]
             double acc = Sg[L][u] - G[L > u ? L : u][L > u ? u : L];
 #pragma unroll
@@ -368,8 +385,72 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
         for (int tt = 0; tt < EPT; ++tt) {           // column j0+tt also depends on the columns j0 .. j0+tt-1 of this launch
 #pragma unroll
             for (int u = 0; u < tt; ++u) acc[tt] = fma(-gv[tt][j0 + u], acc[u], acc[tt]);
-            S[r + (long)(j0 + tt) * ld] = acc[tt];
+            if (COH) coh_st(S + r + (long)(j0 + tt) * ld, acc[tt]);
+            else S[r + (long)(j0 + tt) * ld] = acc[tt];
         }
+    }
+}
+
+__global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
+                                                            const long* __restrict__ base, int j0, double* __restrict__ S,
+                                                            double* __restrict__ cvec, double* __restrict__ qvec,
+                                                            const double* __restrict__ mu_blk, const double* __restrict__ m,
+                                                            const double* __restrict__ y,
+                                                            const double* __restrict__ ttau_prev,
+                                                            const double* __restrict__ tnu_prev,
+                                                            double* __restrict__ ttau_cur, double* __restrict__ tnu_cur) {
+    extern __shared__ __attribute__((aligned(16))) double eps_lds[];   // EPS_LDS_BYTES: more than the 64 KB static limit at EPB = 256
+    ep_sites_lazy_body<false>(Sig, ld, np, base, j0, S, cvec, qvec, mu_blk, m, y, ttau_prev, tnu_prev, ttau_cur, tnu_cur, eps_lds);
+}
+
+// One 128-site block of the sweep as ONE resident kernel: the nsite / EPT steps that ep_sites_lazy_kernel runs as
+// dependent launches (19.8 us of work + ~7 us of launch gap each at N = 4096) become iterations separated by a counter
+// barrier over the grid.  What crosses workgroups between two steps is small -- rows i_t of the factor columns made so
+// far (written by whichever workgroup owns those rows) and the (c, q) entries of workgroup 0 -- and travels through
+// agent-scope loads / stores (coherent across the XCD L2s), so the barrier is one atomic counter without cache-wide
+// write-back / invalidate.  Measured at N = 4096: 52.7 ms per fit against 50.7 with eight launches per block (the same with
+// release / acquire fences instead of coherent accesses): draining the write-through stores plus one round of memory-side
+// atomics costs the ~7 us a dependent launch costs.  Option ep_resident, off by default.  The grid must be co-resident: the host only takes this path for grids <= the CU
+// count (37 KB of LDS and 256 threads per workgroup fit beside anything else that runs).  flags[0] counts arrivals
+// monotonically over the launches of a fit (epoch0 = barriers already passed), flags[1] != 0 = a wait timed out.
+__global__ __launch_bounds__(EPS_THREADS) void ep_block_resident_kernel(const double* __restrict__ Sig, long ld, long np,
+                                                                const long* __restrict__ base, int nsite, double* __restrict__ S,
+                                                                double* __restrict__ cvec, double* __restrict__ qvec,
+                                                                const double* __restrict__ mu_blk, const double* __restrict__ m,
+                                                                const double* __restrict__ y,
+                                                                const double* __restrict__ ttau_prev,
+                                                                const double* __restrict__ tnu_prev,
+                                                                double* __restrict__ ttau_cur, double* __restrict__ tnu_cur,
+                                                                unsigned* flags, unsigned epoch0, long long timeout_ticks) {
+    extern __shared__ __attribute__((aligned(16))) double eps_lds[];
+    __shared__ int s_ok;
+    unsigned epoch = epoch0;
+    if (__hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;     // an earlier block gave up
+    for (int j0 = 0; j0 < nsite; j0 += EPT) {
+        ep_sites_lazy_body<true>(Sig, ld, np, base, j0, S, cvec, qvec, mu_blk, m, y, ttau_prev, tnu_prev, ttau_cur, tnu_cur, eps_lds);
+        if (j0 + EPT >= nsite) break;
+        // ---- grid barrier: drain this wave's stores, release, arrive, poll, acquire ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ++epoch;
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = epoch * gridDim.x;
+            const long long t0 = wall_clock64();
+            int ok = 1;
+            while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                if (wall_clock64() - t0 > timeout_ticks) {
+                    __hip_atomic_store(flags + 1, 1u + (unsigned)j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) return;
     }
 }
 
@@ -485,6 +566,8 @@ struct EpWork {
     double *S, *Sc, *cq, *prev;          // blocked sweep: factor columns, scaled copy, (c, q) vectors, (ttau, tnu) snapshot
     long* base;                          // first site of the current block (device scalar read by the captured launches)
     long* bases;                         // bases[b] = b * EPB: the launches of block b read their offset from here
+    unsigned* bar = nullptr;             // resident block kernel: [0] barrier arrivals (monotonic over the fit), [1] timeout flag
+    unsigned bar_epoch = 0;              // barriers passed so far (host-side count)
 };
 
 }  // namespace
@@ -651,6 +734,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     EP_TRY(dalloc(&w.cq, (size_t)2 * EPB * sizeof(double)));
     EP_TRY(dalloc(&w.prev, (size_t)2 * np * sizeof(double)));
     { double* b8 = nullptr; EP_TRY(dalloc(&b8, 64)); w.base = (long*)b8; }
+    { double* f8 = nullptr; EP_TRY(dalloc(&f8, 64)); w.bar = (unsigned*)f8; HIP_TRY(hipMemsetAsync(w.bar, 0, 64, st)); }
     {
         double* bb = nullptr;
         const long nb = np / EPB + 1;
@@ -705,6 +789,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemsetAsync(w.tnu_d, 0, np * sizeof(double), st));
     }
     HIP_TRY(hipFuncSetAttribute((const void*)ep_sites_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EPS_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)ep_block_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EPS_LDS_BYTES));
     stamp("K built, nlZ0");
     hipGraphExec_t block_graph = nullptr;             // one block of the blocked sweep (EPB / EPT site launches + fold)
     const double tol = 1e-4;
@@ -750,6 +835,15 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
             auto block_launches = [&](int nsite, bool do_fold, const long* base = nullptr, long fold_r0 = -1) -> int {
                 if (!base) base = w.base;
                 int j = 0;
+                const unsigned grid = (unsigned)((np + EPS_ROWS - 1) / EPS_ROWS);
+                if (c->ep_resident && !c->ep_graph && nsite == EPB && grid <= (unsigned)c->prop.multiProcessorCount) {
+                    // the whole block as ONE resident kernel (grid barrier between the EPB / EPT steps)
+                    hipLaunchKernelGGL(ep_block_resident_kernel, dim3(grid), dim3(EPS_THREADS), EPS_LDS_BYTES, st, w.Sig, np, np,
+                                       base, nsite, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
+                                       w.tnu_d, w.bar, w.bar_epoch, (long long)200000000);      // 2 s of 100 MHz ticks
+                    w.bar_epoch += (unsigned)(nsite / EPT - 1);
+                    j = nsite;
+                }
                 for (; j + EPT <= nsite; j += EPT)
                     hipLaunchKernelGGL(ep_sites_lazy_kernel, dim3((unsigned)((np + EPS_ROWS - 1) / EPS_ROWS)), dim3(EPS_THREADS), EPS_LDS_BYTES, st, w.Sig, np, np,
                                        base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
@@ -792,7 +886,16 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         }
         HIP_TRY(hipMemcpyAsync(ttau.data(), w.ttau_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        unsigned bar_h[2] = {0, 0};
+        if (w.bar_epoch) HIP_TRY(hipMemcpyAsync(bar_h, w.bar, sizeof(bar_h), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (bar_h[1] != 0) {                                 // a grid barrier of the resident block kernel gave up
+            char msg[128];
+            snprintf(msg, sizeof(msg), "EP resident block kernel: grid barrier timed out (code %u)", bar_h[1]);
+            pgp_set_last_hip_error(hipErrorLaunchTimeOut, msg, __FILE__, __LINE__);
+            if (block_graph) (void)hipGraphExecDestroy(block_graph);
+            return PGP_ERR_HIP;
+        }
         stamp("sweep done (synced)");
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // inf.py:772
         stamp("params recomputed");
