@@ -57,7 +57,8 @@ def _worker(rank, world, port, backend, n, w, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,backend,n,w", [(1, "nccl", 2048, 512), (2, "gloo", 2048, 512), (2, "gloo", 1900, 256)])
+@pytest.mark.parametrize("world,backend,n,w", [(1, "nccl", 2048, 512), (2, "gloo", 2048, 512), (2, "gloo", 1900, 256),
+                                                (3, "gloo", 2300, 256)])
 def test_block_cyclic_cholesky_on_device(tmp_path, world, backend, n, w):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), backend, n, w, str(tmp_path)), nprocs=world, join=True)
