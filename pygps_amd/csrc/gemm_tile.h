@@ -14,10 +14,21 @@ constexpr int BK = 16;
 // the (wave-uniform) LDS byte address in M0 -- no staging VGPRs, no ds_write.  Issued through asm so that hipcc does not
 // serialise it against the LDS reads of the other buffer (it cannot prove the two stages disjoint); completion is the
 // issuing wave's vmcnt, visibility to the other waves the barrier that follows (cdna guide, LDS-DMA).
-__device__ __forceinline__ void lds_dma_1k(const double* gptr, unsigned lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(gptr), "s"(lds_byte_addr) : "memory");
+// Everything wave-uniform is kept OUT of the vector ALU: the source row is a 64-bit SGPR base (saddr form) plus
+// one loop-invariant per-lane byte offset, the LDS address is an SGPR base plus a compile-time constant.  A stage of the k-loop
+// then issues its eight pieces with scalar instructions only -- VALU instructions of one wave compete with the MFMA issue of
+// the other wave on the same SIMD (measured: the k-loop with loop-invariant addresses runs 8 % faster).
+template <int LDS_OFF>
+__device__ __forceinline__ void lds_dma_1k_s(unsigned voff, const double* sbase, unsigned lds_wave_base) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_wave_base), "n"(LDS_OFF) : "memory", "scc");   // s_add_u32 writes SCC
 }
+__device__ __forceinline__ const double* uniform_ptr(const double* p) {
+    const unsigned long a = (unsigned long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (const double*)(((unsigned long)hi << 32) | lo);
+}
+template <int V> struct IC { static constexpr int value = V; };
 
 // value of the neighbouring lane (l ^ 1): DPP quad_perm [1,0,3,2] on both halves
 __device__ __forceinline__ double swap_adjacent(double v) {
@@ -130,25 +141,34 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         bstep = BK;
     }
     // LDS-DMA variant: wave w stages k-rows w, w+4, w+8, w+12 of both operands (one 1 KiB piece = one k-row of 128 doubles)
-    const double* da[4];
+    const double* da[4];                           // wave-uniform (SGPR) row bases: k-row wave + 4 p of this stage, column i0 / j0
     const double* db[4];
-    if constexpr (DMA) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            da[p] = A + (long)(i0 + 2 * lane) + (long)(k0 + wave + 4 * p) * lda;
-            db[p] = B + (long)(j0 + 2 * lane) + (long)(k0 + wave + 4 * p) * g.ldb;
-        }
-    }
+    unsigned lds_w = 0;                            // LDS byte address of k-row `wave` of stage buffer 0 (wave-uniform)
+    const unsigned dvoff = (unsigned)lane * 16u;   // this lane's 16 bytes inside the 1 KiB row piece
     const unsigned smem_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem;
-    auto dma_stage = [&](int buf) {
-        const unsigned sa_b = smem_lds + (unsigned)(buf * STAGE) * 8u, sb_b = sa_b + (unsigned)ASZ * 8u;
+    if constexpr (DMA) {
+        static_assert(SA == SB, "one LDS row stride for both operands");
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const unsigned kr = (unsigned)(wave + 4 * p);
-            lds_dma_1k(da[p], __builtin_amdgcn_readfirstlane(sa_b + kr * (unsigned)(SA * 8)));
-            lds_dma_1k(db[p], __builtin_amdgcn_readfirstlane(sb_b + kr * (unsigned)(SB * 8)));
-            da[p] += (long)BK * lda;
-            db[p] += (long)BK * g.ldb;
+            da[p] = uniform_ptr(A + (long)i0 + (long)(k0 + wave + 4 * p) * lda);
+            db[p] = uniform_ptr(B + (long)j0 + (long)(k0 + wave + 4 * p) * g.ldb);
+        }
+        lds_w = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)wave * (unsigned)(SA * 8));
+    }
+    const long dstep_a = (long)BK * lda, dstep_b = (long)BK * g.ldb;
+    auto dma_stage = [&](auto bufc) {
+        constexpr int O = decltype(bufc)::value * STAGE * 8;
+        if constexpr (DMA) {
+            lds_dma_1k_s<O + 0 * SA * 8>(dvoff, da[0], lds_w);
+            lds_dma_1k_s<O + ASZ * 8 + 0 * SB * 8>(dvoff, db[0], lds_w);
+            lds_dma_1k_s<O + 4 * SA * 8>(dvoff, da[1], lds_w);
+            lds_dma_1k_s<O + ASZ * 8 + 4 * SB * 8>(dvoff, db[1], lds_w);
+            lds_dma_1k_s<O + 8 * SA * 8>(dvoff, da[2], lds_w);
+            lds_dma_1k_s<O + ASZ * 8 + 8 * SB * 8>(dvoff, db[2], lds_w);
+            lds_dma_1k_s<O + 12 * SA * 8>(dvoff, da[3], lds_w);
+            lds_dma_1k_s<O + ASZ * 8 + 12 * SB * 8>(dvoff, db[3], lds_w);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { da[p] += dstep_a; db[p] += dstep_b; }
         }
     };
     auto gload = [&](int) {
@@ -194,7 +214,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
 
     if (k0 < k1) {
         if constexpr (DMA) {
-            dma_stage(0);
+            dma_stage(IC<0>{});
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             gload(k0);
@@ -205,7 +225,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             GT_STAMP(1);
         }
-        int buf = 0;
         // fragments are double-buffered in registers: the LDS reads of k-substep ks+1 are issued BEFORE the 16 MFMAs of
         // substep ks, so their latency hides behind 1024 cycles of matrix work.  The same holds ACROSS the stage barrier:
         // the last substep's MFMAs of a stage are held back until after the barrier and issued behind the first fragment
@@ -236,9 +255,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         };
         constexpr int NS = BK / 4;                // k-substeps per stage
         ldfrag(0, 0, 0);
-        auto kstep = [&](int kt) {
+        // the stage buffer is a COMPILE-TIME constant of a k-step (the loop below alternates two instantiations): every LDS
+        // address of the step is then the loop-invariant per-lane base plus an immediate, no address arithmetic in the loop
+        auto kstep = [&](int kt, auto bufc) {
+            constexpr int buf = decltype(bufc)::value;
             const bool more = kt + BK < k1;
-            if constexpr (DMA) { if (more) dma_stage(buf ^ 1); }     // the other stage was last read before the previous barrier
+            if constexpr (DMA) { if (more) dma_stage(IC<(buf ^ 1)>{}); }     // the other stage was last read before the previous barrier
             else if (more && !(xdbg & 1)) gload(kt + BK);
 #pragma unroll
             for (int ks = 0; ks + 1 < NS; ++ks) {
@@ -248,8 +270,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             if constexpr (DMA) { if (!(xdbg & 1024)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // dbg 1024: timing experiment (wrong results)
             else if (more && !(xdbg & 1)) sstore(buf ^ 1);
             if (!(xdbg & 2)) __syncthreads();
-            if (!(xdbg & 1)) buf ^= 1;
-            if (more) ldfrag(buf, 0, NS & 1);     // first fragments of the next stage, behind ...
+            if (more) ldfrag(buf ^ 1, 0, NS & 1); // first fragments of the next stage, behind ...
             __builtin_amdgcn_sched_barrier(0);    // (keep the reads AHEAD of the MFMAs: the scheduler sinks them behind otherwise)
             mfmas((NS - 1) & 1);                  // ... the held-back last substep of this one
         };
@@ -273,12 +294,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
 #pragma unroll
                             for (int r = 0; r < 4; ++r) acc[2 * hf + q][in][r] = fma(ab, creg[q][r], acc[2 * hf + q][in][r]);
                     }
-                    kstep(kt);
+                    if (st & 1) kstep(kt, IC<1>{}); else kstep(kt, IC<0>{});     // st is an unrolled constant
                     kt += BK;
                 }
             }
         }
-        for (; kt < k1; kt += BK) kstep(kt);
+        while (kt < k1) {                         // FN * FM is even: the stage parity is 0 here on both paths
+            kstep(kt, IC<0>{});
+            kt += BK;
+            if (kt >= k1) break;
+            kstep(kt, IC<1>{});
+            kt += BK;
+        }
     }
 
     GT_STAMP(2);
