@@ -48,7 +48,7 @@ struct pgp_ctx {
     hipEvent_t eet_join = nullptr;      // non-null: the sweep queued every panel product; the fit joins st_fill on this event
     int eet_tail = 1;                   // the last eet_tail panels go into ONE final product (longer K, after the sweep)
     int eet_tile = 128;                 // tile size of the filler products (64: shorter workgroups in the way of the chain)
-    int eet_first = -1;                 // inline filler: panels 0 .. eet_first are folded into one product (-1: a quarter of the panels)
+    int eet_first = -1;                 // inline filler: panels 0 .. eet_first are folded into one product (-1: a sixth of the panels)
     int eet_merge = 0;                  // inline filler: 1 = same grid as TU_b (gemm_f64_dual_kernel), 0 = its own launch behind it
     int eet_overlap = 3;                // B^-1 = sum_p E_p E_p^T accumulated under the sweep: 0 off (one product after it), 1 on a
                                         // low-priority filler stream, 2 inline on the main stream, 3 inline when npanel <= eet_max_panels
