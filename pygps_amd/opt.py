@@ -142,9 +142,9 @@ class Minimize(Optimizer):
 class ShardedMinimize(Minimize):
     """The restart loop of ``Minimize`` sharded over the GPUs of one node, restart r -> rank r % world.
 
-    Requires ``num_restarts`` (the threshold rule alone is inherently sequential).  With
-    ``min_threshold`` also set, the lowest-index restart that reaches it wins, which is what the
-    sequential loop would have returned.  Without an initialised process group (or world size 1) it
+    With ``num_restarts`` the whole table is drawn up front and sharded; with ``min_threshold`` also set, the
+    lowest-index restart that reaches it wins, which is what the sequential loop would have returned.  With
+    ``min_threshold`` alone the search runs in waves of world x streams_per_gpu restarts (_find_by_threshold).  Without an initialised process group (or world size 1) it
     degenerates to running all restarts locally from the same pre-drawn table, so results do not
     depend on the number of GPUs.
     """
@@ -160,6 +160,22 @@ class ShardedMinimize(Minimize):
         self.runs = None                # per-restart records of the last findMin (all ranks)
         if streams_per_gpu is not None:
             self.streams_per_gpu = int(streams_per_gpu)
+
+    @staticmethod
+    def _cold_start(model):
+        """A restart must not depend on which restart ran before it on the same model object: inference methods that
+        keep warm-start state between evaluations (EP: last_ttau / last_tnu, Core/inf.py:735-741) begin every restart
+        cold.  The sequential reference carries that state from one restart into the next; a sharded search cannot
+        (the predecessor runs on another GPU), so it defines the per-restart result as the cold-started one -- the same
+        on every world size, fit-stream count and timing."""
+        inf = getattr(model, "inffunc", None)
+        for name in ("last_ttau", "last_tnu"):
+            if hasattr(inf, name):
+                setattr(inf, name, None)
+
+    def _one(self, hyp0, numIters):
+        self._cold_start(self.model)
+        return super(ShardedMinimize, self)._one(hyp0, numIters)
 
     def _run_share(self, mine, table, numIters):
         """Optimise the restarts `mine` (indices into table); returns {t: _Run}.  With more than one fit stream
@@ -182,15 +198,61 @@ class ShardedMinimize(Minimize):
                 clone.model.optimizer = clone
                 clone.logger = self.logger
                 while True:                       # restarts are taken from a shared queue: line searches differ in length, a
-                    with lock:                    # static deal can leave one stream idle at the end (results do not depend on it)
-                        if not todo:
+                    with lock:                    # static deal can leave one stream idle at the end.  Results do not depend
+                        if not todo:              # on the deal: every restart starts cold (_cold_start)
                             return
                         t = todo.pop(0)
+                    self._cold_start(clone.model)
                     out[t] = clone._one(table[t].copy(), numIters)
         ths = [threading.Thread(target=work, args=(k,)) for k in range(S)]
         [th.start() for th in ths]
         [th.join() for th in ths]
         return out
+
+    #: threshold-only search (Core/opt.py:322-327 with num_restarts unset): give up after this many waves
+    max_waves = 64
+
+    def _find_by_threshold(self, x, y, numIters):
+        """``min_threshold`` alone (Core/opt.py:301-327 without num_restarts): the reference keeps drawing restarts until
+        the incumbent is at or below the threshold.  Here the restarts run in WAVES of world x streams_per_gpu, each wave
+        one sharded search (same draw order: restart-major, hyp-minor, continuing the global numpy stream on rank 0);
+        the reference's sequential bookkeeping is replayed over the concatenated runs, so the optimum returned is the one
+        the sequential loop would have stopped at -- only the restarts after it inside the last wave are extra work."""
+        cfg = self.searchConfig
+        dist = self._dist()
+        world = dist.get_world_size(self.group) if dist else 1
+        wave = max(2, world * max(1, int(self.streams_per_gpu)))
+        runs_all, tables = [], []
+        hyp_keep = self._convert_to_array()
+        saved = (cfg.num_restarts, cfg.min_threshold)
+        try:
+            for w in range(self.max_waves):
+                cfg.num_restarts, cfg.min_threshold = wave, None
+                self._apply_in_objects(hyp_keep)                # the minimiser leaves the model at its last evaluation
+                self._wave_cont = w > 0                         # only the first wave starts with the model's own hypers
+                self.runs = None
+                try:
+                    ShardedMinimize.findMin(self, x, y, numIters)
+                except Exception:
+                    if self.runs is None:
+                        raise
+                    # "over half failed" inside one wave: the replay below decides, like the sequential bookkeeping
+                finally:
+                    self._wave_cont = False
+                tables.append(self.init_table)
+                runs_all.extend(self.runs)
+                inc = None
+                for k, r in enumerate(runs_all):                # Core/opt.py:289-327 in restart order
+                    if k == 0:
+                        inc = r if r.ok else None
+                    elif r.ok and inc is not None and r.f < inc.f:
+                        inc = r
+                    if k >= 1 and inc is not None and inc.f <= saved[1]:
+                        self.runs, self.init_table = runs_all[:k + 1], np.concatenate(tables)[:k + 1]
+                        return inc.hyp, inc.f
+            raise Exception("ShardedMinimize: min_threshold %g not reached in %d restarts" % (saved[1], len(runs_all)))
+        finally:
+            cfg.num_restarts, cfg.min_threshold = saved
 
     @staticmethod
     def _dist():
@@ -205,8 +267,10 @@ class ShardedMinimize(Minimize):
     def findMin(self, x, y, numIters=200):
         import torch
         cfg = self.searchConfig
-        if not cfg or not cfg.num_restarts:
-            raise Exception("ShardedMinimize needs searchConfig.num_restarts")
+        if not cfg or not (cfg.num_restarts or cfg.min_threshold):
+            raise Exception("Specify at least one of the stop conditions")       # Core/opt.py:303-304
+        if not cfg.num_restarts:
+            return self._find_by_threshold(x, y, numIters)
         dist = self._dist()
         rank = dist.get_rank(self.group) if dist else 0
         world = dist.get_world_size(self.group) if dist else 1
@@ -219,8 +283,9 @@ class ShardedMinimize(Minimize):
         # rank 0 draws the table in the reference's order: restart-major, hyp-minor (Core/opt.py:307-308)
         table = np.empty((R, nh))
         table[0] = hyp0
+        cont = bool(getattr(self, "_wave_cont", False))       # a later wave of a threshold-only search: every row is drawn
         if rank == 0:
-            for t in range(1, R):
+            for t in range(0 if cont else 1, R):
                 for i in range(nh):
                     table[t, i] = np.random.uniform(low=ranges[i][0], high=ranges[i][1])
         # the collectives run whenever a process group exists, world size 1 included: the RCCL path of a one-GPU job is

@@ -204,6 +204,46 @@ def g7(N):
          ref_seconds=dt, **dn(dnlZ))
 
 
+# ----------------------------------------------------------------------------- G16 / G17 (round 3: pins for the verdict's holes)
+def g16(N=2048):
+    """Matern d in {1,3,5,7} fits at N = 2048, d_in = 16 with the reference's own gradients (Core/cov.py:1124-1182; the
+    derivative quirk of :1173-1177 included -- the device path reproduces it with reference_compat=True)."""
+    x, y = synth_reg(N, 16)
+    for md in (1, 3, 5, 7):
+        m = pyGPs.GPR()
+        m.setPrior(kernel=pyGPs.cov.Matern(np.log(np.sqrt(16.0)), md, 0.0))
+        m.setNoise(np.log(0.1))
+        m.setData(x, y)
+        nlZ, dnlZ, post = m.getPosterior()
+        xs = np.random.RandomState(11).randn(64, 16)
+        ym, ys2, fm, fs2, lp = m.predict(xs)
+        aidx = np.arange(0, N, 37)
+        lflat = np.arange(0, N * N, 257 * 31 + 1)
+        save("G16_matern%d_N%d" % (md, N), N=N, d=16, seed=0, para=np.array([md]), nlZ=nlZ,
+             mean_hyp=np.array(m.meanfunc.hyp), cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp),
+             alpha_idx=aidx, alpha_sample=post.alpha[aidx, 0], L_flat_idx=lflat, L_sample=post.L.ravel()[lflat],
+             L_diag=np.diag(post.L).copy(), pred_xs=xs, pred_ym=ym, pred_ys2=ys2, pred_fm=fm, pred_fs2=fs2, **dn(dnlZ))
+
+
+def g17(N=8192, ns=16384):
+    """GP.predict at the bench scale (Core/gp.py:349-437): the cfg-2 posterior (G6 recipe, N = 8192, d = 16) and 16384
+    test points in ONE call -- the reference walks them in batches of 1000, re-factorising L by LU in every batch."""
+    d = 16
+    x, y = synth_reg(N, d)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+    m.setNoise(np.log(0.1))
+    m.setData(x, y)
+    m.getPosterior()
+    rng = np.random.RandomState(7)
+    xs = rng.randn(ns, d)
+    xs[: ns // 4] = x[rng.randint(0, N, ns // 4)] + 0.05 * rng.randn(ns // 4, d)     # a quarter close to training points
+    t = time.time()
+    ym, ys2, fm, fs2, lp = m.predict(xs)
+    save("G17_predict_N%d_ns%d" % (N, ns), N=N, d=d, seed=0, xs_seed=7, ns=ns, pred_ym=ym, pred_ys2=ys2, pred_fm=fm,
+         pred_fs2=fs2, ref_seconds=time.time() - t)
+
+
 # ----------------------------------------------------------------------------- G8 (cfg 5, EP)
 def g8():
     data = np.load("/root/reference/pyGPs/Demo/Classification/classification_data.npz")
@@ -574,7 +614,7 @@ def g15():
 
 
 CASES = {
-    "g15": g15, "g14": g14, "g13": g13, "g12": g12, "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
+    "g16": g16, "g17": g17, "g15": g15, "g14": g14, "g13": g13, "g12": g12, "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
     "g8ii_2048": lambda: g8ii(2048), "g8ii_4096": lambda: g8ii(4096), "g9_2048": lambda: g9(2048),
     "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384),

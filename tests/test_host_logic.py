@@ -103,6 +103,57 @@ def test_minimize_restarts_rng_order_and_selection():
     assert table.shape == (5, 4)
 
 
+def test_sharded_minimize_threshold_only_equals_the_sequential_loop():
+    """min_threshold without num_restarts (Core/opt.py:322-327): the sharded optimiser runs waves of restarts and must
+    return the optimum the sequential loop stops at, from the same RNG stream."""
+    from pygps_amd import opt
+    for thr in (40.0, 8.0, 3.2):
+        m1 = _FakeModel()
+        c1 = _conf(m1, None)
+        c1.min_threshold = thr
+        o1 = opt.Minimize(m1, c1)
+        np.random.seed(11)
+        h1, f1 = o1.findMin(m1.x, m1.y, numIters=15)
+        assert f1 <= thr
+        for streams in (1, 2, 3):
+            m2 = _FakeModel()
+            c2 = _conf(m2, None)
+            c2.min_threshold = thr
+            o2 = opt.ShardedMinimize(m2, c2, streams_per_gpu=streams)
+            np.random.seed(11)
+            h2, f2 = o2.findMin(m2.x, m2.y, numIters=15)
+            assert f2 == f1 and np.array_equal(h1, h2), (thr, streams)
+            assert len(o2.runs) == o1.trailsCounter and o2.init_table.shape == (o1.trailsCounter, 4)
+            assert c2.num_restarts is None and c2.min_threshold == thr           # the configuration is left as it was
+    m = _FakeModel()
+    with pytest.raises(Exception, match="at least one of the stop conditions"):
+        opt.ShardedMinimize(m, _conf(m, None)).findMin(m.x, m.y, numIters=5)
+
+
+def test_sharded_minimize_restarts_start_cold():
+    """A restart's result must not depend on which restart ran before it on the same model object: warm-start
+    state of the inference method is dropped at the beginning of every restart."""
+    from pygps_amd import opt
+
+    class _Inf(object):
+        last_ttau = "warm"
+        last_tnu = "warm"
+    m = _FakeModel()
+    m.inffunc = _Inf()
+    seen = []
+    orig = m.getPosterior
+
+    def spy(der=True):
+        seen.append(m.inffunc.last_ttau)
+        m.inffunc.last_ttau = m.inffunc.last_tnu = "warm"                        # what EP.evaluate leaves behind
+        return orig(der)
+    m.getPosterior = spy
+    o = opt.ShardedMinimize(m, _conf(m, 3), streams_per_gpu=1)
+    np.random.seed(3)
+    o.findMin(m.x, m.y, numIters=4)
+    assert seen.count(None) == 3 and seen[0] is None                              # one cold start per restart
+
+
 def test_minimize_failure_accounting():
     from pygps_amd import opt
     m = _FakeModel()

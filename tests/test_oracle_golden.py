@@ -265,3 +265,45 @@ def test_G15_composites_with_two_ard_leaves():
     g = golden("G15_ep_ard_times_ard_N200")
     out = O.ep_fit(trees["ep_ard_times_ard"], g["cov_hyp"], 0, g["x"], g["y"], np.zeros_like(g["y"]))
     assert relerr(out["nlZ"], g["nlZ"]) < 1e-9 and relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-7
+
+
+@pytest.mark.parametrize("md", [1, 3, 5, 7])
+def test_G16_matern_fits_with_the_reference_gradient_N2048(md):
+    """Round 3: Matern at N = 2048 with the reference's own gradient (the quirk of Core/cov.py:1173-1177 included) and
+    64 predictions; pins the oracle's Matern path beyond the value-only G4b."""
+    g = golden("G16_matern%d_N2048" % md)
+    x, y = synth_reg(2048, 16)
+    c = g["mean_hyp"][0]
+    out = O.exact_fit(O.MATERN, g["cov_hyp"], md, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y),
+                      faithful=False, matern_reference_compat=True)
+    assert relerr(out["nlZ"], g["nlZ"]) < 1e-11
+    assert relerr(out["alpha"][g["alpha_idx"], 0], g["alpha_sample"]) < 1e-8
+    assert relerr(np.diag(out["L"]), g["L_diag"]) < 1e-11
+    assert relerr(out["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-10
+    for k in ("dnlZ_cov", "dnlZ_lik", "dnlZ_mean"):
+        assert relerr(out[k], g[k]) < 1e-8, k
+    xs = g["pred_xs"]
+    ym, ys2, fm, fs2 = O.predict(O.MATERN, g["cov_hyp"], md, g["lik_hyp"][0], x, out["alpha"], out["L"], out["sW"], xs,
+                                 c * np.ones((xs.shape[0], 1)))
+    assert relerr(fm, g["pred_fm"]) < 1e-9 and relerr(fs2, g["pred_fs2"]) < 1e-8
+    assert relerr(ym, g["pred_ym"]) < 1e-9 and relerr(ys2, g["pred_ys2"]) < 1e-8
+
+
+def test_G17_predict_at_bench_scale_first_batch():
+    """The reference's GP.predict on the N = 8192 posterior: the oracle (own fit, general-LU solve like gp.py:415 and the
+    triangular form the GPU tests use) on the first 500 of the 16384 recorded points."""
+    g = golden("G17_predict_N8192_ns16384")
+    N, d, ns = 8192, 16, 16384
+    x, y = synth_reg(N, d)
+    rng = np.random.RandomState(7)
+    xs = rng.randn(ns, d)
+    xs[: ns // 4] = x[rng.randint(0, N, ns // 4)] + 0.05 * rng.randn(ns // 4, d)
+    xs = xs[:500]
+    hyp = np.array([np.log(np.sqrt(d)), 0.0])
+    c = float(y.mean())
+    out = O.exact_fit(O.RBF, hyp, 0, np.log(0.1), x, y, c * np.ones_like(y), None, nargout=1, faithful=False)
+    for faithful in (True, False):
+        ym, ys2, fm, fs2 = O.predict(O.RBF, hyp, 0, np.log(0.1), x, out["alpha"], out["L"], out["sW"], xs,
+                                     c * np.ones((500, 1)), faithful=faithful)
+        assert relerr(fm, g["pred_fm"][:500]) < 1e-9 and relerr(fs2, g["pred_fs2"][:500]) < 1e-8
+        assert relerr(ys2, g["pred_ys2"][:500]) < 1e-8

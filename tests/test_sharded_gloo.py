@@ -67,3 +67,22 @@ def test_sharded_minimize_two_ranks_equals_sequential(tmp_path, R, streams):
     if streams == 1:
         assert int(r0["calls"]) + int(r1["calls"]) == m.calls
         assert 0 < int(r1["calls"]) < m.calls
+
+
+def test_sharded_minimize_world_8_one_restart_per_rank(tmp_path):
+    """BASELINE configs[3] as written: 8 restarts, 8 ranks, restart r on rank r (t % world with world == R)."""
+    from test_host_logic import _FakeModel, _conf
+    from pygps_amd import opt
+    R = 8
+    m = _FakeModel()
+    o = opt.Minimize(m, _conf(m, R))
+    np.random.seed(7)
+    h_seq, f_seq = o.findMin(m.x, m.y, numIters=15)
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, R, str(tmp_path), 1), nprocs=8, join=True)
+    rs = [np.load(tmp_path / ("r%d.npz" % k)) for k in range(8)]
+    for r in rs:
+        assert float(r["f"]) == f_seq and np.array_equal(r["h"], h_seq)
+        assert np.array_equal(r["runs_f"], rs[0]["runs_f"]) and len(r["runs_f"]) == R
+        assert np.array_equal(r["x"], np.arange(4.0).reshape(4, 1))
+    assert sum(int(r["calls"]) for r in rs) == m.calls and all(int(r["calls"]) > 0 for r in rs)
