@@ -34,6 +34,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("PYGPS_AMD_TORCH_FIRST", "1")   # this process runs torch.distributed beside the library (pygps_amd/_lib.py)
 
 PEAK_FP64_MFMA_TF = 78.6      # MI355X fp64 matrix peak: 128 flop/clk/CU x 256 CU x 2.4 GHz (measured issue rate 77.6)
 PEAK_HBM_GBS = 8000.0

@@ -158,22 +158,6 @@ int pgp_profile_reset(pgp_ctx* ctx);
 /* tuning knobs (outer panel width of the blocked Cholesky, look-ahead on/off ...) */
 int pgp_set_option(pgp_ctx* ctx, const char* name, int value);
 
-/* ---- self-test hooks (used by tests/ only) ----------------------------------------------------
- * Column-major GEMM on host buffers through the fp64 MFMA kernel.                                */
-int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_diag, int kmode, int koff,
-                  double alpha, double beta, const double* A, int64_t lda, const double* B, int64_t ldb,
-                  double* C, int64_t ldc, int M, int N, int K, int iters, double* ms_out);
-int pgp_test_probit_hazard(pgp_ctx* ctx, const double* z, double* out, int n);
-int pgp_test_gemm_dual(pgp_ctx* ctx, const double* A1, int64_t lda1, double* C1, int64_t ldc1, int M1, int K1,
-                       const double* A2, int64_t lda2, double* C2, int64_t ldc2, int M2, int K2, int koff2, int zero_from2);
-int pgp_test_valu_peak(pgp_ctx* ctx, int iters, int waves_per_simd, double* out2);
-int pgp_test_mfma_peak(pgp_ctx* ctx, int iters, double* tflops_out);
-int pgp_test_mfma_cycles(pgp_ctx* ctx, int iters, int nacc, int waves_per_simd, double* out3);
-int pgp_test_leaf_ticks(pgp_ctx* ctx, double* ticks_out /* 24 */);
-int pgp_test_ds_ticks(pgp_ctx* ctx, double* ticks_out /* 16 * npanel */, int npanel);
-int pgp_test_overlap(pgp_ctx* ctx, double* out4);
-int pgp_test_assemble(pgp_ctx* ctx, int kind, int mode, int64_t n, int64_t d, int iters, double* ms_out);
-
 #ifdef __cplusplus
 }
 #endif

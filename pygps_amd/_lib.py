@@ -61,21 +61,23 @@ SIGNATURES = {
     "pgp_profile_read": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), _dp, _dp, _dp]),
     "pgp_profile_reset": (C.c_int, [_vp]),
     "pgp_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
-    "pgp_test_gemm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
-                                C.c_double, _dp, _i64, _dp, _i64, _dp, _i64, C.c_int, C.c_int, C.c_int, C.c_int,
-                                _dp]),
     "pgp_dev_panel_factor": (C.c_int, [_vp, C.c_void_p, _i64, _i64, C.c_int]),
     "pgp_dev_panel_update": (C.c_int, [_vp, C.c_void_p, _i64, _i64, C.c_int, C.c_void_p, _i64, C.c_int]),
     "pgp_dev_sync": (C.c_int, [_vp]),
+}
+
+# self-test / calibration hooks (csrc/testhooks.h): exported by the library, NOT part of the drop-in boundary
+TEST_SIGNATURES = {
+    "pgp_test_gemm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                C.c_double, _dp, _i64, _dp, _i64, _dp, _i64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                _dp]),
+    "pgp_test_gemm_shrink": (C.c_int, [_vp, _dp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _i64,
+                                       _i64]),
     "pgp_test_probit_hazard": (C.c_int, [_vp, _dp, _dp, C.c_int]),
-    "pgp_test_gemm_dual": (C.c_int, [_vp, _dp, _i64, _dp, _i64, C.c_int, C.c_int, _dp, _i64, _dp, _i64, C.c_int, C.c_int,
-                                     C.c_int, C.c_int]),
     "pgp_test_valu_peak": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "pgp_test_mfma_peak": (C.c_int, [_vp, C.c_int, _dp]),
     "pgp_test_mfma_cycles": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "pgp_test_leaf_ticks": (C.c_int, [_vp, _dp]),
-    "pgp_test_ds_ticks": (C.c_int, [_vp, _dp, C.c_int]),
-    "pgp_test_overlap": (C.c_int, [_vp, _dp]),
     "pgp_test_assemble": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _i64, C.c_int, _dp]),
 }
 
@@ -89,15 +91,43 @@ def _torch_first():
     copy is loaded first serves the whole process.  Measured on the round-2 GPU boxes: with THIS library loaded first
     (runtime from /opt/rocm) and torch imported afterwards, one of the two then fails to see the GPU ("No HIP GPUs are
     available" / "no ROCm-capable device is detected", node dependent); with torch imported first both run on torch's
-    copy and every order of initialisation works.  ShardedMinimize and bench.py use torch.distributed (RCCL) beside the
-    library, so torch is imported before the dlopen when it is installed (PYGPS_AMD_NO_TORCH=1 skips this; torch is
-    never needed for a fit)."""
+    copy and every order of initialisation works.  So torch goes first -- but only in processes that use it: when it is
+    already imported, or when PYGPS_AMD_TORCH_FIRST=1 asks for it (tests/conftest.py and bench.py do; ShardedMinimize /
+    the sharded fit import torch at module level, before the first context exists).  A plain single-GPU fit never pays
+    the multi-second torch import nor swaps the HIP runtime it was built against."""
+    import sys
     if os.environ.get("PYGPS_AMD_NO_TORCH"):
         return
+    if "torch" in sys.modules or os.environ.get("PYGPS_AMD_TORCH_FIRST") == "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+
+
+def want_torch():
+    """Called by the parts of the package that need torch.distributed (ShardedMinimize, the sharded fit): import torch,
+    before the library if that is still possible; if the library came first, say which HIP runtime serves the process."""
+    import sys
+    if "torch" not in sys.modules and _dll is not None:
+        import logging
+        logging.getLogger(__name__).warning(
+            "pygps_amd: torch is imported AFTER libpygps_amd.so (HIP runtime in use: %s); on some nodes one of the two then "
+            "sees no GPU -- import torch first or set PYGPS_AMD_TORCH_FIRST=1", hip_runtime_path())
+    import torch
+    return torch
+
+
+def hip_runtime_path():
+    """Which libamdhip64 this process ended up with (diagnostics: /opt/rocm's or the torch wheel's copy)."""
     try:
-        import torch  # noqa: F401
-    except Exception:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    return line.split()[-1]
+    except OSError:
         pass
+    return None
 
 
 def load():
@@ -113,10 +143,11 @@ def load():
                     "pygps_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
             dll = C.CDLL(LIB_PATH)
-            for name, (res, args) in SIGNATURES.items():
-                fn = getattr(dll, name)          # AttributeError if the .so lacks a declared symbol
-                fn.restype = res
-                fn.argtypes = args
+            for table in (SIGNATURES, TEST_SIGNATURES):
+                for name, (res, args) in table.items():
+                    fn = getattr(dll, name)      # AttributeError if the .so lacks a declared symbol
+                    fn.restype = res
+                    fn.argtypes = args
             _dll = dll
     return _dll
 

@@ -53,6 +53,7 @@ const char* pgp_strerror(int status) {
 }
 
 __global__ void pgp_noop_kernel() {}
+static int alloc_result_buffer(pgp_ctx* c, long np);
 
 int pgp_init(int device, pgp_ctx** ctx_out) {
     if (!ctx_out) return -2;
@@ -84,20 +85,30 @@ int pgp_init(int device, pgp_ctx** ctx_out) {
     memset(c->last_ms, 0, sizeof(c->last_ms));
     memset(c->pc_ms, 0, sizeof(c->pc_ms)); memset(c->pc_flops, 0, sizeof(c->pc_flops));
     memset(c->pc_bytes, 0, sizeof(c->pc_bytes)); memset(c->pc_launch, 0, sizeof(c->pc_launch));
-    HIP_TRY(hipMalloc((void**)&c->scal, 256 * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->info_dev, sizeof(int)));
+    CHK(alloc_result_buffer(c, 0));
     HIP_TRY(hipMalloc((void**)&c->Dk, (size_t)2048 * 1024 * sizeof(double)));       // 2w x w, w <= 1024
     HIP_TRY(hipMalloc((void**)&c->dpack, (size_t)8 * PACK_DOUBLES * sizeof(double)));
     HIP_TRY(hipMemset(c->Dk, 0, (size_t)2048 * 1024 * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->Dt, (size_t)1024 * 1024 * sizeof(double)));
-    HIP_TRY(hipMemset(c->Dt, 0, (size_t)1024 * 1024 * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->Yn, (size_t)512 * 512 * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->dflags, diag_server_flag_bytes()));
-    HIP_TRY(hipMemset(c->dflags, 0, diag_server_flag_bytes()));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_ds, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_ds2, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void**)&c->dflags, diag_panel_flag_bytes()));
+    HIP_TRY(hipMemset(c->dflags, 0, diag_panel_flag_bytes()));
     ctx_register(c);
     *ctx_out = c;
+    return PGP_OK;
+}
+
+// One device buffer for everything a fit returns: [scalars (RES_HEAD doubles: log det, z'z, ... gradient sums from
+// slot 8; the pivot status word in slot RES_INFO) | alpha (np)], fetched with ONE copy into pinned host memory.
+constexpr long RES_HEAD = 272, RES_INFO = 264;
+static int alloc_result_buffer(pgp_ctx* c, long np) {
+    const size_t bytes = (size_t)(RES_HEAD + np) * sizeof(double);
+    if (c->res_dev) (void)hipFree(c->res_dev);
+    if (c->res_host) (void)hipHostFree(c->res_host);
+    c->res_dev = c->res_host = nullptr; c->scal = c->alpha_dev = nullptr; c->info_dev = nullptr; c->res_cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->res_dev, bytes));
+    HIP_TRY(hipMemset(c->res_dev, 0, bytes));
+    HIP_TRY(hipHostMalloc((void**)&c->res_host, bytes, hipHostMallocDefault));
+    c->scal = c->res_dev; c->info_dev = (int*)(c->res_dev + RES_INFO); c->alpha_dev = c->res_dev + RES_HEAD;
+    c->res_cap = bytes;
     return PGP_OK;
 }
 
@@ -105,19 +116,24 @@ void pgp_destroy(pgp_ctx* c) {
     if (!c) return;
     ctx_unregister(c);
     (void)hipSetDevice(c->device);
+    // every stream of the context may still carry work of the last call (the panel stream runs the last E E^T product)
     (void)hipStreamSynchronize(c->st);
+    if (c->st2) (void)hipStreamSynchronize(c->st2);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     for (auto& kv : c->spool) (void)hipFree(kv.second);
     for (auto& kv : c->orders) (void)hipFree(kv.second.first);
-    void* bufs[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev, c->W, c->T, c->Binv, c->inv16, c->alpha_dev, c->m_dev,
-                    c->rvec, c->zvec, c->partial, c->scal, c->info_dev, c->Dk, c->Dt, c->dpack, c->Xs, c->dflags, c->ds_ticks, c->Yn};
+    void* bufs[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev, c->W, c->T, c->Binv, c->inv16, c->m_dev,
+                    c->rvec, c->zvec, c->partial, c->Dk, c->dpack, c->Xs, c->dflags, c->res_dev};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (c->res_host) (void)hipHostFree(c->res_host);
+    if (c->in_host) (void)hipHostFree(c->in_host);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto& e : c->la_ev) (void)hipEventDestroy(e);
+    for (auto& e : c->fill_ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->st);
     if (c->st2) (void)hipStreamDestroy(c->st2);
-    if (c->st3) (void)hipStreamDestroy(c->st3);
-    for (auto& e : c->la_ev) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -136,74 +152,28 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "small_tile_below")) { c->small_tile_below = value; return PGP_OK; }
     if (!strcmp(name, "trtri_small_tile_below")) { c->trtri_small_tile_below = value; return PGP_OK; }
     if (!strcmp(name, "xcd_order")) { c->xcd_order = value; return PGP_OK; }
-    if (!strcmp(name, "gemm_dbg")) { c->gemm_dbg = value; return PGP_OK; }
+    if (!strcmp(name, "gemm_dbg")) { if (value & ~(64 | 256 | 512)) return -2; c->gemm_dbg = value; return PGP_OK; }
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
-    if (!strcmp(name, "potrf_v1")) { c->potrf_v1 = value; return PGP_OK; }
-    if (!strcmp(name, "dserver")) { c->dserver = value; return PGP_OK; }
-    if (!strcmp(name, "s_side")) { c->s_side = value; return PGP_OK; }
-    if (!strcmp(name, "la2")) { c->la2 = value; return PGP_OK; }
-    if (!strcmp(name, "half_wave")) { c->half_wave = value; return PGP_OK; }
+    if (!strcmp(name, "diag_fused")) { c->diag_fused = value; return PGP_OK; }
+    if (!strcmp(name, "dp_timeout_ms")) { c->dp_timeout_s = 1e-3 * value; return PGP_OK; }
     if (!strcmp(name, "ep_dbg")) { return ep_set_dbg(value); }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
     if (!strcmp(name, "ep_r_direct")) { c->ep_r_direct = value; return PGP_OK; }
     if (!strcmp(name, "ep_alpha_direct")) { c->ep_alpha_direct = value; return PGP_OK; }
     if (!strcmp(name, "ep_sym")) { c->ep_sym = value; return PGP_OK; }
+    if (!strcmp(name, "ep_block")) { c->ep_block = value; return PGP_OK; }
     if (!strcmp(name, "xcd_max_k")) { c->xcd_max_k = value; return PGP_OK; }
     if (!strcmp(name, "xcd_min_tiles")) { c->xcd_min_tiles = value; return PGP_OK; }
     if (!strcmp(name, "xcd_super")) { c->xcd_super = value; return PGP_OK; }
     if (!strcmp(name, "solve_outer")) { if (value < 1) return -2; c->solve_outer = value; return PGP_OK; }
     if (!strcmp(name, "predict_batch")) { if (value < 128 || value % 128) return -2; c->predict_batch = value; return PGP_OK; }
     if (!strcmp(name, "s_tile")) { if (value != 0 && value != 64 && value != 128) return -2; c->s_tile = value; return PGP_OK; }
-    if (!strcmp(name, "s_dma")) { c->s_dma = value; return PGP_OK; }
-    if (!strcmp(name, "merge_tu")) { c->merge_tu = value; return PGP_OK; }
-    if (!strcmp(name, "eet_overlap")) { if (value < 0 || value > 3) return -2; c->eet_overlap = value; return PGP_OK; }
+    if (!strcmp(name, "eet_overlap")) { if (value != 0 && value != 2 && value != 3) return -2; c->eet_overlap = value; return PGP_OK; }
     if (!strcmp(name, "eet_max_panels")) { c->eet_max_panels = value; return PGP_OK; }
     if (!strcmp(name, "eet_first")) { if (value < -1) return -2; c->eet_first = value; return PGP_OK; }
-    if (!strcmp(name, "eet_merge")) { c->eet_merge = value; return PGP_OK; }
-    if (!strcmp(name, "eet_tail")) { if (value < 1) return -2; c->eet_tail = value; return PGP_OK; }
     if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
-    if (!strcmp(name, "ds_exclusive")) { c->ds_exclusive = value; return PGP_OK; }
-    if (!strcmp(name, "ds_fake")) { c->ds_fake = value; return PGP_OK; }
-    if (!strcmp(name, "ds_timeout_ms")) { c->ds_timeout_s = 1e-3 * value; return PGP_OK; }
-    if (!strcmp(name, "ds_ticks")) {            // record wall-clock stamps of the server phases (16 per panel)
-        if (value && !c->ds_ticks) {
-            HIP_TRY(hipMalloc((void**)&c->ds_ticks, (size_t)diag_server_max_panels() * 16 * sizeof(long long)));
-            HIP_TRY(hipMemset(c->ds_ticks, 0, (size_t)diag_server_max_panels() * 16 * sizeof(long long)));
-        } else if (!value && c->ds_ticks) { (void)hipFree(c->ds_ticks); c->ds_ticks = nullptr; }
-        return PGP_OK;
-    }
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
-    if (!strcmp(name, "ep_block")) { c->ep_block = value; return PGP_OK; }
-    if (!strcmp(name, "ep_graph")) { c->ep_graph = value; return PGP_OK; }
-    if (!strcmp(name, "ep_resident")) { c->ep_resident = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { cov_tile_set_grid(value); return PGP_OK; }
-    if (!strcmp(name, "cu_reserve")) {
-        // value > 1: every value-th CU is kept free of bulk work; value < 0: the LAST -value CUs of the mask enumeration;
-        // value in (1000, 2000): the first value - 1000 CUs
-        if (c->st_masked) { (void)hipStreamSynchronize(c->st_masked); (void)hipStreamDestroy(c->st_masked); c->st_masked = nullptr; }
-        c->cu_reserve = value;
-        if (value > 1 || value < 0) {
-            const int ncu = c->prop.multiProcessorCount;
-            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            for (int i = 0; i < ncu; ++i) {
-                bool keep;
-                if (value > 1000) keep = i >= value - 1000;
-                else if (value > 1) keep = i % value != value - 1;
-                else keep = i < ncu + value;
-                if (keep) mask[i / 32] |= (1u << (i % 32));
-            }
-            HIP_TRY(hipExtStreamCreateWithCUMask(&c->st_masked, (uint32_t)mask.size(), mask.data()));
-            // the panel chain gets the complement: its kernels can only land on the CUs the bulk stream never uses
-            if (c->st_pan_masked) { (void)hipStreamSynchronize(c->st_pan_masked); (void)hipStreamDestroy(c->st_pan_masked); c->st_pan_masked = nullptr; }
-            std::vector<uint32_t> inv(mask.size(), 0u);
-            for (int i = 0; i < ncu; ++i)
-                if (!((mask[i / 32] >> (i % 32)) & 1u)) inv[i / 32] |= (1u << (i % 32));
-            HIP_TRY(hipExtStreamCreateWithCUMask(&c->st_pan_masked, (uint32_t)inv.size(), inv.data()));
-            if (!c->ev_fork) { HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                               HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
-        }
-        return PGP_OK;
-    }
     return -2;
 }
 
@@ -517,22 +487,6 @@ int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
     return gemm_f64_launch(g, st);
 }
 
-// a and b in ONE grid when both qualify for the merged 128-tile kernel, else one after the other
-static int gemm_prof_pair(pgp_ctx* c, int cls_a, GemmArgs a, int cls_b, GemmArgs b, hipStream_t st) {
-    if (!st) st = c->st;
-    a.dbg |= c->gemm_dbg; b.dbg |= c->gemm_dbg;
-    if (a.batch < 1) a.batch = 1;
-    if (b.batch < 1) b.batch = 1;
-    if (c->xcd_order || !gemm_f64_dual_ok(a, b)) {
-        CHK(gemm_prof(c, cls_a, a, st));
-        return gemm_prof(c, cls_b, b, st);
-    }
-    if (a.tri == 1 && !a.order) CHK(tri_tile_list(c, a.M / 128, a.N / 128, a.tri_off / 128, &a.order, &a.norder));
-    if (b.tri == 1 && !b.order) CHK(tri_tile_list(c, b.M / 128, b.N / 128, b.tri_off / 128, &b.order, &b.norder));
-    ProfScope ps(c, cls_a, a.flops + b.flops, 0.0, st, PC_KERNEL_DMA128);
-    return gemm_f64_dual_launch(a, b, st);
-}
-
 // Blocked right-looking Cholesky of the (mrows x np) column-major lower matrix F (mrows >= np; rows
 // beyond np are "augmented" right-hand-side rows that receive the forward substitution for free).
 //
@@ -575,94 +529,24 @@ static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s
     return PGP_OK;
 }
 
-// C[rows >= r0, cols c0..c1) -= P P^T, P = F[rows, k0..k1) (block units of 128), lower part only
-static int trailing_update(pgp_ctx* c, double* F, long ld, RowEnd re, int k0, int k1, int c0, int c1,
-                           hipStream_t st) {
-    if (c1 <= c0) return PGP_OK;
-    GemmArgs g{};
-    g.A = F + (long)c0 * 128 + (long)k0 * 128 * ld; g.lda = ld; g.a_kc = 0;
-    g.B = g.A; g.ldb = ld; g.b_kc = 0;
-    g.C = F + (long)c0 * 128 + (long)c0 * 128 * ld; g.ldc = ld;
-    g.M = (int)(re(k1) - (long)c0 * 128); g.N = (c1 - c0) * 128; g.K = (k1 - k0) * 128;
-    g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
-    const long t128 = (long)(g.M / 128) * (g.N / 128) - (long)(g.N / 128) * (g.N / 128 - 1) / 2;
-    g.tile = t128 < c->small_tile_below ? 64 : 128;
-    g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
-    return gemm_prof(c, PC_GEMM_TRAIL, g, st);
-}
-
-// with_inverse: rows mrows .. mrows+np-1 of F hold an identity on entry (E region).  They ride through the sweep like
-// the augmented right-hand-side rows: E <- E L^-T = L^-T = W^T.  Row i of E stays zero left of its own column block, so
-// after nb factored column blocks only the first 128 nb rows of E take part (RowEnd): the extra work is N^3/3 flops --
-// exactly a triangular inverse -- but it runs inside the big K=512 trailing-update launches, which it also keeps
-// large when the Cholesky's own trailing matrix shrinks (tiles per launch ~ constant), instead of a separate
-// recursion of 12 small clipped GEMM launches.
-static int potrf_blocked_v1(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse) {
-    const RowEnd re{mrows, with_inverse};
-    const int nblk = (int)(np / 128);
-    const int q = c->nb_outer > 0 ? c->nb_outer : 4;
-    const int npanel = (nblk + q - 1) / q;
-    if (!c->lookahead || npanel < 3) {
-        for (int s0 = 0; s0 < nblk; s0 += q) {
-            const int s1 = std::min(s0 + q, nblk);
-            CHK(factor_panel(c, F, ld, re, s0, s1, c->st));
-            CHK(trailing_update(c, F, ld, re, s0, s1, s1, nblk, c->st));
-        }
-        return PGP_OK;
-    }
-    while ((int)c->la_ev.size() < 2 * npanel + 2) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->la_ev.push_back(e);
-    }
-    hipStream_t main = c->st, pan = c->st2;
-    if (c->st_masked) {                       // run the trailing updates on a CU subset, leave the rest to the panel stream
-        HIP_TRY(hipEventRecord(c->ev_fork, c->st));
-        HIP_TRY(hipStreamWaitEvent(c->st_masked, c->ev_fork, 0));
-        main = c->st_masked;
-    }
-    // panel 0 on the main stream
-    CHK(factor_panel(c, F, ld, re, 0, std::min(q, nblk), main));
-    for (int p = 0; p < npanel; ++p) {
-        const int s0 = p * q, s1 = std::min(s0 + q, nblk);
-        if (s1 >= nblk) break;
-        const int n0 = s1, n1 = std::min(s1 + q, nblk);              // next panel's columns
-        // TU_a(p): next panel's columns, then hand the next panel to the panel stream
-        CHK(trailing_update(c, F, ld, re, s0, s1, n0, n1, main));
-        HIP_TRY(hipEventRecord(c->la_ev[2 * p], main));
-        HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
-        CHK(factor_panel(c, F, ld, re, n0, n1, pan));
-        HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
-        // TU_b(p): the rest of the trailing matrix, concurrently with the panel factorisation
-        CHK(trailing_update(c, F, ld, re, s0, s1, n1, nblk, main));
-        HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));    // next TU_a needs the factored panel
-    }
-    if (main != c->st) {
-        HIP_TRY(hipEventRecord(c->ev_join, main));
-        HIP_TRY(hipStreamWaitEvent(c->st, c->ev_join, 0));
-    }
-    return PGP_OK;
-}
-
-
 // ------------------------------------------------------------------------------------------------------------------
-// Cholesky sweep, version 2 ("diagonal-panel" schedule; the default).
+// Cholesky sweep ("diagonal-panel" schedule).
 //
-// The v1 sweep above keeps EVERY row below a leaf (Cholesky rows, rhs rows, fused-inverse rows: ~np rows) in the
-// latency-bound leaf-level chain: 64 x (leaf_potrf -> trsm_rows over ~np rows -> K=128 inner update) at 5-11 TF, and
-// those launches queue behind 150 us trailing-update workgroups.  Here only the w x w DIAGONAL block of an outer panel
-// (w = 128 q = 512) goes through the leaf chain, in a small scratch with identity rows appended so that E_D = L_D^-T
-// falls out with it (diag_factor: D(p)).  Everything below the block is then ONE MFMA GEMM per panel
+// Only the w x w DIAGONAL block of an outer panel (w = 128 q = 512) goes through the leaf-level factorisation, in a small
+// scratch with identity rows appended so that E_D = L_D^-T falls out with it (diag_factor: D(p), ONE launch of the fused
+// diag_panel_kernel).  Everything below the block is then ONE MFMA GEMM per panel
 //        Y = X E_D        (solve_below: S(p);  K clipped to the triangle, k < j0 + T)
-// instead of 4 trsm + 3 inner-update launches, and the trailing update TU(p) is unchanged.  The critical chain per panel
-// is D(p) only (~13 tiny launches on <= 8 CUs); S and TU are bulk MFMA work on the main stream:
+// and the trailing update TU(p) is one K = w product.  Depth-1 look-ahead on two streams:
 //
 //   main :  S(p) -> TU_a(p) [next panel's columns, written to the staging buffer Xs] -> TU_b(p) [rest, in place] -> ...
 //   panel:                       D(p+1) (reads its diagonal block from Xs)  ..................^ joined before S(p+1)
 //
 // S is out of place (reads Xs, writes the factor / inverse rows), which is free: TU_a already reads and writes those
 // columns once, it just writes them to Xs instead.  The matrix lives in two pieces: logical rows [0, mrows) in F
-// (factor + rhs rows, what a posterior handle keeps) and rows [mrows, mrows + np) in E (fused inverse, scratch).
+// (factor + rhs rows, what a posterior handle keeps) and rows [mrows, mrows + np) in E (fused inverse, scratch): with
+// the inverse rows riding through the sweep like the augmented right-hand-side rows, E <- E L^-T = L^-T = W^T.  Row i of
+// E stays zero left of its own column block, so after nb factored column blocks only the first 128 nb rows of E take part:
+// the extra work is N^3/3 flops -- exactly a triangular inverse -- inside the big K = w trailing-update launches.
 // dense2 > 0: the second piece is NOT the fused inverse but dense2 extra right-hand-side rows (all of them take part from
 // the first panel on: they receive the forward substitution X <- X L^-T, like the rhs rows inside F)
 struct SweepMat { double* F; long ldf; long mrows; double* E; long lde; long np; long dense2 = 0;
@@ -679,31 +563,41 @@ static int ensure_stage(pgp_ctx* c, long rows, int w) {
     return PGP_OK;
 }
 
-// D(p): factor the diagonal block of columns [s0, s1) (block units), src = its (updated) image with leading dim lds
-static int diag_factor(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* src, long lds, hipStream_t st) {
-    const int w = (s1 - s0) * 128;
+// D: factor the w x w block `src` (leading dimension lds, lower part) and produce E_D = L_D^-T beside it: L_D -> Fd (ldf),
+// E_D -> Ed (lde; may be null), E_D also stays in c->Dk + w (leading dimension 2w) for the panel solve that follows
+int diag_block_factor(pgp_ctx* c, const double* src, long lds, int w, double* Fd, long ldf, double* Ed, long lde,
+                      int info_base, hipStream_t st) {
     const long ldd = 2L * w;
+    if (c->diag_fused) {
+        ProfScope ps(c, PC_LEAF, (double)w * w * w * (1.0 / 3.0 + 1.0 / 3.0), 0.0, st);
+        const unsigned base = c->dp_base;
+        c->dp_base += diag_panel_tickets(w);
+        c->dp_used = true;
+        return diag_panel_launch(src, lds, c->Dk, ldd, c->dpack, Fd, ldf, Ed, lde, w, c->dflags, base, c->info_dev, info_base,
+                                 c->dp_timeout_s, st);
+    }
     { ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
       CHK(diag_in_launch(src, lds, c->Dk, ldd, w, st)); }
-    CHK(factor_panel(c, c->Dk, ldd, RowEnd{(long)w, true}, 0, s1 - s0, st, c->dpack, s0 * 128));
+    CHK(factor_panel(c, c->Dk, ldd, RowEnd{(long)w, true}, 0, w / 128, st, c->dpack, info_base));
     { ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
-      CHK(diag_out_launch(c->Dk, ldd, w, m.F + (long)s0 * 128 * (1 + m.ldf), m.ldf,
-                          (m.E && !m.dense2) ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, st, c->s_dma ? c->Dt : nullptr, w)); }
+      CHK(diag_out_launch(c->Dk, ldd, w, Fd, ldf, Ed, lde, st)); }
     return PGP_OK;
 }
 
+// D(p): the diagonal block of columns [s0, s1) (block units), src = its (updated) image with leading dim lds
+static int diag_factor(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* src, long lds, hipStream_t st) {
+    return diag_block_factor(c, src, lds, (s1 - s0) * 128, m.F + (long)s0 * 128 * (1 + m.ldf), m.ldf,
+                             (m.E && !m.dense2) ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, s0 * 128, st);
+}
+
 // S(p): rows below the diagonal block of panel [s0, s1):  Y = X E_D, X read from the staging buffer (logical rows, ldx)
-static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* Xs, long ldx, hipStream_t st,
-                       const double* Dk = nullptr) {
-    const bool own = !Dk;                                     // the launch chain's own scratch: diag_factor also left E_D^T in c->Dt
-    if (!Dk) Dk = c->Dk;
+static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* Xs, long ldx, hipStream_t st) {
     const int w = (s1 - s0) * 128;
     const long r0 = (long)s1 * 128, r1 = m.mrows + m.rows2(s0);
     if (r1 <= r0) return PGP_OK;
     GemmArgs g{};
     g.A = Xs + r0; g.lda = ldx; g.a_kc = 0;
-    g.B = Dk + w; g.ldb = 2L * w; g.b_kc = 1;                 // B(n,k) = E_D(k,n): K-contiguous
-    if (own && c->s_dma) { g.B = c->Dt; g.ldb = w; g.b_kc = 0; }   // ... or n-contiguous from the transposed copy
+    g.B = c->Dk + w; g.ldb = 2L * w; g.b_kc = 1;              // B(n,k) = E_D(k,n): K-contiguous
     g.C = m.F + r0 + (long)s0 * 128 * m.ldf; g.ldc = m.ldf;
     if (m.E && r1 > m.mrows) { g.C2 = m.E + (long)s0 * 128 * m.lde; g.ldc2 = m.lde; g.c_split = (int)(m.mrows - r0); }
     g.M = (int)(r1 - r0); g.N = w; g.K = w; g.alpha = 1.0; g.beta = 0.0;
@@ -720,11 +614,8 @@ static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const doub
 
 // TU: C[rows >= c0, cols c0..c1) -= P P^T, P = solved columns [k0, k1); out != nullptr: result goes to the staging buffer
 static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c0, int c1, double* out, long ldx,
-                            hipStream_t st, int stage_blocks = 0, unsigned* sig_counter = nullptr,
-                            unsigned* sig_flag = nullptr, int sig_blocks = 0, bool skip_stage_diag = false,
-                            unsigned* stg_counter = nullptr, unsigned* stg_flag = nullptr,
-                            const GemmArgs* extra = nullptr) {
-    if (c1 <= c0) return extra ? gemm_prof(c, PC_GEMM_LAUUM, *extra, st) : PGP_OK;
+                            hipStream_t st) {
+    if (c1 <= c0) return PGP_OK;
     const long r0 = (long)c0 * 128, r1 = m.mrows + m.rows2(k1);
     GemmArgs g{};
     g.A = m.F + r0 + (long)k0 * 128 * m.ldf; g.lda = m.ldf; g.a_kc = 0;
@@ -747,44 +638,7 @@ static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c
     if (split && !m.dense2) g.zero_from = (int)(m.mrows + (long)k0 * 128 - r0);     // this panel's own inverse rows: first touch
     const long t128 = (long)(g.M / 128) * (g.N / 128) - (long)(g.N / 128) * (g.N / 128 - 1) / 2;
     g.tile = t128 < c->small_tile_below ? 64 : 128;
-    // at most one 128-tile per CU (TU_a at N = 8192: 254 tiles): the dispatcher still packs two workgroups onto one CU
-    // and leaves the next CU empty, so each pair runs at half speed.  half_wave 1: pad the LDS request so that only ONE
-    // workgroup fits a CU; 2: 64-tiles instead
-    if (g.tile == 128 && t128 <= 256 && c->half_wave == 1) g.dbg |= 8;
-    if (g.tile == 128 && t128 <= 256 && c->half_wave == 2) g.tile = 64;
-    if (out && stage_blocks > 0) {                    // one launch: the first stage_blocks column blocks -> staging, rest in place
-        g.stage_cols = stage_blocks * 128;
-        g.skip_stage_diag = skip_stage_diag ? 1 : 0;
-        const int T = g.tile, mt = g.M / T, nst = g.stage_cols / T;
-        auto count = [&](int ns) {                                     // active tiles of the first ns tile columns
-            long tot = 0;
-            for (int tj = 0; tj < ns; ++tj)
-                for (int ti = tj; ti < mt; ++ti)
-                    if (!(skip_stage_diag && ti < nst && tj < nst)) ++tot;
-            return (unsigned)tot;
-        };
-        if (sig_counter) {
-            if (sig_blocks <= 0) sig_blocks = stage_blocks;
-            g.sig_counter = sig_counter; g.sig_flag = sig_flag; g.sig_cols = sig_blocks * 128;
-            g.sig_total = count(sig_blocks * 128 / T);
-        }
-        if (stg_counter) {                                             // "the staged columns are complete" (for the next S)
-            g.sig2_counter = stg_counter; g.sig2_flag = stg_flag; g.sig2_cols = g.stage_cols; g.sig2_total = count(nst);
-        }
-        // no active tile carries the signal (e.g. the last update of a sweep without rhs rows: only the skipped diagonal
-        // block is left): post the flag from the stream instead
-        unsigned* late[2] = {nullptr, nullptr};
-        if (g.sig_counter && g.sig_total == 0) { late[0] = g.sig_flag; g.sig_counter = nullptr; }
-        if (g.sig2_counter && g.sig2_total == 0) { late[1] = g.sig2_flag; g.sig2_counter = nullptr; }
-        if (late[0] || late[1]) {
-            g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
-            CHK(gemm_prof(c, PC_GEMM_TRAIL, g, st));
-            for (unsigned* f : late) if (f) CHK(diag_server_post(f, st));
-            return PGP_OK;
-        }
-    }
     g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
-    if (extra) return gemm_prof_pair(c, PC_GEMM_TRAIL, g, PC_GEMM_LAUUM, *extra, st);
     return gemm_prof(c, PC_GEMM_TRAIL, g, st);
 }
 
@@ -818,34 +672,15 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     const int wmax = q * 128;
     const long ldx = m.mrows + (m.dense2 > 0 ? m.dense2 : m.np);   // staging buffer indexed by logical row
     const bool la = c->lookahead && npanel >= 3;
-    // the resident server only pays when there is a trailing update to overlap with
-    const bool server = la && c->dserver && q <= 4 && npanel <= diag_server_max_panels() && !m.dense2;
-    const long xs_stride = ldx * wmax;                            // server mode: two staging buffers (panel parity)
-    CHK(ensure_stage(c, server ? 2 * ldx : ldx, wmax));
+    CHK(ensure_stage(c, ldx, wmax));
     double* Xs = c->Xs;
-    const long dk_stride = 1024L * 1024L;                         // two scratch images inside c->Dk (server mode)
-    if (la && !server)
+    if (la)
         while ((int)c->la_ev.size() < 2 * npanel + 2) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             c->la_ev.push_back(e);
         }
     hipStream_t main = c->st, pan = la ? c->st2 : c->st;
-    if (la && c->st_masked) {                 // bulk work on a CU subset, the reserved CUs belong to the panel chain
-        HIP_TRY(hipEventRecord(c->ev_fork, c->st));
-        HIP_TRY(hipStreamWaitEvent(c->st_masked, c->ev_fork, 0));
-        main = c->st_masked;
-        if (c->st_pan_masked && !server) pan = c->st_pan_masked;
-    }
-    if (server) {
-        // flags zeroed, then the server goes resident on the panel stream BEFORE any bulk work is queued
-        HIP_TRY(hipMemsetAsync(c->dflags, 0, diag_server_flag_bytes(), main));
-        HIP_TRY(hipEventRecord(c->ev_ds, main));
-        HIP_TRY(hipStreamWaitEvent(pan, c->ev_ds, 0));
-        CHK(diag_server_launch(c->Dk, dk_stride, c->dpack, m.F, m.ldf, m.E, m.lde, Xs, ldx, xs_stride, c->Yn, nblk, q,
-                               c->dflags, c->info_dev, c->ds_timeout_s, c->ds_ticks, pan, c->ds_exclusive != 0, c->ds_fake));
-        c->ds_used = true;
-    }
     // panel 0: its columns go to the staging buffer by a plain copy (later panels get there through TU_a)
     {
         const int s1 = std::min(q, nblk);
@@ -856,215 +691,32 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         if (m.E && m.dense2 > 0)                                  // the dense second piece takes part from panel 0 on
             HIP_TRY(hipMemcpy2DAsync(Xs + m.mrows, ldx * sizeof(double), m.E, m.lde * sizeof(double),
                                      m.dense2 * sizeof(double), (size_t)s1 * 128, hipMemcpyDeviceToDevice, main));
-        if (server) CHK(diag_server_go(c->dflags, 0, main));
-        else CHK(diag_factor(c, m, 0, s1, m.F, m.ldf, main));
+        CHK(diag_factor(c, m, 0, s1, m.F, m.ldf, main));
     }
-    if (server) {
-        // server: the whole critical path, left-looking -- it brings the next diagonal block up to date itself and
-        //         factors it, one to two panels ahead of the bulk work (see diag_server_kernel)
-        // side  : S(p) as soon as the server has posted done[p]; overlaps the tail of TU(p-1)
-        // main  : TU(p) as ONE launch -- the next panel's columns first (into staging buffer (p+1)&1; the next panel's
-        //         diagonal block is the server's and skipped), then the rest in place; the tile that completes the first two
-        //         column panels releases go[p+2] from inside the kernel
-        if (!c->st3) {        // created on first use only: every extra stream shifts the hardware-queue placement of the others
-            int lo = 0, hi = 0;   // (two fit contexts per GPU: 91.7 fits/s with two streams each, 80.3 with a third one idle)
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            HIP_TRY(hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, hi));
-        }
-        hipStream_t side = c->st3;
-        while ((int)c->la_ev.size() < npanel + 2) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->la_ev.push_back(e);
-        }
-        HIP_TRY(hipEventRecord(c->ev_ds, main));                      // panel-0 copy before the first S
-        HIP_TRY(hipStreamWaitEvent(side, c->ev_ds, 0));
-        for (int p = 0; p < npanel; ++p) {
-            const int s0 = p * q, s1 = std::min(s0 + q, nblk);
-            CHK(diag_server_wait(c->dflags, p, c->ds_timeout_s, side));
-            // the server may be ahead of the bulk: S(p) also needs panel p's staged columns, i.e. the head of TU(p-1)
-            if (p > 0) CHK(diag_server_wait_staged(c->dflags, p, c->ds_timeout_s, side));
-            CHK(solve_below(c, m, s0, s1, Xs + (p & 1) * xs_stride, ldx, side, c->Dk + (p & 1) * dk_stride));
-            HIP_TRY(hipEventRecord(c->la_ev[p], side));
-            HIP_TRY(hipStreamWaitEvent(main, c->la_ev[p], 0));
-            if (s1 >= nblk) break;
-            const int n1 = std::min(s1 + q, nblk), n2 = std::min(n1 + q, nblk);
-            const bool sig = p + 2 < npanel;
-            CHK(trailing_update2(c, m, s0, s1, s1, nblk, Xs + ((p + 1) & 1) * xs_stride, ldx, main, n1 - s1,
-                                 sig ? diag_server_counter(c->dflags, p + 2) : nullptr,
-                                 sig ? diag_server_go_flag(c->dflags, p + 2) : nullptr, n2 - s1, true,
-                                 diag_server_counter2(c->dflags, p + 1), diag_server_stage_flag(c->dflags, p + 1)));
-        }
-        HIP_TRY(hipEventRecord(c->ev_ds2, pan));                      // the server has exited (or is about to)
-        HIP_TRY(hipStreamWaitEvent(main, c->ev_ds2, 0));
-        return PGP_OK;
-    }
-    if (la && c->merge_tu && !server && !m.dense2) {
-        // One trailing-update launch per panel (next panel's columns first, into the staging buffer); the tile that
-        // completes them releases stg[p+1] from inside the kernel and the panel stream -- parked on that flag -- factors
-        // the next diagonal block while the rest of the update runs.  No half-wave TU_a launch; the price is that the
-        // staged tiles share the first wave with everybody else (flag ~250 us after the launch instead of ~100).
-        HIP_TRY(hipMemsetAsync(c->dflags, 0, diag_server_flag_bytes(), main));
-        std::vector<hipEvent_t>& e2 = c->la_ev;
-        while ((int)e2.size() < 2 * npanel + 4) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            e2.push_back(e);
-        }
-        HIP_TRY(hipEventRecord(e2[2 * npanel + 2], main));            // flags zeroed, D(0) done (main)
-        HIP_TRY(hipStreamWaitEvent(pan, e2[2 * npanel + 2], 0));
-        for (int p = 0; p < npanel; ++p) {
-            const int s0 = p * q, s1 = std::min(s0 + q, nblk);
-            CHK(solve_below(c, m, s0, s1, Xs, ldx, main));
-            if (s1 >= nblk) break;
-            const int n1 = std::min(s1 + q, nblk);
-            CHK(trailing_update2(c, m, s0, s1, s1, nblk, Xs, ldx, main, n1 - s1, nullptr, nullptr, 0, false,
-                                 diag_server_counter2(c->dflags, p + 1), diag_server_stage_flag(c->dflags, p + 1)));
-            CHK(diag_server_wait_staged(c->dflags, p + 1, c->ds_timeout_s, pan));
-            CHK(diag_factor(c, m, s1, n1, Xs + (long)s1 * 128, ldx, pan));
-            HIP_TRY(hipEventRecord(e2[2 * p + 1], pan));
-            HIP_TRY(hipStreamWaitEvent(main, e2[2 * p + 1], 0));      // S(p+1) needs D(p+1); TU(p) is done by then too
-        }
-        c->ds_used = true;
-        if (main != c->st) {
-            HIP_TRY(hipEventRecord(c->ev_join, main));
-            HIP_TRY(hipStreamWaitEvent(c->st, c->ev_join, 0));
-        }
-        return PGP_OK;
-    }
-    if (la && c->la2 && !server && !m.dense2) {
-        // Depth-2 look-ahead on three streams.  The critical chain  D(p) -> S(p) -> TU_a(p) -> D(p+1)  runs on the panel
-        // and side streams; the main stream only carries the big in-place updates TU_b(p), split so that the columns the
-        // NEXT chain step reads (panel p+2: TU_b1) come first.  The half-wave launches of the chain (S, TU_a: ~254 tiles on
-        // 512 slots) then overlap the previous panel's TU_b2 instead of running alone:
-        //   side : S(p) <- D(p);  TU_a(p) <- S(p), TU_b1(p-1);  [-> panel stream: D(p+1)]
-        //   main : TU_b1(p) <- S(p) (and TU_b2(p-1) by stream order);  TU_b2(p)
-        if (!c->st3) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            HIP_TRY(hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, hi));
-        }
-        hipStream_t side = c->st3;
-        std::vector<hipEvent_t>& e2 = c->la_ev;
-        while ((int)e2.size() < 6 * npanel + 6) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            e2.push_back(e);
-        }
-        auto EV = [&](int kind, int p) { return e2[kind * (npanel + 1) + p]; };   // 0: D done, 1: S done, 2: TU_a done, 3: TU_b1 done
-        HIP_TRY(hipEventRecord(EV(0, 0), main));                      // D(0) ran on main above
-        for (int p = 0; p < npanel; ++p) {
-            const int s0 = p * q, s1 = std::min(s0 + q, nblk);
-            HIP_TRY(hipStreamWaitEvent(side, EV(0, p), 0));
-            CHK(solve_below(c, m, s0, s1, Xs, ldx, side));
-            HIP_TRY(hipEventRecord(EV(1, p), side));
-            HIP_TRY(hipStreamWaitEvent(main, EV(1, p), 0));
-            if (s1 >= nblk) break;
-            const int n0 = s1, n1 = std::min(s1 + q, nblk), n2 = std::min(n1 + q, nblk);
-            if (p > 0) HIP_TRY(hipStreamWaitEvent(side, EV(3, p - 1), 0));          // panel p+1's columns carry update p-1
-            CHK(trailing_update2(c, m, s0, s1, n0, n1, Xs, ldx, side));            // TU_a -> staging
-            HIP_TRY(hipEventRecord(EV(2, p), side));
-            HIP_TRY(hipStreamWaitEvent(pan, EV(2, p), 0));
-            CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan));
-            HIP_TRY(hipEventRecord(EV(0, p + 1), pan));
-            CHK(trailing_update2(c, m, s0, s1, n1, n2, nullptr, 0, main));          // TU_b1: the next-next panel's columns
-            HIP_TRY(hipEventRecord(EV(3, p), main));
-            CHK(trailing_update2(c, m, s0, s1, n2, nblk, nullptr, 0, main));        // TU_b2: the rest
-        }
-        HIP_TRY(hipEventRecord(EV(4, 0), side));
-        HIP_TRY(hipStreamWaitEvent(main, EV(4, 0), 0));
-        HIP_TRY(hipEventRecord(EV(4, 1), pan));
-        HIP_TRY(hipStreamWaitEvent(main, EV(4, 1), 0));
-        if (main != c->st) {
-            HIP_TRY(hipEventRecord(c->ev_join, main));
-            HIP_TRY(hipStreamWaitEvent(c->st, c->ev_join, 0));
-        }
-        return PGP_OK;
-    }
-    const SweepMat& mc = m;
-    std::vector<hipEvent_t>& ev = c->la_ev;
-    // side stream: S(p+1) starts as soon as D(p+1) is done and overlaps the tail of TU_b(p) on the main stream
-    hipStream_t side = nullptr;
-    if (la && c->s_side) {
-        if (!c->st3) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            HIP_TRY(hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, hi));
-        }
-        side = c->st3;
-        while ((int)ev.size() < 4 * npanel + 4) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ev.push_back(e);
-        }
-    }
-    // filler stream: panel p's share of B^-1 = E E^T is queued as soon as S(p) has produced the final columns p of E; it
-    // fills the slots the dependent chain leaves idle (lowest priority), instead of one long product after the sweep
-    hipStream_t fill = nullptr;
     c->eet_join = nullptr;
-    // eet_overlap: 1 = filler stream, 2 = inline (behind / inside TU_b on the main stream), 3 = inline up to
-    // eet_max_panels panels (default: beyond that the chain is amortised and the one-shot long-K product is faster)
+    // B^-1 = sum_p E_p E_p^T accumulated under the sweep (eet_overlap 2, or 3 up to eet_max_panels panels: beyond that the
+    // chain is amortised and the one-shot long-K product is faster): panel p's share right behind TU_b(p) on the main
+    // stream -- the main stream stays busy until D(p+1) is done instead of waiting for it
     const bool fill_inline = la && m.E && !m.dense2 && c->eet_out &&
                              (c->eet_overlap == 2 || (c->eet_overlap == 3 && npanel <= c->eet_max_panels));
-    if (la && c->eet_overlap == 1 && m.E && !m.dense2 && c->eet_out) {
-        if (!c->st_fill) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            HIP_TRY(hipStreamCreateWithPriority(&c->st_fill, hipStreamNonBlocking, lo));
-        }
-        fill = c->st_fill;
-        while ((int)c->fill_ev.size() < npanel + 1) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->fill_ev.push_back(e);
-        }
-    }
     for (int p = 0; p < npanel; ++p) {
         const int s0 = p * q, s1 = std::min(s0 + q, nblk);
-        if (side && p > 0) {
-            // D(p) finished on the panel stream (la_ev[2(p-1)+1]): solve on the side stream, the main stream joins after it
-            HIP_TRY(hipStreamWaitEvent(side, c->la_ev[2 * (p - 1) + 1], 0));
-            CHK(solve_below(c, mc, s0, s1, Xs, ldx, side));
-            HIP_TRY(hipEventRecord(ev[2 * npanel + 3 + p], side));
-            HIP_TRY(hipStreamWaitEvent(main, ev[2 * npanel + 3 + p], 0));
-        } else {
-            CHK(solve_below(c, mc, s0, s1, Xs, ldx, main));
-        }
-        if (fill && (p < npanel - c->eet_tail || s1 >= nblk)) {
-            // the last eet_tail panels are folded into ONE product after the last solve (K = eet_tail w: the filler is
-            // starved while trailing updates are queued, so the end of the sweep finds a backlog anyway)
-            const int f0 = s1 >= nblk ? std::max(0, npanel - c->eet_tail) * q : s0;
-            HIP_TRY(hipEventRecord(c->fill_ev[p], main));
-            HIP_TRY(hipStreamWaitEvent(fill, c->fill_ev[p], 0));
-            CHK(eet_panel(c, mc, std::min(f0, s0), s1, c->eet_out, c->eet_ld, fill));
-            if (s1 >= nblk) { HIP_TRY(hipEventRecord(c->fill_ev[npanel], fill)); c->eet_join = c->fill_ev[npanel]; }
-        }
+        CHK(solve_below(c, m, s0, s1, Xs, ldx, main));
         if (s1 >= nblk) break;
         const int n0 = s1, n1 = std::min(s1 + q, nblk);              // next panel's columns
-        CHK(trailing_update2(c, mc, s0, s1, n0, n1, Xs, ldx, main));  // TU_a -> staging
+        CHK(trailing_update2(c, m, s0, s1, n0, n1, Xs, ldx, main));   // TU_a -> staging
         if (la) {
             HIP_TRY(hipEventRecord(c->la_ev[2 * p], main));
             HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
         }
         CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan));
         if (la) HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
-        // inline filler: panel p's share of E E^T in the SAME grid as TU_b(p) (or right behind it when the shapes do not
-        // qualify) -- the main stream stays busy until D(p+1) is done instead of waiting for it, no third stream
+        CHK(trailing_update2(c, m, s0, s1, n1, nblk, nullptr, 0, main));   // TU_b in place, concurrent with D(p+1)
         // the first products are small (few tiles, short k) and the early trailing updates are long enough to hide D by
         // themselves: panels 0 .. eet_first go into ONE product (k = (eet_first + 1) w) behind TU_b(eet_first)
-        // (default: the first sixth of the panels -- npanel / 4 until the GEMM k-loop got faster: 12.35 -> 12.2 ms at N = 8192)
         const int pf = std::min(c->eet_first >= 0 ? c->eet_first : npanel / 6, npanel - 2);
-        if (fill_inline && p >= pf) {
-            const GemmArgs fa = eet_panel_args(c, mc, p == pf ? 0 : s0, s1, c->eet_out, c->eet_ld);
-            if (c->eet_merge)
-                CHK(trailing_update2(c, mc, s0, s1, n1, nblk, nullptr, 0, main, 0, nullptr, nullptr, 0, false, nullptr, nullptr, &fa));
-            else {
-                CHK(trailing_update2(c, mc, s0, s1, n1, nblk, nullptr, 0, main));
-                CHK(gemm_prof(c, PC_GEMM_LAUUM, fa, main));
-            }
-        } else
-            CHK(trailing_update2(c, mc, s0, s1, n1, nblk, nullptr, 0, main));   // TU_b in place, concurrent with D(p+1)
-        if (la && !side) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
+        if (fill_inline && p >= pf) CHK(eet_panel(c, m, p == pf ? 0 : s0, s1, c->eet_out, c->eet_ld, main));
+        if (la) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
     }
     if (fill_inline) {
         // the last product has nothing of the sweep left to hide: it goes to the (now idle) panel stream so that the O(N^2)
@@ -1077,26 +729,26 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         }
         HIP_TRY(hipEventRecord(c->fill_ev[0], main));
         HIP_TRY(hipStreamWaitEvent(pan, c->fill_ev[0], 0));
-        CHK(eet_panel(c, mc, s0, nblk, c->eet_out, c->eet_ld, pan));
+        CHK(eet_panel(c, m, s0, nblk, c->eet_out, c->eet_ld, pan));
         HIP_TRY(hipEventRecord(c->fill_ev[1], pan));
         c->eet_join = c->fill_ev[1];
-    }
-    if (main != c->st) {
-        HIP_TRY(hipEventRecord(c->ev_join, main));
-        HIP_TRY(hipStreamWaitEvent(c->st, c->ev_join, 0));
     }
     return PGP_OK;
 }
 
-// after the stream has been synchronised: did the resident server of the last sweep post an error (timeout)?
-int potrf_server_status(pgp_ctx* c) {
-    if (!c->ds_used) return PGP_OK;
-    c->ds_used = false;
+// after the stream has been synchronised: did a fused diagonal-panel kernel of the last sweep post an error (timeout)?
+int potrf_diag_status(pgp_ctx* c) {
+    if (!c->dp_used) return PGP_OK;
+    c->dp_used = false;
     unsigned err = 0;
-    HIP_TRY(hipMemcpy(&err, c->dflags + diag_server_err_index(), sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&err, c->dflags + diag_panel_err_index(), sizeof(unsigned), hipMemcpyDeviceToHost));
     if (err != 0) {
+        // the barrier tickets of the aborted launch are lost: start over from a clean counter
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(c->dflags, 0, diag_panel_flag_bytes());
+        c->dp_base = 0;
         char msg[128];
-        snprintf(msg, sizeof(msg), "diagonal-panel server timed out (code %u)", err);
+        snprintf(msg, sizeof(msg), "fused diagonal-panel kernel timed out (code %u)", err);
         pgp_set_last_hip_error(hipErrorLaunchTimeOut, msg, __FILE__, __LINE__);
         return PGP_ERR_HIP;
     }
@@ -1105,17 +757,9 @@ int potrf_server_status(pgp_ctx* c) {
 
 // Entry point.  with_inverse: the np rows [mrows, mrows + np) end up holding E = L^-T (upper triangular).  They live at
 // E (leading dimension lde) or, when E is null, directly below the factor's rows in the same buffer (F + mrows, ld).
-// The v2 sweep writes EVERY entry of the inverse rows it later reads, so E needs no initialisation; v1 (option potrf_v1)
-// wants an identity there on entry and a single buffer.
+// The sweep writes EVERY entry of the inverse rows it later reads, so E needs no initialisation.
 int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse, double* E, long lde) {
     if (with_inverse && !E) { E = F + mrows; lde = ld; }
-    if (c->potrf_v1) {
-        if (with_inverse) {
-            if (E != F + mrows || lde != ld) return -1;
-            CHK(identity_upper_launch(E, ld, np, c->st));
-        }
-        return potrf_blocked_v1(c, F, ld, np, mrows, with_inverse);
-    }
     // two-piece row space: the panel solves / updates address "rows >= mrows" through a split that must be positive for
     // every panel, i.e. at least one spare row block between the factor's rows and the inverse rows
     if (with_inverse && E != F + mrows && mrows < np + 128) return -1;
@@ -1127,7 +771,7 @@ int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with
 // column k at R[n + k ldr]): on return R = R L^-T, i.e. row n of R holds (L^-1 r_n)' for the right-hand side r_n = R(n, :)'.
 // The rows ride along in the panel solves and trailing updates of the sweep (N^2 flops per row inside the bulk MFMA launches).
 int potrf_blocked_rhs(pgp_ctx* c, double* F, long ld, long np, long mrows, double* R, long ldr, long nrhs2) {
-    if (c->potrf_v1 || !R || nrhs2 <= 0 || nrhs2 % 128 || mrows < np + 128) return -1;
+    if (!R || nrhs2 <= 0 || nrhs2 % 128 || mrows < np + 128) return -1;
     SweepMat m{F, ld, mrows, R, ldr, np};
     m.dense2 = nrhs2;
     return potrf_blocked_v2(c, m);
@@ -1234,9 +878,10 @@ int eet_lower(pgp_ctx* c, const double* E, long lde, double* Binv, long ldb, lon
 int ensure_workspace(pgp_ctx* c, long np) {
     if (c->ws_np == np) return PGP_OK;
     (void)hipStreamSynchronize(c->st);
-    void* olds[] = {c->W, c->T, c->Binv, c->inv16, c->alpha_dev, c->m_dev, c->rvec, c->zvec};
+    void* olds[] = {c->W, c->T, c->Binv, c->inv16, c->m_dev, c->rvec, c->zvec};
     for (void* b : olds) if (b) (void)hipFree(b);
-    c->W = c->T = c->Binv = c->inv16 = c->alpha_dev = c->m_dev = c->rvec = c->zvec = nullptr;
+    c->W = c->T = c->Binv = c->inv16 = c->m_dev = c->rvec = c->zvec = nullptr;
+    if (c->in_host) { (void)hipHostFree(c->in_host); c->in_host = nullptr; c->in_cap = 0; }
     c->ws_np = 0;          // committed again only once EVERY allocation below has succeeded
     const size_t nn = (size_t)np * np * sizeof(double);
     HIP_TRY(hipMalloc((void**)&c->W, nn));
@@ -1245,12 +890,13 @@ int ensure_workspace(pgp_ctx* c, long np) {
     HIP_TRY(hipMemsetAsync(c->Binv, 0, nn, c->st));
     HIP_TRY(hipMalloc((void**)&c->T, std::max<size_t>(nn / 4, 128 * 128 * sizeof(double))));
     HIP_TRY(hipMalloc((void**)&c->inv16, (size_t)(np / 128) * PACK_DOUBLES * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->alpha_dev, np * sizeof(double)));
+    CHK(alloc_result_buffer(c, np));                          // scalars | alpha: one device buffer, one pinned host image
     HIP_TRY(hipMalloc((void**)&c->m_dev, np * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->rvec, np * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->zvec, np * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(c->alpha_dev, 0, np * sizeof(double), c->st));
     HIP_TRY(hipMemsetAsync(c->rvec, 0, np * sizeof(double), c->st));
+    c->in_cap = (size_t)(np + 1024) * sizeof(double);
+    HIP_TRY(hipHostMalloc((void**)&c->in_host, c->in_cap, hipHostMallocDefault));
     c->ws_np = np;
     return PGP_OK;
 }
@@ -1333,11 +979,11 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     if (c->n <= 0) return -1;
     if (!covhyp) return -3;
     if (want < 1 || want > 3) return -11;
+    if (ncov < 0 || 8 + ncov + 1 > RES_INFO) return -4;
     HIP_TRY(hipSetDevice(c->device));
     const long n = c->n, d = c->d, np = c->np;
     const bool fused = want >= 3 && c->fused_inverse;
-    // v1 sweep (A/B option): inverse rows inside the factor buffer; v2: factor buffer = factor + rhs rows only
-    const long ldf = (c->potrf_v1 && fused) ? 2 * np + 128 : c->ldf;
+    const long ldf = c->ldf;                         // factor buffer = factor rows + rhs rows; the inverse rows are scratch
     CovSpec cp;
     { const int rc = make_spec(c, kind, covhyp, ncov, para, flags, -1, d, cp); if (rc != PGP_OK) return rc == -11 ? -10 : rc; }
     const std::vector<double>& sc = cp.scale;
@@ -1357,15 +1003,14 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     FactorGuard fguard(c, F, (size_t)ldf * np * sizeof(double), /*scrub=*/true);   // back to the pool on every early return
     PoolScratch pscr(c);
     double* E = nullptr;                             // E(i,j) at E[i + j*lde]: ends up as W^T = L^-T (upper triangular)
-    long lde = np;
-    if (fused) {
-        if (c->potrf_v1) { E = F + np + 128; lde = ldf; }
-        else CHK(pscr.alloc(&E, (size_t)np * np * sizeof(double)));
-    }
+    const long lde = np;
+    if (fused) CHK(pscr.alloc(&E, (size_t)np * np * sizeof(double)));
     hipStream_t st = c->st;
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
-    if (mvec) HIP_TRY(hipMemcpyAsync(c->m_dev, mvec, n * sizeof(double), hipMemcpyHostToDevice, st));
-    else HIP_TRY(hipMemsetAsync(c->m_dev, 0, n * sizeof(double), st));
+    if (mvec) {                                      // through pinned memory: an async copy from pageable memory is staged
+        memcpy(c->in_host, mvec, n * sizeof(double));             // and synchronised by the runtime
+        HIP_TRY(hipMemcpyAsync(c->m_dev, c->in_host, n * sizeof(double), hipMemcpyHostToDevice, st));
+    } else HIP_TRY(hipMemsetAsync(c->m_dev, 0, n * sizeof(double), st));
 
     // ---- S1': fused assembly of B = K/sn2 + I into the factor buffer --------------------------
     HIP_TRY(hipEventRecord(c->ev[0], st));
@@ -1377,14 +1022,15 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     CHK(aug_rhs_launch(c->y_dev, c->m_dev, n, F, ldf, np, c->rvec, st));
     // ---- S2: Cholesky (forward substitution of the augmented row -- and L^-T -- ride along) ----------
     HIP_TRY(hipEventRecord(c->ev[1], st));
-    if (fused && !c->potrf_v1) { c->eet_out = c->Binv; c->eet_ld = np; }
+    if (fused) { c->eet_out = c->Binv; c->eet_ld = np; }
     c->eet_join = nullptr;
     const int prc = potrf_blocked(c, F, ldf, np, np + 128, fused, E, lde);
     c->eet_out = nullptr;
     if (prc != PGP_OK) (void)hipDeviceSynchronize();                              // queued products still read the scratch E
     CHK(prc);
     HIP_TRY(hipEventRecord(c->ev[2], st));
-    int info = 0;
+    // scalars first: logdet, z'z  (one small workgroup; it runs beside the last E E^T product instead of behind alpha)
+    CHK(logdet_ztz_launch(F, ldf, n, F + np, ldf, c->scal, st));
     // ---- S5a/S3: W = L^-1, alpha = W^T z / sn2 (or blocked back-substitution when W is not needed)
     CHK(gather_strided_launch(F + np, ldf, np, c->zvec, st));
     if (fused) {
@@ -1403,12 +1049,10 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         { ProfScope ps(c, PC_SMALL, 0.0, 4.0 * (double)np * np);
           CHK(trsv_bwd_launch(F, ldf, c->W, np, c->zvec, c->alpha_dev, (int)(np / 128), st)); }
     }
-    // scalars: logdet, z'z   (note zvec is consumed by the back-substitution, so z'z comes from F)
-    CHK(logdet_ztz_launch(F, ldf, n, F + np, ldf, c->scal, st));
     HIP_TRY(hipEventRecord(c->ev[4], st));
     // ---- S5b: B^-1 = W^T W ; S6: gradient reduce ------------------------------------------------
     if (want >= 3) {
-        if (fused && c->eet_join) HIP_TRY(hipStreamWaitEvent(st, c->eet_join, 0));        // accumulated under the sweep   // accumulated under the sweep
+        if (fused && c->eet_join) HIP_TRY(hipStreamWaitEvent(st, c->eet_join, 0));        // accumulated under the sweep
         else if (fused) CHK(eet_lower(c, E, lde, c->Binv, np, np));                   // B^-1 = W^T W = E E^T
         else CHK(lauum_lower(c, c->W, np, c->Binv, np, np));
         HIP_TRY(hipEventRecord(c->ev[5], st));
@@ -1420,18 +1064,15 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         HIP_TRY(hipEventRecord(c->ev[5], st));
     }
     HIP_TRY(hipEventRecord(c->ev[6], st));
-    // ---- results to host -------------------------------------------------------------------------
-    std::vector<double> sc_host(8 + ncov + 1, 0.0);
-    if (want < 3) {   // back-substitution produced L^-T z; scale to alpha = B^-1 r / sn2
-        // (col_dot path already applied 1/sn2)
-    }
-    HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(sc_host.data(), c->scal, (8 + ncov + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
-    std::vector<double> alpha_h(n);
-    HIP_TRY(hipMemcpyAsync(alpha_h.data(), c->alpha_dev, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    // ---- results to host: ONE copy of [scalars | status | alpha] into pinned memory ---------------------
+    HIP_TRY(hipMemcpyAsync(c->res_host, c->res_dev, (size_t)(RES_HEAD + n) * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    CHK(potrf_server_status(c));
-    if (want < 3) for (auto& a : alpha_h) a /= sn2;
+    CHK(potrf_diag_status(c));
+    const double* sc_host = c->res_host;
+    double* alpha_h = c->res_host + RES_HEAD;
+    int info = 0;
+    memcpy(&info, c->res_host + RES_INFO, sizeof(int));
+    if (want < 3) for (long j = 0; j < n; ++j) alpha_h[j] /= sn2;   // the back-substitution produced L^-T z
     {
         float ms;
         const int map[6][2] = {{0, 1}, {1, 2}, {3, 4}, {2, 3}, {4, 5}, {5, 6}};   // assemble, potrf, solve, trtri, lauum, grad
@@ -1440,10 +1081,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     }
     if (c->prof) prof_collect(c);
     if (info != 0) return info > (int)n ? (int)n : info;     // the buffer now holds NaNs: fguard scrubs it for the pool
-    if (c->potrf_v1 && fused) {                       // v1 leaves E in the spare rows: honour the pool contract (zeros)
-        CHK(zero_strip_launch(F, ldf, np, np + 128, np, st));
-    }
-    if (alpha_out) memcpy(alpha_out, alpha_h.data(), n * sizeof(double));
+    if (alpha_out) memcpy(alpha_out, alpha_h, n * sizeof(double));
     if (want >= 2 && nlZ_out) {
         const double logdet = sc_host[0], ztz = sc_host[1];
         *nlZ_out = 0.5 * ztz / sn2 + logdet + 0.5 * (double)n * log(2.0 * M_PI * sn2);
@@ -1464,7 +1102,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         f->sn2 = sn2; f->sw = 1.0 / sqrt(sn2); f->Wd = nullptr;
         CHK(spool_take(c, np * sizeof(double), (void**)&f->alpha));
         HIP_TRY(hipMemsetAsync(f->alpha, 0, np * sizeof(double), st));
-        HIP_TRY(hipMemcpyAsync(f->alpha, alpha_h.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(f->alpha, alpha_h, n * sizeof(double), hipMemcpyHostToDevice, st));
         CHK(spool_take(c, (size_t)c->dpad * np * sizeof(double), (void**)&f->XsT));
         HIP_TRY(hipMemcpyAsync(f->XsT, c->XsT, (size_t)c->dpad * np * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1584,7 +1222,7 @@ int pgp_dev_panel_factor(pgp_ctx* c, double* panel, int64_t ld, int64_t rows, in
     int info = 0;
     HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    CHK(potrf_server_status(c));
+    CHK(potrf_diag_status(c));
     return info != 0 ? (info > w ? w : info) : PGP_OK;
 }
 
@@ -1643,7 +1281,7 @@ int pgp_potrf(pgp_ctx* c, const double* A, int64_t n, double* L_out) {
     int info = 0;
     HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    CHK(potrf_server_status(c));
+    CHK(potrf_diag_status(c));
     if (c->prof) prof_collect(c);
     if (info != 0) return info > (int)n ? (int)n : info;
     // device holds column-major lower L; numpy wants row-major lower => transpose on the host

@@ -51,7 +51,7 @@ struct GemmArgs {
     int tile;               // 128 or 64
     const int* order;       // optional (ti,tj) pairs per block (XCD-aware / LPT tile order built on the host); grid = norder
     int norder;
-    int dbg;                // experiments only: 1 = no global->LDS restaging in the k-loop, 2 = no barrier, 4 = no C load/store
+    int dbg;                // variant bits (pgp_ctx::gemm_dbg): 64 LDS-DMA staging, 256 lazy C, 512 16-byte epilogue stores
     double flops;           // algorithmic flops of this launch (for profiling; filled by caller)
     // Two-piece row spaces (the factor rows and the fused-inverse rows of a Cholesky sweep live in separate buffers so
     // that a posterior handle only keeps the factor).  Tile rows i0 >= *_split (relative to the operand's row 0, a
@@ -63,20 +63,10 @@ struct GemmArgs {
     const double* Cin; long ldcin; const double* Cin2; long ldcin2;
     int rev_cols;           // rectangular grids: tile columns enumerated last-to-first (KM_LT_J: the long-k tiles start first)
     int zero_from;          // > 0: tile rows i0 >= zero_from take beta = 0 (rows touched for the first time: never read)
-    // Staged columns (look-ahead Cholesky): with Cin set, only tiles with j0 < stage_cols write to C / C2 (the staging
-    // buffer); the other tiles update Cin / Cin2 in place.  stage_cols == 0 with Cin set: every tile goes to C.
-    int stage_cols;
-    int skip_stage_diag;    // 1: tiles with i0 < stage_cols and j0 < stage_cols are not computed (the next panel's diagonal
-                            //    block belongs to the resident server, which updates its private copy itself)
-    // Device-side completion signal: every tile with j0 < sig_cols releases its stores and bumps *sig_counter; the
-    // tile that brings it to sig_total stores 1 to *sig_flag (what the resident diagonal-panel server polls).
-    unsigned* sig_counter; unsigned* sig_flag; int sig_cols; unsigned sig_total;
-    unsigned* sig2_counter; unsigned* sig2_flag; int sig2_cols; unsigned sig2_total;      // a second, independent signal
-    long long* stamps;      // experiments: 4 wall-clock stamps per workgroup (start, first MFMA, loop end, stores done)
+    // Batched launches whose products shrink with the batch index z (the owned column panels of a block-cyclic sweep):
+    // product z has M - z * batch_dm rows (tiles beyond them exit at once) and its first-touch row moves up with it.
+    int batch_dm;
 };
 
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st);
-// two independent products in one grid (both must qualify for the 128-tile LDS-DMA form: gemm_f64_dual_ok)
 bool gemm_f64_uses_dma128(const GemmArgs& g);       // would gemm_f64_launch pick the LDS-DMA 128-tile instantiation?
-bool gemm_f64_dual_ok(const GemmArgs& a, const GemmArgs& b);
-int gemm_f64_dual_launch(const GemmArgs& a, const GemmArgs& b, hipStream_t st);

@@ -39,26 +39,24 @@ struct pgp_ctx {
     int device = 0;
     std::vector<int> composite;         // postfix program of kind PGP_COV_COMPOSITE (pgp_set_composite)
     hipStream_t st = nullptr;
-    hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky
-    hipStream_t st3 = nullptr;          // panel-solve stream (sweep v2 with the resident server)
-    hipStream_t st_fill = nullptr;      // low-priority filler stream: B^-1 accumulated panel by panel under the sweep (eet_overlap)
+    hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky (high priority)
     std::vector<hipEvent_t> fill_ev;
     double* eet_out = nullptr;          // set by the fit for the duration of one sweep: where the filler accumulates B^-1
     long eet_ld = 0;
-    hipEvent_t eet_join = nullptr;      // non-null: the sweep queued every panel product; the fit joins st_fill on this event
-    int eet_tail = 1;                   // the last eet_tail panels go into ONE final product (longer K, after the sweep)
+    hipEvent_t eet_join = nullptr;      // non-null: the sweep queued every panel product; the fit joins on this event
     int eet_tile = 128;                 // tile size of the filler products (64: shorter workgroups in the way of the chain)
     int eet_first = -1;                 // inline filler: panels 0 .. eet_first are folded into one product (-1: a sixth of the panels)
-    int eet_merge = 0;                  // inline filler: 1 = same grid as TU_b (gemm_f64_dual_kernel), 0 = its own launch behind it
-    int eet_overlap = 3;                // B^-1 = sum_p E_p E_p^T accumulated under the sweep: 0 off (one product after it), 1 on a
-                                        // low-priority filler stream, 2 inline on the main stream, 3 inline when npanel <= eet_max_panels
+    int eet_overlap = 3;                // B^-1 = sum_p E_p E_p^T accumulated under the sweep: 0 off (one product after it), 2 behind
+                                        // every TU_b on the main stream, 3 the same when npanel <= eet_max_panels
     int eet_max_panels = 32;
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
-    int ep_resident = 0;                // EP: one resident kernel per 128-site block (grid barrier between its 8 steps) instead of 8 dependent
-                                        // launches.  Measured: 52.7 against 50.7 ms per cfg-5 fit -- a counter barrier over 22 workgroups through
-                                        // memory-side atomics costs as much as the launch gap it replaces; kept as an option (parity-tested)
-    int ep_graph = 0;                   // EP: replay each 128-site block as a captured hipGraph (measured: no gain)
+    int diag_fused = 1;                 // D(p) as ONE launch of 16 cooperating workgroups (csrc/panel.hip diag_panel_kernel);
+                                        // 0 = the chain of 13 small launches (leaf_potrf / trsm_rows / inner update)
+    unsigned* dflags = nullptr;         // barrier counter + error word of the fused diagonal-panel kernel
+    unsigned dp_base = 0;               // next barrier ticket (advanced per launch; the counter is never reset)
+    bool dp_used = false;
+    double dp_timeout_s = 10.0;         // every spin of the fused kernel is bounded
     int ep_fused = 2;                   // EP parameter recomputation: 0 blocked multi-rhs solve, 1 through the fused inverse (V' = K diag(sW)
                                         // L^-T as one product), 2 K diag(sW) as dense right-hand-side rows of the sweep
     int ep_r_direct = 1;                // EP gradient: sW sW' o B^-1 = S - S Sigma S from the rebuilt Sigma; 0 = triangular inverse + W'W
@@ -66,10 +64,6 @@ struct pgp_ctx {
     int ep_sym = 1;                     // EP: Sigma kept current in its lower triangle only (folds and K - V'V on the lower tiles)
     int ep_block = 1;                   // EP: blocked site sweep (rank-1 updates folded every 128 sites); 0 = update Sigma per site
     int fused_inverse = 1;              // 1: L^-T falls out of the Cholesky sweep (appended identity rows); 0: recursive trtri
-    hipStream_t st_pan_masked = nullptr;  // panel stream restricted to the reserved CUs (complement of st_masked's mask)
-    hipStream_t st_masked = nullptr;    // main stream of the look-ahead Cholesky restricted to a CU subset (option cu_reserve)
-    int cu_reserve = 0;                 // reserve every cu_reserve-th CU for the panel stream (0 = off)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop;
     // pooled device buffers, keyed by byte size
     std::mutex pool_mu;                 // pgp_factor_free may run on another thread (Python finalizers / cyclic GC)
@@ -87,32 +81,21 @@ struct pgp_ctx {
            *rvec = nullptr, *zvec = nullptr, *partial = nullptr, *scal = nullptr;
     long partial_cap = 0;
     int* info_dev = nullptr;
-    // Cholesky sweep v2: diagonal-panel scratch (2w x w, w <= 1024), its leaf operand images, column staging buffer
-    double *Dk = nullptr, *dpack = nullptr, *Xs = nullptr, *Yn = nullptr;
-    double* Dt = nullptr;               // E_D transposed (w x w): B operand of the panel solve in the LDS-DMA GEMM's layout
-    int half_wave = 0;                  // trailing updates with <= 256 tiles: 1 = one workgroup per CU, 2 = 64-tiles
-    int xcd_max_k = 512;                // ... and a k extent of at most this
-    int xcd_min_tiles = 256;            // xcd_order applies to launches with at least this many 128-tiles
+    // results of one fit, gathered on the device and fetched with ONE copy into pinned host memory (three separate copies
+    // into pageable memory cost ~270 us per N = 8192 fit: each is staged and synchronised by the runtime)
+    double* res_dev = nullptr;          // [info | 8 scalars + ncov + 1 gradient sums | alpha (np)]
+    double* res_host = nullptr;         // pinned
+    double* in_host = nullptr;          // pinned staging of the per-fit inputs (prior mean, scales)
+    size_t res_cap = 0, in_cap = 0;
+    // Cholesky sweep: diagonal-panel scratch (2w x w, w <= 1024), its leaf operand images, column staging buffer
+    double *Dk = nullptr, *dpack = nullptr, *Xs = nullptr;
+    int xcd_max_k = 512;                // xcd_order applies up to this k extent ...
+    int xcd_min_tiles = 256;            // ... to launches with at least this many 128-tiles
     int xcd_super = 8;                  // xcd_order: super-tile edge in tiles
     int solve_outer = 8;                // leaves per outer panel of the blocked multi-rhs triangular solve (K = 128 solve_outer)
     int predict_batch = 16384;          // test points per batch of pgp_predict (scratch: np x batch doubles)
     int s_tile = 0;                     // tile size of the panel solves: 0 = automatic
-    int s_dma = 0;                      // 1: panel solves read a transposed copy of E_D (n-contiguous, the LDS-DMA GEMM form; measured neutral); 0: K-contiguous E_D
     size_t Xs_bytes = 0;
-    unsigned* dflags = nullptr;         // barrier counter / error word / go[p] / done[p] of the resident diagonal-panel server
-    hipEvent_t ev_ds = nullptr, ev_ds2 = nullptr;
-    int dserver = 0;                    // 1: diagonal panels factored by the resident server kernel (left-looking, runs ahead of the
-                                        //    bulk); 0: by 13 launches each on the panel stream.  Measured equal single-stream (13.5 ms
-                                        //    at N=8192), the launch chain is better with two fit streams per GPU (91 vs 81 fits/s)
-    int merge_tu = 0;                   // 1: one trailing-update launch per panel, next diagonal block released by an in-kernel signal
-    int la2 = 0;                        // 1: depth-2 look-ahead on three streams (see potrf_blocked_v2)
-    int s_side = 0;                     // 1: the panel solves S(p) run on a side stream (overlap the tail of the previous trailing update)
-    int ds_fake = 0;                    // experiment only: the server posts done[p] without factoring (WRONG results)
-    int ds_exclusive = 1;               // 1: server workgroups claim a whole CU each (LDS padding)
-    double ds_timeout_s = 10.0;         // every spin of the server (and of the main stream's wait kernel) is bounded
-    long long* ds_ticks = nullptr;      // optional per-phase wall-clock stamps (option ds_ticks)
-    bool ds_used = false;
-    int potrf_v1 = 0;                   // 1: the round-1 sweep (every row in the leaf chain), kept for A/B measurements
     hipEvent_t ev[PGP_NSTAGE + 2];
     double last_ms[PGP_NSTAGE];
     // profiling
@@ -123,9 +106,8 @@ struct pgp_ctx {
     int64_t pc_launch[PC_COUNT];
     // cached tile-order tables (device), keyed by (mt, nt, tri, tri_off_tiles)
     std::map<std::vector<int>, std::pair<int*, int>> orders;
-    // GEMM variant bits (also the experiment switches of gemm_f64 / gemm_tile.h): 64 LDS-DMA operand staging, 256 lazy C
-    // (fetched during the k-loop into the registers the DMA frees), 512 16-byte epilogue stores -- the measured-best set;
-    // 1/2/4/8 ablations, 16 atomic epilogue, 32 de-phased workgroups, 128 phase stamps
+    // GEMM variant bits: 64 LDS-DMA operand staging, 256 lazy C (fetched during the k-loop into the registers the DMA
+    // frees), 512 16-byte epilogue stores -- the measured-best set; clearing a bit selects the plain form (tests)
     int gemm_dbg = 64 | 256 | 512;
     int xcd_order = 0;    // 1: XCD-aware super-tile order for bulk launches (see gemm_prof): -40 % FETCH per launch, 1-3 % slower
     // options
@@ -307,7 +289,7 @@ void prof_collect(pgp_ctx* c);
 static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int flags, int der, long d, CovSpec& cs);
 int cov_point_value(pgp_ctx* c, const CovSpec& cs, int train, double* out);
-int potrf_server_status(pgp_ctx* c);
+int potrf_diag_status(pgp_ctx* c);
 int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse = false, double* E = nullptr,
                   long lde = 0);
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);

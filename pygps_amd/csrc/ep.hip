@@ -403,57 +403,6 @@ __global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double
     ep_sites_lazy_body<false>(Sig, ld, np, base, j0, S, cvec, qvec, mu_blk, m, y, ttau_prev, tnu_prev, ttau_cur, tnu_cur, eps_lds);
 }
 
-// One 128-site block of the sweep as ONE resident kernel: the nsite / EPT steps that ep_sites_lazy_kernel runs as
-// dependent launches (19.8 us of work + ~7 us of launch gap each at N = 4096) become iterations separated by a counter
-// barrier over the grid.  What crosses workgroups between two steps is small -- rows i_t of the factor columns made so
-// far (written by whichever workgroup owns those rows) and the (c, q) entries of workgroup 0 -- and travels through
-// agent-scope loads / stores (coherent across the XCD L2s), so the barrier is one atomic counter without cache-wide
-// write-back / invalidate.  Measured at N = 4096: 52.7 ms per fit against 50.7 with eight launches per block (the same with
-// release / acquire fences instead of coherent accesses): draining the write-through stores plus one round of memory-side
-// atomics costs the ~7 us a dependent launch costs.  Option ep_resident, off by default.  The grid must be co-resident: the host only takes this path for grids <= the CU
-// count (37 KB of LDS and 256 threads per workgroup fit beside anything else that runs).  flags[0] counts arrivals
-// monotonically over the launches of a fit (epoch0 = barriers already passed), flags[1] != 0 = a wait timed out.
-__global__ __launch_bounds__(EPS_THREADS) void ep_block_resident_kernel(const double* __restrict__ Sig, long ld, long np,
-                                                                const long* __restrict__ base, int nsite, double* __restrict__ S,
-                                                                double* __restrict__ cvec, double* __restrict__ qvec,
-                                                                const double* __restrict__ mu_blk, const double* __restrict__ m,
-                                                                const double* __restrict__ y,
-                                                                const double* __restrict__ ttau_prev,
-                                                                const double* __restrict__ tnu_prev,
-                                                                double* __restrict__ ttau_cur, double* __restrict__ tnu_cur,
-                                                                unsigned* flags, unsigned epoch0, long long timeout_ticks) {
-    extern __shared__ __attribute__((aligned(16))) double eps_lds[];
-    __shared__ int s_ok;
-    unsigned epoch = epoch0;
-    if (__hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;     // an earlier block gave up
-    for (int j0 = 0; j0 < nsite; j0 += EPT) {
-        ep_sites_lazy_body<true>(Sig, ld, np, base, j0, S, cvec, qvec, mu_blk, m, y, ttau_prev, tnu_prev, ttau_cur, tnu_cur, eps_lds);
-        if (j0 + EPT >= nsite) break;
-        // ---- grid barrier: drain this wave's stores, release, arrive, poll, acquire ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        ++epoch;
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = epoch * gridDim.x;
-            const long long t0 = wall_clock64();
-            int ok = 1;
-            while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (__hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
-                if (wall_clock64() - t0 > timeout_ticks) {
-                    __hip_atomic_store(flags + 1, 1u + (unsigned)j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-            }
-            s_ok = ok;
-        }
-        __syncthreads();
-        if (!s_ok) return;
-    }
-}
-
 // Sc(:,k) = c_k S(:,k)
 __global__ __launch_bounds__(256) void ep_colscale_kernel(const double* __restrict__ S, double* __restrict__ Sc, long ld,
                                                           long np, const double* __restrict__ cvec) {
@@ -566,8 +515,6 @@ struct EpWork {
     double *S, *Sc, *cq, *prev;          // blocked sweep: factor columns, scaled copy, (c, q) vectors, (ttau, tnu) snapshot
     long* base;                          // first site of the current block (device scalar read by the captured launches)
     long* bases;                         // bases[b] = b * EPB: the launches of block b read their offset from here
-    unsigned* bar = nullptr;             // resident block kernel: [0] barrier arrivals (monotonic over the fit), [1] timeout flag
-    unsigned bar_epoch = 0;              // barriers passed so far (host-side count)
 };
 
 }  // namespace
@@ -647,7 +594,7 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     HIP_TRY(hipMemcpyAsync(dsig_h.data(), w.diag_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(sc, c->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    CHK(potrf_server_status(c));
+    CHK(potrf_diag_status(c));
     // -log marginal likelihood (inf.py:184-188): the per-site terms were reduced on the device (ep_site_terms_kernel, queued
     // before the copies above); the block partials are added here in block order
     double slZ = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0, t6 = 0.0;
@@ -734,7 +681,6 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     EP_TRY(dalloc(&w.cq, (size_t)2 * EPB * sizeof(double)));
     EP_TRY(dalloc(&w.prev, (size_t)2 * np * sizeof(double)));
     { double* b8 = nullptr; EP_TRY(dalloc(&b8, 64)); w.base = (long*)b8; }
-    { double* f8 = nullptr; EP_TRY(dalloc(&f8, 64)); w.bar = (unsigned*)f8; HIP_TRY(hipMemsetAsync(w.bar, 0, 64, st)); }
     {
         double* bb = nullptr;
         const long nb = np / EPB + 1;
@@ -789,9 +735,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemsetAsync(w.tnu_d, 0, np * sizeof(double), st));
     }
     HIP_TRY(hipFuncSetAttribute((const void*)ep_sites_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EPS_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void*)ep_block_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EPS_LDS_BYTES));
     stamp("K built, nlZ0");
-    hipGraphExec_t block_graph = nullptr;             // one block of the blocked sweep (EPB / EPT site launches + fold)
     const double tol = 1e-4;
     const int max_sweep = 10, min_sweep = 2;
     double nlZ_old = INFINITY;
@@ -835,15 +779,6 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
             auto block_launches = [&](int nsite, bool do_fold, const long* base = nullptr, long fold_r0 = -1) -> int {
                 if (!base) base = w.base;
                 int j = 0;
-                const unsigned grid = (unsigned)((np + EPS_ROWS - 1) / EPS_ROWS);
-                if (c->ep_resident && !c->ep_graph && nsite == EPB && grid <= (unsigned)c->prop.multiProcessorCount) {
-                    // the whole block as ONE resident kernel (grid barrier between the EPB / EPT steps)
-                    hipLaunchKernelGGL(ep_block_resident_kernel, dim3(grid), dim3(EPS_THREADS), EPS_LDS_BYTES, st, w.Sig, np, np,
-                                       base, nsite, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
-                                       w.tnu_d, w.bar, w.bar_epoch, (long long)200000000);      // 2 s of 100 MHz ticks
-                    w.bar_epoch += (unsigned)(nsite / EPT - 1);
-                    j = nsite;
-                }
                 for (; j + EPT <= nsite; j += EPT)
                     hipLaunchKernelGGL(ep_sites_lazy_kernel, dim3((unsigned)((np + EPS_ROWS - 1) / EPS_ROWS)), dim3(EPS_THREADS), EPS_LDS_BYTES, st, w.Sig, np, np,
                                        base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
@@ -856,25 +791,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                 return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
             };
             const long nfull = n / EPB;
-            if (nfull > 0 && !c->prof && c->ep_graph && !block_graph) {               // capture one full block once per fit
-                HIP_TRY(hipStreamSynchronize(st));
-                if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    const int rc_cap = block_launches(EPB, true);
-                    hipGraph_t gr = nullptr;
-                    const hipError_t e_end = hipStreamEndCapture(st, &gr);
-                    if (rc_cap == PGP_OK && e_end == hipSuccess && gr &&
-                        hipGraphInstantiate(&block_graph, gr, nullptr, nullptr, 0) != hipSuccess) block_graph = nullptr;
-                    if (gr) (void)hipGraphDestroy(gr);
-                    (void)hipGetLastError();
-                }
-                if (c->ep_graph == 2) fprintf(stderr, "ep block graph %s\n", block_graph ? "captured" : "NOT captured (falling back to launches)");
-            }
-            for (long b = 0; b < nfull; ++b) {
-                if (block_graph) {                                   // the captured launches read the offset from base[0]
-                    hipLaunchKernelGGL(ep_set_base_kernel, dim3(1), dim3(1), 0, st, w.base, b * EPB);
-                    HIP_TRY(hipGraphLaunch(block_graph, st));
-                } else EP_TRY(block_launches(EPB, true, w.bases + b, c->ep_sym ? (b + 1) * EPB : -1));
-            }
+            for (long b = 0; b < nfull; ++b) EP_TRY(block_launches(EPB, true, w.bases + b, c->ep_sym ? (b + 1) * EPB : -1));
             if (n % EPB) EP_TRY(block_launches((int)(n % EPB), false, w.bases + nfull));
             // Sigma / mu are rebuilt from (ttau, tnu) by ep_compute_params below: the last partial block need not be folded
         } else
@@ -886,25 +803,12 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         }
         HIP_TRY(hipMemcpyAsync(ttau.data(), w.ttau_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
-        unsigned bar_h[2] = {0, 0};
-        if (w.bar_epoch) HIP_TRY(hipMemcpyAsync(bar_h, w.bar, sizeof(bar_h), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (bar_h[1] != 0) {                                 // a grid barrier of the resident block kernel gave up
-            char msg[128];
-            snprintf(msg, sizeof(msg), "EP resident block kernel: grid barrier timed out (code %u)", bar_h[1]);
-            pgp_set_last_hip_error(hipErrorLaunchTimeOut, msg, __FILE__, __LINE__);
-            if (block_graph) (void)hipGraphExecDestroy(block_graph);
-            return PGP_ERR_HIP;
-        }
         stamp("sweep done (synced)");
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // inf.py:772
         stamp("params recomputed");
-        if (rc != PGP_OK) {
-            if (block_graph) { (void)hipStreamSynchronize(st); (void)hipGraphExecDestroy(block_graph); }
-            return rc;
-        }
+        if (rc != PGP_OK) return rc;
     }
-    if (block_graph) { (void)hipStreamSynchronize(st); (void)hipGraphExecDestroy(block_graph); block_graph = nullptr; }
     if (sweeps_out) *sweeps_out = sweep;
     memcpy(ttau_io, ttau.data(), n * sizeof(double));
     memcpy(tnu_io, tnu.data(), n * sizeof(double));

@@ -25,8 +25,6 @@ namespace {
 
 using gemm_tile_ns::BK;
 
-__device__ int g_cu_arrivals[4096];       // de-phasing experiment (gemm_dbg & 32): arrivals per CU
-
 // tile (ti, tj) of workgroup number b of a launch described by g; false: padding entry, nothing to do
 __device__ __forceinline__ bool decode_tile(const GemmArgs& g, int b, int T, int& ti, int& tj) {
     if (g.order) {                                  // host-built tile order (see tile_order() in capi.hip)
@@ -49,67 +47,32 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs& g, int b, int T, int
     return true;
 }
 
-// Two independent products in ONE grid: workgroups [0, na) work on `a`, the rest on `b`.  Used by the Cholesky sweep to
-// append panel p's share of B^-1 = E E^T to the trailing update TU_b(p): consecutive launches on one stream drain the
-// chip at every boundary (the partial last wave of one kernel runs alone), a merged grid has one tail instead of two.
-struct GemmArgsPair { GemmArgs g[2]; int na; };
-template <int TM, int TN, bool AKC, bool BKC, bool DMA>
-__global__ __launch_bounds__(256, 2) void gemm_f64_dual_kernel(GemmArgsPair p) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int na = p.na;
-    const bool second = (int)blockIdx.x >= na;
-    const GemmArgs& g = p.g[second ? 1 : 0];        // uniform index into the kernarg segment: scalar loads, no private copy
-    int ti, tj;
-    if (!decode_tile(g, second ? (int)blockIdx.x - na : (int)blockIdx.x, TM, ti, tj)) return;
-    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA>(g, ti, tj, 0, smem);
-}
-
-template <int TM, int TN, bool AKC, bool BKC, bool DMA = false, bool EXP = false>
+template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int ti, tj;
     if (!decode_tile(g, (int)blockIdx.x, TM, ti, tj)) return;
-    if ((g.dbg & 32) && blockIdx.x < 512) {          // experiment: de-phase the two workgroups that share a CU (first wave only)
-        __shared__ int s_par;
-        if (threadIdx.x == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, 32 bits
-            const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u; // HW_REG_XCC_ID
-            const unsigned key = (xcc << 8) | ((hw >> 8) & 0xffu);                                  // cu_id, sh_id, se_id
-            s_par = atomicAdd(&g_cu_arrivals[key & 4095u], 1) & 1;
-        }
-        __syncthreads();
-        if (s_par) {
-            const long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < 7000) __builtin_amdgcn_s_sleep(10);                        // ~70 us = half a K=512 tile
-        }
-    }
-    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, EXP>(g, ti, tj, blockIdx.z, smem);
+    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA>(g, ti, tj, blockIdx.z, smem);
 }
 
-template <int T, bool AKC, bool BKC, bool DMA = false, bool EXP = false>
+template <int T, bool AKC, bool BKC, bool DMA = false>
 int launch_t(const GemmArgs& g, hipStream_t st) {
     constexpr int SK = BK + 2;
     constexpr int ASZ = AKC ? T * SK : BK * (T + 16);
     constexpr int BSZ = BKC ? T * SK : BK * (T + 16);
-    const size_t shm = 2 * (ASZ + BSZ) * sizeof(double) + ((g.dbg & 8) ? 20000 : 0);   // dbg 8: force 1 workgroup / CU
+    const size_t shm = 2 * (ASZ + BSZ) * sizeof(double);
     const int mt = g.M / T, nt = g.N / T;
     unsigned nblk = (g.tri == 2) ? (unsigned)((long)mt * (mt + 1) / 2) : (unsigned)(mt * nt);
     if (g.order) nblk = (unsigned)g.norder;
     dim3 grid(nblk, 1, g.batch > 0 ? g.batch : 1);
     static std::atomic<size_t> attr_set{0};          // two fit streams (host threads) launch concurrently
     if (attr_set.load(std::memory_order_acquire) < shm) {
-        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC, DMA, EXP>,
+        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC, DMA>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set.store(shm, std::memory_order_release);
     }
-    hipLaunchKernelGGL((gemm_f64_kernel<T, T, AKC, BKC, DMA, EXP>), grid, dim3(256), shm, st, g);
+    hipLaunchKernelGGL((gemm_f64_kernel<T, T, AKC, BKC, DMA>), grid, dim3(256), shm, st, g);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
-}
-
-static unsigned grid_blocks(const GemmArgs& g, int T) {
-    const int mt = g.M / T, nt = g.N / T;
-    if (g.order) return (unsigned)g.norder;
-    return (g.tri == 2) ? (unsigned)((long)mt * (mt + 1) / 2) : (unsigned)(mt * nt);
 }
 
 static bool dma_ok(const GemmArgs& g) {
@@ -128,34 +91,10 @@ int launch_l(const GemmArgs& g, hipStream_t st) {
 
 bool gemm_f64_uses_dma128(const GemmArgs& g) { return dma_ok(g); }
 
-bool gemm_f64_dual_ok(const GemmArgs& a, const GemmArgs& b) {
-    return dma_ok(a) && dma_ok(b) && a.batch <= 1 && b.batch <= 1 && a.M > 0 && a.N > 0 && b.M > 0 && b.N > 0 &&
-           !b.sig_counter && !b.sig2_counter && !a.stamps && !b.stamps;
-}
-
-int gemm_f64_dual_launch(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
-    if (!gemm_f64_dual_ok(a, b)) return -1;
-    constexpr int T = 128;
-    const size_t shm = 2 * 2 * BK * (T + 16) * sizeof(double);
-    const unsigned na = grid_blocks(a, T), nb = grid_blocks(b, T);
-    static std::atomic<size_t> attr_set{0};
-    if (attr_set.load(std::memory_order_acquire) < shm) {
-        (void)hipFuncSetAttribute((const void*)gemm_f64_dual_kernel<T, T, false, false, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set.store(shm, std::memory_order_release);
-    }
-    GemmArgsPair pr;
-    pr.g[0] = a; pr.g[1] = b; pr.na = (int)na;
-    hipLaunchKernelGGL((gemm_f64_dual_kernel<T, T, false, false, true>), dim3(na + nb), dim3(256), shm, st, pr);
-    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
-}
-
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PGP_OK;
     if (g.tile == 64) return launch_l<64>(g, st);
     // LDS-DMA staging (dbg bit 64): 128 x 128 tiles of M-contiguous operands, whole 16-deep k-tiles
-    const bool ablate = (g.dbg & (1 | 2 | 1024)) != 0;        // timing experiments: the instantiations that test those bits
-    if (dma_ok(g)) return ablate ? launch_t<128, false, false, true, true>(g, st) : launch_t<128, false, false, true>(g, st);
-    if (ablate && !g.a_kc && !g.b_kc) return launch_t<128, false, false, false, true>(g, st);
+    if (dma_ok(g)) return launch_t<128, false, false, true>(g, st);
     return launch_l<128>(g, st);
 }

@@ -37,10 +37,8 @@ __device__ __forceinline__ double swap_adjacent(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// EXP: the instantiation that honours the k-loop ablation bits of GemmArgs::dbg (1 no restaging, 2 no barrier, 1024 no DMA
-// wait -- all give wrong results and exist for timing only); the production instantiations compile those tests away, so that
-// a stage of the k-loop is one basic block
-template <int TM, int TN, bool AKC, bool BKC, bool DMA = false, bool EXP = false>
+// A stage of the k-loop is one basic block: nothing run-time selectable is tested inside it.
+template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, long bz, double* __restrict__ smem) {
     static_assert(!DMA || (!AKC && !BKC && TM == 128 && TN == 128), "LDS-DMA staging: 128-wide M-contiguous operands only");
     constexpr int SA = TM + 16, SB = TN + 16, SK = BK + 2;
@@ -52,7 +50,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
     constexpr int BV = TN * BK / 2 / 256;
 
     const int i0 = ti * TM, j0 = tj * TN;
-    if (g.skip_stage_diag && i0 < g.stage_cols && j0 < g.stage_cols) return;
+    // shrinking batch (see GemmArgs::batch_dm): product bz has fewer rows, its first-touch row moves with them
+    if (g.batch_dm && i0 >= g.M - (int)bz * g.batch_dm) return;
+    const int zero_from = g.zero_from > 0 ? g.zero_from - (int)bz * g.batch_dm : 0;
     bool diag = false;
     if (g.tri) {
         if (i0 + g.tri_off < j0) return;
@@ -73,28 +73,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
     const double* __restrict__ A = (a_hi ? g.A2 - g.a_split : g.A) + bz * g.sA;
     const long lda = a_hi ? g.lda2 : g.lda;
     const double* __restrict__ B = g.B + bz * g.sB;
-    const bool inplace = g.Cin && g.stage_cols && j0 >= g.stage_cols;        // not a staged column: update Cin in place
-    double* __restrict__ C = inplace ? (double*)(c_hi ? g.Cin2 - g.c_split : g.Cin)
-                                     : (c_hi ? g.C2 - g.c_split : g.C) + bz * g.sC;
-    const long ldc = inplace ? (c_hi ? g.ldcin2 : g.ldcin) : (c_hi ? g.ldc2 : g.ldc);
+    double* __restrict__ C = (c_hi ? g.C2 - g.c_split : g.C) + bz * g.sC;
+    const long ldc = c_hi ? g.ldc2 : g.ldc;
     const double* __restrict__ Cin = g.Cin ? (c_hi ? g.Cin2 - g.c_split : g.Cin) : C;
     const long ldcin = g.Cin ? (c_hi ? g.ldcin2 : g.ldcin) : ldc;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int xdbg = EXP ? g.dbg : 0;              // ablation bits, only in the EXP instantiation
-#define GT_STAMP(i) do { if (g.stamps && t == 0) g.stamps[4L * blockIdx.x + (i)] = wall_clock64(); } while (0)
-    GT_STAMP(0);
     const int wm = (wave & 1) * (TM / 2), wn = (wave >> 1) * (TN / 2);
     const int l15 = lane & 15, l4 = lane >> 4;
 
     // ---- accumulators, pre-loaded with (beta/alpha)*C (== alpha*beta*C for alpha = +-1) ------
     double4_t acc[FM][FN];
     const double ab = g.beta / g.alpha;
-    // in-place tiles with beta = 1 may skip the C pre-load entirely: acc starts at zero and the epilogue adds alpha*acc
-    // to C with fire-and-forget global_atomic_add_f64 (ONE add per element per launch: bitwise deterministic)
-    const bool atomic_c = (g.dbg & 16) && g.beta == 1.0 && (!g.Cin || inplace) && !(g.zero_from && i0 >= g.zero_from);
-    const bool wantc = g.beta != 0.0 && !(g.dbg & 4) && !(g.zero_from && i0 >= g.zero_from) && !atomic_c;
+    const bool wantc = g.beta != 0.0 && !(zero_from > 0 && i0 >= zero_from);
     // LDS-DMA variant: the staging registers it frees hold one quarter of the C tile at a time, fetched DURING the k-loop
     // and folded into the accumulators two k-steps later ("lazy C": the pre-load no longer delays the first MFMA)
     const bool lazyc = DMA && wantc && (g.dbg & 256) && (k1 - k0) >= (FN * FM + 2) * BK;
@@ -221,10 +213,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             sstore(0);
         }
         __syncthreads();
-        if (g.stamps) {                       // the C pre-load has landed when its first use can issue
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            GT_STAMP(1);
-        }
         // fragments are double-buffered in registers: the LDS reads of k-substep ks+1 are issued BEFORE the 16 MFMAs of
         // substep ks, so their latency hides behind 1024 cycles of matrix work.  The same holds ACROSS the stage barrier:
         // the last substep's MFMAs of a stage are held back until after the barrier and issued behind the first fragment
@@ -261,15 +249,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             constexpr int buf = decltype(bufc)::value;
             const bool more = kt + BK < k1;
             if constexpr (DMA) { if (more) dma_stage(IC<(buf ^ 1)>{}); }     // the other stage was last read before the previous barrier
-            else if (more && !(xdbg & 1)) gload(kt + BK);
+            else if (more) gload(kt + BK);
 #pragma unroll
             for (int ks = 0; ks + 1 < NS; ++ks) {
                 ldfrag(buf, ks + 1, (ks + 1) & 1);
                 mfmas(ks & 1);
             }
-            if constexpr (DMA) { if (!(xdbg & 1024)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // dbg 1024: timing experiment (wrong results)
-            else if (more && !(xdbg & 1)) sstore(buf ^ 1);
-            if (!(xdbg & 2)) __syncthreads();
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (more) sstore(buf ^ 1);
+            __syncthreads();
             if (more) ldfrag(buf ^ 1, 0, NS & 1); // first fragments of the next stage, behind ...
             __builtin_amdgcn_sched_barrier(0);    // (keep the reads AHEAD of the MFMAs: the scheduler sinks them behind otherwise)
             mfmas((NS - 1) & 1);                  // ... the held-back last substep of this one
@@ -308,9 +296,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         }
     }
 
-    GT_STAMP(2);
     // ---- epilogue: C = alpha * acc ---------------------------------------------------------
-    if (!diag && !atomic_c && !(g.dbg & 4) && (g.dbg & 512) && !(ldc & 1) && !((unsigned long)C & 15ul)) {
+    if (!diag && (g.dbg & 512) && !(ldc & 1) && !((unsigned long)C & 15ul)) {
         // 16-byte stores: adjacent lanes (rows m, m+1) trade one value each by a DPP quad_perm, then the even lane stores
         // rows {m, m+1} of column n(r), the odd lane rows {m-1, m} of column n(r+1): half the store instructions (the
         // epilogue is store-ISSUE bound: 64 global_store_dwordx2 per lane otherwise).  C is 16-byte aligned at even rows.
@@ -341,30 +328,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = nb + 4 * r;
-                if ((!diag || m >= n) && (!(g.dbg & 4) || acc[im][in][r] == 12345.678)) {
-                    if (atomic_c) unsafeAtomicAdd(cp + (long)(4 * r) * ldc, g.alpha * acc[im][in][r]);
-                    else cp[(long)(4 * r) * ldc] = g.alpha * acc[im][in][r];
-                }
-            }
-        }
-    }
-    if (g.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GT_STAMP(3); }
-#undef GT_STAMP
-    // ---- completion signal for the resident diagonal-panel server (cdna guide G16: drain, barrier, ONE release) ----
-    const bool s1 = g.sig_counter && j0 < g.sig_cols, s2 = g.sig2_counter && j0 < g.sig2_cols;
-    if (s1 || s2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (s1) {
-                const unsigned prev = __hip_atomic_fetch_add(g.sig_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (prev + 1 == g.sig_total) __hip_atomic_store(g.sig_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (s2) {
-                const unsigned prev = __hip_atomic_fetch_add(g.sig2_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (prev + 1 == g.sig2_total) __hip_atomic_store(g.sig2_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!diag || m >= n) cp[(long)(4 * r) * ldc] = g.alpha * acc[im][in][r];
             }
         }
     }

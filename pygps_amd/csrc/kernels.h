@@ -15,22 +15,14 @@ int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, long wstride
 int trsv_bwd_launch(const double* L, long ldl, const double* W, long ldw, double* z, double* a_out, int nblk,
                     hipStream_t st);
 int diag_in_launch(const double* src, long lds, double* D, long ldd, int w, hipStream_t st);
-int diag_out_launch(const double* D, long ldd, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st,
-                    double* Dt = nullptr, long ldt = 0);
-size_t diag_server_flag_bytes();
-int diag_server_max_panels();
-unsigned* diag_server_counter(unsigned* flags, int p);
-unsigned* diag_server_go_flag(unsigned* flags, int p);
-unsigned* diag_server_counter2(unsigned* flags, int p);
-unsigned* diag_server_stage_flag(unsigned* flags, int p);
-int diag_server_wait_staged(unsigned* flags, int p, double timeout_s, hipStream_t st);
-int diag_server_err_index();
-int diag_server_launch(double* Dk, long dk_stride, double* dpack, double* F, long ldf, double* E, long lde,
-                       const double* Xs, long ldx, long xs_stride, double* Yn, int nblk, int q, unsigned* flags, int* info,
-                       double timeout_s, long long* ticks, hipStream_t st, bool exclusive = true, int fake = 0);
-int diag_server_go(unsigned* flags, int p, hipStream_t st);
-int diag_server_post(unsigned* flag, hipStream_t st);
-int diag_server_wait(unsigned* flags, int p, double timeout_s, hipStream_t st);
+int diag_out_launch(const double* D, long ldd, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st);
+// D(p) of the Cholesky sweep as ONE launch (stage in, 4 x [leaf, trsm, update], stage out with a counter barrier between)
+size_t diag_panel_flag_bytes();
+int diag_panel_err_index();
+unsigned diag_panel_tickets(int w);
+int diag_panel_launch(const double* src, long lds, double* Dk, long ldd, double* dpack, double* Fd, long ldf, double* Ed,
+                      long lde, int w, unsigned* flags, unsigned base, int* info, int info_base, double timeout_s,
+                      hipStream_t st);
 int gather_strided_launch(const double* src, long stride, long n, double* dst, hipStream_t st);
 
 // assemble.hip

@@ -450,21 +450,9 @@ __global__ __launch_bounds__(256) void diag_in_kernel(const double* __restrict__
 }
 // L_D (lower part) -> the factor's diagonal block; E_D (whole w x w block, zeros below its diagonal included) -> the
 // fused-inverse rows of this panel (E may be null: no global inverse wanted)
-// Blocks >= w (present when Dt != null): 64 x 64 tiles of E_D transposed through LDS into Dt(n, k) = E_D(k, n), ld ldt --
-// the panel solve Y = X E_D then reads its B operand n-contiguous like every other operand of the LDS-DMA GEMM.
 __global__ __launch_bounds__(256) void diag_out_kernel(const double* __restrict__ D, long ldd, int w,
                                                        double* __restrict__ Fd, long ldf, double* __restrict__ Ed,
-                                                       long lde, double* __restrict__ Dt, long ldt) {
-    if ((int)blockIdx.x >= w) {
-        __shared__ double tile[64][65];
-        const int tb = blockIdx.x - w, nt = w / 64;
-        const int k0 = (tb % nt) * 64, n0 = (tb / nt) * 64;
-        const int a = threadIdx.x & 63, b = threadIdx.x >> 6;
-        for (int r = b; r < 64; r += 4) tile[r][a] = D[w + k0 + a + (long)(n0 + r) * ldd];      // tile[n][k], k contiguous
-        __syncthreads();
-        for (int r = b; r < 64; r += 4) Dt[n0 + a + (long)(k0 + r) * ldt] = tile[a][r];         // n contiguous
-        return;
-    }
+                                                       long lde) {
     const int j = blockIdx.x;
     for (int i = threadIdx.x; i < 2 * w; i += 256) {
         const double v = D[i + (long)j * ldd];
@@ -474,48 +462,51 @@ __global__ __launch_bounds__(256) void diag_out_kernel(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Resident diagonal-panel server.
+// Fused diagonal-panel kernel: D(p) of the Cholesky sweep (capi.hip: potrf_blocked_v2) as ONE launch.
 //
-// The leaf chain of the Cholesky sweep (13 small dependent launches per 512-column panel) loses its CU slots to the
-// 150-250 us workgroups of the concurrent trailing update: measured, the first leaf of a panel waited ~160 us for a
-// slot, its trsm ~70 us, its inner update ~160 us.  So the chain does not queue at all: ONE kernel of DS_WG workgroups
-// is launched per sweep BEFORE any bulk work, stays resident, and factors every diagonal panel block when the main
-// stream says it is ready:
-//     go[p]   (set by a 1-thread kernel on the main stream after TU_a(p-1))  ->  D(p)  ->  done[p]  (main stream waits)
-// Inside, the phases of D(p) (stage in | per leaf: potrf, trsm of the 2w..w rows, K=128 inner update | stage out) are
-// separated by a counter barrier over the DS_WG workgroups (agent-scope release / acquire, cdna guide G16).
-// Every spin is bounded by a wall-clock timeout: on expiry the server posts an error code and exits.
-constexpr int DS_WG = 16;
-constexpr unsigned DS_BAR = 0, DS_ERR = 1, DS_GO = 16, DS_MAXP = 1024, DS_DONE = DS_GO + DS_MAXP, DS_CNT = DS_DONE + DS_MAXP,
-                   DS_STG = DS_CNT + DS_MAXP, DS_CNT2 = DS_STG + DS_MAXP;
+// As 13 small dependent launches (stage in | per leaf: potrf, trsm of the w rows below, K = 128 inner update | stage out)
+// the chain takes ~220 us on an idle chip but ~620 us next to a trailing update (round-3 kernel trace: every launch queues
+// for a CU slot behind 140 us bulk workgroups, the leaf 28 -> 79 us, the 5 us staging kernel 46 us), and the main stream
+// waited ~1.4 ms per N = 8192 fit for it.  Here DP_WG workgroups are launched once per panel and walk the same phases,
+// separated by a counter barrier (agent-scope release / acquire, cdna guide G16): one wait for slots instead of thirteen,
+// no launch gaps on the critical path.  The barrier counter is never reset: a launch uses the tickets
+// [base, base + nbarrier * DP_WG) and the host advances `base` by exactly that amount per launch (wrap-around safe).
+// Every spin is bounded by a wall-clock timeout: on expiry the kernel posts an error code and every workgroup leaves.
+constexpr int DP_WG = 16;
+constexpr unsigned DP_BAR = 0, DP_ERR = 1;
 
-struct DiagServerArgs {
-    double* Dk; long dk_stride;       // two scratch images (2w x w each), alternating by panel parity
-    double* dpack;
-    double* F; long ldf; double* E; long lde;
-    const double* Xs; long ldx; long xs_stride;    // two staging buffers (panel p's columns live in buffer p & 1)
-    double* Yn;                       // w x w scratch of the next-diagonal-block update
-    int nblk, q;
-    int fake;                         // experiment: post done[p] at once (no factorisation): times the bulk schedule alone
-    unsigned* flags; int* info;
+struct DiagPanelArgs {
+    const double* src; long lds;      // the (updated) diagonal block: w x w, lower part read
+    double* Dk; long ldd;             // scratch 2w x w: block on top, identity below
+    double* dpack;                    // per-leaf packed operand images
+    double* Fd; long ldf;             // L_D goes here (lower part)
+    double* Ed; long lde;             // E_D = L_D^-T goes here (whole block; may be null)
+    int w;
+    unsigned* flags; unsigned base;   // barrier counter / error word; first ticket of this launch
+    int* info; int info_base;
     long long timeout_ticks;          // wall_clock64 ticks (100 MHz)
-    long long* ticks;                 // optional: per panel, per phase wall-clock stamps (16 per panel)
 };
 
 __device__ __forceinline__ unsigned ld_flag(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// thread 0 spins until *p >= target (relaxed agent-scope loads), then ONE acquire; false on timeout / posted error
-__device__ __forceinline__ bool ds_wait(unsigned* flags, unsigned idx, unsigned target, long long timeout, int* s_ok) {
+// barrier over the DP_WG workgroups: every wave drains its stores, one lane releases, arrives, polls, acquires
+__device__ __forceinline__ bool dp_barrier(unsigned* flags, unsigned& target, long long timeout, int* s_ok) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    target += DP_WG;
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(flags + DP_BAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long t0 = wall_clock64();
         int ok = 1;
-        while (ld_flag(flags + idx) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (ld_flag(flags + DS_ERR) != 0) { ok = 0; break; }
+        while ((int)(ld_flag(flags + DP_BAR) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (ld_flag(flags + DP_ERR) != 0) { ok = 0; break; }
             if (wall_clock64() - t0 > timeout) {
-                __hip_atomic_store(flags + DS_ERR, 1000u + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(flags + DP_ERR, 1000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
             }
@@ -527,25 +518,12 @@ __device__ __forceinline__ bool ds_wait(unsigned* flags, unsigned idx, unsigned 
     return *s_ok != 0;
 }
 
-// barrier over the DS_WG workgroups: every wave drains its stores, one lane releases, arrives, polls, acquires
-__device__ __forceinline__ bool ds_barrier(unsigned* flags, unsigned& epoch, long long timeout, int* s_ok) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    ++epoch;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(flags + DS_BAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return ds_wait(flags, DS_BAR, epoch * DS_WG, timeout, s_ok);
-}
-
-// The three phase bodies are real calls (noinline): inlined together they need > 256 VGPRs and spill; as separate
-// functions each keeps the allocation of its stand-alone kernel (leaf 225, trsm, gemm tile < 256).
-__device__ __noinline__ void ds_leaf(double* A, long lda, double* pack, int* info, int info_base, double* smem) {
+// The phase bodies are real calls (noinline): inlined together they need > 256 VGPRs and spill; as separate functions
+// each keeps the allocation of its stand-alone kernel (leaf 225, trsm, update < 256).
+__device__ __noinline__ void dp_leaf(double* A, long lda, double* pack, int* info, int info_base, double* smem) {
     leaf_potrf_body(A, lda, pack, info, info_base, nullptr, smem);
 }
-__device__ __noinline__ void ds_trsm(double* X, long ldx, long nrows, const double* pack, long wg, double* smem) {
+__device__ __noinline__ void dp_trsm(double* X, long ldx, long nrows, const double* pack, long wg, double* smem) {
     trsm_rows_body(X, ldx, nrows, pack, wg, smem);
 }
 // K = 128 update of the scratch columns right of a leaf, one wave per 16 rows (no LDS, no workgroup barrier):
@@ -554,7 +532,7 @@ __device__ __noinline__ void ds_trsm(double* X, long ldx, long nrows, const doub
 // wave's own 16 rows of Y (32 doubles per lane, loaded once), the A operand the 16 rows of Y that belong to the target
 // columns -- L2-resident lines shared by every wave.  Window rows < ncols are the symmetric part: only tiles on or
 // below the diagonal are touched there.
-__device__ __noinline__ void ds_update_rows(const double* __restrict__ Xw, double* __restrict__ C, long ldd, int w,
+__device__ __noinline__ void dp_update_rows(const double* __restrict__ Xw, double* __restrict__ C, long ldd, int w,
                                             int ncols, int grp, int part, int nparts) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = (grp * 4 + wave) * 16;
@@ -594,24 +572,24 @@ __device__ __noinline__ void ds_update_rows(const double* __restrict__ Xw, doubl
     }
 }
 
-// stage in: top = lower part of the (updated) diagonal block, bottom = identity.  Workgroup -> columns wg, wg + DS_WG,
+// stage in: top = lower part of the (updated) diagonal block, bottom = identity.  Workgroup -> columns wg, wg + DP_WG,
 // ...; 8 columns (= 8 independent 16-byte loads per thread) per round: the loop is latency-bound.  (Own functions, like
 // the phase bodies: inlined into the kernel next to the calls they were compiled with a handful of registers and spilled.)
-__device__ __noinline__ void ds_stage_in(const double* __restrict__ src, long lds, double* __restrict__ Dk, long ldd, int w,
+__device__ __noinline__ void dp_stage_in(const double* __restrict__ src, long lds, double* __restrict__ Dk, long ldd, int w,
                                          int wg) {
     const int t = threadIdx.x;
-    for (int jb = wg; jb < w; jb += 8 * DS_WG)
+    for (int jb = wg; jb < w; jb += 8 * DP_WG)
         for (int i = 2 * t; i < w; i += 512) {
             double2_t v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = jb + u * DS_WG;
+                const int j = jb + u * DP_WG;
                 v[u] = double2_t{0.0, 0.0};
                 if (j < w && i + 1 >= j) v[u] = *(const double2_t*)(src + i + (long)j * lds);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = jb + u * DS_WG;
+                const int j = jb + u * DP_WG;
                 if (j >= w) continue;
                 double2_t o = v[u];
                 if (i < j) o[0] = 0.0;
@@ -621,15 +599,15 @@ __device__ __noinline__ void ds_stage_in(const double* __restrict__ src, long ld
         }
 }
 // stage out: L_D (lower part) -> factor, E_D (whole block, zeros below its diagonal included) -> inverse rows
-__device__ __noinline__ void ds_stage_out(const double* __restrict__ Dk, long ldd, int w, double* __restrict__ Fd, long ldf,
+__device__ __noinline__ void dp_stage_out(const double* __restrict__ Dk, long ldd, int w, double* __restrict__ Fd, long ldf,
                                           double* __restrict__ Ed, long lde, int wg) {
     const int t = threadIdx.x;
-    for (int jb = wg; jb < w; jb += 4 * DS_WG)
+    for (int jb = wg; jb < w; jb += 4 * DP_WG)
         for (int i = 2 * t; i < w; i += 512) {
             double2_t lo[4], hi[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int j = jb + u * DS_WG;
+                const int j = jb + u * DP_WG;
                 lo[u] = hi[u] = double2_t{0.0, 0.0};
                 if (j < w) {
                     if (i + 1 >= j) lo[u] = *(const double2_t*)(Dk + i + (long)j * ldd);
@@ -638,7 +616,7 @@ __device__ __noinline__ void ds_stage_out(const double* __restrict__ Dk, long ld
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int j = jb + u * DS_WG;
+                const int j = jb + u * DP_WG;
                 if (j >= w) continue;
                 if (i >= j) *(double2_t*)(Fd + i + (long)j * ldf) = lo[u];
                 else if (i + 1 >= j) Fd[i + 1 + (long)j * ldf] = lo[u][1];
@@ -651,196 +629,67 @@ __device__ __noinline__ void ds_stage_out(const double* __restrict__ Dk, long ld
         }
 }
 
-// The server's own GEMM tiles (64 x 64, the latency-friendly shape): the diagonal block of the NEXT panel is brought up
-// to date here, on the server's CUs, instead of waiting for the bulk trailing update to get to it:
-//   (a) Yn = X E_D(p-1)            X = rows of panel p in panel p-1's (staged) columns          [K clipped: k < j0 + 64]
-//   (b) D_top = F_diag(p) - Yn Yn'  lower tiles only; F_diag(p) carries every older panel's update already
-__device__ __noinline__ void ds_tile_nk(const GemmArgs* g, int ti, int tj, double* smem) {
-    gemm_tile_ns::gemm_tile<128, 128, false, true>(*g, ti, tj, 0, smem);
-}
-__device__ __noinline__ void ds_tile_nt(const GemmArgs* g, int ti, int tj, double* smem) {
-    gemm_tile_ns::gemm_tile<128, 128, false, false>(*g, ti, tj, 0, smem);
-}
-__device__ __noinline__ void ds_identity_bottom(double* __restrict__ Dk, long ldd, int w, int wg) {
-    const int t = threadIdx.x;
-    for (int j = wg; j < w; j += DS_WG)
-        for (int i = 2 * t; i < w; i += 512)
-            *(double2_t*)(Dk + w + i + (long)j * ldd) = double2_t{i == j ? 1.0 : 0.0, i + 1 == j ? 1.0 : 0.0};
-}
-
-__global__ __launch_bounds__(256, 2) void diag_server_kernel(DiagServerArgs a) {
+__global__ __launch_bounds__(256, 2) void diag_panel_kernel(DiagPanelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int* s_ok = (int*)(smem + 36 * 256 + 256 + 1);            // beside the leaf's info word (all LDS stays dynamic)
-    const int wg = blockIdx.x, t = threadIdx.x;
-    const int npanel = (a.nblk + a.q - 1) / a.q;
-    unsigned epoch = 0;
+    const int wg = blockIdx.x;
+    const int w = a.w, qq = w / 128;
+    const long ldd = a.ldd;
+    unsigned target = a.base;
     // the chain is the critical path and shares its CUs with trailing-update workgroups: win the issue arbitration
     __builtin_amdgcn_s_setprio(3);
-#define STAMP(i) do { if (a.ticks && wg == 0 && t == 0) a.ticks[(long)p * 16 + (i)] = wall_clock64(); } while (0)
-    for (int p = 0; p < npanel; ++p) {
-        const int s0 = p * a.q, s1 = min(s0 + a.q, a.nblk), qq = s1 - s0, w = qq * 128;
-        const long ldd = 2L * w;
-        double* Dc = a.Dk + (long)(p & 1) * a.dk_stride;
-        STAMP(0);
-        if (a.fake) {
-            if (p == 0 && !ds_wait(a.flags, DS_GO, 1u, a.timeout_ticks, s_ok)) return;
-            if (p >= 2 && !ds_wait(a.flags, DS_GO + p, 1u, a.timeout_ticks, s_ok)) return;
-            if (wg == 0 && t == 0) __hip_atomic_store(a.flags + DS_DONE + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
+    dp_stage_in(a.src, a.lds, a.Dk, ldd, w, wg);
+    if (!dp_barrier(a.flags, target, a.timeout_ticks, s_ok)) return;
+    for (int cb = 0; cb < qq; ++cb) {
+        double* Acc = a.Dk + (long)cb * 128 * (1 + ldd);
+        double* pack = a.dpack + (long)cb * PACK_DOUBLES;
+        if (wg == 0) dp_leaf(Acc, ldd, pack, a.info, a.info_base + cb * 128, smem);
+        if (!dp_barrier(a.flags, target, a.timeout_ticks, s_ok)) return;
+        // rows below the leaf inside the scratch: (qq-1-cb) 128 block rows + (cb+1) 128 identity-born rows = w rows
+        for (long g0 = wg; g0 * 64 < w; g0 += DP_WG) {
+            dp_trsm(Acc + 128, ldd, w, pack, g0, smem);
+            __syncthreads();
         }
-        if (p == 0) {
-            if (!ds_wait(a.flags, DS_GO, 1u, a.timeout_ticks, s_ok)) return;
-            STAMP(1);
-            ds_stage_in(a.F, a.ldf, Dc, ldd, w, wg);
-            STAMP(7);
-            if (!ds_barrier(a.flags, epoch, a.timeout_ticks, s_ok)) return;
-        } else {
-            // go[p] (p >= 2) is released from INSIDE trailing update TU(p-2) when its first two column panels are done:
-            // rows p x columns p-1 (staged) and the diagonal block p (in place) then carry every update up to panel p-2
-            if (p >= 2 && !ds_wait(a.flags, DS_GO + p, 1u, a.timeout_ticks, s_ok)) return;
-            STAMP(1);
-            const int wp = a.q * 128;                           // panel p-1 is a full panel
-            const double* Dp = a.Dk + (long)((p - 1) & 1) * a.dk_stride;
-            {
-                GemmArgs g{};
-                g.A = a.Xs + (long)((p - 1) & 1) * a.xs_stride + (long)s0 * 128; g.lda = a.ldx; g.a_kc = 0;
-                g.B = Dp + wp; g.ldb = 2L * wp; g.b_kc = 1;
-                g.C = a.Yn; g.ldc = w;
-                g.M = w; g.N = wp; g.K = wp; g.alpha = 1.0; g.beta = 0.0; g.kmode = KM_LT_J;
-                // 128 x 128 tiles (a 64 x 64 tile needs ~1.3 us per 16-deep k-step on a CU of its own: latency, not MFMA),
-                // longest k-range first: one tile per workgroup when w = 512
-                const int mt = w / 128, nt = wp / 128;
-                for (int tile = wg; tile < mt * nt; tile += DS_WG) ds_tile_nk(&g, tile % mt, nt - 1 - tile / mt, smem);
-            }
-            ds_identity_bottom(Dc, ldd, w, wg);
-            STAMP(7);
-            if (!ds_barrier(a.flags, epoch, a.timeout_ticks, s_ok)) return;
-            {
-                GemmArgs g{};
-                g.A = a.Yn; g.lda = w; g.a_kc = 0;
-                g.B = a.Yn; g.ldb = w; g.b_kc = 0;
-                g.Cin = a.F + (long)s0 * 128 * (1 + a.ldf); g.ldcin = a.ldf;
-                g.C = Dc; g.ldc = ldd;
-                g.M = w; g.N = w; g.K = wp; g.alpha = -1.0; g.beta = 1.0;
-                g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
-                const int mt = w / 128;
-                int act = 0;
-                for (int tj = 0; tj < mt; ++tj)
-                    for (int ti = tj; ti < mt; ++ti, ++act)
-                        if (act % DS_WG == wg) ds_tile_nt(&g, ti, tj, smem);
-            }
-            if (!ds_barrier(a.flags, epoch, a.timeout_ticks, s_ok)) return;
+        if (cb + 1 < qq) {                               // K = 128 update of the scratch columns right of the leaf
+            if (!dp_barrier(a.flags, target, a.timeout_ticks, s_ok)) return;
+            // row groups of 64 (4 waves x 16 rows); the column groups of one row group are shared by `np_` workgroups
+            const int ngr = w / 64, np_ = max(1, DP_WG / ngr);
+            for (int u = wg; u < ngr * np_; u += DP_WG)
+                dp_update_rows(Acc + 128, a.Dk + (long)(cb + 1) * 128 * (1 + ldd), ldd, w, (qq - 1 - cb) * 128, u % ngr,
+                               u / ngr, np_);
         }
-        STAMP(2);
-        // (Measured and rejected: in-panel look-ahead -- workgroup 0 factoring leaf cb+1 while the others apply the
-        //  update of leaf cb -- 320 us per panel instead of 296: the deferred update on 15 workgroups is slower than a leaf.)
-        for (int cb = 0; cb < qq; ++cb) {
-            double* Acc = Dc + (long)cb * 128 * (1 + ldd);
-            double* pack = a.dpack + (long)cb * PACK_DOUBLES;
-            if (wg == 0) ds_leaf(Acc, ldd, pack, a.info, (s0 + cb) * 128, smem);
-            if (cb == 0) STAMP(8);
-            if (!ds_barrier(a.flags, epoch, a.timeout_ticks, s_ok)) return;
-            if (cb == 0) STAMP(9);
-            // rows below the leaf inside the scratch: (qq-1-cb) 128 block rows + (cb+1) 128 identity-born rows = w rows
-            for (long g0 = wg; g0 * 64 < w; g0 += DS_WG) {
-                ds_trsm(Acc + 128, ldd, w, pack, g0, smem);
-                __syncthreads();
-            }
-            if (cb == 0) STAMP(10);
-            if (!ds_barrier(a.flags, epoch, a.timeout_ticks, s_ok)) return;
-            if (cb == 0) STAMP(11);
-            if (cb + 1 < qq) {                               // K = 128 update of the scratch columns right of the leaf
-                // row groups of 64 (4 waves x 16 rows); the column groups of one row group are shared by `np_` workgroups
-                const int ngr = w / 64, np_ = max(1, DS_WG / ngr);
-                for (int u = wg; u < ngr * np_; u += DS_WG)
-                    ds_update_rows(Acc + 128, Dc + (long)(cb + 1) * 128 * (1 + ldd), ldd, w, (qq - 1 - cb) * 128, u % ngr,
-                                   u / ngr, np_);
-                if (cb == 0) STAMP(12);
-                if (!ds_barrier(a.flags, epoch, a.timeout_ticks, s_ok)) return;
-            }
-            STAMP(3 + cb);
-        }
-        ds_stage_out(Dc, ldd, w, a.F + (long)s0 * 128 * (1 + a.ldf), a.ldf,
-                     a.E ? a.E + (long)s0 * 128 * (1 + a.lde) : nullptr, a.lde, wg);
-        if (!ds_barrier(a.flags, epoch, a.timeout_ticks, s_ok)) return;      // every store released and arrived
-        if (wg == 0 && t == 0) __hip_atomic_store(a.flags + DS_DONE + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        STAMP(15);
+        if (!dp_barrier(a.flags, target, a.timeout_ticks, s_ok)) return;
     }
-#undef STAMP
-}
-
-__global__ void ds_signal_kernel(unsigned* flag) {
-    __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// main stream: hold the stream until the server has finished D(p) (or posted an error / timed out)
-__global__ void ds_wait_kernel(unsigned* flags, unsigned idx, long long timeout) {
-    if (threadIdx.x != 0) return;
-    const long long t0 = wall_clock64();
-    while (ld_flag(flags + idx) == 0) {
-        __builtin_amdgcn_s_sleep(2);
-        if (ld_flag(flags + DS_ERR) != 0) break;
-        if (wall_clock64() - t0 > timeout) {
-            __hip_atomic_store(flags + DS_ERR, 2000u + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
+    dp_stage_out(a.Dk, ldd, w, a.Fd, a.ldf, a.Ed, a.lde, wg);
 }
 }  // namespace
 
-size_t diag_server_flag_bytes() { return (size_t)(DS_CNT2 + DS_MAXP) * sizeof(unsigned); }
-unsigned* diag_server_counter2(unsigned* flags, int p) { return flags + DS_CNT2 + p; }
-unsigned* diag_server_stage_flag(unsigned* flags, int p) { return flags + DS_STG + p; }
-int diag_server_stage_index(int p) { return (int)(DS_STG + p); }
-unsigned* diag_server_counter(unsigned* flags, int p) { return flags + DS_CNT + p; }
-unsigned* diag_server_go_flag(unsigned* flags, int p) { return flags + DS_GO + p; }
-int diag_server_max_panels() { return (int)DS_MAXP; }
+size_t diag_panel_flag_bytes() { return 64 * sizeof(unsigned); }
+int diag_panel_err_index() { return (int)DP_ERR; }
+// barriers (tickets / DP_WG) one launch with panel width w consumes: 1 after the stage-in, 3 per leaf minus the update of
+// the last one
+unsigned diag_panel_tickets(int w) { const int qq = w / 128; return (unsigned)(1 + 3 * qq - 1) * DP_WG; }
 
-int diag_server_launch(double* Dk, long dk_stride, double* dpack, double* F, long ldf, double* E, long lde,
-                       const double* Xs, long ldx, long xs_stride, double* Yn, int nblk, int q, unsigned* flags, int* info,
-                       double timeout_s, long long* ticks, hipStream_t st, bool exclusive, int fake) {
-    DiagServerArgs a{Dk, dk_stride, dpack, F, ldf, E, lde, Xs, ldx, xs_stride, Yn, nblk, q, fake, flags, info,
-                     (long long)(timeout_s * 1e8), ticks};
-    // 96 KB of LDS although the phases need 74: a server workgroup then has its CU to itself (a 74 KB trailing-update
-    // workgroup no longer fits beside it).  Sharing the CU slowed every phase 2-2.7x (leaf 34 -> 90 us): LDS + MFMA pipe.
-    const size_t shm = exclusive ? 96 * 1024 : (36 * 256 + 256 + 2) * sizeof(double);
+int diag_panel_launch(const double* src, long lds, double* Dk, long ldd, double* dpack, double* Fd, long ldf, double* Ed,
+                      long lde, int w, unsigned* flags, unsigned base, int* info, int info_base, double timeout_s,
+                      hipStream_t st) {
+    DiagPanelArgs a{src, lds, Dk, ldd, dpack, Fd, ldf, Ed, lde, w, flags, base, info, info_base, (long long)(timeout_s * 1e8)};
+    const size_t shm = (36 * 256 + 256 + 2) * sizeof(double);
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute((const void*)diag_server_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)diag_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(diag_server_kernel, dim3(DS_WG), dim3(256), shm, st, a);
+    hipLaunchKernelGGL(diag_panel_kernel, dim3(DP_WG), dim3(256), shm, st, a);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
-int diag_server_post(unsigned* flag, hipStream_t st) {
-    hipLaunchKernelGGL(ds_signal_kernel, dim3(1), dim3(1), 0, st, flag);
-    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
-}
-int diag_server_go(unsigned* flags, int p, hipStream_t st) {
-    hipLaunchKernelGGL(ds_signal_kernel, dim3(1), dim3(1), 0, st, flags + DS_GO + p);
-    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
-}
-int diag_server_wait(unsigned* flags, int p, double timeout_s, hipStream_t st) {
-    hipLaunchKernelGGL(ds_wait_kernel, dim3(1), dim3(64), 0, st, flags, DS_DONE + (unsigned)p, (long long)(timeout_s * 1e8));
-    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
-}
-// hold the stream until the staged columns of panel p are complete (released from inside trailing update TU(p-1))
-int diag_server_wait_staged(unsigned* flags, int p, double timeout_s, hipStream_t st) {
-    hipLaunchKernelGGL(ds_wait_kernel, dim3(1), dim3(64), 0, st, flags, DS_STG + (unsigned)p, (long long)(timeout_s * 1e8));
-    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
-}
-int diag_server_err_index() { return (int)DS_ERR; }
-
-namespace {
-}  // namespace
 
 int diag_in_launch(const double* src, long lds, double* D, long ldd, int w, hipStream_t st) {
     hipLaunchKernelGGL(diag_in_kernel, dim3(w), dim3(256), 0, st, src, lds, D, ldd, w);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
-int diag_out_launch(const double* D, long ldd, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st,
-                    double* Dt, long ldt) {
-    const int extra = Dt ? (w / 64) * (w / 64) : 0;
-    hipLaunchKernelGGL(diag_out_kernel, dim3(w + extra), dim3(256), 0, st, D, ldd, w, Fd, ldf, Ed, lde, Dt, ldt);
+int diag_out_launch(const double* D, long ldd, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st) {
+    hipLaunchKernelGGL(diag_out_kernel, dim3(w), dim3(256), 0, st, D, ldd, w, Fd, ldf, Ed, lde);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 

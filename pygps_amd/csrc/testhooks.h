@@ -1,0 +1,24 @@
+/* Self-test / calibration hooks of libpygps_amd.so: NOT part of the drop-in boundary (include/pygps_amd.h).  They are
+ * exported for tests/, tools/ and bench.py's calibration legs only (pygps_amd/_lib.py: TEST_SIGNATURES). */
+#pragma once
+#include <stdint.h>
+
+#include "../../include/pygps_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Column-major GEMM on host buffers through the fp64 MFMA kernel. */
+int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_diag, int kmode, int koff,
+                  double alpha, double beta, const double* A, int64_t lda, const double* B, int64_t ldb,
+                  double* C, int64_t ldc, int M, int N, int K, int iters, double* ms_out);
+int pgp_test_gemm_shrink(pgp_ctx* ctx, const double* Y, int64_t ldy, int M, int K, int w, int nb, int dm, int zero_from,
+                         double* C, int64_t ldc, int64_t sC);
+int pgp_test_probit_hazard(pgp_ctx* ctx, const double* z, double* out, int n);
+int pgp_test_valu_peak(pgp_ctx* ctx, int iters, int waves_per_simd, double* out2);
+int pgp_test_mfma_peak(pgp_ctx* ctx, int iters, double* tflops_out);
+int pgp_test_mfma_cycles(pgp_ctx* ctx, int iters, int nacc, int waves_per_simd, double* out3);
+int pgp_test_leaf_ticks(pgp_ctx* ctx, double* ticks_out /* 24 */);
+int pgp_test_assemble(pgp_ctx* ctx, int kind, int mode, int64_t n, int64_t d, int iters, double* ms_out);
+#ifdef __cplusplus
+}
+#endif

@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "ctx.h"
+#include "testhooks.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -172,16 +173,6 @@ int pgp_test_leaf_ticks(pgp_ctx* c, double* ticks_out) {
     return PGP_OK;
 }
 
-// wall-clock stamps (100 MHz) of the resident diagonal-panel server's last sweep (option ds_ticks=1): 16 per panel
-int pgp_test_ds_ticks(pgp_ctx* c, double* ticks_out, int npanel) {
-    if (!c || !ticks_out || !c->ds_ticks) return -1;
-    HIP_TRY(hipSetDevice(c->device));
-    std::vector<long long> h((size_t)npanel * 16);
-    HIP_TRY(hipMemcpy(h.data(), c->ds_ticks, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < h.size(); ++i) ticks_out[i] = (double)h[i];
-    return PGP_OK;
-}
-
 // device-only timing of the kernel-assembly tile kernel on synthetic resident coordinates:
 // mode 0 = full symmetric (n,n) output ('train'), 2 = fused lower-triangle B = K/sn2 + I.  ms_out = avg per launch.
 int pgp_test_assemble(pgp_ctx* c, int kind, int mode, int64_t n, int64_t d, int iters, double* ms_out) {
@@ -223,51 +214,6 @@ int pgp_test_assemble(pgp_ctx* c, int kind, int mode, int64_t n, int64_t d, int 
 }
 
 // Does a small panel kernel on the high-priority stream overlap a big trailing GEMM on the main stream?
-// out[0] = ms until the GEMM is done, out[1] = ms until the leaf kernel (issued after it, other stream) is done,
-// out[2] = same for a trsm over 4096 rows, out[3] = leaf alone.
-int pgp_test_overlap(pgp_ctx* c, double* out) {
-    if (!c || !out) return -1;
-    HIP_TRY(hipSetDevice(c->device));
-    const int N = 8192, K = 512;
-    double *A, *Cm, *L, *pk, *X; int* info;
-    HIP_TRY(hipMalloc((void**)&A, (size_t)N * K * 8)); HIP_TRY(hipMalloc((void**)&Cm, (size_t)N * N * 8));
-    HIP_TRY(hipMalloc((void**)&L, 128 * 128 * 8)); HIP_TRY(hipMalloc((void**)&pk, PACK_DOUBLES * 8));
-    HIP_TRY(hipMalloc((void**)&X, (size_t)4096 * 128 * 8)); HIP_TRY(hipMalloc((void**)&info, 4));
-    HIP_TRY(hipMemset(A, 0, (size_t)N * K * 8)); HIP_TRY(hipMemset(Cm, 0, (size_t)N * N * 8));
-    HIP_TRY(hipMemset(X, 0, (size_t)4096 * 128 * 8)); HIP_TRY(hipMemset(info, 0, 4));
-    std::vector<double> Lh(128 * 128, 0.0);
-    for (int i = 0; i < 128; ++i) Lh[i + i * 128] = 2.0;
-    HIP_TRY(hipMemcpy(L, Lh.data(), Lh.size() * 8, hipMemcpyHostToDevice));
-    GemmArgs g{};
-    g.A = A; g.lda = N; g.B = A; g.ldb = N; g.C = Cm; g.ldc = N; g.M = N; g.N = N; g.K = K;
-    g.alpha = -1.0; g.beta = 1.0; g.tile = 128; g.batch = 1;
-    hipEvent_t e0, eg, el, et;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&eg)); HIP_TRY(hipEventCreate(&el)); HIP_TRY(hipEventCreate(&et));
-    for (int rep = 0; rep < 2; ++rep) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipEventRecord(e0, c->st));
-        HIP_TRY(hipStreamWaitEvent(c->st2, e0, 0));
-        CHK(gemm_f64_launch(g, c->st));
-        HIP_TRY(hipEventRecord(eg, c->st));
-        CHK(leaf_potrf_launch(L, 128, pk, info, 0, c->st2));
-        HIP_TRY(hipEventRecord(el, c->st2));
-        CHK(trsm_rows_launch(X, 4096, 4096, L, 128, pk, c->st2));
-        HIP_TRY(hipEventRecord(et, c->st2));
-        HIP_TRY(hipDeviceSynchronize());
-    }
-    float a, b, d;
-    HIP_TRY(hipEventElapsedTime(&a, e0, eg)); HIP_TRY(hipEventElapsedTime(&b, e0, el)); HIP_TRY(hipEventElapsedTime(&d, e0, et));
-    out[0] = a; out[1] = b; out[2] = d;
-    HIP_TRY(hipEventRecord(e0, c->st2));
-    CHK(leaf_potrf_launch(L, 128, pk, info, 0, c->st2));
-    HIP_TRY(hipEventRecord(el, c->st2));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipEventElapsedTime(&a, e0, el));
-    out[3] = a;
-    (void)hipFree(A); (void)hipFree(Cm); (void)hipFree(L); (void)hipFree(pk); (void)hipFree(X); (void)hipFree(info);
-    return PGP_OK;
-}
-
 int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_diag, int kmode, int koff,
                   double alpha, double beta, const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
                   int64_t ldc, int M, int N, int K, int iters, double* ms_out) {
@@ -284,10 +230,7 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
     g.A = Ad; g.lda = lda; g.a_kc = a_kc; g.B = Bd; g.ldb = ldb; g.b_kc = b_kc; g.C = Cd; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.tri = tri; g.tri_off = 0; g.mask_diag = mask_diag;
     g.kmode = kmode; g.koff = koff; g.batch = 1; g.tile = tile; g.dbg = c->gemm_dbg;
-    hipStream_t ts = c->st_masked ? c->st_masked : c->st;         // option cu_reserve: time the CU-masked stream
-    long long* stamps = nullptr;
-    const long nwg = (long)(M / tile) * (N / tile);
-    if (c->gemm_dbg & 128) { HIP_TRY(hipMalloc((void**)&stamps, nwg * 4 * sizeof(long long))); g.stamps = stamps; }
+    hipStream_t ts = c->st;
     int rc = gemm_f64_launch(g, ts);
     HIP_TRY(hipStreamSynchronize(ts));
     if (rc == PGP_OK) HIP_TRY(hipMemcpy(C, Cd, cn * 8, hipMemcpyDeviceToHost));
@@ -303,50 +246,33 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
         *ms_out = ms / iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
-    if (stamps) {                 // per-tile phase times of the LAST launch (wall clock, 100 MHz)
-        std::vector<long long> h((size_t)nwg * 4);
-        HIP_TRY(hipMemcpy(h.data(), stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-        double a = 0, b = 0, d = 0, e = 0; long long tmin = h[0], tmax = 0;
-        for (long w = 0; w < nwg; ++w) {
-            a += (double)(h[4 * w + 1] - h[4 * w]); b += (double)(h[4 * w + 2] - h[4 * w + 1]); d += (double)(h[4 * w + 3] - h[4 * w + 2]);
-            e += (double)(h[4 * w + 3] - h[4 * w]);
-            tmin = std::min(tmin, h[4 * w]); tmax = std::max(tmax, h[4 * w + 3]);
-        }
-        fprintf(stderr, "gemm stamps: %ld tiles; per tile us: prologue (C pre-load + first stage) %.1f, k-loop %.1f, stores %.1f, total %.1f; "
-                        "kernel span %.1f us, sum(tile time)/512 slots = %.1f us\n", nwg, a / nwg / 100, b / nwg / 100, d / nwg / 100,
-                e / nwg / 100, (double)(tmax - tmin) / 100, e / 100 / 512);
-        (void)hipFree(stamps);
-    }
     (void)hipFree(Ad); (void)hipFree(Bd); (void)hipFree(Cd);
     return rc;
 }
 
-// Two products in one grid (gemm_f64_dual_launch): a = trailing-update shape (C1 -= A1 A1^T, lower trapezoid), b = the
-// E E^T filler shape (C2 = [rows < zero_from: C2] + A2 A2^T, packed lower tiles, k >= row + koff).  Results back to the host.
-int pgp_test_gemm_dual(pgp_ctx* ctx, const double* A1, int64_t lda1, double* C1, int64_t ldc1, int M1, int K1,
-                       const double* A2, int64_t lda2, double* C2, int64_t ldc2, int M2, int K2, int koff2, int zero_from2) {
+// Batched trailing update whose products shrink with the batch index (GemmArgs::batch_dm; the owned column panels of the
+// block-cyclic sweep in csrc/sharded.hip): for z < nb
+//     C_z (M - z dm rows x w, at C + z sC)  -=  Y[z dm : M, :] Y[z dm : z dm + w, :]'     lower trapezoid, diagonal tile masked,
+// rows >= zero_from - z dm of C_z taken as zero on input (first touch).  Host buffers, column-major.
+int pgp_test_gemm_shrink(pgp_ctx* ctx, const double* Y, int64_t ldy, int M, int K, int w, int nb, int dm, int zero_from,
+                         double* C, int64_t ldc, int64_t sC) {
     if (!ctx) return -1;
     pgp_ctx* c = ctx;
+    if (!Y || !C || M <= 0 || M % 128 || w % 128 || K % 16 || dm % 128 || nb < 1) return -2;
     HIP_TRY(hipSetDevice(c->device));
     DevScratch scr;
-    double *a1, *c1, *a2, *c2;
-    CHK(scr.alloc(&a1, (size_t)lda1 * K1 * 8)); CHK(scr.alloc(&c1, (size_t)ldc1 * M1 * 8));
-    CHK(scr.alloc(&a2, (size_t)lda2 * K2 * 8)); CHK(scr.alloc(&c2, (size_t)ldc2 * M2 * 8));
-    HIP_TRY(hipMemcpy(a1, A1, (size_t)lda1 * K1 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c1, C1, (size_t)ldc1 * M1 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(a2, A2, (size_t)lda2 * K2 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c2, C2, (size_t)ldc2 * M2 * 8, hipMemcpyHostToDevice));
-    GemmArgs a{}, b{};
-    a.A = a1; a.lda = lda1; a.B = a1; a.ldb = lda1; a.C = c1; a.ldc = ldc1; a.M = M1; a.N = M1; a.K = K1;
-    a.alpha = -1.0; a.beta = 1.0; a.tri = 1; a.mask_diag = 1; a.kmode = KM_FULL; a.batch = 1; a.tile = 128; a.dbg = c->gemm_dbg;
-    b.A = a2; b.lda = lda2; b.B = a2; b.ldb = lda2; b.C = c2; b.ldc = ldc2; b.M = M2; b.N = M2; b.K = K2;
-    b.alpha = 1.0; b.beta = 1.0; b.tri = 2; b.mask_diag = 1; b.kmode = KM_GE_I; b.koff = koff2; b.zero_from = zero_from2;
-    b.batch = 1; b.tile = 128; b.dbg = c->gemm_dbg;
-    if (!gemm_f64_dual_ok(a, b)) return -2;
-    CHK(gemm_f64_dual_launch(a, b, c->st));
+    double *yd, *cd;
+    const size_t cbytes = (size_t)((nb - 1) * sC + ldc * w) * 8;
+    CHK(scr.alloc(&yd, (size_t)ldy * K * 8)); CHK(scr.alloc(&cd, cbytes));
+    HIP_TRY(hipMemcpy(yd, Y, (size_t)ldy * K * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(cd, C, cbytes, hipMemcpyHostToDevice));
+    GemmArgs g{};
+    g.A = yd; g.lda = ldy; g.B = yd; g.ldb = ldy; g.C = cd; g.ldc = ldc; g.M = M; g.N = w; g.K = K;
+    g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.mask_diag = 1; g.kmode = KM_FULL; g.tile = 128;
+    g.batch = nb; g.sA = dm; g.sB = dm; g.sC = sC; g.batch_dm = dm; g.zero_from = zero_from;
+    CHK(gemm_prof(c, PC_GEMM_TRAIL, g, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
-    HIP_TRY(hipMemcpy(C1, c1, (size_t)ldc1 * M1 * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(C2, c2, (size_t)ldc2 * M2 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(C, cd, cbytes, hipMemcpyDeviceToHost));
     return PGP_OK;
 }
 

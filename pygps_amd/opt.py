@@ -156,6 +156,8 @@ class ShardedMinimize(Minimize):
 
     def __init__(self, model, searchConfig=None, group=None, streams_per_gpu=None):
         super(ShardedMinimize, self).__init__(model, searchConfig)
+        from . import _lib
+        _lib.want_torch()               # torch.distributed carries the collectives; torch goes in before the first context
         self.group = group
         self.runs = None                # per-restart records of the last findMin (all ranks)
         if streams_per_gpu is not None:

@@ -4,6 +4,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("PYGPS_AMD_TORCH_FIRST", "1")     # this process uses torch.distributed beside the library (see _lib._torch_first)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

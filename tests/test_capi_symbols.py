@@ -24,6 +24,15 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_prototypes_match_header():
     from pygps_amd import _lib
     assert set(_lib.SIGNATURES) == _declared()
+    # the public header carries the drop-in boundary + measurement only: every self-test hook lives in the private
+    # csrc/testhooks.h (and is bound through a separate table)
+    assert not [n for n in _declared() if n.startswith("pgp_test_")]
+    priv = open(os.path.join(ROOT, "pygps_amd", "csrc", "testhooks.h")).read()
+    priv = re.sub(r"/\*.*?\*/", "", priv, flags=re.S)
+    assert set(re.findall(r"\b(pgp_test_[a-z0-9_]+)\s*\(", priv)) == set(_lib.TEST_SIGNATURES)
+    dll = _lib.load()
+    for n in _lib.TEST_SIGNATURES:
+        assert hasattr(dll, n), n
 
 
 def test_strerror_and_version_without_gpu():

@@ -186,39 +186,49 @@ def test_probit_hazard_of_the_site_update(lib):
     assert worst < 2e-13, (worst, zw)          # v_rcp_f64 + one Newton step (fast_rcp) is good to ~6e-14
 
 
-def test_two_products_in_one_grid(lib):
-    """gemm_f64_dual_kernel: a trailing-update-shaped product and an E E^T-filler-shaped product (packed lower tiles,
-    k clipped to k >= row + koff, first-touch rows from zero_from) launched as ONE grid, against numpy."""
+def test_shrinking_batched_trailing_update(lib):
+    """GemmArgs::batch_dm: ONE launch updates several column panels whose row counts shrink with the batch index (the owned
+    panels of the block-cyclic sweep, csrc/sharded.hip), each with its own first-touch row, against numpy."""
     from pygps_amd import _lib
     ctx = _lib.ctx()
     rng = np.random.RandomState(5)
-    M1, K1, M2, K2, s0 = 1024, 512, 1536, 512, 1024
-    A1 = np.asfortranarray(rng.randn(M1, K1)); C1 = np.asfortranarray(rng.randn(M1, M1))
-    # columns [s0, s0 + K2) of an upper-triangular E: rows <= s0 + k non-zero
-    A2 = np.asfortranarray(np.triu(rng.randn(M2, M2))[:, s0:s0 + K2]); C2 = np.asfortranarray(rng.randn(M2, M2))
-    want1 = C1 - A1 @ A1.T
-    base = C2.copy(); base[s0:, :] = 0.0
-    want2 = base + A2 @ A2.T
-    g1, g2 = C1.copy(order="F"), C2.copy(order="F")
-    _lib.check(lib.pgp_test_gemm_dual(ctx, _lib.ptr(A1), M1, _lib.ptr(g1), M1, M1, K1, _lib.ptr(A2), M2, _lib.ptr(g2), M2,
-                                      M2, K2, -s0, s0))
-    lo1, lo2 = np.tril_indices(M1), np.tril_indices(M2)
-    assert np.abs(g1[lo1] - want1[lo1]).max() < 1e-11
-    assert np.abs(g2[lo2] - want2[lo2]).max() < 1e-11
-    assert np.array_equal(np.triu(g1, 129), np.triu(C1, 129)) and np.array_equal(np.triu(g2, 129), np.triu(C2, 129))
+    M, K, w, nb, dm = 2560, 512, 512, 3, 1024            # panels at rows 0, 1024, 2048 of the broadcast panel Y
+    zf = M - 384                                           # rows >= zf of product 0 are first-touch (garbage on input)
+    Y = np.asfortranarray(rng.randn(M, K))
+    ldc, sC = M, M * w
+    C = rng.randn(nb * sC)
+    want = C.copy()
+    for z in range(nb):
+        Mz = M - z * dm
+        Cz = want[z * sC:z * sC + ldc * w].reshape(w, ldc).T[:Mz]          # column-major (ldc x w) view, first Mz rows
+        old = Cz.copy()
+        old[zf - z * dm:] = 0.0
+        upd = old - Y[z * dm:] @ Y[z * dm:z * dm + w].T
+        lower = np.tril(np.ones((Mz, w), dtype=bool))
+        Cz[lower] = upd[lower]
+    got = C.copy()
+    _lib.check(lib.pgp_test_gemm_shrink(ctx, _lib.ptr(Y), M, M, K, w, nb, dm, zf, _lib.ptr(got), ldc, sC))
+    for z in range(nb):
+        Mz = M - z * dm
+        g = got[z * sC:z * sC + ldc * w].reshape(w, ldc).T
+        wv = want[z * sC:z * sC + ldc * w].reshape(w, ldc).T
+        lower = np.tril(np.ones((Mz, w), dtype=bool))
+        assert np.abs(g[:Mz][lower] - wv[:Mz][lower]).max() < 1e-11, z
+        strict_upper = np.triu(np.ones((w, w), dtype=bool), 129)           # beyond the masked diagonal tiles: untouched
+        assert np.array_equal(g[:w][strict_upper], wv[:w][strict_upper])
+        assert np.array_equal(g[Mz:], wv[Mz:])                             # rows beyond the product: untouched
 
 
-@pytest.mark.parametrize("opts", [dict(dserver=1), dict(dserver=1, ds_exclusive=0), dict(potrf_v1=1), dict(lookahead=0),
-                                  dict(la2=1), dict(s_side=1), dict(merge_tu=1), dict(cu_reserve=-8), dict(cu_reserve=-8, s_side=1),
-                                  dict(eet_overlap=0), dict(eet_overlap=1), dict(eet_overlap=1, eet_tile=64), dict(eet_overlap=2, eet_merge=1), dict(s_dma=1, s_tile=128), dict(s_tile=128), dict(eet_first=0), dict(small_tile_below=256), dict(xcd_order=1), dict(xcd_order=1, xcd_super=4, xcd_min_tiles=64)])
+@pytest.mark.parametrize("opts", [dict(diag_fused=0), dict(lookahead=0), dict(eet_overlap=0), dict(eet_overlap=2, eet_tile=64),
+                                  dict(s_tile=128), dict(eet_first=0), dict(small_tile_below=256), dict(gemm_dbg=0),
+                                  dict(xcd_order=1), dict(xcd_order=1, xcd_super=4, xcd_min_tiles=64)])
 def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
-    """Every schedule of the Cholesky sweep -- the default diagonal-panel chain, the resident diagonal-panel server
-    (left-looking, in-kernel go signals), the round-1 leaf chain, the serial order, and the measured-and-rejected
-    variants kept as options (depth-2 look-ahead, solves on a side stream, one merged update launch, CU
-    reservation for the panel chain), and the ways B^-1 = E E^T is produced (one product after the sweep, panel products
-    on a filler stream, panel products in the same grid as the trailing update; the default runs them behind the
-    trailing update) -- against the reference's own numbers (G6: Core/inf.py:353-384 at N=2048 and
-    at the benchmark size N=8192)."""
+    """The kept schedule options of the Cholesky sweep -- D(p) as the chain of 13 launches instead of the fused kernel,
+    the serial order, B^-1 = E E^T as one product after the sweep or as panel products behind every trailing update, tile
+    choices, the plain (register-staged) GEMM form, the XCD-aware tile order -- against the reference's own numbers
+    (G6: Core/inf.py:353-384 at N=2048 and at the benchmark size N=8192).  The variants that were measured and lost in
+    rounds 1-2 (resident server, depth-2 look-ahead, side streams, CU reservation, merged grids, the round-1 sweep) are
+    gone from the library."""
     from pygps_amd import _lib
     ctx = _lib.ctx()
     try:
@@ -237,8 +247,9 @@ def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
                     assert relerr(got["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-8
     finally:
         for k in opts:
-            lib.pgp_set_option(ctx, k.encode(), {"lookahead": 1, "ds_exclusive": 1, "eet_overlap": 3, "eet_tile": 128, "s_dma": 0, "s_tile": 0, "eet_first": -1, "small_tile_below": 200, "xcd_order": 0, "xcd_super": 8, "xcd_min_tiles": 256}.get(k, 0))
-        lib.pgp_set_option(ctx, b"cu_reserve", 0)
+            lib.pgp_set_option(ctx, k.encode(), {"lookahead": 1, "diag_fused": 1, "eet_overlap": 3, "eet_tile": 128, "s_tile": 0,
+                                                 "eet_first": -1, "small_tile_below": 200, "xcd_order": 0, "xcd_super": 8,
+                                                 "xcd_min_tiles": 256, "gemm_dbg": 64 | 256 | 512}.get(k, 0))
 
 
 def test_exact_fit_golden_G7_ard_d64(lib):

@@ -18,8 +18,6 @@ tile = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 if len(sys.argv) > 7:
     lib.pgp_set_option(ctx, b"gemm_dbg", int(sys.argv[7]))
-if len(sys.argv) > 8:
-    lib.pgp_set_option(ctx, b"cu_reserve", int(sys.argv[8]))
 rng = np.random.RandomState(0)
 A = np.asfortranarray(rng.randn(M, K))
 B = np.asfortranarray(rng.randn(N, K))

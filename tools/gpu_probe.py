@@ -132,12 +132,6 @@ if __name__ == "__main__":
             print("trtri_small_tile_below =", v)
             fit(8192, 16, reps=3, prof=False)
         lib.pgp_set_option(ctx, b"trtri_small_tile_below", 256)
-    if "cumask" in what:
-        for v in (0, 8, 16, 4, 0):
-            lib.pgp_set_option(ctx, b"cu_reserve", v)
-            print("cu_reserve =", v)
-            fit(8192, 16, reps=3, prof=False)
-        lib.pgp_set_option(ctx, b"cu_reserve", 0)
     if "ab" in what:
         for v in (0, 1, 0, 1):
             lib.pgp_set_option(ctx, b"lookahead", v)
@@ -147,10 +141,6 @@ if __name__ == "__main__":
         fit(8192, 16)
         fit(8192, 16, want=2, prof=False)
         fit(2048, 16, prof=False)
-    if "overlap" in what:
-        o = np.zeros(4)
-        assert lib.pgp_test_overlap(ctx, _lib.ptr(o)) == 0
-        print("GEMM done at %.3f ms; leaf (other stream, issued after) done at %.3f ms; trsm done at %.3f ms; leaf alone %.3f ms" % tuple(o))
     if "asm" in what:
       for grid in [int(a[5:]) for a in what if a.startswith("grid=")] or [2048]:
         lib.pgp_set_option(ctx, b"asm_grid", grid)
@@ -169,9 +159,8 @@ if __name__ == "__main__":
             d = 32
             x = rng.randn(N, d); w = rng.randn(d, 1)
             y = np.sign(x @ w / np.sqrt(d) + 0.3 * rng.randn(N, 1)); y[y == 0] = 1
-            for blk, gr in ((0, 0), (1, 0), (1, 1)):
+            for blk, gr in ((0, 0), (1, 0)):
                 lib.pgp_set_option(ctx, b"ep_block", blk)
-                lib.pgp_set_option(ctx, b"ep_graph", gr)
                 m = pyGPs.GPC()
                 m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
                 t = time.time()

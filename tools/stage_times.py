@@ -1,4 +1,4 @@
-"""Stage times of N=8192 (or N=<n>) fits under library options (results may be WRONG with experiment options such as ds_fake)."""
+"""Stage times of N=8192 (or N=<n>) fits under library options."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")

@@ -6,7 +6,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygps_amd import _lib
 
 lib = _lib.load()
