@@ -89,8 +89,6 @@ int pgp_init(int device, pgp_ctx** ctx_out) {
     HIP_TRY(hipMalloc((void**)&c->Dk, (size_t)2048 * 1024 * sizeof(double)));       // 2w x w, w <= 1024
     HIP_TRY(hipMalloc((void**)&c->dpack, (size_t)8 * PACK_DOUBLES * sizeof(double)));
     HIP_TRY(hipMemset(c->Dk, 0, (size_t)2048 * 1024 * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->dflags, diag_panel_flag_bytes()));
-    HIP_TRY(hipMemset(c->dflags, 0, diag_panel_flag_bytes()));
     ctx_register(c);
     *ctx_out = c;
     return PGP_OK;
@@ -123,7 +121,7 @@ void pgp_destroy(pgp_ctx* c) {
     for (auto& kv : c->spool) (void)hipFree(kv.second);
     for (auto& kv : c->orders) (void)hipFree(kv.second.first);
     void* bufs[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev, c->W, c->T, c->Binv, c->inv16, c->m_dev,
-                    c->rvec, c->zvec, c->partial, c->Dk, c->dpack, c->Xs, c->dflags, c->res_dev};
+                    c->rvec, c->zvec, c->partial, c->Dk, c->dpack, c->Xs, c->res_dev};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->in_host) (void)hipHostFree(c->in_host);
@@ -154,8 +152,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "xcd_order")) { c->xcd_order = value; return PGP_OK; }
     if (!strcmp(name, "gemm_dbg")) { if (value & ~(64 | 256 | 512)) return -2; c->gemm_dbg = value; return PGP_OK; }
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
-    if (!strcmp(name, "diag_fused")) { c->diag_fused = value; return PGP_OK; }
-    if (!strcmp(name, "dp_timeout_ms")) { c->dp_timeout_s = 1e-3 * value; return PGP_OK; }
+    if (!strcmp(name, "leaf_first")) { c->leaf_first = value; return PGP_OK; }
     if (!strcmp(name, "ep_dbg")) { return ep_set_dbg(value); }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
     if (!strcmp(name, "ep_r_direct")) { c->ep_r_direct = value; return PGP_OK; }
@@ -498,9 +495,17 @@ int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
 // rows_end(nb) = one past the last row that takes part once nb column blocks are factored
 struct RowEnd { long eoff; bool winv; long operator()(int nb) const { return winv ? eoff + (long)nb * 128 : eoff; } };
 
+// mark / mark_step: record `mark` on the stream after the mark_step-th kernel of the chain (1 = first leaf, 2 = its trsm,
+// 3 = its inner update, ...): the caller holds other work back until the chain has got that far
 static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s1, hipStream_t st,
-                        double* packs = nullptr, int info_base = 0) {
+                        double* packs = nullptr, int info_base = 0, hipEvent_t mark = nullptr, int mark_step = 0) {
     if (!packs) packs = c->inv16;
+    int step = 0;
+    auto stepped = [&]() -> int {
+        if (mark && ++step == mark_step) HIP_TRY(hipEventRecord(mark, st));
+        return PGP_OK;
+    };
+    if (mark && mark_step <= 0) HIP_TRY(hipEventRecord(mark, st));
     for (int cb = s0; cb < s1; ++cb) {
         double* Acc = F + (long)cb * 128 + (long)cb * 128 * ld;
         double* pack = packs + (long)cb * PACK_DOUBLES;
@@ -508,11 +513,13 @@ static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s
             ProfScope ps(c, PC_LEAF, 128.0 * 128.0 * 128.0 / 3.0, 0.0, st);
             CHK(leaf_potrf_launch(Acc, ld, pack, c->info_dev, info_base + cb * 128, st));
         }
+        CHK(stepped());
         const long rows_below = re(cb + 1) - (long)(cb + 1) * 128;
         if (rows_below > 0) {
             ProfScope ps(c, PC_TRSM, (double)rows_below * 128.0 * 128.0, 0.0, st);
             CHK(trsm_rows_launch(Acc + 128, ld, rows_below, Acc, ld, pack, st));
         }
+        CHK(stepped());
         if (cb + 1 < s1) {               // inner update of the rest of this outer panel, K = 128
             GemmArgs g{};
             g.A = Acc + 128; g.lda = ld; g.a_kc = 0;
@@ -525,7 +532,9 @@ static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s
             g.flops = 2.0 * 128.0 * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
             CHK(gemm_prof(c, PC_GEMM_INNER, g, st));
         }
+        CHK(stepped());
     }
+    if (mark && step < mark_step) HIP_TRY(hipEventRecord(mark, st));      // a chain shorter than mark_step
     return PGP_OK;
 }
 
@@ -533,8 +542,8 @@ static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s
 // Cholesky sweep ("diagonal-panel" schedule).
 //
 // Only the w x w DIAGONAL block of an outer panel (w = 128 q = 512) goes through the leaf-level factorisation, in a small
-// scratch with identity rows appended so that E_D = L_D^-T falls out with it (diag_factor: D(p), ONE launch of the fused
-// diag_panel_kernel).  Everything below the block is then ONE MFMA GEMM per panel
+// scratch with identity rows appended so that E_D = L_D^-T falls out with it (diag_factor: D(p), a chain of 13 small
+// launches: stage in | 4 x [leaf_potrf, trsm_rows, K = 128 update] | stage out).  Everything below the block is then ONE MFMA GEMM per panel
 //        Y = X E_D        (solve_below: S(p);  K clipped to the triangle, k < j0 + T)
 // and the trailing update TU(p) is one K = w product.  Depth-1 look-ahead on two streams:
 //
@@ -566,28 +575,21 @@ static int ensure_stage(pgp_ctx* c, long rows, int w) {
 // D: factor the w x w block `src` (leading dimension lds, lower part) and produce E_D = L_D^-T beside it: L_D -> Fd (ldf),
 // E_D -> Ed (lde; may be null), E_D also stays in c->Dk + w (leading dimension 2w) for the panel solve that follows
 int diag_block_factor(pgp_ctx* c, const double* src, long lds, int w, double* Fd, long ldf, double* Ed, long lde,
-                      int info_base, hipStream_t st) {
+                      int info_base, hipStream_t st, hipEvent_t staged) {
     const long ldd = 2L * w;
-    if (c->diag_fused) {
-        ProfScope ps(c, PC_LEAF, (double)w * w * w * (1.0 / 3.0 + 1.0 / 3.0), 0.0, st);
-        const unsigned base = c->dp_base;
-        c->dp_base += diag_panel_tickets(w);
-        c->dp_used = true;
-        return diag_panel_launch(src, lds, c->Dk, ldd, c->dpack, Fd, ldf, Ed, lde, w, c->dflags, base, c->info_dev, info_base,
-                                 c->dp_timeout_s, st);
-    }
     { ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
       CHK(diag_in_launch(src, lds, c->Dk, ldd, w, st)); }
-    CHK(factor_panel(c, c->Dk, ldd, RowEnd{(long)w, true}, 0, w / 128, st, c->dpack, info_base));
+    CHK(factor_panel(c, c->Dk, ldd, RowEnd{(long)w, true}, 0, w / 128, st, c->dpack, info_base, staged, c->leaf_first - 1));
     { ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
       CHK(diag_out_launch(c->Dk, ldd, w, Fd, ldf, Ed, lde, st)); }
     return PGP_OK;
 }
 
 // D(p): the diagonal block of columns [s0, s1) (block units), src = its (updated) image with leading dim lds
-static int diag_factor(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* src, long lds, hipStream_t st) {
+static int diag_factor(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* src, long lds, hipStream_t st,
+                       hipEvent_t staged = nullptr) {
     return diag_block_factor(c, src, lds, (s1 - s0) * 128, m.F + (long)s0 * 128 * (1 + m.ldf), m.ldf,
-                             (m.E && !m.dense2) ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, s0 * 128, st);
+                             (m.E && !m.dense2) ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, s0 * 128, st, staged);
 }
 
 // S(p): rows below the diagonal block of panel [s0, s1):  Y = X E_D, X read from the staging buffer (logical rows, ldx)
@@ -709,7 +711,11 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
             HIP_TRY(hipEventRecord(c->la_ev[2 * p], main));
             HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
         }
-        CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan));
+        // leaf_first: the trailing update is held back until D(p+1)'s stage-in is done, so that the first leaf is dispatched
+        // BEFORE the update's first wave takes every workgroup slot (a leaf dispatched into that wave waits ~140 us for it)
+        const bool lf = la && c->leaf_first;
+        CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan, lf ? c->la_ev[2 * npanel + (p & 1)] : nullptr));
+        if (lf) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * npanel + (p & 1)], 0));
         if (la) HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
         CHK(trailing_update2(c, m, s0, s1, n1, nblk, nullptr, 0, main));   // TU_b in place, concurrent with D(p+1)
         // the first products are small (few tiles, short k) and the early trailing updates are long enough to hide D by
@@ -732,25 +738,6 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         CHK(eet_panel(c, m, s0, nblk, c->eet_out, c->eet_ld, pan));
         HIP_TRY(hipEventRecord(c->fill_ev[1], pan));
         c->eet_join = c->fill_ev[1];
-    }
-    return PGP_OK;
-}
-
-// after the stream has been synchronised: did a fused diagonal-panel kernel of the last sweep post an error (timeout)?
-int potrf_diag_status(pgp_ctx* c) {
-    if (!c->dp_used) return PGP_OK;
-    c->dp_used = false;
-    unsigned err = 0;
-    HIP_TRY(hipMemcpy(&err, c->dflags + diag_panel_err_index(), sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (err != 0) {
-        // the barrier tickets of the aborted launch are lost: start over from a clean counter
-        (void)hipDeviceSynchronize();
-        (void)hipMemset(c->dflags, 0, diag_panel_flag_bytes());
-        c->dp_base = 0;
-        char msg[128];
-        snprintf(msg, sizeof(msg), "fused diagonal-panel kernel timed out (code %u)", err);
-        pgp_set_last_hip_error(hipErrorLaunchTimeOut, msg, __FILE__, __LINE__);
-        return PGP_ERR_HIP;
     }
     return PGP_OK;
 }
@@ -1067,7 +1054,6 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     // ---- results to host: ONE copy of [scalars | status | alpha] into pinned memory ---------------------
     HIP_TRY(hipMemcpyAsync(c->res_host, c->res_dev, (size_t)(RES_HEAD + n) * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    CHK(potrf_diag_status(c));
     const double* sc_host = c->res_host;
     double* alpha_h = c->res_host + RES_HEAD;
     int info = 0;
@@ -1222,7 +1208,6 @@ int pgp_dev_panel_factor(pgp_ctx* c, double* panel, int64_t ld, int64_t rows, in
     int info = 0;
     HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    CHK(potrf_diag_status(c));
     return info != 0 ? (info > w ? w : info) : PGP_OK;
 }
 
@@ -1281,7 +1266,6 @@ int pgp_potrf(pgp_ctx* c, const double* A, int64_t n, double* L_out) {
     int info = 0;
     HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    CHK(potrf_diag_status(c));
     if (c->prof) prof_collect(c);
     if (info != 0) return info > (int)n ? (int)n : info;
     // device holds column-major lower L; numpy wants row-major lower => transpose on the host

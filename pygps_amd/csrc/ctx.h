@@ -51,12 +51,10 @@ struct pgp_ctx {
     int eet_max_panels = 32;
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
-    int diag_fused = 1;                 // D(p) as ONE launch of 16 cooperating workgroups (csrc/panel.hip diag_panel_kernel);
-                                        // 0 = the chain of 13 small launches (leaf_potrf / trsm_rows / inner update)
-    unsigned* dflags = nullptr;         // barrier counter + error word of the fused diagonal-panel kernel
-    unsigned dp_base = 0;               // next barrier ticket (advanced per launch; the counter is never reset)
-    bool dp_used = false;
-    double dp_timeout_s = 10.0;         // every spin of the fused kernel is bounded
+    int leaf_first = 1;                 // 1: TU_b(p) is launched only after D(p+1)'s stage-in kernel, so that the first leaf is
+                                        // dispatched BEFORE the update's first wave takes every workgroup slot (a leaf dispatched
+                                        // into that wave waited ~140 us for it): 12.08 -> 11.72 ms per N = 8192 fit, two fit
+                                        // streams 102.6 -> 105 fits/s.  k > 1: after the (k-1)-th chain kernel (measured worse)
     int ep_fused = 2;                   // EP parameter recomputation: 0 blocked multi-rhs solve, 1 through the fused inverse (V' = K diag(sW)
                                         // L^-T as one product), 2 K diag(sW) as dense right-hand-side rows of the sweep
     int ep_r_direct = 1;                // EP gradient: sW sW' o B^-1 = S - S Sigma S from the rebuilt Sigma; 0 = triangular inverse + W'W
@@ -289,7 +287,6 @@ void prof_collect(pgp_ctx* c);
 static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int flags, int der, long d, CovSpec& cs);
 int cov_point_value(pgp_ctx* c, const CovSpec& cs, int train, double* out);
-int potrf_diag_status(pgp_ctx* c);
 int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse = false, double* E = nullptr,
                   long lde = 0);
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);

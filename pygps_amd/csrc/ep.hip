@@ -594,7 +594,6 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     HIP_TRY(hipMemcpyAsync(dsig_h.data(), w.diag_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(sc, c->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    CHK(potrf_diag_status(c));
     // -log marginal likelihood (inf.py:184-188): the per-site terms were reduced on the device (ep_site_terms_kernel, queued
     // before the copies above); the block partials are added here in block order
     double slZ = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0, t6 = 0.0;

@@ -17,6 +17,7 @@
 //     in memory (128-byte segments) for the C load / store.
 //   - C is pre-loaded into the accumulators (acc = (beta/alpha)*C) before the k-loop so its HBM
 //     latency overlaps the first operand tiles; out = alpha*acc = beta*C + alpha*A*B'.
+#include <algorithm>
 #include <atomic>
 
 #include "gemm_tile.h"

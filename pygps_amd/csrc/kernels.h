@@ -16,13 +16,6 @@ int trsv_bwd_launch(const double* L, long ldl, const double* W, long ldw, double
                     hipStream_t st);
 int diag_in_launch(const double* src, long lds, double* D, long ldd, int w, hipStream_t st);
 int diag_out_launch(const double* D, long ldd, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st);
-// D(p) of the Cholesky sweep as ONE launch (stage in, 4 x [leaf, trsm, update], stage out with a counter barrier between)
-size_t diag_panel_flag_bytes();
-int diag_panel_err_index();
-unsigned diag_panel_tickets(int w);
-int diag_panel_launch(const double* src, long lds, double* Dk, long ldd, double* dpack, double* Fd, long ldf, double* Ed,
-                      long lde, int w, unsigned* flags, unsigned base, int* info, int info_base, double timeout_s,
-                      hipStream_t st);
 int gather_strided_launch(const double* src, long stride, long n, double* dst, hipStream_t st);
 
 // assemble.hip

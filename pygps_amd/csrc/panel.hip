@@ -461,228 +461,7 @@ __global__ __launch_bounds__(256) void diag_out_kernel(const double* __restrict_
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Fused diagonal-panel kernel: D(p) of the Cholesky sweep (capi.hip: potrf_blocked_v2) as ONE launch.
-//
-// As 13 small dependent launches (stage in | per leaf: potrf, trsm of the w rows below, K = 128 inner update | stage out)
-// the chain takes ~220 us on an idle chip but ~620 us next to a trailing update (round-3 kernel trace: every launch queues
-// for a CU slot behind 140 us bulk workgroups, the leaf 28 -> 79 us, the 5 us staging kernel 46 us), and the main stream
-// waited ~1.4 ms per N = 8192 fit for it.  Here DP_WG workgroups are launched once per panel and walk the same phases,
-// separated by a counter barrier (agent-scope release / acquire, cdna guide G16): one wait for slots instead of thirteen,
-// no launch gaps on the critical path.  The barrier counter is never reset: a launch uses the tickets
-// [base, base + nbarrier * DP_WG) and the host advances `base` by exactly that amount per launch (wrap-around safe).
-// Every spin is bounded by a wall-clock timeout: on expiry the kernel posts an error code and every workgroup leaves.
-constexpr int DP_WG = 16;
-constexpr unsigned DP_BAR = 0, DP_ERR = 1;
-
-struct DiagPanelArgs {
-    const double* src; long lds;      // the (updated) diagonal block: w x w, lower part read
-    double* Dk; long ldd;             // scratch 2w x w: block on top, identity below
-    double* dpack;                    // per-leaf packed operand images
-    double* Fd; long ldf;             // L_D goes here (lower part)
-    double* Ed; long lde;             // E_D = L_D^-T goes here (whole block; may be null)
-    int w;
-    unsigned* flags; unsigned base;   // barrier counter / error word; first ticket of this launch
-    int* info; int info_base;
-    long long timeout_ticks;          // wall_clock64 ticks (100 MHz)
-};
-
-__device__ __forceinline__ unsigned ld_flag(const unsigned* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// barrier over the DP_WG workgroups: every wave drains its stores, one lane releases, arrives, polls, acquires
-__device__ __forceinline__ bool dp_barrier(unsigned* flags, unsigned& target, long long timeout, int* s_ok) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    target += DP_WG;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(flags + DP_BAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0 = wall_clock64();
-        int ok = 1;
-        while ((int)(ld_flag(flags + DP_BAR) - target) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (ld_flag(flags + DP_ERR) != 0) { ok = 0; break; }
-            if (wall_clock64() - t0 > timeout) {
-                __hip_atomic_store(flags + DP_ERR, 1000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *s_ok = ok;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-// The phase bodies are real calls (noinline): inlined together they need > 256 VGPRs and spill; as separate functions
-// each keeps the allocation of its stand-alone kernel (leaf 225, trsm, update < 256).
-__device__ __noinline__ void dp_leaf(double* A, long lda, double* pack, int* info, int info_base, double* smem) {
-    leaf_potrf_body(A, lda, pack, info, info_base, nullptr, smem);
-}
-__device__ __noinline__ void dp_trsm(double* X, long ldx, long nrows, const double* pack, long wg, double* smem) {
-    trsm_rows_body(X, ldx, nrows, pack, wg, smem);
-}
-// K = 128 update of the scratch columns right of a leaf, one wave per 16 rows (no LDS, no workgroup barrier):
-//     C[rows, c] -= Y[rows, :] Y[c, :]'      Y = the w solved rows of this leaf (Xw, 128 columns), c = window rows 0..ncols
-// in the transposed MFMA form of trsm_rows (D = C^T tile: row = column of C, col = row of C): the B operand is the
-// wave's own 16 rows of Y (32 doubles per lane, loaded once), the A operand the 16 rows of Y that belong to the target
-// columns -- L2-resident lines shared by every wave.  Window rows < ncols are the symmetric part: only tiles on or
-// below the diagonal are touched there.
-__device__ __noinline__ void dp_update_rows(const double* __restrict__ Xw, double* __restrict__ C, long ldd, int w,
-                                            int ncols, int grp, int part, int nparts) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (grp * 4 + wave) * 16;
-    if (r0 >= w) return;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    double yb[32];
-#pragma unroll
-    for (int ks = 0; ks < 32; ++ks) yb[ks] = Xw[(r0 + l15) + (long)(4 * ks + l4) * ldd];
-    const int ngrp = ncols >> 4;
-    const int jend = (r0 < ncols) ? (r0 >> 4) + 1 : ngrp;               // symmetric part: column groups up to the diagonal
-    // the column groups are dealt round-robin to `nparts` waves; the A fragments (and the C tile) of the NEXT group are
-    // loaded while the 32 MFMAs of the current one issue (software pipeline: the loop is latency-bound otherwise)
-    double ya[32], yn[32];
-    double4_t cn;
-    auto fetch = [&](int jg, double (&dst)[32], double4_t& c) {
-        const int c0 = 16 * jg;
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks) dst[ks] = Xw[(c0 + l15) + (long)(4 * ks + l4) * ldd];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) c[q] = C[(r0 + l15) + (long)(c0 + l4 + 4 * q) * ldd];
-    };
-    if (part < jend) fetch(part, yn, cn);
-    for (int jg = part; jg < jend; jg += nparts) {
-        const int c0 = 16 * jg;
-        double4_t a0 = cn, b0 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks) ya[ks] = -yn[ks];
-        if (jg + nparts < jend) fetch(jg + nparts, yn, cn);
-#pragma unroll
-        for (int ks = 0; ks < 32; ks += 2) {            // two independent accumulation chains
-            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ks], yb[ks], a0, 0, 0, 0);
-            b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ks + 1], yb[ks + 1], b0, 0, 0, 0);
-        }
-        a0 += b0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) C[(r0 + l15) + (long)(c0 + l4 + 4 * q) * ldd] = a0[q];
-    }
-}
-
-// stage in: top = lower part of the (updated) diagonal block, bottom = identity.  Workgroup -> columns wg, wg + DP_WG,
-// ...; 8 columns (= 8 independent 16-byte loads per thread) per round: the loop is latency-bound.  (Own functions, like
-// the phase bodies: inlined into the kernel next to the calls they were compiled with a handful of registers and spilled.)
-__device__ __noinline__ void dp_stage_in(const double* __restrict__ src, long lds, double* __restrict__ Dk, long ldd, int w,
-                                         int wg) {
-    const int t = threadIdx.x;
-    for (int jb = wg; jb < w; jb += 8 * DP_WG)
-        for (int i = 2 * t; i < w; i += 512) {
-            double2_t v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = jb + u * DP_WG;
-                v[u] = double2_t{0.0, 0.0};
-                if (j < w && i + 1 >= j) v[u] = *(const double2_t*)(src + i + (long)j * lds);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = jb + u * DP_WG;
-                if (j >= w) continue;
-                double2_t o = v[u];
-                if (i < j) o[0] = 0.0;
-                *(double2_t*)(Dk + i + (long)j * ldd) = o;
-                *(double2_t*)(Dk + w + i + (long)j * ldd) = double2_t{i == j ? 1.0 : 0.0, i + 1 == j ? 1.0 : 0.0};
-            }
-        }
-}
-// stage out: L_D (lower part) -> factor, E_D (whole block, zeros below its diagonal included) -> inverse rows
-__device__ __noinline__ void dp_stage_out(const double* __restrict__ Dk, long ldd, int w, double* __restrict__ Fd, long ldf,
-                                          double* __restrict__ Ed, long lde, int wg) {
-    const int t = threadIdx.x;
-    for (int jb = wg; jb < w; jb += 4 * DP_WG)
-        for (int i = 2 * t; i < w; i += 512) {
-            double2_t lo[4], hi[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = jb + u * DP_WG;
-                lo[u] = hi[u] = double2_t{0.0, 0.0};
-                if (j < w) {
-                    if (i + 1 >= j) lo[u] = *(const double2_t*)(Dk + i + (long)j * ldd);
-                    if (Ed && i <= j) hi[u] = *(const double2_t*)(Dk + w + i + (long)j * ldd);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = jb + u * DP_WG;
-                if (j >= w) continue;
-                if (i >= j) *(double2_t*)(Fd + i + (long)j * ldf) = lo[u];
-                else if (i + 1 >= j) Fd[i + 1 + (long)j * ldf] = lo[u][1];
-                if (Ed) {
-                    double2_t o = hi[u];
-                    if (i + 1 > j) o[1] = 0.0;
-                    *(double2_t*)(Ed + i + (long)j * lde) = o;
-                }
-            }
-        }
-}
-
-__global__ __launch_bounds__(256, 2) void diag_panel_kernel(DiagPanelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    int* s_ok = (int*)(smem + 36 * 256 + 256 + 1);            // beside the leaf's info word (all LDS stays dynamic)
-    const int wg = blockIdx.x;
-    const int w = a.w, qq = w / 128;
-    const long ldd = a.ldd;
-    unsigned target = a.base;
-    // the chain is the critical path and shares its CUs with trailing-update workgroups: win the issue arbitration
-    __builtin_amdgcn_s_setprio(3);
-    dp_stage_in(a.src, a.lds, a.Dk, ldd, w, wg);
-    if (!dp_barrier(a.flags, target, a.timeout_ticks, s_ok)) return;
-    for (int cb = 0; cb < qq; ++cb) {
-        double* Acc = a.Dk + (long)cb * 128 * (1 + ldd);
-        double* pack = a.dpack + (long)cb * PACK_DOUBLES;
-        if (wg == 0) dp_leaf(Acc, ldd, pack, a.info, a.info_base + cb * 128, smem);
-        if (!dp_barrier(a.flags, target, a.timeout_ticks, s_ok)) return;
-        // rows below the leaf inside the scratch: (qq-1-cb) 128 block rows + (cb+1) 128 identity-born rows = w rows
-        for (long g0 = wg; g0 * 64 < w; g0 += DP_WG) {
-            dp_trsm(Acc + 128, ldd, w, pack, g0, smem);
-            __syncthreads();
-        }
-        if (cb + 1 < qq) {                               // K = 128 update of the scratch columns right of the leaf
-            if (!dp_barrier(a.flags, target, a.timeout_ticks, s_ok)) return;
-            // row groups of 64 (4 waves x 16 rows); the column groups of one row group are shared by `np_` workgroups
-            const int ngr = w / 64, np_ = max(1, DP_WG / ngr);
-            for (int u = wg; u < ngr * np_; u += DP_WG)
-                dp_update_rows(Acc + 128, a.Dk + (long)(cb + 1) * 128 * (1 + ldd), ldd, w, (qq - 1 - cb) * 128, u % ngr,
-                               u / ngr, np_);
-        }
-        if (!dp_barrier(a.flags, target, a.timeout_ticks, s_ok)) return;
-    }
-    dp_stage_out(a.Dk, ldd, w, a.Fd, a.ldf, a.Ed, a.lde, wg);
-}
 }  // namespace
-
-size_t diag_panel_flag_bytes() { return 64 * sizeof(unsigned); }
-int diag_panel_err_index() { return (int)DP_ERR; }
-// barriers (tickets / DP_WG) one launch with panel width w consumes: 1 after the stage-in, 3 per leaf minus the update of
-// the last one
-unsigned diag_panel_tickets(int w) { const int qq = w / 128; return (unsigned)(1 + 3 * qq - 1) * DP_WG; }
-
-int diag_panel_launch(const double* src, long lds, double* Dk, long ldd, double* dpack, double* Fd, long ldf, double* Ed,
-                      long lde, int w, unsigned* flags, unsigned base, int* info, int info_base, double timeout_s,
-                      hipStream_t st) {
-    DiagPanelArgs a{src, lds, Dk, ldd, dpack, Fd, ldf, Ed, lde, w, flags, base, info, info_base, (long long)(timeout_s * 1e8)};
-    const size_t shm = (36 * 256 + 256 + 2) * sizeof(double);
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute((const void*)diag_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set.store(true, std::memory_order_release);
-    }
-    hipLaunchKernelGGL(diag_panel_kernel, dim3(DP_WG), dim3(256), shm, st, a);
-    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
-}
 
 int diag_in_launch(const double* src, long lds, double* D, long ldd, int w, hipStream_t st) {
     hipLaunchKernelGGL(diag_in_kernel, dim3(w), dim3(256), 0, st, src, lds, D, ldd, w);
