@@ -309,62 +309,53 @@ def cfg4_extra(torch, dist, world, n4=8192):
                     "gradients each), wall time of the whole optimize() call of a warmed-up model (max over ranks)"}
 
 
-def sharded_cholesky_extra(torch, dist, n, w=512):
-    """SURVEY 8(f) row 4, measured: ONE Cholesky factorisation of an (n x n) RBF kernel matrix spread over all ranks
-    (pygps_amd.multigpu.ShardedCholesky: 1-D block-cyclic column panels, panel broadcasts over RCCL, trailing updates on
-    the fp64-MFMA GEMM).  The matrix is generated on the device panel by panel (torch: input generation only) and the
-    factor is checked in place with a distributed residual ||L L' v - A v|| / ||A v|| (no gather, no oracle).
-    Collective: every rank calls this."""
-    from pygps_amd.multigpu import ShardedCholesky
-    sc = ShardedCholesky(n, w=w)
-    dev, rank, world, plan = sc.device, sc.rank, sc.world, sc.plan
-    gen = torch.Generator().manual_seed(11)
-    X = torch.rand((n, 8), generator=gen, dtype=torch.float64).to(dev) * 4.0
-    v = torch.randn((n,), generator=gen, dtype=torch.float64).to(dev)
-    x2 = (X * X).sum(1)
-    times = []
-    for rep in range(2):                                                     # the first pass also warms pools, kernels, RCCL
-        Av = torch.zeros(n, dtype=torch.float64, device=dev)
-        for p in plan.owned(rank):
-            c = plan.local_index(p) * w
-            cols = slice(p * w, (p + 1) * w)
-            blk = sc.local[c:c + w]                                         # row a = column p w + a of the matrix
-            torch.mm(X[cols], X.T, out=blk)
-            blk.mul_(-2.0).add_(x2[cols, None]).add_(x2[None, :]).clamp_(min=0.0).mul_(-0.5).exp_()
-            blk[:, cols].diagonal().add_(0.1)
-            Av += blk.T @ v[cols]
-        dist.all_reduce(Av)
+def sharded_fit_extra(torch, dist, n, d=16):
+    """SURVEY 8(f) row 4, measured: ONE exact-GP fit (RBF, d = 16: assembly, Cholesky + fused inverse, alpha, nlZ, E E' and all
+    gradients) spread over ALL ranks -- pgp_sharded_exact_fit (csrc/sharded.hip): 1-D block-cyclic column panels, panel
+    broadcasts by RCCL driven from C (no host synchronisation inside the sweep), two small all-reduces.  The same n at every
+    world size (a strong-scaling series).  Checked in place: the normal equations (K + sn2 I) alpha = y - m on a sample of
+    rows, K rebuilt on the host from the coordinates.  Collective: every rank calls this."""
+    import pygps_amd as pyGPs
+    from pygps_amd import sharded
+    rank, world = dist.get_rank(), dist.get_world_size()
+    x, y = synth_reg(n, d, seed=5)
+    comm = sharded.Comm()
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+    m.setNoise(np.log(0.1))
+    m.setData(x, y)
+    m.inffunc = pyGPs.inf.Exact(sharded=comm)
+    times, stages = [], None
+    for rep in range(2):                                     # the first pass also warms pools, kernels, RCCL
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sc.factor()
+        nlZ, dnlZ, post = m.getPosterior()
         torch.cuda.synchronize(); dist.barrier()
-        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         times.append(float(tt.item()))
+        stages = [float(v) for v in m.inffunc.last_ms]
     dt = times[-1]
-    u = torch.zeros(n, dtype=torch.float64, device=dev)                     # u = L' v, each rank its own columns
-    masked = {}
-    for p in plan.owned(rank):
-        c = plan.local_index(p) * w
-        cols = slice(p * w, (p + 1) * w)
-        Lp = sc.local[c:c + w].clone()
-        Lp[:, :p * w] = 0.0
-        Lp[:, cols] = torch.triu(Lp[:, cols])                               # [a, b] = L[p w + b, p w + a], b >= a
-        u[cols] = Lp @ v
-        masked[p] = Lp
-    dist.all_reduce(u)
-    LLv = torch.zeros(n, dtype=torch.float64, device=dev)
-    for p, Lp in masked.items():
-        LLv += Lp.T @ u[p * w:(p + 1) * w]
-    dist.all_reduce(LLv)
-    res = float(((LLv - Av).norm() / Av.norm()).item())
-    fl = float(n) ** 3 / 3.0
-    return {"what": "ONE (n x n) fp64 Cholesky over all ranks: 1-D block-cyclic column panels of %d, depth-1 look-ahead, panel "
-                    "broadcast over RCCL (pygps_amd.multigpu.ShardedCholesky); matrix generated on the device" % w,
-            "n": n, "world": world, "panels": plan.npanel, "seconds": dt, "seconds_first_pass": times[0], "TFLOPs": fl / dt / 1e12,
-            "TFLOPs_per_gpu": fl / dt / 1e12 / world, "frac_of_peak_per_gpu": fl / dt / 1e12 / world / PEAK_FP64_MFMA_TF,
-            "residual_LLtv_vs_Av": res, "bytes_broadcast": float(sum(s.bcast_bytes for s in plan.steps())),
-            "imbalance": plan.imbalance()}
+    sn2, c = float(np.exp(2 * m.likfunc.hyp[0])), float(m.meanfunc.hyp[0])
+    idx = np.arange(0, n, max(1, n // 64))[:64]
+    ell2 = float(np.exp(2 * m.covfunc.hyp[0]))
+    d2 = ((x[idx, None, :] - x[None, :, :]) ** 2).sum(-1)
+    lhs = np.exp(-0.5 * d2 / ell2) @ post.alpha + sn2 * post.alpha[idx]
+    res = float(np.abs(lhs - (y[idx] - c)).max() / np.abs(y - c).max())
+    w = 1024 if n >= 12288 else 512
+    npad = -(-n // w) * w
+    sweep_s = stages[1] * 1e-3
+    comm.close()
+    return {"what": "ONE exact-GP fit (nlZ + all gradients) over all ranks: pgp_sharded_exact_fit, 1-D block-cyclic column panels "
+                    "of %d (factor | rhs | fused-inverse rows), depth-1 look-ahead, panel broadcasts by RCCL driven from C, "
+                    "partial E E' per rank and the gradient reduce on the partials (no N^2 reduction)" % w,
+            "n": n, "d": d, "world": world, "panels": npad // w, "transport": comm.transport,
+            "seconds": dt, "seconds_first_pass": times[0], "stage_ms": dict(zip(("assemble", "sweep_and_EEt", "epilogue", "total"), stages)),
+            "flops": float(n) ** 3, "TFLOPs": float(n) ** 3 / dt / 1e12, "TFLOPs_per_gpu": float(n) ** 3 / dt / 1e12 / world,
+            "frac_of_peak_per_gpu": float(n) ** 3 / dt / 1e12 / world / PEAK_FP64_MFMA_TF,
+            "sweep_frac_of_peak_per_gpu": float(npad) ** 3 / sweep_s / 1e12 / world / PEAK_FP64_MFMA_TF,
+            "bytes_broadcast_per_rank": float((npad + 128) * npad * 8) * (world > 1),
+            "nlZ": float(nlZ), "residual_normal_equations": res}
 
 
 def main():
@@ -675,9 +666,9 @@ def main():
             partial["cfg4_restarts_N8192"] = {"error": repr(e), "n_gpus": world}
         if sn > 0:
             try:
-                partial["sharded_cholesky"] = sharded_cholesky_extra(torch, dist, sn)
+                partial["sharded_fit"] = sharded_fit_extra(torch, dist, sn)
             except Exception as e:                           # pragma: no cover
-                partial["sharded_cholesky"] = {"error": repr(e), "n": sn, "world": world}
+                partial["sharded_fit"] = {"error": repr(e), "n": sn, "world": world}
         dog.cancel()
         if rank == 0:
             out.update(partial)

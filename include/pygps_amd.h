@@ -120,21 +120,35 @@ int pgp_fitc_predict(pgp_ctx* ctx, pgp_fitc* f, const double* xs, int64_t ns, co
                      double* fs2);
 void pgp_fitc_free(pgp_ctx* ctx, pgp_fitc* f);
 
+/* ---- ONE fit over the GPUs of a node (no reference counterpart: Core/inf.py:353-384 runs on one host) ---
+ * One process per GPU, every rank calls with the same data (pgp_set_data) and arguments.  The factorisation is 1-D
+ * block-cyclic over column panels; panels are broadcast over `comm`, alpha / nlZ / dnlZ come back identical on every
+ * rank (csrc/sharded.hip).  Transports:
+ *   pgp_comm_init_rccl: RCCL bound at run time (rccl_path: the librccl to dlopen, NULL = the system's); rank 0 makes the
+ *                       128-byte id with pgp_comm_unique_id and hands it to the other ranks (any side channel).
+ *   pgp_comm_init_host: call-backs that broadcast / all-reduce HOST buffers (op: 0 sum, 1 max; return 0 on success); the
+ *                       library stages device memory through pinned host memory.  For MPI / gloo style transports and for
+ *                       tests in which several ranks share one GPU. */
+typedef struct pgp_comm pgp_comm;
+typedef int (*pgp_host_bcast_fn)(void* user, void* buf, int64_t bytes, int root);
+typedef int (*pgp_host_allreduce_fn)(void* user, double* buf, int64_t count, int op);
+int pgp_comm_unique_id(const char* rccl_path, char* id_out /* 128 bytes */);
+int pgp_comm_init_rccl(pgp_ctx* ctx, int world, int rank, const char* id /* 128 bytes */, const char* rccl_path,
+                       pgp_comm** comm_out);
+int pgp_comm_init_host(pgp_ctx* ctx, int world, int rank, pgp_host_bcast_fn bcast, pgp_host_allreduce_fn allreduce,
+                       void* user, pgp_comm** comm_out);
+void pgp_comm_free(pgp_comm* comm);
+int pgp_comm_world(pgp_comm* comm);
+int pgp_comm_rank(pgp_comm* comm);
+/* Arguments and results as pgp_exact_fit (no factor handle: the factor stays distributed).  timings_out (optional, 4):
+ * ms of assembly, sweep, epilogue, total. */
+int pgp_sharded_exact_fit(pgp_ctx* ctx, pgp_comm* comm, int kind, const double* covhyp, int ncov, int para, int flags,
+                          double log_sn, const double* mvec, const double* dm, int nmean, int want, double* alpha_out,
+                          double* nlZ_out, double* dnlZ_out, double* timings_out);
+
 /* ---- helper functions: tools.jitchol / tools.solve_chol (Core/tools.py:31-97) ----------------
  * pgp_potrf: A (n,n) symmetric row-major in -> lower Cholesky factor (row-major, zeros above) out.
  * pgp_potrs: R (n,n) UPPER factor row-major, Bm (n,nrhs) row-major in -> X = (R'R)^-1 Bm out.   */
-/* Device-pointer primitives of the single-fit multi-GPU Cholesky (no reference counterpart -- the
- * reference's tools.jitchol, Core/tools.py:31-77, factors on one host).  pygps_amd/multigpu.py drives them: one column panel
- * per call, caller-owned device memory, torch.distributed (RCCL) broadcasts in between.  The work runs on the context's
- * stream: pgp_dev_panel_factor returns after everything queued so far is done, pgp_dev_panel_update only queues its launch,
- * pgp_dev_sync waits for the stream.
- *   pgp_dev_panel_factor: factor the w x w block on top of `panel` (rows x w, column-major, ld), solve the rows below it.
- *                         Returns k > 0 when pivot k of the block is not positive.
- *   pgp_dev_panel_update: C (M x w, ldc) -= Y Y[0:w,:]' over the lower trapezoid, Y (M x k, ldy) = the broadcast panel's
- *                         rows facing C. */
-int pgp_dev_panel_factor(pgp_ctx* ctx, double* panel_dev, int64_t ld, int64_t rows, int w);
-int pgp_dev_panel_update(pgp_ctx* ctx, double* C_dev, int64_t ldc, int64_t M, int w, const double* Y_dev, int64_t ldy, int k);
-int pgp_dev_sync(pgp_ctx* ctx);
 int pgp_potrf(pgp_ctx* ctx, const double* A, int64_t n, double* L_out);
 int pgp_potrs(pgp_ctx* ctx, const double* R, int64_t n, const double* Bm, int64_t nrhs, double* X_out);
 

@@ -61,9 +61,14 @@ SIGNATURES = {
     "pgp_profile_read": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), _dp, _dp, _dp]),
     "pgp_profile_reset": (C.c_int, [_vp]),
     "pgp_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
-    "pgp_dev_panel_factor": (C.c_int, [_vp, C.c_void_p, _i64, _i64, C.c_int]),
-    "pgp_dev_panel_update": (C.c_int, [_vp, C.c_void_p, _i64, _i64, C.c_int, C.c_void_p, _i64, C.c_int]),
-    "pgp_dev_sync": (C.c_int, [_vp]),
+    "pgp_comm_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "pgp_comm_init_rccl": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
+    "pgp_comm_init_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "pgp_comm_free": (None, [_vp]),
+    "pgp_comm_world": (C.c_int, [_vp]),
+    "pgp_comm_rank": (C.c_int, [_vp]),
+    "pgp_sharded_exact_fit": (C.c_int, [_vp, _vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int,
+                                        C.c_int, _dp, _dp, _dp, _dp]),
 }
 
 # self-test / calibration hooks (csrc/testhooks.h): exported by the library, NOT part of the drop-in boundary

@@ -450,16 +450,35 @@ static int tile_table(int tri, long ntr, long ntc, const int2** tab, long* cnt) 
     return PGP_OK;
 }
 
+// kind 3: the tiles of the column-major lower panel of tile columns [t0, t1) of an nt x nt factor: (i, j) with i in
+// [t0, t1), j >= i (the kernel's "row" index i is the factor's COLUMN: row-major upper == column-major lower)
+static int panel_tile_table(long nt, long t0, long t1, const int2** tab, long* cnt) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PGP_ERR_HIP;
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    const std::vector<long> key = {dev, 3, nt, t0, t1};
+    auto it = g_tabs.find(key);
+    if (it == g_tabs.end()) {
+        std::vector<int2> h;
+        for (long i = t0; i < t1; ++i)
+            for (long j = i; j < nt; ++j) h.push_back(make_int2((int)i, (int)j));
+        int2* d = nullptr;
+        if (hipMalloc((void**)&d, std::max<size_t>(1, h.size()) * sizeof(int2)) != hipSuccess) return PGP_ERR_HIP;
+        if (!h.empty() && hipMemcpy(d, h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) return PGP_ERR_HIP;
+        it = g_tabs.emplace(key, std::make_pair(d, (long)h.size())).first;
+    }
+    *tab = it->second.first; *cnt = it->second.second;
+    return PGP_OK;
+}
+
 static int g_tile_grid = 2048;                     // persistent workgroups (4 resident per CU, the rest queue: dynamic balance); option "asm_grid"
 void cov_tile_set_grid(int g) { g_tile_grid = g; }
 
 template <int MODE>
 static int cov_tile_dispatch(const CovSpec& cs, int train, long ntr, long ntc_, hipStream_t st, const double* XrT, long ldr,
                              long n, const double* XcT, long ldc, long m, int dpad, double inv_sn2, double* out,
-                             long ldo) {
-    const int2* tiles = nullptr;
-    long ntiles = 0;
-    { const int rc = tile_table(MODE != MODE_RECT, ntr, ntc_, &tiles, &ntiles); if (rc != PGP_OK) return rc; }
+                             long ldo, const int2* tiles = nullptr, long ntiles = 0) {
+    if (!tiles) { const int rc = tile_table(MODE != MODE_RECT, ntr, ntc_, &tiles, &ntiles); if (rc != PGP_OK) return rc; }
     if (ntiles == 0) return PGP_OK;
     const unsigned nblk = g_tile_grid > 0 ? (unsigned)std::min<long>(ntiles, g_tile_grid) : (unsigned)ntiles;
     if (cs.prog) {
@@ -520,6 +539,21 @@ int cov_factor_launch(const double* XT, long ldp, long n, long np, int dpad, con
                       double* Bf, long ldf, hipStream_t st) {
     const long nt = np / ST;
     return cov_tile_dispatch<MODE_FACTOR>(cs, 1, nt, nt, st, XT, ldp, n, XT, ldp, n, dpad, inv_sn2, Bf, ldf);
+}
+
+// The same fused assembly for ONE column panel of the factor: columns [col0, col0 + ncols) (multiples of 64) of B = K/sn2 + I,
+// rows >= the column, written column-major into `panel` (leading dimension ldpanel) with the panel's first diagonal entry at
+// panel[0] -- the storage of one owned panel of the block-cyclic sweep (csrc/sharded.hip).
+int cov_factor_panel_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double inv_sn2,
+                            long col0, long ncols, double* panel, long ldpanel, hipStream_t st) {
+    const long nt = np / ST;
+    const int2* tiles = nullptr;
+    long ntiles = 0;
+    { const int rc = panel_tile_table(nt, col0 / ST, (col0 + ncols) / ST, &tiles, &ntiles); if (rc != PGP_OK) return rc; }
+    // element (row r, column c) of the factor is written at out[c * ldo + r]: shift the base so that it lands at
+    // panel[(c - col0) * ldpanel + (r - col0)]
+    double* out = panel - col0 * ldpanel - col0;
+    return cov_tile_dispatch<MODE_FACTOR>(cs, 1, nt, nt, st, XT, ldp, n, XT, ldp, n, dpad, inv_sn2, out, ldpanel, tiles, ntiles);
 }
 
 // k(z,z) and its derivatives at zero distance ('self_test' mode): one evaluation of the functor

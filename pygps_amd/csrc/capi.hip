@@ -1178,66 +1178,6 @@ int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n,
 }
 
 // ---- helper functions ------------------------------------------------------------------------------
-// ---- device-pointer primitives of the multi-GPU (1-D block-cyclic) Cholesky executor, pygps_amd/multigpu.py --------
-// The caller owns the device memory (one column panel per call, column-major, leading dimension ld); the work runs on
-// the context's stream (the executor interleaves these calls with torch.distributed broadcasts on torch's stream):
-// pgp_dev_panel_factor returns after everything queued so far has finished, pgp_dev_panel_update only queues its
-// launch, pgp_dev_sync waits for the stream.
-
-// Panel step of the right-looking sweep on ONE column panel: the w x w block at the top of `panel` is factored
-// (lower Cholesky), the rows - w rows below it are solved against it in place (X <- X L_D^-T): D(p) and S(p) of
-// potrf_blocked_v2 on a tall matrix.  w: multiple of 128, <= 1024; rows: multiple of 128, >= w.
-int pgp_dev_panel_factor(pgp_ctx* c, double* panel, int64_t ld, int64_t rows, int w) {
-    if (!c) return -1;
-    if (!panel) return -2;
-    if (w <= 0 || w % 128 || w > 1024 || rows < w || rows % 128 || ld < rows) return -3;
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = c->st;
-    PoolScratch scr(c);
-    double* pack = nullptr;
-    CHK(scr.alloc(&pack, (size_t)(w / 128) * PACK_DOUBLES * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
-    double* pack_save = c->inv16;
-    const int nb_save = c->nb_outer;
-    c->inv16 = pack;
-    c->nb_outer = w / 128;                          // the whole panel is one outer panel: D once, then one solve
-    const int rc = potrf_blocked(c, panel, ld, w, rows);
-    c->inv16 = pack_save;
-    c->nb_outer = nb_save;
-    CHK(rc);
-    int info = 0;
-    HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return info != 0 ? (info > w ? w : info) : PGP_OK;
-}
-
-// Trailing update of ONE owned column panel with a broadcast panel Y (rows x k, column-major, ldy):
-//   C(m, n) -= sum_k Y(m, k) Y(n, k)   for m < M, n < w, lower trapezoid (tiles on or below the diagonal of C's top block),
-// C = the owned panel from its diagonal block down (M x w, ldc), Y = the rows of the broadcast panel that face C's rows.
-int pgp_dev_panel_update(pgp_ctx* c, double* C, int64_t ldc, int64_t M, int w, const double* Y, int64_t ldy, int k) {
-    if (!c) return -1;
-    if (!C || !Y) return -2;
-    if (w <= 0 || w % 128 || M < w || M % 128 || k <= 0 || k % 16 || ldc < M || ldy < M) return -3;
-    HIP_TRY(hipSetDevice(c->device));
-    GemmArgs g{};
-    g.A = Y; g.lda = ldy; g.a_kc = 0;
-    g.B = Y; g.ldb = ldy; g.b_kc = 0;
-    g.C = C; g.ldc = ldc;
-    g.M = (int)M; g.N = w; g.K = k; g.alpha = -1.0; g.beta = 1.0;
-    g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
-    const long t128 = (M / 128) * (w / 128) - (long)(w / 128) * (w / 128 - 1) / 2;
-    g.tile = t128 < c->small_tile_below ? 64 : 128;
-    g.flops = 2.0 * (double)k * ((double)M * w - 0.5 * (double)w * w);
-    return gemm_prof(c, PC_GEMM_TRAIL, g, c->st);       // asynchronous: pgp_dev_sync / the next pgp_dev_panel_factor waits
-}
-
-int pgp_dev_sync(pgp_ctx* c) {
-    if (!c) return -1;
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->st));
-    return PGP_OK;
-}
-
 int pgp_potrf(pgp_ctx* c, const double* A, int64_t n, double* L_out) {
     if (!c) return -1;
     if (!A) return -2;

@@ -290,6 +290,8 @@ int cov_point_value(pgp_ctx* c, const CovSpec& cs, int train, double* out);
 int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse = false, double* E = nullptr,
                   long lde = 0);
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);
+int diag_block_factor(pgp_ctx* c, const double* src, long lds, int w, double* Fd, long ldf, double* Ed, long lde,
+                      int info_base, hipStream_t st, hipEvent_t staged = nullptr);
 int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ldw, double* T, long np);
 int lauum_lower(pgp_ctx* c, const double* W, long ldw, double* Binv, long ldb, long np);
 int upload_scaled(pgp_ctx* c, const double* x_dev, long n, long d, const std::vector<double>& sc, double* XsT, long ldp,

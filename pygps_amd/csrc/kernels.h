@@ -27,6 +27,8 @@ int cov_rect_launch(const double* XrT, long ldr, long n, const double* XcT, long
                     const CovSpec& cs, double* out, long ldo, hipStream_t st);
 int cov_factor_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double inv_sn2,
                       double* Bf, long ldf, hipStream_t st);
+int cov_factor_panel_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double inv_sn2,
+                            long col0, long ncols, double* panel, long ldpanel, hipStream_t st);
 void cov_tile_set_grid(int g);
 int cov_self_launch(const CovSpec& cs, int train, double* out_dev, hipStream_t st);
 int self_fill_launch(double* out, long m, double val, hipStream_t st);

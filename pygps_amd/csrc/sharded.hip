@@ -1,0 +1,556 @@
+// ONE exact-GP fit spread over the GPUs of a node: Exact.evaluate (Core/inf.py:353-384) with the
+// factorisation of B = K/sn2 + I (tools.jitchol, Core/tools.py:31-77), the solves for alpha (:363), nlZ (:370), the inverse
+// behind Q (:373) and the gradient sums (:374-377) all distributed.  No reference counterpart: pyGPs factors on one host.
+//
+// Layout: 1-D block-cyclic over column panels of w columns (w = 512, 1024 from N = 12288: the single-GPU sweep's panel),
+// panel p on rank p % world, one process per GPU.  A panel is stored in the LOGICAL row space of the single-GPU sweep
+// (capi.hip: potrf_blocked_v2) -- factor rows | 128 right-hand-side rows | fused-inverse rows E = L^-T -- compacted:
+//
+//     unfactored panel j  P_j : (np + 128) x w,  row r = logical row - j w :  [ diagonal block w | rows below | rhs 128 | E rows < j w ]
+//     solved panel p      Y_p : (np + 128) x w,  row r = logical row - (p+1) w : [ rows below | rhs 128 | E rows < (p+1) w ]
+//
+// so one contiguous Y_p is everything the other ranks need from panel p: it is what gets broadcast (np + 128 rows for every
+// p: the factor's rows shrink as the inverse's rows grow).  Per step p, exactly the single-GPU sweep:
+//     owner(p)      D(p): diagonal block -> L_D, E_D = L_D^-T (leaf chain);  S(p): Y_p = P_p[w:] E_D (one MFMA GEMM)
+//     broadcast     Y_p from owner(p)                         [RCCL over xGMI; per link bound: (np+128) w 8 B / ~153 GB/s]
+//     every rank    TU(p): P_j -= Y_p[rows of j] Y_p[block j]'  for ALL its owned j > p in ONE batched launch
+//                   (GemmArgs::batch_dm: the products shrink with j), first-touch of the E rows of block p
+// with the depth-1 look-ahead of the single-GPU sweep: the owner of panel p+1 updates that panel first, factors it on the
+// panel stream and solves it, and its broadcast travels on the communication stream while every rank (the owner too) works
+// through the rest of step p.  Storage: a factored panel's P buffer is dead after S, so Y_k of local panel k goes into the
+// buffer P_{k-1} leaves behind: (nloc + 1) buffers per rank, i.e. (np + 128) np / world doubles + one panel.
+//
+// What a fit needs beyond the factor needs almost no communication, because everything is LINEAR in the panels:
+//     alpha = E z / sn2 = sum_p E_p z_p / sn2        per-rank partial matvecs, ONE all-reduce of np + 3 doubles
+//     log det, z'z                                    per-panel scalars, in the same all-reduce
+//     B^-1 = E E' = sum_p E_p E_p'                    each rank accumulates ITS panels' products (N^3 / 3 / world flops) into
+//                                                     a partial B^-1 -- which is never summed: the gradient sums
+//     dnlZ_h = 1/2 sum_ij (B^-1/sn2 - alpha alpha')_ij dK_h,ij    are linear in B^-1, so every rank runs the single-GPU
+//                                                     Hadamard reduce on its partial (alpha scaled by 1/sqrt(world) so that
+//                                                     the alpha alpha' term is counted once) and ONE all-reduce of ncov + 1
+//                                                     doubles finishes the gradient.  No reduce-scatter of N^2 words.
+// Transport: pgp_comm -- RCCL bound at run time (dlopen of librccl: ncclBroadcast on a communication stream, events between
+// it and the compute streams, no host synchronisation inside the sweep), or host call-backs on staged host buffers (the
+// self-test transport: gloo through torch.distributed lets several ranks share the one GPU of a test box).
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ctx.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// transport
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+typedef struct { char internal[128]; } rccl_uid;          // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+typedef void* rccl_comm_t;
+constexpr int RCCL_DOUBLE = 8, RCCL_SUM = 0, RCCL_MAX = 2;   // ncclFloat64, ncclSum, ncclMax (rccl.h)
+
+struct RcclApi {
+    void* dl = nullptr;
+    int (*GetUniqueId)(rccl_uid*) = nullptr;
+    int (*CommInitRank)(rccl_comm_t*, int, rccl_uid, int) = nullptr;
+    int (*CommDestroy)(rccl_comm_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+static int rccl_load(const char* path, RcclApi& api) {
+    const char* names[] = {path && path[0] ? path : nullptr, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        if (!nm) continue;
+        api.dl = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (api.dl) break;
+    }
+    if (!api.dl) {
+        pgp_set_last_hip_error(hipErrorSharedObjectInitFailed, "dlopen(librccl)", __FILE__, __LINE__);
+        return PGP_ERR_HIP;
+    }
+    api.GetUniqueId = (int (*)(rccl_uid*))dlsym(api.dl, "ncclGetUniqueId");
+    api.CommInitRank = (int (*)(rccl_comm_t*, int, rccl_uid, int))dlsym(api.dl, "ncclCommInitRank");
+    api.CommDestroy = (int (*)(rccl_comm_t))dlsym(api.dl, "ncclCommDestroy");
+    api.Broadcast = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(api.dl, "ncclBroadcast");
+    api.AllReduce = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(api.dl, "ncclAllReduce");
+    api.GetErrorString = (const char* (*)(int))dlsym(api.dl, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Broadcast || !api.AllReduce) {
+        pgp_set_last_hip_error(hipErrorSharedObjectSymbolNotFound, "dlsym(librccl)", __FILE__, __LINE__);
+        return PGP_ERR_HIP;
+    }
+    return PGP_OK;
+}
+
+static int rccl_fail(const RcclApi& api, int rc, const char* what) {
+    char msg[256];
+    snprintf(msg, sizeof(msg), "%s: RCCL error %d (%s)", what, rc, api.GetErrorString ? api.GetErrorString(rc) : "?");
+    pgp_set_last_hip_error(hipErrorUnknown, msg, __FILE__, __LINE__);
+    return PGP_ERR_HIP;
+}
+
+}  // namespace
+
+struct pgp_comm {
+    pgp_ctx* ctx = nullptr;
+    int world = 1, rank = 0;
+    int kind = 0;                       // 1 RCCL, 2 host call-backs
+    RcclApi api;
+    rccl_comm_t comm = nullptr;
+    hipStream_t st_comm = nullptr;      // broadcasts travel here, beside the compute streams
+    pgp_host_bcast_fn hb = nullptr;
+    pgp_host_allreduce_fn har = nullptr;
+    void* user = nullptr;
+    void* stage = nullptr;              // pinned staging buffer of the host transport
+    size_t stage_bytes = 0;
+};
+
+namespace {
+
+static int comm_stage(pgp_comm* m, size_t bytes) {
+    if (m->stage_bytes >= bytes) return PGP_OK;
+    if (m->stage) (void)hipHostFree(m->stage);
+    m->stage = nullptr; m->stage_bytes = 0;
+    HIP_TRY(hipHostMalloc(&m->stage, bytes, hipHostMallocDefault));
+    m->stage_bytes = bytes;
+    return PGP_OK;
+}
+
+// Broadcast `bytes` at `buf` (device memory of this rank: the root's source, everybody else's destination).  Starts when
+// `wait_ev` has fired (null: at once), records `done_ev` on the communication stream when buf holds the data.
+static int comm_bcast(pgp_comm* m, void* buf, size_t bytes, int root, hipEvent_t wait_ev, hipEvent_t done_ev) {
+    if (m->kind == 1) {
+        if (wait_ev) HIP_TRY(hipStreamWaitEvent(m->st_comm, wait_ev, 0));
+        const int rc = m->api.Broadcast(buf, buf, bytes / sizeof(double), RCCL_DOUBLE, root, m->comm, m->st_comm);
+        if (rc != 0) return rccl_fail(m->api, rc, "ncclBroadcast");
+        if (done_ev) HIP_TRY(hipEventRecord(done_ev, m->st_comm));
+        return PGP_OK;
+    }
+    if (m->world == 1) {                             // nothing to move: order the consumers behind the producer
+        if (wait_ev) HIP_TRY(hipStreamWaitEvent(m->st_comm, wait_ev, 0));
+        if (done_ev) HIP_TRY(hipEventRecord(done_ev, m->st_comm));
+        return PGP_OK;
+    }
+    // host transport: blocking, through pinned host memory (self-test transport)
+    if (wait_ev) HIP_TRY(hipEventSynchronize(wait_ev));
+    CHK(comm_stage(m, bytes));
+    if (m->rank == root) {
+        HIP_TRY(hipMemcpyAsync(m->stage, buf, bytes, hipMemcpyDeviceToHost, m->st_comm));
+        HIP_TRY(hipStreamSynchronize(m->st_comm));
+    }
+    if (m->world > 1) {
+        const int rc = m->hb(m->user, m->stage, (int64_t)bytes, root);
+        if (rc != 0) { pgp_set_last_hip_error(hipErrorUnknown, "host broadcast call-back failed", __FILE__, __LINE__); return PGP_ERR_HIP; }
+    }
+    if (m->rank != root) {
+        HIP_TRY(hipMemcpyAsync(buf, m->stage, bytes, hipMemcpyHostToDevice, m->st_comm));
+        HIP_TRY(hipStreamSynchronize(m->st_comm));          // the staging buffer is reused by the next call
+    }
+    if (done_ev) HIP_TRY(hipEventRecord(done_ev, m->st_comm));
+    return PGP_OK;
+}
+
+// In-place all-reduce of `count` doubles at `buf`, ordered on stream `st` (after everything queued there; the result is
+// visible to whatever is queued on st afterwards).  op: 0 sum, 1 max.
+static int comm_allreduce(pgp_comm* m, double* buf, size_t count, int op, hipStream_t st) {
+    if (m->kind == 1) {
+        const int rc = m->api.AllReduce(buf, buf, count, RCCL_DOUBLE, op ? RCCL_MAX : RCCL_SUM, m->comm, st);
+        return rc != 0 ? rccl_fail(m->api, rc, "ncclAllReduce") : PGP_OK;
+    }
+    CHK(comm_stage(m, count * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(m->stage, buf, count * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (m->world > 1) {
+        const int rc = m->har(m->user, (double*)m->stage, (int64_t)count, op);
+        if (rc != 0) { pgp_set_last_hip_error(hipErrorUnknown, "host all-reduce call-back failed", __FILE__, __LINE__); return PGP_ERR_HIP; }
+    }
+    HIP_TRY(hipMemcpyAsync(buf, m->stage, count * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// small kernels of the distributed epilogue
+// ------------------------------------------------------------------------------------------------------------------
+// the 128 right-hand-side rows of an unfactored panel: row 0 = r = y - m at the panel's columns, rows 1..127 = 0
+__global__ __launch_bounds__(256) void panel_rhs_kernel(double* __restrict__ P, long ld, long row0, const double* __restrict__ y,
+                                                        const double* __restrict__ mvec, long n, long col0) {
+    const long c = blockIdx.x;                         // column of the panel
+    const long gc = col0 + c;
+    for (int i = threadIdx.x; i < 128; i += 256)
+        P[row0 + i + c * ld] = (i == 0 && gc < n) ? y[gc] - mvec[gc] : 0.0;
+}
+
+// acc[e] += sum_c E(e, c) z[c * zs]   for e < rows  (E column-major rows x w: coalesced over e); one thread per row,
+// eight independent loads in flight, fixed summation order
+__global__ __launch_bounds__(256) void panel_matvec_kernel(const double* __restrict__ E, long ld, long rows, int w,
+                                                           const double* __restrict__ z, long zs, double* __restrict__ acc) {
+    __shared__ double zl[1024];
+    for (int c = threadIdx.x; c < w; c += 256) zl[c] = z[(long)c * zs];
+    __syncthreads();
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows) return;
+    double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < w; c += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = E[e + (long)(c + q) * ld];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a8[q] = fma(v[q], zl[c + q], a8[q]);
+    }
+    acc[e] += ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+}
+
+// out[0] += sum_i log Ld(i, i) ; out[1] += sum_c z_c^2        (one workgroup; panels are accumulated in stream order)
+__global__ __launch_bounds__(256) void panel_scalars_kernel(const double* __restrict__ Ld, int w, const double* __restrict__ z,
+                                                            long zs, double* __restrict__ out) {
+    __shared__ double ra[256], rb[256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < w; i += 256) {
+        a += log(Ld[i + (long)i * w]);
+        const double zi = z[(long)i * zs];
+        b = fma(zi, zi, b);
+    }
+    ra[threadIdx.x] = a; rb[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { ra[threadIdx.x] += ra[threadIdx.x + s]; rb[threadIdx.x] += rb[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] += ra[0]; out[1] += rb[0]; }
+}
+
+// red[np + 2] = 1 if this rank saw a non-positive pivot;  red[np + 3] = BIG - pivot (max over ranks = first bad pivot)
+__global__ void pack_status_kernel(const int* __restrict__ info, double* __restrict__ red2) {
+    const int v = info[0];
+    red2[0] = v != 0 ? 1.0 : 0.0;
+    red2[1] = v != 0 ? 1.0e9 - (double)v : 0.0;
+}
+
+// y[i] = s * x[i]
+__global__ __launch_bounds__(256) void scale_vec_kernel(const double* __restrict__ x, double s, double* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = s * x[i];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int pgp_comm_unique_id(const char* rccl_path, char* id_out) {
+    if (!id_out) return -2;
+    RcclApi api;
+    CHK(rccl_load(rccl_path, api));
+    rccl_uid id;
+    memset(&id, 0, sizeof(id));
+    const int rc = api.GetUniqueId(&id);
+    if (rc != 0) return rccl_fail(api, rc, "ncclGetUniqueId");
+    memcpy(id_out, id.internal, 128);
+    return PGP_OK;                                   // the library handle stays open: RCCL keeps state behind the id
+}
+
+int pgp_comm_init_rccl(pgp_ctx* c, int world, int rank, const char* id, const char* rccl_path, pgp_comm** out) {
+    if (!c) return -1;
+    if (world < 1) return -2;
+    if (rank < 0 || rank >= world) return -3;
+    if (!id) return -4;
+    if (!out) return -6;
+    HIP_TRY(hipSetDevice(c->device));
+    pgp_comm* m = new pgp_comm();
+    m->ctx = c; m->world = world; m->rank = rank; m->kind = 1;
+    int rc = rccl_load(rccl_path, m->api);
+    if (rc != PGP_OK) { delete m; return rc; }
+    rccl_uid uid;
+    memcpy(uid.internal, id, 128);
+    const int nrc = m->api.CommInitRank(&m->comm, world, uid, rank);
+    if (nrc != 0) { rc = rccl_fail(m->api, nrc, "ncclCommInitRank"); delete m; return rc; }
+    if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess) { (void)m->api.CommDestroy(m->comm); delete m; return PGP_ERR_HIP; }
+    *out = m;
+    return PGP_OK;
+}
+
+int pgp_comm_init_host(pgp_ctx* c, int world, int rank, pgp_host_bcast_fn bcast, pgp_host_allreduce_fn allreduce, void* user,
+                       pgp_comm** out) {
+    if (!c) return -1;
+    if (world < 1) return -2;
+    if (rank < 0 || rank >= world) return -3;
+    if (world > 1 && (!bcast || !allreduce)) return -4;
+    if (!out) return -7;
+    HIP_TRY(hipSetDevice(c->device));
+    pgp_comm* m = new pgp_comm();
+    m->ctx = c; m->world = world; m->rank = rank; m->kind = 2;
+    m->hb = bcast; m->har = allreduce; m->user = user;
+    if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess) { delete m; return PGP_ERR_HIP; }
+    *out = m;
+    return PGP_OK;
+}
+
+void pgp_comm_free(pgp_comm* m) {
+    if (!m) return;
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->st_comm) { (void)hipStreamSynchronize(m->st_comm); (void)hipStreamDestroy(m->st_comm); }
+    if (m->kind == 1 && m->comm) (void)m->api.CommDestroy(m->comm);
+    if (m->stage) (void)hipHostFree(m->stage);
+    delete m;
+}
+
+int pgp_comm_world(pgp_comm* m) { return m ? m->world : 0; }
+int pgp_comm_rank(pgp_comm* m) { return m ? m->rank : -1; }
+
+// Exact.evaluate over the ranks of `comm`.  Every rank passes the same data (pgp_set_data) and arguments and receives the
+// same alpha / nlZ / dnlZ.  Status as pgp_exact_fit: > 0 = first non-positive pivot, identical on every rank.
+// timings_out (optional, 4): ms of assembly, sweep (+ E E' under it), epilogue (alpha, gradient, collectives), total.
+int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhyp, int ncov, int para, int flags, double log_sn,
+                          const double* mvec, const double* dm, int nmean, int want, double* alpha_out, double* nlZ_out,
+                          double* dnlZ_out, double* timings_out) {
+    if (!c) return -1;
+    if (!m || m->ctx != c) return -2;
+    if (c->n <= 0) return -1;
+    if (!covhyp) return -4;
+    if (want < 1 || want > 3) return -12;
+    HIP_TRY(hipSetDevice(c->device));
+    const long n = c->n, d = c->d;
+    const int world = m->world, me = m->rank;
+    const int w = c->nb_outer > 0 ? std::min(c->nb_outer, 8) * 128 : (n >= 12288 ? 1024 : 512);
+    const long np = round_up(n, w);                  // padded with identity rows / columns, like the single-GPU path
+    const int npanel = (int)(np / w);
+    const long ldp = np + 128;                       // rows of a panel buffer (P_j and Y_p alike)
+    const size_t pbytes = (size_t)ldp * w * sizeof(double);
+    std::vector<int> mine;                           // owned panels, ascending
+    for (int p = me; p < npanel; p += world) mine.push_back(p);
+    const int nloc = (int)mine.size();
+    CovSpec cp;
+    { const int rc = make_spec(c, kind, covhyp, ncov, para, flags, -1, d, cp); if (rc != PGP_OK) return rc == -11 ? -5 : rc; }
+    const double sn2 = exp(2.0 * log_sn);
+    const bool grad = want >= 3;
+    const int dpad = c->dpad;
+
+    // ---- workspace (pooled: an optimiser calls with identical shapes hundreds of times) --------------------------
+    PoolScratch scr(c);
+    double *Bufs = nullptr, *Ld = nullptr, *R[2] = {nullptr, nullptr}, *Binv = nullptr, *XT = nullptr, *red = nullptr,
+           *partial = nullptr, *mdev = nullptr, *ascaled = nullptr, *gout = nullptr;
+    CHK(scr.alloc(&Bufs, (size_t)(nloc + 1) * pbytes));
+    CHK(scr.alloc(&Ld, (size_t)std::max(nloc, 1) * w * w * sizeof(double)));
+    if (world > 1) { CHK(scr.alloc(&R[0], pbytes)); CHK(scr.alloc(&R[1], pbytes)); }
+    CHK(scr.alloc(&XT, (size_t)dpad * np * sizeof(double)));
+    CHK(scr.alloc(&red, (size_t)(np + 8) * sizeof(double)));
+    CHK(scr.alloc(&mdev, (size_t)np * sizeof(double)));
+    CHK(scr.alloc(&ascaled, (size_t)np * sizeof(double)));
+    CHK(scr.alloc(&gout, (size_t)(ncov + 8) * sizeof(double)));
+    if (grad) {
+        CHK(scr.alloc(&Binv, (size_t)np * np * sizeof(double)));
+        CHK(scr.alloc(&partial, (size_t)hadamard_partial_count(np, ncov) * sizeof(double)));
+    }
+    auto buf = [&](int k) { return Bufs + (size_t)k * ldp * w; };      // P of local panel k = buf(k + 1); Y of local panel k = buf(k)
+    hipStream_t main = c->st, pan = c->st2;
+    const bool pan_solve = world > 1;                // the owner's S(p+1) right behind D(p+1): its broadcast is on the critical path
+    const int nev = 3 * npanel + 8;
+    while ((int)c->la_ev.size() < nev) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->la_ev.push_back(e);
+    }
+    auto EV_S = [&](int p) { return c->la_ev[p]; };                    // Y_p produced (owner)
+    auto EV_Y = [&](int p) { return c->la_ev[npanel + p]; };           // Y_p present on this rank
+    auto EV_F = [&](int p) { return c->la_ev[2 * npanel + p]; };       // TU(p) has left the stream (its receive buffer is free)
+    hipEvent_t ev_stage[2] = {c->la_ev[3 * npanel], c->la_ev[3 * npanel + 1]};
+    hipEvent_t ev_a = c->la_ev[3 * npanel + 2], ev_d = c->la_ev[3 * npanel + 3];
+
+    // ---- inputs ----------------------------------------------------------------------------------------------------
+    HIP_TRY(hipEventRecord(c->ev[0], main));
+    HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), main));
+    HIP_TRY(hipMemsetAsync(mdev, 0, np * sizeof(double), main));
+    if (mvec) HIP_TRY(hipMemcpyAsync(mdev, mvec, n * sizeof(double), hipMemcpyHostToDevice, main));
+    HIP_TRY(hipMemsetAsync(red, 0, (np + 8) * sizeof(double), main));
+    CHK(upload_scaled(c, c->x_dev, n, d, cp.scale, XT, np, dpad, c->scale_dev));
+    if (grad) HIP_TRY(hipMemsetAsync(Binv, 0, (size_t)np * np * sizeof(double), main));
+    // ---- assembly: every rank builds ITS column panels of B = K/sn2 + I straight from the coordinates -------------------
+    for (int k = 0; k < nloc; ++k) {
+        const long col0 = (long)mine[k] * w;
+        { ProfScope ps(c, PC_ASSEMBLE, 0.0, 8.0 * (double)(np - col0) * w);
+          CHK(cov_factor_panel_launch(XT, np, n, np, dpad, cp, 1.0 / sn2, col0, w, buf(k + 1), ldp, main)); }
+        hipLaunchKernelGGL(panel_rhs_kernel, dim3(w), dim3(256), 0, main, buf(k + 1), ldp, np - col0, c->y_dev, mdev, n, col0);
+    }
+    HIP_TRY(hipEventRecord(c->ev[1], main));
+
+    // ---- the sweep ---------------------------------------------------------------------------------------------------
+    auto Yptr = [&](int p) -> double* { return (p % world == me) ? buf(p / world) : R[p & 1]; };
+    auto factor = [&](int p, hipStream_t st, hipEvent_t staged) -> int {          // D(p) on the owner
+        const int k = p / world;
+        return diag_block_factor(c, buf(k + 1), ldp, w, Ld + (size_t)k * w * w, w, buf(k) + (ldp - w), ldp, p * w, st, staged);
+    };
+    auto solve = [&](int p, hipStream_t st) -> int {                               // S(p): Y_p = P_p[w:] E_D
+        const int k = p / world;
+        GemmArgs g{};
+        g.A = buf(k + 1) + w; g.lda = ldp; g.a_kc = 0;
+        g.B = c->Dk + w; g.ldb = 2L * w; g.b_kc = 1;
+        g.C = buf(k); g.ldc = ldp;
+        g.M = (int)(ldp - w); g.N = w; g.K = w; g.alpha = 1.0; g.beta = 0.0; g.kmode = KM_LT_J; g.koff = 0;
+        const long t128 = (long)(g.M / 128) * (w / 128);
+        g.tile = c->s_tile ? c->s_tile : ((t128 < c->small_tile_below || t128 < 512) ? 64 : 128);
+        g.rev_cols = 1;
+        const double nt = (double)(w / g.tile);
+        g.flops = 2.0 * (double)g.M * g.tile * g.tile * nt * (nt + 1.0) * 0.5;
+        return gemm_prof(c, PC_GEMM_SOLVE, g, st);
+    };
+    // TU(p) on the local panels k0 .. k0 + nb - 1 (global j = mine[k], all > p): one batched launch
+    auto update = [&](int p, int k0, int nb, hipStream_t st) -> int {
+        if (nb <= 0) return PGP_OK;
+        const int j = mine[k0];
+        GemmArgs g{};
+        g.A = Yptr(p) + (long)(j - p - 1) * w; g.lda = ldp; g.a_kc = 0;
+        g.B = g.A; g.ldb = ldp; g.b_kc = 0;
+        g.C = buf(k0 + 1); g.ldc = ldp;
+        g.M = (int)(ldp - (long)(j - p - 1) * w); g.N = w; g.K = w;
+        g.alpha = -1.0; g.beta = 1.0; g.tri = 1; g.tri_off = 0; g.mask_diag = 1; g.kmode = KM_FULL;
+        g.zero_from = (int)(ldp - (long)(j - p) * w);                  // the E rows of block p: first touch
+        g.batch = nb; g.sA = (long)world * w; g.sB = g.sA; g.sC = ldp * (long)w; g.batch_dm = nb > 1 ? world * w : 0;
+        double fl = 0.0; long t128 = 0;
+        for (int z = 0; z < nb; ++z) {
+            const double Mz = (double)g.M - (double)z * world * w;
+            fl += 2.0 * w * (Mz * w - 0.5 * (double)w * w);
+            t128 += (long)(Mz / 128) * (w / 128) - (long)(w / 128) * (w / 128 - 1) / 2;
+        }
+        g.tile = t128 < c->small_tile_below ? 64 : 128;
+        g.flops = fl;
+        return gemm_prof(c, PC_GEMM_TRAIL, g, st);
+    };
+    auto eet = [&](int p, hipStream_t st) -> int {                                 // partial B^-1 += E_p E_p'
+        const int k = p / world;
+        const long rows = (long)(p + 1) * w;
+        GemmArgs g{};
+        g.A = buf(k) + (ldp - rows); g.lda = ldp; g.a_kc = 0;
+        g.B = g.A; g.ldb = ldp; g.b_kc = 0;
+        g.C = Binv; g.ldc = np;
+        g.M = (int)rows; g.N = (int)rows; g.K = w; g.alpha = 1.0; g.beta = 1.0;
+        g.tri = 2; g.mask_diag = 1; g.kmode = KM_GE_I; g.koff = -(int)((long)p * w);
+        const long mt = rows / 128;
+        g.tile = (mt * (mt + 1) / 2 < c->small_tile_below) ? 64 : 128;
+        const double wd = (double)w, r0 = (double)p * w;
+        g.flops = wd * r0 * r0 + wd * wd * r0 + wd * wd * wd / 3.0;
+        return gemm_prof(c, PC_GEMM_LAUUM, g, st);
+    };
+
+    if (0 % world == me) {                           // panel 0 on its owner, no look-ahead to hide behind
+        CHK(factor(0, main, nullptr));
+        CHK(solve(0, main));
+        HIP_TRY(hipEventRecord(EV_S(0), main));
+    }
+    int rc_loop = PGP_OK;
+    for (int p = 0; p < npanel && rc_loop == PGP_OK; ++p) {
+        const int owner = p % world;
+        // ---- Y_p to every rank ----
+        {
+            hipEvent_t wait = owner == me ? EV_S(p) : (p >= 2 && world > 1 ? EV_F(p - 2) : nullptr);
+            rc_loop = comm_bcast(m, Yptr(p), pbytes, owner, wait, EV_Y(p));
+            if (rc_loop != PGP_OK) break;
+            HIP_TRY(hipStreamWaitEvent(main, EV_Y(p), 0));
+        }
+        if (p + 1 >= npanel) {
+            if (grad && owner == me) rc_loop = eet(p, main);
+            break;
+        }
+        const int nxt = p + 1;
+        // local panels with global index > p
+        int k_first = 0;
+        while (k_first < nloc && mine[k_first] <= p) ++k_first;
+        if (nxt % world == me) {
+            // look-ahead: the next panel first, then its factorisation on the panel stream beside the rest of the step
+            const int kn = nxt / world;              // == k_first
+            rc_loop = update(p, kn, 1, main);                                      // TU_a
+            if (rc_loop != PGP_OK) break;
+            HIP_TRY(hipEventRecord(ev_a, main));
+            HIP_TRY(hipStreamWaitEvent(pan, ev_a, 0));
+            const bool lf = c->leaf_first != 0;
+            rc_loop = factor(nxt, pan, lf ? ev_stage[p & 1] : nullptr);            // D(p+1)
+            if (rc_loop != PGP_OK) break;
+            if (lf) HIP_TRY(hipStreamWaitEvent(main, ev_stage[p & 1], 0));
+            if (pan_solve) {
+                rc_loop = solve(nxt, pan);                                         // S(p+1) at once: the others wait for it
+                if (rc_loop != PGP_OK) break;
+                HIP_TRY(hipEventRecord(EV_S(nxt), pan));
+            } else HIP_TRY(hipEventRecord(ev_d, pan));
+            rc_loop = update(p, kn + 1, nloc - kn - 1, main);                      // TU_b: the rest, one batched launch
+            if (rc_loop == PGP_OK && grad && owner == me) rc_loop = eet(p, main);
+            if (rc_loop != PGP_OK) break;
+            if (!pan_solve) {
+                HIP_TRY(hipStreamWaitEvent(main, ev_d, 0));
+                rc_loop = solve(nxt, main);                                        // S(p+1)
+                if (rc_loop != PGP_OK) break;
+                HIP_TRY(hipEventRecord(EV_S(nxt), main));
+            }
+        } else {
+            rc_loop = update(p, k_first, nloc - k_first, main);                    // TU(p): every owned panel beyond p
+            if (rc_loop == PGP_OK && grad && owner == me) rc_loop = eet(p, main);
+            if (rc_loop != PGP_OK) break;
+        }
+        HIP_TRY(hipEventRecord(EV_F(p), main));
+    }
+    if (rc_loop != PGP_OK) { (void)hipDeviceSynchronize(); return rc_loop; }
+    HIP_TRY(hipEventRecord(c->ev[2], main));
+
+    // ---- epilogue: alpha, log det, z'z from this rank's panels; ONE all-reduce ------------------------------------------
+    for (int k = 0; k < nloc; ++k) {
+        const int p = mine[k];
+        const long rows = (long)(p + 1) * w;
+        const double* Y = buf(k);
+        const double* z = Y + (np - rows);            // logical row np (r = y - m after the forward substitution)
+        { ProfScope ps(c, PC_SMALL, 0.0, 8.0 * (double)rows * w);
+          hipLaunchKernelGGL(panel_matvec_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, main, Y + (ldp - rows), ldp,
+                             rows, w, z, ldp, red); }
+        hipLaunchKernelGGL(panel_scalars_kernel, dim3(1), dim3(256), 0, main, Ld + (size_t)k * w * w, w, z, ldp, red + np);
+    }
+    hipLaunchKernelGGL(pack_status_kernel, dim3(1), dim3(1), 0, main, c->info_dev, red + np + 2);
+    if (hipGetLastError() != hipSuccess) return PGP_ERR_HIP;
+    CHK(comm_allreduce(m, red, (size_t)np + 3, 0, main));
+    std::vector<double> head(8, 0.0);
+    HIP_TRY(hipMemcpyAsync(head.data(), red + np, 4 * sizeof(double), hipMemcpyDeviceToHost, main));
+    HIP_TRY(hipStreamSynchronize(main));
+    if (head[2] != 0.0) {                            // a non-positive pivot somewhere: every rank learns the first one
+        CHK(comm_allreduce(m, red + np + 3, 1, 1, main));
+        double v = 0.0;
+        HIP_TRY(hipMemcpy(&v, red + np + 3, sizeof(double), hipMemcpyDeviceToHost));
+        (void)hipDeviceSynchronize();
+        const long piv = (long)llround(1.0e9 - v);
+        return (int)(piv > n ? n : (piv < 1 ? 1 : piv));
+    }
+    // alpha = (sum of the partials) / sn2 ; the gradient reduce on the PARTIAL B^-1 with alpha / sqrt(world)
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, main, red, 1.0 / sn2, red, np);
+    if (grad) {
+        hipLaunchKernelGGL(scale_vec_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, main, red, 1.0 / sqrt((double)world),
+                           ascaled, np);
+        { ProfScope ps(c, PC_HADAMARD, 0.0, 8.0 * (double)np * (np + 1) / 2.0 + 8.0 * (double)n * d);
+          CHK(hadamard_reduce_launch(XT, np, n, np, dpad, cp, ncov, sn2, Binv, np, ascaled, partial, gout, main)); }
+        CHK(comm_allreduce(m, gout, (size_t)ncov + 1, 0, main));
+    }
+    HIP_TRY(hipEventRecord(c->ev[3], main));
+    std::vector<double> alpha_h(n), g_h(ncov + 1, 0.0);
+    HIP_TRY(hipMemcpyAsync(alpha_h.data(), red, n * sizeof(double), hipMemcpyDeviceToHost, main));
+    if (grad) HIP_TRY(hipMemcpyAsync(g_h.data(), gout, (ncov + 1) * sizeof(double), hipMemcpyDeviceToHost, main));
+    HIP_TRY(hipStreamSynchronize(main));
+    HIP_TRY(hipStreamSynchronize(pan));
+    if (m->st_comm) HIP_TRY(hipStreamSynchronize(m->st_comm));
+    if (c->prof) prof_collect(c);
+    if (timings_out) {
+        float a = 0, b = 0, e = 0, t = 0;
+        (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&e, c->ev[2], c->ev[3]); (void)hipEventElapsedTime(&t, c->ev[0], c->ev[3]);
+        timings_out[0] = a; timings_out[1] = b; timings_out[2] = e; timings_out[3] = t;
+    }
+    if (alpha_out) memcpy(alpha_out, alpha_h.data(), n * sizeof(double));
+    if (want >= 2 && nlZ_out) *nlZ_out = 0.5 * head[1] / sn2 + head[0] + 0.5 * (double)n * log(2.0 * M_PI * sn2);   // inf.py:370
+    if (grad && dnlZ_out) {
+        for (int i = 0; i < nmean; ++i) {                 // Core/inf.py:378-381
+            double s = 0.0;
+            for (long j = 0; j < n; ++j) s += dm[(long)i * n + j] * alpha_h[j];
+            dnlZ_out[i] = -s;
+        }
+        for (int h = 0; h < ncov; ++h) dnlZ_out[nmean + h] = 0.5 * g_h[h];             // inf.py:377
+        dnlZ_out[nmean + ncov] = g_h[ncov];                                            // inf.py:374
+    }
+    return PGP_OK;
+}
+
+}  // extern "C"

@@ -226,13 +226,45 @@ def _mean_inputs(meanfunc, x):
 class Exact(Inference):
     """Exact inference for a Gaussian likelihood (Core/inf.py:345-384)."""
 
-    def __init__(self):
+    def __init__(self, sharded=False):
+        """sharded: False = one GPU (the reference's unit of work); True or a ``sharded.Comm`` = ONE fit over every rank of
+        the process group (one process per GPU, all ranks call with the same model; pygps_amd/sharded.py)."""
         self.name = "Exact inference"
         self.device = None
+        self.sharded = sharded
+
+    def _evaluate_sharded(self, meanfunc, covfunc, likfunc, x, y, nargout):
+        from . import sharded as _sh
+        comm = self.sharded if isinstance(self.sharded, _sh.Comm) else _sh.default_comm(self.device)
+        dev = comm.device
+        kind, para, flags = _device_kernel(covfunc, comm.ctx)
+        x = _lib.f64(x)
+        n = x.shape[0]
+        y = _lib.f64(y).reshape(n)
+        _Resident.ensure(x, y, dev)
+        m, dm, nm = _mean_inputs(meanfunc, x)
+        nc = len(covfunc.hyp)
+        log_sn = float(likfunc.hyp[0])
+        alpha, nlz, g, self.last_ms = _sh.exact_fit(comm, kind, para, flags, covfunc.hyp, log_sn, m, dm, nm, n, nargout)
+        post = postStruct()
+        post.alpha = alpha.reshape(n, 1)
+        post.sW = np.ones((n, 1)) / np.sqrt(np.exp(2 * log_sn))
+        post.L = _sh.DistributedFactor(n, comm.world)
+        if nargout > 1:
+            if nargout > 2:
+                dnlZ = dnlZStruct(meanfunc, covfunc, likfunc)
+                dnlZ.mean = [np.float64(v) for v in g[:nm]]
+                dnlZ.cov = [np.float64(v) for v in g[nm:nm + nc]]
+                dnlZ.lik = [np.float64(g[nm + nc])]
+                return post, np.float64(nlz), dnlZ
+            return post, np.float64(nlz)
+        return post
 
     def evaluate(self, meanfunc, covfunc, likfunc, x, y, nargout=1):
         if not isinstance(likfunc, _lik.Gauss):
             raise Exception("Exact inference only possible with Gaussian likelihood")
+        if self.sharded:
+            return self._evaluate_sharded(meanfunc, covfunc, likfunc, x, y, nargout)
         dev = _lib.default_device() if self.device is None else self.device
         kind, para, flags = _device_kernel(covfunc, _lib.ctx(dev))
         x = _lib.f64(x)

@@ -463,25 +463,27 @@ def test_device_out_of_memory_raises_and_the_context_recovers(lib):
 
 
 @pytest.mark.gpu
-def test_bench_collective_extras_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_collective_extras_ranks_sharing_one_gpu(tmp_path, world):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with
-    both ranks on the one GPU of the box and the collectives through gloo: the weak-scaled timed region, then the
-    collective extras -- cfg 4's restart search sharded over the ranks and one Cholesky factorisation over the ranks."""
+    all ranks on the one GPU of the box and the collectives through gloo: the weak-scaled timed region, then the collective
+    extras -- cfg 4's restart search sharded over the ranks (world 8: BASELINE configs[3] as written, one restart per rank)
+    and ONE exact-GP fit over the ranks."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYGPS_BENCH_BACKEND="gloo")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "4", "--warmup", "2", "--windows", "1",   # (no --n: torchrun's parser trips on it)
-                          "--no-cpu-baseline", "--collective-extras-only", "--cfg4-n", "512", "--sharded-n", "2048"],
-                         capture_output=True, text=True, timeout=900, env=env)
+                          "--gpus", str(world), "--steps", "4", "--warmup", "2", "--windows", "1",   # (no --n: torchrun's parser trips on it)
+                          "--no-cpu-baseline", "--collective-extras-only", "--cfg4-n", "512", "--sharded-n", "4096"],
+                         capture_output=True, text=True, timeout=1200, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["value"] > 0
+    assert j["n_gpus"] == world and j["value"] > 0
     c4 = j["cfg4_restarts_N8192"]
-    assert c4["n_gpus"] == 2 and c4["restarts"] == 8 and c4["fits"] > 8 and np.isfinite(c4["nlZ_best"]), c4
-    sc = j["sharded_cholesky"]
-    assert sc["world"] == 2 and sc["residual_LLtv_vs_Av"] < 1e-13, sc
+    assert c4["n_gpus"] == world and c4["restarts"] == 8 and c4["fits"] > 8 and np.isfinite(c4["nlZ_best"]), c4
+    sf = j["sharded_fit"]
+    assert sf["world"] == world and sf["panels"] == 8 and sf["residual_normal_equations"] < 1e-10 and np.isfinite(sf["nlZ"]), sf
