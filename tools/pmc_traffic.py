@@ -23,7 +23,8 @@ def load(pattern, counter, match):
 if __name__ == "__main__":
     root = sys.argv[1]
     out = sys.argv[2]
-    DOM = "gemm_f64_kernel<128, 128, false, false, true, false>"  # the dominant instantiation (LDS-DMA 128-tile kernel)
+    DOM = "gemm_f64_kernel<128, 128, false, false, true>"  # the dominant instantiation (LDS-DMA 128-tile kernel)
+    head = sys.argv[3] if len(sys.argv) > 3 else "unknown"
     f, nf = load(root + "/fetch/**/*counter_collection.csv", "FETCH_SIZE", DOM)
     w, nw = load(root + "/write/**/*counter_collection.csv", "WRITE_SIZE", DOM)
     fa, nfa = load(root + "/fetch/**/*counter_collection.csv", "FETCH_SIZE", "gemm_f64_kernel")
@@ -31,7 +32,7 @@ if __name__ == "__main__":
     assert nf and nw, (nf, nw)
     fetch_b = f * 1024.0 * 2.0 / nf
     write_b = w * 1024.0 / nw
-    json.dump({"kernel": DOM, "launches_sampled": nf,
+    json.dump({"kernel": DOM, "launches_sampled": nf, "measured_on_commit": head,
                "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
                "bytes_per_launch": fetch_b + write_b,
                "all_gemm_f64_instantiations": {"launches_sampled": nfa, "bytes_per_launch": fa * 2048.0 / nfa + wa * 1024.0 / nwa},
