@@ -1,7 +1,8 @@
 """cfg 3: SEard N=16384 d=64 (65 cov hypers): stage timings of one fit with all gradients."""
 import sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pygps_amd as pyGPs
 from pygps_amd import _lib
 N, d = 16384, 64

@@ -1,7 +1,8 @@
 """Stage times of N=8192 (or N=<n>) fits under library options."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygps_amd import _lib
 lib = _lib.load(); ctx = _lib.ctx()
 N = 8192
