@@ -487,3 +487,54 @@ def test_bench_collective_extras_ranks_sharing_one_gpu(tmp_path, world):
     assert c4["n_gpus"] == world and c4["restarts"] == 8 and c4["fits"] > 8 and np.isfinite(c4["nlZ_best"]), c4
     sf = j["sharded_fit"]
     assert sf["world"] == world and sf["panels"] == 8 and sf["residual_normal_equations"] < 1e-10 and np.isfinite(sf["nlZ"]), sf
+
+
+def _g9_world8_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pygps_amd as pyGPs
+        g = golden("G9_restarts_N2048")
+        N, d = int(g["N"]), int(g["d"])
+        x, y = synth_reg(N, d)
+        m = pyGPs.GPR()
+        m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+        m.setNoise(np.log(0.1))
+        if rank == 0:
+            m.setData(x, y)
+            np.random.seed(123)
+        else:                                # only rank 0 holds the data and the RNG state: the others get both by broadcast
+            m.setData(np.zeros_like(x), np.ones_like(y))
+            np.random.seed(999 + rank)
+        m.setOptimizer("ShardedMinimize", num_restarts=8)
+        m.optimizer.streams_per_gpu = 1
+        m.optimize(m.x, m.y, numIterations=40)
+        runs = m.optimizer.runs
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), f=np.array([r.f for r in runs]), nls=np.array([r.nls for r in runs]),
+                 X0=m.optimizer.init_table, hyp=np.array(m.optimizer._convert_to_array()), nlZ=m.nlZ)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_cfg4_as_written_eight_ranks_one_restart_each(tmp_path):
+    """BASELINE configs[3] as written -- 8 minimize.py restarts sharded one per rank -- against the reference's own run (G9 at
+    N = 2048: Core/opt.py:301-327 with np.random.seed(123), 40 line searches per restart).  Eight processes share the one GPU
+    of the box and the three collectives go through gloo; restart r runs on rank r (t % world with world == R), the start
+    table and the data reach the ranks by broadcast from rank 0."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_g9_world8_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    g = golden("G9_restarts_N2048")
+    rs = [np.load(os.path.join(str(tmp_path), "r%d.npz" % k)) for k in range(8)]
+    for r in rs:
+        assert relerr(r["X0"], g["run_X0"]) < 1e-14                               # the replayed initial points, on every rank
+        assert np.array_equal(r["f"], rs[0]["f"]) and np.array_equal(r["hyp"], rs[0]["hyp"])
+    f = rs[0]["f"]
+    assert np.max(np.abs(f - g["run_f"]) / np.abs(g["run_f"])) < 1e-5, (f, g["run_f"])
+    near = lambda v: set(np.flatnonzero(v < v.min() + 1e-6 * abs(v.min())).tolist())
+    assert near(f) == near(g["run_f"]) == {0, 2, 6} and int(np.argmin(f)) in near(g["run_f"])
