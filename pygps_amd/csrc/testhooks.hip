@@ -1,5 +1,7 @@
 // Self-test / calibration hooks (tests/ and bench.py only): host-buffer GEMM through the MFMA kernel,
 // and an fp64 MFMA issue-rate micro-benchmark used to restate the roofline peak from measurement.
+#include <time.h>
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 
@@ -277,3 +279,80 @@ int pgp_test_gemm_shrink(pgp_ctx* ctx, const double* Y, int64_t ldy, int M, int 
 }
 
 }  // extern "C"
+
+// ---- dispatcher experiment (tools/slot_probe.py): does a small high-LDS kernel on a second stream find the CUs that a resident
+// grid leaves empty?  `holder`: nwg workgroups of 256 threads and lds_kb KB of LDS spin for hold_us; with reserve > 0 every
+// workgroup that finds itself on the first-claimed CU of its XCD leaves at once.  `probe`: one workgroup (probe_lds_kb) launched
+// on the panel stream delay_us later; it records when it actually started.  out: [0] probe start - probe launch (us, device
+// wall clock), [1] holder workgroups that stayed, [2] holder workgroups that left, [3] probe start - holder start (us).
+namespace {
+__device__ unsigned g_probe_claim[16];
+__device__ unsigned g_probe_cnt[4];
+__device__ long long g_probe_t[4];
+__device__ unsigned g_probe_log[4 * 2048];
+__global__ void holder_kernel(long long hold_ticks, int reserve) {
+    extern __shared__ double hs[];
+    __shared__ int leave;
+    if (threadIdx.x == 0) {
+        int mine = 0;
+        if (reserve > 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u;
+            const unsigned key = 1u + ((hw >> 8) & 0xffu);
+            const unsigned prev = atomicCAS(&g_probe_claim[xcc], 0u, key);
+            mine = prev == 0u || prev == key;
+        }
+        leave = mine;
+        atomicAdd(&g_probe_cnt[mine ? 1 : 0], 1u);
+        if (blockIdx.x < 2048) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+            g_probe_log[4 * blockIdx.x] = hw; g_probe_log[4 * blockIdx.x + 1] = xcc; g_probe_log[4 * blockIdx.x + 2] = mine;
+            g_probe_log[4 * blockIdx.x + 3] = (unsigned)(wall_clock64() & 0xffffffffu);
+        }
+        if (blockIdx.x == 0) g_probe_t[0] = wall_clock64();
+    }
+    __syncthreads();
+    if (leave) return;
+    hs[threadIdx.x] = 1.0;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < hold_ticks) __builtin_amdgcn_s_sleep(20);
+}
+__global__ void probe_kernel() {
+    extern __shared__ double ps[];
+    if (threadIdx.x == 0) { g_probe_t[1] = wall_clock64(); ps[0] = 1.0; }
+}
+__global__ void probe_mark_kernel() { if (threadIdx.x == 0) g_probe_t[2] = wall_clock64(); }
+}  // namespace
+
+extern "C" int pgp_test_slot_probe(pgp_ctx* c, int nwg, int lds_kb, int hold_us, int reserve, int probe_lds_kb, int delay_us,
+                                   double* out4) {
+    if (!c || !out4) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned zero16[16] = {0}; unsigned zero4[4] = {0}; long long zt[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_claim), zero16, sizeof(zero16)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_cnt), zero4, sizeof(zero4)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_t), zt, sizeof(zt)));
+    (void)hipFuncSetAttribute((const void*)holder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    HIP_TRY(hipDeviceSynchronize());
+    hipLaunchKernelGGL(holder_kernel, dim3(nwg), dim3(256), (size_t)lds_kb * 1024, c->st, (long long)hold_us * 100, reserve);
+    // a marker kernel on the panel stream `delay_us` later (host sleep), then the probe right behind it
+    struct timespec ts = {0, (long)delay_us * 1000};
+    nanosleep(&ts, nullptr);
+    hipLaunchKernelGGL(probe_mark_kernel, dim3(1), dim3(64), 0, c->st2);
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(256), (size_t)probe_lds_kb * 1024, c->st2);
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned cnt[4]; long long t[4];
+    HIP_TRY(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_probe_cnt), sizeof(cnt)));
+    HIP_TRY(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_probe_t), sizeof(t)));
+    out4[0] = (double)(t[1] - t[2]) / 100.0; out4[1] = cnt[0]; out4[2] = cnt[1]; out4[3] = (double)(t[1] - t[0]) / 100.0;
+    if (getenv("PGP_PROBE_DUMP")) {
+        static unsigned lg[4 * 2048];
+        HIP_TRY(hipMemcpyFromSymbol(lg, HIP_SYMBOL(g_probe_log), sizeof(lg)));
+        for (int i = 0; i < nwg && i < 2048; ++i)
+            fprintf(stderr, "wg %4d hw %08x cu %2u sh %u se %u xcc %08x leave %u t %u\n", i, lg[4 * i], (lg[4 * i] >> 8) & 15u, (lg[4 * i] >> 12) & 1u,
+                    (lg[4 * i] >> 13) & 7u, lg[4 * i + 1], lg[4 * i + 2], lg[4 * i + 3] - lg[3]);
+    }
+    return PGP_OK;
+}
