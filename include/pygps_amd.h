@@ -102,6 +102,18 @@ void pgp_factor_free(pgp_ctx* ctx, pgp_factor* f);
 int pgp_predict(pgp_ctx* ctx, pgp_factor* f, const double* xs, int64_t ns, const double* ms, double* fmu,
                 double* fs2);
 
+/* ---- the same path from CALLER-BUILT covariance matrices (csrc/dense.hip) ---------------------------------
+ * For covariance functions that are not device programs (Core/cov.py:230-328 composes anything; a tree with more than two
+ * ARD leaves or more than 8 leaves has getCovMatrix / getDerMatrix only): K (n,n) = getCovMatrix(x, 'train'), r = y - m.
+ * pgp_exact_fit_dense: want as pgp_exact_fit; dnlZ_lik_out = sn2 tr Q.  pgp_dense_grad_term: 1/2 sum(Q o dK) for one
+ * derivative matrix dK = getDerMatrix(x, 'train', h), with the Q of the dense fit that directly precedes it on this context
+ * (Core/inf.py:373-377).  pgp_predict_dense: Ks (n,ns) = getCovMatrix(x, xs, 'cross'), kss (ns) = 'self_test'.        */
+int pgp_exact_fit_dense(pgp_ctx* ctx, const double* K, int64_t n, const double* r, double log_sn, int want,
+                        double* alpha_out, double* nlZ_out, double* dnlZ_lik_out, pgp_factor** factor_out);
+int pgp_dense_grad_term(pgp_ctx* ctx, const double* dK, int64_t n, double log_sn, double* out);
+int pgp_predict_dense(pgp_ctx* ctx, pgp_factor* f, const double* Ks, int64_t ns, const double* kss, const double* ms,
+                      double* fmu, double* fs2);
+
 /* ---- EP.evaluate with lik.Erf (Core/inf.py:731-806, 174-189; Core/lik.py:295-366) ----------
  * ttau/tnu (n): in = warm start (ignored if warm == 0), out = final site parameters.           */
 int pgp_ep_fit(pgp_ctx* ctx, int kind, const double* covhyp, int ncov, int para, int flags, const double* mvec,

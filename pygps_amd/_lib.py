@@ -46,6 +46,9 @@ SIGNATURES = {
     "pgp_factor_n": (_i64, [_vp]),
     "pgp_factor_free": (None, [_vp, _vp]),
     "pgp_predict": (C.c_int, [_vp, _vp, _dp, _i64, _dp, _dp, _dp]),
+    "pgp_exact_fit_dense": (C.c_int, [_vp, _dp, _i64, _dp, C.c_double, C.c_int, _dp, _dp, _dp, C.POINTER(_vp)]),
+    "pgp_dense_grad_term": (C.c_int, [_vp, _dp, _i64, C.c_double, _dp]),
+    "pgp_predict_dense": (C.c_int, [_vp, _vp, _dp, _i64, _dp, _dp, _dp, _dp]),
     "pgp_ep_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
                              _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int), C.POINTER(_vp)]),
     "pgp_fitc_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _i64, _dp, _dp, C.c_int,

@@ -117,6 +117,56 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     return PGP_OK;
 }
 
+// GP.predict (Core/gp.py:395-417) for a posterior whose covariance function is not a device program (csrc/dense.hip): the
+// caller hands in the cross-covariance block Ks (n, ns) row-major = getCovMatrix(x, xs, 'cross') and kss (ns) =
+// getCovMatrix(z = xs, 'self_test'); fmu = ms + Ks' alpha, fs2 = max(kss - colsum((R'^-1 (sW o Ks))^2), 0).
+int pgp_predict_dense(pgp_ctx* c, pgp_factor* f, const double* Ks_host, int64_t ns, const double* kss, const double* ms,
+                      double* fmu, double* fs2) {
+    if (!c) return -1;
+    if (!f) return -2;
+    if (!Ks_host) return -3;
+    if (ns <= 0) return -4;
+    if (!kss) return -5;
+    if (!fmu) return -7;
+    if (!fs2) return -8;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->st;
+    CHK(ensure_wd(c, f));
+    const long np = f->np, n = f->n;
+    const long NSB = std::max<long>(128, std::min<long>(c->predict_batch, round_up(ns, 128)));
+    PoolScratch tmp(c);
+    double *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *o2 = nullptr;
+    CHK(tmp.alloc(&Ks, (size_t)np * NSB * sizeof(double)));
+    CHK(tmp.alloc(&msd, NSB * sizeof(double)));
+    CHK(tmp.alloc(&o1, NSB * sizeof(double)));
+    CHK(tmp.alloc(&o2, NSB * sizeof(double)));
+    std::vector<double> blk;
+    for (long a = 0; a < ns; a += NSB) {
+        const long nb_ = std::min<long>(NSB, ns - a);
+        const int nrhs = (int)round_up(nb_, 128);
+        blk.resize((size_t)nb_ * n);
+        for (long i = 0; i < n; ++i)                               // column j of the device block = test point a + j
+            for (long j = 0; j < nb_; ++j) blk[(size_t)j * n + i] = Ks_host[(size_t)i * ns + a + j];
+        HIP_TRY(hipMemsetAsync(Ks, 0, (size_t)np * nrhs * sizeof(double), st));
+        HIP_TRY(hipMemcpy2DAsync(Ks, np * sizeof(double), blk.data(), n * sizeof(double), n * sizeof(double), nb_,
+                                 hipMemcpyHostToDevice, st));
+        if (ms) HIP_TRY(hipMemcpyAsync(msd, ms + a, nb_ * sizeof(double), hipMemcpyHostToDevice, st));
+        else HIP_TRY(hipMemsetAsync(msd, 0, nb_ * sizeof(double), st));
+        CHK(col_dot_full_launch(Ks, np, n, nb_, f->alpha, msd, o1, st));                  // fmu = ms + Ks' alpha
+        if (f->sWv) CHK(row_scale_launch(Ks, np, n, nrhs, f->sWv, st));
+        CHK(solve_lower_multi(c, f->F, f->ldf, f->Wd, Ks, np, np, nrhs, false));
+        // the raw column sums of squares (kss differs per test point here): out = max(BIG - scale * s, 0) would clip, so take
+        // them through kss = 0 with a NEGATIVE scale: out = max(scale' * s, 0) = scale' * s
+        CHK(col_sumsq_launch(Ks, np, n, nb_, 0.0, -(f->sWv ? 1.0 : f->sw * f->sw), o2, st));
+        HIP_TRY(hipMemcpyAsync(fmu + a, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(fs2 + a, o2, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));                          // blk is reused by the next batch
+        for (long j = 0; j < nb_; ++j) fs2[a + j] = std::max(kss[a + j] - fs2[a + j], 0.0);
+    }
+    if (c->prof) prof_collect(c);
+    return PGP_OK;
+}
+
 int pgp_potrs(pgp_ctx* c, const double* R, int64_t n, const double* Bm, int64_t nrhs, double* X_out) {
     if (!c) return -1;
     if (!R) return -2;

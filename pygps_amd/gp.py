@@ -145,6 +145,14 @@ class GP(object):
         ms = _lib.f64(self.meanfunc.getMean(xs)).reshape(ns)
         fmu = np.empty(ns)
         fs2 = np.empty(ns)
+        if getattr(L, "dense", False):
+            # a covariance function that is not a device program (inf.Exact._evaluate_dense): the cross-covariance block is
+            # built by getCovMatrix and handed in; solve and reductions on the device (pgp_predict_dense)
+            Ks = _lib.f64(self.covfunc.getCovMatrix(x=self.x, z=xs, mode="cross"))
+            kss = _lib.f64(self.covfunc.getCovMatrix(z=xs, mode="self_test")).reshape(ns)
+            _lib.check(_lib.load().pgp_predict_dense(L.ctx, L.handle, _lib.ptr(Ks), ns, _lib.ptr(kss), _lib.ptr(ms), _lib.ptr(fmu),
+                                                     _lib.ptr(fs2)), "pgp_predict_dense")
+            return fmu.reshape(ns, 1), fs2.reshape(ns, 1)
         rc = _lib.load().pgp_predict(L.ctx, L.handle, _lib.ptr(xs), ns, _lib.ptr(ms), _lib.ptr(fmu), _lib.ptr(fs2))
         if rc == -99:
             raise NotImplementedError("pygps_amd: the device predict path is not built in this version")

@@ -260,9 +260,58 @@ class Exact(Inference):
             return post, np.float64(nlz)
         return post
 
+    def _evaluate_dense(self, meanfunc, covfunc, likfunc, x, y, nargout):
+        """Covariance functions that are not device programs (a tree with more than two ARD leaves or more than 8 leaves /
+        products, Core/cov.py:230-328): K and the derivative matrices come from getCovMatrix / getDerMatrix (the children's
+        device-built matrices combined on the host), the factorisation with the fused inverse, alpha, nlZ and every Hadamard
+        sum sum(Q o dK_h) / 2 run on the device (csrc/dense.hip).  Costs PCIe traffic (n^2 doubles per matrix), never raises."""
+        dev = _lib.default_device() if self.device is None else self.device
+        ctx = _lib.ctx(dev)
+        lib = _lib.load()
+        x = _lib.f64(x)
+        n = x.shape[0]
+        y = _lib.f64(y).reshape(n)
+        m, dm, nm = _mean_inputs(meanfunc, x)
+        nc = len(covfunc.hyp)
+        log_sn = float(likfunc.hyp[0])
+        K = _lib.f64(covfunc.getCovMatrix(x=x, mode="train"))
+        r = _lib.f64(y - m)
+        alpha = np.empty(n)
+        nlZ = np.zeros(1)
+        glik = np.zeros(1)
+        fh = C.c_void_p()
+        DeviceFactor.reserve(n, dev)
+        want = int(min(max(nargout, 1), 3))
+        _lib.check(lib.pgp_exact_fit_dense(ctx, _lib.ptr(K), n, _lib.ptr(r), log_sn, want, _lib.ptr(alpha), _lib.ptr(nlZ),
+                                           _lib.ptr(glik), C.byref(fh)), "pgp_exact_fit_dense")
+        del K
+        post = postStruct()
+        post.alpha = alpha.reshape(n, 1)
+        post.sW = np.ones((n, 1)) / np.sqrt(np.exp(2 * log_sn))
+        post.L = DeviceFactor(fh, n, dev, _lib.current_slot())
+        post.L.dense = True                          # predict hands the cross-covariance block in (GP._latent)
+        if nargout > 1:
+            if nargout > 2:
+                g = np.zeros(1)
+                dnlZ = dnlZStruct(meanfunc, covfunc, likfunc)
+                dnlZ.cov = []
+                for h in range(nc):                                               # Core/inf.py:376-377, one matrix at a time
+                    dK = _lib.f64(covfunc.getDerMatrix(x=x, mode="train", der=h))
+                    _lib.check(lib.pgp_dense_grad_term(ctx, _lib.ptr(dK), n, log_sn, _lib.ptr(g)), "pgp_dense_grad_term")
+                    dnlZ.cov.append(np.float64(g[0]))
+                dnlZ.mean = [np.float64(-(dm[i] @ alpha)) for i in range(nm)]     # Core/inf.py:378-381
+                dnlZ.lik = [np.float64(glik[0])]
+                return post, np.float64(nlZ[0]), dnlZ
+            return post, np.float64(nlZ[0])
+        return post
+
     def evaluate(self, meanfunc, covfunc, likfunc, x, y, nargout=1):
         if not isinstance(likfunc, _lik.Gauss):
             raise Exception("Exact inference only possible with Gaussian likelihood")
+        if isinstance(covfunc, _cov._Composite) and not covfunc._on_device():
+            if self.sharded:
+                raise NotImplementedError("pygps_amd: a sharded fit needs a covariance function that runs as a device program")
+            return self._evaluate_dense(meanfunc, covfunc, likfunc, x, y, nargout)
         if self.sharded:
             return self._evaluate_sharded(meanfunc, covfunc, likfunc, x, y, nargout)
         dev = _lib.default_device() if self.device is None else self.device

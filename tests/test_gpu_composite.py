@@ -149,8 +149,10 @@ def test_G11_ep_with_a_composite_kernel():
 
 
 def test_composite_limits_and_ard_leaves():
-    """More than 8 leaves, or more than two ARD leaves: getCovMatrix still works (children on the device, combined on the
-    host); fits refuse loudly -- there is no CPU fallback."""
+    """More than 8 leaves, or more than two ARD leaves: not a device program -- getCovMatrix / getDerMatrix combine the
+    children's device-built matrices, and fits / predictions take the dense path (csrc/dense.hip: factorisation, alpha, nlZ, the
+    Hadamard sums and the predictive solve on the device from caller-built matrices).  Core/cov.py:230-328 composes anything;
+    nothing raises."""
     import pygps_amd as pyGPs
     from pygps_amd import cov
     rng = np.random.RandomState(0)
@@ -166,11 +168,30 @@ def test_composite_limits_and_ard_leaves():
     assert not ard._on_device() and (cov.RBFard(D=2) * cov.RBF())._on_device() and (cov.RBFard(D=2) * cov.RQard(D=2))._on_device()
     t3 = ("sum", ("prod", ("leaf", O.RBFARD, 0), ("leaf", O.RQARD, 0)), ("leaf", O.RBFARD, 0))
     _close(ard.getCovMatrix(x=x, mode="train"), O.cov_matrix(t3, np.array(ard.hyp, float), 0, x=x, mode="train"))
-    for k in (big, ard):
+    tbig = ("leaf", O.RBF, 0)
+    for i in range(8):
+        tbig = ("sum", tbig, ("leaf", O.RBF, 0))
+    xs = rng.randn(9, 2)
+    for k, tree in ((big, tbig), (ard, t3)):
         m = pyGPs.GPR()
         m.setPrior(kernel=k)
-        with pytest.raises(NotImplementedError):
-            m.getPosterior(x, y)
+        m.setNoise(np.log(0.3))
+        m.setData(x, y)
+        nlZ, dnlZ, post = m.getPosterior()
+        c = m.meanfunc.hyp[0]
+        hyp = np.array(m.covfunc.hyp, float)
+        ref = O.exact_fit(tree, hyp, 0, m.likfunc.hyp[0], x, y, c * np.ones((30, 1)), np.ones((30, 1)), faithful=False,
+                          matern_reference_compat=False)
+        assert abs(nlZ - ref["nlZ"]) < 1e-10 * abs(ref["nlZ"])
+        _close(post.alpha, ref["alpha"], 1e-9)
+        _close(np.array(dnlZ.mean + dnlZ.cov + dnlZ.lik), np.concatenate([ref["dnlZ_mean"], ref["dnlZ_cov"], ref["dnlZ_lik"]]), 1e-8)
+        _close(np.asarray(post.L), ref["L"], 1e-10)
+        nlZ2, post2 = m.getPosterior(der=False)                       # value-only call: no inverse
+        assert abs(nlZ2 - nlZ) < 1e-12 * abs(nlZ)
+        ym, ys2, fm, fs2, lp = m.predict(xs)
+        rym, rys2, rfm, rfs2 = O.predict(tree, hyp, 0, m.likfunc.hyp[0], x, ref["alpha"], ref["L"], ref["sW"], xs, c * np.ones((9, 1)))
+        _close(fm, rfm, 1e-9)
+        _close(fs2, rfs2, 1e-8)
     # exactly at the limit: 8 products from (a+b)*(c+d)*(e+f)
     k8 = (cov.RBF(0.1, 0.) + cov.RQ(0.2, 0., 0.1)) * (cov.RBF(0.3, 0.) + cov.Matern(0.2, 3, 0.)) * (cov.RBFunit(0.5) + cov.Const(-1.))
     assert k8._on_device()
@@ -305,3 +326,37 @@ def test_G15_ep_with_two_ard_leaves_and_larger_sizes_vs_oracle():
                       matern_reference_compat=False)
     assert relerr(nlZ, out["nlZ"]) < 1e-9 and relerr(post.alpha, out["alpha"]) < 1e-7
     assert np.allclose(dnlZ.cov, out["dnlZ_cov"], rtol=1e-6, atol=1e-7 * np.max(np.abs(out["dnlZ_cov"])))
+
+
+def test_three_ard_leaves_fit_and_predict_at_N1500_against_the_oracle():
+    """A tree the device programs cannot hold (three ARD leaves, 16 hypers) at a size where the dense path's linear algebra
+    runs through the panel sweep: fit, all gradients, 200 predictions and a few line searches of the optimiser."""
+    import pygps_amd as pyGPs
+    from pygps_amd import cov
+    rng = np.random.RandomState(2)
+    n, d = 1500, 4
+    x = rng.randn(n, d)
+    y = np.sin(x[:, :1] * 1.3) + 0.5 * np.cos(x[:, 1:2]) + 0.1 * rng.randn(n, 1)
+    k = cov.RBFard(log_ell_list=[0.2, 0.4, 0.1, 0.6], log_sigma=0.0) * cov.RQard(log_ell_list=[0.5, 0.3, 0.7, 0.2], log_sigma=-0.1, log_alpha=0.3) \
+        + cov.RBFard(log_ell_list=[1.0, 0.8, 1.2, 0.9], log_sigma=-0.5)
+    assert not k._on_device()
+    tree = ("sum", ("prod", ("leaf", O.RBFARD, 0), ("leaf", O.RQARD, 0)), ("leaf", O.RBFARD, 0))
+    m = pyGPs.GPR()
+    m.setPrior(kernel=k)
+    m.setNoise(np.log(0.15))
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    c = m.meanfunc.hyp[0]
+    hyp = np.array(m.covfunc.hyp, float)
+    ref = O.exact_fit(tree, hyp, 0, m.likfunc.hyp[0], x, y, c * np.ones((n, 1)), np.ones((n, 1)), faithful=False,
+                      matern_reference_compat=False)
+    assert abs(nlZ - ref["nlZ"]) < 1e-9 * abs(ref["nlZ"])
+    _close(post.alpha, ref["alpha"], 1e-7)
+    _close(np.array(dnlZ.mean + dnlZ.cov + dnlZ.lik), np.concatenate([ref["dnlZ_mean"], ref["dnlZ_cov"], ref["dnlZ_lik"]]), 1e-7)
+    xs = rng.randn(200, d)
+    ym, ys2, fm, fs2, lp = m.predict(xs)
+    rym, rys2, rfm, rfs2 = O.predict(tree, hyp, 0, m.likfunc.hyp[0], x, ref["alpha"], ref["L"], ref["sW"], xs, c * np.ones((200, 1)))
+    _close(fm, rfm, 1e-8)
+    _close(fs2, rfs2, 1e-7)
+    m.optimize(x, y, numIterations=3)
+    assert m.nlZ < nlZ
