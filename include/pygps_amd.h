@@ -153,10 +153,11 @@ void pgp_comm_free(pgp_comm* comm);
 int pgp_comm_world(pgp_comm* comm);
 int pgp_comm_rank(pgp_comm* comm);
 /* Arguments and results as pgp_exact_fit (no factor handle: the factor stays distributed).  timings_out (optional, 4):
- * ms of assembly, sweep, epilogue, total. */
+ * ms of assembly, sweep, epilogue, total.  L_out (optional, (n,n) row-major, zero-filled by the caller): THIS rank's
+ * columns of the factor in post.L's form (upper R, R'R = K/sn2 + I); the sum over the ranks is the whole factor. */
 int pgp_sharded_exact_fit(pgp_ctx* ctx, pgp_comm* comm, int kind, const double* covhyp, int ncov, int para, int flags,
                           double log_sn, const double* mvec, const double* dm, int nmean, int want, double* alpha_out,
-                          double* nlZ_out, double* dnlZ_out, double* timings_out);
+                          double* nlZ_out, double* dnlZ_out, double* timings_out, double* L_out);
 
 /* ---- helper functions: tools.jitchol / tools.solve_chol (Core/tools.py:31-97) ----------------
  * pgp_potrf: A (n,n) symmetric row-major in -> lower Cholesky factor (row-major, zeros above) out.

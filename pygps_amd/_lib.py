@@ -71,7 +71,7 @@ SIGNATURES = {
     "pgp_comm_world": (C.c_int, [_vp]),
     "pgp_comm_rank": (C.c_int, [_vp]),
     "pgp_sharded_exact_fit": (C.c_int, [_vp, _vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int,
-                                        C.c_int, _dp, _dp, _dp, _dp]),
+                                        C.c_int, _dp, _dp, _dp, _dp, _dp]),
 }
 
 # self-test / calibration hooks (csrc/testhooks.h): exported by the library, NOT part of the drop-in boundary

@@ -302,9 +302,11 @@ int pgp_comm_rank(pgp_comm* m) { return m ? m->rank : -1; }
 // Exact.evaluate over the ranks of `comm`.  Every rank passes the same data (pgp_set_data) and arguments and receives the
 // same alpha / nlZ / dnlZ.  Status as pgp_exact_fit: > 0 = first non-positive pivot, identical on every rank.
 // timings_out (optional, 4): ms of assembly, sweep (+ E E' under it), epilogue (alpha, gradient, collectives), total.
+// L_out (optional, (n,n) row-major, zero-filled by the caller): this rank's columns of the factor in post.L's form (upper R =
+// L', Core/inf.py:362): R(j, i) = L(i, j) for the owned columns j; the sum over the ranks is the whole factor.
 int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhyp, int ncov, int para, int flags, double log_sn,
                           const double* mvec, const double* dm, int nmean, int want, double* alpha_out, double* nlZ_out,
-                          double* dnlZ_out, double* timings_out) {
+                          double* dnlZ_out, double* timings_out, double* L_out) {
     if (!c) return -1;
     if (!m || m->ctx != c) return -2;
     if (c->n <= 0) return -1;
@@ -366,6 +368,7 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
     HIP_TRY(hipMemsetAsync(red, 0, (np + 8) * sizeof(double), main));
     CHK(upload_scaled(c, c->x_dev, n, d, cp.scale, XT, np, dpad, c->scale_dev));
     if (grad) HIP_TRY(hipMemsetAsync(Binv, 0, (size_t)np * np * sizeof(double), main));
+    if (L_out) HIP_TRY(hipMemsetAsync(Ld, 0, (size_t)std::max(nloc, 1) * w * w * sizeof(double), main));   // strict upper parts: exact zeros
     // ---- assembly: every rank builds ITS column panels of B = K/sn2 + I straight from the coordinates -------------------
     for (int k = 0; k < nloc; ++k) {
         const long col0 = (long)mine[k] * w;
@@ -538,6 +541,20 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
         (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
         (void)hipEventElapsedTime(&e, c->ev[2], c->ev[3]); (void)hipEventElapsedTime(&t, c->ev[0], c->ev[3]);
         timings_out[0] = a; timings_out[1] = b; timings_out[2] = e; timings_out[3] = t;
+    }
+    if (L_out) {                                     // owned columns of L: the diagonal block from Ld, the rows below from Y
+        for (int k = 0; k < nloc; ++k) {
+            const long col0 = (long)mine[k] * w;
+            if (col0 >= n) break;
+            const long ncol = std::min<long>(w, n - col0);
+            // column-major lower L(i, j) at L_out[j * n + i]  (== row-major upper R(j, i))
+            HIP_TRY(hipMemcpy2D(L_out + col0 * n + col0, n * sizeof(double), Ld + (size_t)k * w * w, w * sizeof(double),
+                                ncol * sizeof(double), ncol, hipMemcpyDeviceToHost));
+            const long below = n - (col0 + w);
+            if (below > 0)
+                HIP_TRY(hipMemcpy2D(L_out + col0 * n + col0 + w, n * sizeof(double), buf(k), ldp * sizeof(double),
+                                    below * sizeof(double), ncol, hipMemcpyDeviceToHost));
+        }
     }
     if (alpha_out) memcpy(alpha_out, alpha_h.data(), n * sizeof(double));
     if (want >= 2 && nlZ_out) *nlZ_out = 0.5 * head[1] / sn2 + head[0] + 0.5 * (double)n * log(2.0 * M_PI * sn2);   // inf.py:370

@@ -226,12 +226,14 @@ def _mean_inputs(meanfunc, x):
 class Exact(Inference):
     """Exact inference for a Gaussian likelihood (Core/inf.py:345-384)."""
 
-    def __init__(self, sharded=False):
+    def __init__(self, sharded=False, gather_factor=False):
         """sharded: False = one GPU (the reference's unit of work); True or a ``sharded.Comm`` = ONE fit over every rank of
-        the process group (one process per GPU, all ranks call with the same model; pygps_amd/sharded.py)."""
+        the process group (one process per GPU, all ranks call with the same model; pygps_amd/sharded.py).  gather_factor:
+        a sharded fit also returns post.L as a host array on every rank (n^2 doubles; moderate n)."""
         self.name = "Exact inference"
         self.device = None
         self.sharded = sharded
+        self.gather_factor = gather_factor
 
     def _evaluate_sharded(self, meanfunc, covfunc, likfunc, x, y, nargout):
         from . import sharded as _sh
@@ -245,11 +247,12 @@ class Exact(Inference):
         m, dm, nm = _mean_inputs(meanfunc, x)
         nc = len(covfunc.hyp)
         log_sn = float(likfunc.hyp[0])
-        alpha, nlz, g, self.last_ms = _sh.exact_fit(comm, kind, para, flags, covfunc.hyp, log_sn, m, dm, nm, n, nargout)
+        alpha, nlz, g, self.last_ms, Lh = _sh.exact_fit(comm, kind, para, flags, covfunc.hyp, log_sn, m, dm, nm, n, nargout,
+                                                        gather_factor=self.gather_factor)
         post = postStruct()
         post.alpha = alpha.reshape(n, 1)
         post.sW = np.ones((n, 1)) / np.sqrt(np.exp(2 * log_sn))
-        post.L = _sh.DistributedFactor(n, comm.world)
+        post.L = Lh if Lh is not None else _sh.DistributedFactor(n, comm.world)
         if nargout > 1:
             if nargout > 2:
                 dnlZ = dnlZStruct(meanfunc, covfunc, likfunc)

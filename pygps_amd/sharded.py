@@ -127,19 +127,31 @@ def default_comm(device=None):
     return _default_comm[device]
 
 
-def exact_fit(comm, kind, para, flags, cov_hyp, log_sn, m, dm, nm, n, nargout=3):
-    """pgp_sharded_exact_fit on the data the context of ``comm`` holds.  Returns (alpha (n,), nlZ, g (nm+nc+1,), ms (4,))."""
+def exact_fit(comm, kind, para, flags, cov_hyp, log_sn, m, dm, nm, n, nargout=3, gather_factor=False):
+    """pgp_sharded_exact_fit on the data the context of ``comm`` holds.  Returns (alpha (n,), nlZ, g (nm+nc+1,), ms (4,), L).
+    gather_factor: L = the (n,n) upper factor post.L on every rank (each rank fetches its own columns, the host arrays are
+    summed over the ranks) -- for moderate n only: it is n^2 doubles on every host; None otherwise."""
     hyp = _lib.f64(np.asarray(cov_hyp, dtype=float))
     nc = len(hyp)
     alpha = np.empty(n)
     nlZ = np.zeros(1)
     g = np.zeros(nm + nc + 1)
     ms = np.zeros(4)
+    L = np.zeros((n, n)) if gather_factor else None
     rc = comm.lib.pgp_sharded_exact_fit(comm.ctx, comm.handle, int(kind), _lib.ptr(hyp), nc, int(para), int(flags),
                                         float(log_sn), _lib.ptr(m), _lib.ptr(dm), int(nm), int(min(max(nargout, 1), 3)),
-                                        _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(g), _lib.ptr(ms))
+                                        _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(g), _lib.ptr(ms), _lib.ptr(L))
     _lib.check(rc, "pgp_sharded_exact_fit")
-    return alpha, float(nlZ[0]), g, ms
+    if L is not None and comm.world > 1:
+        import torch
+        t = torch.from_numpy(L)
+        if comm.dist.get_backend(comm.group) == "nccl":
+            t = t.cuda(comm.device)
+            comm.dist.all_reduce(t, group=comm.group)
+            L = t.cpu().numpy()
+        else:
+            comm.dist.all_reduce(t, group=comm.group)
+    return alpha, float(nlZ[0]), g, ms, L
 
 
 class DistributedFactor(object):

@@ -35,13 +35,13 @@ def _flat(d):
     return np.array(list(d.mean) + list(d.cov) + list(d.lik), dtype=float)
 
 
-def _g6_model(pyGPs, N, sharded):
+def _g6_model(pyGPs, N, sharded, gather=False):
     x, y = synth_reg(N, 16)
     m = pyGPs.GPR()
     m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(16.0)), 0.0))
     m.setNoise(np.log(0.1))
     m.setData(x, y)
-    m.inffunc = pyGPs.inf.Exact(sharded=sharded)
+    m.inffunc = pyGPs.inf.Exact(sharded=sharded, gather_factor=gather)
     return m
 
 
@@ -50,6 +50,9 @@ def _check_g6(N, nlZ, dnlZ, post):
     assert relerr(nlZ, g["nlZ"]) < 1e-9                                               # north star 1e-8
     assert relerr(post.alpha[g["alpha_idx"], 0], g["alpha_sample"]) < 1e-7           # 1e-6
     assert relerr(_flat(dnlZ), np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7
+    if isinstance(post.L, np.ndarray):                                               # gathered factor: the reference's post.L
+        assert relerr(np.diag(post.L), g["L_diag"]) < 1e-9 and relerr(post.L.ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-8   # 1e-6
+        assert np.array_equal(np.tril(post.L[:600, :600], -1), np.zeros((600, 600)))
 
 
 @pytest.mark.parametrize("N", [2048, 8192])
@@ -86,7 +89,7 @@ def _worker(rank, world, port, backend, case, out_dir):
         res = {}
         if case.startswith("g6_"):
             N = int(case[3:])
-            m = _g6_model(pyGPs, N, sharded=comm)
+            m = _g6_model(pyGPs, N, sharded=comm, gather=True)
             nlZ, dnlZ, post = m.getPosterior()
             _check_g6(N, nlZ, dnlZ, post)
             res = dict(nlZ=nlZ, g=_flat(dnlZ), alpha=post.alpha, ms=m.inffunc.last_ms)
