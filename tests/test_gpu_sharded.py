@@ -98,12 +98,13 @@ def _worker(rank, world, port, backend, case, out_dir):
         elif case == "kernels":
             # ragged n (not a multiple of the 512 panel, nor of 128), ARD / Matern / composite kernels against the oracle
             rng = np.random.RandomState(11)
-            for name, n, d in (("ard", 1333, 7), ("matern", 2111, 3), ("sum", 1600, 4)):
+            # ("tiny", 700, 3): two panels over three ranks -- rank 2 owns nothing and only takes part in the collectives
+            for name, n, d in (("ard", 1333, 7), ("matern", 2111, 3), ("sum", 1600, 4), ("tiny", 700, 3), ("one", 300, 2)):
                 x = rng.randn(n, d)
                 y = np.sin(x.sum(1, keepdims=True)) + 0.2 * rng.randn(n, 1)
                 if name == "ard":
                     k, kind, hyp, para = pyGPs.cov.RBFard(log_ell_list=list(rng.uniform(-0.2, 0.8, d)), log_sigma=0.3), O.RBFARD, None, 0
-                elif name == "matern":
+                elif name in ("matern", "tiny", "one"):
                     k, kind, hyp, para = pyGPs.cov.Matern(0.4, 5, 0.2), O.MATERN, None, 5
                 else:
                     k, kind, hyp, para = pyGPs.cov.RBF(0.3, 0.1) + pyGPs.cov.RQ(0.5, -0.2, 0.4), ("sum", ("leaf", O.RBF, 0), ("leaf", O.RQ, 0)), None, 0
@@ -173,7 +174,7 @@ def test_world_8_one_panel_per_rank(tmp_path):
 
 def test_ragged_sizes_and_other_kernels_world_3(tmp_path):
     out = _run(tmp_path, 3, "gloo", "kernels")
-    assert set(out[0]) == {"ard", "matern", "sum"} and all(out[0][k] == out[2][k] for k in out[0])
+    assert set(out[0]) == {"ard", "matern", "sum", "tiny", "one"} and all(out[0][k] == out[2][k] for k in out[0])
 
 
 def test_non_positive_definite_input_raises_on_every_rank(tmp_path):
