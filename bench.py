@@ -196,6 +196,7 @@ def extras(lib, _lib, local, d, roof):
             nlz5 = m5.getPosterior(x5, y5)[0]
             ts.append(time.perf_counter() - t)
             sw = int(m5.inffunc.sweeps)
+            ph5 = _lib.last_timings(local)            # EP phases (host wall clock, each phase ends synchronised): see csrc/ep.hip
         t5 = min(ts)
         # blocked sweep: per site one column of S (8 N B written) + the <=128 (64 on average) pending factor columns re-read
         # by the 16-site kernel once per 16 sites (8 N 64 / 16 B per site); per 128 sites one K=128 fold of the rows >= r0
@@ -208,6 +209,13 @@ def extras(lib, _lib, local, d, roof):
             "site_sweep_GB_per_sweep": bytes_sweep / 1e9,
             # sweep + fused inverse 2 N^3 / 3, V' = K diag(sW) L^-T N^3 (clipped), Sigma = K - V'V'^T N^3 (lower tiles)
             "epComputeParams_flops_per_sweep": 8.0 * n5 ** 3 / 3.0,
+            # the split the site sweep / parameter recomputation figures are read from (last of the two fits)
+            "site_sweep_ms": ph5["solve"] / max(sw, 1), "site_sweep_GBs": bytes_sweep / (ph5["solve"] / max(sw, 1)) / 1e6,
+            "site_sweep_frac_of_hbm_peak": bytes_sweep / (ph5["solve"] / max(sw, 1)) / 1e6 / PEAK_HBM_GBS,
+            "site_sweep_bound": "4096 sequentially dependent site updates per sweep (~0.94 us each), not bandwidth",
+            "params_ms": ph5["potrf"] / max(sw, 1), "params_TFLOPs": 8.0 * n5 ** 3 / 3.0 / (ph5["potrf"] / max(sw, 1)) / 1e9,
+            "params_frac_of_mfma_peak": 8.0 * n5 ** 3 / 3.0 / (ph5["potrf"] / max(sw, 1)) / 1e9 / PEAK_FP64_MFMA_TF,
+            "first_params_and_K_ms": ph5["assemble"], "alpha_and_gradients_ms": ph5["grad"],
             "workload": "BASELINE configs[4]: GPC + RBF, infEP, N=4096 d=32 (cold start, nlZ + gradients, through model.getPosterior)"}
     except Exception as e:           # pragma: no cover
         out["cfg5_ep_N4096_d32"] = {"error": repr(e)}

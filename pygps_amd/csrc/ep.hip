@@ -655,8 +655,15 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     }
     static const bool ep_timing = getenv("PGP_EP_TIMING") != nullptr;      // host wall-clock stamps of the phases (stderr)
     const auto tp0 = std::chrono::steady_clock::now();
-    auto stamp = [&](const char* what) {
-        if (ep_timing) fprintf(stderr, "[ep] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+    // phase times of this fit, host wall clock (every phase ends synchronised): pgp_last_timings reports them as
+    // assemble = K + first parameters, solve = the site sweeps, potrf = the parameter recomputations, grad = alpha + gradients
+    double ph_ms[4] = {0.0, 0.0, 0.0, 0.0};
+    auto tlast = tp0;
+    auto stamp = [&](const char* what, int phase = -1) {
+        const auto now = std::chrono::steady_clock::now();
+        if (phase >= 0) ph_ms[phase] += std::chrono::duration<double, std::milli>(now - tlast).count();
+        tlast = now;
+        if (ep_timing) fprintf(stderr, "[ep] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tp0).count());
     };
     EpWork w{};
     w.n = n; w.np = np; w.ldf = ldf;
@@ -734,7 +741,8 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemsetAsync(w.tnu_d, 0, np * sizeof(double), st));
     }
     HIP_TRY(hipFuncSetAttribute((const void*)ep_sites_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EPS_LDS_BYTES));
-    stamp("K built, nlZ0");
+    HIP_TRY(hipStreamSynchronize(st));
+    stamp("K built, nlZ0", 0);
     const double tol = 1e-4;
     const int max_sweep = 10, min_sweep = 2;
     double nlZ_old = INFINITY;
@@ -803,9 +811,10 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemcpyAsync(ttau.data(), w.ttau_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        stamp("sweep done (synced)");
+        stamp("sweep done (synced)", 1);
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // inf.py:772
-        stamp("params recomputed");
+        HIP_TRY(hipStreamSynchronize(st));
+        stamp("params recomputed", 2);
         if (rc != PGP_OK) return rc;
     }
     if (sweeps_out) *sweeps_out = sweep;
@@ -838,7 +847,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     if (sW_out) memcpy(sW_out, sW.data(), n * sizeof(double));
     if (nlZ_out) *nlZ_out = nlZ;
     HIP_TRY(hipMemcpyAsync(w.s_d, sW.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
-    stamp("alpha");
+    stamp("alpha", 3);
     // ---- derivatives (inf.py:780-803) ------------------------------------------------------------------------
     if (want >= 3 && dnlZ_out) {
         HIP_TRY(hipMemsetAsync(c->alpha_dev, 0, np * sizeof(double), st));
@@ -879,7 +888,11 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         dnlZ_out[nmean + ncov] = 0.0;                                                   // lik.Erf has no hyper
     }
     if (c->prof) prof_collect(c);
-    stamp("gradients");
+    HIP_TRY(hipStreamSynchronize(st));
+    stamp("gradients", 3);
+    c->last_ms[PGP_STAGE_ASSEMBLE] = ph_ms[0]; c->last_ms[PGP_STAGE_SOLVE] = ph_ms[1]; c->last_ms[PGP_STAGE_POTRF] = ph_ms[2];
+    c->last_ms[PGP_STAGE_GRAD] = ph_ms[3]; c->last_ms[PGP_STAGE_TRTRI] = 0.0; c->last_ms[PGP_STAGE_LAUUM] = 0.0;
+    c->last_ms[PGP_STAGE_TOTAL] = ph_ms[0] + ph_ms[1] + ph_ms[2] + ph_ms[3];
     if (factor_out) {
         FactorHandleGuard hg(c, new pgp_factor());
         pgp_factor* f = hg.f;
