@@ -356,3 +356,48 @@ extern "C" int pgp_test_slot_probe(pgp_ctx* c, int nwg, int lds_kb, int hold_us,
     }
     return PGP_OK;
 }
+
+// ---- CU-mask experiment (tools/cumask_probe.py): the K-deep trailing-update-shaped GEMM (M = N, lower trapezoid off) on a
+// stream created with hipExtStreamCreateWithCUMask.  reserve_per_xcd CUs of every XCD are masked OUT (0 = a full mask); the
+// mask word order is probed by the caller through `stride` (bit i of the mask = CU i in the runtime's enumeration; CUs of one
+// XCD are `stride` apart).  out: ms per launch on the masked stream, ms per launch on the plain stream.
+extern "C" int pgp_test_cumask_gemm(pgp_ctx* c, int M, int K, int reserve_per_xcd, int stride, int iters, double* out2) {
+    if (!c || !out2) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    const int ncu = c->prop.multiProcessorCount;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    int kept = 0;
+    for (int i = 0; i < ncu; ++i) {
+        // XCD of CU i = i % stride' ... two enumerations are tried by the caller: stride = 8 (interleaved: CU i on XCD i % 8,
+        // index within the XCD i / 8) or stride = 1 (blocked: XCD i / 32, index i % 32)
+        const int within = stride == 8 ? i / 8 : i % (ncu / 8);
+        const bool keep = within >= reserve_per_xcd;
+        if (keep) { mask[i / 32] |= 1u << (i % 32); ++kept; }
+    }
+    hipStream_t ms = nullptr;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&ms, (uint32_t)mask.size(), mask.data()));
+    DevScratch scr;
+    double *A, *Cm;
+    CHK(scr.alloc(&A, (size_t)M * K * 8)); CHK(scr.alloc(&Cm, (size_t)M * M * 8));
+    HIP_TRY(hipMemset(A, 0, (size_t)M * K * 8)); HIP_TRY(hipMemset(Cm, 0, (size_t)M * M * 8));
+    GemmArgs g{};
+    g.A = A; g.lda = M; g.B = A; g.ldb = M; g.C = Cm; g.ldc = M; g.M = M; g.N = M; g.K = K;
+    g.alpha = -1.0; g.beta = 1.0; g.tile = 128; g.batch = 1; g.dbg = c->gemm_dbg;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    hipStream_t sts[2] = {ms, c->st};
+    for (int s = 0; s < 2; ++s) {
+        for (int i = 0; i < 3; ++i) CHK(gemm_f64_launch(g, sts[s]));
+        HIP_TRY(hipStreamSynchronize(sts[s]));
+        HIP_TRY(hipEventRecord(e0, sts[s]));
+        for (int i = 0; i < iters; ++i) CHK(gemm_f64_launch(g, sts[s]));
+        HIP_TRY(hipEventRecord(e1, sts[s]));
+        HIP_TRY(hipStreamSynchronize(sts[s]));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        out2[s] = t / iters;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(ms);
+    return kept;
+}
