@@ -576,7 +576,7 @@ def main():
         # kernel that runs every trailing update and E E^T product.  Its algorithmic flops: N^3 per fit minus everything
         # the OTHER gemm_f64 instantiations execute (panel solves, 64-tile updates of the leaf chain; executed >= algorithmic
         # there, so this is a lower bound)
-        kd = next((v for k_, v in prof.items() if k_.startswith("kernel gemm_f64_kernel<128,128,false,false,true>")), None)
+        kd = next((v for k_, v in prof.items() if k_.startswith("kernel gemm_f64_kernel<128,128,false,false,true")), None)
         if kd and kd["launches"]:
             alg_dom = alg * nfit - (gf - kd["flops"])
             dom_ms, dom_l = kd["ms"], kd["launches"]
@@ -598,7 +598,7 @@ def main():
                                                                                      tj.get("measured_on_commit", "of round 2")))
             except Exception:
                 traffic = None
-        roof = {"kernel": "gemm_f64_kernel<128,128,false,false,true> (fp64 MFMA, LDS-DMA operand staging: every trailing update of "
+        roof = {"kernel": "gemm_f64_kernel<128,128,false,false,true,true> (fp64 MFMA, LDS-DMA operand staging, yield poll: every trailing update of "
                           "the Cholesky sweep incl. the fused inverse, and the E E^T products)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_MFMA_TF, "traffic": traffic, "traffic_source": tsrc,

@@ -55,6 +55,19 @@ const char* pgp_strerror(int status) {
 __global__ void pgp_noop_kernel() {}
 static int alloc_result_buffer(pgp_ctx* c, long np);
 
+// one yield table per device (4096 words, zeroed once): every context on the device polls / marks the same words
+static unsigned* yield_table(int device) {
+    static std::mutex mu;
+    static unsigned* tab[64] = {nullptr};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64) return nullptr;
+    if (!tab[device]) {
+        if (hipMalloc((void**)&tab[device], 4096 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); tab[device] = nullptr; return nullptr; }
+        (void)hipMemset(tab[device], 0, 4096 * sizeof(unsigned));
+    }
+    return tab[device];
+}
+
 int pgp_init(int device, pgp_ctx** ctx_out) {
     if (!ctx_out) return -2;
     HIP_TRY(hipSetDevice(device));
@@ -86,6 +99,7 @@ int pgp_init(int device, pgp_ctx** ctx_out) {
     memset(c->pc_ms, 0, sizeof(c->pc_ms)); memset(c->pc_flops, 0, sizeof(c->pc_flops));
     memset(c->pc_bytes, 0, sizeof(c->pc_bytes)); memset(c->pc_launch, 0, sizeof(c->pc_launch));
     CHK(alloc_result_buffer(c, 0));
+    c->yield_flags = yield_table(device);
     HIP_TRY(hipMalloc((void**)&c->Dk, (size_t)2048 * 1024 * sizeof(double)));       // 2w x w, w <= 1024
     HIP_TRY(hipMalloc((void**)&c->dpack, (size_t)8 * PACK_DOUBLES * sizeof(double)));
     HIP_TRY(hipMemset(c->Dk, 0, (size_t)2048 * 1024 * sizeof(double)));
@@ -153,6 +167,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "gemm_dbg")) { if (value & ~(64 | 256 | 512)) return -2; c->gemm_dbg = value; return PGP_OK; }
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     if (!strcmp(name, "leaf_first")) { c->leaf_first = value; return PGP_OK; }
+    if (!strcmp(name, "yield")) { c->yield = value; return PGP_OK; }
     if (!strcmp(name, "ep_dbg")) { return ep_set_dbg(value); }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
     if (!strcmp(name, "ep_r_direct")) { c->ep_r_direct = value; return PGP_OK; }
@@ -480,6 +495,11 @@ int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
         CHK(tri_tile_list(c, g.M / T, g.N / T, g.tri_off / T, &g.order, &g.norder));
     }
     if (xcd) CHK(tile_order(c, g.M / 128, g.N / 128, g.tri, g.tri ? g.tri_off / 128 : 0, &g.order, &g.norder));
+    if (c->yield && c->yield_flags) {
+        g.yield_flags = c->yield_flags;
+        // the chain's own small products mark their CUs; every bulk (128-tile, LDS-DMA) launch polls
+        g.yield_role = c->chain_now ? 2 : (gemm_f64_uses_dma128(g) ? 1 : 0);
+    }
     ProfScope ps(c, cls, g.flops, 0.0, st, gemm_f64_uses_dma128(g) ? PC_KERNEL_DMA128 : -1);
     return gemm_f64_launch(g, st);
 }
@@ -500,6 +520,10 @@ struct RowEnd { long eoff; bool winv; long operator()(int nb) const { return win
 static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s1, hipStream_t st,
                         double* packs = nullptr, int info_base = 0, hipEvent_t mark = nullptr, int mark_step = 0) {
     if (!packs) packs = c->inv16;
+    // the diagonal-panel chain of a look-ahead sweep (mark != null or a scratch factorisation next to bulk work): its kernels
+    // mark their CUs so that the bulk workgroups there give way
+    const bool chain = c->yield && c->yield_flags && packs == c->dpack;
+    unsigned* yfl = chain ? c->yield_flags : nullptr;
     int step = 0;
     auto stepped = [&]() -> int {
         if (mark && ++step == mark_step) HIP_TRY(hipEventRecord(mark, st));
@@ -511,13 +535,13 @@ static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s
         double* pack = packs + (long)cb * PACK_DOUBLES;
         {
             ProfScope ps(c, PC_LEAF, 128.0 * 128.0 * 128.0 / 3.0, 0.0, st);
-            CHK(leaf_potrf_launch(Acc, ld, pack, c->info_dev, info_base + cb * 128, st));
+            CHK(leaf_potrf_launch(Acc, ld, pack, c->info_dev, info_base + cb * 128, st, nullptr, yfl));
         }
         CHK(stepped());
         const long rows_below = re(cb + 1) - (long)(cb + 1) * 128;
         if (rows_below > 0) {
             ProfScope ps(c, PC_TRSM, (double)rows_below * 128.0 * 128.0, 0.0, st);
-            CHK(trsm_rows_launch(Acc + 128, ld, rows_below, Acc, ld, pack, st));
+            CHK(trsm_rows_launch(Acc + 128, ld, rows_below, Acc, ld, pack, st, yfl));
         }
         CHK(stepped());
         if (cb + 1 < s1) {               // inner update of the rest of this outer panel, K = 128
@@ -530,7 +554,10 @@ static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s
             const long t128 = (long)(g.M / 128) * (g.N / 128);
             g.tile = t128 < c->small_tile_below ? 64 : 128;
             g.flops = 2.0 * 128.0 * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
-            CHK(gemm_prof(c, PC_GEMM_INNER, g, st));
+            c->chain_now = chain ? 1 : 0;
+            const int rc_u = gemm_prof(c, PC_GEMM_INNER, g, st);
+            c->chain_now = 0;
+            CHK(rc_u);
         }
         CHK(stepped());
     }

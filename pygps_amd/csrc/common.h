@@ -66,7 +66,25 @@ struct GemmArgs {
     // Batched launches whose products shrink with the batch index z (the owned column panels of a block-cyclic sweep):
     // product z has M - z * batch_dm rows (tiles beyond them exit at once) and its first-touch row moves up with it.
     int batch_dm;
+    // Cooperative yield (see gemm_tile.h): a per-CU word counts the workgroups of the latency-critical diagonal-panel chain that
+    // are resident on that CU.  yield_role 1 (bulk launches): the k-loop polls its CU's word once per stage and sleeps while it
+    // is non-zero; yield_role 2 (the chain's own small GEMMs): the workgroup increments the word while it runs.
+    unsigned* yield_flags; int yield_role;
 };
+
+// index of the calling workgroup's CU in a yield-flag table (XCC id | shader engine, array, CU of HW_ID): < 4096
+__device__ __forceinline__ unsigned pgp_cu_key() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        // HW_REG_HW_ID, 32 bits
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u; // HW_REG_XCC_ID
+    return (xcc << 8) | ((hw >> 8) & 0xffu);
+}
+// the chain's kernels: +1 on entry, -1 on exit (thread 0; the caller puts a workgroup barrier before the exit mark)
+__device__ __forceinline__ void pgp_yield_mark(unsigned* flags, int delta) {
+    if (flags && threadIdx.x == 0) {
+        if (delta > 0) __hip_atomic_fetch_add(flags + pgp_cu_key(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_sub(flags + pgp_cu_key(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st);
 bool gemm_f64_uses_dma128(const GemmArgs& g);       // would gemm_f64_launch pick the LDS-DMA 128-tile instantiation?

@@ -17,7 +17,7 @@ static const char* const kProfNames[PC_COUNT] = {
     "hadamard_reduce_kernel", "small/O(N) kernels", "gemm_f64(panel solve X E_D)", "diag_in/out staging",
     // shadow class: every launch of the dominant kernel INSTANTIATION (one row of a rocprofv3 kernel-stats CSV), whatever
     // its purpose class above -- each such launch is counted here AND in its purpose class
-    "kernel gemm_f64_kernel<128,128,false,false,true> (+ dual)"};
+    "kernel gemm_f64_kernel<128,128,false,false,true,*> (LDS-DMA 128-tile)"};
 
 struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; int shadow; };
 
@@ -51,10 +51,14 @@ struct pgp_ctx {
     int eet_max_panels = 32;
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
-    int leaf_first = 1;                 // 1: TU_b(p) is launched only after D(p+1)'s stage-in kernel, so that the first leaf is
+    int leaf_first = 0;                 // 1: TU_b(p) is launched only after D(p+1)'s stage-in kernel, so that the first leaf is
                                         // dispatched BEFORE the update's first wave takes every workgroup slot (a leaf dispatched
                                         // into that wave waited ~140 us for it): 12.08 -> 11.72 ms per N = 8192 fit, two fit
                                         // streams 102.6 -> 105 fits/s.  k > 1: after the (k-1)-th chain kernel (measured worse)
+    int yield = 1;                      // cooperative yield: bulk GEMM workgroups sleep while a workgroup of the diagonal-panel
+                                        // chain is resident on their CU (csrc/gemm_tile.h); 0 = off
+    unsigned* yield_flags = nullptr;    // the device's per-CU table (shared by every context on the device)
+    int chain_now = 0;                  // set by the sweep while it queues the chain's kernels (factor_panel)
     int ep_fused = 2;                   // EP parameter recomputation: 0 blocked multi-rhs solve, 1 through the fused inverse (V' = K diag(sW)
                                         // L^-T as one product), 2 K diag(sW) as dense right-hand-side rows of the sweep
     int ep_r_direct = 1;                // EP gradient: sW sW' o B^-1 = S - S Sigma S from the rebuilt Sigma; 0 = triangular inverse + W'W

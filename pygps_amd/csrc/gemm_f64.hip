@@ -48,15 +48,22 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs& g, int b, int T, int
     return true;
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
+template <int TM, int TN, bool AKC, bool BKC, bool DMA = false, bool YIELD = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int ti, tj;
     if (!decode_tile(g, (int)blockIdx.x, TM, ti, tj)) return;
-    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA>(g, ti, tj, blockIdx.z, smem);
+    if (!YIELD && g.yield_role == 2) {               // one of the chain's own small products: its CU's bulk workgroups give way
+        pgp_yield_mark(g.yield_flags, +1);
+        gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, false>(g, ti, tj, blockIdx.z, smem);
+        __syncthreads();
+        pgp_yield_mark(g.yield_flags, -1);
+        return;
+    }
+    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, YIELD>(g, ti, tj, blockIdx.z, smem);
 }
 
-template <int T, bool AKC, bool BKC, bool DMA = false>
+template <int T, bool AKC, bool BKC, bool DMA = false, bool YIELD = false>
 int launch_t(const GemmArgs& g, hipStream_t st) {
     constexpr int SK = BK + 2;
     constexpr int ASZ = AKC ? T * SK : BK * (T + 16);
@@ -68,11 +75,11 @@ int launch_t(const GemmArgs& g, hipStream_t st) {
     dim3 grid(nblk, 1, g.batch > 0 ? g.batch : 1);
     static std::atomic<size_t> attr_set{0};          // two fit streams (host threads) launch concurrently
     if (attr_set.load(std::memory_order_acquire) < shm) {
-        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC, DMA>,
+        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC, DMA, YIELD>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set.store(shm, std::memory_order_release);
     }
-    hipLaunchKernelGGL((gemm_f64_kernel<T, T, AKC, BKC, DMA>), grid, dim3(256), shm, st, g);
+    hipLaunchKernelGGL((gemm_f64_kernel<T, T, AKC, BKC, DMA, YIELD>), grid, dim3(256), shm, st, g);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
@@ -96,6 +103,7 @@ int gemm_f64_launch(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PGP_OK;
     if (g.tile == 64) return launch_l<64>(g, st);
     // LDS-DMA staging (dbg bit 64): 128 x 128 tiles of M-contiguous operands, whole 16-deep k-tiles
-    if (dma_ok(g)) return launch_t<128, false, false, true>(g, st);
+    if (dma_ok(g)) return (g.yield_role == 1 && g.yield_flags) ? launch_t<128, false, false, true, true>(g, st)
+                                                               : launch_t<128, false, false, true>(g, st);
     return launch_l<128>(g, st);
 }

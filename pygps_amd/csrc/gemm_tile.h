@@ -37,8 +37,19 @@ __device__ __forceinline__ double swap_adjacent(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// A stage of the k-loop is one basic block: nothing run-time selectable is tested inside it.
-template <int TM, int TN, bool AKC, bool BKC, bool DMA = false>
+// A bulk workgroup gives way: while a workgroup of the diagonal-panel chain is resident on this CU (its word in the yield table
+// is non-zero) the wave sleeps instead of issuing MFMAs -- the chain's pivot wave runs a dependent fp64 VALU chain on the same
+// pipe and is 3-4x slower beside a saturating bulk wave.  Bounded: gives up after ~350 us.
+__device__ __noinline__ void gemm_yield_wait(const unsigned* yf) {
+    for (int i = 0; i < 400; ++i) {
+        __builtin_amdgcn_s_sleep(32);
+        if (__hip_atomic_load(yf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
+    }
+}
+
+// A stage of the k-loop is one basic block: nothing run-time selectable is tested inside it (YIELD adds one load per stage,
+// issued beside the LDS-DMA pieces and consumed after the stage's barrier, and a never-taken branch).
+template <int TM, int TN, bool AKC, bool BKC, bool DMA = false, bool YIELD = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, long bz, double* __restrict__ smem) {
     static_assert(!DMA || (!AKC && !BKC && TM == 128 && TN == 128), "LDS-DMA staging: 128-wide M-contiguous operands only");
     constexpr int SA = TM + 16, SB = TN + 16, SK = BK + 2;
@@ -245,11 +256,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         ldfrag(0, 0, 0);
         // the stage buffer is a COMPILE-TIME constant of a k-step (the loop below alternates two instantiations): every LDS
         // address of the step is then the loop-invariant per-lane base plus an immediate, no address arithmetic in the loop
+        const unsigned* yf = nullptr;
+        if constexpr (YIELD) yf = g.yield_flags + pgp_cu_key();
         auto kstep = [&](int kt, auto bufc) {
             constexpr int buf = decltype(bufc)::value;
             const bool more = kt + BK < k1;
             if constexpr (DMA) { if (more) dma_stage(IC<(buf ^ 1)>{}); }     // the other stage was last read before the previous barrier
             else if (more) gload(kt + BK);
+            unsigned yv = 0u;
+            if constexpr (YIELD) yv = __hip_atomic_load(yf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int ks = 0; ks + 1 < NS; ++ks) {
                 ldfrag(buf, ks + 1, (ks + 1) & 1);
@@ -258,6 +273,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (more) sstore(buf ^ 1);
             __syncthreads();
+            if constexpr (YIELD) { if (__builtin_amdgcn_readfirstlane(yv) != 0u) gemm_yield_wait(yf); }
             if (more) ldfrag(buf ^ 1, 0, NS & 1); // first fragments of the next stage, behind ...
             __builtin_amdgcn_sched_barrier(0);    // (keep the reads AHEAD of the MFMAs: the scheduler sinks them behind otherwise)
             mfmas((NS - 1) & 1);                  // ... the held-back last substep of this one

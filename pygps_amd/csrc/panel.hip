@@ -298,9 +298,12 @@ __device__ __forceinline__ void leaf_potrf_body(double* __restrict__ A, long lda
 
 __global__ __launch_bounds__(256, 2) void leaf_potrf_kernel(double* __restrict__ A, long lda,
                                                             double* __restrict__ pack, int* __restrict__ info,
-                                                            int info_base, long long* __restrict__ tick) {
+                                                            int info_base, long long* __restrict__ tick, unsigned* yield_flags) {
     extern __shared__ __attribute__((aligned(16))) double s[];
+    pgp_yield_mark(yield_flags, +1);                 // the bulk workgroups on this CU give way while the leaf runs (gemm_tile.h)
     leaf_potrf_body(A, lda, pack, info, info_base, tick, s);
+    __syncthreads();
+    pgp_yield_mark(yield_flags, -1);
 }
 
 // X (nrows x 128, column-major, ld) <- X * L^-T, L = 128x128 lower at Ld (ld), inv16 = 8 inverted
@@ -368,9 +371,13 @@ __device__ __forceinline__ void trsm_rows_body(double* __restrict__ X, long ldx,
 
 __global__ __launch_bounds__(256, 2) void trsm_rows_kernel(double* __restrict__ X, long ldx, long nrows,
                                                            const double* __restrict__ Ld, long ldl,
-                                                           const double* __restrict__ inv16 /* packed image */) {
+                                                           const double* __restrict__ inv16 /* packed image */,
+                                                           unsigned* yield_flags) {
     extern __shared__ __attribute__((aligned(16))) double sl[];
+    pgp_yield_mark(yield_flags, +1);
     trsm_rows_body(X, ldx, nrows, inv16, blockIdx.x, sl);
+    __syncthreads();
+    pgp_yield_mark(yield_flags, -1);
 }
 
 // W_kk = inv(L_kk) for every 128x128 diagonal block k (blockIdx.x), written into W (same layout).
@@ -397,19 +404,19 @@ __global__ __launch_bounds__(128, 1) void leaf_inv_kernel(const double* __restri
 }  // namespace
 
 int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st,
-                      long long* tick) {
+                      long long* tick, unsigned* yield_flags) {
     const size_t shm = (36 * 256 + 256 + 2) * sizeof(double);
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
         (void)hipFuncSetAttribute((const void*)leaf_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(leaf_potrf_kernel, dim3(1), dim3(256), shm, st, A, lda, inv16, info, info_base, tick);
+    hipLaunchKernelGGL(leaf_potrf_kernel, dim3(1), dim3(256), shm, st, A, lda, inv16, info, info_base, tick, yield_flags);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
 int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl, const double* inv16,
-                     hipStream_t st) {
+                     hipStream_t st, unsigned* yield_flags) {
     if (nrows <= 0) return PGP_OK;
     const unsigned nblk = (unsigned)((nrows + 63) / 64);
     const size_t shm = 36 * 256 * sizeof(double);
@@ -418,7 +425,7 @@ int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl
         (void)hipFuncSetAttribute((const void*)trsm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(trsm_rows_kernel, dim3(nblk), dim3(256), shm, st, X, ldx, nrows, Ld, ldl, inv16);
+    hipLaunchKernelGGL(trsm_rows_kernel, dim3(nblk), dim3(256), shm, st, X, ldx, nrows, Ld, ldl, inv16, yield_flags);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 

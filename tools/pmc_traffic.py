@@ -23,7 +23,7 @@ def load(pattern, counter, match):
 if __name__ == "__main__":
     root = sys.argv[1]
     out = sys.argv[2]
-    DOM = "gemm_f64_kernel<128, 128, false, false, true>"  # the dominant instantiation (LDS-DMA 128-tile kernel)
+    DOM = "gemm_f64_kernel<128, 128, false, false, true"   # the dominant instantiation (LDS-DMA 128-tile kernel; with or without the yield poll)
     head = sys.argv[3] if len(sys.argv) > 3 else "unknown"
     f, nf = load(root + "/fetch/**/*counter_collection.csv", "FETCH_SIZE", DOM)
     w, nw = load(root + "/write/**/*counter_collection.csv", "WRITE_SIZE", DOM)

@@ -5,7 +5,7 @@ import csv, glob, json, os, re, subprocess, sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = sys.argv[1]
-DOM = "gemm_f64_kernel<128, 128, false, false, true>"
+DOM = "gemm_f64_kernel<128, 128, false, false, true"
 PASSES = {"fetch": "FETCH_SIZE", "mfma": "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE", "l2": "TCC_HIT_sum TCC_MISS_sum",
           "wait": "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"}
 out = {"kernel": DOM, "what": "per launch of the dominant instantiation, averaged over the launches of 4 single-stream N=8192 fits "
