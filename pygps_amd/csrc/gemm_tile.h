@@ -258,13 +258,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         // address of the step is then the loop-invariant per-lane base plus an immediate, no address arithmetic in the loop
         const unsigned* yf = nullptr;
         if constexpr (YIELD) yf = g.yield_flags + pgp_cu_key();
-        auto kstep = [&](int kt, auto bufc) {
+        auto kstep = [&](int kt, auto bufc, auto pollc) {
             constexpr int buf = decltype(bufc)::value;
+            constexpr bool POLL = YIELD && decltype(pollc)::value != 0;       // the yield word is looked at every fourth stage
             const bool more = kt + BK < k1;
             if constexpr (DMA) { if (more) dma_stage(IC<(buf ^ 1)>{}); }     // the other stage was last read before the previous barrier
             else if (more) gload(kt + BK);
             unsigned yv = 0u;
-            if constexpr (YIELD) yv = __hip_atomic_load(yf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (POLL) yv = __hip_atomic_load(yf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int ks = 0; ks + 1 < NS; ++ks) {
                 ldfrag(buf, ks + 1, (ks + 1) & 1);
@@ -273,7 +274,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
             if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (more) sstore(buf ^ 1);
             __syncthreads();
-            if constexpr (YIELD) { if (__builtin_amdgcn_readfirstlane(yv) != 0u) gemm_yield_wait(yf); }
+            if constexpr (POLL) { if (__builtin_amdgcn_readfirstlane(yv) != 0u) gemm_yield_wait(yf); }
             if (more) ldfrag(buf ^ 1, 0, NS & 1); // first fragments of the next stage, behind ...
             __builtin_amdgcn_sched_barrier(0);    // (keep the reads AHEAD of the MFMAs: the scheduler sinks them behind otherwise)
             mfmas((NS - 1) & 1);                  // ... the held-back last substep of this one
@@ -298,17 +299,27 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
 #pragma unroll
                             for (int r = 0; r < 4; ++r) acc[2 * hf + q][in][r] = fma(ab, creg[q][r], acc[2 * hf + q][in][r]);
                     }
-                    if (st & 1) kstep(kt, IC<1>{}); else kstep(kt, IC<0>{});     // st is an unrolled constant
+                    if (st & 1) kstep(kt, IC<1>{}, IC<0>{});                     // st is an unrolled constant
+                    else if ((st & 3) == 0) kstep(kt, IC<0>{}, IC<1>{});
+                    else kstep(kt, IC<0>{}, IC<0>{});
                     kt += BK;
                 }
             }
         }
         while (kt < k1) {                         // FN * FM is even: the stage parity is 0 here on both paths
-            kstep(kt, IC<0>{});
+            kstep(kt, IC<0>{}, IC<1>{});
             kt += BK;
             if (kt >= k1) break;
-            kstep(kt, IC<1>{});
+            kstep(kt, IC<1>{}, IC<0>{});
             kt += BK;
+            if constexpr (YIELD) {                // four stages per trip: one poll
+                if (kt >= k1) break;
+                kstep(kt, IC<0>{}, IC<0>{});
+                kt += BK;
+                if (kt >= k1) break;
+                kstep(kt, IC<1>{}, IC<0>{});
+                kt += BK;
+            }
         }
     }
 
