@@ -3,6 +3,7 @@
 // triangular inverse, W^T W, fused gradient reduce.  See DESIGN.md for the pipeline.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,28 @@
 #include "ctx.h"
 
 // ------------------------------------------------------------------------------------------------
+// ---- fit streams in flight per device (eet_overlap 4) ----------------------------------------------------------------------
+namespace {
+struct DeviceLoad { std::atomic<int> active{0}; std::atomic<long long> shared_ns{0}; };
+DeviceLoad g_load[64];
+long long now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+FitScope::FitScope(pgp_ctx* ctx) : c(ctx) {
+    DeviceLoad& L = g_load[c->device & 63];
+    const long long t = now_ns();
+    if (L.active.fetch_add(1) > 0) L.shared_ns.store(t);
+    c->solo = t - L.shared_ns.load() > 20000000LL;          // nobody else for 20 ms: gaps between the fits of a host thread are shorter
+    static const bool dbg = getenv("PGP_DEBUG_SOLO") != nullptr;
+    if (dbg) fprintf(stderr, "[solo] ctx %p t %.3f ms active-before %d since-shared %.3f ms solo %d\n", (void*)c, (t % 100000000000LL) * 1e-6,
+                     L.active.load() - 1, (t - L.shared_ns.load()) * 1e-6, (int)c->solo);
+}
+FitScope::~FitScope() {
+    DeviceLoad& L = g_load[c->device & 63];
+    if (L.active.fetch_sub(1) > 1) L.shared_ns.store(now_ns());
+}
+
 static thread_local char g_err[512] = "";
 void pgp_set_last_hip_error(hipError_t e, const char* what, const char* file, int line) {
     snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
@@ -131,6 +154,7 @@ void pgp_destroy(pgp_ctx* c) {
     // every stream of the context may still carry work of the last call (the panel stream runs the last E E^T product)
     (void)hipStreamSynchronize(c->st);
     if (c->st2) (void)hipStreamSynchronize(c->st2);
+    if (c->st3) { (void)hipStreamSynchronize(c->st3); (void)hipStreamDestroy(c->st3); }
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     for (auto& kv : c->spool) (void)hipFree(kv.second);
     for (auto& kv : c->orders) (void)hipFree(kv.second.first);
@@ -144,6 +168,7 @@ void pgp_destroy(pgp_ctx* c) {
     for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto& e : c->la_ev) (void)hipEventDestroy(e);
     for (auto& e : c->fill_ev) (void)hipEventDestroy(e);
+    for (auto& e : c->ep_ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->st);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     delete c;
@@ -180,7 +205,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "solve_outer")) { if (value < 1) return -2; c->solve_outer = value; return PGP_OK; }
     if (!strcmp(name, "predict_batch")) { if (value < 128 || value % 128) return -2; c->predict_batch = value; return PGP_OK; }
     if (!strcmp(name, "s_tile")) { if (value != 0 && value != 64 && value != 128) return -2; c->s_tile = value; return PGP_OK; }
-    if (!strcmp(name, "eet_overlap")) { if (value != 0 && value != 2 && value != 3) return -2; c->eet_overlap = value; return PGP_OK; }
+    if (!strcmp(name, "eet_overlap")) { if (value < 0 || value > 4) return -2; c->eet_overlap = value; return PGP_OK; }
     if (!strcmp(name, "eet_max_panels")) { c->eet_max_panels = value; return PGP_OK; }
     if (!strcmp(name, "eet_first")) { if (value < -1) return -2; c->eet_first = value; return PGP_OK; }
     if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
@@ -726,11 +751,42 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // B^-1 = sum_p E_p E_p^T accumulated under the sweep (eet_overlap 2, or 3 up to eet_max_panels panels: beyond that the
     // chain is amortised and the one-shot long-K product is faster): panel p's share right behind TU_b(p) on the main
     // stream -- the main stream stays busy until D(p+1) is done instead of waiting for it
-    const bool fill_inline = la && m.E && !m.dense2 && c->eet_out &&
-                             (c->eet_overlap == 2 || (c->eet_overlap == 3 && npanel <= c->eet_max_panels));
+    const bool fill_any = la && m.E && !m.dense2 && c->eet_out &&
+                          (c->eet_overlap == 1 || c->eet_overlap == 2 || (c->eet_overlap >= 3 && npanel <= c->eet_max_panels));
+    // eet_overlap 1 (4: while no other fit stream works on the device): the products go to a third stream as soon
+    // as S(p) has produced their columns: they fill the partial last waves of the main stream's launches and the half-empty
+    // S / TU_a launches (-1.7 % for a single chain at N = 8192; -17 % when a second fit stream already fills those holes)
+    hipStream_t fill = nullptr;
+    if (fill_any && (c->eet_overlap == 1 || (c->eet_overlap == 4 && c->solo))) {
+        // default priority on purpose: a stream of the LOWEST priority costs two concurrent fit streams 11 % by merely
+        // existing (106 -> 95 fits/s with the stream created and never used; measured, round 3)
+        if (!c->st3) HIP_TRY(hipStreamCreateWithFlags(&c->st3, hipStreamNonBlocking));
+        fill = c->st3;
+        while ((int)c->fill_ev.size() < npanel + 3) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->fill_ev.push_back(e);
+        }
+    }
+    else if (c->st3 && fill_any) {
+        // a context that shares the device gives its filler stream back: beyond four streams of one priority the runtime maps
+        // streams onto shared hardware queues, and two fit streams that land on one queue serialise (measured inside
+        // bench.py: cfg 4 on two fit streams 104 -> 92 fits/s with the idle third stream of one context still alive)
+        (void)hipStreamSynchronize(c->st3);
+        (void)hipStreamDestroy(c->st3);
+        c->st3 = nullptr;
+    }
+    const bool fill_inline = fill_any && !fill;
+    const int pf0 = std::min(c->eet_first >= 0 ? c->eet_first : npanel / 6, npanel - 2);
     for (int p = 0; p < npanel; ++p) {
         const int s0 = p * q, s1 = std::min(s0 + q, nblk);
         CHK(solve_below(c, m, s0, s1, Xs, ldx, main));
+        if (fill && (p >= pf0 || s1 >= nblk)) {                       // E's columns of panels <= p are final
+            HIP_TRY(hipEventRecord(c->fill_ev[2 + p], main));
+            HIP_TRY(hipStreamWaitEvent(fill, c->fill_ev[2 + p], 0));
+            CHK(eet_panel(c, m, p == pf0 ? 0 : s0, s1, c->eet_out, c->eet_ld, fill));
+            if (s1 >= nblk) { HIP_TRY(hipEventRecord(c->fill_ev[1], fill)); c->eet_join = c->fill_ev[1]; }
+        }
         if (s1 >= nblk) break;
         const int n0 = s1, n1 = std::min(s1 + q, nblk);              // next panel's columns
         CHK(trailing_update2(c, m, s0, s1, n0, n1, Xs, ldx, main));   // TU_a -> staging
@@ -995,6 +1051,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     if (want < 1 || want > 3) return -11;
     if (ncov < 0 || 8 + ncov + 1 > RES_INFO) return -4;
     HIP_TRY(hipSetDevice(c->device));
+    FitScope in_flight(c);
     const long n = c->n, d = c->d, np = c->np;
     const bool fused = want >= 3 && c->fused_inverse;
     const long ldf = c->ldf;                         // factor buffer = factor rows + rhs rows; the inverse rows are scratch

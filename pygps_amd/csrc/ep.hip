@@ -211,40 +211,88 @@ __device__ __forceinline__ double erfcx_0_6(double u) {
     const double r0 = fma(q[1], t4, q[0]), r1 = fma(q[3], t4, q[2]), r2 = fma(q[5], t4, q[4]);
     return fma(r2, t16, fma(r1, t8, r0));
 }
+// exp(x) for -800 <= x <= 0: x = n ln 2 + r (Cody-Waite in two pieces), Taylor polynomial of degree 13 on |r| <= ln 2 / 2
+// (remainder < 4e-18), v_ldexp_f64.  ~20 instructions against ~40 of the library's exp: every instruction of the site update
+// is on the chain of 4096 dependent updates.
+__device__ __forceinline__ double exp_neg(double x) {
+    const double n = rint(x * 1.44269504088896340736);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
 // N(z) / Phi(z) for z > -5 (the branch of lik.py:340-343 without asymptotics).  z <= 0: Phi = exp(-z^2/2) erfcx(-z/sqrt 2) / 2,
 // so the ratio is sqrt(2/pi) / erfcx(-z/sqrt 2) -- no exponential at all; z > 0: Phi = 1 - exp(-u^2) erfcx(u) / 2, u = z/sqrt 2
-// (beyond u = 6 exp(-u^2) < 2.4e-16 makes Phi = 1 whatever the clamped polynomial returns).
-__device__ __forceinline__ double probit_hazard(double z) {
+// (beyond u = 6 exp(-u^2) < 2.4e-16 makes Phi = 1 whatever the clamped polynomial returns).  The callers evaluate it on
+// wave-uniform arguments, so the sign test is a real branch: z <= 0 never pays for the exponential.
+__device__ __forceinline__ void probit_hazard_frac(double z, double& P, double& Q) {      // N(z) / Phi(z) = P / Q
     const double u = fabs(z) * 0.70710678118654752440;
     const double gx = erfcx_0_6(fmin(u, erfcx_poly::UMAX));
-    const double e = exp(-u * u);                                              // only used for z > 0: off the z <= 0 chain
-    const double neg = 0.79788456080286535588 * fast_rcp(gx);
-    const double pos = e * 0.39894228040143267794 * fast_rcp(fma(-0.5 * e, gx, 1.0));
-    return z <= 0.0 ? neg : pos;
+    if (z <= 0.0) { P = 0.79788456080286535588; Q = gx; return; }
+    const double e = exp_neg(fmax(-u * u, -800.0));
+    P = e * 0.39894228040143267794;
+    Q = fma(-0.5 * e, gx, 1.0);
+}
+__device__ __forceinline__ double probit_hazard(double z) {
+    double P, Q;
+    probit_hazard_frac(z, P, Q);
+    return P * fast_rcp(Q);
 }
 
-__device__ __forceinline__ void ep_site_update(double sii, double mui, double tp, double np_, double mi, double yi,
-                                               double& t_new, double& nu_new, double& cj, double& qj) {
+// One site update (inf.py:759-769 + lik.py:295-311) on the chain of 4096 dependent updates.  The likelihood ratio
+// n_p = N(z) / Phi(z) stays a FRACTION P / Q all the way to the rank-1 coefficient, so the chain from (Sigma_ii, mu_i) to c_j
+// has three reciprocals (cavity, the polynomial's argument map, c_j) and one reciprocal square root instead of six:
+//   a = -d2lZ = n_p (z + n_p) / (1 + s2) = A / Q^2,  A = P (z Q + P) rden^2        den = 1 + d2lZ s2 = D / Q^2,  D = Q^2 - A s2
+//   ttau_new = a / den = A / D            ds2 = (A - tp D) / D            c_j = ds2 / (1 + ds2 Sigma_ii) = N / (D + N Sigma_ii),  N = A - tp D
+//   tnu_new = (dlZ + (m - mu_c) d2lZ) / den = (ys P Q rden - (m - mu_c) A) / D   (its reciprocal runs beside c_j's)
+// ttau_new < 0 (inf.py:765 clamps it to 0) <=> A D < 0: then ds2 = -tp and c_j = -tp / (1 - tp Sigma_ii) = -tp r1.
+struct EpSiteMid { double r1, s2, mu_c, ys, rden, z, P, Q; };
+__device__ __forceinline__ void ep_site_update_a(double sii, double mui, double tp, double np_, double mi, double yi, EpSiteMid& h) {
     // cavity (inf.py:759-760) with ONE reciprocal: tau_ni = 1/sii - tp = d1/sii, d1 = 1 - tp sii
     const double d1 = fma(-tp, sii, 1.0);
-    const double r1 = fast_rcp(d1);
-    const double s2 = sii * r1;                                                // 1 / tau_ni
-    const double mu_c = fma(mi, d1, fma(-np_, sii, mui)) * r1;                 // nu_ni / tau_ni
-    const double ys = (yi < 0.0) ? -1.0 : 1.0;
-    const double rden = fast_rsqrt(1.0 + s2);
-    const double z = ys * mu_c * rden;
-    double n_p;
-    if (z > -5.0) n_p = probit_hazard(z);                                      // lik.py:340-343 (naive ratio)
-    else n_p = erf_ratio(z, exp(erf_logphi(z)));
-    const double dlZ = ys * n_p * rden;                                        // lik.py:304-309
-    const double d2lZ = -n_p * (z + n_p) * (rden * rden);
-    const double w = fast_rcp(fma(d2lZ, s2, 1.0));
-    t_new = fmax(-d2lZ * w, 0.0);                                              // inf.py:764-765
-    nu_new = (dlZ + (mi - mu_c) * d2lZ) * w;
-    const double ds2 = t_new - tp;
-    cj = ds2 * fast_rcp(fma(ds2, sii, 1.0));
+    h.r1 = fast_rcp(d1);
+    h.s2 = sii * h.r1;                                                         // 1 / tau_ni
+    h.mu_c = fma(mi, d1, fma(-np_, sii, mui)) * h.r1;                          // nu_ni / tau_ni
+    h.ys = (yi < 0.0) ? -1.0 : 1.0;
+    h.rden = fast_rsqrt(1.0 + h.s2);
+    h.z = h.ys * h.mu_c * h.rden;
+    if (h.z > -5.0) probit_hazard_frac(h.z, h.P, h.Q);                        // lik.py:340-343 (naive ratio)
+    else { h.P = erf_ratio(h.z, exp(erf_logphi(h.z))); h.Q = 1.0; }
+}
+__device__ __forceinline__ void ep_site_update_b(double sii, double mui, double tp, double np_, double mi, const EpSiteMid& h,
+                                                 double& t_new, double& nu_new, double& cj, double& qj) {
+    const double r1 = h.r1, s2 = h.s2, mu_c = h.mu_c, ys = h.ys, rden = h.rden, z = h.z, P = h.P, Q = h.Q;
+    const double A = P * fma(z, Q, P) * (rden * rden);
+    const double Q2 = Q * Q;
+    const double D = fma(-A, s2, Q2);
+    const double N = fma(-tp, D, A);
+    const double rc = fast_rcp(fma(N, sii, D));
+    const double wq = fast_rcp(D);
+    const bool clamp = A * D < 0.0;                                            // inf.py:764-765
+    t_new = clamp ? 0.0 : A * wq;
+    cj = clamp ? -tp * r1 : N * rc;
+    nu_new = fma(ys * P * rden, Q, -(mi - mu_c) * A) * wq;
     const double dnu = nu_new - np_;
     qj = dnu - cj * fma(dnu, sii, mui);
+}
+__device__ __forceinline__ void ep_site_update(double sii, double mui, double tp, double np_, double mi, double yi,
+                                               double& t_new, double& nu_new, double& cj, double& qj) {
+    EpSiteMid h;
+    ep_site_update_a(sii, mui, tp, np_, mi, yi, h);
+    ep_site_update_b(sii, mui, tp, np_, mi, h, t_new, nu_new, cj, qj);
 }
 
 // EPT consecutive sites per launch.  The sites are sequentially dependent, but site t+1 only needs ROW i_(t+1) of the
@@ -443,6 +491,250 @@ __global__ __launch_bounds__(256) void ep_fold_prep_kernel(const double* __restr
     if (grp == 0 && r < np) mu[r] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
+// ---- block sweep (ep_block 2, round 3) ---------------------------------------------------------------------------------
+// The sites of one block B of 128 consecutive sites only ever read Sigma_BB and mu_B: the sequential site loop of the block is
+// EP on a 128-point problem, run by ONE workgroup with Sigma_BB in registers (ep_chain_kernel, 128 dependent site updates in
+// one launch, no launch boundary and no global memory between two sites).  What the block did to the rest of Sigma follows
+// from the matrix inversion lemma, exactly and all at once: with dT = diag(ttau_new - ttau_old) on B,
+//     Sigma_new = (Sigma^-1 + E_B dT E_B')^-1 = Sigma - Sigma(:,B) W Sigma(B,:),   W = (dT^-1 + Sigma_BB)^-1 = dT - dT Sigma_BB,new dT
+// (Sigma_BB,new is what the chain ends with; no inverse, and dT = 0 rows are fine), and for mu = Sigma tnu with
+// h = dnu - dT o mu_B,old:                 mu_new = mu + Sigma(:,B) g,    g = h - dT o (Sigma_BB,new h).
+// Same sites in the same order with the same scalar update as inf.py:757-770; only the order in which the rank-1 terms are
+// summed differs.  Two streams: the chain stream runs  prep(b) -> chain(b)  (prep brings the NEXT diagonal block and its mu up
+// to date: one 128 x 128 tile), the bulk stream copies the strip Sigma(:,B), forms U = strip W and folds U strip' into the rows
+// of the sites still to come -- beside the next block's chain.
+// The waves are SPECIALISED.  A first version in which every wave did everything (site update evaluated redundantly, 8 x 8
+// entries of Sigma_BB per thread, one barrier per site) took 2850 s_memtime ticks per site, of which the scalar site update
+// is ~1050 and everything around it ~1800: a lone wave issues one fp64 instruction per 5.4 ticks, and LDS is bandwidth-bound
+// per LANE (a ds_read_b64 costs the 4 waves 17 ticks whether the lanes share an address or not: tools/wave_costs.py) -- the 16
+// broadcast reads, the 64 + 16 FMAs of the rank-1 share and the column hand-over all sat in series with the site update.
+// Here wave 0 does nothing but the site updates, back to back: at the end of
+// site k it needs only three numbers -- Sigma(k+1,k), Sigma(k+1,k+1) and mu(k+1) as they were BEFORE site k -- which the three
+// update waves (Sigma_BB in their registers, 48 row slots each) published one site earlier, and applies site k's own rank-1
+// term to them itself.  The update waves run one site behind: they wait for (c_k, q_k), pass column k+1 / diagonal / mu on
+// (double-buffered by the parity of k), then do their share of the rank-1 update while wave 0 is already inside site k+1.
+// Hand-over through LDS sequence counters, no workgroup barrier inside the loop.
+constexpr int EPR = 12;                          // row slots of an update lane: rows 48 u + ti + 4 r (rows >= 128 are padding)
+constexpr int EPCP = 144;
+__device__ __forceinline__ int lds_seq(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict__ Sig, long ld, long i0, int nb,
+                                                        const double* __restrict__ mu, const double* __restrict__ m,
+                                                        const double* __restrict__ y, double* __restrict__ ttau,
+                                                        double* __restrict__ tnu, double* __restrict__ Wout,
+                                                        double* __restrict__ gout, unsigned* yield_flags,
+                                                        long long* __restrict__ stamps) {
+    __shared__ __attribute__((aligned(16))) double colb[2][EPCP];     // column k of Sigma_BB before site k, by parity of k
+    __shared__ double diagb[2][EPB], mub[2][EPB];                     // diagonal and mu before site k, by parity of k
+    __shared__ __attribute__((aligned(16))) double cq[2][2];          // (c_k, q_k)
+    __shared__ __attribute__((aligned(32))) double prm[EPB][4];       // the sites' (ttau, tnu) of the previous sweep, m, y
+    __shared__ double s_mu0[EPB], s_dt[EPB], s_dn[EPB], s_tn[EPB], s_nn[EPB];
+    __shared__ int seqC, seqP;                   // sites wave 0 has finished ; 3 x sites the update waves have passed on
+    pgp_yield_mark(yield_flags, +1);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int u = wv - 1, ti = lane >> 4, tj = lane & 15;
+    long long spinC = 0, spinP = 0, spinQ = 0;
+    if (stamps && t == 0) stamps[0] = __builtin_amdgcn_s_memtime();
+    if (t == 0) { seqC = 0; seqP = 0; }
+    if (t < EPB) {
+        const bool live = t < nb;
+        prm[t][0] = live ? ttau[i0 + t] : 0.0; prm[t][1] = live ? tnu[i0 + t] : 0.0;
+        prm[t][2] = live ? m[i0 + t] : 0.0; prm[t][3] = live ? y[i0 + t] : 1.0;
+        s_mu0[t] = mu[i0 + t]; s_dt[t] = 0.0; s_dn[t] = 0.0; s_tn[t] = 0.0; s_nn[t] = 0.0;
+        diagb[0][t] = Sig[(i0 + t) + (i0 + t) * ld]; mub[0][t] = mu[i0 + t];
+    }
+    if (t < 2 * (EPCP - EPB)) colb[t / (EPCP - EPB)][EPB + t % (EPCP - EPB)] = 0.0;
+    double D[EPR][8];                            // update waves: D[r][c] = Sigma_BB(48 u + ti + 4 r, tj + 16 c)
+    if (wv > 0) {
+#pragma unroll
+        for (int r = 0; r < EPR; ++r) {
+            const int row = 48 * u + ti + 4 * r;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) D[r][c] = row < EPB ? sym_at(Sig, ld, i0 + row, i0 + tj + 16 * c) : 0.0;
+            if (tj == 0 && row < EPB) colb[0][row] = D[r][0];
+        }
+    }
+    __syncthreads();
+    if (stamps && t == 0) stamps[1] = __builtin_amdgcn_s_memtime();
+    if (wv == 0) {
+        // ---- the chain: inf.py:757-770 for the sites of the block, nothing else -------------------------------------------
+        double dkk = diagb[0][0], muk = mub[0][0];
+        double pc0 = prm[0][0], pc1 = prm[0][1], pc2 = prm[0][2], pc3 = prm[0][3];
+        for (int k = 0; k < nb; ++k) {
+            const int kn = k + 1 < EPB ? k + 1 : EPB - 1;
+            const double pn0 = prm[kn][0], pn1 = prm[kn][1], pn2 = prm[kn][2], pn3 = prm[kn][3];
+            double t_new, nu_new, cj, qj;
+            ep_site_update(dkk, muk, pc0, pc1, pc2, pc3, t_new, nu_new, cj, qj);
+            if (lane == 0) {
+                cq[k & 1][0] = cj; cq[k & 1][1] = qj;
+                s_dt[k] = t_new - pc0; s_dn[k] = nu_new - pc1; s_tn[k] = t_new; s_nn[k] = nu_new;
+                __hip_atomic_store(&seqC, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (k + 1 < nb) {
+                // Sigma(k+1,k), Sigma(k+1,k+1), mu(k+1) before site k: passed on by the update waves during their step k-1
+                while (lds_seq(&seqP) < 3 * k) { __builtin_amdgcn_s_sleep(1); ++spinC; }
+                const double e1 = colb[k & 1][k + 1], d1 = diagb[k & 1][k + 1], m1 = mub[k & 1][k + 1];
+                dkk = fma(-cj * e1, e1, d1);
+                muk = fma(qj, e1, m1);
+            }
+            pc0 = pn0; pc1 = pn1; pc2 = pn2; pc3 = pn3;
+        }
+    } else {
+        // ---- the update waves, one site behind ------------------------------------------------------------------------------
+        const int di_ = 64 * u + lane;           // the diagonal / mu entry this lane keeps up to date (< 128: two of the three waves)
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            const int lim = nb - 16 * kc < 16 ? nb - 16 * kc : 16;
+            for (int kr = 0; kr < lim; ++kr) {
+                const int k = 16 * kc + kr, b = k & 1;
+                while (lds_seq(&seqP) < 3 * k) { __builtin_amdgcn_s_sleep(1); ++spinP; }       // column k, diagonal, mu of every update wave are in
+                double cr[EPR], cc[8];
+#pragma unroll
+                for (int r = 0; r < EPR; ++r) cr[r] = colb[b][48 * u + ti + 4 * r];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) cc[c] = colb[b][tj + 16 * c];
+                double dI = 0.0, mI = 0.0, cI = 0.0;
+                if (di_ < EPB) { dI = diagb[b][di_]; mI = mub[b][di_]; cI = colb[b][di_]; }
+                while (lds_seq(&seqC) < k + 1) { __builtin_amdgcn_s_sleep(1); ++spinQ; }       // (c_k, q_k)
+                const double cj = cq[b][0], qj = cq[b][1];
+                const double ncj = -cj;
+                if (k + 1 < EPB) {
+                    const bool wrap = kr == 15;
+                    const int krn = wrap ? 0 : kr + 1;
+                    if (tj == krn) {
+                        const double cv = ncj * (wrap ? cc[(kc + 1) & 7] : cc[kc]);
+#pragma unroll
+                        for (int r = 0; r < EPR; ++r) {
+                            const int row = 48 * u + ti + 4 * r;
+                            const double dv = wrap ? D[r][(kc + 1) & 7] : D[r][kc];
+                            if (row < EPB) colb[b ^ 1][row] = fma(cr[r], cv, dv);
+                        }
+                    }
+                    if (di_ < EPB) { diagb[b ^ 1][di_] = fma(ncj * cI, cI, dI); mub[b ^ 1][di_] = fma(qj, cI, mI); }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(&seqP, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                double sc[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sc[c] = ncj * cc[c];
+#pragma unroll
+                for (int r = 0; r < EPR; ++r)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) D[r][c] = fma(cr[r], sc[c], D[r][c]);
+            }
+        }
+    }
+    __syncthreads();
+    if (stamps && t == 0) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[4] = stamps[1] + spinC; }
+    if (stamps && t == 64) { stamps[5] = spinP; stamps[6] = spinQ; }
+    if (t < nb) { ttau[i0 + t] = s_tn[t]; tnu[i0 + t] = s_nn[t]; }
+    // W(i, j) = dT_i [i == j] - dT_i dT_j Sigma_BB,new(i, j) ;  g = h - dT o (Sigma_BB,new h)
+    if (wv > 0) {
+        double hv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const int j = tj + 16 * c; hv[c] = fma(-s_dt[j], s_mu0[j], s_dn[j]); }
+#pragma unroll
+        for (int r = 0; r < EPR; ++r) {
+            const int i = 48 * u + ti + 4 * r;
+            const bool live = i < EPB;
+            const double di = live ? s_dt[i] : 0.0;
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int j = tj + 16 * c;
+                acc = fma(D[r][c], hv[c], acc);
+                if (live) Wout[j + (long)EPB * i] = (i == j ? di : 0.0) - di * s_dt[j] * D[r][c];
+            }
+            acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 8, 64);
+            if (live && tj == 0) gout[i] = fma(-di, acc, fma(-di, s_mu0[i], s_dn[i]));
+        }
+    }
+    __syncthreads();
+    if (stamps && t == 0) stamps[3] = __builtin_amdgcn_s_memtime();
+    pgp_yield_mark(yield_flags, -1);
+}
+
+// prep(b -> b+1): the diagonal tile and the mu entries of the NEXT block, brought up to date in place:
+//   Sigma(B', B') -= X W X',  mu(B') += X g,   X = strip(B', :) = Sigma(B', B) before the block.   Grid (8, 8): 16 x 16 outputs
+// per workgroup, tiles on or below the diagonal (the lower triangle is the one kept current).
+__global__ __launch_bounds__(256) void ep_prep_kernel(double* __restrict__ Sig, long ld, long r0, const double* __restrict__ S,
+                                                      const double* __restrict__ W, const double* __restrict__ g,
+                                                      double* __restrict__ mu) {
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bi < bj) return;
+    __shared__ double Xr[16][EPB + 1], Xc[16][EPB + 1], T[16][EPB + 1];
+    const int t = threadIdx.x;
+    for (int v = t; v < 16 * EPB; v += 256) {
+        const int ii = v & 15, q = v >> 4;
+        Xr[ii][q] = S[r0 + 16 * bi + ii + (long)q * ld];
+        Xc[ii][q] = S[r0 + 16 * bj + ii + (long)q * ld];
+    }
+    __syncthreads();
+    {   // T = X_rows W : thread = (column kk, 8 of the 16 rows)
+        const int kk = t & 127, half = t >> 7;
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < EPB; ++q) {
+            const double w = W[kk + (long)EPB * q];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) acc[s2] = fma(Xr[half + 2 * s2][q], w, acc[s2]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) T[half + 2 * s2][kk] = acc[s2];
+    }
+    __syncthreads();
+    {
+        const int ii = t >> 4, jj = t & 15;
+        double acc = 0.0;
+        for (int k = 0; k < EPB; ++k) acc = fma(T[ii][k], Xc[jj][k], acc);
+        const long row = r0 + 16 * bi + ii, cl = r0 + 16 * bj + jj;
+        if (row >= cl) Sig[row + cl * ld] -= acc;
+    }
+    if (bi == bj && t < 16) {
+        double acc = 0.0;
+        for (int k = 0; k < EPB; ++k) acc = fma(Xr[t][k], g[k], acc);
+        mu[r0 + 16 * bi + t] += acc;
+    }
+}
+
+// strip(:, k) = column i0 + k of the symmetric Sigma (kept in its lower triangle), all np rows.  Grid (np / 256, 8).
+__global__ __launch_bounds__(256) void ep_strip_kernel(const double* __restrict__ Sig, long ld, long np, long i0,
+                                                       double* __restrict__ S) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    const int k0 = 16 * blockIdx.y;
+    if (r >= np) return;
+    double v[16];
+    if (r >= i0 + EPB) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = Sig[r + (i0 + k0 + k) * ld];
+    } else if (r < i0) {
+        const double2_t* src = reinterpret_cast<const double2_t*>(Sig + i0 + k0 + r * ld);
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) { const double2_t x = src[k / 2]; v[k] = x[0]; v[k + 1] = x[1]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = sym_at(Sig, ld, r, i0 + k0 + k);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) S[r + (long)(k0 + k) * ld] = v[k];
+}
+
+// mu_r += sum_k S(r, k) g_k for the rows r >= rlo (64 rows per workgroup, the columns split over the 4 waves, fixed order)
+__global__ __launch_bounds__(256) void ep_mu_strip_kernel(const double* __restrict__ S, long ld, long np, long rlo,
+                                                          const double* __restrict__ g, double* __restrict__ mu) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long r = rlo + (long)blockIdx.x * 64 + lane;
+    double acc = 0.0;
+    if (r < np) {
+#pragma unroll 4
+        for (int k = grp * (EPB / 4); k < (grp + 1) * (EPB / 4); ++k) acc = fma(g[k], S[r + (long)k * ld], acc);
+    }
+    part[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && r < np) mu[r] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+
 // F (column-major lower, ldf) = I + s s' o K ; Y (column-major, ld np) = diag(s) K     (K symmetric, ld np)
 __global__ __launch_bounds__(256) void ep_build_kernel(const double* __restrict__ K, long np,
                                                        const double* __restrict__ s, double* __restrict__ F, long ldf,
@@ -513,6 +805,7 @@ struct EpWork {
     double *Kd, *Sig, *Vd, *F, *Wd, *rhs;
     double *ttau_d, *tnu_d, *mu_d, *m_d, *s_d, *sbuf, *coef, *diag_d, *tmp_d;
     double *S, *Sc, *cq, *prev;          // blocked sweep: factor columns, scaled copy, (c, q) vectors, (ttau, tnu) snapshot
+    double *Wb, *gb;                     // block sweep: W and g of the last two blocks
     long* base;                          // first site of the current block (device scalar read by the captured launches)
     long* bases;                         // bases[b] = b * EPB: the launches of block b read their offset from here
 };
@@ -636,6 +929,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     if (!covhyp) return -3;
     if (!ttau_io || !tnu_io) return -12;
     HIP_TRY(hipSetDevice(c->device));
+    FitScope in_flight(c);
     hipStream_t st = c->st;
     const long n = c->n, d = c->d, np = c->np, ldf = c->ldf;
     CovSpec cp;
@@ -686,6 +980,8 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     EP_TRY(dalloc(&w.Sc, (size_t)EPB * np * sizeof(double)));
     EP_TRY(dalloc(&w.cq, (size_t)2 * EPB * sizeof(double)));
     EP_TRY(dalloc(&w.prev, (size_t)2 * np * sizeof(double)));
+    EP_TRY(dalloc(&w.Wb, (size_t)2 * EPB * EPB * sizeof(double)));
+    EP_TRY(dalloc(&w.gb, (size_t)(2 * EPB + 16) * sizeof(double)));
     { double* b8 = nullptr; EP_TRY(dalloc(&b8, 64)); w.base = (long*)b8; }
     {
         double* bb = nullptr;
@@ -750,7 +1046,79 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     while ((fabs(nlZ - nlZ_old) > tol && sweep < max_sweep) || sweep < min_sweep) {
         nlZ_old = nlZ;
         ++sweep;
-        if (c->ep_block) {
+        if (c->ep_block == 2) {
+            // block sweep: chain stream (the high-priority panel stream) = prep(b) -> chain(b); bulk stream (main) = strip(b),
+            // U(b), fold(b), mu(b).  Events: S[b] strip(b) done, C[b] chain(b) done, P[b] prep(b) done.
+            const long nbl = (n + EPB - 1) / EPB;
+            hipStream_t sa = c->st2 ? c->st2 : st, sb = st;
+            while ((long)c->ep_ev.size() < 3 * nbl + 1) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                c->ep_ev.push_back(e);
+            }
+            auto evS = [&](long b) { return c->ep_ev[3 * b]; };
+            auto evC = [&](long b) { return c->ep_ev[3 * b + 1]; };
+            auto evP = [&](long b) { return c->ep_ev[3 * b + 2]; };
+            unsigned* yfl = (c->yield && c->yield_flags) ? c->yield_flags : nullptr;
+            HIP_TRY(hipEventRecord(c->ep_ev[3 * nbl], st));
+            if (sa != st) HIP_TRY(hipStreamWaitEvent(sa, c->ep_ev[3 * nbl], 0));
+            for (long b = 0; b < nbl; ++b) {
+                const long i0 = b * EPB;
+                const int nb = (int)std::min<long>(EPB, n - i0);
+                double* Wb = w.Wb + (b & 1) * EPB * EPB;
+                double* gb = w.gb + (b & 1) * EPB;
+                if (b > 0) {
+                    const double* Wp = w.Wb + ((b - 1) & 1) * EPB * EPB;
+                    const double* gp = w.gb + ((b - 1) & 1) * EPB;
+                    HIP_TRY(hipStreamWaitEvent(sa, evS(b - 1), 0));
+                    hipLaunchKernelGGL(ep_prep_kernel, dim3(8, 8), dim3(256), 0, sa, w.Sig, np, i0, w.S, Wp, gp, w.mu_d);
+                    HIP_TRY(hipEventRecord(evP(b), sa));
+                }
+                hipLaunchKernelGGL(ep_chain_kernel, dim3(1), dim3(256), 0, sa, w.Sig, np, i0, nb, w.mu_d, w.m_d, c->y_dev, w.ttau_d,
+                                   w.tnu_d, Wb, gb, yfl, ep_timing && b == 5 ? (long long*)(w.gb + 2 * EPB) : (long long*)nullptr);
+                HIP_TRY(hipEventRecord(evC(b), sa));
+                if (b + 1 >= nbl) break;               // nothing of this sweep reads what the last block does to the rest
+                if (b > 0) HIP_TRY(hipStreamWaitEvent(sb, evP(b), 0));
+                hipLaunchKernelGGL(ep_strip_kernel, dim3((unsigned)((np + 255) / 256), 8), dim3(256), 0, sb, w.Sig, np, np, i0, w.S);
+                HIP_TRY(hipEventRecord(evS(b), sb));
+                HIP_TRY(hipStreamWaitEvent(sb, evC(b), 0));
+                const long r0 = i0 + EPB;               // rows of the sites still to come
+                {
+                    GemmArgs g{};                       // U = strip W on the rows >= r0
+                    g.A = w.S + r0; g.lda = np; g.a_kc = 0; g.B = Wb; g.ldb = EPB; g.b_kc = 0;
+                    g.C = w.Sc + r0; g.ldc = np; g.M = (int)(np - r0); g.N = EPB; g.K = EPB;
+                    g.alpha = 1.0; g.beta = 0.0; g.tile = 64; g.flops = 2.0 * (double)(np - r0) * EPB * EPB;
+                    EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
+                }
+                {
+                    GemmArgs g{};                       // the next block's rows left of its diagonal tile (prep owns that tile)
+                    g.A = w.Sc + r0; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
+                    g.C = w.Sig + r0; g.ldc = np; g.M = EPB; g.N = (int)r0; g.K = EPB;
+                    g.alpha = -1.0; g.beta = 1.0; g.tile = 64; g.flops = 2.0 * (double)EPB * r0 * EPB;
+                    EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
+                }
+                const long r1 = r0 + EPB;
+                if (r1 < np) {
+                    GemmArgs g{};                       // rows >= r1: lower trapezoid
+                    g.A = w.Sc + r1; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
+                    g.C = w.Sig + r1; g.ldc = np; g.M = (int)(np - r1); g.N = (int)np; g.K = EPB;
+                    g.alpha = -1.0; g.beta = 1.0; g.tile = 128; g.tri = 1; g.tri_off = (int)r1;
+                    g.flops = (double)EPB * ((double)np * np - (double)r1 * r1);
+                    EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
+                    hipLaunchKernelGGL(ep_mu_strip_kernel, dim3((unsigned)((np - r1 + 63) / 64)), dim3(256), 0, sb, w.S, np, np, r1, gb,
+                                       w.mu_d);
+                }
+            }
+            if (sa != st) HIP_TRY(hipStreamWaitEvent(st, evC(nbl - 1), 0));
+            if (hipGetLastError() != hipSuccess) return PGP_ERR_HIP;
+            if (ep_timing) {
+                long long sp[8];
+                HIP_TRY(hipMemcpyAsync(sp, w.gb + 2 * EPB, sizeof(sp), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                fprintf(stderr, "[ep] chain(5) stamps (10 ns ticks): load %lld  loop %lld (first half %lld)  epilogue %lld\n", sp[1] - sp[0], sp[2] - sp[1], sp[4] - sp[1], sp[3] - sp[2]);
+                fprintf(stderr, "[ep]   spins: chain waiting for the update waves %lld, update wave 1 waiting for its peers %lld, for the chain %lld\n", sp[4] - sp[1], sp[5], sp[6]);
+            }
+        } else if (c->ep_block) {
             // blocked sweep: site i reads the (ttau, tnu) it had at the start of the sweep (each site is visited once)
             HIP_TRY(hipMemcpyAsync(w.prev, w.ttau_d, np * sizeof(double), hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.prev + np, w.tnu_d, np * sizeof(double), hipMemcpyDeviceToDevice, st));

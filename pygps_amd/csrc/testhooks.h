@@ -18,6 +18,7 @@ int pgp_test_valu_peak(pgp_ctx* ctx, int iters, int waves_per_simd, double* out2
 int pgp_test_mfma_peak(pgp_ctx* ctx, int iters, double* tflops_out);
 int pgp_test_mfma_cycles(pgp_ctx* ctx, int iters, int nacc, int waves_per_simd, double* out3);
 int pgp_test_leaf_ticks(pgp_ctx* ctx, double* ticks_out /* 24 */);
+int pgp_test_wave_costs(pgp_ctx* ctx, double* out16);
 int pgp_test_slot_probe(pgp_ctx* ctx, int nwg, int lds_kb, int hold_us, int reserve, int probe_lds_kb, int delay_us, double* out4);
 int pgp_test_cumask_gemm(pgp_ctx* ctx, int M, int K, int reserve_per_xcd, int stride, int iters, double* out2);
 int pgp_test_assemble(pgp_ctx* ctx, int kind, int mode, int64_t n, int64_t d, int iters, double* ms_out);

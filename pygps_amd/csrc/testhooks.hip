@@ -175,6 +175,102 @@ int pgp_test_leaf_ticks(pgp_ctx* c, double* ticks_out) {
     return PGP_OK;
 }
 
+// What single instructions cost ONE workgroup of 4 waves on an otherwise idle chip (the situation of the latency-bound chain
+// kernels): s_memtime ticks per step of (0) a dependent v_fma_f64 chain, (2) eight independent chains, (3) a dependent LDS
+// read chain, (4) 20 independent LDS reads + one use, (5) s_barrier, (6) LDS write -> barrier -> read, (7) a dependent
+// v_rcp_f64 chain, (8) dependent v_rsq_f64; out[1] = s_memrealtime (100 MHz) ticks of test 0, i.e. the s_memtime rate.
+namespace {
+__global__ __launch_bounds__(256) void wave_costs_kernel(double* __restrict__ out, double seed) {
+    __shared__ double lds[512];
+    __shared__ int nxt[256];
+    const int t = threadIdx.x;
+    lds[t] = seed + t; lds[t + 256] = seed - t; nxt[t] = (t * 7 + 1) & 255;
+    __syncthreads();
+    long long a, b, ra, rb;
+    double x = seed, acc = 0.0;
+    a = __builtin_amdgcn_s_memtime(); ra = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 16
+    for (int i = 0; i < 2048; ++i) x = fma(x, 0.999999, 1e-9);
+    acc += x;
+    asm volatile("" :: "v"(x));
+    b = __builtin_amdgcn_s_memtime(); rb = __builtin_amdgcn_s_memrealtime();
+    if (t == 0) { out[0] = (double)(b - a) / 2048.0; out[1] = (double)(rb - ra); out[9] = (double)(b - a); }
+    double y[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y[q] = seed + q;
+    a = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 256; ++i) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) y[q] = fma(y[q], 0.999999, 1e-9);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc += y[q];
+    asm volatile("" :: "v"(acc));
+    b = __builtin_amdgcn_s_memtime();
+    if (t == 0) out[2] = (double)(b - a) / 2048.0;
+    int idx = t;
+    a = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 512; ++i) idx = nxt[idx];
+    asm volatile("" :: "v"(idx));
+    b = __builtin_amdgcn_s_memtime();
+    if (t == 0) out[3] = (double)(b - a) / 512.0;
+    acc += idx;
+    a = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 512; ++i) {
+        double sum = 0.0;
+        const int o = (i & 1) * 256;
+#pragma unroll
+        for (int q = 0; q < 20; ++q) sum += lds[o + ((t >> 4) + 16 * q) % 256];
+        acc = fma(sum, 1e-9, acc);
+        asm volatile("" :: "v"(acc));
+    }
+    b = __builtin_amdgcn_s_memtime();
+    if (t == 0) out[4] = (double)(b - a) / 512.0;
+    a = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 512; ++i) __syncthreads();
+    b = __builtin_amdgcn_s_memtime();
+    if (t == 0) out[5] = (double)(b - a) / 512.0;
+    a = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 512; ++i) {
+        if ((t & 15) == (i & 15)) lds[(i & 1) * 256 + (t >> 4)] = acc + i;
+        __syncthreads();
+        acc += lds[(i & 1) * 256 + (i & 15)];
+        asm volatile("" :: "v"(acc));
+    }
+    b = __builtin_amdgcn_s_memtime();
+    if (t == 0) out[6] = (double)(b - a) / 512.0;
+    x = seed + 2.0;
+    a = __builtin_amdgcn_s_memtime();
+#pragma unroll 16
+    for (int i = 0; i < 512; ++i) x = __builtin_amdgcn_rcp(x) + 1.5;
+    asm volatile("" :: "v"(x));
+    b = __builtin_amdgcn_s_memtime();
+    if (t == 0) out[7] = (double)(b - a) / 512.0;
+    acc += x;
+    x = seed + 2.0;
+    a = __builtin_amdgcn_s_memtime();
+#pragma unroll 16
+    for (int i = 0; i < 512; ++i) x = __builtin_amdgcn_rsq(x) + 1.5;
+    asm volatile("" :: "v"(x));
+    b = __builtin_amdgcn_s_memtime();
+    if (t == 0) out[8] = (double)(b - a) / 512.0;
+    acc += x;
+    if (acc == 12345.678 && t == 0) out[15] = acc;
+}
+}  // namespace
+int pgp_test_wave_costs(pgp_ctx* c, double* out16) {
+    if (!c || !out16) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    double* od;
+    HIP_TRY(hipMalloc((void**)&od, 16 * 8));
+    HIP_TRY(hipMemset(od, 0, 16 * 8));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(wave_costs_kernel, dim3(1), dim3(256), 0, c->st, od, 1.0 + 1e-3 * rep);
+    HIP_TRY(hipStreamSynchronize(c->st));
+    HIP_TRY(hipMemcpy(out16, od, 16 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(od);
+    return PGP_OK;
+}
+
 // device-only timing of the kernel-assembly tile kernel on synthetic resident coordinates:
 // mode 0 = full symmetric (n,n) output ('train'), 2 = fused lower-triangle B = K/sn2 + I.  ms_out = avg per launch.
 int pgp_test_assemble(pgp_ctx* c, int kind, int mode, int64_t n, int64_t d, int iters, double* ms_out) {

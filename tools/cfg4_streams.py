@@ -7,7 +7,9 @@ import bench
 import pygps_amd as pyGPs
 from pygps_amd import opt
 x, y = bench.synth_reg(8192, 16)
-for S in [int(a) for a in sys.argv[1:]] or [2, 4]:
+from pygps_amd import _lib
+OPTS = [a.split("=") for a in sys.argv[1:] if "=" in a]
+for S in [int(a) for a in sys.argv[1:] if "=" not in a] or [2, 4]:
     opt.ShardedMinimize.streams_per_gpu = S
     m = pyGPs.GPR()
     m.setPrior(kernel=pyGPs.cov.RBF(np.log(4.0), 0.0)); m.setNoise(np.log(0.1))
@@ -20,6 +22,9 @@ for S in [int(a) for a in sys.argv[1:]] or [2, 4]:
         return orig(self_, *a, **k)
     pyGPs.inf.Exact.evaluate = counted
     np.random.seed(7); m.optimize(x, y, numIterations=2)
+    for h in list(_lib._ctx.values()):
+        for k_, v_ in OPTS:
+            _lib.check(_lib.load().pgp_set_option(h, k_.encode(), int(v_)))
     for rep in range(2):
         calls[0] = 0
         np.random.seed(7)
