@@ -157,7 +157,7 @@ def extras(lib, _lib, local, d, roof):
             ts = None
             if tb and lib.pgp_set_option(hb, b"eet_overlap", 0) == 0:
                 ts = run_fits(2, 3)                                # E E^T as one product after the sweep: the sweep-alone figure
-                lib.pgp_set_option(hb, b"eet_overlap", 4)
+                lib.pgp_set_option(hb, b"eet_overlap", 3)
             if tb and ts:
                 pm = min(t["potrf"] for t in ts)
                 ft = min(t["total"] for t in tb[1:])
@@ -477,7 +477,7 @@ def main():
         for o in args.option:
             k_, v_ = o.split("=")
             _lib.check(lib.pgp_set_option(h, k_.encode(), int(v_)), "pgp_set_option")
-    eet_default = int(dict(o.split("=") for o in args.option).get("eet_overlap", 4))
+    eet_default = int(dict(o.split("=") for o in args.option).get("eet_overlap", 3))
     bufs = [(np.empty(N), np.zeros(1), np.zeros(4)) for _ in range(S)]
 
     def fit(step, k=0):
@@ -525,8 +525,6 @@ def main():
         windows.append(wt)
     dt = float(np.median(windows))
     # single-stream latency of one fit in a dependent chain (what cfg 4's one-restart-per-GPU minimize.run sees)
-    for s in range(3):                                # untimed: the library sees ONE fit stream again (eet_overlap 4 looks back 20 ms)
-        fit(args.warmup + s)
     t1 = time.perf_counter()
     lat_stage = []
     for s in range(6):
@@ -549,16 +547,18 @@ def main():
         assert np.all(np.isfinite(vals_all)) and vals_all.shape == (world, args.steps)
     stages = {k: float(np.median([t[k] for t in lat_stage])) for k in lat_stage[0]}
 
+    # the extra fit-stream contexts of the timed region are done: give their HIP streams back before the extras create
+    # their own (beyond four streams of one priority the runtime maps streams onto SHARED hardware queues, and two fit
+    # streams that land on one queue serialise: cfg 4 below measured 92 instead of 105 fits/s with them alive)
+    for h in ctxs[1:]:
+        lib.pgp_destroy(h)
+    ctxs = ctxs[:1]
     # ---- roofline of the dominant kernel: single-stream profiled pass over the same steps (HIP events per launch,
     #      recorded on the library's own stream) -------------------------------------------------------------------
     roof = None
     classes = {}
     extra = {}
     if rank == 0:
-        # per-launch durations only mean something while the bulk launches do not share the chip with each other: the profiled
-        # pass pins the schedule of the timed two-stream region (E E^T products behind the trailing updates on the main stream,
-        # eet_overlap 3) -- alone on the device the default (4) would move them to a filler stream, beside the updates
-        lib.pgp_set_option(ctx, b"eet_overlap", 3)
         lib.pgp_profile_reset(ctx)
         lib.pgp_set_profiling(ctx, 1)
         prof_stage = []
@@ -566,7 +566,6 @@ def main():
             fit(args.warmup + s)
             prof_stage.append(_lib.last_timings(local))
         lib.pgp_set_profiling(ctx, 0)
-        lib.pgp_set_option(ctx, b"eet_overlap", eet_default)
         prof = _lib.profile(local)
         nfit = float(args.prof_steps)
         gl = gm = gf = 0.0
@@ -611,8 +610,7 @@ def main():
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_MFMA_TF, "traffic": traffic, "traffic_source": tsrc,
                 "how": "algorithmic flops of this instantiation's launches (N^3 per fit minus what the other gemm_f64 "
-                       "instantiations execute) / summed HIP-event durations of its launches, %d single-stream fits with the E E^T products behind the trailing updates "
-                              "(option eet_overlap=3, the schedule of the timed two-stream region: no two bulk launches overlap)" % args.prof_steps,
+                       "instantiations execute) / summed HIP-event durations of its launches, %d single-stream fits" % args.prof_steps,
                 "launches_per_fit": dom_l / nfit, "flops_per_launch": alg_dom / max(dom_l, 1), "avg_launch_ms": dom_ms / max(dom_l, 1),
                 "algorithmic_flops_per_fit": alg_dom / nfit,
                 "all_gemm_f64_instantiations": {

@@ -3,7 +3,6 @@
 // triangular inverse, W^T W, fused gradient reduce.  See DESIGN.md for the pipeline.
 #include <algorithm>
 #include <atomic>
-#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -16,28 +15,6 @@
 #include "ctx.h"
 
 // ------------------------------------------------------------------------------------------------
-// ---- fit streams in flight per device (eet_overlap 4) ----------------------------------------------------------------------
-namespace {
-struct DeviceLoad { std::atomic<int> active{0}; std::atomic<long long> shared_ns{0}; };
-DeviceLoad g_load[64];
-long long now_ns() {
-    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-}  // namespace
-FitScope::FitScope(pgp_ctx* ctx) : c(ctx) {
-    DeviceLoad& L = g_load[c->device & 63];
-    const long long t = now_ns();
-    if (L.active.fetch_add(1) > 0) L.shared_ns.store(t);
-    c->solo = t - L.shared_ns.load() > 20000000LL;          // nobody else for 20 ms: gaps between the fits of a host thread are shorter
-    static const bool dbg = getenv("PGP_DEBUG_SOLO") != nullptr;
-    if (dbg) fprintf(stderr, "[solo] ctx %p t %.3f ms active-before %d since-shared %.3f ms solo %d\n", (void*)c, (t % 100000000000LL) * 1e-6,
-                     L.active.load() - 1, (t - L.shared_ns.load()) * 1e-6, (int)c->solo);
-}
-FitScope::~FitScope() {
-    DeviceLoad& L = g_load[c->device & 63];
-    if (L.active.fetch_sub(1) > 1) L.shared_ns.store(now_ns());
-}
-
 static thread_local char g_err[512] = "";
 void pgp_set_last_hip_error(hipError_t e, const char* what, const char* file, int line) {
     snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
@@ -154,7 +131,6 @@ void pgp_destroy(pgp_ctx* c) {
     // every stream of the context may still carry work of the last call (the panel stream runs the last E E^T product)
     (void)hipStreamSynchronize(c->st);
     if (c->st2) (void)hipStreamSynchronize(c->st2);
-    if (c->st3) { (void)hipStreamSynchronize(c->st3); (void)hipStreamDestroy(c->st3); }
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     for (auto& kv : c->spool) (void)hipFree(kv.second);
     for (auto& kv : c->orders) (void)hipFree(kv.second.first);
@@ -198,6 +174,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "ep_r_direct")) { c->ep_r_direct = value; return PGP_OK; }
     if (!strcmp(name, "ep_alpha_direct")) { c->ep_alpha_direct = value; return PGP_OK; }
     if (!strcmp(name, "ep_sym")) { c->ep_sym = value; return PGP_OK; }
+    if (!strcmp(name, "ep_sigma_under")) { c->ep_sigma_under = value; return PGP_OK; }
     if (!strcmp(name, "ep_block")) { c->ep_block = value; return PGP_OK; }
     if (!strcmp(name, "xcd_max_k")) { c->xcd_max_k = value; return PGP_OK; }
     if (!strcmp(name, "xcd_min_tiles")) { c->xcd_min_tiles = value; return PGP_OK; }
@@ -205,7 +182,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "solve_outer")) { if (value < 1) return -2; c->solve_outer = value; return PGP_OK; }
     if (!strcmp(name, "predict_batch")) { if (value < 128 || value % 128) return -2; c->predict_batch = value; return PGP_OK; }
     if (!strcmp(name, "s_tile")) { if (value != 0 && value != 64 && value != 128) return -2; c->s_tile = value; return PGP_OK; }
-    if (!strcmp(name, "eet_overlap")) { if (value < 0 || value > 4) return -2; c->eet_overlap = value; return PGP_OK; }
+    if (!strcmp(name, "eet_overlap")) { if (value != 0 && value != 2 && value != 3) return -2; c->eet_overlap = value; return PGP_OK; }
     if (!strcmp(name, "eet_max_panels")) { c->eet_max_panels = value; return PGP_OK; }
     if (!strcmp(name, "eet_first")) { if (value < -1) return -2; c->eet_first = value; return PGP_OK; }
     if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
@@ -751,42 +728,25 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // B^-1 = sum_p E_p E_p^T accumulated under the sweep (eet_overlap 2, or 3 up to eet_max_panels panels: beyond that the
     // chain is amortised and the one-shot long-K product is faster): panel p's share right behind TU_b(p) on the main
     // stream -- the main stream stays busy until D(p+1) is done instead of waiting for it
-    const bool fill_any = la && m.E && !m.dense2 && c->eet_out &&
-                          (c->eet_overlap == 1 || c->eet_overlap == 2 || (c->eet_overlap >= 3 && npanel <= c->eet_max_panels));
-    // eet_overlap 1 (4: while no other fit stream works on the device): the products go to a third stream as soon
-    // as S(p) has produced their columns: they fill the partial last waves of the main stream's launches and the half-empty
-    // S / TU_a launches (-1.7 % for a single chain at N = 8192; -17 % when a second fit stream already fills those holes)
-    hipStream_t fill = nullptr;
-    if (fill_any && (c->eet_overlap == 1 || (c->eet_overlap == 4 && c->solo))) {
-        // default priority on purpose: a stream of the LOWEST priority costs two concurrent fit streams 11 % by merely
-        // existing (106 -> 95 fits/s with the stream created and never used; measured, round 3)
-        if (!c->st3) HIP_TRY(hipStreamCreateWithFlags(&c->st3, hipStreamNonBlocking));
-        fill = c->st3;
-        while ((int)c->fill_ev.size() < npanel + 3) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->fill_ev.push_back(e);
-        }
-    }
-    else if (c->st3 && fill_any) {
-        // a context that shares the device gives its filler stream back: beyond four streams of one priority the runtime maps
-        // streams onto shared hardware queues, and two fit streams that land on one queue serialise (measured inside
-        // bench.py: cfg 4 on two fit streams 104 -> 92 fits/s with the idle third stream of one context still alive)
-        (void)hipStreamSynchronize(c->st3);
-        (void)hipStreamDestroy(c->st3);
-        c->st3 = nullptr;
-    }
-    const bool fill_inline = fill_any && !fill;
-    const int pf0 = std::min(c->eet_first >= 0 ? c->eet_first : npanel / 6, npanel - 2);
+    const bool fill_inline = la && m.E && !m.dense2 && c->eet_out &&
+                             (c->eet_overlap == 2 || (c->eet_overlap == 3 && npanel <= c->eet_max_panels));
+    // dense right-hand-side rows R (EP: R L^-T = V' = K sW L^-T): the caller's symmetric C -= V' V'^T is accumulated panel by
+    // panel behind TU_b as well -- at N = 4096 the sweep is bound by the chain of diagonal blocks and the main stream would
+    // wait for D(p+1) anyway
+    const bool fill2 = m.dense2 > 0 && c->fill2_C != nullptr;
+    auto rhs_product = [&](int s0, int s1) -> int {
+        GemmArgs g{};
+        g.A = m.E + (long)s0 * 128 * m.lde; g.lda = m.lde; g.a_kc = 0;
+        g.B = g.A; g.ldb = m.lde; g.b_kc = 0;
+        g.C = c->fill2_C; g.ldc = c->fill2_ld; g.M = (int)m.dense2; g.N = (int)m.dense2; g.K = (s1 - s0) * 128;
+        g.alpha = -1.0; g.beta = 1.0; g.tile = 128; g.tri = 2; g.mask_diag = 1;
+        g.flops = (double)m.dense2 * m.dense2 * g.K;
+        return gemm_prof(c, PC_GEMM_INNER, g, main);
+    };
     for (int p = 0; p < npanel; ++p) {
         const int s0 = p * q, s1 = std::min(s0 + q, nblk);
         CHK(solve_below(c, m, s0, s1, Xs, ldx, main));
-        if (fill && (p >= pf0 || s1 >= nblk)) {                       // E's columns of panels <= p are final
-            HIP_TRY(hipEventRecord(c->fill_ev[2 + p], main));
-            HIP_TRY(hipStreamWaitEvent(fill, c->fill_ev[2 + p], 0));
-            CHK(eet_panel(c, m, p == pf0 ? 0 : s0, s1, c->eet_out, c->eet_ld, fill));
-            if (s1 >= nblk) { HIP_TRY(hipEventRecord(c->fill_ev[1], fill)); c->eet_join = c->fill_ev[1]; }
-        }
+        if (fill2 && s1 >= nblk) CHK(rhs_product(s0, s1));
         if (s1 >= nblk) break;
         const int n0 = s1, n1 = std::min(s1 + q, nblk);              // next panel's columns
         CHK(trailing_update2(c, m, s0, s1, n0, n1, Xs, ldx, main));   // TU_a -> staging
@@ -805,6 +765,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         // themselves: panels 0 .. eet_first go into ONE product (k = (eet_first + 1) w) behind TU_b(eet_first)
         const int pf = std::min(c->eet_first >= 0 ? c->eet_first : npanel / 6, npanel - 2);
         if (fill_inline && p >= pf) CHK(eet_panel(c, m, p == pf ? 0 : s0, s1, c->eet_out, c->eet_ld, main));
+        if (fill2) CHK(rhs_product(s0, s1));
         if (la) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
     }
     if (fill_inline) {
@@ -1051,7 +1012,6 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     if (want < 1 || want > 3) return -11;
     if (ncov < 0 || 8 + ncov + 1 > RES_INFO) return -4;
     HIP_TRY(hipSetDevice(c->device));
-    FitScope in_flight(c);
     const long n = c->n, d = c->d, np = c->np;
     const bool fused = want >= 3 && c->fused_inverse;
     const long ldf = c->ldf;                         // factor buffer = factor rows + rhs rows; the inverse rows are scratch

@@ -21,15 +21,6 @@ static const char* const kProfNames[PC_COUNT] = {
 
 struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; int shadow; };
 
-struct pgp_ctx;
-// One fit in flight on a device (RAII around the public fit entry points): whether the context is the only fit stream there
-// decides where the E E^T products go (eet_overlap 4).  Defined in capi.hip.
-struct FitScope {
-    pgp_ctx* c;
-    explicit FitScope(pgp_ctx* ctx);
-    ~FitScope();
-};
-
 struct pgp_factor {
     long n, np, ldf;
     double* F;            // (ldf x np) column-major lower factor == row-major upper R (+ augmented rows)
@@ -49,18 +40,17 @@ struct pgp_ctx {
     std::vector<int> composite;         // postfix program of kind PGP_COV_COMPOSITE (pgp_set_composite)
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky (high priority)
-    hipStream_t st3 = nullptr;          // filler stream (eet_overlap 1), created on first use
     std::vector<hipEvent_t> fill_ev;
     std::vector<hipEvent_t> ep_ev;      // EP block sweep: strip / chain / prep events per block
     double* eet_out = nullptr;          // set by the fit for the duration of one sweep: where the filler accumulates B^-1
     long eet_ld = 0;
+    double* fill2_C = nullptr;          // potrf_blocked_rhs: symmetric matrix (lower tiles) that receives -= V' V'^T panel by panel, or null
+    long fill2_ld = 0;
     hipEvent_t eet_join = nullptr;      // non-null: the sweep queued every panel product; the fit joins on this event
     int eet_tile = 128;                 // tile size of the filler products (64: shorter workgroups in the way of the chain)
     int eet_first = -1;                 // inline filler: panels 0 .. eet_first are folded into one product (-1: a sixth of the panels)
-    int eet_overlap = 4;                // B^-1 = sum_p E_p E_p^T accumulated under the sweep: 0 off (one product after it), 2 behind
-                                        // every TU_b on the main stream, 3 the same when npanel <= eet_max_panels, 1 on a third
-                                        // stream, 4 (default) = 1 while this is the only fit stream on the device, else 3
-    bool solo = false;                  // set by FitScope: no other fit has been in flight on this device for 20 ms
+    int eet_overlap = 3;                // B^-1 = sum_p E_p E_p^T accumulated under the sweep: 0 off (one product after it), 2 behind
+                                        // every TU_b on the main stream, 3 the same when npanel <= eet_max_panels
     int eet_max_panels = 32;
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     int lookahead = 1;
@@ -76,6 +66,7 @@ struct pgp_ctx {
                                         // L^-T as one product), 2 K diag(sW) as dense right-hand-side rows of the sweep
     int ep_r_direct = 1;                // EP gradient: sW sW' o B^-1 = S - S Sigma S from the rebuilt Sigma; 0 = triangular inverse + W'W
     int ep_alpha_direct = 1;            // EP: alpha = tnu - ttau o mu (identity, no solve); 0 = the reference's two triangular solves
+    int ep_sigma_under = 1;             // EP: Sigma = K - V'V'^T accumulated under the sweep of the parameter recomputation (ep_fused 2)
     int ep_sym = 1;                     // EP: Sigma kept current in its lower triangle only (folds and K - V'V on the lower tiles)
     int ep_block = 2;                   // EP site sweep: 2 = one chain launch per 128 sites + Woodbury fold beside the next chain, 1 = 16 sites per
                                         // launch with lazy rank-1 factors (rounds 1-2), 0 = update Sigma per site

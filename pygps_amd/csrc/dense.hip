@@ -80,7 +80,6 @@ int pgp_exact_fit_dense(pgp_ctx* c, const double* K, int64_t n, const double* r,
     if (!r) return -4;
     if (want < 1 || want > 3) return -6;
     HIP_TRY(hipSetDevice(c->device));
-    FitScope in_flight(c);
     const long np = round_up(n, 128), ldf = np + 128;
     const bool fused = want >= 3;
     CHK(ensure_workspace(c, np));

@@ -16,6 +16,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "ctx.h"
@@ -23,6 +25,8 @@
 #include "erfcx_poly.h"
 
 namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -514,8 +518,12 @@ __global__ __launch_bounds__(256) void ep_fold_prep_kernel(const double* __restr
 // term to them itself.  The update waves run one site behind: they wait for (c_k, q_k), pass column k+1 / diagonal / mu on
 // (double-buffered by the parity of k), then do their share of the rank-1 update while wave 0 is already inside site k+1.
 // Hand-over through LDS sequence counters, no workgroup barrier inside the loop.
-constexpr int EPR = 12;                          // row slots of an update lane: rows 48 u + ti + 4 r (rows >= 128 are padding)
 constexpr int EPCP = 144;
+template <int V> using IntC = std::integral_constant<int, V>;
+template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(IntC<Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 __device__ __forceinline__ int lds_seq(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict__ Sig, long ld, long i0, int nb,
@@ -524,16 +532,16 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
                                                         double* __restrict__ tnu, double* __restrict__ Wout,
                                                         double* __restrict__ gout, unsigned* yield_flags,
                                                         long long* __restrict__ stamps) {
-    __shared__ __attribute__((aligned(16))) double colb[2][EPCP];     // column k of Sigma_BB before site k, by parity of k
+    __shared__ __attribute__((aligned(16))) double colb[8][EPCP];     // column k of Sigma_BB before site k: ring over k mod 8
     __shared__ double diagb[2][EPB], mub[2][EPB];                     // diagonal and mu before site k, by parity of k
-    __shared__ __attribute__((aligned(16))) double cq[2][2];          // (c_k, q_k)
+    __shared__ __attribute__((aligned(16))) double cq[8][2];          // (c_k, q_k): ring over k mod 8
     __shared__ __attribute__((aligned(32))) double prm[EPB][4];       // the sites' (ttau, tnu) of the previous sweep, m, y
     __shared__ double s_mu0[EPB], s_dt[EPB], s_dn[EPB], s_tn[EPB], s_nn[EPB];
     __shared__ int seqC, seqP;                   // sites wave 0 has finished ; 3 x sites the update waves have passed on
     pgp_yield_mark(yield_flags, +1);
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int u = wv - 1, ti = lane >> 4, tj = lane & 15;
+    const int u = wv - 1;
     long long spinC = 0, spinP = 0, spinQ = 0;
     if (stamps && t == 0) stamps[0] = __builtin_amdgcn_s_memtime();
     if (t == 0) { seqC = 0; seqP = 0; }
@@ -544,20 +552,13 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
         s_mu0[t] = mu[i0 + t]; s_dt[t] = 0.0; s_dn[t] = 0.0; s_tn[t] = 0.0; s_nn[t] = 0.0;
         diagb[0][t] = Sig[(i0 + t) + (i0 + t) * ld]; mub[0][t] = mu[i0 + t];
     }
-    if (t < 2 * (EPCP - EPB)) colb[t / (EPCP - EPB)][EPB + t % (EPCP - EPB)] = 0.0;
-    double D[EPR][8];                            // update waves: D[r][c] = Sigma_BB(48 u + ti + 4 r, tj + 16 c)
-    if (wv > 0) {
-#pragma unroll
-        for (int r = 0; r < EPR; ++r) {
-            const int row = 48 * u + ti + 4 * r;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) D[r][c] = row < EPB ? sym_at(Sig, ld, i0 + row, i0 + tj + 16 * c) : 0.0;
-            if (tj == 0 && row < EPB) colb[0][row] = D[r][0];
-        }
-    }
-    __syncthreads();
-    if (stamps && t == 0) stamps[1] = __builtin_amdgcn_s_memtime();
+    if (t < 8 * (EPCP - EPB)) colb[t / (EPCP - EPB)][EPB + t % (EPCP - EPB)] = 0.0;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // (the two roles share nothing but LDS: everything of a role, its barriers included, sits inside its branch, so that the
+    //  96 accumulator registers of the update waves are not live across the chain's code)
     if (wv == 0) {
+        __syncthreads();
+        if (stamps && t == 0) stamps[1] = __builtin_amdgcn_s_memtime();
         // ---- the chain: inf.py:757-770 for the sites of the block, nothing else -------------------------------------------
         double dkk = diagb[0][0], muk = mub[0][0];
         double pc0 = prm[0][0], pc1 = prm[0][1], pc2 = prm[0][2], pc3 = prm[0][3];
@@ -567,133 +568,271 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
             double t_new, nu_new, cj, qj;
             ep_site_update(dkk, muk, pc0, pc1, pc2, pc3, t_new, nu_new, cj, qj);
             if (lane == 0) {
-                cq[k & 1][0] = cj; cq[k & 1][1] = qj;
+                cq[k & 7][0] = cj; cq[k & 7][1] = qj;
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                __hip_atomic_store(&seqC, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // LDS stores of one wave land in order
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
                 s_dt[k] = t_new - pc0; s_dn[k] = nu_new - pc1; s_tn[k] = t_new; s_nn[k] = nu_new;
-                __hip_atomic_store(&seqC, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (k + 1 < nb) {
                 // Sigma(k+1,k), Sigma(k+1,k+1), mu(k+1) before site k: passed on by the update waves during their step k-1
-                while (lds_seq(&seqP) < 3 * k) { __builtin_amdgcn_s_sleep(1); ++spinC; }
-                const double e1 = colb[k & 1][k + 1], d1 = diagb[k & 1][k + 1], m1 = mub[k & 1][k + 1];
+                // (the sequence number and the three values in one round trip, see the update waves)
+                double e1, d1, m1;
+                for (;;) {
+                    const int sp = __hip_atomic_load(&seqP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    e1 = colb[k & 7][k + 1]; d1 = diagb[k & 1][k + 1];
+                    m1 = mub[k & 1][k + 1];
+                    if (sp >= 3 * k) break;
+                    ++spinC;
+                    __builtin_amdgcn_s_sleep(1);
+                }
                 dkk = fma(-cj * e1, e1, d1);
                 muk = fma(qj, e1, m1);
             }
             pc0 = pn0; pc1 = pn1; pc2 = pn2; pc3 = pn3;
         }
+        __syncthreads();
+        if (stamps && t == 0) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[4] = stamps[1] + spinC; }
+        for (int k = lane; k < nb; k += 64) { ttau[i0 + k] = s_tn[k]; tnu[i0 + k] = s_nn[k]; }
+        __syncthreads();
     } else {
-        // ---- the update waves, one site behind ------------------------------------------------------------------------------
-        const int di_ = 64 * u + lane;           // the diagonal / mu entry this lane keeps up to date (< 128: two of the three waves)
+        // update waves: Sigma_BB in the MFMA accumulator layout -- tile (I, J) of wave u: rows 48 u + 16 I + l15, columns
+        // 16 J + l4 + 4 r in component r (rows >= 128 are padding and stay zero)
+        double4_t A[3][8];
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            const int lim = nb - 16 * kc < 16 ? nb - 16 * kc : 16;
-            for (int kr = 0; kr < lim; ++kr) {
-                const int k = 16 * kc + kr, b = k & 1;
-                while (lds_seq(&seqP) < 3 * k) { __builtin_amdgcn_s_sleep(1); ++spinP; }       // column k, diagonal, mu of every update wave are in
-                double cr[EPR], cc[8];
+        for (int I = 0; I < 3; ++I) {
+            const int row = 48 * u + 16 * I + l15;
 #pragma unroll
-                for (int r = 0; r < EPR; ++r) cr[r] = colb[b][48 * u + ti + 4 * r];
+            for (int J = 0; J < 8; ++J)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) cc[c] = colb[b][tj + 16 * c];
-                double dI = 0.0, mI = 0.0, cI = 0.0;
-                if (di_ < EPB) { dI = diagb[b][di_]; mI = mub[b][di_]; cI = colb[b][di_]; }
-                while (lds_seq(&seqC) < k + 1) { __builtin_amdgcn_s_sleep(1); ++spinQ; }       // (c_k, q_k)
-                const double cj = cq[b][0], qj = cq[b][1];
-                const double ncj = -cj;
-                if (k + 1 < EPB) {
-                    const bool wrap = kr == 15;
-                    const int krn = wrap ? 0 : kr + 1;
-                    if (tj == krn) {
-                        const double cv = ncj * (wrap ? cc[(kc + 1) & 7] : cc[kc]);
-#pragma unroll
-                        for (int r = 0; r < EPR; ++r) {
-                            const int row = 48 * u + ti + 4 * r;
-                            const double dv = wrap ? D[r][(kc + 1) & 7] : D[r][kc];
-                            if (row < EPB) colb[b ^ 1][row] = fma(cr[r], cv, dv);
-                        }
-                    }
-                    if (di_ < EPB) { diagb[b ^ 1][di_] = fma(ncj * cI, cI, dI); mub[b ^ 1][di_] = fma(qj, cI, mI); }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_fetch_add(&seqP, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                double sc[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) sc[c] = ncj * cc[c];
-#pragma unroll
-                for (int r = 0; r < EPR; ++r)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) D[r][c] = fma(cr[r], sc[c], D[r][c]);
-            }
+                for (int r = 0; r < 4; ++r) A[I][J][r] = row < EPB ? sym_at(Sig, ld, i0 + row, i0 + 16 * J + l4 + 4 * r) : 0.0;
+            if (l4 == 0 && row < EPB) colb[0][row] = A[I][0][0];
         }
-    }
-    __syncthreads();
-    if (stamps && t == 0) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[4] = stamps[1] + spinC; }
-    if (stamps && t == 64) { stamps[5] = spinP; stamps[6] = spinQ; }
-    if (t < nb) { ttau[i0 + t] = s_tn[t]; tnu[i0 + t] = s_nn[t]; }
-    // W(i, j) = dT_i [i == j] - dT_i dT_j Sigma_BB,new(i, j) ;  g = h - dT o (Sigma_BB,new h)
-    if (wv > 0) {
-        double hv[8];
+        __syncthreads();
+        // ---- the update waves, one site behind ------------------------------------------------------------------------------
+        // Per site the VALU keeps only the tile column(s) current from which the NEXT sites' columns leave (J = k / 16, 12 FMAs;
+        // during the last four sites of a tile column also its successor).  Everything else gets the FOUR rank-1 terms of the
+        // sites 4 g .. 4 g + 3 at once, as one 16 x 16 x 4 MFMA per tile whose k index is the site: lane group l4 feeds column
+        // 4 g + l4 (the last eight columns and (c, q) pairs stay in LDS rings) -- 24 matrix instructions per four sites
+        // instead of 4 x (96 + 8) VALU instructions.  (One MFMA per SITE with the k = 1..3 lanes zeroed was measured first:
+        // 21 x 32 cycles per site on the matrix pipe is slower than the VALU form.)
+        const int di_ = 64 * u + lane;           // the diagonal / mu entry this lane keeps up to date (< 128: two of the three waves)
+        // the tile column(s) the VALU works on live in their own registers (the accumulators sit in AGPRs, where every VALU
+        // access costs two copies): Pa = tile column kc, Pb = its successor during the last four sites of kc
+        double4_t Pa[3], Pb[3];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { const int j = tj + 16 * c; hv[c] = fma(-s_dt[j], s_mu0[j], s_dn[j]); }
+        for (int I = 0; I < 3; ++I) { Pa[I] = A[I][0]; Pb[I] = A[I][0]; }
+        // one site of tile column kc (runtime): the panel Pa is that tile column, Pb its successor (kept current during the
+        // last four sites, WB = true).  The early column k+1 is component (second ? R1 : R0) of Pa in the lanes l4 == bn, or
+        // (from_b) component 0 of Pb in the lanes l4 == 0.  Only R0 / R1 / WB are compile-time: four code bodies, reused by
+        // every tile column (one body per site would be 130 KB of straight-line code).
+        auto u_site = [&](const int k, const int kc, auto R0t, auto R1t, auto WBt, const bool second, const bool from_b, const int bn) {
+            constexpr int r0 = decltype(R0t)::value, r1 = decltype(R1t)::value;
+            constexpr bool wb = decltype(WBt)::value;
+            const int b = k & 1;
+            // ONE LDS round trip per try: both sequence numbers and everything they guard are read in the same batch -- LDS
+            // executes a wave's instructions in order and the writers store their data before they raise the number, so data
+            // read AFTER a number that has arrived has arrived too
+            const double* cb = colb[k & 7];
+            double crow[3], cca[4], ccb[4], dI = 0.0, mI = 0.0, cI = 0.0, cj, qj;
+            for (;;) {
+                const int sp = __hip_atomic_load(&seqP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int sc = __hip_atomic_load(&seqC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
 #pragma unroll
-        for (int r = 0; r < EPR; ++r) {
-            const int i = 48 * u + ti + 4 * r;
+                for (int I = 0; I < 3; ++I) crow[I] = cb[48 * u + 16 * I + l15];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cca[r] = cb[16 * kc + l4 + 4 * r];
+                    ccb[r] = wb ? cb[16 * kc + 16 + l4 + 4 * r] : 0.0;        // (kc = 7: the zero padding of the column)
+                }
+                if (di_ < EPB) { dI = diagb[b][di_]; mI = mub[b][di_]; cI = cb[di_]; }
+                cj = cq[k & 7][0]; qj = cq[k & 7][1];
+                if (sp >= 3 * k && sc >= k + 1) break;
+                if (sp < 3 * k) ++spinP; else ++spinQ;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const double ncj = -cj;
+#pragma unroll
+            for (int I = 0; I < 3; ++I) {
+                const double sr = ncj * crow[I];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Pa[I][r] = fma(sr, cca[r], Pa[I][r]);
+                    if (wb) Pb[I][r] = fma(sr, ccb[r], Pb[I][r]);
+                }
+            }
+            if (k + 1 < EPB) {
+                if (l4 == bn) {
+#pragma unroll
+                    for (int I = 0; I < 3; ++I) {
+                        const int row = 48 * u + 16 * I + l15;
+                        const double nv = (wb && from_b) ? Pb[I][0] : (second ? Pa[I][r1] : Pa[I][r0]);
+                        if (row < EPB) colb[(k + 1) & 7][row] = nv;
+                    }
+                }
+                if (di_ < EPB) { diagb[b ^ 1][di_] = fma(ncj * cI, cI, dI); mub[b ^ 1][di_] = fma(qj, cI, mI); }
+            }
+            // (no wait for the stores: LDS executes this wave's add after them)
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if (lane == 0) __hip_atomic_fetch_add(&seqP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        };
+        // the four sites k0 .. k0+3 as ONE rank-4 update of all 24 tiles (the panels' own tiles too: they are overwritten from
+        // the panels when their tile column is done -- 3 or 6 wasted MFMAs, but no compile-time tile column in this code)
+        auto u_group = [&](const int k0) {
+            const int ks = k0 + l4;
+            const double* cb = colb[ks & 7];
+            const double ncl = ks < nb ? -cq[ks & 7][0] : 0.0;
+            double yop[3];
+#pragma unroll
+            for (int I = 0; I < 3; ++I) yop[I] = ncl * cb[48 * u + 16 * I + l15];
+#pragma unroll
+            for (int J = 0; J < 8; ++J) {
+                const double x = cb[16 * J + l15];
+#pragma unroll
+                for (int I = 0; I < 3; ++I) A[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, yop[I], A[I][J], 0, 0, 0);
+            }
+        };
+#pragma unroll 1
+        for (int kc = 0; kc < 8; ++kc) {
+            if (16 * kc >= nb) break;
+            static_for<4>([&](auto KQt) {
+                // sites 16 kc + 4 kq + kb: column k+1 is component kq (kb < 3) or kq + 1 (kb == 3) of tile column kc, lanes l4 == kb + 1 mod 4
+                constexpr int kq = decltype(KQt)::value, kbn = kq == 3 ? 3 : 4;
+                if constexpr (kq == 3) {          // the successor joins: its accumulators have every group before this one
+                    switch (kc) {
+#define PGP_EP_LOADB(J) case J: { _Pragma("unroll") for (int I = 0; I < 3; ++I) Pb[I] = A[I][J + 1]; } break;
+                        PGP_EP_LOADB(0) PGP_EP_LOADB(1) PGP_EP_LOADB(2) PGP_EP_LOADB(3) PGP_EP_LOADB(4) PGP_EP_LOADB(5) PGP_EP_LOADB(6)
+#undef PGP_EP_LOADB
+                        default: break;
+                    }
+                }
+                if (16 * kc + 4 * kq < nb) {
+#pragma unroll 1
+                    for (int kb = 0; kb < kbn; ++kb) {
+                        const int k = 16 * kc + 4 * kq + kb;
+                        if (k < nb) u_site(k, kc, IntC<kq>{}, IntC<(kq + 1) & 3>{}, std::integral_constant<bool, kq == 3>{}, kb == 3, false, (kb + 1) & 3);
+                    }
+                    if constexpr (kq == 3) {      // site 16 kc + 15: the next column is column 0 of the NEXT tile column
+                        const int k = 16 * kc + 15;
+                        if (k < nb) u_site(k, kc, IntC<0>{}, IntC<0>{}, std::true_type{}, false, true, 0);
+                    }
+                    u_group(16 * kc + 4 * kq);
+                }
+            });
+            // tile column kc goes back to the accumulators (the later groups update it there); its successor becomes the panel
+            switch (kc) {
+#define PGP_EP_STOREA(J) case J: { _Pragma("unroll") for (int I = 0; I < 3; ++I) A[I][J] = Pa[I]; } break;
+                PGP_EP_STOREA(0) PGP_EP_STOREA(1) PGP_EP_STOREA(2) PGP_EP_STOREA(3) PGP_EP_STOREA(4) PGP_EP_STOREA(5) PGP_EP_STOREA(6) PGP_EP_STOREA(7)
+#undef PGP_EP_STOREA
+                default: break;
+            }
+#pragma unroll
+            for (int I = 0; I < 3; ++I) Pa[I] = Pb[I];
+        }
+        __syncthreads();
+        if (stamps && t == 64) { stamps[5] = spinP; stamps[6] = spinQ; }
+        // W(i, j) = dT_i [i == j] - dT_i dT_j Sigma_BB,new(i, j) ;  g = h - dT o (Sigma_BB,new h)
+        // (W is stored as W(row, col) at [row + 128 col]: 16 consecutive rows per lane group; it is symmetric up to rounding)
+#pragma unroll
+        for (int I = 0; I < 3; ++I) {
+            const int i = 48 * u + 16 * I + l15;
             const bool live = i < EPB;
             const double di = live ? s_dt[i] : 0.0;
             double acc = 0.0;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int j = tj + 16 * c;
-                acc = fma(D[r][c], hv[c], acc);
-                if (live) Wout[j + (long)EPB * i] = (i == j ? di : 0.0) - di * s_dt[j] * D[r][c];
-            }
-            acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 8, 64);
-            if (live && tj == 0) gout[i] = fma(-di, acc, fma(-di, s_mu0[i], s_dn[i]));
+            for (int J = 0; J < 8; ++J)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * J + l4 + 4 * r;
+                    const double hj = fma(-s_dt[j], s_mu0[j], s_dn[j]);
+                    acc = fma(A[I][J][r], hj, acc);
+                    if (live) Wout[i + (long)EPB * j] = (i == j ? di : 0.0) - di * s_dt[j] * A[I][J][r];
+                }
+            acc += __shfl_xor(acc, 16, 64); acc += __shfl_xor(acc, 32, 64);
+            if (live && l4 == 0) gout[i] = fma(-di, acc, fma(-di, s_mu0[i], s_dn[i]));
         }
+        __syncthreads();
     }
-    __syncthreads();
     if (stamps && t == 0) stamps[3] = __builtin_amdgcn_s_memtime();
     pgp_yield_mark(yield_flags, -1);
 }
 
 // prep(b -> b+1): the diagonal tile and the mu entries of the NEXT block, brought up to date in place:
-//   Sigma(B', B') -= X W X',  mu(B') += X g,   X = strip(B', :) = Sigma(B', B) before the block.   Grid (8, 8): 16 x 16 outputs
-// per workgroup, tiles on or below the diagonal (the lower triangle is the one kept current).
+//   Sigma(B', B') -= X W X',  mu(B') += X g,   X = strip(B', :) = Sigma(B', B) before the block.   36 workgroups: the 16 x 16
+// output tiles on or below the diagonal (the lower triangle is the one kept current); T = X_rows W (16 x 128, K = 128: each wave
+// two column tiles, W straight from global memory as the MFMA operand), then T X_cols' with K split over the four waves.
+// It sits between two chain launches, on the critical path of the sweep.
 __global__ __launch_bounds__(256) void ep_prep_kernel(double* __restrict__ Sig, long ld, long r0, const double* __restrict__ S,
                                                       const double* __restrict__ W, const double* __restrict__ g,
                                                       double* __restrict__ mu) {
-    const int bi = blockIdx.x, bj = blockIdx.y;
-    if (bi < bj) return;
-    __shared__ double Xr[16][EPB + 1], Xc[16][EPB + 1], T[16][EPB + 1];
-    const int t = threadIdx.x;
-    for (int v = t; v < 16 * EPB; v += 256) {
-        const int ii = v & 15, q = v >> 4;
-        Xr[ii][q] = S[r0 + 16 * bi + ii + (long)q * ld];
-        Xc[ii][q] = S[r0 + 16 * bj + ii + (long)q * ld];
-    }
-    __syncthreads();
-    {   // T = X_rows W : thread = (column kk, 8 of the 16 rows)
-        const int kk = t & 127, half = t >> 7;
-        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int q = 0; q < EPB; ++q) {
-            const double w = W[kk + (long)EPB * q];
+    int bi = 0, rem = blockIdx.x;
+    while (rem > bi) { rem -= bi + 1; ++bi; }
+    const int bj = rem;                                  // bi >= bj
+    __shared__ double Xr[16][EPB + 1], Xc[16][EPB + 1], T[16][EPB + 1], red[4][16][17], gl[EPB];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+    // every global read of the kernel is issued up front (the kernel is a chain of memory round trips otherwise): the 64 W
+    // operands of this lane, its 16 strip entries, the output entry it will update
+    const double* w0 = W + 16 * (2 * wv) + l15 + (long)EPB * l4;              // W(q, kk) at W[kk + 128 q]
+    double wx[EPB / 4][2];
 #pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) acc[s2] = fma(Xr[half + 2 * s2][q], w, acc[s2]);
+    for (int ks = 0; ks < EPB / 4; ++ks) { wx[ks][0] = w0[(long)EPB * 4 * ks]; wx[ks][1] = w0[(long)EPB * 4 * ks + 16]; }
+    double xr[8], xc[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const int e = t + 256 * v, ii = e & 15, q = e >> 4;
+        xr[v] = S[r0 + 16 * bi + ii + (long)q * ld];
+        xc[v] = S[r0 + 16 * bj + ii + (long)q * ld];
+    }
+    const long orow = r0 + 16 * bi + (t >> 4), ocol = r0 + 16 * bj + (t & 15);
+    const double old = Sig[orow + ocol * ld];
+    const double gk = t < EPB ? g[t] : 0.0;
+    double muold = 0.0;
+    if (bi == bj && t < 16) muold = mu[r0 + 16 * bi + t];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const int e = t + 256 * v, ii = e & 15, q = e >> 4;
+        Xr[ii][q] = xr[v]; Xc[ii][q] = xc[v];
+    }
+    if (t < EPB) gl[t] = gk;
+    __syncthreads();
+    {
+        double4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int ks = 0; ks < EPB / 4; ++ks) {
+            const double y = Xr[l15][4 * ks + l4];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx[ks][0], y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx[ks][1], y, acc[1], 0, 0, 0);
         }
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) T[half + 2 * s2][kk] = acc[s2];
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[l15][16 * (2 * wv + q) + l4 + 4 * r] = acc[q][r];
+    }
+    __syncthreads();
+    {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int k = 32 * wv + 4 * ks + l4;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xc[l15][k], T[l15][k], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][l15][l4 + 4 * r] = acc[r];
     }
     __syncthreads();
     {
         const int ii = t >> 4, jj = t & 15;
-        double acc = 0.0;
-        for (int k = 0; k < EPB; ++k) acc = fma(T[ii][k], Xc[jj][k], acc);
-        const long row = r0 + 16 * bi + ii, cl = r0 + 16 * bj + jj;
-        if (row >= cl) Sig[row + cl * ld] -= acc;
+        const double out = ((red[0][ii][jj] + red[1][ii][jj]) + red[2][ii][jj]) + red[3][ii][jj];
+        (void)ii; (void)jj;
+        if (orow >= ocol) Sig[orow + ocol * ld] = old - out;
     }
     if (bi == bj && t < 16) {
         double acc = 0.0;
-        for (int k = 0; k < EPB; ++k) acc = fma(Xr[t][k], g[k], acc);
-        mu[r0 + 16 * bi + t] += acc;
+        for (int k = 0; k < EPB; ++k) acc = fma(Xr[t][k], gl[k], acc);
+        mu[r0 + 16 * bi + t] = muold + acc;
     }
 }
 
@@ -826,6 +965,7 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
     const bool fusedp = c->ep_fused == 1 && w.Ed;
     const bool rhsp = c->ep_fused == 2;             // V' = (K diag(sW)) L^-T as dense right-hand-side ROWS of the sweep itself
+    bool sigma_done = false;
     hipLaunchKernelGGL(ep_build_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Kd, np,
                        w.s_d, w.F, w.ldf, fusedp ? nullptr : w.Vd, rhsp ? 1 : 0);
     // fused path: the sweep also yields E = L^-T, so V' = (K diag(sW)) E is ONE clipped MFMA product (no blocked multi-rhs
@@ -840,7 +980,16 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
         // launches, which at N = 4096 also gives the chain of diagonal blocks enough work to hide behind): no inverse
         // rows (np^3 / 3 less) and no separate product
         CHK(zero_strip_launch(w.F, w.ldf, np, np, 128, st));
-        CHK(potrf_blocked_rhs(c, w.F, w.ldf, np, np + 128, w.Vd, np, np));
+        // Sigma = K - V'V'^T accumulated under the sweep, panel by panel (lower tiles; mirrored below)
+        const bool under = c->ep_sym && c->ep_sigma_under;
+        if (under) {
+            HIP_TRY(hipMemcpyAsync(w.Sig, w.Kd, (size_t)np * np * sizeof(double), hipMemcpyDeviceToDevice, st));
+            c->fill2_C = w.Sig; c->fill2_ld = np;
+        }
+        const int prc = potrf_blocked_rhs(c, w.F, w.ldf, np, np + 128, w.Vd, np, np);
+        c->fill2_C = nullptr;
+        CHK(prc);
+        sigma_done = under;
     }
     else CHK(potrf_blocked(c, w.F, w.ldf, np, np));
     int info = 0;
@@ -861,6 +1010,8 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
         CHK(leaf_inv_launch(w.F, w.ldf, w.Wd, 128, 128L * 128L, (int)(np / 128), st));
         CHK(solve_lower_multi(c, w.F, w.ldf, w.Wd, w.Vd, np, np, (int)np, false));    // V = L^-1 (sW o K)
     }
+    if (sigma_done) hipLaunchKernelGGL(ep_mirror_kernel, dim3((unsigned)(np / 64), (unsigned)(np / 64)), dim3(256), 0, st, w.Sig, np);
+    else {
     HIP_TRY(hipMemcpyAsync(w.Sig, w.Kd, (size_t)np * np * sizeof(double), hipMemcpyDeviceToDevice, st));
     {
         GemmArgs g{};                                                                   // Sigma = K - V'V
@@ -873,6 +1024,7 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
         CHK(gemm_prof(c, PC_GEMM_INNER, g));
         if (c->ep_sym)
             hipLaunchKernelGGL(ep_mirror_kernel, dim3((unsigned)(np / 64), (unsigned)(np / 64)), dim3(256), 0, st, w.Sig, np);
+    }
     }
     CHK(col_dot_full_launch(w.Sig, np, np, np, w.tnu_d, nullptr, w.mu_d, st));           // mu = Sigma tnu
     CHK(gather_strided_launch(w.Sig, np + 1, np, w.diag_d, st));
@@ -929,7 +1081,6 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     if (!covhyp) return -3;
     if (!ttau_io || !tnu_io) return -12;
     HIP_TRY(hipSetDevice(c->device));
-    FitScope in_flight(c);
     hipStream_t st = c->st;
     const long n = c->n, d = c->d, np = c->np, ldf = c->ldf;
     CovSpec cp;
@@ -1071,7 +1222,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                     const double* Wp = w.Wb + ((b - 1) & 1) * EPB * EPB;
                     const double* gp = w.gb + ((b - 1) & 1) * EPB;
                     HIP_TRY(hipStreamWaitEvent(sa, evS(b - 1), 0));
-                    hipLaunchKernelGGL(ep_prep_kernel, dim3(8, 8), dim3(256), 0, sa, w.Sig, np, i0, w.S, Wp, gp, w.mu_d);
+                    hipLaunchKernelGGL(ep_prep_kernel, dim3(36), dim3(256), 0, sa, w.Sig, np, i0, w.S, Wp, gp, w.mu_d);
                     HIP_TRY(hipEventRecord(evP(b), sa));
                 }
                 hipLaunchKernelGGL(ep_chain_kernel, dim3(1), dim3(256), 0, sa, w.Sig, np, i0, nb, w.mu_d, w.m_d, c->y_dev, w.ttau_d,
@@ -1112,7 +1263,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
             if (sa != st) HIP_TRY(hipStreamWaitEvent(st, evC(nbl - 1), 0));
             if (hipGetLastError() != hipSuccess) return PGP_ERR_HIP;
             if (ep_timing) {
-                long long sp[8];
+                long long sp[16];
                 HIP_TRY(hipMemcpyAsync(sp, w.gb + 2 * EPB, sizeof(sp), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 fprintf(stderr, "[ep] chain(5) stamps (10 ns ticks): load %lld  loop %lld (first half %lld)  epilogue %lld\n", sp[1] - sp[0], sp[2] - sp[1], sp[4] - sp[1], sp[3] - sp[2]);

@@ -215,7 +215,6 @@ int pgp_fitc_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para,
     if (!xu || nu <= 0) return -8;
     if (want < 1 || want > 3) return -11;
     HIP_TRY(hipSetDevice(c->device));
-    FitScope in_flight(c);
     hipStream_t st = c->st;
     const long n = c->n, d = c->d, np = c->np;
     const int dpad = c->dpad;
@@ -398,7 +397,6 @@ int pgp_fitc_predict(pgp_ctx* c, pgp_fitc* f, const double* xs, int64_t ns, cons
     if (!xs || ns <= 0) return -3;
     if (!fmu || !fs2) return -6;
     HIP_TRY(hipSetDevice(c->device));
-    FitScope in_flight(c);
     hipStream_t st = c->st;
     const long nup = f->nup, nu = f->nu;
     const int d = f->d, dpad = f->dpad;

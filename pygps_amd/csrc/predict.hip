@@ -74,7 +74,6 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     if (!fmu) return -6;
     if (!fs2) return -7;
     HIP_TRY(hipSetDevice(c->device));
-    FitScope in_flight(c);
     hipStream_t st = c->st;
     CHK(ensure_wd(c, f));
     const long np = f->np, n = f->n;
@@ -131,7 +130,6 @@ int pgp_predict_dense(pgp_ctx* c, pgp_factor* f, const double* Ks_host, int64_t 
     if (!fmu) return -7;
     if (!fs2) return -8;
     HIP_TRY(hipSetDevice(c->device));
-    FitScope in_flight(c);
     hipStream_t st = c->st;
     CHK(ensure_wd(c, f));
     const long np = f->np, n = f->n;
@@ -177,7 +175,6 @@ int pgp_potrs(pgp_ctx* c, const double* R, int64_t n, const double* Bm, int64_t 
     if (nrhs <= 0) return -5;
     if (!X_out) return -6;
     HIP_TRY(hipSetDevice(c->device));
-    FitScope in_flight(c);
     hipStream_t st = c->st;
     const long np = round_up(n, 128);
     const int nr = (int)round_up(nrhs, 128);

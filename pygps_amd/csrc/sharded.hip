@@ -313,7 +313,6 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
     if (!covhyp) return -4;
     if (want < 1 || want > 3) return -12;
     HIP_TRY(hipSetDevice(c->device));
-    FitScope in_flight(c);
     const long n = c->n, d = c->d;
     const int world = m->world, me = m->rank;
     const int w = c->nb_outer > 0 ? std::min(c->nb_outer, 8) * 128 : (n >= 12288 ? 1024 : 512);

@@ -14,7 +14,7 @@ ccsv() { find $1 -name "*counter_collection.csv" | head -1; }
 timeout 1200 python $R/bench.py > $O/bench.json 2> $O/bench.err
 grep '^{' $O/bench.json > $O/final/r03_bench.json
 # 2a. kernel-trace stats of the SINGLE-STREAM command: the run whose per-kernel averages reproduce roofline.frac
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python $R/bench.py --streams 1 --option eet_overlap=3 --no-cpu-baseline --no-extras > $O/s1.json 2> $O/stats1.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python $R/bench.py --streams 1 --no-cpu-baseline --no-extras > $O/s1.json 2> $O/stats1.err
 grep '^{' $O/s1.json > $O/final/r03_bench_streams1_under_rocprof.json; cp $(kstats $O/stats1) $O/final/r03_bench_streams1_kernel_stats.csv
 # 2b. the same for the timed (two fit streams) configuration: kernel time sums overlap there
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python $R/bench.py --no-cpu-baseline --no-extras > $O/s2.json 2> $O/stats2.err
@@ -22,7 +22,7 @@ grep '^{' $O/s2.json > $O/final/r03_bench_streams2_under_rocprof.json; cp $(ksta
 # 3. PMC traffic of gemm_f64 (separate passes, single stream)
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -- python $R/bench.py --steps 3 --windows 1 --prof-steps 1 --streams 1 --option eet_overlap=3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_$d.err
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -- python $R/bench.py --steps 3 --windows 1 --prof-steps 1 --streams 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_$d.err
   cp $(ccsv $O/pmc/$d) $O/final/r03_pmc_${d}_counter_collection.csv
 done
 python $R/tools/pmc_traffic.py $O/pmc $O/final/r03_gemm_f64_hbm_traffic.json $HEAD > /dev/null 2>> $O/pmc.err
