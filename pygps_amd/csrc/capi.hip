@@ -169,7 +169,6 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     if (!strcmp(name, "leaf_first")) { c->leaf_first = value; return PGP_OK; }
     if (!strcmp(name, "yield")) { c->yield = value; return PGP_OK; }
-    if (!strcmp(name, "ep_dbg")) { return ep_set_dbg(value); }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
     if (!strcmp(name, "ep_r_direct")) { c->ep_r_direct = value; return PGP_OK; }
     if (!strcmp(name, "ep_alpha_direct")) { c->ep_alpha_direct = value; return PGP_OK; }

@@ -68,8 +68,8 @@ struct pgp_ctx {
     int ep_alpha_direct = 1;            // EP: alpha = tnu - ttau o mu (identity, no solve); 0 = the reference's two triangular solves
     int ep_sigma_under = 1;             // EP: Sigma = K - V'V'^T accumulated under the sweep of the parameter recomputation (ep_fused 2)
     int ep_sym = 1;                     // EP: Sigma kept current in its lower triangle only (folds and K - V'V on the lower tiles)
-    int ep_block = 2;                   // EP site sweep: 2 = one chain launch per 128 sites + Woodbury fold beside the next chain, 1 = 16 sites per
-                                        // launch with lazy rank-1 factors (rounds 1-2), 0 = update Sigma per site
+    int ep_block = 1;                   // EP site sweep: 1 = one chain launch per 128 sites + Woodbury fold beside the next chain (round 3),
+                                        // 0 = the reference's arithmetic literally: Sigma updated per site
     int fused_inverse = 1;              // 1: L^-T falls out of the Cholesky sweep (appended identity rows); 0: recursive trtri
     hipDeviceProp_t prop;
     // pooled device buffers, keyed by byte size
@@ -309,6 +309,5 @@ int alloc_factor_buffer(pgp_ctx* c, long np, long ldf, double** F);
 int ensure_workspace(pgp_ctx* c, long np);
 int solve_lower_multi(pgp_ctx* c, const double* L, long ldl, const double* Wd, double* Y, long ldy, long np, int nrhs,
                       bool trans);
-int ep_set_dbg(int v);
 int potrf_blocked_rhs(pgp_ctx* c, double* F, long ld, long np, long mrows, double* R, long ldr, long nrhs2);
 int eet_lower(pgp_ctx* c, const double* E, long lde, double* Binv, long ldb, long np);

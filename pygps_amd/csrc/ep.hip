@@ -1,16 +1,19 @@
 // Expectation propagation for the probit likelihood on the device -- reference: Core/inf.py EP.evaluate
 // :731-806, Inference._epComputeParams :174-189, Core/lik.py Erf (EP mode) :295-366.
 //
-// The site loop is inherently sequential (site i+1 needs Sigma_ii, mu_i after site i's update, fixed order
-// 0..n-1, inf.py:757).  Per site two launches mirror the reference's arithmetic exactly:
-//   ep_site_kernel      cavity, probit moments, new (ttau_i, tnu_i), rank-1 coefficient; copies column i
-//   ep_rank1_mu_kernel  Sigma -= c s_i s_i' fused with the full recompute mu = Sigma tnu (inf.py:769-770):
-//                       ONE read+write pass over Sigma per site (16 N^2 B; Sigma = 128 MiB at N=4096 lives in
-//                       the 256 MiB Infinity Cache) instead of the reference's ~5 full-matrix temporaries.
-// After every sweep the posterior is recomputed from scratch with the SAME kernels as exact inference:
-//   B = I + sW sW' o K (fused build) -> blocked MFMA Cholesky -> V = L^-1 (sW o K) (blocked multi-RHS solve on
-//   the MFMA GEMM) -> Sigma = K - V'V (MFMA GEMM, TN) -> mu = Sigma tnu.
-// Gradients reuse the triangular inverse, W'W and the Hadamard-reduce kernel with per-point weights sW.
+// The site loop is inherently sequential (site i+1 needs Sigma_ii, mu_i after site i's update, fixed order 0..n-1,
+// inf.py:757).  Two forms:
+//   ep_block 0   the reference's arithmetic literally, two launches per site: ep_site_kernel (cavity, probit moments, new
+//                (ttau_i, tnu_i), rank-1 coefficient) and ep_rank1_mu_kernel (Sigma -= c s_i s_i' fused with mu = Sigma tnu:
+//                16 N^2 bytes per site).  Kept as the parity anchor of the variants test.
+//   ep_block 1   (default) the BLOCK sweep: the 128 sites of a block only read Sigma_BB and mu_B, so one workgroup runs them
+//                in one launch with Sigma_BB in registers (ep_chain_kernel) and the rest of Sigma gets the block's effect all
+//                at once by the matrix inversion lemma, folded in beside the next block's chain -- see "block sweep" below.
+// After every sweep the posterior is recomputed from scratch with the SAME kernels as exact inference (inf.py:772):
+//   B = I + sW sW' o K (fused build) -> blocked MFMA Cholesky with K diag(sW) riding along as right-hand-side rows
+//   (V' = K sW L^-T) -> Sigma = K - V'V'^T accumulated panel by panel under that sweep -> mu = Sigma tnu.
+// alpha and sW sW' o B^-1 follow from Sigma and mu by identities (no further solve); the gradients reuse the Hadamard-reduce
+// kernel of the exact fit.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -91,18 +94,7 @@ __global__ __launch_bounds__(256) void ep_rank1_mu_kernel(double* __restrict__ S
     if (lane == 0) mu[r] = acc;
 }
 
-// ---- blocked ("lazy") site sweep ------------------------------------------------------------------------------
-// The reference updates the full Sigma and recomputes mu = Sigma tnu after every site (inf.py:769-770): 16 N^2 bytes per
-// site.  A site only ever reads column i of Sigma and mu_i, so the rank-1 updates of the last j < EPB sites are kept
-// as factors instead:   Sigma = Sigma_blk - sum_k c_k s_k s_k',   mu = mu_blk + sum_k q_k s_k
-// (mu' = (Sigma - c s s')(tnu + d e_i) = mu + s (d - c (mu_i + d Sigma_ii)), because s' tnu = (Sigma tnu)_i = mu_i).
-// One launch per site: every workgroup recomputes the (cheap, deterministic) scalar site update itself, so no
-// cross-workgroup synchronisation is needed; rows are spread over the workgroups.  After EPB sites the factors are
-// folded into Sigma_blk with one MFMA GEMM (K = EPB) and into mu_blk with one matvec.  Same site order, same
-// mathematics; only the floating-point summation order of the updates differs from the reference.
-constexpr int EPB = 128;
-
-__global__ void ep_set_base_kernel(long* base, long v) { base[0] = v; }
+constexpr int EPB = 128;                       // sites per block of the sweep
 
 // Sigma_blk is kept current in its LOWER triangle only (the folds and Sigma = K - V'V are symmetric rank-k updates: half
 // the tiles); element (r, c) of the symmetric matrix:
@@ -123,68 +115,11 @@ __global__ __launch_bounds__(256) void ep_mirror_kernel(double* __restrict__ A, 
         if (!diag || a < q) A[c0 + a + (r0 + q) * ld] = tile[a][q];
 }
 
-// site index i = base[0] + j: the 128 launches of one block are captured once into a hipGraph and replayed for every
-// block (only base[0] changes), instead of 128 separate kernel launches of ~5 us each
-__global__ __launch_bounds__(256) void ep_site_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
-                                                           const long* __restrict__ base, int j,
-                                                           double* __restrict__ S, double* __restrict__ cvec,
-                                                           double* __restrict__ qvec, const double* __restrict__ mu_blk,
-                                                           const double* __restrict__ m, const double* __restrict__ y,
-                                                           const double* __restrict__ ttau_prev,
-                                                           const double* __restrict__ tnu_prev,
-                                                           double* __restrict__ ttau_cur, double* __restrict__ tnu_cur) {
-    __shared__ double g[EPB];            // c_k S(i,k)
-    __shared__ double red[2][4];
-    const long i = base[0] + j;
-    const int t = threadIdx.x;
-    double a = 0.0, b = 0.0;
-    if (t < j) {
-        const double sik = S[i + (long)t * ld];
-        g[t] = cvec[t] * sik;
-        a = g[t] * sik;                   // Sigma_ii correction
-        b = qvec[t] * sik;                // mu_i correction
-    }
-    a = wave_sum(a); b = wave_sum(b);
-    if ((t & 63) == 0) { red[0][t >> 6] = a; red[1][t >> 6] = b; }
-    __syncthreads();
-    const double sii = Sig[i + i * ld] - (red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    const double mui = mu_blk[i] + (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-    // site update (inf.py:759-769), identical in every workgroup
-    const double tau_ni = 1.0 / sii - ttau_prev[i];
-    const double nu_ni = mui / sii + m[i] * tau_ni - tnu_prev[i];
-    double lZ, dlZ, d2lZ;
-    erf_ep_moments(y[i], nu_ni / tau_ni, 1.0 / tau_ni, &lZ, &dlZ, &d2lZ);
-    double t_new = -d2lZ / (1.0 + d2lZ / tau_ni);
-    t_new = fmax(t_new, 0.0);
-    const double nu_new = (dlZ + (m[i] - nu_ni / tau_ni) * d2lZ) / (1.0 + d2lZ / tau_ni);
-    const double ds2 = t_new - ttau_prev[i];
-    const double cj = ds2 / (1.0 + ds2 * sii);
-    const double dnu = nu_new - tnu_prev[i];
-    if (blockIdx.x == 0 && t == 0) {
-        ttau_cur[i] = t_new; tnu_cur[i] = nu_new;
-        cvec[j] = cj;
-        qvec[j] = dnu - cj * (mui + dnu * sii);
-    }
-    // column i of the current Sigma -> factor column j
-    const long r = (long)blockIdx.x * 256 + t;
-    if (r < np) {
-        double sr = sym_at(Sig, ld, r, i);
-        for (int k = 0; k < j; ++k) sr = fma(-g[k], S[r + (long)k * ld], sr);
-        S[r + (long)j * ld] = sr;
-    }
-}
-
 // Latency-trimmed site update for the replay chain (4096 sequentially dependent evaluations per sweep: every cycle of
 // this function is on the critical path).  Same formulas as Core/inf.py:759-769 + lik.py:295-311, but: reciprocals by
 // v_rcp_f64 + one Newton step instead of IEEE division sequences (10 divisions per site), 1/sqrt by v_rsq_f64 + Newton, and
 // for z > -5 (the branch without asymptotics) N(z)/Phi(z) straight from Phi -- the reference's exp(log Phi) round trip and
 // log Phi itself are not needed for the derivatives.  Differences to the scalar path: a few ulp (parity tests: 1e-8).
-// value of lane `src` (compile-time constant after unrolling) in every lane: two v_readlane_b32, no LDS round trip
-__device__ __forceinline__ double bcast_lane(double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
@@ -299,203 +234,7 @@ __device__ __forceinline__ void ep_site_update(double sii, double mui, double tp
     ep_site_update_b(sii, mui, tp, np_, mi, h, t_new, nu_new, cj, qj);
 }
 
-// EPT consecutive sites per launch.  The sites are sequentially dependent, but site t+1 only needs ROW i_(t+1) of the
-// factor columns, including those created by the sites before it in the same launch -- single elements any
-// workgroup can recompute -- so every workgroup replays the EPT scalar site updates itself and then computes its rows of
-// all EPT new factor columns in one pass over S(r, 0..j0): the chain of dependent kernel launches gets EPT times
-// shorter and S is read once instead of EPT times.
-// Round 2: the replay is split into (i) everything that only involves the j0 columns that existed before the launch --
-// the EPT x EPT Gram matrix G = Srow diag(c) Srow', the weighted rows gv and b0 = Srow q -- computed by all 256 threads
-// at once, and (ii) the EPT x EPT triangular recurrence over the columns created inside the launch, run by ONE wave with
-// lane = site and the in-launch entries in registers (shuffles instead of LDS round trips).  The serial part per launch
-// fell from ~40 wave reductions of length j0 to ~EPT probit evaluations: EPT = 16 (was 8), 14 -> 4 ms per sweep at N=4096.
-constexpr int EPT = 16;
-__device__ int g_ep_dbg = 0;            // timing experiments only (option ep_dbg): 1 skip the recurrence, 2 skip the Gram phase, 4 skip the rows loop
-constexpr size_t EPS_LDS_BYTES = (size_t)(EPT * (EPB + 1) + EPT * (EPB + EPT) + 2 * EPB) * sizeof(double);
-constexpr int EPS_THREADS = 256;          // wave 0: the in-launch recurrence, alone on its SIMD; waves 1-3: EPS_ROWS rows of the new factor columns
-constexpr int EPS_ROWS = EPS_THREADS - 64;
-// COH: what other workgroups wrote earlier in the SAME kernel (rows i_t of the factor columns, the (c, q) entries) is read with
-// agent-scope loads, and the factor columns / (c, q) are written with agent-scope stores (coherent across the XCD L2s without
-// cache-wide write-back / invalidate); false for the one-step-per-launch kernel, where the launch boundary does that.
-__device__ __forceinline__ double coh_ld(const double* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void coh_st(double* p, double v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COH>
-__device__ __forceinline__ void ep_sites_lazy_body(const double* __restrict__ Sig, long ld, long np,
-                                                   const long* __restrict__ base, int j0, double* __restrict__ S,
-                                                   double* __restrict__ cvec, double* __restrict__ qvec,
-                                                   const double* __restrict__ mu_blk, const double* __restrict__ m,
-                                                   const double* __restrict__ y,
-                                                   const double* __restrict__ ttau_prev,
-                                                   const double* __restrict__ tnu_prev,
-                                                   double* __restrict__ ttau_cur, double* __restrict__ tnu_cur,
-                                                   double* __restrict__ eps_lds /* EPS_LDS_BYTES of dynamic LDS */) {
-    double (*Srow)[EPB + 1] = reinterpret_cast<double (*)[EPB + 1]>(eps_lds);                         // row i_t of the factor columns 0 .. j0-1
-    double (*gv)[EPB + EPT] = reinterpret_cast<double (*)[EPB + EPT]>(eps_lds + EPT * (EPB + 1));     // g_t[k] = c_k S(i_t, k), k < j0 + t
-    double* cl = eps_lds + EPT * (EPB + 1) + EPT * (EPB + EPT);
-    double* ql = cl + EPB;
-    __shared__ double Sg[EPT][EPT];              // Sigma_blk(i_t, i_u)
-    __shared__ double G[EPT][EPT];               // sum_{k<j0} c_k S(i_t,k) S(i_u,k)
-    __shared__ double b0[EPT];                   // sum_{k<j0} q_k S(i_t,k)
-    __shared__ double sv[4][EPT];                // the sites' (ttau, tnu) of the previous sweep, m, y
-    const int t = threadIdx.x, lane = t & 63;
-    const long i0 = base[0] + j0;
-    for (int v = t; v < EPT * j0; v += EPS_THREADS) {
-        const int tt = v / j0, k = v % j0;
-        Srow[tt][k] = COH ? coh_ld(S + i0 + tt + (long)k * ld) : S[i0 + tt + (long)k * ld];
-    }
-    for (int k = t; k < j0; k += EPS_THREADS) { cl[k] = COH ? coh_ld(cvec + k) : cvec[k]; ql[k] = COH ? coh_ld(qvec + k) : qvec[k]; }
-    if (t < EPT * EPT) Sg[t / EPT][t % EPT] = sym_at(Sig, ld, i0 + t / EPT, i0 + t % EPT);
-    __syncthreads();
-    for (int v = t; v < EPT * j0; v += EPS_THREADS) { const int tt = v / j0, k = v % j0; gv[tt][k] = cl[k] * Srow[tt][k]; }
-    __syncthreads();
-    const int dbg = g_ep_dbg;
-    if (!(dbg & 2))
-    {   // (i) Gram matrix (lower part) and b0: EPT (EPT+1) / 2 + EPT dots of length j0, one per thread
-        constexpr int NG = EPT * (EPT + 1) / 2;
-        if (t < NG) {
-            int tt = 0, rem = t;
-            while (rem > tt) { rem -= tt + 1; ++tt; }
-            const int u = rem;
-            double a = 0.0;
-            for (int k = 0; k < j0; ++k) a = fma(gv[u][k], Srow[tt][k], a);
-            G[tt][u] = a;
-        } else if (t < NG + EPT) {
-            const int tt = t - NG;
-            double a = 0.0;
-            for (int k = 0; k < j0; ++k) a = fma(ql[k], Srow[tt][k], a);
-            b0[tt] = a;
-        }
-    }
-    __syncthreads();
-    if (t < 64 && !(dbg & 1)) {                  // (ii) one wave, lane L = site L (lanes >= EPT idle along)
-        const int L = lane < EPT ? lane : EPT - 1;
-        const long i = i0 + L;
-        double e[EPT], cN[EPT], qN[EPT];         // e[u] = S(i_L, j0 + u) for u < L; cN / qN: the sites' new (c, q), wave-uniform
-        const double Sgd = Sg[L][L] - G[L][L], mub = mu_blk[i] + b0[L];
-        if (lane < EPT) { sv[0][lane] = ttau_prev[i]; sv[1][lane] = tnu_prev[i]; sv[2][lane] = m[i]; sv[3][lane] = y[i]; }
-        __builtin_amdgcn_wave_barrier();
-        double sa = 0.0, sb = 0.0;               // running sum_{v<u} c_v e_L[v]^2 and sum_{v<u} q_v e_L[v] of this lane's row
-#pragma unroll
-        for (int u = 0; u < EPT; ++u) {
-            // site u's scalar update on lane u's row, evaluated wave-UNIFORMLY (inputs broadcast first): the branches of the
-            // probit moments are then taken once, not once per distinct lane value
-            const double sii = bcast_lane(Sgd - sa, u);
-            const double mui = bcast_lane(mub + sb, u);
-            double t_new, nu_new, cj, qj;
-            ep_site_update(sii, mui, sv[0][u], sv[1][u], sv[2][u], sv[3][u], t_new, nu_new, cj, qj);
-            cN[u] = cj;
-            qN[u] = qj;
-            if (lane == 0 && blockIdx.x == 0) {
-                ttau_cur[i0 + u] = t_new; tnu_cur[i0 + u] = nu_new;
-                if (COH) { coh_st(cvec + j0 + u, cj); coh_st(qvec + j0 + u, qj); }
-                else { cvec[j0 + u] = cj; qvec[j0 + u] = qj; }
-            }
-            // column j0 + u at the rows of the later sites:  e_L[u] = Sigma_blk(i_L, i_u) - G[L][u] - sum_{v<u} c_v e_u[v] e_L[v]
-            double acc = Sg[L][u] - G[L > u ? L : u][L > u ? u : L];
-#pragma unroll
-            for (int v = 0; v < u; ++v) acc = fma(-cN[v] * bcast_lane(e[v], u), e[v], acc);
-            e[u] = acc;
-            sa = fma(cN[u] * acc, acc, sa);
-            sb = fma(qN[u], acc, sb);
-        }
-        if (lane < EPT) {
-#pragma unroll
-            for (int u = 0; u < EPT; ++u)
-                if (u < L) gv[L][j0 + u] = cN[u] * e[u];
-        }
-    }
-    // rows of the EPT new factor columns (waves 1-4), one pass over S(r, 0..j0).  The pass over the columns that existed
-    // before the launch needs nothing from the recurrence, so it runs BESIDE it; only the short in-launch correction waits.
-    const long r = (long)blockIdx.x * EPS_ROWS + (t - 64);
-    double acc[EPT];
-    if (t >= 64 && r < np) {
-        if (r >= i0 + EPT) {                         // below the launch's sites: column reads, coalesced over the rows
-#pragma unroll
-            for (int tt = 0; tt < EPT; ++tt) acc[tt] = Sig[r + (i0 + tt) * ld];
-        } else if (r < i0) {                         // above: row r of the lower triangle, EPT contiguous doubles per thread
-            const double2_t* src = reinterpret_cast<const double2_t*>(Sig + i0 + r * ld);     // i0 % EPT == 0, ld even
-#pragma unroll
-            for (int tt = 0; tt < EPT; tt += 2) { const double2_t v = src[tt / 2]; acc[tt] = v[0]; acc[tt + 1] = v[1]; }
-        } else {
-#pragma unroll
-            for (int tt = 0; tt < EPT; ++tt) acc[tt] = sym_at(Sig, ld, r, i0 + tt);
-        }
-        if (!(dbg & 4))
-        for (int k = 0; k < j0; ++k) {
-            const double srk = S[r + (long)k * ld];
-#pragma unroll
-            for (int tt = 0; tt < EPT; ++tt) acc[tt] = fma(-gv[tt][k], srk, acc[tt]);
-        }
-    }
-    __syncthreads();                                 // gv[.][j0 ..] of the recurrence
-    if (t >= 64 && r < np) {
-#pragma unroll
-        for (int tt = 0; tt < EPT; ++tt) {           // column j0+tt also depends on the columns j0 .. j0+tt-1 of this launch
-#pragma unroll
-            for (int u = 0; u < tt; ++u) acc[tt] = fma(-gv[tt][j0 + u], acc[u], acc[tt]);
-            if (COH) coh_st(S + r + (long)(j0 + tt) * ld, acc[tt]);
-            else S[r + (long)(j0 + tt) * ld] = acc[tt];
-        }
-    }
-}
-
-__global__ __launch_bounds__(EPS_THREADS) void ep_sites_lazy_kernel(const double* __restrict__ Sig, long ld, long np,
-                                                            const long* __restrict__ base, int j0, double* __restrict__ S,
-                                                            double* __restrict__ cvec, double* __restrict__ qvec,
-                                                            const double* __restrict__ mu_blk, const double* __restrict__ m,
-                                                            const double* __restrict__ y,
-                                                            const double* __restrict__ ttau_prev,
-                                                            const double* __restrict__ tnu_prev,
-                                                            double* __restrict__ ttau_cur, double* __restrict__ tnu_cur) {
-    extern __shared__ __attribute__((aligned(16))) double eps_lds[];   // EPS_LDS_BYTES: more than the 64 KB static limit at EPB = 256
-    ep_sites_lazy_body<false>(Sig, ld, np, base, j0, S, cvec, qvec, mu_blk, m, y, ttau_prev, tnu_prev, ttau_cur, tnu_cur, eps_lds);
-}
-
-// Sc(:,k) = c_k S(:,k)
-__global__ __launch_bounds__(256) void ep_colscale_kernel(const double* __restrict__ S, double* __restrict__ Sc, long ld,
-                                                          long np, const double* __restrict__ cvec) {
-    const long r = (long)blockIdx.x * 256 + threadIdx.x;
-    const int k = blockIdx.y;
-    if (r < np) Sc[r + (long)k * ld] = cvec[k] * S[r + (long)k * ld];
-}
-
-// mu_r += sum_k q_k S(r,k)
-__global__ __launch_bounds__(256) void ep_mu_fold_kernel(const double* __restrict__ S, long ld, long np,
-                                                         const double* __restrict__ qvec, double* __restrict__ mu) {
-    const long r = (long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= np) return;
-    double acc = mu[r];
-    for (int k = 0; k < EPB; ++k) acc = fma(qvec[k], S[r + (long)k * ld], acc);
-    mu[r] = acc;
-}
-
-// Both of the above in one pass over S: 64 rows per workgroup, the EPB columns split over the 4 waves; the 4 partial sums
-// of a row meet in LDS and are added in a fixed order (bitwise reproducible)
-__global__ __launch_bounds__(256) void ep_fold_prep_kernel(const double* __restrict__ S, double* __restrict__ Sc, long ld,
-                                                           long np, const double* __restrict__ cvec,
-                                                           const double* __restrict__ qvec, double* __restrict__ mu) {
-    __shared__ double part[4][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long r = (long)blockIdx.x * 64 + lane;
-    double acc = 0.0;
-    if (r < np) {
-#pragma unroll 4
-        for (int k = grp * (EPB / 4); k < (grp + 1) * (EPB / 4); ++k) {
-            const double v = S[r + (long)k * ld];
-            Sc[r + (long)k * ld] = cvec[k] * v;
-            acc = fma(qvec[k], v, acc);
-        }
-    }
-    part[grp][lane] = acc;
-    __syncthreads();
-    if (grp == 0 && r < np) mu[r] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-}
-
-// ---- block sweep (ep_block 2, round 3) ---------------------------------------------------------------------------------
+// ---- block sweep (round 3) ---------------------------------------------------------------------------------
 // The sites of one block B of 128 consecutive sites only ever read Sigma_BB and mu_B: the sequential site loop of the block is
 // EP on a 128-point problem, run by ONE workgroup with Sigma_BB in registers (ep_chain_kernel, 128 dependent site updates in
 // one launch, no launch boundary and no global memory between two sites).  What the block did to the rest of Sigma follows
@@ -943,10 +682,8 @@ struct EpWork {
     double* Ed;                          // fused path: E = L^-T from the sweep, then diag(sW) E
     double *Kd, *Sig, *Vd, *F, *Wd, *rhs;
     double *ttau_d, *tnu_d, *mu_d, *m_d, *s_d, *sbuf, *coef, *diag_d, *tmp_d;
-    double *S, *Sc, *cq, *prev;          // blocked sweep: factor columns, scaled copy, (c, q) vectors, (ttau, tnu) snapshot
+    double *S, *Sc;                      // block sweep: the strip Sigma(:, B) and U = strip W
     double *Wb, *gb;                     // block sweep: W and g of the last two blocks
-    long* base;                          // first site of the current block (device scalar read by the captured launches)
-    long* bases;                         // bases[b] = b * EPB: the launches of block b read their offset from here
 };
 
 }  // namespace
@@ -1070,7 +807,6 @@ extern "C" int pgp_test_probit_hazard(pgp_ctx* c, const double* z, double* out, 
     return PGP_OK;
 }
 
-int ep_set_dbg(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ep_dbg), &v, sizeof(int)) == hipSuccess ? PGP_OK : PGP_ERR_HIP; }
 
 extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para, int flags, const double* mvec,
                           const double* dm, int nmean, int want, int warm, double* ttau_io, double* tnu_io,
@@ -1129,21 +865,8 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     HIP_TRY(hipMemsetAsync(vecs, 0, (size_t)10 * np * sizeof(double), st));
     EP_TRY(dalloc(&w.S, (size_t)EPB * np * sizeof(double)));
     EP_TRY(dalloc(&w.Sc, (size_t)EPB * np * sizeof(double)));
-    EP_TRY(dalloc(&w.cq, (size_t)2 * EPB * sizeof(double)));
-    EP_TRY(dalloc(&w.prev, (size_t)2 * np * sizeof(double)));
     EP_TRY(dalloc(&w.Wb, (size_t)2 * EPB * EPB * sizeof(double)));
     EP_TRY(dalloc(&w.gb, (size_t)(2 * EPB + 16) * sizeof(double)));
-    { double* b8 = nullptr; EP_TRY(dalloc(&b8, 64)); w.base = (long*)b8; }
-    {
-        double* bb = nullptr;
-        const long nb = np / EPB + 1;
-        EP_TRY(dalloc(&bb, (size_t)nb * sizeof(long)));
-        w.bases = (long*)bb;
-        std::vector<long> hb(nb);
-        for (long b = 0; b < nb; ++b) hb[b] = b * EPB;
-        HIP_TRY(hipMemcpyAsync(w.bases, hb.data(), (size_t)nb * sizeof(long), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));                       // hb goes out of scope
-    }
     HIP_TRY(hipMemsetAsync(w.Kd, 0, nn, st));
     EP_TRY(alloc_factor_buffer(c, np, ldf, &w.F));
     FactorGuard fguard(c, w.F, (size_t)ldf * np * sizeof(double), /*scrub=*/true);
@@ -1187,7 +910,6 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemsetAsync(w.ttau_d, 0, np * sizeof(double), st));
         HIP_TRY(hipMemsetAsync(w.tnu_d, 0, np * sizeof(double), st));
     }
-    HIP_TRY(hipFuncSetAttribute((const void*)ep_sites_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EPS_LDS_BYTES));
     HIP_TRY(hipStreamSynchronize(st));
     stamp("K built, nlZ0", 0);
     const double tol = 1e-4;
@@ -1197,7 +919,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     while ((fabs(nlZ - nlZ_old) > tol && sweep < max_sweep) || sweep < min_sweep) {
         nlZ_old = nlZ;
         ++sweep;
-        if (c->ep_block == 2) {
+        if (c->ep_block) {
             // block sweep: chain stream (the high-priority panel stream) = prep(b) -> chain(b); bulk stream (main) = strip(b),
             // U(b), fold(b), mu(b).  Events: S[b] strip(b) done, C[b] chain(b) done, P[b] prep(b) done.
             const long nbl = (n + EPB - 1) / EPB;
@@ -1269,57 +991,6 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                 fprintf(stderr, "[ep] chain(5) stamps (10 ns ticks): load %lld  loop %lld (first half %lld)  epilogue %lld\n", sp[1] - sp[0], sp[2] - sp[1], sp[4] - sp[1], sp[3] - sp[2]);
                 fprintf(stderr, "[ep]   spins: chain waiting for the update waves %lld, update wave 1 waiting for its peers %lld, for the chain %lld\n", sp[4] - sp[1], sp[5], sp[6]);
             }
-        } else if (c->ep_block) {
-            // blocked sweep: site i reads the (ttau, tnu) it had at the start of the sweep (each site is visited once)
-            HIP_TRY(hipMemcpyAsync(w.prev, w.ttau_d, np * sizeof(double), hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(w.prev + np, w.tnu_d, np * sizeof(double), hipMemcpyDeviceToDevice, st));
-            // r0 >= 0: only the rows >= r0 of the lower triangle are brought up to date -- the sites still to come in this
-            // sweep are i >= r0 and read column i of the symmetric matrix = row i of its lower triangle (left of the
-            // diagonal) and column i below it; rows < r0 are never read again before _epComputeParams rebuilds Sigma from
-            // scratch.  Halves the fold work once more and ends the 528-tiles-on-512-slots second round.  r0 < 0: everything
-            // (the captured-graph path replays one fold for every block).
-            auto fold = [&](long r0) -> int {
-                if (r0 >= np) return PGP_OK;                                           // nothing of this sweep reads it any more
-                hipLaunchKernelGGL(ep_fold_prep_kernel, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, st, w.S, w.Sc, np, np,
-                                   w.cq, w.cq + EPB, w.mu_d);                          // Sc = S diag(c) ; mu += S q
-                GemmArgs g{};                                                          // Sigma -= S diag(c) S'
-                g.A = w.Sc; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
-                g.C = w.Sig; g.ldc = np; g.M = (int)np; g.N = (int)np; g.K = EPB;
-                g.alpha = -1.0; g.beta = 1.0; g.tile = (np / 128) * (np / 128) < c->small_tile_below ? 64 : 128;
-                g.flops = 2.0 * (double)np * np * EPB;
-                // symmetric rank-EPB update: only the lower tiles (the site kernels read Sigma_blk through its lower triangle)
-                if (c->ep_sym) { g.tri = 2; g.mask_diag = 1; g.flops *= 0.5; }
-                if (c->ep_sym && r0 > 0) {                                             // rows >= r0: lower trapezoid, tri_off = r0
-                    g.A = w.Sc + r0; g.C = w.Sig + r0; g.M = (int)(np - r0);
-                    g.tri = 1; g.tri_off = (int)r0;
-                    g.flops = (double)EPB * ((double)np * np - (double)r0 * r0);
-                    g.tile = 128;
-                }
-                CHK(gemm_prof(c, PC_GEMM_INNER, g));
-                // no re-zeroing of S / c / q: every site launch of the next block writes its columns (all rows) and its c, q
-                // entries before anything reads them, and a fold only follows a full block
-                return PGP_OK;
-            };
-            HIP_TRY(hipMemsetAsync(w.S, 0, (size_t)EPB * np * sizeof(double), st));
-            HIP_TRY(hipMemsetAsync(w.cq, 0, (size_t)2 * EPB * sizeof(double), st));
-            auto block_launches = [&](int nsite, bool do_fold, const long* base = nullptr, long fold_r0 = -1) -> int {
-                if (!base) base = w.base;
-                int j = 0;
-                for (; j + EPT <= nsite; j += EPT)
-                    hipLaunchKernelGGL(ep_sites_lazy_kernel, dim3((unsigned)((np + EPS_ROWS - 1) / EPS_ROWS)), dim3(EPS_THREADS), EPS_LDS_BYTES, st, w.Sig, np, np,
-                                       base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
-                                       w.tnu_d);
-                for (; j < nsite; ++j)
-                    hipLaunchKernelGGL(ep_site_lazy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np,
-                                       base, j, w.S, w.cq, w.cq + EPB, w.mu_d, w.m_d, c->y_dev, w.prev, w.prev + np, w.ttau_d,
-                                       w.tnu_d);
-                if (do_fold) CHK(fold(fold_r0));
-                return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
-            };
-            const long nfull = n / EPB;
-            for (long b = 0; b < nfull; ++b) EP_TRY(block_launches(EPB, true, w.bases + b, c->ep_sym ? (b + 1) * EPB : -1));
-            if (n % EPB) EP_TRY(block_launches((int)(n % EPB), false, w.bases + nfull));
-            // Sigma / mu are rebuilt from (ttau, tnu) by ep_compute_params below: the last partial block need not be folded
         } else
         for (long i = 0; i < n; ++i) {
             hipLaunchKernelGGL(ep_site_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, w.Sig, np, np, i,

@@ -165,7 +165,7 @@ if __name__ == "__main__":
                 m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
                 t = time.time()
                 nlZ, dnlZ, post = m.getPosterior(x, y)
-                print("EP N=%d d=%d ep_block=%d graph=%d: %.3f s, %d sweeps, nlZ=%.12g dnlZ.cov=%s alpha[:2]=%s" % (
+                print("EP N=%d d=%d ep_block=%d (0 = per-site reference form, 1 = block sweep) %d: %.3f s, %d sweeps, nlZ=%.12g dnlZ.cov=%s alpha[:2]=%s" % (
                     N, d, blk, gr, time.time() - t, m.inffunc.sweeps, nlZ, dnlZ.cov, post.alpha[:2, 0]))
     if "fit16k" in what:
         fit(16384, 64, kind=1, reps=1)
