@@ -198,10 +198,12 @@ def extras(lib, _lib, local, d, roof):
             sw = int(m5.inffunc.sweeps)
             ph5 = _lib.last_timings(local)            # EP phases (host wall clock, each phase ends synchronised): see csrc/ep.hip
         t5 = min(ts)
-        # blocked sweep: per site one column of S (8 N B written) + the <=128 (64 on average) pending factor columns re-read
-        # by the 16-site kernel once per 16 sites (8 N 64 / 16 B per site); per 128 sites one K=128 fold of the rows >= r0
-        # of the LOWER triangle of Sigma (r0 = first site still to come: read + write 8 (N^2 - r0^2) B)
-        bytes_sweep = n5 * (8.0 * n5 + 8.0 * n5 * 64 / 16.0) + sum(8.0 * (n5 * n5 - float(r0) ** 2) for r0 in range(128, n5, 128))
+        # block sweep: per block of 128 sites the strip Sigma(:, B) is copied (8 N 128 B read + written), U = strip W written and
+        # read (2 x 8 N 128), and ONE K = 128 fold touches the lower triangle of Sigma (read + write 8 N^2 B: every row -- the
+        # posterior is carried through the sweeps, not rebuilt after each)
+        nblk5 = n5 // 128
+        bytes_sweep = nblk5 * (4 * 8.0 * n5 * 128 + 8.0 * n5 * n5)
+        rebuilds = 1                                   # _epComputeParams runs once, on the converged site parameters
         out["cfg5_ep_N4096_d32"] = {
             "fit_ms": t5 * 1e3, "sweeps": sw, "ms_per_sweep_incl_params": t5 * 1e3 / max(sw, 1), "nlZ": float(nlz5),
             "algorithmic_bytes_per_sweep_blocked": bytes_sweep,
@@ -209,12 +211,16 @@ def extras(lib, _lib, local, d, roof):
             "site_sweep_GB_per_sweep": bytes_sweep / 1e9,
             # sweep + fused inverse 2 N^3 / 3, V' = K diag(sW) L^-T N^3 (clipped), Sigma = K - V'V'^T N^3 (lower tiles)
             "epComputeParams_flops_per_sweep": 8.0 * n5 ** 3 / 3.0,
+            "epComputeParams_calls_per_fit": rebuilds,
+            "schedule": "Sigma, mu, log det B carried through the sweeps by exact identities (Woodbury folds per block of 128 sites, "
+                        "determinant lemma per site); ONE rebuild from the converged site parameters (option ep_recompute=1: after "
+                        "every sweep, the reference's schedule, inf.py:772)",
             # the split the site sweep / parameter recomputation figures are read from (last of the two fits)
             "site_sweep_ms": ph5["solve"] / max(sw, 1), "site_sweep_GBs": bytes_sweep / (ph5["solve"] / max(sw, 1)) / 1e6,
             "site_sweep_frac_of_hbm_peak": bytes_sweep / (ph5["solve"] / max(sw, 1)) / 1e6 / PEAK_HBM_GBS,
-            "site_sweep_bound": "4096 sequentially dependent site updates per sweep (~0.94 us each), not bandwidth",
-            "params_ms": ph5["potrf"] / max(sw, 1), "params_TFLOPs": 8.0 * n5 ** 3 / 3.0 / (ph5["potrf"] / max(sw, 1)) / 1e9,
-            "params_frac_of_mfma_peak": 8.0 * n5 ** 3 / 3.0 / (ph5["potrf"] / max(sw, 1)) / 1e9 / PEAK_FP64_MFMA_TF,
+            "site_sweep_bound": "4096 sequentially dependent site updates per sweep (~0.5 us each inside ep_chain_kernel), not bandwidth",
+            "params_ms": ph5["potrf"] / rebuilds, "params_TFLOPs": 8.0 * n5 ** 3 / 3.0 / (ph5["potrf"] / rebuilds) / 1e9,
+            "params_frac_of_mfma_peak": 8.0 * n5 ** 3 / 3.0 / (ph5["potrf"] / rebuilds) / 1e9 / PEAK_FP64_MFMA_TF,
             "first_params_and_K_ms": ph5["assemble"], "alpha_and_gradients_ms": ph5["grad"],
             "workload": "BASELINE configs[4]: GPC + RBF, infEP, N=4096 d=32 (cold start, nlZ + gradients, through model.getPosterior)"}
     except Exception as e:           # pragma: no cover

@@ -66,6 +66,8 @@ struct pgp_ctx {
                                         // L^-T as one product), 2 K diag(sW) as dense right-hand-side rows of the sweep
     int ep_r_direct = 1;                // EP gradient: sW sW' o B^-1 = S - S Sigma S from the rebuilt Sigma; 0 = triangular inverse + W'W
     int ep_alpha_direct = 1;            // EP: alpha = tnu - ttau o mu (identity, no solve); 0 = the reference's two triangular solves
+    int ep_recompute = 0;               // EP: 1 = rebuild Sigma, mu, L after EVERY sweep like the reference (inf.py:772); 0 = carry them by exact
+                                        // identities and rebuild once, from the converged site parameters
     int ep_sigma_under = 1;             // EP: Sigma = K - V'V'^T accumulated under the sweep of the parameter recomputation (ep_fused 2)
     int ep_sym = 1;                     // EP: Sigma kept current in its lower triangle only (folds and K - V'V on the lower tiles)
     int ep_block = 1;                   // EP site sweep: 1 = one chain launch per 128 sites + Woodbury fold beside the next chain (round 3),

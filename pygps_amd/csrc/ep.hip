@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
                                                         const double* __restrict__ mu, const double* __restrict__ m,
                                                         const double* __restrict__ y, double* __restrict__ ttau,
                                                         double* __restrict__ tnu, double* __restrict__ Wout,
-                                                        double* __restrict__ gout, unsigned* yield_flags,
-                                                        long long* __restrict__ stamps) {
+                                                        double* __restrict__ gout, double* __restrict__ ldout,
+                                                        unsigned* yield_flags, long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) double colb[8][EPCP];     // column k of Sigma_BB before site k: ring over k mod 8
     __shared__ double diagb[2][EPB], mub[2][EPB];                     // diagonal and mu before site k, by parity of k
     __shared__ __attribute__((aligned(16))) double cq[8][2];          // (c_k, q_k): ring over k mod 8
@@ -301,11 +301,15 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
         // ---- the chain: inf.py:757-770 for the sites of the block, nothing else -------------------------------------------
         double dkk = diagb[0][0], muk = mub[0][0];
         double pc0 = prm[0][0], pc1 = prm[0][1], pc2 = prm[0][2], pc3 = prm[0][3];
+        // log det B moves with every site by the matrix determinant lemma: det(Sigma^-1 + dtau e e') = det(Sigma^-1) (1 + dtau Sigma_ii)
+        double fprod = 1.0, lsum = 0.0;
         for (int k = 0; k < nb; ++k) {
             const int kn = k + 1 < EPB ? k + 1 : EPB - 1;
             const double pn0 = prm[kn][0], pn1 = prm[kn][1], pn2 = prm[kn][2], pn3 = prm[kn][3];
             double t_new, nu_new, cj, qj;
             ep_site_update(dkk, muk, pc0, pc1, pc2, pc3, t_new, nu_new, cj, qj);
+            fprod *= fma(t_new - pc0, dkk, 1.0);
+            if ((k & 31) == 31) { lsum += log(fprod); fprod = 1.0; }
             if (lane == 0) {
                 cq[k & 7][0] = cj; cq[k & 7][1] = qj;
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -334,6 +338,7 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
         __syncthreads();
         if (stamps && t == 0) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[4] = stamps[1] + spinC; }
         for (int k = lane; k < nb; k += 64) { ttau[i0 + k] = s_tn[k]; tnu[i0 + k] = s_nn[k]; }
+        if (lane == 0) ldout[0] = lsum + log(fprod);
         __syncthreads();
     } else {
         // update waves: Sigma_BB in the MFMA accumulator layout -- tile (I, J) of wave u: rows 48 u + 16 I + l15, columns
@@ -597,9 +602,10 @@ __global__ __launch_bounds__(256) void ep_strip_kernel(const double* __restrict_
     for (int k = 0; k < 16; ++k) S[r + (long)(k0 + k) * ld] = v[k];
 }
 
-// mu_r += sum_k S(r, k) g_k for the rows r >= rlo (64 rows per workgroup, the columns split over the 4 waves, fixed order)
-__global__ __launch_bounds__(256) void ep_mu_strip_kernel(const double* __restrict__ S, long ld, long np, long rlo,
+// mu_r += sum_k S(r, k) g_k for the rows rlo <= r < rhi (64 rows per workgroup, the columns split over the 4 waves, fixed order)
+__global__ __launch_bounds__(256) void ep_mu_strip_kernel(const double* __restrict__ S, long ld, long rhi, long rlo,
                                                           const double* __restrict__ g, double* __restrict__ mu) {
+    const long np = rhi;
     __shared__ double part[4][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long r = rlo + (long)blockIdx.x * 64 + lane;
@@ -683,7 +689,7 @@ struct EpWork {
     double *Kd, *Sig, *Vd, *F, *Wd, *rhs;
     double *ttau_d, *tnu_d, *mu_d, *m_d, *s_d, *sbuf, *coef, *diag_d, *tmp_d;
     double *S, *Sc;                      // block sweep: the strip Sigma(:, B) and U = strip W
-    double *Wb, *gb;                     // block sweep: W and g of the last two blocks
+    double *Wb, *gb, *ldb;               // block sweep: W and g of the last two blocks, log of the blocks' determinant factors
 };
 
 }  // namespace
@@ -691,7 +697,7 @@ struct EpWork {
 // recompute Sigma, mu, L from (ttau, tnu) and return nlZ (inf.py:174-189).  Host vectors in/out.
 static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y, const std::vector<double>& m,
                              const std::vector<double>& ttau, const std::vector<double>& tnu, double* nlZ_out,
-                             std::vector<double>& mu_h, std::vector<double>& dsig_h) {
+                             std::vector<double>& mu_h, std::vector<double>& dsig_h, double* half_logdet_out = nullptr) {
     hipStream_t st = c->st;
     const long n = w.n, np = w.np;
     std::vector<double> s_h(np, 0.0);
@@ -783,6 +789,7 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
         slZ += part_h[5 * b]; t3 += part_h[5 * b + 1]; t4 += part_h[5 * b + 2]; t5 += part_h[5 * b + 3]; t6 += part_h[5 * b + 4];
     }
     *nlZ_out = sc[0] - slZ - 0.5 * t3 - 0.5 * t4 + 0.5 * t5 - 0.5 * t6;
+    if (half_logdet_out) *half_logdet_out = sc[0];
     return PGP_OK;
 }
 
@@ -867,6 +874,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     EP_TRY(dalloc(&w.Sc, (size_t)EPB * np * sizeof(double)));
     EP_TRY(dalloc(&w.Wb, (size_t)2 * EPB * EPB * sizeof(double)));
     EP_TRY(dalloc(&w.gb, (size_t)(2 * EPB + 16) * sizeof(double)));
+    EP_TRY(dalloc(&w.ldb, (size_t)(np / EPB + 1) * sizeof(double)));
     HIP_TRY(hipMemsetAsync(w.Kd, 0, nn, st));
     EP_TRY(alloc_factor_buffer(c, np, ldf, &w.F));
     FactorGuard fguard(c, w.F, (size_t)ldf * np * sizeof(double), /*scrub=*/true);
@@ -893,10 +901,16 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     double nlZ = nlZ0;
     bool fresh = true;
     int rc = PGP_OK;
+    // track (default): Sigma, mu and log det B are carried through the sweeps by exact identities (Woodbury folds of whole
+    // blocks, the determinant lemma per site) and the posterior is rebuilt from scratch ONCE, from the converged site
+    // parameters (everything returned comes from that rebuild).  ep_recompute 1: the reference's schedule, a rebuild after
+    // every sweep (inf.py:772).
+    const bool track = c->ep_block && !c->ep_recompute;
+    double half_logdet = 0.0;                          // sum log diag chol(B): B = I at the cold start
     if (warm) {                                                                       // inf.py:744-753
         memcpy(ttau.data(), ttau_io, n * sizeof(double));
         memcpy(tnu.data(), tnu_io, n * sizeof(double));
-        rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);
+        rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig, &half_logdet);
         if (rc == PGP_OK && !(nlZ > nlZ0)) fresh = false;
         if (rc > 0) rc = PGP_OK;                                                      // bad warm start: fall back to zeros
         if (rc != PGP_OK) return rc;
@@ -905,6 +919,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         std::fill(ttau.begin(), ttau.end(), 0.0);
         std::fill(tnu.begin(), tnu.end(), 0.0);
         nlZ = nlZ0;
+        half_logdet = 0.0;
         HIP_TRY(hipMemcpyAsync(w.Sig, w.Kd, nn, hipMemcpyDeviceToDevice, st));        // Sigma = K, mu = 0
         HIP_TRY(hipMemsetAsync(w.mu_d, 0, np * sizeof(double), st));
         HIP_TRY(hipMemsetAsync(w.ttau_d, 0, np * sizeof(double), st));
@@ -948,22 +963,24 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                     HIP_TRY(hipEventRecord(evP(b), sa));
                 }
                 hipLaunchKernelGGL(ep_chain_kernel, dim3(1), dim3(256), 0, sa, w.Sig, np, i0, nb, w.mu_d, w.m_d, c->y_dev, w.ttau_d,
-                                   w.tnu_d, Wb, gb, yfl, ep_timing && b == 5 ? (long long*)(w.gb + 2 * EPB) : (long long*)nullptr);
+                                   w.tnu_d, Wb, gb, w.ldb + b, yfl, ep_timing && b == 5 ? (long long*)(w.gb + 2 * EPB) : (long long*)nullptr);
                 HIP_TRY(hipEventRecord(evC(b), sa));
-                if (b + 1 >= nbl) break;               // nothing of this sweep reads what the last block does to the rest
+                const bool last = b + 1 >= nbl;
+                if (last && !track) break;             // nothing of this sweep reads what the last block does to the rest
                 if (b > 0) HIP_TRY(hipStreamWaitEvent(sb, evP(b), 0));
                 hipLaunchKernelGGL(ep_strip_kernel, dim3((unsigned)((np + 255) / 256), 8), dim3(256), 0, sb, w.Sig, np, np, i0, w.S);
                 HIP_TRY(hipEventRecord(evS(b), sb));
                 HIP_TRY(hipStreamWaitEvent(sb, evC(b), 0));
-                const long r0 = i0 + EPB;               // rows of the sites still to come
+                const long r0 = std::min<long>(i0 + EPB, np);   // first row of the sites still to come
+                const long u0 = track ? 0 : r0;        // track: Sigma stays complete (every row), otherwise only the rows still to be read
                 {
-                    GemmArgs g{};                       // U = strip W on the rows >= r0
-                    g.A = w.S + r0; g.lda = np; g.a_kc = 0; g.B = Wb; g.ldb = EPB; g.b_kc = 0;
-                    g.C = w.Sc + r0; g.ldc = np; g.M = (int)(np - r0); g.N = EPB; g.K = EPB;
-                    g.alpha = 1.0; g.beta = 0.0; g.tile = 64; g.flops = 2.0 * (double)(np - r0) * EPB * EPB;
+                    GemmArgs g{};                       // U = strip W
+                    g.A = w.S + u0; g.lda = np; g.a_kc = 0; g.B = Wb; g.ldb = EPB; g.b_kc = 0;
+                    g.C = w.Sc + u0; g.ldc = np; g.M = (int)(np - u0); g.N = EPB; g.K = EPB;
+                    g.alpha = 1.0; g.beta = 0.0; g.tile = 64; g.flops = 2.0 * (double)(np - u0) * EPB * EPB;
                     EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
                 }
-                {
+                if (!last) {
                     GemmArgs g{};                       // the next block's rows left of its diagonal tile (prep owns that tile)
                     g.A = w.Sc + r0; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
                     g.C = w.Sig + r0; g.ldc = np; g.M = EPB; g.N = (int)r0; g.K = EPB;
@@ -971,7 +988,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                     EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
                 }
                 const long r1 = r0 + EPB;
-                if (r1 < np) {
+                if (!last && r1 < np) {
                     GemmArgs g{};                       // rows >= r1: lower trapezoid
                     g.A = w.Sc + r1; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
                     g.C = w.Sig + r1; g.ldc = np; g.M = (int)(np - r1); g.N = (int)np; g.K = EPB;
@@ -980,6 +997,15 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                     EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
                     hipLaunchKernelGGL(ep_mu_strip_kernel, dim3((unsigned)((np - r1 + 63) / 64)), dim3(256), 0, sb, w.S, np, np, r1, gb,
                                        w.mu_d);
+                }
+                if (track) {
+                    GemmArgs g{};                       // the rows of the sites already done (this block's included): lower triangle
+                    g.A = w.Sc; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
+                    g.C = w.Sig; g.ldc = np; g.M = (int)r0; g.N = (int)r0; g.K = EPB;
+                    g.alpha = -1.0; g.beta = 1.0; g.tile = r0 >= 1024 ? 128 : 64; g.tri = 2; g.mask_diag = 1;
+                    g.flops = (double)EPB * (double)r0 * r0;
+                    EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
+                    hipLaunchKernelGGL(ep_mu_strip_kernel, dim3((unsigned)((r0 + 63) / 64)), dim3(256), 0, sb, w.S, np, r0, 0L, gb, w.mu_d);
                 }
             }
             if (sa != st) HIP_TRY(hipStreamWaitEvent(st, evC(nbl - 1), 0));
@@ -1000,11 +1026,39 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         }
         HIP_TRY(hipMemcpyAsync(ttau.data(), w.ttau_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (track) {
+            // nlZ (inf.py:184-188) from the carried state: the per-site terms on diag Sigma and mu as the sweep left them, log det B
+            // from the sites' determinant factors
+            const long nbl = (n + EPB - 1) / EPB, nbt = (n + 255) / 256;
+            std::vector<double> ldh(nbl), ph(5 * nbt);
+            HIP_TRY(hipMemcpyAsync(ldh.data(), w.ldb, (size_t)nbl * sizeof(double), hipMemcpyDeviceToHost, st));
+            EP_TRY(gather_strided_launch(w.Sig, np + 1, np, w.diag_d, st));
+            hipLaunchKernelGGL(ep_site_terms_kernel, dim3((unsigned)nbt), dim3(256), 0, st, n, c->y_dev, w.m_d, w.mu_d, w.diag_d, 0.0,
+                               w.ttau_d, w.tnu_d, 1, w.tmp_d, (double*)nullptr);
+            HIP_TRY(hipMemcpyAsync(ph.data(), w.tmp_d, ph.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (long b = 0; b < nbl; ++b) half_logdet += 0.5 * ldh[b];
+            double slZ = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0, t6 = 0.0;
+            for (long b = 0; b < nbt; ++b) { slZ += ph[5 * b]; t3 += ph[5 * b + 1]; t4 += ph[5 * b + 2]; t5 += ph[5 * b + 3]; t6 += ph[5 * b + 4]; }
+            nlZ = half_logdet - slZ - 0.5 * t3 - 0.5 * t4 + 0.5 * t5 - 0.5 * t6;
+            if (!std::isfinite(nlZ)) {                 // let the rebuild say what is wrong (first bad pivot)
+                rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig, &half_logdet);
+                if (rc != PGP_OK) return rc;
+            }
+            stamp("sweep done, nlZ from the carried state", 1);
+            continue;
+        }
         HIP_TRY(hipStreamSynchronize(st));
         stamp("sweep done (synced)", 1);
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // inf.py:772
         HIP_TRY(hipStreamSynchronize(st));
         stamp("params recomputed", 2);
+        if (rc != PGP_OK) return rc;
+    }
+    if (track && sweep > 0) {
+        rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // the posterior of the converged site parameters
+        HIP_TRY(hipStreamSynchronize(st));
+        stamp("params rebuilt from the converged sites", 2);
         if (rc != PGP_OK) return rc;
     }
     if (sweeps_out) *sweeps_out = sweep;
