@@ -9,7 +9,9 @@
 //   ep_block 1   (default) the BLOCK sweep: the 128 sites of a block only read Sigma_BB and mu_B, so one workgroup runs them
 //                in one launch with Sigma_BB in registers (ep_chain_kernel) and the rest of Sigma gets the block's effect all
 //                at once by the matrix inversion lemma, folded in beside the next block's chain -- see "block sweep" below.
-// After every sweep the posterior is recomputed from scratch with the SAME kernels as exact inference (inf.py:772):
+// The posterior -- Sigma, mu, log det B -- is CARRIED through the sweeps (every step of the block sweep is an exact identity; the
+// determinant lemma per site) and rebuilt from scratch once, from the converged site parameters, with the SAME kernels as
+// exact inference; option ep_recompute 1 rebuilds it after every sweep like the reference (inf.py:772):
 //   B = I + sW sW' o K (fused build) -> blocked MFMA Cholesky with K diag(sW) riding along as right-hand-side rows
 //   (V' = K sW L^-T) -> Sigma = K - V'V'^T accumulated panel by panel under that sweep -> mu = Sigma tnu.
 // alpha and sW sW' o B^-1 follow from Sigma and mu by identities (no further solve); the gradients reuse the Hadamard-reduce

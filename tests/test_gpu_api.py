@@ -442,6 +442,42 @@ def test_ep_ragged_sizes_against_the_oracle(lib):
         assert relerr(post.alpha, out["alpha"]) < 1e-7 and relerr(dnlZ.cov, out["dnlZ_cov"]) < 1e-7, n
 
 
+def test_ep_carried_posterior_against_rebuilding_it_every_sweep(lib):
+    """The default EP schedule carries Sigma, mu and log det B through the sweeps by exact identities and rebuilds the posterior
+    once at the end; `ep_recompute=1` rebuilds it after every sweep like the reference (inf.py:772).  Problems on which K is
+    badly conditioned (long length scale, strong signal, overlapping classes, ragged n): the same number of
+    sweeps, nlZ to 1e-9, alpha / sW / gradients to 1e-7 between the two, and against the oracle."""
+    import pygps_amd as pyGPs
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    rng = np.random.RandomState(5)
+    cases = []
+    for n, d, ell, sf, flip in ((1500, 2, 3.0, 3.0, 0.2), (777, 5, 6.0, 1.0, 0.35), (2050, 3, 0.7, 2.0, 0.05)):
+        x = rng.randn(n, d)
+        y = np.sign(np.sin(x[:, :1] * 1.3) + 0.2 * rng.randn(n, 1)); y[y == 0] = 1
+        y[rng.rand(n, 1) < flip] *= -1
+        cases.append((x, y, np.array([np.log(ell), np.log(sf)])))
+    res = {}
+    try:
+        for mode in (0, 1):
+            _lib.check(lib.pgp_set_option(ctx, b"ep_recompute", mode))
+            for ci, (x, y, hyp) in enumerate(cases):
+                m = pyGPs.GPC()
+                m.setPrior(kernel=pyGPs.cov.RBF(hyp[0], hyp[1]))
+                nlZ, dnlZ, post = m.getPosterior(x, y)
+                res[mode, ci] = (nlZ, np.array(post.alpha), np.array(post.sW), np.array(dnlZ.cov), int(m.inffunc.sweeps))
+    finally:
+        lib.pgp_set_option(ctx, b"ep_recompute", 0)
+    for ci, (x, y, hyp) in enumerate(cases):
+        a, b = res[0, ci], res[1, ci]
+        assert a[4] == b[4] and a[4] >= 3, (ci, a[4], b[4])
+        assert relerr(a[0], b[0]) < 1e-9, ci
+        assert relerr(a[1], b[1]) < 1e-7 and relerr(a[2], b[2]) < 1e-7 and relerr(a[3], b[3]) < 1e-7, ci
+        if ci == 1:                                        # the oracle's sequential loop is slow: the small case only
+            out = O.ep_fit(O.RBF, hyp, 0, x, y, np.zeros_like(y))
+            assert relerr(a[0], out["nlZ"]) < 1e-9 and relerr(a[1], out["alpha"]) < 1e-7 and relerr(a[3], out["dnlZ_cov"]) < 1e-7
+
+
 def test_device_out_of_memory_raises_and_the_context_recovers(lib):
     """A fit whose N x N workspaces exceed the HBM fails with RuntimeError (status <= -100), and the next fit works."""
     import pygps_amd as pyGPs
