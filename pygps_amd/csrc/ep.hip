@@ -267,7 +267,7 @@ template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F&
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 __device__ __forceinline__ int lds_seq(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-__global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict__ Sig, long ld, long i0, int nb,
+__global__ __launch_bounds__(512) void ep_chain_kernel(const double* __restrict__ Sig, long ld, long i0, int nb,
                                                         const double* __restrict__ mu, const double* __restrict__ m,
                                                         const double* __restrict__ y, double* __restrict__ ttau,
                                                         double* __restrict__ tnu, double* __restrict__ Wout,
@@ -275,17 +275,22 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
                                                         unsigned* yield_flags, long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) double colb[8][EPCP];     // column k of Sigma_BB before site k: ring over k mod 8
     __shared__ double diagb[2][EPB], mub[2][EPB];                     // diagonal and mu before site k, by parity of k
-    __shared__ __attribute__((aligned(16))) double cq[8][2];          // (c_k, q_k): ring over k mod 8
+    __shared__ __attribute__((aligned(16))) double cq[16][2];         // (c_k, q_k): ring over k mod 16
+    __shared__ double gpart[2][EPCP];                                 // epilogue: the two column halves of Sigma_BB,new h
     __shared__ __attribute__((aligned(32))) double prm[EPB][4];       // the sites' (ttau, tnu) of the previous sweep, m, y
     __shared__ double s_mu0[EPB], s_dt[EPB], s_dn[EPB], s_tn[EPB], s_nn[EPB];
-    __shared__ int seqC, seqP;                   // sites wave 0 has finished ; 3 x sites the update waves have passed on
+    __shared__ int seqC, seqP, seqG;             // sites wave 0 has finished ; 3 x sites the update waves have passed on ; 6 x groups read
     pgp_yield_mark(yield_flags, +1);
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int u = wv - 1;
+    // eight waves, two per SIMD: wave 0 = the chain (alone on SIMD 0: wave 4 only keeps the barriers company); waves 1-3 and
+    // 5-7 = the update waves, pair u on SIMD u + 1: both hold the rows 48 u .. 48 u + 47, `half` 0 the tile columns 0-3, 1 the
+    // tile columns 4-7.  The wave that owns the current tile column does the per-site work; the other one only has the
+    // rank-4 MFMAs of its 12 tiles, which it issues one site late -- in the shadow of its partner's hand-overs
+    const int u = (wv & 3) - 1, half = wv >> 2;
     long long spinC = 0, spinP = 0, spinQ = 0;
     if (stamps && t == 0) stamps[0] = __builtin_amdgcn_s_memtime();
-    if (t == 0) { seqC = 0; seqP = 0; }
+    if (t == 0) { seqC = 0; seqP = 0; seqG = 0; }
     if (t < EPB) {
         const bool live = t < nb;
         prm[t][0] = live ? ttau[i0 + t] : 0.0; prm[t][1] = live ? tnu[i0 + t] : 0.0;
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
         __syncthreads();
         if (stamps && t == 0) stamps[1] = __builtin_amdgcn_s_memtime();
         // ---- the chain: inf.py:757-770 for the sites of the block, nothing else -------------------------------------------
+        __builtin_amdgcn_s_setprio(3);
         double dkk = diagb[0][0], muk = mub[0][0];
         double pc0 = prm[0][0], pc1 = prm[0][1], pc2 = prm[0][2], pc3 = prm[0][3];
         // log det B moves with every site by the matrix determinant lemma: det(Sigma^-1 + dtau e e') = det(Sigma^-1) (1 + dtau Sigma_ii)
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
             fprod *= fma(t_new - pc0, dkk, 1.0);
             if ((k & 31) == 31) { lsum += log(fprod); fprod = 1.0; }
             if (lane == 0) {
-                cq[k & 7][0] = cj; cq[k & 7][1] = qj;
+                cq[k & 15][0] = cj; cq[k & 15][1] = qj;
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
                 __hip_atomic_store(&seqC, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // LDS stores of one wave land in order
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -342,49 +348,56 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
         for (int k = lane; k < nb; k += 64) { ttau[i0 + k] = s_tn[k]; tnu[i0 + k] = s_nn[k]; }
         if (lane == 0) ldout[0] = lsum + log(fprod);
         __syncthreads();
+        __syncthreads();
+    } else if (u < 0) {                          // wave 4
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
     } else {
         // update waves: Sigma_BB in the MFMA accumulator layout -- tile (I, J) of wave u: rows 48 u + 16 I + l15, columns
         // 16 J + l4 + 4 r in component r (rows >= 128 are padding and stay zero)
-        double4_t A[3][8];
+        double4_t A[3][4];                       // tile (I, 4 half + jj)
 #pragma unroll
         for (int I = 0; I < 3; ++I) {
             const int row = 48 * u + 16 * I + l15;
 #pragma unroll
-            for (int J = 0; J < 8; ++J)
+            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) A[I][J][r] = row < EPB ? sym_at(Sig, ld, i0 + row, i0 + 16 * J + l4 + 4 * r) : 0.0;
-            if (l4 == 0 && row < EPB) colb[0][row] = A[I][0][0];
+                for (int r = 0; r < 4; ++r) A[I][jj][r] = row < EPB ? sym_at(Sig, ld, i0 + row, i0 + 16 * (4 * half + jj) + l4 + 4 * r) : 0.0;
+            if (half == 0 && l4 == 0 && row < EPB) colb[0][row] = A[I][0][0];
         }
         __syncthreads();
         // ---- the update waves, one site behind ------------------------------------------------------------------------------
         // Per site the VALU keeps only the tile column(s) current from which the NEXT sites' columns leave (J = k / 16, 12 FMAs;
-        // during the last four sites of a tile column also its successor).  Everything else gets the FOUR rank-1 terms of the
+        // during the last four sites of a tile column also its successor) -- in "panel" registers Pa / Pb of the wave that
+        // owns that tile column; the other wave of the pair skips the site.  Everything gets the FOUR rank-1 terms of the
         // sites 4 g .. 4 g + 3 at once, as one 16 x 16 x 4 MFMA per tile whose k index is the site: lane group l4 feeds column
-        // 4 g + l4 (the last eight columns and (c, q) pairs stay in LDS rings) -- 24 matrix instructions per four sites
-        // instead of 4 x (96 + 8) VALU instructions.  (One MFMA per SITE with the k = 1..3 lanes zeroed was measured first:
-        // 21 x 32 cycles per site on the matrix pipe is slower than the VALU form.)
-        const int di_ = 64 * u + lane;           // the diagonal / mu entry this lane keeps up to date (< 128: two of the three waves)
-        // the tile column(s) the VALU works on live in their own registers (the accumulators sit in AGPRs, where every VALU
-        // access costs two copies): Pa = tile column kc, Pb = its successor during the last four sites of kc
+        // 4 g + l4 (the last eight columns and sixteen (c, q) pairs stay in LDS rings) -- 12 matrix instructions per wave and
+        // four sites instead of 4 x (96 + 8) VALU instructions.  (One MFMA per SITE with the k = 1..3 lanes zeroed was measured
+        // first: fp64 MFMA and fp64 VALU both do 16 FMA per cycle and SIMD here, so three quarters of each were wasted.)
+        const int di_ = 64 * u + lane;           // the diagonal / mu entry the publishing wave of the pair keeps up to date (< 128)
         double4_t Pa[3], Pb[3];
 #pragma unroll
         for (int I = 0; I < 3; ++I) { Pa[I] = A[I][0]; Pb[I] = A[I][0]; }
-        // one site of tile column kc (runtime): the panel Pa is that tile column, Pb its successor (kept current during the
-        // last four sites, WB = true).  The early column k+1 is component (second ? R1 : R0) of Pa in the lanes l4 == bn, or
-        // (from_b) component 0 of Pb in the lanes l4 == 0.  Only R0 / R1 / WB are compile-time: four code bodies, reused by
-        // every tile column (one body per site would be 130 KB of straight-line code).
-        auto u_site = [&](const int k, const int kc, auto R0t, auto R1t, auto WBt, const bool second, const bool from_b, const int bn) {
+        // one site of tile column kc for the wave(s) that own Pa (mine_a) / Pb (mine_b, WB sites only); `pub`: this wave passes
+        // column k+1, the diagonal and mu on.  The early column is component (second ? R1 : R0) of Pa in the lanes l4 == bn, or
+        // (from_b) component 0 of Pb in the lanes l4 == 0.  Only R0 / R1 / WB are compile-time: four code bodies.
+        auto u_site = [&](const int k, const int kc, auto R0t, auto R1t, auto WBt, const bool mine_a, const bool mine_b, const bool pub,
+                          const bool second, const bool from_b, const int bn) {
             constexpr int r0 = decltype(R0t)::value, r1 = decltype(R1t)::value;
             constexpr bool wb = decltype(WBt)::value;
             const int b = k & 1;
-            // ONE LDS round trip per try: both sequence numbers and everything they guard are read in the same batch -- LDS
+            // ONE LDS round trip per try: the sequence numbers and everything they guard are read in the same batch -- LDS
             // executes a wave's instructions in order and the writers store their data before they raise the number, so data
             // read AFTER a number that has arrived has arrived too
             const double* cb = colb[k & 7];
+            const int need_g = k >= 7 ? 6 * (((k - 7) >> 2) + 1) : 0;         // the column this step overwrites has been read by all
             double crow[3], cca[4], ccb[4], dI = 0.0, mI = 0.0, cI = 0.0, cj, qj;
             for (;;) {
                 const int sp = __hip_atomic_load(&seqP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int sc = __hip_atomic_load(&seqC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int sg = __hip_atomic_load(&seqG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
 #pragma unroll
                 for (int I = 0; I < 3; ++I) crow[I] = cb[48 * u + 16 * I + l15];
@@ -393,9 +406,9 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
                     cca[r] = cb[16 * kc + l4 + 4 * r];
                     ccb[r] = wb ? cb[16 * kc + 16 + l4 + 4 * r] : 0.0;        // (kc = 7: the zero padding of the column)
                 }
-                if (di_ < EPB) { dI = diagb[b][di_]; mI = mub[b][di_]; cI = cb[di_]; }
-                cj = cq[k & 7][0]; qj = cq[k & 7][1];
-                if (sp >= 3 * k && sc >= k + 1) break;
+                if (pub && di_ < EPB) { dI = diagb[b][di_]; mI = mub[b][di_]; cI = cb[di_]; }
+                cj = cq[k & 15][0]; qj = cq[k & 15][1];
+                if (sp >= 3 * k && sc >= k + 1 && (!pub || sg >= need_g)) break;
                 if (sp < 3 * k) ++spinP; else ++spinQ;
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -405,75 +418,102 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
                 const double sr = ncj * crow[I];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    Pa[I][r] = fma(sr, cca[r], Pa[I][r]);
-                    if (wb) Pb[I][r] = fma(sr, ccb[r], Pb[I][r]);
+                    if (mine_a) Pa[I][r] = fma(sr, cca[r], Pa[I][r]);
+                    if (wb && mine_b) Pb[I][r] = fma(sr, ccb[r], Pb[I][r]);
                 }
             }
-            if (k + 1 < EPB) {
-                if (l4 == bn) {
+            if (pub) {
+                if (k + 1 < EPB) {
+                    if (l4 == bn) {
 #pragma unroll
-                    for (int I = 0; I < 3; ++I) {
-                        const int row = 48 * u + 16 * I + l15;
-                        const double nv = (wb && from_b) ? Pb[I][0] : (second ? Pa[I][r1] : Pa[I][r0]);
-                        if (row < EPB) colb[(k + 1) & 7][row] = nv;
+                        for (int I = 0; I < 3; ++I) {
+                            const int row = 48 * u + 16 * I + l15;
+                            const double nv = (wb && from_b) ? Pb[I][0] : (second ? Pa[I][r1] : Pa[I][r0]);
+                            if (row < EPB) colb[(k + 1) & 7][row] = nv;
+                        }
                     }
+                    if (di_ < EPB) { diagb[b ^ 1][di_] = fma(ncj * cI, cI, dI); mub[b ^ 1][di_] = fma(qj, cI, mI); }
                 }
-                if (di_ < EPB) { diagb[b ^ 1][di_] = fma(ncj * cI, cI, dI); mub[b ^ 1][di_] = fma(qj, cI, mI); }
+                // (no wait for the stores: LDS executes this wave's add after them)
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                if (lane == 0) __hip_atomic_fetch_add(&seqP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
             }
-            // (no wait for the stores: LDS executes this wave's add after them)
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            if (lane == 0) __hip_atomic_fetch_add(&seqP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
         };
-        // the four sites k0 .. k0+3 as ONE rank-4 update of all 24 tiles (the panels' own tiles too: they are overwritten from
-        // the panels when their tile column is done -- 3 or 6 wasted MFMAs, but no compile-time tile column in this code)
-        auto u_group = [&](const int k0) {
+        // the four sites k0 .. k0+3 as ONE rank-4 update of this wave's 12 tiles (the panels' own tiles too: they are overwritten
+        // from the panels when their tile column is done).  `late`: the wave that skipped the sites waits one hand-over longer,
+        // so that its MFMAs do not share the matrix pipe with its partner's batch
+        auto u_group = [&](const int k0, const bool late) {
             const int ks = k0 + l4;
             const double* cb = colb[ks & 7];
-            const double ncl = ks < nb ? -cq[ks & 7][0] : 0.0;
-            double yop[3];
+            const int last = k0 + 3 < nb ? k0 + 3 : nb - 1;
+            const int wait_p = late ? (last + 2 < nb ? 3 * (last + 2) : 3 * last) : 3 * last;
+            double ncl, yop[3], xop[4];
+            for (;;) {
+                const int sp = __hip_atomic_load(&seqP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int sc = __hip_atomic_load(&seqC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                ncl = ks < nb ? -cq[ks & 15][0] : 0.0;
 #pragma unroll
-            for (int I = 0; I < 3; ++I) yop[I] = ncl * cb[48 * u + 16 * I + l15];
+                for (int I = 0; I < 3; ++I) yop[I] = cb[48 * u + 16 * I + l15];
 #pragma unroll
-            for (int J = 0; J < 8; ++J) {
-                const double x = cb[16 * J + l15];
-#pragma unroll
-                for (int I = 0; I < 3; ++I) A[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, yop[I], A[I][J], 0, 0, 0);
+                for (int jj = 0; jj < 4; ++jj) xop[jj] = cb[16 * (4 * half + jj) + l15];
+                if (sp >= wait_p && sc >= last + 1) break;
+                __builtin_amdgcn_s_sleep(2);
             }
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if (lane == 0) __hip_atomic_fetch_add(&seqG, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (late) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int I = 0; I < 3; ++I) yop[I] *= ncl;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int I = 0; I < 3; ++I) A[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[jj], yop[I], A[I][jj], 0, 0, 0);
         };
 #pragma unroll 1
         for (int kc = 0; kc < 8; ++kc) {
             if (16 * kc >= nb) break;
+            const bool own_a = (kc >> 2) == half;                    // tile column kc is mine
+            const bool own_b = kc < 7 && ((kc + 1) >> 2) == half;    // its successor is mine
             static_for<4>([&](auto KQt) {
                 // sites 16 kc + 4 kq + kb: column k+1 is component kq (kb < 3) or kq + 1 (kb == 3) of tile column kc, lanes l4 == kb + 1 mod 4
                 constexpr int kq = decltype(KQt)::value, kbn = kq == 3 ? 3 : 4;
                 if constexpr (kq == 3) {          // the successor joins: its accumulators have every group before this one
-                    switch (kc) {
-#define PGP_EP_LOADB(J) case J: { _Pragma("unroll") for (int I = 0; I < 3; ++I) Pb[I] = A[I][J + 1]; } break;
-                        PGP_EP_LOADB(0) PGP_EP_LOADB(1) PGP_EP_LOADB(2) PGP_EP_LOADB(3) PGP_EP_LOADB(4) PGP_EP_LOADB(5) PGP_EP_LOADB(6)
+                    if (own_b) {
+                        switch ((kc + 1) & 3) {
+#define PGP_EP_LOADB(J) case J: { _Pragma("unroll") for (int I = 0; I < 3; ++I) Pb[I] = A[I][J]; } break;
+                            PGP_EP_LOADB(0) PGP_EP_LOADB(1) PGP_EP_LOADB(2) PGP_EP_LOADB(3)
 #undef PGP_EP_LOADB
-                        default: break;
+                            default: break;
+                        }
                     }
                 }
                 if (16 * kc + 4 * kq < nb) {
+                    const bool act = own_a || (kq == 3 && own_b);
+                    if (act) {
 #pragma unroll 1
-                    for (int kb = 0; kb < kbn; ++kb) {
-                        const int k = 16 * kc + 4 * kq + kb;
-                        if (k < nb) u_site(k, kc, IntC<kq>{}, IntC<(kq + 1) & 3>{}, std::integral_constant<bool, kq == 3>{}, kb == 3, false, (kb + 1) & 3);
+                        for (int kb = 0; kb < kbn; ++kb) {
+                            const int k = 16 * kc + 4 * kq + kb;
+                            if (k < nb) u_site(k, kc, IntC<kq>{}, IntC<(kq + 1) & 3>{}, std::integral_constant<bool, kq == 3>{}, own_a, own_b, own_a,
+                                               kb == 3, false, (kb + 1) & 3);
+                        }
+                        if constexpr (kq == 3) {  // site 16 kc + 15: the next column is column 0 of the NEXT tile column
+                            const int k = 16 * kc + 15;
+                            if (k < nb) u_site(k, kc, IntC<0>{}, IntC<0>{}, std::true_type{}, own_a, own_b, kc < 7 ? own_b : own_a, false, true, 0);
+                        }
                     }
-                    if constexpr (kq == 3) {      // site 16 kc + 15: the next column is column 0 of the NEXT tile column
-                        const int k = 16 * kc + 15;
-                        if (k < nb) u_site(k, kc, IntC<0>{}, IntC<0>{}, std::true_type{}, false, true, 0);
-                    }
-                    u_group(16 * kc + 4 * kq);
+                    u_group(16 * kc + 4 * kq, !act);
                 }
             });
             // tile column kc goes back to the accumulators (the later groups update it there); its successor becomes the panel
-            switch (kc) {
+            if (own_a) {
+                switch (kc & 3) {
 #define PGP_EP_STOREA(J) case J: { _Pragma("unroll") for (int I = 0; I < 3; ++I) A[I][J] = Pa[I]; } break;
-                PGP_EP_STOREA(0) PGP_EP_STOREA(1) PGP_EP_STOREA(2) PGP_EP_STOREA(3) PGP_EP_STOREA(4) PGP_EP_STOREA(5) PGP_EP_STOREA(6) PGP_EP_STOREA(7)
+                    PGP_EP_STOREA(0) PGP_EP_STOREA(1) PGP_EP_STOREA(2) PGP_EP_STOREA(3)
 #undef PGP_EP_STOREA
-                default: break;
+                    default: break;
+                }
             }
 #pragma unroll
             for (int I = 0; I < 3; ++I) Pa[I] = Pb[I];
@@ -489,16 +529,27 @@ __global__ __launch_bounds__(256) void ep_chain_kernel(const double* __restrict_
             const double di = live ? s_dt[i] : 0.0;
             double acc = 0.0;
 #pragma unroll
-            for (int J = 0; J < 8; ++J)
+            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * J + l4 + 4 * r;
+                    const int j = 16 * (4 * half + jj) + l4 + 4 * r;
                     const double hj = fma(-s_dt[j], s_mu0[j], s_dn[j]);
-                    acc = fma(A[I][J][r], hj, acc);
-                    if (live) Wout[i + (long)EPB * j] = (i == j ? di : 0.0) - di * s_dt[j] * A[I][J][r];
+                    acc = fma(A[I][jj][r], hj, acc);
+                    if (live) Wout[i + (long)EPB * j] = (i == j ? di : 0.0) - di * s_dt[j] * A[I][jj][r];
                 }
             acc += __shfl_xor(acc, 16, 64); acc += __shfl_xor(acc, 32, 64);
-            if (live && l4 == 0) gout[i] = fma(-di, acc, fma(-di, s_mu0[i], s_dn[i]));
+            if (l4 == 0) gpart[half][48 * u + 16 * I + l15] = acc;
+        }
+        __syncthreads();
+        if (half == 0 && l4 == 0) {
+#pragma unroll
+            for (int I = 0; I < 3; ++I) {
+                const int i = 48 * u + 16 * I + l15;
+                if (i < EPB) {
+                    const double di = s_dt[i];
+                    gout[i] = fma(-di, gpart[0][i] + gpart[1][i], fma(-di, s_mu0[i], s_dn[i]));
+                }
+            }
         }
         __syncthreads();
     }
@@ -964,7 +1015,7 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
                     hipLaunchKernelGGL(ep_prep_kernel, dim3(36), dim3(256), 0, sa, w.Sig, np, i0, w.S, Wp, gp, w.mu_d);
                     HIP_TRY(hipEventRecord(evP(b), sa));
                 }
-                hipLaunchKernelGGL(ep_chain_kernel, dim3(1), dim3(256), 0, sa, w.Sig, np, i0, nb, w.mu_d, w.m_d, c->y_dev, w.ttau_d,
+                hipLaunchKernelGGL(ep_chain_kernel, dim3(1), dim3(512), 0, sa, w.Sig, np, i0, nb, w.mu_d, w.m_d, c->y_dev, w.ttau_d,
                                    w.tnu_d, Wb, gb, w.ldb + b, yfl, ep_timing && b == 5 ? (long long*)(w.gb + 2 * EPB) : (long long*)nullptr);
                 HIP_TRY(hipEventRecord(evC(b), sa));
                 const bool last = b + 1 >= nbl;
