@@ -7,7 +7,8 @@ import numpy as np
 from pygps_amd import _lib
 
 lib = _lib.load()
-sizes = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 8192, 12288, 16384, 24576, 32768]
+sizes = [int(a) for a in sys.argv[1:] if '=' not in a] or [1024, 2048, 4096, 8192, 12288, 16384, 24576, 32768]
+OPTS = [a.split('=') for a in sys.argv[1:] if '=' in a]
 d = 16
 for N in sizes:
     rng = np.random.RandomState(0)
@@ -16,6 +17,8 @@ for N in sizes:
     h = C.c_void_p()
     assert lib.pgp_init(0, C.byref(h)) == 0
     assert lib.pgp_set_data(h, _lib.ptr(x), N, d, _lib.ptr(y)) == 0
+    for k_, v_ in OPTS:
+        assert lib.pgp_set_option(h, k_.encode(), int(v_)) == 0
     hyp = np.array([np.log(np.sqrt(d)), 0.0]); m = np.full(N, y.mean()); dm = np.ones((1, N))
     alpha = np.zeros(N); nlZ = np.zeros(1); g = np.zeros(4)
     ts = []
