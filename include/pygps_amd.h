@@ -120,6 +120,15 @@ int pgp_ep_fit(pgp_ctx* ctx, int kind, const double* covhyp, int ncov, int para,
                const double* dm, int nmean, int want, int warm, double* ttau, double* tnu, double* alpha_out,
                double* sW_out, double* nlZ_out, double* dnlZ_out, int* sweeps_out, pgp_factor** factor_out);
 
+/* EP.evaluate (Core/inf.py:723-806) from a CALLER-BUILT covariance matrix: the covariance trees of Core/cov.py:230-328 that are
+ * not device programs.  K (n, n) symmetric row-major host; n, y as set by pgp_set_data (x is not used).  dnlZ_mean_out: nmean + 1
+ * entries (mean gradients, then 0: lik.Erf has no hyper-parameter).  want = 3 leaves sW sW' o B^-1 and alpha in the context's
+ * workspace: pgp_dense_grad_term(ctx, dK_h, n, 0.0, &g) directly afterwards gives dnlZ.cov[h] (Core/inf.py:780-786).
+ * Other arguments and status codes as pgp_ep_fit. */
+int pgp_ep_fit_dense(pgp_ctx* ctx, const double* K, const double* mvec, const double* dm, int nmean, int want, int warm,
+                     double* ttau_io, double* tnu_io, double* alpha_out, double* sW_out, double* nlZ_out,
+                     double* dnlZ_mean_out, int* sweeps_out, pgp_factor** factor_out);
+
 /* ---- FITC sparse regression: FITC_Exact.evaluate (Core/inf.py:398-455) with FITCOfKernel (Core/cov.py:332-390)
  * x, y of the last pgp_set_data; xu (nu,d) inducing inputs.  alpha_out (nu), L_out (nu,nu) = post.L (dense,
  * symmetric; NULL to skip), dnlZ_out = [mean.., cov.., lik].  snu2 = 1e-6 sn2 like the reference (inf.py:410).

@@ -51,6 +51,8 @@ SIGNATURES = {
     "pgp_predict_dense": (C.c_int, [_vp, _vp, _dp, _i64, _dp, _dp, _dp, _dp]),
     "pgp_ep_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
                              _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "pgp_ep_fit_dense": (C.c_int, [_vp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp,
+                                   C.POINTER(C.c_int), C.POINTER(_vp)]),
     "pgp_fitc_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _i64, _dp, _dp, C.c_int,
                                C.c_int, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
     "pgp_fitc_predict": (C.c_int, [_vp, _vp, _dp, _i64, _dp, _dp, _dp]),

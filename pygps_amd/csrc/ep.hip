@@ -868,26 +868,34 @@ extern "C" int pgp_test_probit_hazard(pgp_ctx* c, const double* z, double* out, 
 }
 
 
-extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para, int flags, const double* mvec,
-                          const double* dm, int nmean, int want, int warm, double* ttau_io, double* tnu_io,
-                          double* alpha_out, double* sW_out, double* nlZ_out, double* dnlZ_out, int* sweeps_out,
-                          pgp_factor** factor_out) {
+// The EP fit.  Kdense == nullptr: K is a device program (kind, covhyp, ...) assembled on the device, the gradients come back in
+// dnlZ_out.  Kdense != nullptr (pgp_ep_fit_dense): K (n x n, symmetric, host) is handed in -- a covariance tree that is not
+// a device program --; dnlZ_out receives the mean gradients only, and R = sW sW' o B^-1 and alpha stay in the context's
+// workspace for the pgp_dense_grad_term calls that follow (1/2 sum (R - alpha alpha') o dK_h, inf.py:780-786).
+static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double* covhyp, int ncov, int para, int flags,
+                       const double* mvec, const double* dm, int nmean, int want, int warm, double* ttau_io, double* tnu_io,
+                       double* alpha_out, double* sW_out, double* nlZ_out, double* dnlZ_out, int* sweeps_out,
+                       pgp_factor** factor_out) {
     if (!c) return -1;
     if (c->n <= 0) return -1;
-    if (!covhyp) return -3;
+    if (!covhyp && !Kdense) return -3;
     if (!ttau_io || !tnu_io) return -12;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->st;
     const long n = c->n, d = c->d, np = c->np, ldf = c->ldf;
+    const bool dense = Kdense != nullptr;
     CovSpec cp;
-    { const int rc = make_spec(c, kind, covhyp, ncov, para, flags, -1, d, cp); if (rc != PGP_OK) return rc == -11 ? -10 : rc; }
+    if (dense) ncov = 0;
+    else { const int rc = make_spec(c, kind, covhyp, ncov, para, flags, -1, d, cp); if (rc != PGP_OK) return rc == -11 ? -10 : rc; }
     const std::vector<double>& sc = cp.scale;
     CHK(ensure_workspace(c, np));
     double kdiag = 0.0;                               // K_ii, identical for every training point (stationary kernels)
-    CHK(cov_point_value(c, cp, 1, &kdiag));
     double kss = 0.0;
-    CHK(cov_point_value(c, cp, 2, &kss));
-    const long need = hadamard_partial_count(np, ncov);
+    if (!dense) {
+        CHK(cov_point_value(c, cp, 1, &kdiag));
+        CHK(cov_point_value(c, cp, 2, &kss));
+    }
+    const long need = std::max<long>(hadamard_partial_count(np, ncov), np);
     if (want >= 3 && c->partial_cap < need) {
         if (c->partial) (void)hipFree(c->partial);
         c->partial = nullptr; c->partial_cap = 0;      // a failed realloc must not leave a dangling pointer behind
@@ -933,8 +941,11 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     FactorGuard fguard(c, w.F, (size_t)ldf * np * sizeof(double), /*scrub=*/true);
     stamp("scratch acquired");
     // ---- K (full symmetric, padded with zeros) --------------------------------------------------------
-    EP_TRY(upload_scaled(c, c->x_dev, n, d, sc, c->XsT, np, c->dpad, c->scale_dev));
-    EP_TRY(cov_sym_launch(c->XsT, np, n, c->dpad, cp, w.Kd, st, np));
+    if (dense) HIP_TRY(hipMemcpy2DAsync(w.Kd, np * sizeof(double), Kdense, n * sizeof(double), n * sizeof(double), n, hipMemcpyHostToDevice, st));
+    else {
+        EP_TRY(upload_scaled(c, c->x_dev, n, d, sc, c->XsT, np, c->dpad, c->scale_dev));
+        EP_TRY(cov_sym_launch(c->XsT, np, n, c->dpad, cp, w.Kd, st, np));
+    }
     std::vector<double> m(n, 0.0), y(n), ttau(n, 0.0), tnu(n, 0.0), mu(n, 0.0), dsig(n, kdiag);
     if (mvec) memcpy(m.data(), mvec, n * sizeof(double));
     HIP_TRY(hipMemcpyAsync(y.data(), c->y_dev, n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -945,8 +956,10 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     {   // the same per-site kernel with mu = 0, Sigma_ii = K_ii, zero site parameters: lZ_i = lik(y_i, m_i, K_ii)
         const long nbt = (n + 255) / 256;
         std::vector<double> ph(5 * nbt);
+        if (dense) EP_TRY(gather_strided_launch(w.Kd, np + 1, np, w.diag_d, st));          // K_ii differs from point to point
         hipLaunchKernelGGL(ep_site_terms_kernel, dim3((unsigned)nbt), dim3(256), 0, st, n, c->y_dev, w.m_d, (const double*)nullptr,
-                           (const double*)nullptr, kdiag, (const double*)nullptr, (const double*)nullptr, 1, w.tmp_d, (double*)nullptr);
+                           dense ? (const double*)w.diag_d : (const double*)nullptr, kdiag, (const double*)nullptr, (const double*)nullptr,
+                           1, w.tmp_d, (double*)nullptr);
         HIP_TRY(hipMemcpyAsync(ph.data(), w.tmp_d, ph.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (long b = 0; b < nbt; ++b) nlZ0 -= ph[5 * b];
@@ -1150,7 +1163,11 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
         HIP_TRY(hipMemsetAsync(c->alpha_dev, 0, np * sizeof(double), st));
         HIP_TRY(hipMemcpyAsync(c->alpha_dev, alpha.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
         // F = alpha alpha' - sW sW' o B^-1 ; dnlZ.cov[j] = -sum(F o dK_j)/2 = sum((sW sW' o B^-1 - alpha alpha') o dK_j)/2
-        if (c->ep_fused == 1 && w.Ed) {
+        if (dense) {
+            // R = sW sW' o B^-1 stays in the workspace: the caller hands the derivative matrices in one at a time
+            hipLaunchKernelGGL(ep_r_from_sigma_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Sig, np, np,
+                               w.ttau_d, c->Binv, np);
+        } else if (c->ep_fused == 1 && w.Ed) {
             // Ed holds diag(sW) L^-T of the final parameters: (diag(sW) E)(diag(sW) E)' = sW sW' o B^-1 in one product
             EP_TRY(eet_lower(c, w.Ed, np, c->Binv, np, np));
             EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
@@ -1166,8 +1183,8 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
             EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
                                           c->scal + 8, st, w.s_d));
         }
-        std::vector<double> g(ncov + 1);
-        HIP_TRY(hipMemcpyAsync(g.data(), c->scal + 8, (ncov + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+        std::vector<double> g(ncov + 1, 0.0);
+        if (!dense) HIP_TRY(hipMemcpyAsync(g.data(), c->scal + 8, (ncov + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (nmean > 0) {                              // d lZ_j / d mu on the device (inf.py:788-790: no m term in nu_n), dot with dm on the host
             std::vector<double> dl(n);
@@ -1193,15 +1210,18 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     if (factor_out) {
         FactorHandleGuard hg(c, new pgp_factor());
         pgp_factor* f = hg.f;
-        f->n = n; f->np = np; f->ldf = ldf; f->F = fguard.release(); f->dpad = c->dpad; f->d = (int)d; f->cs = cp; f->kss = kss;
-        f->sn2 = 1.0; f->sw = 1.0; f->Wd = nullptr;
+        f->n = n; f->np = np; f->ldf = ldf; f->F = fguard.release(); f->dpad = dense ? 0 : c->dpad; f->d = dense ? 0 : (int)d; f->kss = kss;
+        if (!dense) f->cs = cp;
+        f->sn2 = 1.0; f->sw = 1.0; f->Wd = nullptr; f->XsT = nullptr;
         CHK(spool_take(c, np * sizeof(double), (void**)&f->alpha));
         HIP_TRY(hipMemsetAsync(f->alpha, 0, np * sizeof(double), st));
         HIP_TRY(hipMemcpyAsync(f->alpha, alpha.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
         CHK(spool_take(c, np * sizeof(double), (void**)&f->sWv));
         HIP_TRY(hipMemcpyAsync(f->sWv, sW.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
-        CHK(spool_take(c, (size_t)c->dpad * np * sizeof(double), (void**)&f->XsT));
-        HIP_TRY(hipMemcpyAsync(f->XsT, c->XsT, (size_t)c->dpad * np * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (!dense) {
+            CHK(spool_take(c, (size_t)c->dpad * np * sizeof(double), (void**)&f->XsT));
+            HIP_TRY(hipMemcpyAsync(f->XsT, c->XsT, (size_t)c->dpad * np * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
         HIP_TRY(hipStreamSynchronize(st));
         *factor_out = hg.release();
     } else {
@@ -1210,4 +1230,25 @@ extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, 
     }
     return PGP_OK;
 #undef EP_TRY
+}
+
+extern "C" int pgp_ep_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para, int flags, const double* mvec,
+                          const double* dm, int nmean, int want, int warm, double* ttau_io, double* tnu_io,
+                          double* alpha_out, double* sW_out, double* nlZ_out, double* dnlZ_out, int* sweeps_out,
+                          pgp_factor** factor_out) {
+    if (!covhyp) return -3;
+    return ep_fit_core(c, nullptr, kind, covhyp, ncov, para, flags, mvec, dm, nmean, want, warm, ttau_io, tnu_io, alpha_out, sW_out,
+                       nlZ_out, dnlZ_out, sweeps_out, factor_out);
+}
+
+// EP.evaluate from a CALLER-BUILT covariance matrix K (n x n, symmetric, row-major host; n and y as set by pgp_set_data): the
+// covariance trees that are not device programs.  dnlZ_mean_out (nmean + 1 entries: the mean gradients, then 0 for lik.Erf);
+// the covariance gradients follow from pgp_dense_grad_term(ctx, dK_h, n, 0.0, &g) calls made directly afterwards
+// (want = 3): g = 1/2 sum (sW sW' o B^-1 - alpha alpha') o dK_h  (Core/inf.py:780-786).
+extern "C" int pgp_ep_fit_dense(pgp_ctx* c, const double* K, const double* mvec, const double* dm, int nmean, int want, int warm,
+                                double* ttau_io, double* tnu_io, double* alpha_out, double* sW_out, double* nlZ_out,
+                                double* dnlZ_mean_out, int* sweeps_out, pgp_factor** factor_out) {
+    if (!K) return -2;
+    return ep_fit_core(c, K, 0, nullptr, 0, 0, 0, mvec, dm, nmean, want, warm, ttau_io, tnu_io, alpha_out, sW_out, nlZ_out,
+                       dnlZ_mean_out, sweeps_out, factor_out);
 }

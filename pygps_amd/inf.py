@@ -369,7 +369,9 @@ class EP(Inference):
         if not isinstance(likfunc, _lik.Erf):
             raise NotImplementedError("pygps_amd: EP runs on the device for lik.Erf only (no CPU fallback)")
         dev = _lib.default_device() if self.device is None else self.device
-        kind, para, flags = _device_kernel(covfunc, _lib.ctx(dev))
+        dense = isinstance(covfunc, _cov._Composite) and not covfunc._on_device()
+        if not dense:
+            kind, para, flags = _device_kernel(covfunc, _lib.ctx(dev))
         x = _lib.f64(x)
         n, D = x.shape
         y = _lib.f64(y).reshape(n)
@@ -378,6 +380,8 @@ class EP(Inference):
         m, dm, nm = _mean_inputs(meanfunc, x)
         hyp = _lib.f64(np.asarray(covfunc.hyp, dtype=float))
         nc = len(hyp)
+        if dense:
+            return self._evaluate_dense(meanfunc, covfunc, likfunc, x, n, m, dm, nm, nc, dev, nargout)
         warm = self.last_ttau is not None
         ttau = _lib.f64(self.last_ttau).reshape(n).copy() if warm else np.zeros(n)
         tnu = _lib.f64(self.last_tnu).reshape(n).copy() if warm else np.zeros(n)
@@ -407,6 +411,51 @@ class EP(Inference):
             dnlZ = dnlZStruct(meanfunc, covfunc, likfunc)
             dnlZ.mean = [np.float64(v) for v in g[:nm]]
             dnlZ.cov = [np.float64(v) for v in g[nm:nm + nc]]
+            dnlZ.lik = []
+            return post, np.float64(nlZ[0]), dnlZ
+        return post, np.float64(nlZ[0])
+
+
+    def _evaluate_dense(self, meanfunc, covfunc, likfunc, x, n, m, dm, nm, nc, dev, nargout):
+        """Covariance functions that are not device programs (Core/cov.py:230-328 composes anything): K and the derivative
+        matrices come from getCovMatrix / getDerMatrix, the site sweeps, the posterior, alpha, nlZ and every Hadamard sum
+        1/2 sum((sW sW' o B^-1 - alpha alpha') o dK_h) (Core/inf.py:780-786) run on the device."""
+        lib = _lib.load()
+        ctx = _lib.ctx(dev)
+        K = _lib.f64(covfunc.getCovMatrix(x=x, mode="train"))
+        warm = self.last_ttau is not None
+        ttau = _lib.f64(self.last_ttau).reshape(n).copy() if warm else np.zeros(n)
+        tnu = _lib.f64(self.last_tnu).reshape(n).copy() if warm else np.zeros(n)
+        alpha = np.empty(n)
+        sW = np.empty(n)
+        nlZ = np.zeros(1)
+        g = np.zeros(nm + 1)
+        sweeps = C.c_int()
+        fh = C.c_void_p()
+        want = int(min(max(nargout, 1), 3))
+        _lib.check(lib.pgp_ep_fit_dense(ctx, _lib.ptr(K), _lib.ptr(m), _lib.ptr(dm), nm, want, int(warm), _lib.ptr(ttau),
+                                        _lib.ptr(tnu), _lib.ptr(alpha), _lib.ptr(sW), _lib.ptr(nlZ), _lib.ptr(g),
+                                        C.byref(sweeps), C.byref(fh)), "pgp_ep_fit_dense")
+        del K
+        self.sweeps = sweeps.value
+        if self.sweeps == 10:
+            logging.getLogger(__name__).warning("maximum number of sweeps reached in function infEP")
+        self.last_ttau = ttau.reshape(n, 1)
+        self.last_tnu = tnu.reshape(n, 1)
+        post = postStruct()
+        post.alpha = alpha.reshape(n, 1)
+        post.sW = sW.reshape(n, 1)
+        post.L = DeviceFactor(fh, n, dev, _lib.current_slot())
+        post.L.dense = True                          # predict hands the cross-covariance block in (GP._latent)
+        if nargout > 2:
+            dnlZ = dnlZStruct(meanfunc, covfunc, likfunc)
+            gh = np.zeros(1)
+            dnlZ.cov = []
+            for h in range(nc):                                                   # one derivative matrix at a time
+                dK = _lib.f64(covfunc.getDerMatrix(x=x, mode="train", der=h))
+                _lib.check(lib.pgp_dense_grad_term(ctx, _lib.ptr(dK), n, 0.0, _lib.ptr(gh)), "pgp_dense_grad_term")
+                dnlZ.cov.append(np.float64(gh[0]))
+            dnlZ.mean = [np.float64(v) for v in g[:nm]]
             dnlZ.lik = []
             return post, np.float64(nlZ[0]), dnlZ
         return post, np.float64(nlZ[0])

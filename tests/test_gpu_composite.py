@@ -208,6 +208,44 @@ def test_composite_limits_and_ard_leaves():
     assert relerr(nlZ, out["nlZ"]) < 1e-10 and relerr(dnlZ.cov, out["dnlZ_cov"]) < 1e-8
 
 
+def test_ep_on_a_tree_that_is_no_device_program():
+    """GPC + EP with a covariance tree the device programs cannot hold (three ARD leaves; nine leaves): K and the derivative
+    matrices are handed in (pgp_ep_fit_dense, pgp_dense_grad_term), sweeps, posterior, alpha, nlZ, the gradient sums and the
+    predictive solve run on the device -- against the oracle's EP (Core/inf.py:731-806), ragged n, with a warm start."""
+    import pygps_amd as pyGPs
+    from pygps_amd import cov
+    rng = np.random.RandomState(3)
+    for n in (150, 333):
+        x = rng.randn(n, 2)
+        y = np.sign(np.sin(1.7 * x[:, :1]) + 0.3 * x[:, 1:2] + 0.2 * rng.randn(n, 1)); y[y == 0] = 1
+        ard = cov.RBFard(D=2) * cov.RQard(D=2) + cov.RBFard(D=2)
+        ard.hyp = list(0.3 * rng.randn(len(ard.hyp)))
+        t3 = ("sum", ("prod", ("leaf", O.RBFARD, 0), ("leaf", O.RQARD, 0)), ("leaf", O.RBFARD, 0))
+        big = cov.RBF(0.1, 0.0)
+        tbig = ("leaf", O.RBF, 0)
+        for i in range(8):
+            big = big + cov.RBF(0.1 * i, -0.2)
+            tbig = ("sum", tbig, ("leaf", O.RBF, 0))
+        xs = rng.randn(11, 2)
+        for k, tree in ((ard, t3), (big, tbig)):
+            assert not k._on_device()
+            m = pyGPs.GPC()
+            m.setPrior(mean=pyGPs.mean.Zero(), kernel=k)
+            nlZ, dnlZ, post = m.getPosterior(x, y)
+            hyp = np.array(k.hyp, float)
+            ref = O.ep_fit(tree, hyp, 0, x, y, np.zeros_like(y), matern_reference_compat=False)
+            assert m.inffunc.sweeps == ref["sweeps"]
+            assert relerr(nlZ, ref["nlZ"]) < 1e-8, (n, nlZ, ref["nlZ"])
+            assert relerr(post.alpha, ref["alpha"]) < 1e-6 and relerr(post.sW, ref["sW"]) < 1e-6
+            assert relerr(dnlZ.cov, ref["dnlZ_cov"]) < 1e-6
+            ym, ys2, fm, fs2, lp = m.predict(xs)
+            rym, rys2, rfm, rfs2 = O.predict(tree, hyp, 0, None, x, ref["alpha"], ref["L"], ref["sW"], xs, np.zeros((11, 1)), gauss=False,
+                                             faithful=False)
+            assert relerr(fm, rfm) < 1e-7 and relerr(fs2, rfs2) < 1e-6
+            nlZ2, dnlZ2, post2 = m.getPosterior(x, y)                      # warm start from the converged sites: the same optimum
+            assert relerr(nlZ2, nlZ) < 1e-6
+
+
 def test_periodic_needs_1d_inputs():
     from pygps_amd import cov
     with pytest.raises(AssertionError):
