@@ -19,6 +19,12 @@ grep '^{' $O/s1.json > $O/final/r03_bench_streams1_under_rocprof.json; cp $(ksta
 # 2b. the same for the timed (two fit streams) configuration: kernel time sums overlap there
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python $R/bench.py --no-cpu-baseline --no-extras > $O/s2.json 2> $O/stats2.err
 grep '^{' $O/s2.json > $O/final/r03_bench_streams2_under_rocprof.json; cp $(kstats $O/stats2) $O/final/r03_bench_streams2_kernel_stats.csv
+# (un-profiled timing runs come BEFORE the --pmc passes: right after a counter pass the next process starts at a fraction of the
+#  clock for a few seconds -- measured: the N = 8192 fit of tools/sharded_time.py 10x slow directly behind xcd_decision.py)
+# 2c. the sharded fit at world 1 against the single-GPU fit
+timeout 900 python $R/tools/sharded_time.py 8192 16384 32768 65536 2> $O/sharded.err | grep "N=" > $O/final/r03_sharded_fit_world1.txt
+# 2d. single- and two-stream rates of the raw C-ABI loop
+NSTREAMS=1,2 timeout 300 python $R/tools/two_streams.py 2> /dev/null | grep fits > $O/final/r03_two_streams.txt
 # 3. PMC traffic of gemm_f64 (separate passes, single stream)
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
@@ -38,8 +44,4 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 cp $(ccsv $O/asm_w) $O/final/r03_assembly_pmc_write_counter_collection.csv
 # 6. the XCD-aware tile order: same-box A/B of speed, L2-side fetch, MFMA-pipe busy cycles, L2 hit rate
 python $R/tools/xcd_decision.py $O > $O/final/r03_xcd_order_decision.json 2> $O/xcd.err
-# 7. the sharded fit at world 1 against the single-GPU fit
-timeout 900 python $R/tools/sharded_time.py 8192 16384 32768 65536 2> $O/sharded.err | grep "N=" > $O/final/r03_sharded_fit_world1.txt
-# 8. single- and two-stream rates of the raw C-ABI loop
-NSTREAMS=1,2 timeout 300 python $R/tools/two_streams.py 2> /dev/null | grep fits > $O/final/r03_two_streams.txt
 ls -la $O/final
