@@ -70,6 +70,9 @@ struct GemmArgs {
     // are resident on that CU.  yield_role 1 (bulk launches): the k-loop polls its CU's word once per stage and sleeps while it
     // is non-zero; yield_role 2 (the chain's own small GEMMs): the workgroup increments the word while it runs.
     unsigned* yield_flags; int yield_role;
+    // Tiles whose first row AND first column lie in [skip_lo, skip_hi) are left alone (0, 0: none): the diagonal block another
+    // kernel owns inside a whole-matrix update (EP's block sweep: the next block's tile belongs to its prep workgroups).
+    int skip_lo, skip_hi;
 };
 
 // index of the calling workgroup's CU in a yield-flag table (XCC id | shader engine, array, CU of HW_ID): < 4096

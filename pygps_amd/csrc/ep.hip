@@ -267,19 +267,130 @@ template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F&
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 __device__ __forceinline__ int lds_seq(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-__global__ __launch_bounds__(512) void ep_chain_kernel(const double* __restrict__ Sig, long ld, long i0, int nb,
-                                                        const double* __restrict__ mu, const double* __restrict__ m,
+struct EpChainLds {
+    __attribute__((aligned(16))) double colb[8][EPCP];     // column k of Sigma_BB before site k: ring over k mod 8
+    double diagb[2][EPB], mub[2][EPB];                     // diagonal and mu before site k, by parity of k
+    __attribute__((aligned(16))) double cq[16][2];         // (c_k, q_k): ring over k mod 16
+    double gpart[2][EPCP];                                 // epilogue: the two column halves of Sigma_BB,new h
+    __attribute__((aligned(32))) double prm[EPB][4];       // the sites' (ttau, tnu) of the previous sweep, m, y
+    double s_mu0[EPB], s_dt[EPB], s_dn[EPB], s_tn[EPB], s_nn[EPB];
+    int seqC, seqP, seqG;             // sites wave 0 has finished ; 3 x sites the update waves have passed on ; 6 x groups read
+};
+struct EpPrepLds {
+    double Xr[16][EPB + 1], Xc[16][EPB + 1], T[16][EPB + 1], red[4][16][17], gl[EPB];
+};
+constexpr size_t EP_BLOCK_LDS = sizeof(EpPrepLds) > sizeof(EpChainLds) ? sizeof(EpPrepLds) : sizeof(EpChainLds);
+
+// prep(b -> b+1): the diagonal tile and the mu entries of the NEXT block, brought up to date in place:
+//   Sigma(B', B') -= X W X',  mu(B') += X g,   X = strip(B', :) = Sigma(B', B) before the block.   36 workgroups: the 16 x 16
+// output tiles on or below the diagonal (the lower triangle is the one kept current); T = X_rows W (16 x 128, K = 128: each wave
+// two column tiles, W straight from global memory as the MFMA operand), then T X_cols' with K split over the four waves.
+// The tile also goes, mirrored, into the rows B' of the NEXT strip buffer (Snext(r, k) = Sigma(r, r0 + k)): the strip kernel of
+// block b+1 then has nothing to wait for (it skips these rows).  It sits between two chains, on the critical path of the sweep:
+// workgroups 1 .. 36 of the launch whose workgroup 0 is the chain of block b+1, 256 of their 512 threads.
+__device__ __forceinline__ void ep_prep_body(int blk, double* __restrict__ Sig, long ld, long r0, const double* __restrict__ S,
+                                             double* __restrict__ Snext, const double* __restrict__ W, const double* __restrict__ g,
+                                             double* __restrict__ mu, EpPrepLds& L) {
+    int bi = 0, rem = blk;
+    while (rem > bi) { rem -= bi + 1; ++bi; }
+    const int bj = rem;                                  // bi >= bj
+    auto& Xr = L.Xr; auto& Xc = L.Xc; auto& T = L.T; auto& red = L.red; auto& gl = L.gl;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+    // every global read is issued up front (a chain of memory round trips otherwise): the 64 W operands of this lane, its 16
+    // strip entries, the output entry it will update
+    const double* w0 = W + 16 * (2 * wv) + l15 + (long)EPB * l4;              // W(q, kk) at W[kk + 128 q]
+    double wx[EPB / 4][2];
+#pragma unroll
+    for (int ks = 0; ks < EPB / 4; ++ks) { wx[ks][0] = w0[(long)EPB * 4 * ks]; wx[ks][1] = w0[(long)EPB * 4 * ks + 16]; }
+    double xr[8], xc[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const int e = t + 256 * v, ii = e & 15, q = e >> 4;
+        xr[v] = S[r0 + 16 * bi + ii + (long)q * ld];
+        xc[v] = S[r0 + 16 * bj + ii + (long)q * ld];
+    }
+    const long orow = r0 + 16 * bi + (t >> 4), ocol = r0 + 16 * bj + (t & 15);
+    const double old = Sig[orow + ocol * ld];
+    const double gk = t < EPB ? g[t] : 0.0;
+    double muold = 0.0;
+    if (bi == bj && t < 16) muold = mu[r0 + 16 * bi + t];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const int e = t + 256 * v, ii = e & 15, q = e >> 4;
+        Xr[ii][q] = xr[v]; Xc[ii][q] = xc[v];
+    }
+    if (t < EPB) gl[t] = gk;
+    __syncthreads();
+    {
+        double4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int ks = 0; ks < EPB / 4; ++ks) {
+            const double y = Xr[l15][4 * ks + l4];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx[ks][0], y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx[ks][1], y, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[l15][16 * (2 * wv + q) + l4 + 4 * r] = acc[q][r];
+    }
+    __syncthreads();
+    {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int k = 32 * wv + 4 * ks + l4;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xc[l15][k], T[l15][k], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][l15][l4 + 4 * r] = acc[r];
+    }
+    __syncthreads();
+    {
+        const int ii = t >> 4, jj = t & 15;
+        const double out = ((red[0][ii][jj] + red[1][ii][jj]) + red[2][ii][jj]) + red[3][ii][jj];
+        if (orow >= ocol) {
+            const double nv = old - out;
+            Sig[orow + ocol * ld] = nv;
+            Snext[orow + (ocol - r0) * ld] = nv;
+            Snext[ocol + (orow - r0) * ld] = nv;
+        }
+    }
+    if (bi == bj && t < 16) {
+        double acc = 0.0;
+        for (int k = 0; k < EPB; ++k) acc = fma(Xr[t][k], gl[k], acc);
+        mu[r0 + 16 * bi + t] = muold + acc;
+    }
+}
+
+// One launch per block of sites: workgroup 0 = the chain of the block (below), workgroups 1 .. nprep = prep of THIS block from the
+// previous block's (W, g) -- the chain's workgroup sets itself up meanwhile and then waits for `pcnt` to reach `ptarget` (a
+// counter that only grows: 36 per launch).  One launch and one launch gap less per block than prep and chain as two kernels.
+__global__ __launch_bounds__(512) void ep_chain_kernel(double* __restrict__ Sig, long ld, long i0, int nb,
+                                                        double* __restrict__ mu, const double* __restrict__ m,
                                                         const double* __restrict__ y, double* __restrict__ ttau,
                                                         double* __restrict__ tnu, double* __restrict__ Wout,
                                                         double* __restrict__ gout, double* __restrict__ ldout,
-                                                        unsigned* yield_flags, long long* __restrict__ stamps) {
-    __shared__ __attribute__((aligned(16))) double colb[8][EPCP];     // column k of Sigma_BB before site k: ring over k mod 8
-    __shared__ double diagb[2][EPB], mub[2][EPB];                     // diagonal and mu before site k, by parity of k
-    __shared__ __attribute__((aligned(16))) double cq[16][2];         // (c_k, q_k): ring over k mod 16
-    __shared__ double gpart[2][EPCP];                                 // epilogue: the two column halves of Sigma_BB,new h
-    __shared__ __attribute__((aligned(32))) double prm[EPB][4];       // the sites' (ttau, tnu) of the previous sweep, m, y
-    __shared__ double s_mu0[EPB], s_dt[EPB], s_dn[EPB], s_tn[EPB], s_nn[EPB];
-    __shared__ int seqC, seqP, seqG;             // sites wave 0 has finished ; 3 x sites the update waves have passed on ; 6 x groups read
+                                                        unsigned* yield_flags, long long* __restrict__ stamps,
+                                                        const double* __restrict__ Sprev, double* __restrict__ Snext,
+                                                        const double* __restrict__ Wp, const double* __restrict__ gp,
+                                                        unsigned* pcnt, unsigned ptarget) {
+    extern __shared__ __attribute__((aligned(32))) double ep_smem[];
+    if (blockIdx.x > 0) {
+        if (threadIdx.x < 256) {
+            ep_prep_body((int)blockIdx.x - 1, Sig, ld, i0, Sprev, Snext, Wp, gp, mu, *reinterpret_cast<EpPrepLds*>(ep_smem));
+            __syncthreads();                     // (every wave's stores have left before thread 0 publishes them)
+            if (threadIdx.x == 0) {
+                __threadfence();
+                __hip_atomic_fetch_add(pcnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    EpChainLds& L = *reinterpret_cast<EpChainLds*>(ep_smem);
+    auto& colb = L.colb; auto& diagb = L.diagb; auto& mub = L.mub; auto& cq = L.cq; auto& gpart = L.gpart; auto& prm = L.prm;
+    auto& s_mu0 = L.s_mu0; auto& s_dt = L.s_dt; auto& s_dn = L.s_dn; auto& s_tn = L.s_tn; auto& s_nn = L.s_nn;
+    int& seqC = L.seqC; int& seqP = L.seqP; int& seqG = L.seqG;
     pgp_yield_mark(yield_flags, +1);
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -295,8 +406,19 @@ __global__ __launch_bounds__(512) void ep_chain_kernel(const double* __restrict_
         const bool live = t < nb;
         prm[t][0] = live ? ttau[i0 + t] : 0.0; prm[t][1] = live ? tnu[i0 + t] : 0.0;
         prm[t][2] = live ? m[i0 + t] : 0.0; prm[t][3] = live ? y[i0 + t] : 1.0;
-        s_mu0[t] = mu[i0 + t]; s_dt[t] = 0.0; s_dn[t] = 0.0; s_tn[t] = 0.0; s_nn[t] = 0.0;
-        diagb[0][t] = Sig[(i0 + t) + (i0 + t) * ld]; mub[0][t] = mu[i0 + t];
+        s_dt[t] = 0.0; s_dn[t] = 0.0; s_tn[t] = 0.0; s_nn[t] = 0.0;
+    }
+    // Sigma_BB and mu_B are this launch's prep workgroups' to finish
+    if (pcnt) {
+        if (t == 0) {
+            while (__hip_atomic_load(pcnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < ptarget) __builtin_amdgcn_s_sleep(4);
+            __threadfence();
+        }
+        __syncthreads();
+    }
+    if (t < EPB) {
+        s_mu0[t] = mu[i0 + t];
+        diagb[0][t] = Sig[(i0 + t) + (i0 + t) * ld]; mub[0][t] = s_mu0[t];
     }
     if (t < 8 * (EPCP - EPB)) colb[t / (EPCP - EPB)][EPB + t % (EPCP - EPB)] = 0.0;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -557,88 +679,13 @@ __global__ __launch_bounds__(512) void ep_chain_kernel(const double* __restrict_
     pgp_yield_mark(yield_flags, -1);
 }
 
-// prep(b -> b+1): the diagonal tile and the mu entries of the NEXT block, brought up to date in place:
-//   Sigma(B', B') -= X W X',  mu(B') += X g,   X = strip(B', :) = Sigma(B', B) before the block.   36 workgroups: the 16 x 16
-// output tiles on or below the diagonal (the lower triangle is the one kept current); T = X_rows W (16 x 128, K = 128: each wave
-// two column tiles, W straight from global memory as the MFMA operand), then T X_cols' with K split over the four waves.
-// It sits between two chain launches, on the critical path of the sweep.
-__global__ __launch_bounds__(256) void ep_prep_kernel(double* __restrict__ Sig, long ld, long r0, const double* __restrict__ S,
-                                                      const double* __restrict__ W, const double* __restrict__ g,
-                                                      double* __restrict__ mu) {
-    int bi = 0, rem = blockIdx.x;
-    while (rem > bi) { rem -= bi + 1; ++bi; }
-    const int bj = rem;                                  // bi >= bj
-    __shared__ double Xr[16][EPB + 1], Xc[16][EPB + 1], T[16][EPB + 1], red[4][16][17], gl[EPB];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l15 = lane & 15, l4 = lane >> 4;
-    // every global read of the kernel is issued up front (the kernel is a chain of memory round trips otherwise): the 64 W
-    // operands of this lane, its 16 strip entries, the output entry it will update
-    const double* w0 = W + 16 * (2 * wv) + l15 + (long)EPB * l4;              // W(q, kk) at W[kk + 128 q]
-    double wx[EPB / 4][2];
-#pragma unroll
-    for (int ks = 0; ks < EPB / 4; ++ks) { wx[ks][0] = w0[(long)EPB * 4 * ks]; wx[ks][1] = w0[(long)EPB * 4 * ks + 16]; }
-    double xr[8], xc[8];
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        const int e = t + 256 * v, ii = e & 15, q = e >> 4;
-        xr[v] = S[r0 + 16 * bi + ii + (long)q * ld];
-        xc[v] = S[r0 + 16 * bj + ii + (long)q * ld];
-    }
-    const long orow = r0 + 16 * bi + (t >> 4), ocol = r0 + 16 * bj + (t & 15);
-    const double old = Sig[orow + ocol * ld];
-    const double gk = t < EPB ? g[t] : 0.0;
-    double muold = 0.0;
-    if (bi == bj && t < 16) muold = mu[r0 + 16 * bi + t];
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        const int e = t + 256 * v, ii = e & 15, q = e >> 4;
-        Xr[ii][q] = xr[v]; Xc[ii][q] = xc[v];
-    }
-    if (t < EPB) gl[t] = gk;
-    __syncthreads();
-    {
-        double4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-#pragma unroll
-        for (int ks = 0; ks < EPB / 4; ++ks) {
-            const double y = Xr[l15][4 * ks + l4];
-            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx[ks][0], y, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wx[ks][1], y, acc[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) T[l15][16 * (2 * wv + q) + l4 + 4 * r] = acc[q][r];
-    }
-    __syncthreads();
-    {
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int k = 32 * wv + 4 * ks + l4;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xc[l15][k], T[l15][k], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wv][l15][l4 + 4 * r] = acc[r];
-    }
-    __syncthreads();
-    {
-        const int ii = t >> 4, jj = t & 15;
-        const double out = ((red[0][ii][jj] + red[1][ii][jj]) + red[2][ii][jj]) + red[3][ii][jj];
-        (void)ii; (void)jj;
-        if (orow >= ocol) Sig[orow + ocol * ld] = old - out;
-    }
-    if (bi == bj && t < 16) {
-        double acc = 0.0;
-        for (int k = 0; k < EPB; ++k) acc = fma(Xr[t][k], gl[k], acc);
-        mu[r0 + 16 * bi + t] = muold + acc;
-    }
-}
-
-// strip(:, k) = column i0 + k of the symmetric Sigma (kept in its lower triangle), all np rows.  Grid (np / 256, 8).
+// strip(:, k) = column i0 + k of the symmetric Sigma (kept in its lower triangle), all np rows but [skip0, skip1) (the block's own
+// rows when its prep workgroups have written them).  Grid (np / 256, 8).
 __global__ __launch_bounds__(256) void ep_strip_kernel(const double* __restrict__ Sig, long ld, long np, long i0,
-                                                       double* __restrict__ S) {
+                                                       double* __restrict__ S, long skip0, long skip1) {
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
     const int k0 = 16 * blockIdx.y;
-    if (r >= np) return;
+    if (r >= np || (r >= skip0 && r < skip1)) return;
     double v[16];
     if (r >= i0 + EPB) {
 #pragma unroll
@@ -655,21 +702,23 @@ __global__ __launch_bounds__(256) void ep_strip_kernel(const double* __restrict_
     for (int k = 0; k < 16; ++k) S[r + (long)(k0 + k) * ld] = v[k];
 }
 
-// mu_r += sum_k S(r, k) g_k for the rows rlo <= r < rhi (64 rows per workgroup, the columns split over the 4 waves, fixed order)
+// mu_r += sum_k S(r, k) g_k for the rows rlo <= r < rhi outside [skip0, skip1) (64 rows per workgroup, the columns split over the
+// 4 waves, fixed order)
 __global__ __launch_bounds__(256) void ep_mu_strip_kernel(const double* __restrict__ S, long ld, long rhi, long rlo,
-                                                          const double* __restrict__ g, double* __restrict__ mu) {
+                                                          const double* __restrict__ g, double* __restrict__ mu, long skip0, long skip1) {
     const long np = rhi;
     __shared__ double part[4][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long r = rlo + (long)blockIdx.x * 64 + lane;
+    const bool mine = r < np && !(r >= skip0 && r < skip1);
     double acc = 0.0;
-    if (r < np) {
+    if (mine) {
 #pragma unroll 4
         for (int k = grp * (EPB / 4); k < (grp + 1) * (EPB / 4); ++k) acc = fma(g[k], S[r + (long)k * ld], acc);
     }
     part[grp][lane] = acc;
     __syncthreads();
-    if (grp == 0 && r < np) mu[r] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (grp == 0 && mine) mu[r] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 // F (column-major lower, ldf) = I + s s' o K ; Y (column-major, ld np) = diag(s) K     (K symmetric, ld np)
@@ -741,8 +790,9 @@ struct EpWork {
     double* Ed;                          // fused path: E = L^-T from the sweep, then diag(sW) E
     double *Kd, *Sig, *Vd, *F, *Wd, *rhs;
     double *ttau_d, *tnu_d, *mu_d, *m_d, *s_d, *sbuf, *coef, *diag_d, *tmp_d;
-    double *S, *Sc;                      // block sweep: the strip Sigma(:, B) and U = strip W
+    double *S, *Sc;                      // block sweep: the strips Sigma(:, B) of the last two blocks and U = strip W
     double *Wb, *gb, *ldb;               // block sweep: W and g of the last two blocks, log of the blocks' determinant factors
+    unsigned* prep_cnt; unsigned prep_target;   // prep workgroups that have finished (a counter that only grows), and the count the next chain waits for
 };
 
 }  // namespace
@@ -931,11 +981,14 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
     w.ttau_d = vecs; w.tnu_d = vecs + np; w.mu_d = vecs + 2 * np; w.m_d = vecs + 3 * np; w.s_d = vecs + 4 * np;
     w.sbuf = vecs + 5 * np; w.coef = vecs + 6 * np; w.diag_d = vecs + 7 * np; w.tmp_d = vecs + 8 * np;
     HIP_TRY(hipMemsetAsync(vecs, 0, (size_t)10 * np * sizeof(double), st));
-    EP_TRY(dalloc(&w.S, (size_t)EPB * np * sizeof(double)));
+    EP_TRY(dalloc(&w.S, (size_t)2 * EPB * np * sizeof(double)));
     EP_TRY(dalloc(&w.Sc, (size_t)EPB * np * sizeof(double)));
     EP_TRY(dalloc(&w.Wb, (size_t)2 * EPB * EPB * sizeof(double)));
     EP_TRY(dalloc(&w.gb, (size_t)(2 * EPB + 16) * sizeof(double)));
-    EP_TRY(dalloc(&w.ldb, (size_t)(np / EPB + 1) * sizeof(double)));
+    EP_TRY(dalloc(&w.ldb, (size_t)(np / EPB + 2) * sizeof(double)));
+    w.prep_cnt = (unsigned*)(w.ldb + np / EPB + 1);
+    w.prep_target = 0u;
+    HIP_TRY(hipMemsetAsync(w.prep_cnt, 0, sizeof(double), st));
     HIP_TRY(hipMemsetAsync(w.Kd, 0, nn, st));
     EP_TRY(alloc_factor_buffer(c, np, ldf, &w.F));
     FactorGuard fguard(c, w.F, (size_t)ldf * np * sizeof(double), /*scrub=*/true);
@@ -1002,7 +1055,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
         ++sweep;
         if (c->ep_block) {
             // block sweep: chain stream (the high-priority panel stream) = prep(b) -> chain(b); bulk stream (main) = strip(b),
-            // U(b), fold(b), mu(b).  Events: S[b] strip(b) done, C[b] chain(b) done, P[b] prep(b) done.
+            // U(b), fold(b), mu(b).  Events: S[b] strip(b) done, C[b] chain(b) and prep(b+1) done.
             const long nbl = (n + EPB - 1) / EPB;
             hipStream_t sa = c->st2 ? c->st2 : st, sb = st;
             while ((long)c->ep_ev.size() < 3 * nbl + 1) {
@@ -1012,7 +1065,6 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
             }
             auto evS = [&](long b) { return c->ep_ev[3 * b]; };
             auto evC = [&](long b) { return c->ep_ev[3 * b + 1]; };
-            auto evP = [&](long b) { return c->ep_ev[3 * b + 2]; };
             unsigned* yfl = (c->yield && c->yield_flags) ? c->yield_flags : nullptr;
             HIP_TRY(hipEventRecord(c->ep_ev[3 * nbl], st));
             if (sa != st) HIP_TRY(hipStreamWaitEvent(sa, c->ep_ev[3 * nbl], 0));
@@ -1021,57 +1073,68 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
                 const int nb = (int)std::min<long>(EPB, n - i0);
                 double* Wb = w.Wb + (b & 1) * EPB * EPB;
                 double* gb = w.gb + (b & 1) * EPB;
-                if (b > 0) {
-                    const double* Wp = w.Wb + ((b - 1) & 1) * EPB * EPB;
-                    const double* gp = w.gb + ((b - 1) & 1) * EPB;
-                    HIP_TRY(hipStreamWaitEvent(sa, evS(b - 1), 0));
-                    hipLaunchKernelGGL(ep_prep_kernel, dim3(36), dim3(256), 0, sa, w.Sig, np, i0, w.S, Wp, gp, w.mu_d);
-                    HIP_TRY(hipEventRecord(evP(b), sa));
-                }
-                hipLaunchKernelGGL(ep_chain_kernel, dim3(1), dim3(512), 0, sa, w.Sig, np, i0, nb, w.mu_d, w.m_d, c->y_dev, w.ttau_d,
-                                   w.tnu_d, Wb, gb, w.ldb + b, yfl, ep_timing && b == 5 ? (long long*)(w.gb + 2 * EPB) : (long long*)nullptr);
-                HIP_TRY(hipEventRecord(evC(b), sa));
+                double* Sb = w.S + (b & 1) * EPB * np;  // strip(b); its rows B come from the prep workgroups of block b's launch
+                // chain stream: one launch per block -- workgroup 0 the chain, workgroups 1-36 prep from the previous block's (W, g)
+                if (b == 0)
+                    hipLaunchKernelGGL(ep_chain_kernel, dim3(1), dim3(512), EP_BLOCK_LDS, sa, w.Sig, np, i0, nb, w.mu_d, w.m_d, c->y_dev,
+                                       w.ttau_d, w.tnu_d, Wb, gb, w.ldb + b, yfl, (long long*)nullptr, (const double*)nullptr,
+                                       (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (unsigned*)nullptr, 0u);
                 const bool last = b + 1 >= nbl;
+                HIP_TRY(hipEventRecord(evC(b), sa));
                 if (last && !track) break;             // nothing of this sweep reads what the last block does to the rest
-                if (b > 0) HIP_TRY(hipStreamWaitEvent(sb, evP(b), 0));
-                hipLaunchKernelGGL(ep_strip_kernel, dim3((unsigned)((np + 255) / 256), 8), dim3(256), 0, sb, w.Sig, np, np, i0, w.S);
+                hipLaunchKernelGGL(ep_strip_kernel, dim3((unsigned)((np + 255) / 256), 8), dim3(256), 0, sb, w.Sig, np, np, i0, Sb,
+                                   b > 0 ? i0 : 0L, b > 0 ? i0 + EPB : 0L);
                 HIP_TRY(hipEventRecord(evS(b), sb));
+                if (!last) {
+                    const long i1 = i0 + EPB;
+                    const int nb1 = (int)std::min<long>(EPB, n - i1);
+                    HIP_TRY(hipStreamWaitEvent(sa, evS(b), 0));
+                    w.prep_target += 36u;
+                    hipLaunchKernelGGL(ep_chain_kernel, dim3(37), dim3(512), EP_BLOCK_LDS, sa, w.Sig, np, i1, nb1, w.mu_d, w.m_d, c->y_dev,
+                                       w.ttau_d, w.tnu_d, w.Wb + ((b + 1) & 1) * EPB * EPB, w.gb + ((b + 1) & 1) * EPB, w.ldb + b + 1, yfl,
+                                       ep_timing && b + 1 == 5 ? (long long*)(w.gb + 2 * EPB) : (long long*)nullptr, (const double*)Sb,
+                                       w.S + ((b + 1) & 1) * EPB * np, (const double*)Wb, (const double*)gb, w.prep_cnt, w.prep_target);
+                }
                 HIP_TRY(hipStreamWaitEvent(sb, evC(b), 0));
                 const long r0 = std::min<long>(i0 + EPB, np);   // first row of the sites still to come
                 const long u0 = track ? 0 : r0;        // track: Sigma stays complete (every row), otherwise only the rows still to be read
                 {
                     GemmArgs g{};                       // U = strip W
-                    g.A = w.S + u0; g.lda = np; g.a_kc = 0; g.B = Wb; g.ldb = EPB; g.b_kc = 0;
+                    g.A = Sb + u0; g.lda = np; g.a_kc = 0; g.B = Wb; g.ldb = EPB; g.b_kc = 0;
                     g.C = w.Sc + u0; g.ldc = np; g.M = (int)(np - u0); g.N = EPB; g.K = EPB;
                     g.alpha = 1.0; g.beta = 0.0; g.tile = 64; g.flops = 2.0 * (double)(np - u0) * EPB * EPB;
                     EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
                 }
-                if (!last) {
-                    GemmArgs g{};                       // the next block's rows left of its diagonal tile (prep owns that tile)
-                    g.A = w.Sc + r0; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
-                    g.C = w.Sig + r0; g.ldc = np; g.M = EPB; g.N = (int)r0; g.K = EPB;
-                    g.alpha = -1.0; g.beta = 1.0; g.tile = 64; g.flops = 2.0 * (double)EPB * r0 * EPB;
-                    EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
-                }
                 const long r1 = r0 + EPB;
-                if (!last && r1 < np) {
-                    GemmArgs g{};                       // rows >= r1: lower trapezoid
-                    g.A = w.Sc + r1; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
-                    g.C = w.Sig + r1; g.ldc = np; g.M = (int)(np - r1); g.N = (int)np; g.K = EPB;
-                    g.alpha = -1.0; g.beta = 1.0; g.tile = 128; g.tri = 1; g.tri_off = (int)r1;
-                    g.flops = (double)EPB * ((double)np * np - (double)r1 * r1);
-                    EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
-                    hipLaunchKernelGGL(ep_mu_strip_kernel, dim3((unsigned)((np - r1 + 63) / 64)), dim3(256), 0, sb, w.S, np, np, r1, gb,
-                                       w.mu_d);
-                }
                 if (track) {
-                    GemmArgs g{};                       // the rows of the sites already done (this block's included): lower triangle
-                    g.A = w.Sc; g.lda = np; g.a_kc = 0; g.B = w.S; g.ldb = np; g.b_kc = 0;
-                    g.C = w.Sig; g.ldc = np; g.M = (int)r0; g.N = (int)r0; g.K = EPB;
-                    g.alpha = -1.0; g.beta = 1.0; g.tile = r0 >= 1024 ? 128 : 64; g.tri = 2; g.mask_diag = 1;
-                    g.flops = (double)EPB * (double)r0 * r0;
+                    // the whole lower triangle in ONE launch (but the next block's diagonal tile: its prep workgroups own it), mu likewise
+                    GemmArgs g{};
+                    g.A = w.Sc; g.lda = np; g.a_kc = 0; g.B = Sb; g.ldb = np; g.b_kc = 0;
+                    g.C = w.Sig; g.ldc = np; g.M = (int)np; g.N = (int)np; g.K = EPB;
+                    g.alpha = -1.0; g.beta = 1.0; g.tile = np >= 1024 ? 128 : 64; g.tri = 2; g.mask_diag = 1;
+                    if (!last) { g.skip_lo = (int)r0; g.skip_hi = (int)r1; }
+                    g.flops = (double)EPB * ((double)np * np - (last ? 0.0 : (double)EPB * EPB));
                     EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
-                    hipLaunchKernelGGL(ep_mu_strip_kernel, dim3((unsigned)((r0 + 63) / 64)), dim3(256), 0, sb, w.S, np, r0, 0L, gb, w.mu_d);
+                    hipLaunchKernelGGL(ep_mu_strip_kernel, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, sb, Sb, np, np, 0L, gb, w.mu_d,
+                                       last ? 0L : r0, last ? 0L : r1);
+                } else {
+                    if (!last) {
+                        GemmArgs g{};                   // the next block's rows left of its diagonal tile (prep owns that tile)
+                        g.A = w.Sc + r0; g.lda = np; g.a_kc = 0; g.B = Sb; g.ldb = np; g.b_kc = 0;
+                        g.C = w.Sig + r0; g.ldc = np; g.M = EPB; g.N = (int)r0; g.K = EPB;
+                        g.alpha = -1.0; g.beta = 1.0; g.tile = 64; g.flops = 2.0 * (double)EPB * r0 * EPB;
+                        EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
+                    }
+                    if (!last && r1 < np) {
+                        GemmArgs g{};                   // rows >= r1: lower trapezoid
+                        g.A = w.Sc + r1; g.lda = np; g.a_kc = 0; g.B = Sb; g.ldb = np; g.b_kc = 0;
+                        g.C = w.Sig + r1; g.ldc = np; g.M = (int)(np - r1); g.N = (int)np; g.K = EPB;
+                        g.alpha = -1.0; g.beta = 1.0; g.tile = 128; g.tri = 1; g.tri_off = (int)r1;
+                        g.flops = (double)EPB * ((double)np * np - (double)r1 * r1);
+                        EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
+                        hipLaunchKernelGGL(ep_mu_strip_kernel, dim3((unsigned)((np - r1 + 63) / 64)), dim3(256), 0, sb, Sb, np, np, r1, gb,
+                                           w.mu_d, 0L, 0L);
+                    }
                 }
             }
             if (sa != st) HIP_TRY(hipStreamWaitEvent(st, evC(nbl - 1), 0));

@@ -64,6 +64,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
     // shrinking batch (see GemmArgs::batch_dm): product bz has fewer rows, its first-touch row moves with them
     if (g.batch_dm && i0 >= g.M - (int)bz * g.batch_dm) return;
     const int zero_from = g.zero_from > 0 ? g.zero_from - (int)bz * g.batch_dm : 0;
+    if (i0 < g.skip_hi && j0 < g.skip_hi && i0 >= g.skip_lo && j0 >= g.skip_lo) return;
     bool diag = false;
     if (g.tri) {
         if (i0 + g.tri_off < j0) return;
