@@ -73,6 +73,9 @@ struct GemmArgs {
     // Tiles whose first row AND first column lie in [skip_lo, skip_hi) are left alone (0, 0: none): the diagonal block another
     // kernel owns inside a whole-matrix update (EP's block sweep: the next block's tile belongs to its prep workgroups).
     int skip_lo, skip_hi;
+    // Device-side dependency (0: none): every workgroup waits until the counter *wait_flag has reached wait_target before it reads
+    // anything -- an operand another RESIDENT kernel publishes (EP's sweep kernel: W of the block).  Bounded; a timeout sets *wait_err.
+    unsigned* wait_flag; unsigned wait_target; unsigned* wait_err;
 };
 
 // index of the calling workgroup's CU in a yield-flag table (XCC id | shader engine, array, CU of HW_ID): < 4096

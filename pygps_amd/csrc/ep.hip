@@ -7,8 +7,8 @@
 //                (ttau_i, tnu_i), rank-1 coefficient) and ep_rank1_mu_kernel (Sigma -= c s_i s_i' fused with mu = Sigma tnu:
 //                16 N^2 bytes per site).  Kept as the parity anchor of the variants test.
 //   ep_block 1   (default) the BLOCK sweep: the 128 sites of a block only read Sigma_BB and mu_B, so one workgroup runs them
-//                in one launch with Sigma_BB in registers (ep_chain_kernel) and the rest of Sigma gets the block's effect all
-//                at once by the matrix inversion lemma, folded in beside the next block's chain -- see "block sweep" below.
+//                with Sigma_BB in registers (ep_chain_kernel, one launch per SWEEP) and the rest of Sigma gets the block's effect
+//                all at once by the matrix inversion lemma, folded in beside the next block's chain -- see "block sweep" below.
 // The posterior -- Sigma, mu, log det B -- is CARRIED through the sweeps (every step of the block sweep is an exact identity; the
 // determinant lemma per site) and rebuilt from scratch once, from the converged site parameters, with the SAME kernels as
 // exact inference; option ep_recompute 1 rebuilds it after every sweep like the reference (inf.py:772):
@@ -245,9 +245,10 @@ __device__ __forceinline__ void ep_site_update(double sii, double mui, double tp
 // (Sigma_BB,new is what the chain ends with; no inverse, and dT = 0 rows are fine), and for mu = Sigma tnu with
 // h = dnu - dT o mu_B,old:                 mu_new = mu + Sigma(:,B) g,    g = h - dT o (Sigma_BB,new h).
 // Same sites in the same order with the same scalar update as inf.py:757-770; only the order in which the rank-1 terms are
-// summed differs.  Two streams: the chain stream runs  prep(b) -> chain(b)  (prep brings the NEXT diagonal block and its mu up
-// to date: one 128 x 128 tile), the bulk stream copies the strip Sigma(:,B), forms U = strip W and folds U strip' into the rows
-// of the sites still to come -- beside the next block's chain.
+// summed differs.  Two streams: the chain stream runs ONE resident kernel per sweep -- one workgroup the chain, 36 workgroups
+// prep (they bring the NEXT diagonal block and its mu up to date: one 128 x 128 tile) -- the bulk stream copies the strip
+// Sigma(:,B), forms U = strip W and folds U strip' into all of Sigma in one launch, beside the next block's chain.  The two
+// meet through device counters, not events (ep_chain_kernel).
 // The waves are SPECIALISED.  A first version in which every wave did everything (site update evaluated redundantly, 8 x 8
 // entries of Sigma_BB per thread, one barrier per site) took 2850 s_memtime ticks per site, of which the scalar site update
 // is ~1050 and everything around it ~1800: a lone wave issues one fp64 instruction per 5.4 ticks, and LDS is bandwidth-bound
@@ -281,39 +282,90 @@ struct EpPrepLds {
 };
 constexpr size_t EP_BLOCK_LDS = sizeof(EpPrepLds) > sizeof(EpChainLds) ? sizeof(EpPrepLds) : sizeof(EpChainLds);
 
-// prep(b -> b+1): the diagonal tile and the mu entries of the NEXT block, brought up to date in place:
-//   Sigma(B', B') -= X W X',  mu(B') += X g,   X = strip(B', :) = Sigma(B', B) before the block.   36 workgroups: the 16 x 16
-// output tiles on or below the diagonal (the lower triangle is the one kept current); T = X_rows W (16 x 128, K = 128: each wave
-// two column tiles, W straight from global memory as the MFMA operand), then T X_cols' with K split over the four waves.
-// The tile also goes, mirrored, into the rows B' of the NEXT strip buffer (Snext(r, k) = Sigma(r, r0 + k)): the strip kernel of
-// block b+1 then has nothing to wait for (it skips these rows).  It sits between two chains, on the critical path of the sweep:
-// workgroups 1 .. 36 of the launch whose workgroup 0 is the chain of block b+1, 256 of their 512 threads.
-__device__ __forceinline__ void ep_prep_body(int blk, double* __restrict__ Sig, long ld, long r0, const double* __restrict__ S,
-                                             double* __restrict__ Snext, const double* __restrict__ W, const double* __restrict__ g,
-                                             double* __restrict__ mu, EpPrepLds& L) {
+// ---- hand-overs of the resident sweep kernel ----------------------------------------------------------------------------
+// Device counters that only grow within a fit (flags[EPF_*], see ep_chain_kernel) and data read / written at AGENT scope: the
+// sc1 forms of global_load / global_store are coherent across the XCDs' L2s by themselves.  A hand-over is then "stores, the
+// s_waitcnt of a barrier, counter" on one side and "counter, loads" on the other -- no release / acquire fence: those write back
+// and invalidate a WHOLE L2, which the bulk stream's folds keep full of dirty tiles (measured: 21 us per block with fences, 15
+// without; a launch boundary costs the same flush plus the dispatch).
+enum { EPF_CHAIN = 0, EPF_PREP = 1, EPF_STRIP = 2, EPF_ERR = 3 };
+__device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ld_dev with a wave-uniform base (SGPR pair), a 32-bit per-lane byte offset and an immediate: the 48 tile loads of an update wave
+// then cost two address registers, not 96 (as compiler-generated atomic loads they pushed the accumulators into scratch).  The
+// compiler does not count asm loads: ep_loads_done() waits for them and is the only place their results become usable.
+template <int OFF>
+__device__ __forceinline__ void ld_dev_issue(double& x, const double* sbase, unsigned voff) {
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 sc1" : "=v"(x) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+__device__ __forceinline__ void ep_loads_done(double (&v)[12]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                   "+v"(v[10]), "+v"(v[11]));
+}
+// wait until the counter *f has reached `target`.  Bounded (~1 s, at once when another wait has already given up): a launch that
+// never came must not hang the device; the fit then fails through flags[EPF_ERR]
+__device__ __forceinline__ void ep_wait_ge(unsigned* f, unsigned target, unsigned* err) {
+    for (unsigned it = 0; (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0; ++it) {
+        if (it > (1u << 22) || ((it & 1023u) == 1023u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
+// prep(b): the diagonal tile and the mu entries of block b, brought up to date in place from block b-1's (W, g):
+//   Sigma(B, B) -= X W X',  mu(B) += X g,   X = strip(B, :) = Sigma(B, B_prev) before the previous block.   36 workgroups: the
+// 16 x 16 output tiles on or below the diagonal (the lower triangle is the one kept current); T = X_rows W (16 x 128, K = 128: each
+// wave two column tiles, W straight from global memory as the MFMA operand), then T X_cols' with K split over the four waves.
+// The result goes to three places: Sigma itself, the rows B of the strip buffer of block b (Snext(r, k) = Sigma(r, r0 + k): the
+// bulk stream's strip kernel skips them and has nothing to wait for) and the tile buffer the chain reads.  It sits between two
+// blocks of the chain, on the critical path of the sweep: workgroups 1 .. 36 of the sweep kernel, 256 of their 512 threads.
+// Index of Sigma_BB(R, C) in the tile buffer: the chain workgroup's accumulator layout (update wave pair u = R / 48, tile row
+// I, tile column J = C / 16 of wave `half` = J / 4, component r, lane), so that its 96 loads per lane are contiguous per wave.
+constexpr int EP_TILE_N = 3 * 2 * 3 * 4 * 4 * 64;        // (rows 128 .. 143 of the layout are padding, never written or read)
+__device__ __forceinline__ int ep_tile_index(int R, int C) {
+    const int u = R / 48, I = (R % 48) >> 4, l15 = R & 15, J = C >> 4, half = J >> 2, jj = J & 3, c16 = C & 15, l4 = c16 & 3, r = c16 >> 2;
+    return ((((u * 2 + half) * 3 + I) * 4 + jj) * 4 + r) * 64 + l15 + 16 * l4;
+}
+// copy_only (the first block of a sweep: nothing to fold in): the tile, its diagonal and mu_B as they are.
+__device__ __forceinline__ void ep_prep_body(int blk, double* Sig, long ld, long r0, const double* S, double* Snext, const double* W,
+                                             const double* g, double* mu, double* Tile, bool copy_only, EpPrepLds& L) {
     int bi = 0, rem = blk;
     while (rem > bi) { rem -= bi + 1; ++bi; }
     const int bj = rem;                                  // bi >= bj
     auto& Xr = L.Xr; auto& Xc = L.Xc; auto& T = L.T; auto& red = L.red; auto& gl = L.gl;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const long orow = r0 + 16 * bi + (t >> 4), ocol = r0 + 16 * bj + (t & 15);
+    const int R = 16 * bi + (t >> 4), C = 16 * bj + (t & 15);
+    if (copy_only) {
+        if (R >= C) {
+            const double v = ld_dev(Sig + orow + ocol * ld);
+            st_dev(Tile + ep_tile_index(R, C), v);
+            st_dev(Tile + ep_tile_index(C, R), v);
+            if (R == C) st_dev(Tile + EP_TILE_N + EPB + R, v);
+        }
+        if (bi == bj && t < 16) st_dev(Tile + EP_TILE_N + 16 * bi + t, ld_dev(mu + r0 + 16 * bi + t));
+        return;
+    }
     // every global read is issued up front (a chain of memory round trips otherwise): the 64 W operands of this lane, its 16
     // strip entries, the output entry it will update
     const double* w0 = W + 16 * (2 * wv) + l15 + (long)EPB * l4;              // W(q, kk) at W[kk + 128 q]
     double wx[EPB / 4][2];
 #pragma unroll
-    for (int ks = 0; ks < EPB / 4; ++ks) { wx[ks][0] = w0[(long)EPB * 4 * ks]; wx[ks][1] = w0[(long)EPB * 4 * ks + 16]; }
+    for (int ks = 0; ks < EPB / 4; ++ks) { wx[ks][0] = ld_dev(w0 + (long)EPB * 4 * ks); wx[ks][1] = ld_dev(w0 + (long)EPB * 4 * ks + 16); }
     double xr[8], xc[8];
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
         const int e = t + 256 * v, ii = e & 15, q = e >> 4;
-        xr[v] = S[r0 + 16 * bi + ii + (long)q * ld];
-        xc[v] = S[r0 + 16 * bj + ii + (long)q * ld];
+        xr[v] = ld_dev(S + r0 + 16 * bi + ii + (long)q * ld);
+        xc[v] = ld_dev(S + r0 + 16 * bj + ii + (long)q * ld);
     }
-    const long orow = r0 + 16 * bi + (t >> 4), ocol = r0 + 16 * bj + (t & 15);
-    const double old = Sig[orow + ocol * ld];
-    const double gk = t < EPB ? g[t] : 0.0;
+    const double old = ld_dev(Sig + orow + ocol * ld);
+    const double gk = t < EPB ? ld_dev(g + t) : 0.0;
     double muold = 0.0;
-    if (bi == bj && t < 16) muold = mu[r0 + 16 * bi + t];
+    if (bi == bj && t < 16) muold = ld_dev(mu + r0 + 16 * bi + t);
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
         const int e = t + 256 * v, ii = e & 15, q = e >> 4;
@@ -351,38 +403,55 @@ __device__ __forceinline__ void ep_prep_body(int blk, double* __restrict__ Sig, 
         const double out = ((red[0][ii][jj] + red[1][ii][jj]) + red[2][ii][jj]) + red[3][ii][jj];
         if (orow >= ocol) {
             const double nv = old - out;
-            Sig[orow + ocol * ld] = nv;
-            Snext[orow + (ocol - r0) * ld] = nv;
-            Snext[ocol + (orow - r0) * ld] = nv;
+            st_dev(Tile + ep_tile_index(R, C), nv);
+            st_dev(Tile + ep_tile_index(C, R), nv);
+            if (R == C) st_dev(Tile + EP_TILE_N + EPB + R, nv);
+            st_dev(Sig + orow + ocol * ld, nv);
+            st_dev(Snext + orow + (ocol - r0) * ld, nv);
+            st_dev(Snext + ocol + (orow - r0) * ld, nv);
         }
     }
     if (bi == bj && t < 16) {
         double acc = 0.0;
         for (int k = 0; k < EPB; ++k) acc = fma(Xr[t][k], gl[k], acc);
-        mu[r0 + 16 * bi + t] = muold + acc;
+        st_dev(Tile + EP_TILE_N + 16 * bi + t, muold + acc);
+        st_dev(mu + r0 + 16 * bi + t, muold + acc);
     }
 }
 
-// One launch per block of sites: workgroup 0 = the chain of the block (below), workgroups 1 .. nprep = prep of THIS block from the
-// previous block's (W, g) -- the chain's workgroup sets itself up meanwhile and then waits for `pcnt` to reach `ptarget` (a
-// counter that only grows: 36 per launch).  One launch and one launch gap less per block than prep and chain as two kernels.
-__global__ __launch_bounds__(512) void ep_chain_kernel(double* __restrict__ Sig, long ld, long i0, int nb,
-                                                        double* __restrict__ mu, const double* __restrict__ m,
-                                                        const double* __restrict__ y, double* __restrict__ ttau,
-                                                        double* __restrict__ tnu, double* __restrict__ Wout,
-                                                        double* __restrict__ gout, double* __restrict__ ldout,
-                                                        unsigned* yield_flags, long long* __restrict__ stamps,
-                                                        const double* __restrict__ Sprev, double* __restrict__ Snext,
-                                                        const double* __restrict__ Wp, const double* __restrict__ gp,
-                                                        unsigned* pcnt, unsigned ptarget) {
+// ONE launch per sweep, resident for all its blocks.  Workgroup 0 = the chain: the sites of block 0, 1, ... back to back (below);
+// workgroups 1 .. 36 = prep: the diagonal tile and mu of block b from block b-1's (W, g) as soon as the chain has published them
+// (block 0: a plain copy into the tile buffer).  No launch boundary on the sweep's critical path; the hand-overs are counters --
+//   flags[EPF_CHAIN]  blocks the chain has finished (W, g of the block are in memory): prep(b+1) and, on the bulk stream,
+//                     U(b) = strip W (inside its kernel: GemmArgs::wait_flag) wait for it;
+//   flags[EPF_PREP]   prep workgroups that have finished: chain(b) waits for 36 more;
+//   flags[EPF_STRIP]  workgroups of the bulk stream's strip kernels that have finished: prep(b+1) reads strip(b).
+// cbase / pbase / sbase: the counters' values before this sweep's first block (sbase in strip LAUNCHES of swg workgroups each).
+// Buffers by block parity: W (128 x 128), g (128), strip (np x 128).  Measured on the way here (cfg 5, same box): prep and chain as
+// two launches per block 22.4 ms; prep workgroups inside the chain's launch 21.7; + one fold launch per block 21.2; events
+// replaced by these counters but still one launch per block 21.2; resident with release / acquire fences 21.1; with agent-scope
+// loads and stores 20.7.  (The body of a block as a non-inlined function: callee-saved registers in scratch, site loop 14 % slower:
+// 24.0.  One loop over the blocks AROUND the roles instead of one inside each: 636 bytes of spills.)
+template <bool TIMED>                            // TIMED: s_memtime stamps and spin counts of block 5 (PGP_EP_TIMING); costs registers
+__global__ __launch_bounds__(512) void ep_chain_kernel(double* Sig, long ld, long n, int nbl, double* mu, const double* __restrict__ m,
+                                                        const double* __restrict__ y, double* ttau, double* tnu, double* Wbuf,
+                                                        double* gbuf, double* ldbuf, unsigned* yield_flags, long long* stamps_b5,
+                                                        double* Sbuf, double* Tile, unsigned* flags, unsigned cbase, unsigned pbase,
+                                                        unsigned sbase, unsigned swg) {
     extern __shared__ __attribute__((aligned(32))) double ep_smem[];
     if (blockIdx.x > 0) {
         if (threadIdx.x < 256) {
-            ep_prep_body((int)blockIdx.x - 1, Sig, ld, i0, Sprev, Snext, Wp, gp, mu, *reinterpret_cast<EpPrepLds*>(ep_smem));
-            __syncthreads();                     // (every wave's stores have left before thread 0 publishes them)
-            if (threadIdx.x == 0) {
-                __threadfence();
-                __hip_atomic_fetch_add(pcnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (int b = 0; b < nbl; ++b) {
+                if (b > 0 && threadIdx.x == 0) {
+                    ep_wait_ge(flags + EPF_CHAIN, cbase + (unsigned)b, flags + EPF_ERR);
+                    ep_wait_ge(flags + EPF_STRIP, (sbase + (unsigned)b) * swg, flags + EPF_ERR);
+                }
+                __syncthreads();
+                ep_prep_body((int)blockIdx.x - 1, Sig, ld, (long)b * EPB, Sbuf + (long)((b + 1) & 1) * EPB * ld, Sbuf + (long)(b & 1) * EPB * ld,
+                             Wbuf + ((b + 1) & 1) * EPB * EPB, gbuf + ((b + 1) & 1) * EPB, mu, Tile, b == 0, *reinterpret_cast<EpPrepLds*>(ep_smem));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a barrier only waits for LDS: every wave sees its stores through first)
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + EPF_PREP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         return;
@@ -399,307 +468,371 @@ __global__ __launch_bounds__(512) void ep_chain_kernel(double* __restrict__ Sig,
     // tile columns 4-7.  The wave that owns the current tile column does the per-site work; the other one only has the
     // rank-4 MFMAs of its 12 tiles, which it issues one site late -- in the shadow of its partner's hand-overs
     const int u = (wv & 3) - 1, half = wv >> 2;
-    long long spinC = 0, spinP = 0, spinQ = 0;
-    if (stamps && t == 0) stamps[0] = __builtin_amdgcn_s_memtime();
-    if (t == 0) { seqC = 0; seqP = 0; seqG = 0; }
-    if (t < EPB) {
-        const bool live = t < nb;
-        prm[t][0] = live ? ttau[i0 + t] : 0.0; prm[t][1] = live ? tnu[i0 + t] : 0.0;
-        prm[t][2] = live ? m[i0 + t] : 0.0; prm[t][3] = live ? y[i0 + t] : 1.0;
-        s_dt[t] = 0.0; s_dn[t] = 0.0; s_tn[t] = 0.0; s_nn[t] = 0.0;
-    }
-    // Sigma_BB and mu_B are this launch's prep workgroups' to finish
-    if (pcnt) {
-        if (t == 0) {
-            while (__hip_atomic_load(pcnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < ptarget) __builtin_amdgcn_s_sleep(4);
-            __threadfence();
-        }
-        __syncthreads();
-    }
-    if (t < EPB) {
-        s_mu0[t] = mu[i0 + t];
-        diagb[0][t] = Sig[(i0 + t) + (i0 + t) * ld]; mub[0][t] = s_mu0[t];
-    }
-    if (t < 8 * (EPCP - EPB)) colb[t / (EPCP - EPB)][EPB + t % (EPCP - EPB)] = 0.0;
     const int l15 = lane & 15, l4 = lane >> 4;
-    // (the two roles share nothing but LDS: everything of a role, its barriers included, sits inside its branch, so that the
-    //  96 accumulator registers of the update waves are not live across the chain's code)
-    if (wv == 0) {
+    // what every wave does at the head of a block
+    auto prologue = [&](const int b, const long i0, const int nb, long long* const stamps) {
+        if (stamps && t == 0) stamps[0] = __builtin_amdgcn_s_memtime();
+        if (t == 0) { seqC = 0; seqP = 0; seqG = 0; }
+        if (t < EPB) {
+            const bool live = t < nb;
+            prm[t][0] = live ? ttau[i0 + t] : 0.0; prm[t][1] = live ? tnu[i0 + t] : 0.0;
+            prm[t][2] = live ? m[i0 + t] : 0.0; prm[t][3] = live ? y[i0 + t] : 1.0;
+            s_dt[t] = 0.0; s_dn[t] = 0.0; s_tn[t] = 0.0; s_nn[t] = 0.0;
+        }
+        // Sigma_BB and mu_B are the prep workgroups' to finish
+        if (t == 0) ep_wait_ge(flags + EPF_PREP, pbase + 36u * ((unsigned)b + 1u), flags + EPF_ERR);
         __syncthreads();
-        if (stamps && t == 0) stamps[1] = __builtin_amdgcn_s_memtime();
-        // ---- the chain: inf.py:757-770 for the sites of the block, nothing else -------------------------------------------
-        __builtin_amdgcn_s_setprio(3);
-        double dkk = diagb[0][0], muk = mub[0][0];
-        double pc0 = prm[0][0], pc1 = prm[0][1], pc2 = prm[0][2], pc3 = prm[0][3];
-        // log det B moves with every site by the matrix determinant lemma: det(Sigma^-1 + dtau e e') = det(Sigma^-1) (1 + dtau Sigma_ii)
-        double fprod = 1.0, lsum = 0.0;
-        for (int k = 0; k < nb; ++k) {
-            const int kn = k + 1 < EPB ? k + 1 : EPB - 1;
-            const double pn0 = prm[kn][0], pn1 = prm[kn][1], pn2 = prm[kn][2], pn3 = prm[kn][3];
-            double t_new, nu_new, cj, qj;
-            ep_site_update(dkk, muk, pc0, pc1, pc2, pc3, t_new, nu_new, cj, qj);
-            fprod *= fma(t_new - pc0, dkk, 1.0);
-            if ((k & 31) == 31) { lsum += log(fprod); fprod = 1.0; }
-            if (lane == 0) {
-                cq[k & 15][0] = cj; cq[k & 15][1] = qj;
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                __hip_atomic_store(&seqC, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // LDS stores of one wave land in order
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                s_dt[k] = t_new - pc0; s_dn[k] = nu_new - pc1; s_tn[k] = t_new; s_nn[k] = nu_new;
+        if (t < EPB) {
+            s_mu0[t] = ld_dev(Tile + EP_TILE_N + t);
+            diagb[0][t] = ld_dev(Tile + EP_TILE_N + EPB + t); mub[0][t] = s_mu0[t];
+        }
+        if (t < 8 * (EPCP - EPB)) colb[t / (EPCP - EPB)][EPB + t % (EPCP - EPB)] = 0.0;
+    };
+    // (the roles share nothing but LDS: everything of a role -- its loop over the blocks, its barriers -- sits inside its branch, so
+    //  that the 96 accumulator registers of the update waves are not live across the chain's code)
+    if (wv == 0) {
+#pragma unroll 1
+        for (int b = 0; b < nbl; ++b) {
+            const long i0 = (long)b * EPB;
+            const int nb = (int)(n - i0 < EPB ? n - i0 : EPB);
+            double* const Wout = Wbuf + (b & 1) * EPB * EPB;
+            double* const gout = gbuf + (b & 1) * EPB;
+            double* const ldout = ldbuf + b;
+            long long* const stamps = (TIMED && b == 5) ? stamps_b5 : nullptr;
+            long long spinC = 0, spinP = 0, spinQ = 0;
+            (void)Wout; (void)gout; (void)ldout; (void)spinC; (void)spinP; (void)spinQ;
+            prologue(b, i0, nb, stamps);
+            __syncthreads();
+            if (stamps && t == 0) stamps[1] = __builtin_amdgcn_s_memtime();
+            // ---- the chain: inf.py:757-770 for the sites of the block, nothing else -------------------------------------------
+            __builtin_amdgcn_s_setprio(3);
+            double dkk = diagb[0][0], muk = mub[0][0];
+            double pc0 = prm[0][0], pc1 = prm[0][1], pc2 = prm[0][2], pc3 = prm[0][3];
+            // log det B moves with every site by the matrix determinant lemma: det(Sigma^-1 + dtau e e') = det(Sigma^-1) (1 + dtau Sigma_ii)
+            double fprod = 1.0, lsum = 0.0;
+            for (int k = 0; k < nb; ++k) {
+                const int kn = k + 1 < EPB ? k + 1 : EPB - 1;
+                const double pn0 = prm[kn][0], pn1 = prm[kn][1], pn2 = prm[kn][2], pn3 = prm[kn][3];
+                double t_new, nu_new, cj, qj;
+                ep_site_update(dkk, muk, pc0, pc1, pc2, pc3, t_new, nu_new, cj, qj);
+                fprod *= fma(t_new - pc0, dkk, 1.0);
+                if ((k & 31) == 31) { lsum += log(fprod); fprod = 1.0; }
+                if (lane == 0) {
+                    cq[k & 15][0] = cj; cq[k & 15][1] = qj;
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    __hip_atomic_store(&seqC, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // LDS stores of one wave land in order
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    s_dt[k] = t_new - pc0; s_dn[k] = nu_new - pc1; s_tn[k] = t_new; s_nn[k] = nu_new;
+                }
+                if (k + 1 < nb) {
+                    // Sigma(k+1,k), Sigma(k+1,k+1), mu(k+1) before site k: passed on by the update waves during their step k-1
+                    // (the sequence number and the three values in one round trip, see the update waves)
+                    double e1, d1, m1;
+                    for (;;) {
+                        const int sp = __hip_atomic_load(&seqP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                        e1 = colb[k & 7][k + 1]; d1 = diagb[k & 1][k + 1];
+                        m1 = mub[k & 1][k + 1];
+                        if (sp >= 3 * k) break;
+                        if (TIMED) ++spinC;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    dkk = fma(-cj * e1, e1, d1);
+                    muk = fma(qj, e1, m1);
+                }
+                pc0 = pn0; pc1 = pn1; pc2 = pn2; pc3 = pn3;
             }
-            if (k + 1 < nb) {
-                // Sigma(k+1,k), Sigma(k+1,k+1), mu(k+1) before site k: passed on by the update waves during their step k-1
-                // (the sequence number and the three values in one round trip, see the update waves)
-                double e1, d1, m1;
+            __syncthreads();
+            if (stamps && t == 0) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[4] = stamps[1] + spinC; }
+            for (int k = lane; k < nb; k += 64) { ttau[i0 + k] = s_tn[k]; tnu[i0 + k] = s_nn[k]; }
+            if (lane == 0) ldout[0] = lsum + log(fprod);
+            __syncthreads();
+            __syncthreads();
+            if (stamps && t == 0) stamps[3] = __builtin_amdgcn_s_memtime();
+            // (the update waves saw W and g through before that last barrier)
+            if (t == 0) __hip_atomic_store(flags + EPF_CHAIN, cbase + (unsigned)b + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (u < 0) {                          // wave 4
+#pragma unroll 1
+        for (int b = 0; b < nbl; ++b) {
+            const long i0 = (long)b * EPB;
+            const int nb = (int)(n - i0 < EPB ? n - i0 : EPB);
+            double* const Wout = Wbuf + (b & 1) * EPB * EPB;
+            double* const gout = gbuf + (b & 1) * EPB;
+            double* const ldout = ldbuf + b;
+            long long* const stamps = (TIMED && b == 5) ? stamps_b5 : nullptr;
+            long long spinC = 0, spinP = 0, spinQ = 0;
+            (void)Wout; (void)gout; (void)ldout; (void)spinC; (void)spinP; (void)spinQ;
+            prologue(b, i0, nb, stamps);
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+        }
+    } else {
+#pragma unroll 1
+        for (int b = 0; b < nbl; ++b) {
+            const long i0 = (long)b * EPB;
+            const int nb = (int)(n - i0 < EPB ? n - i0 : EPB);
+            double* const Wout = Wbuf + (b & 1) * EPB * EPB;
+            double* const gout = gbuf + (b & 1) * EPB;
+            double* const ldout = ldbuf + b;
+            long long* const stamps = (TIMED && b == 5) ? stamps_b5 : nullptr;
+            long long spinC = 0, spinP = 0, spinQ = 0;
+            (void)Wout; (void)gout; (void)ldout; (void)spinC; (void)spinP; (void)spinQ;
+            prologue(b, i0, nb, stamps);
+            // update waves: Sigma_BB in the MFMA accumulator layout -- tile (I, J) of wave u: rows 48 u + 16 I + l15, columns
+            // 16 J + l4 + 4 r in component r (rows >= 128 are padding and stay zero)
+            double4_t A[3][4];                       // tile (I, 4 half + jj)
+            {
+                // 48 values per lane, 512 bytes apart (ep_tile_index): windows of eight loads share one offset register
+                const double* const tbase = Tile + __builtin_amdgcn_readfirstlane((u * 2 + half) * (3 * 4 * 4 * 64));
+                double tv[4][12];
+                static_for<6>([&](auto Wt) {
+                    constexpr int wdw = decltype(Wt)::value;
+                    const unsigned voff = (unsigned)lane * 8u + (unsigned)wdw * 4096u;
+                    static_for<8>([&](auto Et) {
+                        constexpr int e = 8 * wdw + decltype(Et)::value;
+                        ld_dev_issue<512 * decltype(Et)::value>(tv[e / 12][e % 12], tbase, voff);
+                    });
+                });
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ep_loads_done(tv[q]);
+                const bool pad_wave = u == 2;            // its tile row 2 = rows 128 .. 143: padding, zero
+#pragma unroll
+                for (int I = 0; I < 3; ++I)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int e = (I * 4 + jj) * 4 + r;
+                            A[I][jj][r] = (I == 2 && pad_wave) ? 0.0 : tv[e / 12][e % 12];
+                        }
+#pragma unroll
+                for (int I = 0; I < 3; ++I) {
+                    const int row = 48 * u + 16 * I + l15;
+                    if (half == 0 && l4 == 0 && row < EPB) colb[0][row] = A[I][0][0];
+                }
+            }
+            __syncthreads();
+            // ---- the update waves, one site behind ------------------------------------------------------------------------------
+            // Per site the VALU keeps only the tile column(s) current from which the NEXT sites' columns leave (J = k / 16, 12 FMAs;
+            // during the last four sites of a tile column also its successor) -- in "panel" registers Pa / Pb of the wave that
+            // owns that tile column; the other wave of the pair skips the site.  Everything gets the FOUR rank-1 terms of the
+            // sites 4 g .. 4 g + 3 at once, as one 16 x 16 x 4 MFMA per tile whose k index is the site: lane group l4 feeds column
+            // 4 g + l4 (the last eight columns and sixteen (c, q) pairs stay in LDS rings) -- 12 matrix instructions per wave and
+            // four sites instead of 4 x (96 + 8) VALU instructions.  (One MFMA per SITE with the k = 1..3 lanes zeroed was measured
+            // first: fp64 MFMA and fp64 VALU both do 16 FMA per cycle and SIMD here, so three quarters of each were wasted.)
+            const int di_ = 64 * u + lane;           // the diagonal / mu entry the publishing wave of the pair keeps up to date (< 128)
+            double4_t Pa[3], Pb[3];
+    #pragma unroll
+            for (int I = 0; I < 3; ++I) { Pa[I] = A[I][0]; Pb[I] = A[I][0]; }
+            // one site of tile column kc for the wave(s) that own Pa (mine_a) / Pb (mine_b, WB sites only); `pub`: this wave passes
+            // column k+1, the diagonal and mu on.  The early column is component (second ? R1 : R0) of Pa in the lanes l4 == bn, or
+            // (from_b) component 0 of Pb in the lanes l4 == 0.  Only R0 / R1 / WB are compile-time: four code bodies.
+            auto u_site = [&](const int k, const int kc, auto R0t, auto R1t, auto WBt, const bool mine_a, const bool mine_b, const bool pub,
+                              const bool second, const bool from_b, const int bn) {
+                constexpr int r0 = decltype(R0t)::value, r1 = decltype(R1t)::value;
+                constexpr bool wb = decltype(WBt)::value;
+                const int b = k & 1;
+                // ONE LDS round trip per try: the sequence numbers and everything they guard are read in the same batch -- LDS
+                // executes a wave's instructions in order and the writers store their data before they raise the number, so data
+                // read AFTER a number that has arrived has arrived too
+                const double* cb = colb[k & 7];
+                const int need_g = k >= 7 ? 6 * (((k - 7) >> 2) + 1) : 0;         // the column this step overwrites has been read by all
+                double crow[3], cca[4], ccb[4], dI = 0.0, mI = 0.0, cI = 0.0, cj, qj;
                 for (;;) {
                     const int sp = __hip_atomic_load(&seqP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int sc = __hip_atomic_load(&seqC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int sg = __hip_atomic_load(&seqG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                    e1 = colb[k & 7][k + 1]; d1 = diagb[k & 1][k + 1];
-                    m1 = mub[k & 1][k + 1];
-                    if (sp >= 3 * k) break;
-                    ++spinC;
+    #pragma unroll
+                    for (int I = 0; I < 3; ++I) crow[I] = cb[48 * u + 16 * I + l15];
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        cca[r] = cb[16 * kc + l4 + 4 * r];
+                        ccb[r] = wb ? cb[16 * kc + 16 + l4 + 4 * r] : 0.0;        // (kc = 7: the zero padding of the column)
+                    }
+                    if (pub && di_ < EPB) { dI = diagb[b][di_]; mI = mub[b][di_]; cI = cb[di_]; }
+                    cj = cq[k & 15][0]; qj = cq[k & 15][1];
+                    if (sp >= 3 * k && sc >= k + 1 && (!pub || sg >= need_g)) break;
+                    if (TIMED) { if (sp < 3 * k) ++spinP; else ++spinQ; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                dkk = fma(-cj * e1, e1, d1);
-                muk = fma(qj, e1, m1);
-            }
-            pc0 = pn0; pc1 = pn1; pc2 = pn2; pc3 = pn3;
-        }
-        __syncthreads();
-        if (stamps && t == 0) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[4] = stamps[1] + spinC; }
-        for (int k = lane; k < nb; k += 64) { ttau[i0 + k] = s_tn[k]; tnu[i0 + k] = s_nn[k]; }
-        if (lane == 0) ldout[0] = lsum + log(fprod);
-        __syncthreads();
-        __syncthreads();
-    } else if (u < 0) {                          // wave 4
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
-    } else {
-        // update waves: Sigma_BB in the MFMA accumulator layout -- tile (I, J) of wave u: rows 48 u + 16 I + l15, columns
-        // 16 J + l4 + 4 r in component r (rows >= 128 are padding and stay zero)
-        double4_t A[3][4];                       // tile (I, 4 half + jj)
-#pragma unroll
-        for (int I = 0; I < 3; ++I) {
-            const int row = 48 * u + 16 * I + l15;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) A[I][jj][r] = row < EPB ? sym_at(Sig, ld, i0 + row, i0 + 16 * (4 * half + jj) + l4 + 4 * r) : 0.0;
-            if (half == 0 && l4 == 0 && row < EPB) colb[0][row] = A[I][0][0];
-        }
-        __syncthreads();
-        // ---- the update waves, one site behind ------------------------------------------------------------------------------
-        // Per site the VALU keeps only the tile column(s) current from which the NEXT sites' columns leave (J = k / 16, 12 FMAs;
-        // during the last four sites of a tile column also its successor) -- in "panel" registers Pa / Pb of the wave that
-        // owns that tile column; the other wave of the pair skips the site.  Everything gets the FOUR rank-1 terms of the
-        // sites 4 g .. 4 g + 3 at once, as one 16 x 16 x 4 MFMA per tile whose k index is the site: lane group l4 feeds column
-        // 4 g + l4 (the last eight columns and sixteen (c, q) pairs stay in LDS rings) -- 12 matrix instructions per wave and
-        // four sites instead of 4 x (96 + 8) VALU instructions.  (One MFMA per SITE with the k = 1..3 lanes zeroed was measured
-        // first: fp64 MFMA and fp64 VALU both do 16 FMA per cycle and SIMD here, so three quarters of each were wasted.)
-        const int di_ = 64 * u + lane;           // the diagonal / mu entry the publishing wave of the pair keeps up to date (< 128)
-        double4_t Pa[3], Pb[3];
-#pragma unroll
-        for (int I = 0; I < 3; ++I) { Pa[I] = A[I][0]; Pb[I] = A[I][0]; }
-        // one site of tile column kc for the wave(s) that own Pa (mine_a) / Pb (mine_b, WB sites only); `pub`: this wave passes
-        // column k+1, the diagonal and mu on.  The early column is component (second ? R1 : R0) of Pa in the lanes l4 == bn, or
-        // (from_b) component 0 of Pb in the lanes l4 == 0.  Only R0 / R1 / WB are compile-time: four code bodies.
-        auto u_site = [&](const int k, const int kc, auto R0t, auto R1t, auto WBt, const bool mine_a, const bool mine_b, const bool pub,
-                          const bool second, const bool from_b, const int bn) {
-            constexpr int r0 = decltype(R0t)::value, r1 = decltype(R1t)::value;
-            constexpr bool wb = decltype(WBt)::value;
-            const int b = k & 1;
-            // ONE LDS round trip per try: the sequence numbers and everything they guard are read in the same batch -- LDS
-            // executes a wave's instructions in order and the writers store their data before they raise the number, so data
-            // read AFTER a number that has arrived has arrived too
-            const double* cb = colb[k & 7];
-            const int need_g = k >= 7 ? 6 * (((k - 7) >> 2) + 1) : 0;         // the column this step overwrites has been read by all
-            double crow[3], cca[4], ccb[4], dI = 0.0, mI = 0.0, cI = 0.0, cj, qj;
-            for (;;) {
-                const int sp = __hip_atomic_load(&seqP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int sc = __hip_atomic_load(&seqC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int sg = __hip_atomic_load(&seqG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-#pragma unroll
-                for (int I = 0; I < 3; ++I) crow[I] = cb[48 * u + 16 * I + l15];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    cca[r] = cb[16 * kc + l4 + 4 * r];
-                    ccb[r] = wb ? cb[16 * kc + 16 + l4 + 4 * r] : 0.0;        // (kc = 7: the zero padding of the column)
-                }
-                if (pub && di_ < EPB) { dI = diagb[b][di_]; mI = mub[b][di_]; cI = cb[di_]; }
-                cj = cq[k & 15][0]; qj = cq[k & 15][1];
-                if (sp >= 3 * k && sc >= k + 1 && (!pub || sg >= need_g)) break;
-                if (sp < 3 * k) ++spinP; else ++spinQ;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            const double ncj = -cj;
-#pragma unroll
-            for (int I = 0; I < 3; ++I) {
-                const double sr = ncj * crow[I];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (mine_a) Pa[I][r] = fma(sr, cca[r], Pa[I][r]);
-                    if (wb && mine_b) Pb[I][r] = fma(sr, ccb[r], Pb[I][r]);
-                }
-            }
-            if (pub) {
-                if (k + 1 < EPB) {
-                    if (l4 == bn) {
-#pragma unroll
-                        for (int I = 0; I < 3; ++I) {
-                            const int row = 48 * u + 16 * I + l15;
-                            const double nv = (wb && from_b) ? Pb[I][0] : (second ? Pa[I][r1] : Pa[I][r0]);
-                            if (row < EPB) colb[(k + 1) & 7][row] = nv;
-                        }
-                    }
-                    if (di_ < EPB) { diagb[b ^ 1][di_] = fma(ncj * cI, cI, dI); mub[b ^ 1][di_] = fma(qj, cI, mI); }
-                }
-                // (no wait for the stores: LDS executes this wave's add after them)
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                if (lane == 0) __hip_atomic_fetch_add(&seqP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            }
-        };
-        // the four sites k0 .. k0+3 as ONE rank-4 update of this wave's 12 tiles (the panels' own tiles too: they are overwritten
-        // from the panels when their tile column is done).  `late`: the wave that skipped the sites waits one hand-over longer,
-        // so that its MFMAs do not share the matrix pipe with its partner's batch
-        auto u_group = [&](const int k0, const bool late) {
-            const int ks = k0 + l4;
-            const double* cb = colb[ks & 7];
-            const int last = k0 + 3 < nb ? k0 + 3 : nb - 1;
-            const int wait_p = late ? (last + 2 < nb ? 3 * (last + 2) : 3 * last) : 3 * last;
-            double ncl, yop[3], xop[4];
-            for (;;) {
-                const int sp = __hip_atomic_load(&seqP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int sc = __hip_atomic_load(&seqC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                ncl = ks < nb ? -cq[ks & 15][0] : 0.0;
-#pragma unroll
-                for (int I = 0; I < 3; ++I) yop[I] = cb[48 * u + 16 * I + l15];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) xop[jj] = cb[16 * (4 * half + jj) + l15];
-                if (sp >= wait_p && sc >= last + 1) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            if (lane == 0) __hip_atomic_fetch_add(&seqG, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (late) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
-#pragma unroll
-            for (int I = 0; I < 3; ++I) yop[I] *= ncl;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int I = 0; I < 3; ++I) A[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[jj], yop[I], A[I][jj], 0, 0, 0);
-        };
-#pragma unroll 1
-        for (int kc = 0; kc < 8; ++kc) {
-            if (16 * kc >= nb) break;
-            const bool own_a = (kc >> 2) == half;                    // tile column kc is mine
-            const bool own_b = kc < 7 && ((kc + 1) >> 2) == half;    // its successor is mine
-            static_for<4>([&](auto KQt) {
-                // sites 16 kc + 4 kq + kb: column k+1 is component kq (kb < 3) or kq + 1 (kb == 3) of tile column kc, lanes l4 == kb + 1 mod 4
-                constexpr int kq = decltype(KQt)::value, kbn = kq == 3 ? 3 : 4;
-                if constexpr (kq == 3) {          // the successor joins: its accumulators have every group before this one
-                    if (own_b) {
-                        switch ((kc + 1) & 3) {
-#define PGP_EP_LOADB(J) case J: { _Pragma("unroll") for (int I = 0; I < 3; ++I) Pb[I] = A[I][J]; } break;
-                            PGP_EP_LOADB(0) PGP_EP_LOADB(1) PGP_EP_LOADB(2) PGP_EP_LOADB(3)
-#undef PGP_EP_LOADB
-                            default: break;
-                        }
+                const double ncj = -cj;
+    #pragma unroll
+                for (int I = 0; I < 3; ++I) {
+                    const double sr = ncj * crow[I];
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mine_a) Pa[I][r] = fma(sr, cca[r], Pa[I][r]);
+                        if (wb && mine_b) Pb[I][r] = fma(sr, ccb[r], Pb[I][r]);
                     }
                 }
-                if (16 * kc + 4 * kq < nb) {
-                    const bool act = own_a || (kq == 3 && own_b);
-                    if (act) {
-#pragma unroll 1
-                        for (int kb = 0; kb < kbn; ++kb) {
-                            const int k = 16 * kc + 4 * kq + kb;
-                            if (k < nb) u_site(k, kc, IntC<kq>{}, IntC<(kq + 1) & 3>{}, std::integral_constant<bool, kq == 3>{}, own_a, own_b, own_a,
-                                               kb == 3, false, (kb + 1) & 3);
+                if (pub) {
+                    if (k + 1 < EPB) {
+                        if (l4 == bn) {
+    #pragma unroll
+                            for (int I = 0; I < 3; ++I) {
+                                const int row = 48 * u + 16 * I + l15;
+                                const double nv = (wb && from_b) ? Pb[I][0] : (second ? Pa[I][r1] : Pa[I][r0]);
+                                if (row < EPB) colb[(k + 1) & 7][row] = nv;
+                            }
                         }
-                        if constexpr (kq == 3) {  // site 16 kc + 15: the next column is column 0 of the NEXT tile column
-                            const int k = 16 * kc + 15;
-                            if (k < nb) u_site(k, kc, IntC<0>{}, IntC<0>{}, std::true_type{}, own_a, own_b, kc < 7 ? own_b : own_a, false, true, 0);
+                        if (di_ < EPB) { diagb[b ^ 1][di_] = fma(ncj * cI, cI, dI); mub[b ^ 1][di_] = fma(qj, cI, mI); }
+                    }
+                    // (no wait for the stores: LDS executes this wave's add after them)
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    if (lane == 0) __hip_atomic_fetch_add(&seqP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                }
+            };
+            // the four sites k0 .. k0+3 as ONE rank-4 update of this wave's 12 tiles (the panels' own tiles too: they are overwritten
+            // from the panels when their tile column is done).  `late`: the wave that skipped the sites waits one hand-over longer,
+            // so that its MFMAs do not share the matrix pipe with its partner's batch
+            auto u_group = [&](const int k0, const bool late) {
+                const int ks = k0 + l4;
+                const double* cb = colb[ks & 7];
+                const int last = k0 + 3 < nb ? k0 + 3 : nb - 1;
+                const int wait_p = late ? (last + 2 < nb ? 3 * (last + 2) : 3 * last) : 3 * last;
+                double ncl, yop[3], xop[4];
+                for (;;) {
+                    const int sp = __hip_atomic_load(&seqP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int sc = __hip_atomic_load(&seqC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    ncl = ks < nb ? -cq[ks & 15][0] : 0.0;
+    #pragma unroll
+                    for (int I = 0; I < 3; ++I) yop[I] = cb[48 * u + 16 * I + l15];
+    #pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) xop[jj] = cb[16 * (4 * half + jj) + l15];
+                    if (sp >= wait_p && sc >= last + 1) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                if (lane == 0) __hip_atomic_fetch_add(&seqG, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (late) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+    #pragma unroll
+                for (int I = 0; I < 3; ++I) yop[I] *= ncl;
+    #pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+    #pragma unroll
+                    for (int I = 0; I < 3; ++I) A[I][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[jj], yop[I], A[I][jj], 0, 0, 0);
+            };
+    #pragma unroll 1
+            for (int kc = 0; kc < 8; ++kc) {
+                if (16 * kc >= nb) break;
+                const bool own_a = (kc >> 2) == half;                    // tile column kc is mine
+                const bool own_b = kc < 7 && ((kc + 1) >> 2) == half;    // its successor is mine
+                static_for<4>([&](auto KQt) {
+                    // sites 16 kc + 4 kq + kb: column k+1 is component kq (kb < 3) or kq + 1 (kb == 3) of tile column kc, lanes l4 == kb + 1 mod 4
+                    constexpr int kq = decltype(KQt)::value, kbn = kq == 3 ? 3 : 4;
+                    if constexpr (kq == 3) {          // the successor joins: its accumulators have every group before this one
+                        if (own_b) {
+                            switch ((kc + 1) & 3) {
+    #define PGP_EP_LOADB(J) case J: { _Pragma("unroll") for (int I = 0; I < 3; ++I) Pb[I] = A[I][J]; } break;
+                                PGP_EP_LOADB(0) PGP_EP_LOADB(1) PGP_EP_LOADB(2) PGP_EP_LOADB(3)
+    #undef PGP_EP_LOADB
+                                default: break;
+                            }
                         }
                     }
-                    u_group(16 * kc + 4 * kq, !act);
+                    if (16 * kc + 4 * kq < nb) {
+                        const bool act = own_a || (kq == 3 && own_b);
+                        if (act) {
+    #pragma unroll 1
+                            for (int kb = 0; kb < kbn; ++kb) {
+                                const int k = 16 * kc + 4 * kq + kb;
+                                if (k < nb) u_site(k, kc, IntC<kq>{}, IntC<(kq + 1) & 3>{}, std::integral_constant<bool, kq == 3>{}, own_a, own_b, own_a,
+                                                   kb == 3, false, (kb + 1) & 3);
+                            }
+                            if constexpr (kq == 3) {  // site 16 kc + 15: the next column is column 0 of the NEXT tile column
+                                const int k = 16 * kc + 15;
+                                if (k < nb) u_site(k, kc, IntC<0>{}, IntC<0>{}, std::true_type{}, own_a, own_b, kc < 7 ? own_b : own_a, false, true, 0);
+                            }
+                        }
+                        u_group(16 * kc + 4 * kq, !act);
+                    }
+                });
+                // tile column kc goes back to the accumulators (the later groups update it there); its successor becomes the panel
+                if (own_a) {
+                    switch (kc & 3) {
+    #define PGP_EP_STOREA(J) case J: { _Pragma("unroll") for (int I = 0; I < 3; ++I) A[I][J] = Pa[I]; } break;
+                        PGP_EP_STOREA(0) PGP_EP_STOREA(1) PGP_EP_STOREA(2) PGP_EP_STOREA(3)
+    #undef PGP_EP_STOREA
+                        default: break;
+                    }
                 }
-            });
-            // tile column kc goes back to the accumulators (the later groups update it there); its successor becomes the panel
-            if (own_a) {
-                switch (kc & 3) {
-#define PGP_EP_STOREA(J) case J: { _Pragma("unroll") for (int I = 0; I < 3; ++I) A[I][J] = Pa[I]; } break;
-                    PGP_EP_STOREA(0) PGP_EP_STOREA(1) PGP_EP_STOREA(2) PGP_EP_STOREA(3)
-#undef PGP_EP_STOREA
-                    default: break;
-                }
+    #pragma unroll
+                for (int I = 0; I < 3; ++I) Pa[I] = Pb[I];
             }
-#pragma unroll
-            for (int I = 0; I < 3; ++I) Pa[I] = Pb[I];
-        }
-        __syncthreads();
-        if (stamps && t == 64) { stamps[5] = spinP; stamps[6] = spinQ; }
-        // W(i, j) = dT_i [i == j] - dT_i dT_j Sigma_BB,new(i, j) ;  g = h - dT o (Sigma_BB,new h)
-        // (W is stored as W(row, col) at [row + 128 col]: 16 consecutive rows per lane group; it is symmetric up to rounding)
-#pragma unroll
-        for (int I = 0; I < 3; ++I) {
-            const int i = 48 * u + 16 * I + l15;
-            const bool live = i < EPB;
-            const double di = live ? s_dt[i] : 0.0;
-            double acc = 0.0;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * (4 * half + jj) + l4 + 4 * r;
-                    const double hj = fma(-s_dt[j], s_mu0[j], s_dn[j]);
-                    acc = fma(A[I][jj][r], hj, acc);
-                    if (live) Wout[i + (long)EPB * j] = (i == j ? di : 0.0) - di * s_dt[j] * A[I][jj][r];
-                }
-            acc += __shfl_xor(acc, 16, 64); acc += __shfl_xor(acc, 32, 64);
-            if (l4 == 0) gpart[half][48 * u + 16 * I + l15] = acc;
-        }
-        __syncthreads();
-        if (half == 0 && l4 == 0) {
-#pragma unroll
+            __syncthreads();
+            if (stamps && t == 64) { stamps[5] = spinP; stamps[6] = spinQ; }
+            // W(i, j) = dT_i [i == j] - dT_i dT_j Sigma_BB,new(i, j) ;  g = h - dT o (Sigma_BB,new h)
+            // (W is stored as W(row, col) at [row + 128 col]: 16 consecutive rows per lane group; it is symmetric up to rounding)
+    #pragma unroll
             for (int I = 0; I < 3; ++I) {
                 const int i = 48 * u + 16 * I + l15;
-                if (i < EPB) {
-                    const double di = s_dt[i];
-                    gout[i] = fma(-di, gpart[0][i] + gpart[1][i], fma(-di, s_mu0[i], s_dn[i]));
+                const bool live = i < EPB;
+                const double di = live ? s_dt[i] : 0.0;
+                double acc = 0.0;
+    #pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * (4 * half + jj) + l4 + 4 * r;
+                        const double hj = fma(-s_dt[j], s_mu0[j], s_dn[j]);
+                        acc = fma(A[I][jj][r], hj, acc);
+                        if (live) st_dev(Wout + i + (long)EPB * j, (i == j ? di : 0.0) - di * s_dt[j] * A[I][jj][r]);
+                    }
+                acc += __shfl_xor(acc, 16, 64); acc += __shfl_xor(acc, 32, 64);
+                if (l4 == 0) gpart[half][48 * u + 16 * I + l15] = acc;
+            }
+            __syncthreads();
+            if (half == 0 && l4 == 0) {
+    #pragma unroll
+                for (int I = 0; I < 3; ++I) {
+                    const int i = 48 * u + 16 * I + l15;
+                    if (i < EPB) {
+                        const double di = s_dt[i];
+                        st_dev(gout + i, fma(-di, gpart[0][i] + gpart[1][i], fma(-di, s_mu0[i], s_dn[i])));
+                    }
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // W and g are through before wave 0 says so (a barrier only waits for LDS)
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (stamps && t == 0) stamps[3] = __builtin_amdgcn_s_memtime();
     pgp_yield_mark(yield_flags, -1);
 }
 
 // strip(:, k) = column i0 + k of the symmetric Sigma (kept in its lower triangle), all np rows but [skip0, skip1) (the block's own
 // rows when its prep workgroups have written them).  Grid (np / 256, 8).
 __global__ __launch_bounds__(256) void ep_strip_kernel(const double* __restrict__ Sig, long ld, long np, long i0,
-                                                       double* __restrict__ S, long skip0, long skip1) {
+                                                       double* __restrict__ S, long skip0, long skip1, unsigned* done) {
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
     const int k0 = 16 * blockIdx.y;
-    if (r >= np || (r >= skip0 && r < skip1)) return;
-    double v[16];
-    if (r >= i0 + EPB) {
+    if (r < np && !(r >= skip0 && r < skip1)) {
+        double v[16];
+        if (r >= i0 + EPB) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = Sig[r + (i0 + k0 + k) * ld];
-    } else if (r < i0) {
-        const double2_t* src = reinterpret_cast<const double2_t*>(Sig + i0 + k0 + r * ld);
+            for (int k = 0; k < 16; ++k) v[k] = Sig[r + (i0 + k0 + k) * ld];
+        } else if (r < i0) {
+            const double2_t* src = reinterpret_cast<const double2_t*>(Sig + i0 + k0 + r * ld);
 #pragma unroll
-        for (int k = 0; k < 16; k += 2) { const double2_t x = src[k / 2]; v[k] = x[0]; v[k + 1] = x[1]; }
-    } else {
+            for (int k = 0; k < 16; k += 2) { const double2_t x = src[k / 2]; v[k] = x[0]; v[k + 1] = x[1]; }
+        } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = sym_at(Sig, ld, r, i0 + k0 + k);
+            for (int k = 0; k < 16; ++k) v[k] = sym_at(Sig, ld, r, i0 + k0 + k);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) S[r + (long)(k0 + k) * ld] = v[k];
     }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) S[r + (long)(k0 + k) * ld] = v[k];
+    // the resident sweep kernel's prep workgroups count the workgroups that are through (EPF_STRIP)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // mu_r += sum_k S(r, k) g_k for the rows rlo <= r < rhi outside [skip0, skip1) (64 rows per workgroup, the columns split over the
@@ -792,7 +925,9 @@ struct EpWork {
     double *ttau_d, *tnu_d, *mu_d, *m_d, *s_d, *sbuf, *coef, *diag_d, *tmp_d;
     double *S, *Sc;                      // block sweep: the strips Sigma(:, B) of the last two blocks and U = strip W
     double *Wb, *gb, *ldb;               // block sweep: W and g of the last two blocks, log of the blocks' determinant factors
-    unsigned* prep_cnt; unsigned prep_target;   // prep workgroups that have finished (a counter that only grows), and the count the next chain waits for
+    double* tile;                        // block sweep: Sigma_BB, mu_B, diag Sigma_BB as the prep workgroups hand them to the chain
+    unsigned* flags;                     // EPF_*: the device counters through which the resident sweep kernel and the bulk stream meet
+    unsigned chain_total, prep_total, strip_total;   // their values once everything launched so far has run (strips in launches)
 };
 
 }  // namespace
@@ -984,11 +1119,12 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
     EP_TRY(dalloc(&w.S, (size_t)2 * EPB * np * sizeof(double)));
     EP_TRY(dalloc(&w.Sc, (size_t)EPB * np * sizeof(double)));
     EP_TRY(dalloc(&w.Wb, (size_t)2 * EPB * EPB * sizeof(double)));
+    EP_TRY(dalloc(&w.tile, (size_t)(EP_TILE_N + 2 * EPB) * sizeof(double)));
     EP_TRY(dalloc(&w.gb, (size_t)(2 * EPB + 16) * sizeof(double)));
-    EP_TRY(dalloc(&w.ldb, (size_t)(np / EPB + 2) * sizeof(double)));
-    w.prep_cnt = (unsigned*)(w.ldb + np / EPB + 1);
-    w.prep_target = 0u;
-    HIP_TRY(hipMemsetAsync(w.prep_cnt, 0, sizeof(double), st));
+    EP_TRY(dalloc(&w.ldb, (size_t)(np / EPB + 3) * sizeof(double)));
+    w.flags = (unsigned*)(w.ldb + np / EPB + 1);
+    w.chain_total = w.prep_total = w.strip_total = 0u;
+    HIP_TRY(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), st));
     HIP_TRY(hipMemsetAsync(w.Kd, 0, nn, st));
     EP_TRY(alloc_factor_buffer(c, np, ldf, &w.F));
     FactorGuard fguard(c, w.F, (size_t)ldf * np * sizeof(double), /*scrub=*/true);
@@ -1054,48 +1190,42 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
         nlZ_old = nlZ;
         ++sweep;
         if (c->ep_block) {
-            // block sweep: chain stream (the high-priority panel stream) = prep(b) -> chain(b); bulk stream (main) = strip(b),
-            // U(b), fold(b), mu(b).  Events: S[b] strip(b) done, C[b] chain(b) and prep(b+1) done.
+            // block sweep: the chain stream (the high-priority panel stream) runs ONE resident kernel per sweep (chain + prep workgroups);
+            // the bulk stream (main) strip(b), U(b), fold(b), mu(b) per block.  The two meet through device counters (ep_chain_kernel).
             const long nbl = (n + EPB - 1) / EPB;
             hipStream_t sa = c->st2 ? c->st2 : st, sb = st;
-            while ((long)c->ep_ev.size() < 3 * nbl + 1) {
+            while ((long)c->ep_ev.size() < 2) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 c->ep_ev.push_back(e);
             }
-            auto evS = [&](long b) { return c->ep_ev[3 * b]; };
-            auto evC = [&](long b) { return c->ep_ev[3 * b + 1]; };
             unsigned* yfl = (c->yield && c->yield_flags) ? c->yield_flags : nullptr;
-            HIP_TRY(hipEventRecord(c->ep_ev[3 * nbl], st));
-            if (sa != st) HIP_TRY(hipStreamWaitEvent(sa, c->ep_ev[3 * nbl], 0));
+            const unsigned swg = (unsigned)((np + 255) / 256) * 8u;       // workgroups of one strip launch
+            HIP_TRY(hipEventRecord(c->ep_ev[0], st));
+            if (sa != st) HIP_TRY(hipStreamWaitEvent(sa, c->ep_ev[0], 0));
+            if (sa == st) return PGP_ERR_HIP;          // (the resident kernel needs a stream of its own beside the bulk launches)
+            if (ep_timing)
+                hipLaunchKernelGGL(ep_chain_kernel<true>, dim3(37), dim3(512), EP_BLOCK_LDS, sa, w.Sig, np, n, (int)nbl, w.mu_d, w.m_d,
+                                   c->y_dev, w.ttau_d, w.tnu_d, w.Wb, w.gb, w.ldb, yfl, (long long*)(w.gb + 2 * EPB), w.S, w.tile, w.flags,
+                                   w.chain_total, w.prep_total, w.strip_total, swg);
+            else
+                hipLaunchKernelGGL(ep_chain_kernel<false>, dim3(37), dim3(512), EP_BLOCK_LDS, sa, w.Sig, np, n, (int)nbl, w.mu_d, w.m_d,
+                                   c->y_dev, w.ttau_d, w.tnu_d, w.Wb, w.gb, w.ldb, yfl, (long long*)nullptr, w.S, w.tile, w.flags,
+                                   w.chain_total, w.prep_total, w.strip_total, swg);
+            HIP_TRY(hipEventRecord(c->ep_ev[1], sa));
+            const unsigned cbase = w.chain_total;
+            w.chain_total += (unsigned)nbl;
+            w.prep_total += 36u * (unsigned)nbl;
             for (long b = 0; b < nbl; ++b) {
                 const long i0 = b * EPB;
-                const int nb = (int)std::min<long>(EPB, n - i0);
                 double* Wb = w.Wb + (b & 1) * EPB * EPB;
                 double* gb = w.gb + (b & 1) * EPB;
-                double* Sb = w.S + (b & 1) * EPB * np;  // strip(b); its rows B come from the prep workgroups of block b's launch
-                // chain stream: one launch per block -- workgroup 0 the chain, workgroups 1-36 prep from the previous block's (W, g)
-                if (b == 0)
-                    hipLaunchKernelGGL(ep_chain_kernel, dim3(1), dim3(512), EP_BLOCK_LDS, sa, w.Sig, np, i0, nb, w.mu_d, w.m_d, c->y_dev,
-                                       w.ttau_d, w.tnu_d, Wb, gb, w.ldb + b, yfl, (long long*)nullptr, (const double*)nullptr,
-                                       (double*)nullptr, (const double*)nullptr, (const double*)nullptr, (unsigned*)nullptr, 0u);
+                double* Sb = w.S + (b & 1) * EPB * np;  // strip(b); its rows B come from the prep workgroups
                 const bool last = b + 1 >= nbl;
-                HIP_TRY(hipEventRecord(evC(b), sa));
                 if (last && !track) break;             // nothing of this sweep reads what the last block does to the rest
                 hipLaunchKernelGGL(ep_strip_kernel, dim3((unsigned)((np + 255) / 256), 8), dim3(256), 0, sb, w.Sig, np, np, i0, Sb,
-                                   b > 0 ? i0 : 0L, b > 0 ? i0 + EPB : 0L);
-                HIP_TRY(hipEventRecord(evS(b), sb));
-                if (!last) {
-                    const long i1 = i0 + EPB;
-                    const int nb1 = (int)std::min<long>(EPB, n - i1);
-                    HIP_TRY(hipStreamWaitEvent(sa, evS(b), 0));
-                    w.prep_target += 36u;
-                    hipLaunchKernelGGL(ep_chain_kernel, dim3(37), dim3(512), EP_BLOCK_LDS, sa, w.Sig, np, i1, nb1, w.mu_d, w.m_d, c->y_dev,
-                                       w.ttau_d, w.tnu_d, w.Wb + ((b + 1) & 1) * EPB * EPB, w.gb + ((b + 1) & 1) * EPB, w.ldb + b + 1, yfl,
-                                       ep_timing && b + 1 == 5 ? (long long*)(w.gb + 2 * EPB) : (long long*)nullptr, (const double*)Sb,
-                                       w.S + ((b + 1) & 1) * EPB * np, (const double*)Wb, (const double*)gb, w.prep_cnt, w.prep_target);
-                }
-                HIP_TRY(hipStreamWaitEvent(sb, evC(b), 0));
+                                   b > 0 ? i0 : 0L, b > 0 ? i0 + EPB : 0L, w.flags + EPF_STRIP);
+                ++w.strip_total;
                 const long r0 = std::min<long>(i0 + EPB, np);   // first row of the sites still to come
                 const long u0 = track ? 0 : r0;        // track: Sigma stays complete (every row), otherwise only the rows still to be read
                 {
@@ -1103,6 +1233,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
                     g.A = Sb + u0; g.lda = np; g.a_kc = 0; g.B = Wb; g.ldb = EPB; g.b_kc = 0;
                     g.C = w.Sc + u0; g.ldc = np; g.M = (int)(np - u0); g.N = EPB; g.K = EPB;
                     g.alpha = 1.0; g.beta = 0.0; g.tile = 64; g.flops = 2.0 * (double)(np - u0) * EPB * EPB;
+                    g.wait_flag = w.flags + EPF_CHAIN; g.wait_target = cbase + (unsigned)b + 1u; g.wait_err = w.flags + EPF_ERR;
                     EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
                 }
                 const long r1 = r0 + EPB;
@@ -1137,13 +1268,13 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
                     }
                 }
             }
-            if (sa != st) HIP_TRY(hipStreamWaitEvent(st, evC(nbl - 1), 0));
+            HIP_TRY(hipStreamWaitEvent(st, c->ep_ev[1], 0));
             if (hipGetLastError() != hipSuccess) return PGP_ERR_HIP;
             if (ep_timing) {
                 long long sp[16];
                 HIP_TRY(hipMemcpyAsync(sp, w.gb + 2 * EPB, sizeof(sp), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
-                fprintf(stderr, "[ep] chain(5) stamps (10 ns ticks): load %lld  loop %lld (first half %lld)  epilogue %lld\n", sp[1] - sp[0], sp[2] - sp[1], sp[4] - sp[1], sp[3] - sp[2]);
+                fprintf(stderr, "[ep] chain(5) stamps (s_memtime ticks): load %lld  loop %lld (first half %lld)  epilogue %lld\n", sp[1] - sp[0], sp[2] - sp[1], sp[4] - sp[1], sp[3] - sp[2]);
                 fprintf(stderr, "[ep]   spins: chain waiting for the update waves %lld, update wave 1 waiting for its peers %lld, for the chain %lld\n", sp[4] - sp[1], sp[5], sp[6]);
             }
         } else
@@ -1155,6 +1286,8 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
         }
         HIP_TRY(hipMemcpyAsync(ttau.data(), w.ttau_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        unsigned eflags[4] = {0u, 0u, 0u, 0u};          // EPF_ERR: a device-side wait of the block sweep gave up
+        if (c->ep_block) HIP_TRY(hipMemcpyAsync(eflags, w.flags, sizeof(eflags), hipMemcpyDeviceToHost, st));
         if (track) {
             // nlZ (inf.py:184-188) from the carried state: the per-site terms on diag Sigma and mu as the sweep left them, log det B
             // from the sites' determinant factors
@@ -1166,6 +1299,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
                                w.ttau_d, w.tnu_d, 1, w.tmp_d, (double*)nullptr);
             HIP_TRY(hipMemcpyAsync(ph.data(), w.tmp_d, ph.size() * sizeof(double), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            if (eflags[EPF_ERR]) { pgp_set_last_hip_error(hipErrorLaunchTimeOut, "EP block sweep: a device-side wait gave up", __FILE__, __LINE__); return PGP_ERR_HIP; }
             for (long b = 0; b < nbl; ++b) half_logdet += 0.5 * ldh[b];
             double slZ = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0, t6 = 0.0;
             for (long b = 0; b < nbt; ++b) { slZ += ph[5 * b]; t3 += ph[5 * b + 1]; t4 += ph[5 * b + 2]; t5 += ph[5 * b + 3]; t6 += ph[5 * b + 4]; }
@@ -1178,6 +1312,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
             continue;
         }
         HIP_TRY(hipStreamSynchronize(st));
+        if (eflags[EPF_ERR]) { pgp_set_last_hip_error(hipErrorLaunchTimeOut, "EP block sweep: a device-side wait gave up", __FILE__, __LINE__); return PGP_ERR_HIP; }
         stamp("sweep done (synced)", 1);
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // inf.py:772
         HIP_TRY(hipStreamSynchronize(st));

@@ -53,6 +53,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int ti, tj;
     if (!decode_tile(g, (int)blockIdx.x, TM, ti, tj)) return;
+    if (g.wait_flag) {
+        if (threadIdx.x == 0) {
+            for (unsigned it = 0; (int)(__hip_atomic_load(g.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - g.wait_target) < 0; ++it) {
+                if (it > (1u << 22) || ((it & 1023u) == 1023u && __hip_atomic_load(g.wait_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(g.wait_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+    }
     if (!YIELD && g.yield_role == 2) {               // one of the chain's own small products: its CU's bulk workgroups give way
         pgp_yield_mark(g.yield_flags, +1);
         gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, false>(g, ti, tj, blockIdx.z, smem);
