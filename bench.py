@@ -214,11 +214,12 @@ def extras(lib, _lib, local, d, roof):
             "epComputeParams_calls_per_fit": rebuilds,
             "schedule": "Sigma, mu, log det B carried through the sweeps by exact identities (Woodbury folds per block of 128 sites, "
                         "determinant lemma per site); ONE rebuild from the converged site parameters (option ep_recompute=1: after "
-                        "every sweep, the reference's schedule, inf.py:772)",
+                        "every sweep, the reference's schedule, inf.py:772).  One resident kernel per sweep (1 chain + 36 prep "
+                        "workgroups) beside the bulk stream's folds; hand-overs through device counters, no launch per block",
             # the split the site sweep / parameter recomputation figures are read from (last of the two fits)
             "site_sweep_ms": ph5["solve"] / max(sw, 1), "site_sweep_GBs": bytes_sweep / (ph5["solve"] / max(sw, 1)) / 1e6,
             "site_sweep_frac_of_hbm_peak": bytes_sweep / (ph5["solve"] / max(sw, 1)) / 1e6 / PEAK_HBM_GBS,
-            "site_sweep_bound": "4096 sequentially dependent site updates per sweep (~0.5 us each inside ep_chain_kernel), not bandwidth",
+            "site_sweep_bound": "4096 sequentially dependent site updates per sweep (~0.7 us each inside ep_chain_kernel) + a ~22 us hand-over per block of 128, not bandwidth",
             "params_ms": ph5["potrf"] / rebuilds, "params_TFLOPs": 8.0 * n5 ** 3 / 3.0 / (ph5["potrf"] / rebuilds) / 1e9,
             "params_frac_of_mfma_peak": 8.0 * n5 ** 3 / 3.0 / (ph5["potrf"] / rebuilds) / 1e9 / PEAK_FP64_MFMA_TF,
             "first_params_and_K_ms": ph5["assemble"], "alpha_and_gradients_ms": ph5["grad"],
