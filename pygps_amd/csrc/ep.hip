@@ -1121,7 +1121,8 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
     EP_TRY(dalloc(&w.Wb, (size_t)2 * EPB * EPB * sizeof(double)));
     EP_TRY(dalloc(&w.tile, (size_t)(EP_TILE_N + 2 * EPB) * sizeof(double)));
     EP_TRY(dalloc(&w.gb, (size_t)(2 * EPB + 16) * sizeof(double)));
-    EP_TRY(dalloc(&w.ldb, (size_t)(np / EPB + 3) * sizeof(double)));
+    w.ldb = c->alpha_dev;                // [log det factors (np / 128) | . | counters (2 doubles) | per-site partial sums]: the head of the
+                                         // result buffer (alpha is written there when the sweeps are over), one pinned copy per sweep
     w.flags = (unsigned*)(w.ldb + np / EPB + 1);
     w.chain_total = w.prep_total = w.strip_total = 0u;
     HIP_TRY(hipMemsetAsync(w.flags, 0, 2 * sizeof(double), st));
@@ -1284,33 +1285,45 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
             hipLaunchKernelGGL(ep_rank1_mu_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, st, w.Sig, np, np,
                                w.sbuf, w.coef, w.tnu_d, w.mu_d);
         }
-        HIP_TRY(hipMemcpyAsync(ttau.data(), w.ttau_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        auto sites_to_host = [&]() -> int {
+            HIP_TRY(hipMemcpyAsync(ttau.data(), w.ttau_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+            return PGP_OK;
+        };
         unsigned eflags[4] = {0u, 0u, 0u, 0u};          // EPF_ERR: a device-side wait of the block sweep gave up
-        if (c->ep_block) HIP_TRY(hipMemcpyAsync(eflags, w.flags, sizeof(eflags), hipMemcpyDeviceToHost, st));
         if (track) {
             // nlZ (inf.py:184-188) from the carried state: the per-site terms on diag Sigma and mu as the sweep left them, log det B
-            // from the sites' determinant factors
+            // from the sites' determinant factors.  What the host needs to decide about the next sweep -- [log det factors of the
+            // blocks | counters | the per-site partial sums] -- sits in ONE device buffer and comes back in ONE copy into pinned
+            // memory (an asynchronous copy into pageable memory is staged and synchronised by the runtime: five of them per sweep
+            // were most of the 0.25 ms between two sweeps); the site parameters themselves are fetched when the sweeps are over
             const long nbl = (n + EPB - 1) / EPB, nbt = (n + 255) / 256;
-            std::vector<double> ldh(nbl), ph(5 * nbt);
-            HIP_TRY(hipMemcpyAsync(ldh.data(), w.ldb, (size_t)nbl * sizeof(double), hipMemcpyDeviceToHost, st));
+            double* const part_d = w.ldb + np / EPB + 3;
+            const double* const res_h = c->res_host + (w.ldb - c->res_dev);
             EP_TRY(gather_strided_launch(w.Sig, np + 1, np, w.diag_d, st));
             hipLaunchKernelGGL(ep_site_terms_kernel, dim3((unsigned)nbt), dim3(256), 0, st, n, c->y_dev, w.m_d, w.mu_d, w.diag_d, 0.0,
-                               w.ttau_d, w.tnu_d, 1, w.tmp_d, (double*)nullptr);
-            HIP_TRY(hipMemcpyAsync(ph.data(), w.tmp_d, ph.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+                               w.ttau_d, w.tnu_d, 1, part_d, (double*)nullptr);
+            HIP_TRY(hipMemcpyAsync((void*)res_h, w.ldb, (size_t)(np / EPB + 3 + 5 * nbt) * sizeof(double), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            memcpy(eflags, res_h + np / EPB + 1, sizeof(eflags));
+            const double* const ldh = res_h;
+            const double* const ph = res_h + np / EPB + 3;
             if (eflags[EPF_ERR]) { pgp_set_last_hip_error(hipErrorLaunchTimeOut, "EP block sweep: a device-side wait gave up", __FILE__, __LINE__); return PGP_ERR_HIP; }
             for (long b = 0; b < nbl; ++b) half_logdet += 0.5 * ldh[b];
             double slZ = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0, t6 = 0.0;
             for (long b = 0; b < nbt; ++b) { slZ += ph[5 * b]; t3 += ph[5 * b + 1]; t4 += ph[5 * b + 2]; t5 += ph[5 * b + 3]; t6 += ph[5 * b + 4]; }
             nlZ = half_logdet - slZ - 0.5 * t3 - 0.5 * t4 + 0.5 * t5 - 0.5 * t6;
             if (!std::isfinite(nlZ)) {                 // let the rebuild say what is wrong (first bad pivot)
+                EP_TRY(sites_to_host());
+                HIP_TRY(hipStreamSynchronize(st));
                 rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig, &half_logdet);
                 if (rc != PGP_OK) return rc;
             }
             stamp("sweep done, nlZ from the carried state", 1);
             continue;
         }
+        EP_TRY(sites_to_host());
+        if (c->ep_block) HIP_TRY(hipMemcpyAsync(eflags, w.flags, sizeof(eflags), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (eflags[EPF_ERR]) { pgp_set_last_hip_error(hipErrorLaunchTimeOut, "EP block sweep: a device-side wait gave up", __FILE__, __LINE__); return PGP_ERR_HIP; }
         stamp("sweep done (synced)", 1);
@@ -1320,6 +1333,9 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
         if (rc != PGP_OK) return rc;
     }
     if (track && sweep > 0) {
+        HIP_TRY(hipMemcpyAsync(ttau.data(), w.ttau_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // the posterior of the converged site parameters
         HIP_TRY(hipStreamSynchronize(st));
         stamp("params rebuilt from the converged sites", 2);
