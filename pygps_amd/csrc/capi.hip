@@ -173,6 +173,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "ep_r_direct")) { c->ep_r_direct = value; return PGP_OK; }
     if (!strcmp(name, "ep_alpha_direct")) { c->ep_alpha_direct = value; return PGP_OK; }
     if (!strcmp(name, "ep_sym")) { c->ep_sym = value; return PGP_OK; }
+    if (!strcmp(name, "ep_wait_kernel")) { c->ep_wait_kernel = value; return PGP_OK; }
     if (!strcmp(name, "ep_sigma_under")) { c->ep_sigma_under = value; return PGP_OK; }
     if (!strcmp(name, "ep_recompute")) { c->ep_recompute = value; return PGP_OK; }
     if (!strcmp(name, "ep_block")) { c->ep_block = value; return PGP_OK; }

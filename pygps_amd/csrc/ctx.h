@@ -69,6 +69,8 @@ struct pgp_ctx {
     int ep_recompute = 0;               // EP: 1 = rebuild Sigma, mu, L after EVERY sweep like the reference (inf.py:772); 0 = carry them by exact
                                         // identities and rebuild once, from the converged site parameters
     int ep_sigma_under = 1;             // EP: Sigma = K - V'V'^T accumulated under the sweep of the parameter recomputation (ep_fused 2)
+    int ep_wait_kernel = 1;             // EP block sweep: the bulk stream waits for the chain in a one-wave kernel of its own (1) or inside
+                                        // every workgroup of U = strip W (0: GemmArgs::wait_flag; 128 spinning workgroups cost 2.5 % of a fit)
     int ep_sym = 1;                     // EP: Sigma kept current in its lower triangle only (folds and K - V'V on the lower tiles)
     int ep_block = 1;                   // EP site sweep: 1 = one chain launch per 128 sites + Woodbury fold beside the next chain (round 3),
                                         // 0 = the reference's arithmetic literally: Sigma updated per site

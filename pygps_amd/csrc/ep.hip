@@ -423,7 +423,7 @@ __device__ __forceinline__ void ep_prep_body(int blk, double* Sig, long ld, long
 // workgroups 1 .. 36 = prep: the diagonal tile and mu of block b from block b-1's (W, g) as soon as the chain has published them
 // (block 0: a plain copy into the tile buffer).  No launch boundary on the sweep's critical path; the hand-overs are counters --
 //   flags[EPF_CHAIN]  blocks the chain has finished (W, g of the block are in memory): prep(b+1) and, on the bulk stream,
-//                     U(b) = strip W (inside its kernel: GemmArgs::wait_flag) wait for it;
+//                     a one-wave ep_wait_kernel ahead of U(b) = strip W (or U's own workgroups: GemmArgs::wait_flag) wait for it;
 //   flags[EPF_PREP]   prep workgroups that have finished: chain(b) waits for 36 more;
 //   flags[EPF_STRIP]  workgroups of the bulk stream's strip kernels that have finished: prep(b+1) reads strip(b).
 // cbase / pbase / sbase: the counters' values before this sweep's first block (sbase in strip LAUNCHES of swg workgroups each).
@@ -803,6 +803,15 @@ __global__ __launch_bounds__(512) void ep_chain_kernel(double* Sig, long ld, lon
         }
     }
     pgp_yield_mark(yield_flags, -1);
+}
+
+// The bulk stream waits for the chain's counter in a one-wave kernel of its own; stream order holds U, the fold and the strips back
+// behind it (128 workgroups of U spinning on the counter themselves: 20.2 instead of 19.7 ms per fit, option ep_wait_kernel 0)
+__global__ __launch_bounds__(64) void ep_wait_kernel(unsigned* f, unsigned target, unsigned* err) {
+    if (threadIdx.x == 0) {
+        ep_wait_ge(f, target, err);
+        __threadfence();
+    }
 }
 
 // strip(:, k) = column i0 + k of the symmetric Sigma (kept in its lower triangle), all np rows but [skip0, skip1) (the block's own
@@ -1234,7 +1243,8 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
                     g.A = Sb + u0; g.lda = np; g.a_kc = 0; g.B = Wb; g.ldb = EPB; g.b_kc = 0;
                     g.C = w.Sc + u0; g.ldc = np; g.M = (int)(np - u0); g.N = EPB; g.K = EPB;
                     g.alpha = 1.0; g.beta = 0.0; g.tile = 64; g.flops = 2.0 * (double)(np - u0) * EPB * EPB;
-                    g.wait_flag = w.flags + EPF_CHAIN; g.wait_target = cbase + (unsigned)b + 1u; g.wait_err = w.flags + EPF_ERR;
+                    if (c->ep_wait_kernel) hipLaunchKernelGGL(ep_wait_kernel, dim3(1), dim3(64), 0, sb, w.flags + EPF_CHAIN, cbase + (unsigned)b + 1u, w.flags + EPF_ERR);
+                    else { g.wait_flag = w.flags + EPF_CHAIN; g.wait_target = cbase + (unsigned)b + 1u; g.wait_err = w.flags + EPF_ERR; }
                     EP_TRY(gemm_prof(c, PC_GEMM_INNER, g, sb));
                 }
                 const long r1 = r0 + EPB;

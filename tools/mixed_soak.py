@@ -1,5 +1,5 @@
 """Mixed soak: one host thread runs cold EP fits (cfg 5 shape), another exact fits (cfg 2 shape) on a second fit stream of the
-same GPU, for SECONDS.  Both results must stay bit-identical from call to call: the EP chain kernel hands data between its
+same GPU, for SECONDS (argv[1]; further k=v arguments are library options of the EP context).  Both results must stay bit-identical from call to call: the EP chain kernel hands data between its
 waves through LDS sequence counters, and a co-running bulk workload changes every timing in it."""
 import sys, time, os, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +17,8 @@ out = {}
 
 def ep_loop():
     with _lib.fit_stream(0):
+        for o in sys.argv[2:]:                     # k=v library options for the EP context
+            k_, v_ = o.split('='); _lib.load().pgp_set_option(_lib.ctx(), k_.encode(), int(v_))
         ref, k = None, 0
         while time.perf_counter() < stop:
             m = pyGPs.GPC(); m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(d5)), 0.0))
