@@ -41,7 +41,7 @@ struct pgp_ctx {
     hipStream_t st = nullptr;
     hipStream_t st2 = nullptr;          // panel stream of the look-ahead Cholesky (high priority)
     std::vector<hipEvent_t> fill_ev;
-    std::vector<hipEvent_t> ep_ev;      // EP block sweep: strip / chain / prep events per block
+    std::vector<hipEvent_t> ep_ev;      // EP block sweep: the two events around a sweep (bulk stream -> chain stream and back)
     double* eet_out = nullptr;          // set by the fit for the duration of one sweep: where the filler accumulates B^-1
     long eet_ld = 0;
     double* fill2_C = nullptr;          // potrf_blocked_rhs: symmetric matrix (lower tiles) that receives -= V' V'^T panel by panel, or null
