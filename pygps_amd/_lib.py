@@ -83,6 +83,8 @@ TEST_SIGNATURES = {
                                 _dp]),
     "pgp_test_gemm_shrink": (C.c_int, [_vp, _dp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _i64,
                                        _i64]),
+    "pgp_test_gemm_skip_wait": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_int)]),
     "pgp_test_probit_hazard": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "pgp_test_valu_peak": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "pgp_test_mfma_peak": (C.c_int, [_vp, C.c_int, _dp]),

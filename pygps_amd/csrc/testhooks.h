@@ -13,6 +13,10 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
                   double* C, int64_t ldc, int M, int N, int K, int iters, double* ms_out);
 int pgp_test_gemm_shrink(pgp_ctx* ctx, const double* Y, int64_t ldy, int M, int K, int w, int nb, int dm, int zero_from,
                          double* C, int64_t ldc, int64_t sC);
+/* C -= A B' on the lower tiles (packed, masked diagonal tiles) but those whose first row and column lie in [skip_lo, skip_hi); with
+   wait_ms > 0 every workgroup waits inside the kernel for a device counter that the second stream raises wait_ms later. */
+int pgp_test_gemm_skip_wait(pgp_ctx* ctx, int tile, const double* A, const double* B, double* C, int n, int K, int skip_lo,
+                            int skip_hi, int wait_ms, int* timed_out);
 int pgp_test_probit_hazard(pgp_ctx* ctx, const double* z, double* out, int n);
 int pgp_test_valu_peak(pgp_ctx* ctx, int iters, int waves_per_simd, double* out2);
 int pgp_test_mfma_peak(pgp_ctx* ctx, int iters, double* tflops_out);

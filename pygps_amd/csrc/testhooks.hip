@@ -6,6 +6,9 @@
 #include <vector>
 
 #include "ctx.h"
+#include <chrono>
+#include <thread>
+
 #include "testhooks.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -345,6 +348,41 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     (void)hipFree(Ad); (void)hipFree(Bd); (void)hipFree(Cd);
+    return rc;
+}
+
+// GemmArgs::skip_lo / skip_hi and GemmArgs::wait_flag (EP's block sweep): n x n lower-triangular update, column-major host buffers
+int pgp_test_gemm_skip_wait(pgp_ctx* ctx, int tile, const double* A, const double* B, double* C, int n, int K, int skip_lo,
+                            int skip_hi, int wait_ms, int* timed_out) {
+    if (!ctx) return -1;
+    pgp_ctx* c = ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    DevScratch scr;
+    double *Ad = nullptr, *Bd = nullptr, *Cd = nullptr;
+    unsigned* fl = nullptr;
+    const size_t an = (size_t)n * K * 8, cn = (size_t)n * n * 8;
+    CHK(scr.alloc(&Ad, an)); CHK(scr.alloc(&Bd, an)); CHK(scr.alloc(&Cd, cn));
+    CHK(scr.alloc(&fl, 16));
+    HIP_TRY(hipMemcpy(Ad, A, an, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(Bd, B, an, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(Cd, C, cn, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(fl, 0, 16));
+    GemmArgs g{};
+    g.A = Ad; g.lda = n; g.B = Bd; g.ldb = n; g.C = Cd; g.ldc = n; g.M = n; g.N = n; g.K = K; g.alpha = -1.0; g.beta = 1.0;
+    g.tri = 2; g.mask_diag = 1; g.batch = 1; g.tile = tile; g.dbg = c->gemm_dbg; g.skip_lo = skip_lo; g.skip_hi = skip_hi;
+    if (wait_ms > 0) { g.wait_flag = fl; g.wait_target = 7u; g.wait_err = fl + 1; }
+    int rc = gemm_f64_launch(g, c->st);
+    if (rc == PGP_OK && wait_ms > 0) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(wait_ms));
+        const unsigned seven = 7u;
+        HIP_TRY(hipMemcpyAsync(fl, &seven, sizeof(seven), hipMemcpyHostToDevice, c->st2));     // the other stream raises the counter
+        HIP_TRY(hipStreamSynchronize(c->st2));
+    }
+    HIP_TRY(hipStreamSynchronize(c->st));
+    unsigned flh[2] = {0u, 0u};
+    HIP_TRY(hipMemcpy(flh, fl, sizeof(flh), hipMemcpyDeviceToHost));
+    if (timed_out) *timed_out = (int)flh[1];
+    if (rc == PGP_OK) HIP_TRY(hipMemcpy(C, Cd, cn, hipMemcpyDeviceToHost));
     return rc;
 }
 

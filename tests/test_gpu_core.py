@@ -322,3 +322,30 @@ def test_exp_nonpos_accuracy_over_the_whole_range(lib):
     assert np.max(np.abs(K[normal] / ref[normal] - 1.0)) < 1e-15
     assert np.all(K[~normal] >= 0.0) and np.all(np.abs(K[~normal] - ref[~normal]) < 1e-300)
     assert K[0] == 1.0 and K[-1] == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile,n,skip,wait_ms", [(128, 1024, (256, 384), 0), (64, 512, (128, 256), 0), (128, 1024, (0, 0), 0),
+                                                  (128, 1024, (512, 640), 20), (64, 512, (0, 0), 20)])
+def test_gemm_skip_block_and_in_kernel_wait(lib, tile, n, skip, wait_ms):
+    """GemmArgs::skip_lo / skip_hi (the diagonal block another kernel owns inside a whole-matrix update) and GemmArgs::wait_flag
+    (every workgroup waits for a device counter that another stream raises): the two pieces of the EP block sweep's fold / U
+    launches, here on their own.  Lower tiles (masked diagonal) of C -= A B'; the skipped block must come back untouched and a
+    launch that waited 20 ms for its counter must not have timed out."""
+    from pygps_amd import _lib
+    rng = np.random.RandomState(5)
+    K = 128
+    A = np.asfortranarray(rng.randn(n, K)); B = np.asfortranarray(rng.randn(n, K)); C0 = np.asfortranarray(rng.randn(n, n))
+    Cst = C0.copy(order="F")
+    to = C.c_int(-1)
+    _lib.check(lib.pgp_test_gemm_skip_wait(_lib.ctx(), tile, _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cst), n, K, skip[0], skip[1], wait_ms,
+                                           C.byref(to)))
+    assert to.value == 0
+    ref = C0 - A @ B.T
+    low = np.tril(np.ones((n, n), bool))
+    touched = low.copy()
+    # tiles strictly above the diagonal are not part of the launch; within diagonal tiles only i >= j is written
+    if skip[1] > skip[0]:
+        touched[skip[0]:skip[1], skip[0]:skip[1]] = False
+    assert np.max(np.abs(Cst[touched] - ref[touched])) < 1e-10
+    assert np.array_equal(Cst[~touched], C0[~touched])
