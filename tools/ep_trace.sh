@@ -5,3 +5,4 @@ f=$(ls -t /tmp/epprof/*/*_kernel_stats.csv | head -1)
 head -16 $f | cut -c1-200
 t=$(ls -t /tmp/epprof/*/*_kernel_trace.csv | head -1)
 gzip -c $t > $GRAFT_REPO_ROOT/gpurun_out/ep_trace.csv.gz
+PYTHONPATH=$GRAFT_REPO_ROOT python $GRAFT_REPO_ROOT/tools/ep_timeline.py $t > $GRAFT_REPO_ROOT/gpurun_out/ep_timeline.txt 2>&1
