@@ -23,6 +23,12 @@ rocprofv3 CSV reproduces it); the executed/algorithmic flop ratio and the aggreg
 (multi-stream) window are reported beside it.  `cpu_baseline` (N=1 only) times the oracle's
 reference-faithful CPU path (scipy cdist + LAPACK dpotrf + general-LU solve_chol + one derivative matrix
 per hyper, call-for-call what pyGPs does) on this host's cores: ONE full fit at the benchmark size.
+
+Schema notes.  `per_rank_fits_per_s` lists every rank's own rate, `value` the aggregate (the slowest rank's window).  The
+collective extras (`cfg4_restarts_N8192`, `sharded_fit`) run after the timed region behind a 300 s watchdog:
+`collective_extras_ok` is false -- and `collective_extras_error` says why -- when they did not finish; the line (and rc 0)
+still goes out so that the headline survives a stall on hardware the collective path has never seen.  With `--gpus N > 1`
+and no launcher environment the script re-executes itself under `python -m torch.distributed.run --nproc-per-node N`.
 """
 import argparse
 import json
@@ -90,6 +96,63 @@ def cpu_baseline(N, d, budget_s=150.0):
     ts = one(N // 2, faithful=False)                    # same maths with triangular solves + potri, half size, scaled
     out["value_sane_linear_algebra"] = 1.0 / (ts * 8)
     out["sane_sample"] = "N=%d in %.1f s, scaled by 2^3" % (N // 2, ts)
+    return out
+
+
+def cpu_baseline_other_configs(cfg2_fits_per_s):
+    """CPU baselines of BASELINE configs[2], [3], [4] on this host, bounded samples of the same workloads through the oracle's
+    reference-faithful path, scaled to the configured size by the stated model and LABELLED as extrapolations.  Beside them:
+    the wall times the reference itself took in the build container (8 cores) when the fixtures were recorded."""
+    from oracle import gp_oracle as O
+    out = {}
+    # cfg 3: GPR + SEard, N = 16384, d = 64.  Sample: one faithful fit at N = 2048 (67 gradients: 65 derivative matrices).
+    try:
+        n, d = 2048, 64
+        x, y = synth_reg(n, d)
+        c = float(y.mean())
+        hyp = np.concatenate([np.full(d, np.log(np.sqrt(d))), [0.0]])
+        t = time.perf_counter()
+        O.exact_fit(O.RBFARD, hyp, 0, np.log(0.1), x, y, c * np.ones_like(y), np.ones_like(y), nargout=3, faithful=True)
+        t3 = time.perf_counter() - t
+        # model (SURVEY 8d): dense linear algebra ~ N^3, derivative assembly 65 N^2 d; both terms grow by >= 64 from N = 2048
+        # to 16384 -- the N^2 d term by 64, the N^3 term by 512: the bracket [x64, x512] is reported, the headline uses x512
+        # only for the share the N = 2048 fit spends outside getDerMatrix (timed separately below)
+        t = time.perf_counter()
+        O.der_matrix(O.RBFARD, hyp, 0, x=x, mode="train", der=0)
+        tder = (time.perf_counter() - t) * (d + 1)
+        tder = min(tder, t3)
+        est = (t3 - tder) * 512.0 + tder * 64.0
+        out["cfg3"] = {"value": 1.0 / est, "unit": "fits/s", "kind": "port", "extrapolated": True,
+                       "sample": "1 faithful oracle fit at N=2048 d=64 (%.1f s, of which ~%.1f s in 65 getDerMatrix calls), scaled to "
+                                 "N=16384 as x512 on the N^3 part and x64 on the 65 N^2 d part => %.0f s per fit (EXTRAPOLATED)"
+                                 % (t3, tder, est),
+                       "reference_recorded": "the reference itself, build container, 8 cores: N=16384 d=64 getPosterior 2969 s "
+                                             "(tests/golden/G7_rbfard_d64_N16384.npz ref_seconds); N=4096: 160 s"}
+    except Exception as e:           # pragma: no cover
+        out["cfg3"] = {"error": repr(e)}
+    # cfg 5: GPC + RBF, infEP, N = 4096, d = 32.  Sample: oracle EP (the reference's per-site full-matrix update) at N = 512.
+    try:
+        n, d = 512, 32
+        rng = np.random.RandomState(0)
+        x = rng.randn(n, d); w = rng.randn(d, 1)
+        y = np.sign(x @ w / np.sqrt(d) + 0.3 * rng.randn(n, 1)); y[y == 0] = 1
+        t = time.perf_counter()
+        r = O.ep_fit(O.RBF, np.array([np.log(np.sqrt(d)), 0.0]), 0, x, y, np.zeros_like(y))
+        t5 = time.perf_counter() - t
+        sw = int(r.get("sweeps", 4))
+        est = t5 * 8.0 ** 3                      # per sweep: N sites x O(N^2) each + an N^3 rebuild; same sweep count (4) at N = 4096
+        out["cfg5"] = {"value": 1.0 / est, "unit": "fits/s", "kind": "port", "extrapolated": True,
+                       "sample": "1 oracle EP fit at N=512 d=32 (%.1f s, %d sweeps), scaled by 8^3 to N=4096 => %.0f s per fit "
+                                 "(EXTRAPOLATED; N^3 per sweep, 4 sweeps at both sizes)" % (t5, sw, est),
+                       "reference_recorded": "the reference itself, build container, 8 cores: N=4096 ~43 min per fit (G8ii N=4096), "
+                                             "N=512 4.1 s"}
+    except Exception as e:           # pragma: no cover
+        out["cfg5"] = {"error": repr(e)}
+    # cfg 4 = the cfg-2 fit, 8 restarts x minimize.run: the optimiser's cost is the fits it asks for
+    out["cfg4"] = {"value": cfg2_fits_per_s, "unit": "fits/s", "kind": "port", "extrapolated": True,
+                   "sample": "derived: every objective evaluation of the restart search is one cfg-2 fit (N=8192 d=16), so the CPU "
+                             "rate is the cfg-2 figure of this run; a cfg-4 search of ~374 fits would take %.1f h on this host"
+                             % (374.0 / cfg2_fits_per_s / 3600.0)}
     return out
 
 
@@ -411,6 +474,18 @@ def main():
                          "0 = skip")
     args = ap.parse_args()
 
+    # `python3 bench.py --gpus N` with N > 1 and no launcher around it: become the launcher (one rank per GPU under
+    # torch.distributed.run, rendezvous on 127.0.0.1) and hand its output through -- rank 0 of the children prints the line
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     # stdout carries exactly ONE line (the JSON).  Native libraries print there too (RCCL writes its version banner to
     # the C stdout when the first communicator is made), so fd 1 is pointed at stderr for the life of the process and
     # the JSON line goes out through a private duplicate of the original stdout.
@@ -517,7 +592,7 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(0, max(args.warmup, S))
-    windows = []
+    windows, own_windows = [], []
     vals = None
     for wdw in range(max(1, args.windows)):           # EXACTLY K steps per window, barrier + synchronize on both sides
         fence()
@@ -525,12 +600,21 @@ def main():
         vals = run_steps(args.warmup, args.steps)
         fence()
         wt = time.perf_counter() - t0
+        own_windows.append(wt)
         if dist:
             tt = torch.tensor([wt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)                                # slowest rank defines the window
             wt = float(tt.item())
         windows.append(wt)
     dt = float(np.median(windows))
+    # every rank's own rate (its median window, before the max over ranks): the 1/2/4/8 table shows stragglers directly
+    own = float(np.median(own_windows))
+    rank_rates = [args.steps / own]
+    if dist:
+        rr = torch.tensor([args.steps / own], dtype=torch.float64, device=cdev)
+        parts_r = [torch.empty_like(rr) for _ in range(world)]
+        dist.all_gather(parts_r, rr)
+        rank_rates = [float(p_.item()) for p_ in parts_r]
     # single-stream latency of one fit in a dependent chain (what cfg 4's one-restart-per-GPU minimize.run sees)
     t1 = time.perf_counter()
     lat_stage = []
@@ -667,6 +751,7 @@ def main():
                        "parallelism": "independent fits (restart evaluations) per GPU, %d concurrent fit streams per "
                                       "GPU; RCCL broadcast + all-reduce(max) + all-gather only%s"
                                       % (S, "" if dist else " (no process group at world size 1)")},
+            "per_rank_fits_per_s": rank_rates, "per_gpu_fits_per_s": (total_fits / dt) / world,
             "timed_windows_s": windows, "window_spread": (max(windows) - min(windows)) / dt,
             "single_stream_ms_per_fit": lat_ms, "single_stream_fits_per_s": 1e3 / lat_ms,
             "stage_ms_single_stream_median": stages,
@@ -694,6 +779,7 @@ def main():
             if rank == 0:
                 out.update(partial)
                 out["collective_extras_error"] = "no result within 300 s (world %d)" % world
+                out["collective_extras_ok"] = False
                 os.write(json_fd, (json.dumps(out) + "\n").encode())
             os._exit(0)
         dog = threading.Timer(300.0, bail)
@@ -711,10 +797,32 @@ def main():
         dog.cancel()
         if rank == 0:
             out.update(partial)
+            out["collective_extras_ok"] = all("error" not in v for v in partial.values())
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, d, args.cpu_budget)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if not args.no_extras:
+                others = cpu_baseline_other_configs(out["cpu_baseline"]["value"])
+                out["cpu_baseline"]["other_configs"] = others
+                for key, cfg in (("cfg3_seard_N16384_d64", "cfg3"), ("cfg5_ep_N4096_d32", "cfg5"), ("cfg4_restarts_N8192", "cfg4")):
+                    if isinstance(out.get(key), dict) and cfg in others:
+                        out[key]["cpu_baseline"] = others[cfg]
+        # the driver's parser keeps the contract keys, `config`, `roofline` and `cpu_baseline`: the other configs' headline
+        # scalars ride inside `roofline` so that they survive in BENCH_rNN.json (the full objects stay at top level)
+        if out.get("roofline") is not None:
+            def pick(key, *names):
+                o = out.get(key)
+                return {n_: o.get(n_) for n_ in names if isinstance(o, dict) and n_ in o} if isinstance(o, dict) else None
+            out["roofline"]["other_configs"] = {
+                "single_stream_ms_per_fit": out.get("single_stream_ms_per_fit"),
+                "cfg3_seard_N16384_d64": pick("cfg3_seard_N16384_d64", "fit_ms", "hadamard_reduce_ms", "assembly_fused_ms",
+                                              "cholesky_sweep_frac_of_peak"),
+                "cfg5_ep_N4096_d32": pick("cfg5_ep_N4096_d32", "fit_ms", "sweeps", "site_sweep_ms", "params_ms"),
+                "cfg4_restarts_N8192": pick("cfg4_restarts_N8192", "fits_per_s", "fits", "wall_s", "n_gpus"),
+                "sharded_fit": pick("sharded_fit", "n", "world", "seconds", "frac_of_peak_per_gpu", "peak_bytes_per_rank"),
+                "predict_N8192_ns65536": pick("predict_N8192_ns65536", "ms"),
+                "fitc_n131072_nu1024": pick("fitc_n131072_nu1024", "fit_ms")}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()

@@ -30,7 +30,7 @@ typedef struct pgp_fitc pgp_fitc;     /* FITC posterior on the device (alpha, de
 
 /* covariance kinds            reference class                      */
 #define PGP_COV_RBF 0     /* Core/cov.py:786-828   hyp=[log ell, log sf]               */
-#define PGP_COV_RBFARD 1  /* Core/cov.py:872-938   hyp=[log ell_1..log ell_D, log sf]  */
+#define PGP_COV_RBFARD 1  /* Core/cov.py:872-938   hyp=[log ell_1..log ell_D, log sf]   (any D with nhyp <= 255) */
 #define PGP_COV_MATERN 2  /* Core/cov.py:1078-1182 hyp=[log ell, log sf], para=d in {1,3,5,7} */
 #define PGP_COV_RBFUNIT 3 /* Core/cov.py:832-869   hyp=[log ell]                                  */
 #define PGP_COV_RQ 4      /* Core/cov.py:1304-1347 hyp=[log ell, log sf, log alpha]               */
@@ -41,7 +41,7 @@ typedef struct pgp_fitc pgp_fitc;     /* FITC posterior on the device (alpha, de
 #define PGP_COV_NOISE 9   /* Core/cov.py:1254-1300 hyp=[log sf]                                      */
 #define PGP_COV_CONST 10  /* Core/cov.py:941-982   hyp=[log sf]  (sf2 = exp(hyp0), as the reference) */
 #define PGP_COV_NKIND 11
-/* Sum / Product / Scale tree over non-ARD primitives (Core/cov.py:230-328), registered with
+/* Sum / Product / Scale tree over primitives (Core/cov.py:230-328; up to two ARD leaves), registered with
  * pgp_set_composite and selected by kind = PGP_COV_COMPOSITE in pgp_cov / pgp_exact_fit / pgp_ep_fit.
  * hyp is the composite's flattened list in the reference's order (cov1.hyp + cov2.hyp; [scalar] + cov.hyp). */
 #define PGP_COV_COMPOSITE 100
@@ -74,7 +74,10 @@ int pgp_cov(pgp_ctx* ctx, int kind, int mode, int der, const double* x, int64_t 
 
 /* Composite kernels: ProductOfKernel / SumOfKernel / ScaleOfKernel (Core/cov.py:230-328).  prog is the tree in
  * postfix order (PGP_PROG_* tokens); it stays registered in the context until replaced.  Limits: 8 leaves, 8 Scale
- * nodes, 8 products after distributing products over sums; at most one ARD leaf (RBFard / RQard, D <= 64); else -13. */
+ * nodes, 8 products after distributing products over sums; at most TWO ARD leaves (RBFard / RQard), each with D <= 64
+ * (their 1 / ell_k^2 weights travel as kernel arguments); anything beyond returns -13 from the calls that use the program
+ * -- the Python layer then takes the dense path (pgp_exact_fit_dense / pgp_ep_fit_dense).  The PLAIN kinds
+ * PGP_COV_RBFARD / PGP_COV_RQARD take any D (the scales are folded into the coordinates). */
 int pgp_set_composite(pgp_ctx* ctx, const int32_t* prog, int nprog);
 
 /* ---- data residency -------------------------------------------------------------------------

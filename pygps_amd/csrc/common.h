@@ -66,6 +66,10 @@ struct GemmArgs {
     // Batched launches whose products shrink with the batch index z (the owned column panels of a block-cyclic sweep):
     // product z has M - z * batch_dm rows (tiles beyond them exit at once) and its first-touch row moves up with it.
     int batch_dm;
+    int batch_dk;           // ... and the k clip of product z is koff + z * batch_dk (strips of a triangular product: sharded.hip)
+    // ... whose C pieces are stored COMPACTLY one behind the other: piece z has leading dimension ldc - z * batch_dldc and
+    // starts at C + z * sC - z (z - 1) / 2 * batch_sC2  (column strips of a lower triangle, each as tall as it needs to be)
+    int batch_dldc; long batch_sC2;
     // Cooperative yield (see gemm_tile.h): a per-CU word counts the workgroups of the latency-critical diagonal-panel chain that
     // are resident on that CU.  yield_role 1 (bulk launches): the k-loop polls its CU's word once per stage and sleeps while it
     // is non-zero; yield_role 2 (the chain's own small GEMMs): the workgroup increments the word while it runs.

@@ -96,7 +96,7 @@ int launch_t(const GemmArgs& g, hipStream_t st) {
 }
 
 static bool dma_ok(const GemmArgs& g) {
-    return g.tile != 64 && (g.dbg & 64) && !g.a_kc && !g.b_kc && (g.K % 16) == 0 && (g.koff % 16) == 0;
+    return g.tile != 64 && (g.dbg & 64) && !g.a_kc && !g.b_kc && (g.K % 16) == 0 && (g.koff % 16) == 0 && (g.batch_dk % 16) == 0;
 }
 
 template <int T>

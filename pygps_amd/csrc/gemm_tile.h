@@ -71,10 +71,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         diag = g.mask_diag && (i0 + g.tri_off == j0);
     }
     int k0 = 0, k1 = g.K;
-    if (g.kmode == KM_GE_I) k0 = i0 + g.koff;
-    else if (g.kmode == KM_GE_J) k0 = j0 + g.koff;
-    else if (g.kmode == KM_LT_I) k1 = i0 + TM + g.koff;
-    else if (g.kmode == KM_LT_J) k1 = j0 + TN + g.koff;
+    const int koff = g.koff + (int)bz * g.batch_dk;
+    if (g.kmode == KM_GE_I) k0 = i0 + koff;
+    else if (g.kmode == KM_GE_J) k0 = j0 + koff;
+    else if (g.kmode == KM_LT_I) k1 = i0 + TM + koff;
+    else if (g.kmode == KM_LT_J) k1 = j0 + TN + koff;
     if (k0 < 0) k0 = 0;
     if (k1 > g.K) k1 = g.K;
     k0 &= ~(BK - 1);
@@ -85,8 +86,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
     const double* __restrict__ A = (a_hi ? g.A2 - g.a_split : g.A) + bz * g.sA;
     const long lda = a_hi ? g.lda2 : g.lda;
     const double* __restrict__ B = g.B + bz * g.sB;
-    double* __restrict__ C = (c_hi ? g.C2 - g.c_split : g.C) + bz * g.sC;
-    const long ldc = c_hi ? g.ldc2 : g.ldc;
+    double* __restrict__ C = (c_hi ? g.C2 - g.c_split : g.C) + bz * g.sC - (bz * (bz - 1) / 2) * g.batch_sC2;
+    const long ldc = (c_hi ? g.ldc2 : g.ldc) - bz * g.batch_dldc;
     const double* __restrict__ Cin = g.Cin ? (c_hi ? g.Cin2 - g.c_split : g.Cin) : C;
     const long ldcin = g.Cin ? (c_hi ? g.ldcin2 : g.ldcin) : ldc;
 

@@ -12,6 +12,9 @@
 #include "kernels.h"
 #include "sqdist_tile.h"
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+#define CHK_RC(x) do { int rc__ = (x); if (rc__ != PGP_OK) return rc__; } while (0)
+
 namespace {
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -46,69 +49,134 @@ __device__ __forceinline__ void block_sum4(double (&v)[4], double* red16 /* 16 d
     for (int q = 0; q < 4; ++q) v[q] = red16[q] + red16[4 + q] + red16[8 + q] + red16[12 + q];
 }
 
-// ARD length-scale sums of one 64x64 tile: out[k] = sum_rc w_rc wk[k] (x_rk - x_ck)^2 for k < D, 16 coordinates per
-// staged slab (wk == nullptr: the weights are already folded into the scaled coordinates).  sm: 2*SKC*ST doubles.
+// value of lane DPP(l) inside the 16-lane row of the wave (both halves of the double)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row, every lane ends with the same bits: quad_perm xor 1, xor 2, row_half_mirror, row_mirror
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return v;
+}
+
+constexpr int STP = ST + 2;     // slab row stride of the ARD reduce (the MFMA fragment reads walk ACROSS the slab rows)
+
+// ARD length-scale sums of one 64x64 tile: out[k] = wk[k] * sum_rc w_rc (x_rk - x_ck)^2 for every k < D (wk == nullptr: the
+// weights are already folded into the scaled coordinates) -- Core/cov.py:924-931 summed against Q, all D derivatives at once.
+//
+// On the matrix cores, and for ANY D (round 4; the VALU form walked 3 instructions per element and coordinate and stopped at
+// D = 64).  With row sums R_r = sum_c w_rc and column sums C_c = sum_r w_rc of the tile,
+//     sum_rc w_rc (x_rk - x_ck)^2 = sum_r R_r x_rk^2 + sum_c x_ck (C_c x_ck - 2 P_ck),      P = W' Xr   (64 x 64 by 64 x D)
+// and P needs no LDS round trip for W: thread (tr, tc) holds w[a][q] at row 4 tr + a, column 2 tc + (q & 1) + 32 (q >> 1), so
+// for fixed (a, q) the wave's 64 lanes hold a 4 (rows: lane / 16) x 16 (columns: lane % 16) block -- the B operand of
+// v_mfma_f64_16x16x4 with the contraction running over the wave's rows; the A operand is the slab of row coordinates
+// (16 coordinates x those 4 rows).  Each wave contracts over ITS 16 rows (16 MFMAs per 16 coordinates) and keeps a partial
+// P; everything after it is linear, so the partials are folded with the wave's own column sums and only the D results meet
+// in LDS (fixed order).  The three terms cancel where a difference would not, so the coordinates are CENTRED first
+// (mu[k] = column mean; the sums are shift-invariant): the rounding error is then c eps sum |w_rc| (|x_rk| + |x_ck|)^2
+// against the difference form's c' eps sum |w_rc| (x_rk - x_ck)^2 -- the same order for centred data.
+// sm: 2 * SKC * STP doubles.
 __device__ __forceinline__ void ard_dim_reduce(const double* __restrict__ XT, long ldp, long r0, long c0, int dpad,
                                                double* __restrict__ sm, const double (&w)[4][4],
-                                               const double* __restrict__ wk, int D, double* __restrict__ out) {
-    __shared__ double ardred[4][CP_MAXARD];     // per-wave sums of every coordinate: the four waves meet ONCE, after the last slab
-    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
-    const int lane_ = t & 63, wave_ = t >> 6;
+                                               const double* __restrict__ wk, const double* __restrict__ mu, int D,
+                                               double* __restrict__ out) {
+    __shared__ double ardA[4][64], ardB[4][64];   // per-wave sums of a chunk of 64 coordinates: the waves meet once per chunk
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6, l4 = lane >> 4, l15 = lane & 15;
     double* xr = sm;
-    double* xc = sm + SKC * ST;
-    for (int k0 = 0; k0 < dpad; k0 += SKC) {
-        __syncthreads();
+    double* xc = sm + SKC * STP;
+    double Cw[4], Rr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                  // column sums over the wave's 16 rows, at the lane's four columns
+        double v = (w[0][q] + w[1][q]) + (w[2][q] + w[3][q]);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        Cw[q] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) Rr[a] = row16_sum((w[a][0] + w[a][1]) + (w[a][2] + w[a][3]));   // full row sums of the lane's rows
+    const int sk = t >> 5, spr = t & 31;           // staging share: coordinates sk and sk + 8 of the slab, points 2 spr, 2 spr + 1
+    double2_t gr[2], gc[2];
+    double gm[2];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int v = t + p * 256;
-            const int k = v >> 5, pr = v & 31;
-            *(double2_t*)(xr + k * ST + 2 * pr) = *(const double2_t*)(XT + (long)(k0 + k) * ldp + r0 + 2 * pr);
-            *(double2_t*)(xc + k * ST + 2 * pr) = *(const double2_t*)(XT + (long)(k0 + k) * ldp + c0 + 2 * pr);
+            const long k = k0 + sk + 8 * p;
+            gr[p] = *(const double2_t*)(XT + k * ldp + r0 + 2 * spr);
+            gc[p] = *(const double2_t*)(XT + k * ldp + c0 + 2 * spr);
+            gm[p] = mu[k];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < dpad; k0 += SKC) {
+        __syncthreads();                            // the previous slab (or the caller's use of sm) is consumed
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int k = sk + 8 * p;
+            *(double2_t*)(xr + k * STP + 2 * spr) = double2_t{gr[p][0] - gm[p], gr[p][1] - gm[p]};
+            *(double2_t*)(xc + k * STP + 2 * spr) = double2_t{gc[p][0] - gm[p], gc[p][1] - gm[p]};
         }
         __syncthreads();
-        double gk[SKC];
+        if (k0 + SKC < dpad) fetch(k0 + SKC);
+        // A fragments: coordinate l15 of the slab at the wave's rows 16 wave + 4 l4 + a
+        const double2_t f01 = *(const double2_t*)(xr + l15 * STP + 16 * wave + 4 * l4);
+        const double2_t f23 = *(const double2_t*)(xr + l15 * STP + 16 * wave + 4 * l4 + 2);
+        const double fa[4] = {f01[0], f01[1], f23[0], f23[1]};
+        double4_t acc[4];
 #pragma unroll
-        for (int k = 0; k < SKC; ++k) {
-            const double2_t r01 = *(const double2_t*)(xr + k * ST + 4 * tr);
-            const double2_t r23 = *(const double2_t*)(xr + k * ST + 4 * tr + 2);
-            const double2_t c01 = *(const double2_t*)(xc + k * ST + 2 * tc);
-            const double2_t c23 = *(const double2_t*)(xc + k * ST + 2 * tc + 32);
-            const double rv[4] = {r01[0], r01[1], r23[0], r23[1]};
-            const double cv[4] = {c01[0], c01[1], c23[0], c23[1]};
-            double acc = 0.0;
+        for (int q = 0; q < 4; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int bq = 0; bq < 4; ++bq) {
-                    const double df = rv[a] - cv[bq];
-                    acc = fma(w[a][bq], df * df, acc);
-                }
-            gk[k] = wk ? acc * ((k0 + k) < CP_MAXARD ? wk[k0 + k] : 0.0) : acc;
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], w[a][q], acc[q], 0, 0, 0);
+        // acc[q][r4] = P(coordinate 4 r4 + l4, column 2 l15 + (q & 1) + 32 (q >> 1)), partial over the wave's rows
+        const int kc = k0 & 63;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const double* row = xc + (4 * r4 + l4) * STP + 2 * l15;
+            const double2_t c01 = *(const double2_t*)row;
+            const double2_t c23 = *(const double2_t*)(row + 32);
+            const double xv[4] = {c01[0], c01[1], c23[0], c23[1]};
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s = fma(xv[q], fma(Cw[q], xv[q], -2.0 * acc[q][r4]), s);
+            s = row16_sum(s);
+            if (l15 == 0) ardA[wave][kc + 4 * r4 + l4] = s;
         }
-        // 16 sums over the 256 threads: butterfly transpose-reduce inside the wave (17 shuffles instead of
-        // 16 x 6: after the four halving steps lane l holds coordinate bitrev4(l & 15) summed over its 16-lane
-        // row, two more steps fold the four rows), then the four waves meet in LDS (fixed order)
+        double rt = 0.0;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int m = 1 << st, cnt = SKC >> (st + 1);
-            const bool up = (lane_ & m) != 0;
-#pragma unroll
-            for (int i = 0; i < cnt; ++i) {
-                const double keep = up ? gk[i + cnt] : gk[i];
-                const double send = up ? gk[i] : gk[i + cnt];
-                gk[i] = keep + __shfl_xor(send, m, 64);
+        for (int a = 0; a < 4; ++a) rt = fma(Rr[a] * fa[a], fa[a], rt);
+        rt += __shfl_xor(rt, 16, 64);
+        rt += __shfl_xor(rt, 32, 64);
+        if (l4 == 0) ardB[wave][kc + l15] = rt;
+        if (kc == 64 - SKC || k0 + SKC >= dpad) {  // a chunk of 64 coordinates (or the last one) is complete
+            __syncthreads();
+            const int kb = k0 - kc;
+            if (t <= kc + SKC - 1 && kb + t < D) {
+                const double v = ((ardA[0][t] + ardB[0][t]) + (ardA[1][t] + ardB[1][t])) +
+                                 ((ardA[2][t] + ardB[2][t]) + (ardA[3][t] + ardB[3][t]));
+                out[kb + t] = wk ? wk[kb + t] * v : v;
             }
-        }
-        gk[0] += __shfl_xor(gk[0], 16, 64);
-        gk[0] += __shfl_xor(gk[0], 32, 64);
-        if (lane_ < 16) {
-            const int kk = ((lane_ & 1) << 3) | ((lane_ & 2) << 1) | ((lane_ & 4) >> 1) | ((lane_ & 8) >> 3);
-            if (k0 + kk < CP_MAXARD) ardred[wave_][k0 + kk] = gk[0];
+            // the next chunk's first writes to ardA / ardB come after the next slab's two barriers
         }
     }
-    __syncthreads();
-    for (int k = t; k < D && k < CP_MAXARD; k += 256) out[k] = ardred[0][k] + ardred[1][k] + ardred[2][k] + ardred[3][k];
-    __syncthreads();                                            // a second call (second ARD leaf) reuses ardred
+    __syncthreads();                                // a second call (second ARD leaf) reuses sm and ardA / ardB
+}
+
+// mu[k] = mean over the n points of coordinate k (fixed order); one block per coordinate
+__global__ __launch_bounds__(256) void coord_mean_kernel(const double* __restrict__ XT, long ldp, long n, double* __restrict__ mu) {
+    __shared__ double red[4];
+    const double* row = XT + (long)blockIdx.x * ldp;
+    double v = 0.0;
+    for (long p = threadIdx.x; p < n; p += 256) v += row[p];
+    const double tot = block_sum(v, red);
+    if (threadIdx.x == 0) mu[blockIdx.x] = tot / (double)n;
 }
 
 // partial[blk * nacc + h]: h < ncov -> sum Q dK_h ; h == ncov -> sn2 * trace(Q)
@@ -119,11 +187,12 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
                                                               const double* __restrict__ Binv, long ldb,
                                                               const double* __restrict__ alpha,
                                                               const double* __restrict__ wv,
-                                                              double* __restrict__ partial, long nt) {
-    __shared__ __attribute__((aligned(16))) double sm[2 * SKC * ST];
+                                                              double* __restrict__ partial, long nt,
+                                                              const double* __restrict__ mu, long b0) {
+    __shared__ __attribute__((aligned(16))) double sm[2 * SKC * STP];
     CovParams cp = cp0;
     cp.kind = KIND;
-    const long b = blockIdx.x;
+    const long b = blockIdx.x + b0;                 // b0: first block of a range of tile rows (sharded fit: one strip of B^-1)
     long r = (long)(((2.0 * nt + 1.0) - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)b)) * 0.5);
     if (r < 0) r = 0;
     while (r > 0 && r * nt - r * (r - 1) / 2 > b) --r;
@@ -187,10 +256,10 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
             }
         }
     }
-    double* out = partial + b * (long)(ncov + 1);
+    double* out = partial + (long)blockIdx.x * (long)(ncov + 1);
     __shared__ double red16[16];
     if (cov_is_ard(cp)) {
-        ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, nullptr, cp.D, out);
+        ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, nullptr, mu, cp.D, out);
         double v4[4] = {g1, tq, g2, 0.0};
         block_sum4(v4, red16);
         if (t == 0) {
@@ -221,11 +290,12 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
                                                             const double* __restrict__ Binv, long ldb,
                                                             const double* __restrict__ alpha,
                                                             const double* __restrict__ wv,
-                                                            double* __restrict__ partial, long nt) {
+                                                            double* __restrict__ partial, long nt,
+                                                            const double* __restrict__ mu, long b0) {
     constexpr bool PARD = NARD >= 1, PARD2 = NARD == 2;
     __shared__ __attribute__((aligned(16))) double sm[(PARD ? 2 : 1) * 16 * 256];
     __shared__ double red[4];
-    const long b = blockIdx.x;
+    const long b = blockIdx.x + b0;
     long r = (long)(((2.0 * nt + 1.0) - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)b)) * 0.5);
     if (r < 0) r = 0;
     while (r > 0 && r * nt - r * (r - 1) / 2 > b) --r;
@@ -322,7 +392,7 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
             }
         }
     }
-    double* out = partial + b * (long)(ncov + 1);
+    double* out = partial + (long)blockIdx.x * (long)(ncov + 1);
 #pragma unroll
     for (int l = 0; l < CP_MAXLEAF; ++l) {
         if (l < P.nleaf) {
@@ -348,11 +418,11 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
 #pragma unroll
         for (int e = 0; e < 16; ++e) w[e >> 2][e & 3] = sv1[e * 256];
         const int la = P.ard_leaf & 7;
-        ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, P.ardw, P.leaf[la].D, out + P.hyp0[la]);
+        ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, P.ardw, mu, P.leaf[la].D, out + P.hyp0[la]);
         if constexpr (PARD2) {
             const int lb = P.ard_leaf2 & 7;
             __syncthreads();
-            ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w2, P.ardw2, P.leaf[lb].D, out + P.hyp0[lb]);
+            ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w2, P.ardw2, mu, P.leaf[lb].D, out + P.hyp0[lb]);
         }
     }
 #pragma unroll
@@ -467,6 +537,19 @@ __global__ __launch_bounds__(256) void col_sumsq_kernel(const double* __restrict
     if (lane == 0) out[j] = fmax(kss - scale * s, 0.0);
 }
 
+// acc[j] += sum_i A(i,j)^2   (one wave per column; the panels of a distributed factor add up in stream order)
+__global__ __launch_bounds__(256) void colsumsq_acc_kernel(const double* __restrict__ A, long lda, long nrows, long ncols,
+                                                           double* __restrict__ acc) {
+    const int lane = threadIdx.x & 63;
+    const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= ncols) return;
+    const double* col = A + j * lda;
+    double s = 0.0;
+    for (long i = lane; i < nrows; i += 64) s = fma(col[i], col[i], s);
+    s = wave_sum(s);
+    if (lane == 0) acc[j] += s;
+}
+
 // A(i,j) *= s[i]
 __global__ __launch_bounds__(256) void row_scale_kernel(double* __restrict__ A, long lda, long nrows, long ncols,
                                                         const double* __restrict__ s) {
@@ -546,34 +629,58 @@ int col_sumsq_launch(const double* A, long lda, long nrows, long ncols, double k
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
+int colsumsq_acc_launch(const double* A, long lda, long nrows, long ncols, double* acc, hipStream_t st) {
+    hipLaunchKernelGGL(colsumsq_acc_kernel, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, A, lda, nrows, ncols, acc);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
 int row_scale_launch(double* A, long lda, long nrows, long ncols, const double* s, hipStream_t st) {
     hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((nrows + 255) / 256), (unsigned)ncols), dim3(256), 0, st, A, lda,
                        nrows, ncols, s);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
-int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, int ncov,
-                           double sn2, const double* Binv, long ldb, const double* alpha, double* partial,
-                           double* out_dev, hipStream_t st, const double* wv) {
+// blocks of the tile rows [tr0, tr0 + trn) of the upper-triangular 64-tile grid of an np x np matrix
+static long tri_blocks_before(long nt, long r) { return r * nt - r * (r - 1) / 2; }
+long hadamard_block_count(long np, long tr0, long trn) {
     const long nt = np / ST;
-    const long nblk = nt * (nt + 1) / 2;
+    return tri_blocks_before(nt, tr0 + trn) - tri_blocks_before(nt, tr0);
+}
+
+// the coordinate means the ARD reduce centres with (no-op for covariance functions without an ARD leaf)
+int hadamard_prepare_launch(const double* XT, long ldp, long n, int dpad, const CovSpec& cs, double* mu, hipStream_t st) {
+    const bool ard = cs.prog ? cs.pg.ard_leaf >= 0 : (cs.cp.kind == 1 || cs.cp.kind == 6);
+    if (ard) hipLaunchKernelGGL(coord_mean_kernel, dim3((unsigned)dpad), dim3(256), 0, st, XT, ldp, n, mu);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+// Per-block partial sums of the tile rows [tr0, tr0 + trn) (64 rows each): `Binv` is addressed as Binv[r * ldb + c] for
+// c >= r (GLOBAL indices: the caller of a strip passes a pointer shifted accordingly), partial receives
+// hadamard_block_count(np, tr0, trn) * (ncov + 1) doubles.
+int hadamard_partial_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, int ncov, double sn2,
+                            const double* Binv, long ldb, const double* alpha, const double* wv, double* partial,
+                            const double* mu, long tr0, long trn, hipStream_t st) {
+    const long nt = np / ST;
+    const long b0 = tri_blocks_before(nt, tr0);
+    const long nblk = tri_blocks_before(nt, tr0 + trn) - b0;
+    if (nblk <= 0) return PGP_OK;
     if (cs.prog) {
         CovProgram pg = cs.pg;
         for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = 1;
         if (pg.ard_leaf2 >= 0)
             hipLaunchKernelGGL(hadamard_prog_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
-                               1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
+                               1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt, mu, b0);
         else if (pg.ard_leaf >= 0)
             hipLaunchKernelGGL(hadamard_prog_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
-                               1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
+                               1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt, mu, b0);
         else
             hipLaunchKernelGGL(hadamard_prog_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
-                               1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt);
+                               1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt, mu, b0);
     } else {
         CovParams cp = cs.cp;
         cp.train = 1;
 #define HLAUNCH(K) hipLaunchKernelGGL(hadamard_reduce_kernel<K>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, cp, \
-                                      ncov, 1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt)
+                                      ncov, 1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt, mu, b0)
         switch (cp.kind) {
             case 0: HLAUNCH(0); break;
             case 1: HLAUNCH(1); break;
@@ -586,14 +693,31 @@ int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad
         }
 #undef HLAUNCH
     }
-    hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)(ncov + 1)), dim3(256), 0, st, partial, nblk, ncov + 1,
-                       out_dev);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+// out_dev[h] = sum over the nblk blocks, fixed order
+int hadamard_final_launch(const double* partial, long nblk, int ncov, double* out_dev, hipStream_t st) {
+    hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)(ncov + 1)), dim3(256), 0, st, partial, nblk, ncov + 1, out_dev);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, int ncov,
+                           double sn2, const double* Binv, long ldb, const double* alpha, double* partial,
+                           double* out_dev, hipStream_t st, const double* wv) {
+    const long nt = np / ST;
+    const long nblk = nt * (nt + 1) / 2;
+    // ARD leaves: the per-coordinate sums run in the product form on centred coordinates (ard_dim_reduce); the means live
+    // behind the per-block partials (hadamard_partial_count leaves room for them)
+    double* mu = partial + nblk * (long)(ncov + 1);
+    CHK_RC(hadamard_prepare_launch(XT, ldp, n, dpad, cs, mu, st));
+    CHK_RC(hadamard_partial_launch(XT, ldp, n, np, dpad, cs, ncov, sn2, Binv, ldb, alpha, wv, partial, mu, 0, nt, st));
+    return hadamard_final_launch(partial, nblk, ncov, out_dev, st);
 }
 
 long hadamard_partial_count(long np, int ncov) {
     const long nt = np / ST;
-    return nt * (nt + 1) / 2 * (long)(ncov + 1);
+    return nt * (nt + 1) / 2 * (long)(ncov + 1) + 272;       // + the coordinate means of the ARD reduce (dpad <= 256 + slack)
 }
 
 int col_dot_launch(const double* W, long ldw, long n, const double* z, long zs, double scale, double* y,

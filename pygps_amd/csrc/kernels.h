@@ -38,6 +38,14 @@ int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad
                            double sn2, const double* Binv, long ldb, const double* alpha, double* partial,
                            double* out_dev, hipStream_t st, const double* wv = nullptr);
 long hadamard_partial_count(long np, int ncov);
+// the same reduce in pieces, for a B^-1 that exists as column strips only (csrc/sharded.hip)
+long hadamard_block_count(long np, long tr0, long trn);
+int hadamard_prepare_launch(const double* XT, long ldp, long n, int dpad, const CovSpec& cs, double* mu, hipStream_t st);
+int hadamard_partial_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, int ncov, double sn2,
+                            const double* Binv, long ldb, const double* alpha, const double* wv, double* partial,
+                            const double* mu, long tr0, long trn, hipStream_t st);
+int hadamard_final_launch(const double* partial, long nblk, int ncov, double* out_dev, hipStream_t st);
+int colsumsq_acc_launch(const double* A, long lda, long nrows, long ncols, double* acc, hipStream_t st);
 int col_dot_launch(const double* W, long ldw, long n, const double* z, long zs, double scale, double* y,
                    hipStream_t st);
 int logdet_ztz_launch(const double* L, long ldl, long n, const double* z, long zs, double* out, hipStream_t st);

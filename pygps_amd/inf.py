@@ -78,6 +78,9 @@ class DeviceFactor(object):
     ``predict`` uses the handle directly and never materialises it."""
     ndim = 2
     dtype = np.dtype(np.float64)
+    #: True on the factors of the dense path (inf.Exact._evaluate_dense sets it on the instance).  A CLASS attribute so that
+    #: `predict`'s test never reaches __getattr__, which forwards unknown names to the host copy (an n x n D2H transfer).
+    dense = False
     #: bytes of factor buffers ((n + 128) n doubles each: factor + rhs rows) held by live DeviceFactor objects.
     #: Models sit in reference cycles (model <-> optimizer), so a dropped model frees its factor only when the cyclic
     #: garbage collector runs; `reserve` forces a collection before the device fills up with unreachable factors.

@@ -204,6 +204,52 @@ def g7(N):
          ref_seconds=dt, **dn(dnlZ))
 
 
+# ----------------------------------------------------------------------------- G18 (round 4: ARD kernels with D > 64)
+def g18_inputs(N, d, seed, cls=False):
+    """Inputs of the D > 64 fixtures: the SURVEY 8(d) recipe, plus a constant offset on every third coordinate (raw data
+    is rarely centred: the device's per-coordinate gradient sums run in a product form that is only well conditioned on
+    centred coordinates) and per-coordinate length scales that differ."""
+    x, y = (synth_cls if cls else synth_reg)(N, d, seed)
+    x = x.copy()
+    x[:, ::3] += 40.0
+    rng = np.random.RandomState(1000 + seed)
+    log_ell = np.log(np.sqrt(d)) + rng.uniform(-0.4, 0.4, d)
+    return x, y, log_ell
+
+
+def g18():
+    """RBFard at d = 100 (N = 1500) and d = 65 (N = 700), RQard at d = 70 (N = 700) through Exact.evaluate
+    (Core/cov.py:872-938, :1356-1425; Core/inf.py:353-384) and RBFard at d = 80 through EP (N = 300, Core/inf.py:731-806):
+    the reference takes any D."""
+    for tag, N, d, seed in (("rbfard_d100_N1500", 1500, 100, 3), ("rbfard_d65_N700", 700, 65, 4)):
+        x, y, log_ell = g18_inputs(N, d, seed)
+        m = pyGPs.GPR()
+        m.setPrior(kernel=pyGPs.cov.RBFard(log_ell_list=[float(v) for v in log_ell], log_sigma=0.1))
+        m.setNoise(np.log(0.1))
+        m.setData(x, y)
+        nlZ, dnlZ, post = m.getPosterior()
+        save("G18_fit_" + tag, N=N, d=d, seed=seed, nlZ=nlZ, mean_hyp=np.array(m.meanfunc.hyp),
+             cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp), alpha=post.alpha,
+             L_diag=np.diag(post.L).copy(), **dn(dnlZ))
+    N, d, seed = 700, 70, 5
+    x, y, log_ell = g18_inputs(N, d, seed)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RQard(log_ell_list=[float(v) for v in log_ell], log_sigma=0.1, log_alpha=0.3))
+    m.setNoise(np.log(0.1))
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    save("G18_fit_rqard_d70_N700", N=N, d=d, seed=seed, nlZ=nlZ, mean_hyp=np.array(m.meanfunc.hyp),
+         cov_hyp=np.array(m.covfunc.hyp), lik_hyp=np.array(m.likfunc.hyp), alpha=post.alpha,
+         L_diag=np.diag(post.L).copy(), **dn(dnlZ))
+    N, d, seed = 300, 80, 6
+    x, y, log_ell = g18_inputs(N, d, seed, cls=True)
+    m = pyGPs.GPC()
+    m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBFard(log_ell_list=[float(v) for v in log_ell], log_sigma=0.2))
+    nlZ, dnlZ, post = m.getPosterior(x, y)
+    save("G18_ep_rbfard_d80_N300", N=N, d=d, seed=seed, nlZ=nlZ, cov_hyp=np.array(m.covfunc.hyp), alpha=post.alpha,
+         sW=post.sW, L_diag=np.diag(post.L).copy(), ttau=m.inffunc.last_ttau, tnu=m.inffunc.last_tnu, **dn(dnlZ))
+
+
 # ----------------------------------------------------------------------------- G16 / G17 (round 3: pins for the verdict's holes)
 def g16(N=2048):
     """Matern d in {1,3,5,7} fits at N = 2048, d_in = 16 with the reference's own gradients (Core/cov.py:1124-1182; the
@@ -617,7 +663,7 @@ CASES = {
     "g16": g16, "g17": g17, "g15": g15, "g14": g14, "g13": g13, "g12": g12, "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
     "g8ii_2048": lambda: g8ii(2048), "g8ii_4096": lambda: g8ii(4096), "g9_2048": lambda: g9(2048),
-    "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384),
+    "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384), "g18": g18,
 }
 
 if __name__ == "__main__":

@@ -1,0 +1,181 @@
+"""GPU: round 4 -- ARD kernels with more than 64 input dimensions.
+
+The reference takes any D (Core/cov.py:872-938 RBFard, :1356-1425 RQard: one getDerMatrix per length scale).  Up to round 3
+the device's per-coordinate gradient sums stopped at coordinate 63 (and left the rest of the gradient vector unwritten);
+they now run on the matrix cores in a product form over chunks of 64 coordinates (csrc/grad.hip ard_dim_reduce).
+
+* G18 fixtures recorded from the reference: RBFard d = 100 (N = 1500), d = 65 (N = 700), RQard d = 70 (N = 700) through
+  Exact.evaluate, RBFard d = 80 through EP (N = 300) -- every one of the D + 1 (+1) gradients.
+* d in {65, 100, 200} at N ~ 1500 and an EP fit at d = 80 against the oracle.
+* the product form's conditioning: coordinates with a large common offset (the sums are shift-invariant; the kernel centres).
+* the randomised sweep of round 3 with d up to 130.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, synth_cls, synth_reg
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _flat(d):
+    return np.array(list(d.mean) + list(d.cov) + list(d.lik), dtype=float)
+
+
+def g18_inputs(N, d, seed, cls=False):
+    x, y = (synth_cls if cls else synth_reg)(N, d, seed)
+    x = x.copy()
+    x[:, ::3] += 40.0
+    return x, y
+
+
+@pytest.mark.parametrize("tag,N,d,seed", [("rbfard_d100_N1500", 1500, 100, 3), ("rbfard_d65_N700", 700, 65, 4),
+                                           ("rqard_d70_N700", 700, 70, 5)])
+def test_G18_ard_fits_beyond_64_dimensions(lib, tag, N, d, seed):
+    import pygps_amd as pyGPs
+    g = golden("G18_fit_" + tag)
+    x, y = g18_inputs(N, d, seed)
+    hyp = [float(v) for v in g["cov_hyp"]]
+    rq = tag.startswith("rqard")
+    k = pyGPs.cov.RQard(D=d) if rq else pyGPs.cov.RBFard(D=d)
+    k.hyp = hyp
+    k.reference_compat = True          # RQard: the reference's length-scale derivative (Core/cov.py:1412-1418) for the fixture
+    m = pyGPs.GPR()
+    m.setPrior(kernel=k)
+    m.setNoise(float(g["lik_hyp"][0]))
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    assert len(dnlZ.cov) == len(hyp)
+    assert relerr(nlZ, g["nlZ"]) < 1e-9 and relerr(post.alpha, g["alpha"]) < 1e-7
+    assert relerr(np.diag(np.asarray(post.L)), g["L_diag"]) < 1e-9
+    gref = np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])
+    assert np.max(np.abs(_flat(dnlZ) - gref)) < 1e-7 * np.max(np.abs(gref))
+    # every single length-scale gradient, not only the largest (the unwritten ones of round 3 were garbage of any size)
+    assert np.allclose(dnlZ.cov, g["dnlZ_cov"], rtol=1e-6, atol=1e-7 * np.max(np.abs(g["dnlZ_cov"])))
+    if rq:                             # the default (mathematically correct) RQard derivative vs the oracle without the quirk
+        k2 = pyGPs.cov.RQard(D=d)
+        k2.hyp = hyp
+        m.setPrior(kernel=k2)
+        m.setData(x, y)
+        nlZ2, dn2, _ = m.getPosterior()
+        c = m.meanfunc.hyp[0]
+        out = O.exact_fit(O.RQARD, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y), faithful=False,
+                          matern_reference_compat=False)
+        assert relerr(nlZ2, out["nlZ"]) < 1e-9 and relerr(dn2.cov, out["dnlZ_cov"]) < 1e-7
+        assert np.max(np.abs(np.array(dn2.cov[:d]))) > 1e-3
+
+
+def test_G18_ep_ard_d80(lib):
+    import pygps_amd as pyGPs
+    g = golden("G18_ep_rbfard_d80_N300")
+    x, y = g18_inputs(300, 80, 6, cls=True)
+    k = pyGPs.cov.RBFard(D=80)
+    k.hyp = [float(v) for v in g["cov_hyp"]]
+    m = pyGPs.GPC()
+    m.setPrior(mean=pyGPs.mean.Zero(), kernel=k)
+    nlZ, dnlZ, post = m.getPosterior(x, y)
+    assert relerr(nlZ, g["nlZ"]) < 1e-8 and relerr(post.alpha, g["alpha"]) < 1e-6 and relerr(post.sW, g["sW"]) < 1e-6
+    assert len(dnlZ.cov) == 81
+    assert np.allclose(dnlZ.cov, g["dnlZ_cov"], rtol=1e-5, atol=1e-6 * np.max(np.abs(g["dnlZ_cov"])))
+
+
+@pytest.mark.parametrize("d,N", [(65, 1500), (100, 1411), (200, 1537), (254, 700)])
+def test_rbfard_fit_vs_oracle_high_dim(lib, d, N):
+    """nlZ <= 1e-9, ALL D + 1 covariance gradients (and mean, noise) <= 1e-7 against oracle.exact_fit; d = 254 is the largest
+    the C ABI takes (ncov <= 255)."""
+    import pygps_amd as pyGPs
+    rng = np.random.RandomState(d)
+    x = rng.randn(N, d) * rng.uniform(0.5, 2.0, d) + rng.uniform(-3.0, 3.0, d)
+    w = rng.randn(d, 1)
+    y = np.sin(x @ w / np.sqrt(d)) + 0.1 * rng.randn(N, 1)
+    log_ell = np.log(np.sqrt(d)) + rng.uniform(-0.5, 0.7, d)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBFard(log_ell_list=[float(v) for v in log_ell], log_sigma=0.15))
+    m.setNoise(np.log(0.12))
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    c = m.meanfunc.hyp[0]
+    ref = O.exact_fit(O.RBFARD, np.array(m.covfunc.hyp), 0, m.likfunc.hyp[0], x, y, c * np.ones((N, 1)), np.ones((N, 1)),
+                      faithful=False)
+    want = np.concatenate([ref["dnlZ_mean"], ref["dnlZ_cov"], ref["dnlZ_lik"]])
+    assert relerr(nlZ, ref["nlZ"]) < 1e-9 and relerr(post.alpha, ref["alpha"]) < 1e-7
+    assert len(dnlZ.cov) == d + 1
+    assert np.max(np.abs(_flat(dnlZ) - want)) < 1e-7 * np.max(np.abs(want))
+    assert np.allclose(dnlZ.cov, ref["dnlZ_cov"], rtol=1e-6, atol=1e-7 * np.max(np.abs(ref["dnlZ_cov"])))
+
+
+def test_ep_rbfard_d80_vs_oracle(lib):
+    import pygps_amd as pyGPs
+    N, d = 900, 80
+    x, y = synth_cls(N, d, seed=11)
+    rng = np.random.RandomState(5)
+    log_ell = np.log(np.sqrt(d)) + rng.uniform(-0.3, 0.5, d)
+    k = pyGPs.cov.RBFard(log_ell_list=[float(v) for v in log_ell], log_sigma=0.3)
+    m = pyGPs.GPC()
+    m.setPrior(mean=pyGPs.mean.Zero(), kernel=k)
+    nlZ, dnlZ, post = m.getPosterior(x, y)
+    out = O.ep_fit(O.RBFARD, np.array(k.hyp), 0, x, y, np.zeros_like(y))
+    assert relerr(nlZ, out["nlZ"]) < 1e-8 and relerr(post.alpha, out["alpha"]) < 1e-6
+    assert np.max(np.abs(np.array(dnlZ.cov) - out["dnlZ_cov"])) < 1e-7 * np.max(np.abs(out["dnlZ_cov"]))
+
+
+@pytest.mark.parametrize("offset", [0.0, 1e3, 1e6])
+def test_ard_gradient_sums_with_a_common_offset(lib, offset):
+    """The per-coordinate sums run as  sum_r R_r x_r^2 + sum_c x_c (C_c x_c - 2 (W'X)_c)  on centred coordinates: a common offset
+    of the inputs (a year, a temperature in kelvin) must not cost digits -- the difference form of the reference
+    (Core/cov.py:929-930, cdist on one column) does not see it either."""
+    import pygps_amd as pyGPs
+    N, d = 1100, 24
+    x, y = synth_reg(N, d, seed=2)
+    x = x + offset
+    log_ell = np.log(np.sqrt(d)) + np.linspace(-0.3, 0.3, d)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBFard(log_ell_list=[float(v) for v in log_ell], log_sigma=0.0))
+    m.setNoise(np.log(0.1))
+    m.setData(x, y)
+    nlZ, dnlZ, post = m.getPosterior()
+    c = m.meanfunc.hyp[0]
+    ref = O.exact_fit(O.RBFARD, np.array(m.covfunc.hyp), 0, m.likfunc.hyp[0], x, y, c * np.ones((N, 1)), np.ones((N, 1)),
+                      faithful=True)
+    tol = 1e-7 if offset <= 1e3 else 1e-6          # at 1e6 the INPUTS carry 1e-10 relative rounding of their own
+    assert relerr(nlZ, ref["nlZ"]) < tol * 1e-2
+    assert np.max(np.abs(np.array(dnlZ.cov) - ref["dnlZ_cov"])) < tol * np.max(np.abs(ref["dnlZ_cov"]))
+
+
+def test_randomised_ard_fits_up_to_130_dimensions(lib):
+    """Round 3's fixed-seed sweep, ARD kinds only, d drawn up to 130 (ragged against the slabs of 16 and the chunks of 64)."""
+    from pygps_amd import _lib
+    rng = np.random.RandomState(20260929)
+    for case in range(14):
+        n = int(rng.choice([rng.randint(2, 200), rng.randint(200, 1500), rng.randint(1536, 2300)]))
+        d = int(rng.choice([rng.randint(1, 64), rng.randint(64, 131), rng.randint(64, 131)]))
+        kind = int(rng.choice([O.RBFARD, O.RBFARD, O.RQARD]))
+        x = rng.randn(n, d) * rng.uniform(0.5, 2.0) + rng.uniform(-2, 2)
+        y = np.sin(x.sum(1, keepdims=True) / np.sqrt(d)) + 0.2 * rng.randn(n, 1)
+        nh = d + 1 if kind == O.RBFARD else d + 2
+        hyp = np.concatenate([np.log(np.sqrt(d)) + rng.uniform(-0.5, 1.0, d), rng.uniform(-0.5, 0.5, nh - d)])
+        log_sn = float(rng.uniform(-2.5, -0.5))
+        mvec = np.full((n, 1), float(y.mean()))
+        dm = np.ones((1, n))
+        ref = O.exact_fit(kind, hyp, 0, log_sn, x, y, mvec, dm=dm.T, faithful=False, matern_reference_compat=False)
+        h = C.c_void_p()
+        assert lib.pgp_init(0, C.byref(h)) == 0
+        try:
+            xx = np.ascontiguousarray(x)
+            yy = np.ascontiguousarray(y).ravel()
+            assert lib.pgp_set_data(h, _lib.ptr(xx), n, d, _lib.ptr(yy)) == 0
+            alpha, nlZ, gvec = np.zeros(n), np.zeros(1), np.full(1 + nh + 1, np.nan)
+            mv, dmv, hv = np.ascontiguousarray(mvec).ravel(), np.ascontiguousarray(dm), np.ascontiguousarray(hyp)
+            rc = lib.pgp_exact_fit(h, kind, _lib.ptr(hv), nh, 0, 0, log_sn, _lib.ptr(mv), _lib.ptr(dmv), 1, 3,
+                                   _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(gvec), None)
+            assert rc == 0, (rc, n, d, kind)
+        finally:
+            lib.pgp_destroy(h)
+        gref = np.concatenate([np.ravel(ref["dnlZ_mean"]), np.ravel(ref["dnlZ_cov"]), np.ravel(ref["dnlZ_lik"])])
+        e1 = abs(nlZ[0] - ref["nlZ"]) / max(1.0, abs(ref["nlZ"]))
+        e2 = np.abs(alpha - ref["alpha"].ravel()).max() / max(1e-300, np.abs(ref["alpha"]).max())
+        e3 = np.abs(gvec - gref).max() / max(1.0, np.abs(gref).max())
+        assert e1 < 1e-9 and e2 < 1e-7 and e3 < 1e-7, (case, n, d, kind, e1, e2, e3)

@@ -307,3 +307,33 @@ def test_G17_predict_at_bench_scale_first_batch():
                                      c * np.ones((500, 1)), faithful=faithful)
         assert relerr(fm, g["pred_fm"][:500]) < 1e-9 and relerr(fs2, g["pred_fs2"][:500]) < 1e-8
         assert relerr(ys2, g["pred_ys2"][:500]) < 1e-8
+
+
+def g18_inputs(N, d, seed, cls=False):
+    """make_golden.py g18_inputs: the 8(d) recipe with a constant offset on every third coordinate and ragged length scales."""
+    x, y = (synth_cls if cls else synth_reg)(N, d, seed)
+    x = x.copy()
+    x[:, ::3] += 40.0
+    return x, y
+
+
+@pytest.mark.parametrize("tag,kind,N,d,seed", [("rbfard_d100_N1500", O.RBFARD, 1500, 100, 3), ("rbfard_d65_N700", O.RBFARD, 700, 65, 4),
+                                                ("rqard_d70_N700", O.RQARD, 700, 70, 5)])
+def test_G18_ard_fits_beyond_64_dimensions(tag, kind, N, d, seed):
+    """ARD kernels with D > 64 (Core/cov.py:872-938, :1356-1425 take any D) -- recorded from the reference in round 4."""
+    g = golden("G18_fit_" + tag)
+    x, y = g18_inputs(N, d, seed)
+    c = g["mean_hyp"][0]
+    for faithful in ((True, False) if N <= 700 else (False,)):
+        out = O.exact_fit(kind, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, c * np.ones_like(y), np.ones_like(y), faithful=faithful)
+        assert relerr(out["nlZ"], g["nlZ"]) < 1e-11 and relerr(out["alpha"], g["alpha"]) < 1e-9
+        assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-8 and relerr(out["dnlZ_lik"], g["dnlZ_lik"]) < 1e-8
+        assert relerr(np.diag(out["L"]), g["L_diag"]) < 1e-11
+
+
+def test_G18_ep_ard_d80():
+    g = golden("G18_ep_rbfard_d80_N300")
+    x, y = g18_inputs(300, 80, 6, cls=True)
+    out = O.ep_fit(O.RBFARD, g["cov_hyp"], 0, x, y, np.zeros_like(y))
+    assert relerr(out["nlZ"], g["nlZ"]) < 1e-10 and relerr(out["alpha"], g["alpha"]) < 1e-8
+    assert relerr(out["dnlZ_cov"], g["dnlZ_cov"]) < 1e-7 and relerr(out["ttau"], g["ttau"]) < 1e-9
