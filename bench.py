@@ -435,10 +435,24 @@ def sharded_fit_extra(torch, dist, n, d=16):
     w = 1024 if n >= 12288 else 512
     npad = -(-n // w) * w
     sweep_s = stages[1] * 1e-3
+    # per-rank device memory (max over ranks) against the panel storage the layout needs, and predict on the distributed posterior
+    lb = m.inffunc.last_bytes
+    bt = torch.tensor([float(lb["peak_device_bytes"]), float(lb["factor_device_bytes"])], dtype=torch.float64, device="cuda")
+    dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+    panel_bytes = 2.0 * (npad + 128) * npad / world * 8
+    ns_p = 16384
+    xs_p = np.random.RandomState(9).randn(ns_p, d)
+    m.predict(xs_p[:1024])
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fm_p = m.predict(xs_p)[2]
+    tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tp, op=dist.ReduceOp.MAX)
     comm.close()
     return {"what": "ONE exact-GP fit (nlZ + all gradients) over all ranks: pgp_sharded_exact_fit, 1-D block-cyclic column panels "
                     "of %d (factor | rhs | fused-inverse rows), depth-1 look-ahead, panel broadcasts by RCCL driven from C, "
-                    "partial E E' per rank and the gradient reduce on the partials (no N^2 reduction)" % w,
+                    "every rank accumulates ITS column strips of B^-1 = E E' from the broadcast panels (no N^2 reduction, "
+                    "np^2 / (2 world) doubles per rank) and runs the gradient reduce on them" % w,
             "n": n, "d": d, "world": world, "panels": npad // w, "transport": comm.transport,
             "seconds": dt, "seconds_what": "device time of the fit (max over ranks)", "wall_seconds": wall,
             "wall_seconds_first_pass": times[0][0], "stage_ms": dict(zip(("assemble", "sweep_and_EEt", "epilogue", "total"), stages)),
@@ -446,7 +460,14 @@ def sharded_fit_extra(torch, dist, n, d=16):
             "frac_of_peak_per_gpu": float(n) ** 3 / dt / 1e12 / world / PEAK_FP64_MFMA_TF,
             "sweep_frac_of_peak_per_gpu": float(npad) ** 3 / sweep_s / 1e12 / world / PEAK_FP64_MFMA_TF,
             "bytes_broadcast_per_rank": float((npad + 128) * npad * 8) * (world > 1),
-            "nlZ": float(nlZ), "residual_normal_equations": res}
+            "nlZ": float(nlZ), "residual_normal_equations": res,
+            "peak_bytes_per_rank": float(bt[0].item()), "factor_bytes_per_rank": float(bt[1].item()),
+            "peak_bytes_over_2x_panel_storage": float(bt[0].item()) / panel_bytes,
+            "bytes_what": "device bytes one call of pgp_sharded_exact_fit holds at its peak (max over ranks: panels + spare + two "
+                          "receive buffers + strips of B^-1 + scratch) / 2 (np + 128) np / world * 8; what the posterior handle keeps",
+            "predict_ns16384_ms": float(tp[0].item()) * 1e3, "predict_finite": bool(np.all(np.isfinite(fm_p))),
+            "predict_what": "GP.predict of 16384 test points on the distributed posterior (pgp_sharded_predict: V = E' Ks on the "
+                            "owners, one all-reduce of ns doubles per batch)"}
 
 
 def main():

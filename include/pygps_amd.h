@@ -164,12 +164,22 @@ int pgp_comm_init_host(pgp_ctx* ctx, int world, int rank, pgp_host_bcast_fn bcas
 void pgp_comm_free(pgp_comm* comm);
 int pgp_comm_world(pgp_comm* comm);
 int pgp_comm_rank(pgp_comm* comm);
-/* Arguments and results as pgp_exact_fit (no factor handle: the factor stays distributed).  timings_out (optional, 4):
- * ms of assembly, sweep, epilogue, total.  L_out (optional, (n,n) row-major, zero-filled by the caller): THIS rank's
- * columns of the factor in post.L's form (upper R, R'R = K/sn2 + I); the sum over the ranks is the whole factor. */
+/* Arguments and results as pgp_exact_fit.  timings_out (optional, 6): ms of assembly, sweep, epilogue, total; device bytes
+ * this call held at its peak; device bytes the posterior handle keeps.  L_out (optional, (n,n) row-major, zero-filled by the
+ * caller): THIS rank's columns of the factor in post.L's form (upper R, R'R = K/sn2 + I); the sum over the ranks is the whole
+ * factor.  factor_out (optional): this rank's part of the distributed posterior (its column panels of L and of L^-T, alpha, the
+ * coordinates) for pgp_sharded_predict.  Per-rank memory is O(n^2 / world): the panels, and for want = 3 the rank's column
+ * strips of B^-1.  A rank that fails (out of memory, a launch error) makes EVERY rank return an error, none is left waiting. */
+typedef struct pgp_sfactor pgp_sfactor;
 int pgp_sharded_exact_fit(pgp_ctx* ctx, pgp_comm* comm, int kind, const double* covhyp, int ncov, int para, int flags,
                           double log_sn, const double* mvec, const double* dm, int nmean, int want, double* alpha_out,
-                          double* nlZ_out, double* dnlZ_out, double* timings_out, double* L_out);
+                          double* nlZ_out, double* dnlZ_out, double* timings_out, double* L_out, pgp_sfactor** factor_out);
+/* GP.predict (Core/gp.py:395-417) on the distributed posterior; every rank calls with the same test points (ns, d) and
+ * receives the same fmu / fs2.  One all-reduce of ns doubles per batch of test points. */
+int pgp_sharded_predict(pgp_ctx* ctx, pgp_comm* comm, pgp_sfactor* f, const double* xs, int64_t ns, const double* ms,
+                        double* fmu, double* fs2);
+void pgp_sfactor_free(pgp_ctx* ctx, pgp_sfactor* f);
+int64_t pgp_sfactor_bytes(pgp_sfactor* f);
 
 /* ---- helper functions: tools.jitchol / tools.solve_chol (Core/tools.py:31-97) ----------------
  * pgp_potrf: A (n,n) symmetric row-major in -> lower Cholesky factor (row-major, zeros above) out.

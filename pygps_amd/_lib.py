@@ -73,7 +73,10 @@ SIGNATURES = {
     "pgp_comm_world": (C.c_int, [_vp]),
     "pgp_comm_rank": (C.c_int, [_vp]),
     "pgp_sharded_exact_fit": (C.c_int, [_vp, _vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int,
-                                        C.c_int, _dp, _dp, _dp, _dp, _dp]),
+                                        C.c_int, _dp, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
+    "pgp_sharded_predict": (C.c_int, [_vp, _vp, _vp, _dp, _i64, _dp, _dp, _dp]),
+    "pgp_sfactor_free": (None, [_vp, _vp]),
+    "pgp_sfactor_bytes": (_i64, [_vp]),
 }
 
 # self-test / calibration hooks (csrc/testhooks.h): exported by the library, NOT part of the drop-in boundary

@@ -480,6 +480,27 @@ static int tri_tile_list(pgp_ctx* c, int mt, int nt, int off_tiles, const int** 
     return PGP_OK;
 }
 
+// Tiles of a SHRINKING batch of lower-trapezoidal products (GemmArgs::batch_dm: product z has mt0 - z dmt tile rows, nt tile
+// columns, the top nt x nt tile block lower-triangular), product by product, column-major inside a product; ti carries z in
+// its bits 16.. (GemmArgs::order_z).
+int batch_tile_list(pgp_ctx* c, int mt0, int nt, int nb, int dmt, const int** out, int* n) {
+    std::vector<int> key = {mt0, nt, nb, dmt, 7777};
+    auto it = c->orders.find(key);
+    if (it != c->orders.end()) { *out = it->second.first; *n = it->second.second; return PGP_OK; }
+    std::vector<int> ord;
+    for (int z = 0; z < nb; ++z)
+        for (int tj = 0; tj < nt; ++tj)
+            for (int ti = tj; ti < mt0 - z * dmt; ++ti) { ord.push_back(ti | (z << 16)); ord.push_back(tj); }
+    if (ord.empty()) { ord.push_back(-1); ord.push_back(-1); }
+    int* dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev, ord.size() * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(dev, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    c->orders[key] = {dev, (int)ord.size() / 2};
+    *out = dev; *n = (int)ord.size() / 2;
+    return PGP_OK;
+}
+
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
     if (!st) st = c->st;
     if (g.batch < 1) g.batch = 1;

@@ -51,6 +51,8 @@ struct GemmArgs {
     int tile;               // 128 or 64
     const int* order;       // optional (ti,tj) pairs per block (XCD-aware / LPT tile order built on the host); grid = norder
     int norder;
+    int order_z;            // 1: the list spans a whole batch -- ti carries the batch index in its bits 16.. (grid.z = 1): a shrinking
+                            // batch dispatches exactly its tiles instead of batch x (tiles of the largest product)
     int dbg;                // variant bits (pgp_ctx::gemm_dbg): 64 LDS-DMA staging, 256 lazy C, 512 16-byte epilogue stores
     double flops;           // algorithmic flops of this launch (for profiling; filled by caller)
     // Two-piece row spaces (the factor rows and the fused-inverse rows of a Cholesky sweep live in separate buffers so

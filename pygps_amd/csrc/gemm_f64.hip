@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int ti, tj;
     if (!decode_tile(g, (int)blockIdx.x, TM, ti, tj)) return;
+    long bz = blockIdx.z;
+    if (g.order_z) { bz = ti >> 16; ti &= 0xffff; }
     if (g.wait_flag) {
         if (threadIdx.x == 0) {
             for (unsigned it = 0; (int)(__hip_atomic_load(g.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - g.wait_target) < 0; ++it) {
@@ -67,12 +69,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     if (!YIELD && g.yield_role == 2) {               // one of the chain's own small products: its CU's bulk workgroups give way
         pgp_yield_mark(g.yield_flags, +1);
-        gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, false>(g, ti, tj, blockIdx.z, smem);
+        gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, false>(g, ti, tj, bz, smem);
         __syncthreads();
         pgp_yield_mark(g.yield_flags, -1);
         return;
     }
-    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, YIELD>(g, ti, tj, blockIdx.z, smem);
+    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, YIELD>(g, ti, tj, bz, smem);
 }
 
 template <int T, bool AKC, bool BKC, bool DMA = false, bool YIELD = false>
@@ -84,7 +86,7 @@ int launch_t(const GemmArgs& g, hipStream_t st) {
     const int mt = g.M / T, nt = g.N / T;
     unsigned nblk = (g.tri == 2) ? (unsigned)((long)mt * (mt + 1) / 2) : (unsigned)(mt * nt);
     if (g.order) nblk = (unsigned)g.norder;
-    dim3 grid(nblk, 1, g.batch > 0 ? g.batch : 1);
+    dim3 grid(nblk, 1, (g.batch > 0 && !g.order_z) ? g.batch : 1);
     static std::atomic<size_t> attr_set{0};          // two fit streams (host threads) launch concurrently
     if (attr_set.load(std::memory_order_acquire) < shm) {
         (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC, DMA, YIELD>,

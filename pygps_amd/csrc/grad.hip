@@ -10,6 +10,8 @@
 //   col_dot_kernel           alpha' = W^T z           (W = L^-1 column-major lower)
 //   logdet_ztz_kernel        sum log L_jj, z'z, alpha'alpha
 #include "kernels.h"
+#include <atomic>
+
 #include "sqdist_tile.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -277,6 +279,189 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
             out[ncov] = v4[3];
         }
     }
+}
+
+// The Hadamard reduce of the plain ARD kinds (RBFard = SEard, RQard) -- cfg 3 -- with BOTH contractions on the matrix cores:
+//   * the squared distances of the tile in the Gram form  r^2 = |a|^2 + |b|^2 - 2 a.b  on CENTRED, scaled coordinates (one
+//     v_mfma_f64_16x16x4 per 4 coordinates and 16 x 16 outputs: a third of the VALU difference form's issue slots).  This K
+//     only WEIGHTS the gradient sums (tolerance 1e-7 on dnlZ): its absolute error in r^2 is eps (|a|^2 + |b|^2), i.e. a relative
+//     error of that size in K -- 1e-16 at ell ~ sqrt(D), 3e-10 at the smallest length scale the optimiser's range allows
+//     (ell = e^-5, D = 64).  K itself (the factor, nlZ, alpha) keeps the difference form of the reference's cdist (assemble.hip).
+//     The diagonal is forced to r^2 = 0, negative round-off is clamped.
+//   * the per-coordinate sums through W' Xr as in ard_dim_reduce.
+// Thread layout = the MFMA accumulator layout, so nothing is transposed between the two: wave w, lane (l4, l15) holds rows
+// 16 w + 4 a + l4 (a < 4) and columns 16 q + l15 (q < 4) of the 64 x 64 tile.  The coordinates of both point sets are staged
+// ONCE per chunk of 64 coordinates (dynamic LDS, 2 x 64 x 66 doubles): two barriers per tile for D <= 64 instead of sixteen.
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void hadamard_ard_kernel(const double* __restrict__ XT, long ldp, long n, int dpad,
+                                                              CovParams cp0, int ncov, double inv_sn2, double sn2,
+                                                              const double* __restrict__ Binv, long ldb,
+                                                              const double* __restrict__ alpha,
+                                                              const double* __restrict__ wv,
+                                                              double* __restrict__ partial, long nt,
+                                                              const double* __restrict__ mu,
+                                                              const double* __restrict__ nrm, long b0) {
+    extern __shared__ __attribute__((aligned(16))) double smx[];
+    __shared__ double ardA[4][64], ardB[4][64];
+    __shared__ double red16[16];
+    CovParams cp = cp0;
+    cp.kind = KIND;
+    const long b = blockIdx.x + b0;
+    long r = (long)(((2.0 * nt + 1.0) - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)b)) * 0.5);
+    if (r < 0) r = 0;
+    while (r > 0 && r * nt - r * (r - 1) / 2 > b) --r;
+    while ((r + 1) * nt - (r + 1) * r / 2 <= b) ++r;
+    const long ti = r, tj = ti + (b - (r * nt - r * (r - 1) / 2));
+    const long r0 = ti * ST, c0 = tj * ST;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l4 = lane >> 4, l15 = lane & 15;
+    const int CH = dpad < 64 ? dpad : 64;            // coordinates per staged chunk
+    double* xr = smx;
+    double* xc = smx + CH * STP;
+    auto stage = [&](int k0, int kk) {                // coordinates k0 .. k0 + kk of both point sets, centred
+        const int nv = kk * 64;                       // double2 pieces: per coordinate 32 of the rows, 32 of the columns
+        for (int v = t; v < nv; v += 256) {
+            const int k = v >> 6, pr = v & 63, side = pr >> 5, pair = pr & 31;
+            const double m_ = mu[k0 + k];
+            const double2_t g = *(const double2_t*)(XT + (long)(k0 + k) * ldp + (side ? c0 : r0) + 2 * pair);
+            *(double2_t*)((side ? xc : xr) + k * STP + 2 * pair) = double2_t{g[0] - m_, g[1] - m_};
+        }
+    };
+    // ---- Gram products: S(row, col) = sum_k xr(k, row) xc(k, col) ------------------------------------------------------
+    double4_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < dpad; k0 += 64) {
+        const int kk = (dpad - k0) < 64 ? (dpad - k0) : 64;
+        if (k0) __syncthreads();
+        stage(k0, kk);
+        __syncthreads();
+        for (int ks = 0; ks < kk; ks += 4) {
+            const double a_ = xr[(ks + l4) * STP + 16 * wave + l15];
+            const double* bp = xc + (ks + l4) * STP + l15;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bp[16 * q], acc[q], 0, 0, 0);
+        }
+    }
+    // ---- element-wise: Q, K, the weights of the per-coordinate sums ------------------------------------------------------
+    double w[4][4];
+    double g1 = 0.0, g2 = 0.0, tq = 0.0;
+    double ar[4], wr[4], nr[4], ac[4], wc[4], nc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long rr = r0 + 16 * wave + 4 * a + l4;
+        ar[a] = rr < n ? alpha[rr] : 0.0;
+        wr[a] = wv ? (rr < n ? wv[rr] : 0.0) : inv_sn2;
+        nr[a] = nrm[rr];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long cc = c0 + 16 * q + l15;
+        ac[q] = cc < n ? alpha[cc] : 0.0;
+        wc[q] = wv ? (cc < n ? wv[cc] : 0.0) : 1.0;
+        nc[q] = nrm[cc];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long rr = r0 + 16 * wave + 4 * a + l4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long cc = c0 + 16 * q + l15;
+            const double bv = Binv[rr * ldb + cc];
+            double wt = (cc > rr) ? 2.0 : (cc == rr ? 1.0 : 0.0);     // symmetric: count the mirror
+            if (rr >= n || cc >= n) wt = 0.0;                          // padding
+            const double qv = bv * (wr[a] * wc[q]) - ar[a] * ac[q];
+            const double wq = (wt != 0.0) ? wt * qv : 0.0;             // never let unused entries in
+            if (cc == rr && rr < n) tq += sn2 * qv;
+            double s = fmax(fma(-2.0, acc[q][a], nr[a] + nc[q]), 0.0);
+            if (cc == rr) s = 0.0;
+            if (KIND == 1) {
+                const double K = cp.sf2 * exp_nonpos(-0.5 * s);
+                w[a][q] = wq * K;
+                g1 += 2.0 * wq * K;                                    // d/d log sf
+            } else {                                                   // RQard (Core/cov.py:1412-1425)
+                const double Kp = 1.0 + 0.5 * s / cp.alpha;
+                const double lk = log(Kp);
+                const double Ka = cp.sf2 * exp(-cp.alpha * lk);
+                w[a][q] = cp.ref_der ? 0.0 : wq * Ka / Kp;             // compat: zero length-scale gradient (cov.py:1415)
+                g1 = fma(wq, 2.0 * Ka, g1);
+                g2 = fma(wq, Ka * (0.5 * s / Kp - cp.alpha * lk), g2);
+            }
+        }
+    }
+    // ---- per-coordinate sums:  sum_rc w_rc (x_rk - x_ck)^2 = sum_r R_r x_rk^2 + sum_c x_ck (C_c x_ck - 2 (W' Xr)_ck) ----------
+    double Cw[4], Rr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                     // column sums over the wave's 16 rows, at the lane's four columns
+        double v = (w[0][q] + w[1][q]) + (w[2][q] + w[3][q]);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        Cw[q] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) Rr[a] = row16_sum((w[a][0] + w[a][1]) + (w[a][2] + w[a][3]));   // full row sums
+    double* out = partial + (long)blockIdx.x * (long)(ncov + 1);
+    for (int k0 = 0; k0 < dpad; k0 += 64) {
+        const int kk = (dpad - k0) < 64 ? (dpad - k0) : 64;
+        if (dpad > 64) {                              // more than one chunk: the Gram pass left the LAST one in LDS
+            __syncthreads();
+            stage(k0, kk);
+            __syncthreads();
+        }
+        for (int jb = 0; jb < kk; jb += 16) {
+            double fa[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fa[a] = xr[(jb + l15) * STP + 16 * wave + 4 * a + l4];
+            double4_t p2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p2[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], w[a][q], p2[q], 0, 0, 0);
+            // p2[q][r4] = (W' Xr)(coordinate jb + 4 r4 + l4, column 16 q + l15), partial over the wave's rows
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const double* row = xc + (jb + 4 * r4 + l4) * STP + l15;
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double xv = row[16 * q];
+                    s = fma(xv, fma(Cw[q], xv, -2.0 * p2[q][r4]), s);
+                }
+                s = row16_sum(s);
+                if (l15 == 0) ardA[wave][jb + 4 * r4 + l4] = s;
+            }
+            double rt = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) rt = fma(Rr[a] * fa[a], fa[a], rt);
+            rt += __shfl_xor(rt, 16, 64);
+            rt += __shfl_xor(rt, 32, 64);
+            if (l4 == 0) ardB[wave][jb + l15] = rt;
+        }
+        __syncthreads();
+        if (t < kk && k0 + t < cp.D)
+            out[k0 + t] = ((ardA[0][t] + ardB[0][t]) + (ardA[1][t] + ardB[1][t])) + ((ardA[2][t] + ardB[2][t]) + (ardA[3][t] + ardB[3][t]));
+    }
+    double v4[4] = {g1, tq, g2, 0.0};
+    block_sum4(v4, red16);
+    if (t == 0) {
+        out[cp.D] = v4[0];
+        if (KIND == 6) out[cp.D + 1] = v4[2];
+        out[ncov] = v4[1];
+    }
+}
+
+// nrm[p] = sum_k (x_pk - mu_k)^2 of the scaled coordinates, p < np (padding points included: they carry weight 0)
+__global__ __launch_bounds__(256) void point_norm_kernel(const double* __restrict__ XT, long ldp, long np, int dpad,
+                                                         const double* __restrict__ mu, double* __restrict__ nrm) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= np) return;
+    double s = 0.0;
+    for (int k = 0; k < dpad; ++k) {
+        const double v = XT[(long)k * ldp + p] - mu[k];
+        s = fma(v, v, s);
+    }
+    nrm[p] = s;
 }
 
 // Same reduction for a composite program: per element the leaf values, their (up to three) derivatives and the
@@ -648,9 +833,16 @@ long hadamard_block_count(long np, long tr0, long trn) {
 }
 
 // the coordinate means the ARD reduce centres with (no-op for covariance functions without an ARD leaf)
-int hadamard_prepare_launch(const double* XT, long ldp, long n, int dpad, const CovSpec& cs, double* mu, hipStream_t st) {
+// mu: HADAMARD_PREP_MU doubles of means, then np squared norms of the centred points (plain ARD kinds: the Gram form of
+// hadamard_ard_kernel) -- hadamard_prep_count(np) doubles in all
+constexpr long HADAMARD_PREP_MU = 272;                // dpad <= 256 + slack
+long hadamard_prep_count(long np) { return HADAMARD_PREP_MU + np; }
+int hadamard_prepare_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double* mu, hipStream_t st) {
     const bool ard = cs.prog ? cs.pg.ard_leaf >= 0 : (cs.cp.kind == 1 || cs.cp.kind == 6);
     if (ard) hipLaunchKernelGGL(coord_mean_kernel, dim3((unsigned)dpad), dim3(256), 0, st, XT, ldp, n, mu);
+    if (ard && !cs.prog)
+        hipLaunchKernelGGL(point_norm_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, XT, ldp, np, dpad, mu,
+                           mu + HADAMARD_PREP_MU);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
@@ -676,6 +868,27 @@ int hadamard_partial_launch(const double* XT, long ldp, long n, long np, int dpa
         else
             hipLaunchKernelGGL(hadamard_prog_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
                                1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt, mu, b0);
+    } else if (cs.cp.kind == 1 || cs.cp.kind == 6) {
+        CovParams cp = cs.cp;
+        cp.train = 1;
+        const int CH = dpad < 64 ? dpad : 64;
+        const size_t shm = (size_t)2 * CH * STP * sizeof(double);
+        static std::atomic<size_t> attr1{0}, attr6{0};
+        if (cp.kind == 1) {
+            if (attr1.load(std::memory_order_acquire) < shm) {
+                (void)hipFuncSetAttribute((const void*)hadamard_ard_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                attr1.store(shm, std::memory_order_release);
+            }
+            hipLaunchKernelGGL(hadamard_ard_kernel<1>, dim3((unsigned)nblk), dim3(256), shm, st, XT, ldp, n, dpad, cp, ncov, 1.0 / sn2,
+                               sn2, Binv, ldb, alpha, wv, partial, nt, mu, mu + HADAMARD_PREP_MU, b0);
+        } else {
+            if (attr6.load(std::memory_order_acquire) < shm) {
+                (void)hipFuncSetAttribute((const void*)hadamard_ard_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                attr6.store(shm, std::memory_order_release);
+            }
+            hipLaunchKernelGGL(hadamard_ard_kernel<6>, dim3((unsigned)nblk), dim3(256), shm, st, XT, ldp, n, dpad, cp, ncov, 1.0 / sn2,
+                               sn2, Binv, ldb, alpha, wv, partial, nt, mu, mu + HADAMARD_PREP_MU, b0);
+        }
     } else {
         CovParams cp = cs.cp;
         cp.train = 1;
@@ -683,12 +896,10 @@ int hadamard_partial_launch(const double* XT, long ldp, long n, long np, int dpa
                                       ncov, 1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt, mu, b0)
         switch (cp.kind) {
             case 0: HLAUNCH(0); break;
-            case 1: HLAUNCH(1); break;
             case 2: HLAUNCH(2); break;
             case 3: HLAUNCH(3); break;
             case 4: HLAUNCH(4); break;
             case 5: HLAUNCH(5); break;
-            case 6: HLAUNCH(6); break;
             default: return -2;
         }
 #undef HLAUNCH
@@ -710,14 +921,14 @@ int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad
     // ARD leaves: the per-coordinate sums run in the product form on centred coordinates (ard_dim_reduce); the means live
     // behind the per-block partials (hadamard_partial_count leaves room for them)
     double* mu = partial + nblk * (long)(ncov + 1);
-    CHK_RC(hadamard_prepare_launch(XT, ldp, n, dpad, cs, mu, st));
+    CHK_RC(hadamard_prepare_launch(XT, ldp, n, np, dpad, cs, mu, st));
     CHK_RC(hadamard_partial_launch(XT, ldp, n, np, dpad, cs, ncov, sn2, Binv, ldb, alpha, wv, partial, mu, 0, nt, st));
     return hadamard_final_launch(partial, nblk, ncov, out_dev, st);
 }
 
 long hadamard_partial_count(long np, int ncov) {
     const long nt = np / ST;
-    return nt * (nt + 1) / 2 * (long)(ncov + 1) + 272;       // + the coordinate means of the ARD reduce (dpad <= 256 + slack)
+    return nt * (nt + 1) / 2 * (long)(ncov + 1) + hadamard_prep_count(np);   // + the coordinate means / point norms of the ARD reduce
 }
 
 int col_dot_launch(const double* W, long ldw, long n, const double* z, long zs, double scale, double* y,

@@ -40,7 +40,8 @@ int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad
 long hadamard_partial_count(long np, int ncov);
 // the same reduce in pieces, for a B^-1 that exists as column strips only (csrc/sharded.hip)
 long hadamard_block_count(long np, long tr0, long trn);
-int hadamard_prepare_launch(const double* XT, long ldp, long n, int dpad, const CovSpec& cs, double* mu, hipStream_t st);
+long hadamard_prep_count(long np);
+int hadamard_prepare_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double* mu, hipStream_t st);
 int hadamard_partial_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, int ncov, double sn2,
                             const double* Binv, long ldb, const double* alpha, const double* wv, double* partial,
                             const double* mu, long tr0, long trn, hipStream_t st);

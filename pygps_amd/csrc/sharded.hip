@@ -23,12 +23,17 @@
 // What a fit needs beyond the factor needs almost no communication, because everything is LINEAR in the panels:
 //     alpha = E z / sn2 = sum_p E_p z_p / sn2        per-rank partial matvecs, ONE all-reduce of np + 3 doubles
 //     log det, z'z                                    per-panel scalars, in the same all-reduce
-//     B^-1 = E E' = sum_p E_p E_p'                    each rank accumulates ITS panels' products (N^3 / 3 / world flops) into
-//                                                     a partial B^-1 -- which is never summed: the gradient sums
-//     dnlZ_h = 1/2 sum_ij (B^-1/sn2 - alpha alpha')_ij dK_h,ij    are linear in B^-1, so every rank runs the single-GPU
-//                                                     Hadamard reduce on its partial (alpha scaled by 1/sqrt(world) so that
-//                                                     the alpha alpha' term is counted once) and ONE all-reduce of ncov + 1
-//                                                     doubles finishes the gradient.  No reduce-scatter of N^2 words.
+//     B^-1 = E E' = sum_p E_p E_p'                    every rank sees every Y_p (it is broadcast), and Y_p carries E_p: rank r
+//                                                     accumulates the COLUMN STRIPS j = r, r + world, ... of the lower triangle
+//                                                     of B^-1 (strip j: rows >= j w, w columns, stored as tall as it needs to be)
+//                                                     from every E_p, p >= j, in ONE batched launch per step (N^3 / 3 / world
+//                                                     flops per rank, np^2 / (2 world) doubles per rank; round 3 kept a full
+//                                                     np^2 partial on every rank).  No communication: the strips are complete.
+//     dnlZ_h = 1/2 sum_ij (B^-1/sn2 - alpha alpha')_ij dK_h,ij    the single-GPU Hadamard reduce, restricted to the tile rows of
+//                                                     the rank's strips, and ONE all-reduce of ncov + 1 doubles.
+// The posterior stays distributed: pgp_sfactor keeps the rank's Y panels (factor rows + E columns), alpha and the scaled
+// coordinates; pgp_sharded_predict forms V = L^-1 Ks / sn = E' Ks / sn panel by panel on the owners (one MFMA product per
+// owned panel -- E is there, no triangular solve) and all-reduces the column sums of squares (Core/gp.py:395-417).
 // Transport: pgp_comm -- RCCL bound at run time (dlopen of librccl: ncclBroadcast on a communication stream, events between
 // it and the compute streams, no host synchronisation inside the sweep), or host call-backs on staged host buffers (the
 // self-test transport: gloo through torch.distributed lets several ranks share the one GPU of a test box).
@@ -234,10 +239,39 @@ __global__ __launch_bounds__(256) void scale_vec_kernel(const double* __restrict
     if (i < n) y[i] = s * x[i];
 }
 
+// take a buffer out of a PoolScratch (ownership moves to a posterior handle)
+static void scratch_release(PoolScratch& scr, void* p) {
+    for (auto it = scr.held.begin(); it != scr.held.end(); ++it)
+        if (it->second == p) { scr.held.erase(it); return; }
+}
+
 }  // namespace
+
+// the distributed posterior of one rank (pgp_sharded_exact_fit -> pgp_sharded_predict)
+struct pgp_sfactor {
+    long n = 0, np = 0, ldp = 0;
+    int w = 0, world = 1, me = 0, nloc = 0, npanel = 0, d = 0, dpad = 0;
+    double* Bufs = nullptr; size_t bufs_bytes = 0;     // (nloc + 1) panel buffers; Y of local panel k = Bufs + k ldp w
+    double* alpha = nullptr;                           // np
+    double* XT = nullptr; size_t xt_bytes = 0;         // dpad x np scaled training coordinates
+    CovSpec cs;
+    double sn2 = 1.0, kss = 0.0;
+};
 
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" {
+
+void pgp_sfactor_free(pgp_ctx* c, pgp_sfactor* f) {
+    if (!f) return;
+    if (c) (void)hipSetDevice(c->device);
+    spool_give(c, f->bufs_bytes, f->Bufs);
+    spool_give(c, (size_t)f->np * sizeof(double), f->alpha);
+    spool_give(c, f->xt_bytes, f->XT);
+    delete f;
+}
+int64_t pgp_sfactor_bytes(pgp_sfactor* f) {
+    return f ? (int64_t)(f->bufs_bytes + (size_t)f->np * sizeof(double) + f->xt_bytes) : 0;
+}
 
 int pgp_comm_unique_id(const char* rccl_path, char* id_out) {
     if (!id_out) return -2;
@@ -301,12 +335,14 @@ int pgp_comm_rank(pgp_comm* m) { return m ? m->rank : -1; }
 
 // Exact.evaluate over the ranks of `comm`.  Every rank passes the same data (pgp_set_data) and arguments and receives the
 // same alpha / nlZ / dnlZ.  Status as pgp_exact_fit: > 0 = first non-positive pivot, identical on every rank.
-// timings_out (optional, 4): ms of assembly, sweep (+ E E' under it), epilogue (alpha, gradient, collectives), total.
+// timings_out (optional, 6): ms of assembly, sweep (+ E E' under it), epilogue (alpha, gradient, collectives), total; then the
+// device bytes this call held at its peak (panels, receive buffers, strips of B^-1, scratch) and the bytes the handle keeps.
 // L_out (optional, (n,n) row-major, zero-filled by the caller): this rank's columns of the factor in post.L's form (upper R =
 // L', Core/inf.py:362): R(j, i) = L(i, j) for the owned columns j; the sum over the ranks is the whole factor.
+// factor_out (optional): the rank's part of the distributed posterior for pgp_sharded_predict.
 int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhyp, int ncov, int para, int flags, double log_sn,
                           const double* mvec, const double* dm, int nmean, int want, double* alpha_out, double* nlZ_out,
-                          double* dnlZ_out, double* timings_out, double* L_out) {
+                          double* dnlZ_out, double* timings_out, double* L_out, pgp_sfactor** factor_out) {
     if (!c) return -1;
     if (!m || m->ctx != c) return -2;
     if (c->n <= 0) return -1;
@@ -330,21 +366,44 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
     const int dpad = c->dpad;
 
     // ---- workspace (pooled: an optimiser calls with identical shapes hundreds of times) --------------------------
+    // strips of B^-1: local strip k = columns of panel mine[k], rows >= mine[k] w, leading dimension np - mine[k] w, one
+    // behind the other (GemmArgs::batch_dldc / batch_sC2 address them from the batch index)
+    std::vector<size_t> strip_off(nloc + 1, 0);
+    for (int k = 0; k < nloc; ++k) strip_off[k + 1] = strip_off[k] + (size_t)w * (size_t)(np - (long)mine[k] * w);
+    long hblocks = 0;
+    for (int k = 0; k < nloc; ++k) hblocks += hadamard_block_count(np, (long)mine[k] * w / 64, w / 64);
     PoolScratch scr(c);
-    double *Bufs = nullptr, *Ld = nullptr, *R[2] = {nullptr, nullptr}, *Binv = nullptr, *XT = nullptr, *red = nullptr,
-           *partial = nullptr, *mdev = nullptr, *ascaled = nullptr, *gout = nullptr;
-    CHK(scr.alloc(&Bufs, (size_t)(nloc + 1) * pbytes));
-    CHK(scr.alloc(&Ld, (size_t)std::max(nloc, 1) * w * w * sizeof(double)));
-    if (world > 1) { CHK(scr.alloc(&R[0], pbytes)); CHK(scr.alloc(&R[1], pbytes)); }
-    CHK(scr.alloc(&XT, (size_t)dpad * np * sizeof(double)));
+    double *Bufs = nullptr, *Ld = nullptr, *R[2] = {nullptr, nullptr}, *Sbuf = nullptr, *XT = nullptr, *red = nullptr,
+           *partial = nullptr, *mdev = nullptr, *gout = nullptr, *adev = nullptr;
+    size_t held_bytes = 0;
+    int arc = PGP_OK;                                // the first allocation failure; agreed on with the other ranks below
+    auto take = [&](double** out, size_t bytes) {
+        if (arc == PGP_OK) { arc = scr.alloc(out, bytes); if (arc == PGP_OK) held_bytes += bytes; }
+    };
     CHK(scr.alloc(&red, (size_t)(np + 8) * sizeof(double)));
-    CHK(scr.alloc(&mdev, (size_t)np * sizeof(double)));
-    CHK(scr.alloc(&ascaled, (size_t)np * sizeof(double)));
-    CHK(scr.alloc(&gout, (size_t)(ncov + 8) * sizeof(double)));
+    take(&Bufs, (size_t)(nloc + 1) * pbytes);
+    take(&Ld, (size_t)std::max(nloc, 1) * w * w * sizeof(double));
+    if (world > 1) { take(&R[0], pbytes); take(&R[1], pbytes); }
+    const size_t xt_bytes = (size_t)dpad * np * sizeof(double);
+    take(&XT, xt_bytes);
+    take(&mdev, (size_t)np * sizeof(double));
+    take(&gout, (size_t)(ncov + 8) * sizeof(double));
+    if (factor_out) take(&adev, (size_t)np * sizeof(double));
     if (grad) {
-        CHK(scr.alloc(&Binv, (size_t)np * np * sizeof(double)));
-        CHK(scr.alloc(&partial, (size_t)hadamard_partial_count(np, ncov) * sizeof(double)));
+        take(&Sbuf, std::max<size_t>(strip_off[nloc], 1) * sizeof(double));
+        take(&partial, (size_t)(hblocks * (ncov + 1) + hadamard_prep_count(np)) * sizeof(double));
     }
+    if (world > 1) {                                 // a rank that ran out of memory must not leave the others in a collective
+        const double flag = arc != PGP_OK ? 1.0 : 0.0;
+        HIP_TRY(hipMemcpy(red, &flag, sizeof(double), hipMemcpyHostToDevice));
+        CHK(comm_allreduce(m, red, 1, 1, c->st));
+        double any = 0.0;
+        HIP_TRY(hipMemcpy(&any, red, sizeof(double), hipMemcpyDeviceToHost));
+        if (arc != PGP_OK) return arc;
+        if (any != 0.0) { pgp_set_last_hip_error(hipErrorOutOfMemory, "another rank of the sharded fit ran out of device memory", __FILE__, __LINE__); return PGP_ERR_HIP; }
+    } else if (arc != PGP_OK) return arc;
+    double kss = 0.0;
+    if (factor_out) CHK(cov_point_value(c, cp, 2, &kss));
     auto buf = [&](int k) { return Bufs + (size_t)k * ldp * w; };      // P of local panel k = buf(k + 1); Y of local panel k = buf(k)
     hipStream_t main = c->st, pan = c->st2;
     const bool pan_solve = world > 1;                // the owner's S(p+1) right behind D(p+1): its broadcast is on the critical path
@@ -367,7 +426,7 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
     if (mvec) HIP_TRY(hipMemcpyAsync(mdev, mvec, n * sizeof(double), hipMemcpyHostToDevice, main));
     HIP_TRY(hipMemsetAsync(red, 0, (np + 8) * sizeof(double), main));
     CHK(upload_scaled(c, c->x_dev, n, d, cp.scale, XT, np, dpad, c->scale_dev));
-    if (grad) HIP_TRY(hipMemsetAsync(Binv, 0, (size_t)np * np * sizeof(double), main));
+    if (grad && strip_off[nloc]) HIP_TRY(hipMemsetAsync(Sbuf, 0, strip_off[nloc] * sizeof(double), main));
     if (L_out) HIP_TRY(hipMemsetAsync(Ld, 0, (size_t)std::max(nloc, 1) * w * w * sizeof(double), main));   // strict upper parts: exact zeros
     // ---- assembly: every rank builds ITS column panels of B = K/sn2 + I straight from the coordinates -------------------
     for (int k = 0; k < nloc; ++k) {
@@ -418,99 +477,125 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
         }
         g.tile = t128 < c->small_tile_below ? 64 : 128;
         g.flops = fl;
+        if (nb > 1) { CHK(batch_tile_list(c, g.M / g.tile, w / g.tile, nb, world * w / g.tile, &g.order, &g.norder)); g.order_z = 1; }
         return gemm_prof(c, PC_GEMM_TRAIL, g, st);
     };
-    auto eet = [&](int p, hipStream_t st) -> int {                                 // partial B^-1 += E_p E_p'
-        const int k = p / world;
+    // the rank's strips of B^-1 += E_p E_p' : strips j = mine[0 .. nb) <= p, ONE batched launch.  Product z: rows and
+    // columns of E_p from j_z w on (M shrinks by world w per strip), k clipped to the triangle of the diagonal block
+    auto eet = [&](int p, hipStream_t st) -> int {
+        int nb = 0;
+        while (nb < nloc && mine[nb] <= p) ++nb;
+        if (nb == 0) return PGP_OK;
         const long rows = (long)(p + 1) * w;
+        const long j0 = (long)mine[0] * w;
+        const double* E = Yptr(p) + (ldp - rows);                                  // E_p: logical row i at E[i], ld = ldp
         GemmArgs g{};
-        g.A = buf(k) + (ldp - rows); g.lda = ldp; g.a_kc = 0;
+        g.A = E + j0; g.lda = ldp; g.a_kc = 0;
         g.B = g.A; g.ldb = ldp; g.b_kc = 0;
-        g.C = Binv; g.ldc = np;
-        g.M = (int)rows; g.N = (int)rows; g.K = w; g.alpha = 1.0; g.beta = 1.0;
-        g.tri = 2; g.mask_diag = 1; g.kmode = KM_GE_I; g.koff = -(int)((long)p * w);
-        const long mt = rows / 128;
-        g.tile = (mt * (mt + 1) / 2 < c->small_tile_below) ? 64 : 128;
-        const double wd = (double)w, r0 = (double)p * w;
-        g.flops = wd * r0 * r0 + wd * wd * r0 + wd * wd * wd / 3.0;
+        g.C = Sbuf; g.ldc = np - j0;
+        g.M = (int)(rows - j0); g.N = w; g.K = w; g.alpha = 1.0; g.beta = 1.0;
+        g.tri = 1; g.tri_off = 0; g.mask_diag = 1;
+        g.kmode = KM_GE_I; g.koff = (int)(j0 - (long)p * w);
+        g.batch = nb; g.sA = (long)world * w; g.sB = g.sA; g.sC = (long)w * (np - j0);
+        if (nb > 1) { g.batch_dm = world * w; g.batch_dk = world * w; g.batch_dldc = world * w; g.batch_sC2 = (long)w * world * w; }
+        double fl = 0.0; long t128 = 0;
+        for (int z = 0; z < nb; ++z) {
+            const double Mz = (double)g.M - (double)z * world * w;
+            fl += 2.0 * w * (Mz * w - 0.5 * (double)w * w);
+            t128 += (long)(Mz / 128) * (w / 128) - (long)(w / 128) * (w / 128 - 1) / 2;
+        }
+        g.tile = t128 < c->small_tile_below ? 64 : 128;
+        g.flops = fl;
+        if (nb > 1) { CHK(batch_tile_list(c, g.M / g.tile, w / g.tile, nb, world * w / g.tile, &g.order, &g.norder)); g.order_z = 1; }
         return gemm_prof(c, PC_GEMM_LAUUM, g, st);
     };
 
-    if (0 % world == me) {                           // panel 0 on its owner, no look-ahead to hide behind
-        CHK(factor(0, main, nullptr));
-        CHK(solve(0, main));
-        HIP_TRY(hipEventRecord(EV_S(0), main));
-    }
-    int rc_loop = PGP_OK;
-    for (int p = 0; p < npanel && rc_loop == PGP_OK; ++p) {
+    // A launch failure on one rank must not leave the others inside a collective: the rank goes on taking part in the
+    // broadcasts (its compute is skipped), its flag rides in the first all-reduce and EVERY rank returns an error.
+    int poison = PGP_OK;
+    auto body = [&](int p) -> int {                   // everything of step p that follows the arrival of Y_p
         const int owner = p % world;
-        // ---- Y_p to every rank ----
-        {
-            hipEvent_t wait = owner == me ? EV_S(p) : (p >= 2 && world > 1 ? EV_F(p - 2) : nullptr);
-            rc_loop = comm_bcast(m, Yptr(p), pbytes, owner, wait, EV_Y(p));
-            if (rc_loop != PGP_OK) break;
-            HIP_TRY(hipStreamWaitEvent(main, EV_Y(p), 0));
-        }
-        if (p + 1 >= npanel) {
-            if (grad && owner == me) rc_loop = eet(p, main);
-            break;
-        }
+        if (p + 1 >= npanel) return grad ? eet(p, main) : PGP_OK;
         const int nxt = p + 1;
-        // local panels with global index > p
-        int k_first = 0;
+        int k_first = 0;                              // local panels with global index > p
         while (k_first < nloc && mine[k_first] <= p) ++k_first;
         if (nxt % world == me) {
             // look-ahead: the next panel first, then its factorisation on the panel stream beside the rest of the step
             const int kn = nxt / world;              // == k_first
-            rc_loop = update(p, kn, 1, main);                                      // TU_a
-            if (rc_loop != PGP_OK) break;
+            CHK(update(p, kn, 1, main));                                           // TU_a
             HIP_TRY(hipEventRecord(ev_a, main));
             HIP_TRY(hipStreamWaitEvent(pan, ev_a, 0));
             const bool lf = c->leaf_first != 0;
-            rc_loop = factor(nxt, pan, lf ? ev_stage[p & 1] : nullptr);            // D(p+1)
-            if (rc_loop != PGP_OK) break;
+            CHK(factor(nxt, pan, lf ? ev_stage[p & 1] : nullptr));                 // D(p+1)
             if (lf) HIP_TRY(hipStreamWaitEvent(main, ev_stage[p & 1], 0));
             if (pan_solve) {
-                rc_loop = solve(nxt, pan);                                         // S(p+1) at once: the others wait for it
-                if (rc_loop != PGP_OK) break;
+                CHK(solve(nxt, pan));                                              // S(p+1) at once: the others wait for it
                 HIP_TRY(hipEventRecord(EV_S(nxt), pan));
             } else HIP_TRY(hipEventRecord(ev_d, pan));
-            rc_loop = update(p, kn + 1, nloc - kn - 1, main);                      // TU_b: the rest, one batched launch
-            if (rc_loop == PGP_OK && grad && owner == me) rc_loop = eet(p, main);
-            if (rc_loop != PGP_OK) break;
+            CHK(update(p, kn + 1, nloc - kn - 1, main));                           // TU_b: the rest, one batched launch
+            if (grad) CHK(eet(p, main));
             if (!pan_solve) {
                 HIP_TRY(hipStreamWaitEvent(main, ev_d, 0));
-                rc_loop = solve(nxt, main);                                        // S(p+1)
-                if (rc_loop != PGP_OK) break;
+                CHK(solve(nxt, main));                                             // S(p+1)
                 HIP_TRY(hipEventRecord(EV_S(nxt), main));
             }
         } else {
-            rc_loop = update(p, k_first, nloc - k_first, main);                    // TU(p): every owned panel beyond p
-            if (rc_loop == PGP_OK && grad && owner == me) rc_loop = eet(p, main);
-            if (rc_loop != PGP_OK) break;
+            CHK(update(p, k_first, nloc - k_first, main));                         // TU(p): every owned panel beyond p
+            if (grad) CHK(eet(p, main));
         }
+        (void)owner;
         HIP_TRY(hipEventRecord(EV_F(p), main));
+        return PGP_OK;
+    };
+    if (0 % world == me) {                           // panel 0 on its owner, no look-ahead to hide behind
+        poison = factor(0, main, nullptr);
+        if (poison == PGP_OK) poison = solve(0, main);
+        if (poison == PGP_OK && hipEventRecord(EV_S(0), main) != hipSuccess) poison = PGP_ERR_HIP;
     }
-    if (rc_loop != PGP_OK) { (void)hipDeviceSynchronize(); return rc_loop; }
+    for (int p = 0; p < npanel; ++p) {
+        const int owner = p % world;
+        // ---- Y_p to every rank (a never-recorded event does not block: a poisoned owner still broadcasts) ----
+        hipEvent_t wait = owner == me ? EV_S(p) : (p >= 2 && world > 1 ? EV_F(p - 2) : nullptr);
+        const int brc = comm_bcast(m, Yptr(p), pbytes, owner, wait, EV_Y(p));
+        if (brc != PGP_OK) { (void)hipDeviceSynchronize(); return brc; }           // the transport itself failed: nothing to agree over
+        if (poison != PGP_OK) continue;
+        if (hipStreamWaitEvent(main, EV_Y(p), 0) != hipSuccess) { poison = PGP_ERR_HIP; continue; }
+        poison = body(p);
+    }
+    if (poison != PGP_OK) {
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        if (world == 1) return poison;
+        const double one = 1.0;
+        (void)hipMemcpy(red + np + 4, &one, sizeof(double), hipMemcpyHostToDevice);
+    }
     HIP_TRY(hipEventRecord(c->ev[2], main));
 
     // ---- epilogue: alpha, log det, z'z from this rank's panels; ONE all-reduce ------------------------------------------
-    for (int k = 0; k < nloc; ++k) {
-        const int p = mine[k];
-        const long rows = (long)(p + 1) * w;
-        const double* Y = buf(k);
-        const double* z = Y + (np - rows);            // logical row np (r = y - m after the forward substitution)
-        { ProfScope ps(c, PC_SMALL, 0.0, 8.0 * (double)rows * w);
-          hipLaunchKernelGGL(panel_matvec_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, main, Y + (ldp - rows), ldp,
-                             rows, w, z, ldp, red); }
-        hipLaunchKernelGGL(panel_scalars_kernel, dim3(1), dim3(256), 0, main, Ld + (size_t)k * w * w, w, z, ldp, red + np);
+    if (poison == PGP_OK) {
+        for (int k = 0; k < nloc; ++k) {
+            const int p = mine[k];
+            const long rows = (long)(p + 1) * w;
+            const double* Y = buf(k);
+            const double* z = Y + (np - rows);            // logical row np (r = y - m after the forward substitution)
+            { ProfScope ps(c, PC_SMALL, 0.0, 8.0 * (double)rows * w);
+              hipLaunchKernelGGL(panel_matvec_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, main, Y + (ldp - rows), ldp,
+                                 rows, w, z, ldp, red); }
+            hipLaunchKernelGGL(panel_scalars_kernel, dim3(1), dim3(256), 0, main, Ld + (size_t)k * w * w, w, z, ldp, red + np);
+        }
+        hipLaunchKernelGGL(pack_status_kernel, dim3(1), dim3(1), 0, main, c->info_dev, red + np + 2);
+        if (hipGetLastError() != hipSuccess) return PGP_ERR_HIP;
     }
-    hipLaunchKernelGGL(pack_status_kernel, dim3(1), dim3(1), 0, main, c->info_dev, red + np + 2);
-    if (hipGetLastError() != hipSuccess) return PGP_ERR_HIP;
-    CHK(comm_allreduce(m, red, (size_t)np + 3, 0, main));
+    CHK(comm_allreduce(m, red, (size_t)np + 5, 0, main));
     std::vector<double> head(8, 0.0);
-    HIP_TRY(hipMemcpyAsync(head.data(), red + np, 4 * sizeof(double), hipMemcpyDeviceToHost, main));
+    HIP_TRY(hipMemcpyAsync(head.data(), red + np, 5 * sizeof(double), hipMemcpyDeviceToHost, main));
     HIP_TRY(hipStreamSynchronize(main));
+    if (head[4] != 0.0) {                            // a rank failed inside the sweep: everybody leaves, with its own code or this one
+        (void)hipDeviceSynchronize();
+        if (poison != PGP_OK) return poison;
+        pgp_set_last_hip_error(hipErrorUnknown, "another rank of the sharded fit failed inside the sweep", __FILE__, __LINE__);
+        return PGP_ERR_HIP;
+    }
     if (head[2] != 0.0) {                            // a non-positive pivot somewhere: every rank learns the first one
         CHK(comm_allreduce(m, red + np + 3, 1, 1, main));
         double v = 0.0;
@@ -519,15 +604,28 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
         const long piv = (long)llround(1.0e9 - v);
         return (int)(piv > n ? n : (piv < 1 ? 1 : piv));
     }
-    // alpha = (sum of the partials) / sn2 ; the gradient reduce on the PARTIAL B^-1 with alpha / sqrt(world)
+    // alpha = (sum of the partials) / sn2 ; the gradient reduce over the tile rows of the rank's strips (the strips are
+    // COMPLETE entries of B^-1: the true alpha, every (row, column) pair on exactly one rank), then one all-reduce
     hipLaunchKernelGGL(scale_vec_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, main, red, 1.0 / sn2, red, np);
     if (grad) {
-        hipLaunchKernelGGL(scale_vec_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, main, red, 1.0 / sqrt((double)world),
-                           ascaled, np);
-        { ProfScope ps(c, PC_HADAMARD, 0.0, 8.0 * (double)np * (np + 1) / 2.0 + 8.0 * (double)n * d);
-          CHK(hadamard_reduce_launch(XT, np, n, np, dpad, cp, ncov, sn2, Binv, np, ascaled, partial, gout, main)); }
+        double* mu = partial + hblocks * (long)(ncov + 1);
+        CHK(hadamard_prepare_launch(XT, np, n, np, dpad, cp, mu, main));
+        long done = 0;
+        for (int k = 0; k < nloc; ++k) {
+            const long j0 = (long)mine[k] * w, ldk = np - j0;
+            // Binv[r * ldb + c] (global r in the strip's columns, c >= r) = strip[(r - j0) * ldk + (c - j0)]
+            const double* Bv = Sbuf + strip_off[k] - j0 * ldk - j0;
+            const long nb_ = hadamard_block_count(np, j0 / 64, w / 64);
+            { ProfScope ps(c, PC_HADAMARD, 0.0, 8.0 * (double)w * ldk + 8.0 * (double)n * d);
+              CHK(hadamard_partial_launch(XT, np, n, np, dpad, cp, ncov, sn2, Bv, ldk, red, nullptr, partial + done * (ncov + 1), mu,
+                                          j0 / 64, w / 64, main)); }
+            done += nb_;
+        }
+        if (done > 0) CHK(hadamard_final_launch(partial, done, ncov, gout, main));
+        else HIP_TRY(hipMemsetAsync(gout, 0, (size_t)(ncov + 1) * sizeof(double), main));
         CHK(comm_allreduce(m, gout, (size_t)ncov + 1, 0, main));
     }
+    if (factor_out) HIP_TRY(hipMemcpyAsync(adev, red, (size_t)np * sizeof(double), hipMemcpyDeviceToDevice, main));
     HIP_TRY(hipEventRecord(c->ev[3], main));
     std::vector<double> alpha_h(n), g_h(ncov + 1, 0.0);
     HIP_TRY(hipMemcpyAsync(alpha_h.data(), red, n * sizeof(double), hipMemcpyDeviceToHost, main));
@@ -541,6 +639,8 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
         (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
         (void)hipEventElapsedTime(&e, c->ev[2], c->ev[3]); (void)hipEventElapsedTime(&t, c->ev[0], c->ev[3]);
         timings_out[0] = a; timings_out[1] = b; timings_out[2] = e; timings_out[3] = t;
+        timings_out[4] = (double)(held_bytes + (size_t)(np + 8) * sizeof(double));
+        timings_out[5] = factor_out ? (double)((size_t)(nloc + 1) * pbytes + xt_bytes + (size_t)np * sizeof(double)) : 0.0;
     }
     if (L_out) {                                     // owned columns of L: the diagonal block from Ld, the rows below from Y
         for (int k = 0; k < nloc; ++k) {
@@ -567,6 +667,95 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
         for (int h = 0; h < ncov; ++h) dnlZ_out[nmean + h] = 0.5 * g_h[h];             // inf.py:377
         dnlZ_out[nmean + ncov] = g_h[ncov];                                            // inf.py:374
     }
+    if (factor_out) {                                // the rank's panels, alpha and the coordinates move into the handle
+        pgp_sfactor* f = new pgp_sfactor();
+        f->n = n; f->np = np; f->ldp = ldp; f->w = w; f->world = world; f->me = me; f->nloc = nloc; f->npanel = npanel;
+        f->d = (int)d; f->dpad = dpad; f->cs = cp; f->sn2 = sn2; f->kss = kss;
+        f->Bufs = Bufs; f->bufs_bytes = (size_t)(nloc + 1) * pbytes; scratch_release(scr, Bufs);
+        f->alpha = adev; scratch_release(scr, adev);
+        f->XT = XT; f->xt_bytes = xt_bytes; scratch_release(scr, XT);
+        *factor_out = f;
+    }
+    return PGP_OK;
+}
+
+// GP.predict (Core/gp.py:395-417) on the distributed posterior: every rank calls with the same test points and gets the same
+// fmu = ms + Ks' alpha and fs2 = max(kss - colsum(V^2), 0), V = L^-1 (sW o Ks) = E' Ks / sn: rank r forms the rows of V that
+// belong to ITS panels (V_p = E_p' Ks, one clipped MFMA product per owned panel), sums their squares per test point, and one
+// all-reduce of ns doubles per batch finishes fs2.  No triangular solve: E = L^-T came out of the sweep.
+int pgp_sharded_predict(pgp_ctx* c, pgp_comm* m, pgp_sfactor* f, const double* xs, int64_t ns, const double* ms, double* fmu,
+                        double* fs2) {
+    if (!c) return -1;
+    if (!m || m->ctx != c) return -2;
+    if (!f || f->world != m->world || f->me != m->rank) return -3;
+    if (!xs) return -4;
+    if (ns <= 0) return -5;
+    if (!fmu) return -7;
+    if (!fs2) return -8;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->st;
+    const long np = f->np, n = f->n, ldp = f->ldp;
+    const int w = f->w, d = f->d, dpad = f->dpad;
+    const long NSB = std::max<long>(128, std::min<long>(c->predict_batch, round_up(ns, 128)));
+    const long ldc = NSB;
+    PoolScratch tmp(c);
+    double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *acc = nullptr, *V = nullptr;
+    int arc = PGP_OK;
+    auto take = [&](double** out, size_t bytes) { if (arc == PGP_OK) arc = tmp.alloc(out, bytes); };
+    CHK(tmp.alloc(&acc, NSB * sizeof(double)));
+    take(&xd, NSB * d * sizeof(double));
+    take(&XcT, (size_t)dpad * ldc * sizeof(double));
+    take(&scd, dpad * sizeof(double));
+    take(&Ks, (size_t)np * NSB * sizeof(double));
+    take(&msd, NSB * sizeof(double));
+    take(&o1, NSB * sizeof(double));
+    take(&V, (size_t)w * NSB * sizeof(double));
+    if (m->world > 1) {
+        const double flag = arc != PGP_OK ? 1.0 : 0.0;
+        HIP_TRY(hipMemcpy(acc, &flag, sizeof(double), hipMemcpyHostToDevice));
+        CHK(comm_allreduce(m, acc, 1, 1, st));
+        double any = 0.0;
+        HIP_TRY(hipMemcpy(&any, acc, sizeof(double), hipMemcpyDeviceToHost));
+        if (arc != PGP_OK) return arc;
+        if (any != 0.0) { pgp_set_last_hip_error(hipErrorOutOfMemory, "another rank of the sharded predict ran out of device memory", __FILE__, __LINE__); return PGP_ERR_HIP; }
+    } else if (arc != PGP_OK) return arc;
+    HIP_TRY(hipMemcpyAsync(scd, f->cs.scale.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
+    CovSpec cp = f->cs;
+    cp.cp.der = -1; cp.pg.der = -1;
+    std::vector<double> acc_h(NSB);
+    for (long a = 0; a < ns; a += NSB) {
+        const long nb_ = std::min<long>(NSB, ns - a);
+        const int nrhs = (int)round_up(nb_, 128);
+        HIP_TRY(hipMemcpyAsync(xd, xs + a * d, nb_ * d * sizeof(double), hipMemcpyHostToDevice, st));
+        if (ms) HIP_TRY(hipMemcpyAsync(msd, ms + a, nb_ * sizeof(double), hipMemcpyHostToDevice, st));
+        else HIP_TRY(hipMemsetAsync(msd, 0, nb_ * sizeof(double), st));
+        CHK(scale_transpose_launch(xd, nb_, d, scd, XcT, ldc, dpad, st));
+        HIP_TRY(hipMemsetAsync(Ks, 0, (size_t)np * nrhs * sizeof(double), st));
+        CHK(cov_rect_launch(XcT, ldc, nb_, f->XT, np, n, dpad, cp, Ks, np, st));     // column-major (np x nrhs): column = test point
+        CHK(col_dot_full_launch(Ks, np, n, nb_, f->alpha, msd, o1, st));                 // fmu = ms + Ks' alpha (every rank, O(n ns))
+        HIP_TRY(hipMemsetAsync(acc, 0, (size_t)nrhs * sizeof(double), st));
+        for (int k = 0; k < f->nloc; ++k) {
+            const int p = f->me + k * f->world;
+            const long rows = (long)(p + 1) * w;
+            GemmArgs g{};
+            g.A = f->Bufs + (size_t)k * ldp * w + (ldp - rows); g.lda = ldp; g.a_kc = 1;     // A(m, k) = E_p(k, m)
+            g.B = Ks; g.ldb = np; g.b_kc = 1;                                              // B(t, k) = Ks(k, t)
+            g.C = V; g.ldc = w;
+            g.M = w; g.N = nrhs; g.K = (int)rows; g.alpha = 1.0; g.beta = 0.0;
+            g.kmode = KM_LT_I; g.koff = (int)((long)p * w);                                // E_p(k, m) = 0 for k > p w + m
+            const long t128 = (long)(w / 128) * (nrhs / 128);
+            g.tile = t128 < c->small_tile_below ? 64 : 128;
+            g.flops = 2.0 * (double)w * nrhs * ((double)rows - 0.5 * w);
+            CHK(gemm_prof(c, PC_GEMM_SOLVE, g, st));
+            CHK(colsumsq_acc_launch(V, w, w, nb_, acc, st));
+        }
+        CHK(comm_allreduce(m, acc, (size_t)nrhs, 0, st));
+        HIP_TRY(hipMemcpyAsync(fmu + a, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(acc_h.data(), acc, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (long j = 0; j < nb_; ++j) fs2[a + j] = std::max(f->kss - acc_h[j] / f->sn2, 0.0);
+    }
+    if (c->prof) prof_collect(c);
     return PGP_OK;
 }
 

@@ -137,6 +137,9 @@ class GP(object):
             _lib.check(_lib.load().pgp_fitc_predict(fitc.ctx, fitc.handle, _lib.ptr(xs), ns, _lib.ptr(ms), _lib.ptr(fmu),
                                                     _lib.ptr(fs2)), "pgp_fitc_predict")
             return fmu.reshape(ns, 1), fs2.reshape(ns, 1)
+        if type(L).__name__ == "DistributedFactor":            # a sharded fit: collective predict on the distributed posterior
+            xs = _lib.f64(xs)
+            return L.predict(xs, self.meanfunc.getMean(xs))
         if not isinstance(L, inf.DeviceFactor):
             raise NotImplementedError("pygps_amd: predict needs a posterior produced by pygps_amd inference "
                                       "(device-resident factor); there is no CPU fallback")

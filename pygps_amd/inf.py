@@ -250,12 +250,14 @@ class Exact(Inference):
         m, dm, nm = _mean_inputs(meanfunc, x)
         nc = len(covfunc.hyp)
         log_sn = float(likfunc.hyp[0])
-        alpha, nlz, g, self.last_ms, Lh = _sh.exact_fit(comm, kind, para, flags, covfunc.hyp, log_sn, m, dm, nm, n, nargout,
-                                                        gather_factor=self.gather_factor)
+        alpha, nlz, g, ms6, Lh, fh = _sh.exact_fit(comm, kind, para, flags, covfunc.hyp, log_sn, m, dm, nm, n, nargout,
+                                                   gather_factor=self.gather_factor, keep_factor=not self.gather_factor)
+        self.last_ms = ms6[:4]
+        self.last_bytes = {"peak_device_bytes": int(ms6[4]), "factor_device_bytes": int(ms6[5])}
         post = postStruct()
         post.alpha = alpha.reshape(n, 1)
         post.sW = np.ones((n, 1)) / np.sqrt(np.exp(2 * log_sn))
-        post.L = Lh if Lh is not None else _sh.DistributedFactor(n, comm.world)
+        post.L = Lh if Lh is not None else _sh.DistributedFactor(n, comm, fh)
         if nargout > 1:
             if nargout > 2:
                 dnlZ = dnlZStruct(meanfunc, covfunc, likfunc)

@@ -14,11 +14,14 @@ and everything else a fit returns (alpha, nlZ, dnlZ) needs two small all-reduces
   share the ONE GPU of a test box (RCCL refuses two ranks on one device).
 * no process group: world size 1 over the host transport (nothing moves).
 
-``inf.Exact(sharded=True)`` (or ``sharded=Comm(...)``) routes ``evaluate`` through it; ``post.L`` is then not available
-(the factor stays distributed) and ``predict`` is not supported on such a posterior.  No CPU fallback.
+``inf.Exact(sharded=True)`` (or ``sharded=Comm(...)``) routes ``evaluate`` through it; ``post.L`` is then a
+``DistributedFactor``: the factor stays on the ranks (every rank keeps its column panels of L and of L^-T, O(n^2 / world)
+bytes), ``GP.predict`` runs on it collectively (``pgp_sharded_predict``: every rank calls with the same test points), and
+touching it as an array raises unless ``gather_factor=True`` was asked for.  No CPU fallback.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -127,20 +130,24 @@ def default_comm(device=None):
     return _default_comm[device]
 
 
-def exact_fit(comm, kind, para, flags, cov_hyp, log_sn, m, dm, nm, n, nargout=3, gather_factor=False):
-    """pgp_sharded_exact_fit on the data the context of ``comm`` holds.  Returns (alpha (n,), nlZ, g (nm+nc+1,), ms (4,), L).
-    gather_factor: L = the (n,n) upper factor post.L on every rank (each rank fetches its own columns, the host arrays are
-    summed over the ranks) -- for moderate n only: it is n^2 doubles on every host; None otherwise."""
+def exact_fit(comm, kind, para, flags, cov_hyp, log_sn, m, dm, nm, n, nargout=3, gather_factor=False, keep_factor=True):
+    """pgp_sharded_exact_fit on the data the context of ``comm`` holds.  Returns (alpha (n,), nlZ, g (nm+nc+1,), ms (6,), L, h).
+    ms: stage times (assembly, sweep, epilogue, total) in ms, then the device bytes the call held at its peak and the bytes the
+    posterior handle keeps.  gather_factor: L = the (n,n) upper factor post.L on every rank (each rank fetches its own columns,
+    the host arrays are summed over the ranks) -- for moderate n only: it is n^2 doubles on every host; None otherwise.
+    h: the rank's part of the distributed posterior (a ``pgp_sfactor`` handle) when keep_factor, else None."""
     hyp = _lib.f64(np.asarray(cov_hyp, dtype=float))
     nc = len(hyp)
     alpha = np.empty(n)
     nlZ = np.zeros(1)
     g = np.zeros(nm + nc + 1)
-    ms = np.zeros(4)
+    ms = np.zeros(6)
     L = np.zeros((n, n)) if gather_factor else None
+    h = C.c_void_p()
     rc = comm.lib.pgp_sharded_exact_fit(comm.ctx, comm.handle, int(kind), _lib.ptr(hyp), nc, int(para), int(flags),
                                         float(log_sn), _lib.ptr(m), _lib.ptr(dm), int(nm), int(min(max(nargout, 1), 3)),
-                                        _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(g), _lib.ptr(ms), _lib.ptr(L))
+                                        _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(g), _lib.ptr(ms), _lib.ptr(L),
+                                        C.byref(h) if keep_factor else None)
     _lib.check(rc, "pgp_sharded_exact_fit")
     if L is not None and comm.world > 1:
         import torch
@@ -151,19 +158,48 @@ def exact_fit(comm, kind, para, flags, cov_hyp, log_sn, m, dm, nm, n, nargout=3,
             L = t.cpu().numpy()
         else:
             comm.dist.all_reduce(t, group=comm.group)
-    return alpha, float(nlZ[0]), g, ms, L
+    return alpha, float(nlZ[0]), g, ms, L, (h if keep_factor else None)
 
 
 class DistributedFactor(object):
-    """``post.L`` of a sharded fit: the factor stays distributed over the ranks (column panels); touching it raises."""
+    """``post.L`` of a sharded fit: the factor stays distributed over the ranks -- this rank's column panels of L and of
+    L^-T, alpha and the scaled coordinates live behind a ``pgp_sfactor`` handle on its GPU.  ``GP.predict`` uses it
+    collectively (``predict`` below); touching it as an array raises (``Exact(gather_factor=True)`` gathers it instead)."""
 
-    def __init__(self, n, world):
+    def __init__(self, n, comm, handle):
         self.shape = (int(n), int(n))
-        self.world = int(world)
+        self.world = int(comm.world)
+        self.comm = comm
+        self.handle = handle
+        self.nbytes_device = int(comm.lib.pgp_sfactor_bytes(handle)) if handle else 0
+        if handle:
+            self._fin = weakref.finalize(self, DistributedFactor._release, comm.lib.pgp_sfactor_free, comm.ctx, handle)
+
+    @staticmethod
+    def _release(free_fn, ctx, handle):
+        try:
+            free_fn(ctx, handle)
+        except Exception:           # interpreter shutdown
+            pass
+
+    def predict(self, xs, ms):
+        """fmu, fs2 of GP.predict (Core/gp.py:395-417) for test points xs (ns, d) with prior mean ms (ns,): collective, every
+        rank calls with the same arguments and receives the same result."""
+        if not self.handle:
+            raise NotImplementedError("this sharded posterior was computed without a factor handle")
+        xs = _lib.f64(xs)
+        ns = xs.shape[0]
+        ms = _lib.f64(ms).reshape(ns)
+        fmu = np.empty(ns)
+        fs2 = np.empty(ns)
+        _lib.check(self.comm.lib.pgp_sharded_predict(self.comm.ctx, self.comm.handle, self.handle, _lib.ptr(xs), ns, _lib.ptr(ms),
+                                                    _lib.ptr(fmu), _lib.ptr(fs2)), "pgp_sharded_predict")
+        return fmu.reshape(ns, 1), fs2.reshape(ns, 1)
 
     def _no(self, *a, **k):
-        raise NotImplementedError("the Cholesky factor of a sharded fit is distributed over %d ranks and is not gathered; "
-                                  "use inf.Exact() for a posterior that predict() can use" % self.world)
+        raise NotImplementedError("the Cholesky factor of a sharded fit is distributed over %d ranks and is not gathered "
+                                  "(predict() works on it as it is; Exact(gather_factor=True) returns post.L as an array)"
+                                  % self.world)
 
     __array__ = __getitem__ = _no
 
@@ -171,4 +207,4 @@ class DistributedFactor(object):
         return self
 
     def __repr__(self):
-        return "DistributedFactor(n=%d over %d ranks)" % (self.shape[0], self.world)
+        return "DistributedFactor(n=%d over %d ranks, %d device bytes on this rank)" % (self.shape[0], self.world, self.nbytes_device)

@@ -121,6 +121,52 @@ def _worker(rank, world, port, backend, case, out_dir):
                 assert relerr(post.alpha, ref["alpha"]) < 1e-7, name
                 assert relerr(_flat(dnlZ), np.concatenate([ref["dnlZ_mean"], ref["dnlZ_cov"], ref["dnlZ_lik"]])) < 1e-7, name
                 res[name] = nlZ
+        elif case == "predict_g17":
+            # GP.predict on the DISTRIBUTED posterior (pgp_sharded_predict: V = E' Ks panel by panel on the owners, one all-reduce
+            # of the column sums per batch) against the reference's own predictions at the bench scale (G17: N = 8192 posterior,
+            # 16384 test points, every point) -- Core/gp.py:395-417 after Core/inf.py:353-384
+            g = golden("G17_predict_N8192_ns16384")
+            N, d, ns = 8192, 16, 16384
+            m = _g6_model(pyGPs, N, sharded=comm)
+            nlZ, dnlZ, post = m.getPosterior()
+            _check_g6(N, nlZ, dnlZ, post)
+            assert type(post.L).__name__ == "DistributedFactor" and post.L.nbytes_device > 0
+            x = m.x
+            rng = np.random.RandomState(7)                                           # make_golden.py g17: same draws
+            xs = rng.randn(ns, d)
+            xs[: ns // 4] = x[rng.randint(0, N, ns // 4)] + 0.05 * rng.randn(ns // 4, d)
+            ym, ys2, fm, fs2, lp = m.predict(xs)
+            scale = float(np.max(np.abs(g["pred_fm"])))
+            assert np.max(np.abs(fm - g["pred_fm"])) < 1e-8 * scale and np.max(np.abs(ym - g["pred_ym"])) < 1e-8 * scale
+            assert np.max(np.abs(fs2 - g["pred_fs2"])) < 1e-7 * float(np.max(g["pred_fs2"]))
+            assert np.max(np.abs(ys2 - g["pred_ys2"])) < 1e-7 * float(np.max(g["pred_ys2"]))
+            ym2, ys22, fm2, fs22, lp2 = m.predict(xs[:300])                          # a ragged count, one small batch
+            assert np.max(np.abs(fm2 - fm[:300])) < 1e-12 * scale and np.max(np.abs(fs22 - fs2[:300])) < 1e-11
+            res = dict(fm=fm, fs2=fs2, bytes=m.inffunc.last_bytes)
+        elif case == "g7_16384":
+            # cfg 3's size over 8 ranks: 16 panels of 1024, two per rank (the look-ahead and the batched updates live), SEard d = 64,
+            # against the reference's own alpha / nlZ / 67 gradients (G7 N = 16384)
+            g = golden("G7_rbfard_d64_N16384")
+            N, d = 16384, 64
+            x, y = synth_reg(N, d)
+            m = pyGPs.GPR()
+            m.setPrior(kernel=pyGPs.cov.RBFard(log_ell_list=[float(np.log(np.sqrt(d)))] * d, log_sigma=0.0))
+            m.setNoise(np.log(0.1))
+            m.setData(x, y)
+            m.inffunc = pyGPs.inf.Exact(sharded=comm)
+            nlZ, dnlZ, post = m.getPosterior()
+            assert relerr(nlZ, g["nlZ"]) < 1e-9
+            assert relerr(post.alpha[g["alpha_idx"], 0], g["alpha_sample"]) < 1e-7
+            gref = np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])
+            assert np.max(np.abs(_flat(dnlZ) - gref)) < 1e-6 * np.max(np.abs(gref))
+            b = m.inffunc.last_bytes
+            np_ = 16384
+            # per-rank device memory: the rank's panels (+ one spare, + two receive buffers) and its strips of B^-1 -- a fraction
+            # of ONE np x np matrix (round 3 held a full np^2 partial B^-1 on every rank: 2.1 GB here)
+            assert b["peak_device_bytes"] < 0.5 * np_ * np_ * 8, b
+            res = dict(nlZ=nlZ, g=_flat(dnlZ), alpha=post.alpha, bytes=b)
+            if rank == 0:
+                print("sharded fit N=16384 d=64 world=%d: %s ms, bytes %s" % (world, np.round(m.inffunc.last_ms, 1), b))
         elif case == "nonpd":
             # duplicate points + a tiny noise: B = K/sn2 + I loses positive definiteness in floating point somewhere in the
             # sweep; every rank must raise LinAlgError with the SAME pivot (no rank may hang in a broadcast)
@@ -180,3 +226,32 @@ def test_ragged_sizes_and_other_kernels_world_3(tmp_path):
 def test_non_positive_definite_input_raises_on_every_rank(tmp_path):
     out = _run(tmp_path, 2, "gloo", "nonpd")
     assert out[0]["msg"] == out[1]["msg"] and "first bad pivot" in out[0]["msg"]
+
+
+def test_predict_on_the_distributed_posterior_world_2(tmp_path):
+    out = _run(tmp_path, 2, "gloo", "predict_g17")
+    assert np.array_equal(out[0]["fm"], out[1]["fm"]) and np.array_equal(out[0]["fs2"], out[1]["fs2"])
+    # every rank keeps about half of the distributed factor: (np + 128) np / world doubles + one spare panel
+    np_, w = 8192, 512
+    for r in out:
+        assert r["bytes"]["factor_device_bytes"] < ((np_ + 128) * np_ / 2 + 2 * (np_ + 128) * w) * 8 * 1.05
+
+
+def test_predict_on_the_distributed_posterior_world_1(lib):
+    """The same path without a process group (host transport, world 1) against the single-GPU predict."""
+    import pygps_amd as pyGPs
+    N = 2048
+    m = _g6_model(pyGPs, N, sharded=True)
+    m.getPosterior()
+    m1 = _g6_model(pyGPs, N, sharded=False)
+    m1.getPosterior()
+    xs = np.random.RandomState(3).randn(777, 16)
+    a, b = m.predict(xs), m1.predict(xs)
+    for u, v in zip(a[:4], b[:4]):
+        assert relerr(u, v) < 1e-9
+
+
+def test_cfg3_size_over_8_ranks_against_the_reference(tmp_path):
+    out = _run(tmp_path, 8, "gloo", "g7_16384")
+    for r in out[1:]:
+        assert r["nlZ"] == out[0]["nlZ"] and np.array_equal(r["alpha"], out[0]["alpha"]) and np.array_equal(r["g"], out[0]["g"])

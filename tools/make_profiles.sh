@@ -1,10 +1,10 @@
 #!/bin/bash
-# Regenerate profiles/r03_* on the GPU box:  gpurun -- 'bash tools/make_profiles.sh <git-head>'
+# Regenerate profiles/r04_* on the GPU box:  gpurun -- 'bash tools/make_profiles.sh <git-head>'
 # (kernel-trace stats and PMC counters in SEPARATE rocprofv3 runs; PMC runs use --kernel-trace only)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 HEAD=${1:-unknown}
-O=$R/gpurun_out/prof_r03
+O=$R/gpurun_out/prof_r04
 rm -rf $O; mkdir -p $O/final
 export PYTHONPATH=$R
 cd /tmp && export TMPDIR=/tmp
@@ -12,36 +12,36 @@ kstats() { find $1 -name "*kernel_stats.csv" | head -1; }
 ccsv() { find $1 -name "*counter_collection.csv" | head -1; }
 # 1. the bench line itself (with cpu_baseline, extras)
 timeout 1200 python $R/bench.py > $O/bench.json 2> $O/bench.err
-grep '^{' $O/bench.json > $O/final/r03_bench.json
+grep '^{' $O/bench.json > $O/final/r04_bench.json
 # 2a. kernel-trace stats of the SINGLE-STREAM command: the run whose per-kernel averages reproduce roofline.frac
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python $R/bench.py --streams 1 --no-cpu-baseline --no-extras > $O/s1.json 2> $O/stats1.err
-grep '^{' $O/s1.json > $O/final/r03_bench_streams1_under_rocprof.json; cp $(kstats $O/stats1) $O/final/r03_bench_streams1_kernel_stats.csv
+grep '^{' $O/s1.json > $O/final/r04_bench_streams1_under_rocprof.json; cp $(kstats $O/stats1) $O/final/r04_bench_streams1_kernel_stats.csv
 # 2b. the same for the timed (two fit streams) configuration: kernel time sums overlap there
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python $R/bench.py --no-cpu-baseline --no-extras > $O/s2.json 2> $O/stats2.err
-grep '^{' $O/s2.json > $O/final/r03_bench_streams2_under_rocprof.json; cp $(kstats $O/stats2) $O/final/r03_bench_streams2_kernel_stats.csv
+grep '^{' $O/s2.json > $O/final/r04_bench_streams2_under_rocprof.json; cp $(kstats $O/stats2) $O/final/r04_bench_streams2_kernel_stats.csv
 # (un-profiled timing runs come BEFORE the --pmc passes: right after a counter pass the next process starts at a fraction of the
 #  clock for a few seconds -- measured: the N = 8192 fit of tools/sharded_time.py 10x slow directly behind xcd_decision.py)
 # 2c. the sharded fit at world 1 against the single-GPU fit
-timeout 900 python $R/tools/sharded_time.py 8192 16384 32768 65536 2> $O/sharded.err | grep "N=" > $O/final/r03_sharded_fit_world1.txt
+timeout 900 python $R/tools/sharded_time.py 8192 16384 32768 65536 2> $O/sharded.err | grep "N=" > $O/final/r04_sharded_fit_world1.txt
 # 2d. single- and two-stream rates of the raw C-ABI loop
-NSTREAMS=1,2 timeout 300 python $R/tools/two_streams.py 2> /dev/null | grep fits > $O/final/r03_two_streams.txt
+NSTREAMS=1,2 timeout 300 python $R/tools/two_streams.py 2> /dev/null | grep fits > $O/final/r04_two_streams.txt
 # 3. PMC traffic of gemm_f64 (separate passes, single stream)
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -- python $R/bench.py --steps 3 --windows 1 --prof-steps 1 --streams 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_$d.err
-  cp $(ccsv $O/pmc/$d) $O/final/r03_pmc_${d}_counter_collection.csv
+  cp $(ccsv $O/pmc/$d) $O/final/r04_pmc_${d}_counter_collection.csv
 done
-python $R/tools/pmc_traffic.py $O/pmc $O/final/r03_gemm_f64_hbm_traffic.json $HEAD > /dev/null 2>> $O/pmc.err
+python $R/tools/pmc_traffic.py $O/pmc $O/final/r04_gemm_f64_hbm_traffic.json $HEAD > /dev/null 2>> $O/pmc.err
 # 4. cfg 3 (SEard N=16384 d=64) and cfg 5 (EP N=4096 d=32): per-kernel stats
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -- python $R/tools/cfg3_time.py > $O/final/r03_cfg3_time.txt 2> $O/cfg3.err
-cp $(kstats $O/cfg3) $O/final/r03_cfg3_seard_N16384_kernel_stats.csv
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -- python $R/tools/ep_time.py > $O/final/r03_cfg5_time.txt 2> $O/cfg5.err
-cp $(kstats $O/cfg5) $O/final/r03_cfg5_ep_N4096_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -- python $R/tools/cfg3_time.py > $O/final/r04_cfg3_time.txt 2> $O/cfg3.err
+cp $(kstats $O/cfg3) $O/final/r04_cfg3_seard_N16384_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -- python $R/tools/ep_time.py > $O/final/r04_cfg5_time.txt 2> $O/cfg5.err
+cp $(kstats $O/cfg5) $O/final/r04_cfg5_ep_N4096_kernel_stats.csv
 # 5. kernel assembly at N=16384 (RBF d=16, SEard d=64; full symmetric output and the fused factor form): stats + WRITE_SIZE
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/asm -- python $R/tools/gpu_probe.py asm > $O/final/r03_assembly_probe.txt 2> $O/asm.err
-cp $(kstats $O/asm) $O/final/r03_assembly_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/asm -- python $R/tools/gpu_probe.py asm > $O/final/r04_assembly_probe.txt 2> $O/asm.err
+cp $(kstats $O/asm) $O/final/r04_assembly_kernel_stats.csv
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/asm_w -- python $R/tools/gpu_probe.py asm > /dev/null 2> $O/asm_w.err
-cp $(ccsv $O/asm_w) $O/final/r03_assembly_pmc_write_counter_collection.csv
+cp $(ccsv $O/asm_w) $O/final/r04_assembly_pmc_write_counter_collection.csv
 # 6. the XCD-aware tile order: same-box A/B of speed, L2-side fetch, MFMA-pipe busy cycles, L2 hit rate
-python $R/tools/xcd_decision.py $O > $O/final/r03_xcd_order_decision.json 2> $O/xcd.err
+python $R/tools/xcd_decision.py $O > $O/final/r04_xcd_order_decision.json 2> $O/xcd.err
 ls -la $O/final
