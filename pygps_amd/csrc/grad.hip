@@ -292,6 +292,20 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
 // Thread layout = the MFMA accumulator layout, so nothing is transposed between the two: wave w, lane (l4, l15) holds rows
 // 16 w + 4 a + l4 (a < 4) and columns 16 q + l15 (q < 4) of the 64 x 64 tile.  The coordinates of both point sets are staged
 // ONCE per chunk of 64 coordinates (dynamic LDS, 2 x 64 x 66 doubles): two barriers per tile for D <= 64 instead of sixteen.
+// NP double2 pieces of one thread's share of a staged chunk: piece i = coordinate 4 i of the wave's residue class
+template <int NP>
+__device__ __forceinline__ void stage_pieces(const double* __restrict__ gp, long ldp, const double* __restrict__ mup,
+                                             double* __restrict__ slp) {
+    double2_t g[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) g[i] = *(const double2_t*)(gp + (long)(4 * i) * ldp);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const double m_ = mup[4 * i];
+        *(double2_t*)(slp + 4 * i * STP) = double2_t{g[i][0] - m_, g[i][1] - m_};
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void hadamard_ard_kernel(const double* __restrict__ XT, long ldp, long n, int dpad,
                                                               CovParams cp0, int ncov, double inv_sn2, double sn2,
@@ -317,15 +331,46 @@ __global__ __launch_bounds__(256, 2) void hadamard_ard_kernel(const double* __re
     const int CH = dpad < 64 ? dpad : 64;            // coordinates per staged chunk
     double* xr = smx;
     double* xc = smx + CH * STP;
-    auto stage = [&](int k0, int kk) {                // coordinates k0 .. k0 + kk of both point sets, centred
-        const int nv = kk * 64;                       // double2 pieces: per coordinate 32 of the rows, 32 of the columns
-        for (int v = t; v < nv; v += 256) {
-            const int k = v >> 6, pr = v & 63, side = pr >> 5, pair = pr & 31;
-            const double m_ = mu[k0 + k];
-            const double2_t g = *(const double2_t*)(XT + (long)(k0 + k) * ldp + (side ? c0 : r0) + 2 * pair);
-            *(double2_t*)((side ? xc : xr) + k * STP + 2 * pair) = double2_t{g[0] - m_, g[1] - m_};
+    // coordinates k0 .. k0 + kk of both point sets, centred.  kk / 4 double2 pieces per thread (piece i: coordinate wave + 4 i,
+    // 32 lanes the rows' points, 32 the columns'); ALL pieces of a chunk are in flight before the first is used (one round
+    // trip per chunk, not one per piece), the means come through the scalar unit (the coordinate index is wave-uniform)
+    const int spr = lane & 31, sside = lane >> 5;
+    const int wvu = __builtin_amdgcn_readfirstlane(wave);
+    const double* sgp = XT + (sside ? c0 : r0) + 2 * spr + (long)wvu * ldp;
+    double* slp = (sside ? xc : xr) + 2 * spr + wvu * STP;
+    const double* mup = mu + wvu;
+    auto stage = [&](int k0, int kk) {                // kk is a multiple of 16: 4, 8, 12 or 16 pieces, branch-free inside
+        const double* gp = sgp + (long)k0 * ldp;
+        switch (kk >> 4) {
+            case 1: stage_pieces<4>(gp, ldp, mup + k0, slp); break;
+            case 2: stage_pieces<8>(gp, ldp, mup + k0, slp); break;
+            case 3: stage_pieces<12>(gp, ldp, mup + k0, slp); break;
+            default: stage_pieces<16>(gp, ldp, mup + k0, slp); break;
         }
     };
+    // the tile of B^-1, alpha, the per-point weights and norms: requested NOW, used after the Gram products
+    double bvv[4][4];
+    double ar[4], wr[4], nr[4], ac[4], wc[4], nc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bvv[a][q] = Binv[(r0 + 16 * wave + 4 * a + l4) * ldb + c0 + 16 * q + l15];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long rr = r0 + 16 * wave + 4 * a + l4, rl = rr < n ? rr : n - 1;      // loads without a branch: clamped index,
+        const double av = alpha[rl], wvv = wv ? wv[rl] : inv_sn2;                      // the value selected afterwards
+        ar[a] = rr < n ? av : 0.0;
+        wr[a] = wv ? (rr < n ? wvv : 0.0) : inv_sn2;
+        nr[a] = nrm[rr];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long cc = c0 + 16 * q + l15, cl = cc < n ? cc : n - 1;
+        const double av = alpha[cl], wvv = wv ? wv[cl] : 1.0;
+        ac[q] = cc < n ? av : 0.0;
+        wc[q] = wv ? (cc < n ? wvv : 0.0) : 1.0;
+        nc[q] = nrm[cc];
+    }
     // ---- Gram products: S(row, col) = sum_k xr(k, row) xc(k, col) ------------------------------------------------------
     double4_t acc[4];
 #pragma unroll
@@ -335,38 +380,35 @@ __global__ __launch_bounds__(256, 2) void hadamard_ard_kernel(const double* __re
         if (k0) __syncthreads();
         stage(k0, kk);
         __syncthreads();
-        for (int ks = 0; ks < kk; ks += 4) {
-            const double a_ = xr[(ks + l4) * STP + 16 * wave + l15];
-            const double* bp = xc + (ks + l4) * STP + l15;
+        // fragments of step ks + 4 are read before the MFMAs of step ks are issued
+        const double* ap = xr + l4 * STP + 16 * wave + l15;
+        const double* bp = xc + l4 * STP + l15;
+        double fa0 = ap[0], fb0[4] = {bp[0], bp[16], bp[32], bp[48]};
+        for (int ks = 0; ks < kk; ks += 8) {
+            const double* a1 = ap + (ks + 4) * STP;
+            const double* b1 = bp + (ks + 4) * STP;
+            const double fa1 = a1[0], fb1[4] = {b1[0], b1[16], b1[32], b1[48]};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bp[16 * q], acc[q], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb0[q], acc[q], 0, 0, 0);
+            if (ks + 8 < kk) {
+                const double* a2 = ap + (ks + 8) * STP;
+                const double* b2 = bp + (ks + 8) * STP;
+                fa0 = a2[0]; fb0[0] = b2[0]; fb0[1] = b2[16]; fb0[2] = b2[32]; fb0[3] = b2[48];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb1[q], acc[q], 0, 0, 0);
         }
     }
     // ---- element-wise: Q, K, the weights of the per-coordinate sums ------------------------------------------------------
     double w[4][4];
     double g1 = 0.0, g2 = 0.0, tq = 0.0;
-    double ar[4], wr[4], nr[4], ac[4], wc[4], nc[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const long rr = r0 + 16 * wave + 4 * a + l4;
-        ar[a] = rr < n ? alpha[rr] : 0.0;
-        wr[a] = wv ? (rr < n ? wv[rr] : 0.0) : inv_sn2;
-        nr[a] = nrm[rr];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const long cc = c0 + 16 * q + l15;
-        ac[q] = cc < n ? alpha[cc] : 0.0;
-        wc[q] = wv ? (cc < n ? wv[cc] : 0.0) : 1.0;
-        nc[q] = nrm[cc];
-    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const long rr = r0 + 16 * wave + 4 * a + l4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long cc = c0 + 16 * q + l15;
-            const double bv = Binv[rr * ldb + cc];
+            const double bv = bvv[a][q];
             double wt = (cc > rr) ? 2.0 : (cc == rr ? 1.0 : 0.0);     // symmetric: count the mirror
             if (rr >= n || cc >= n) wt = 0.0;                          // padding
             const double qv = bv * (wr[a] * wc[q]) - ar[a] * ac[q];
@@ -400,6 +442,10 @@ __global__ __launch_bounds__(256, 2) void hadamard_ard_kernel(const double* __re
 #pragma unroll
     for (int a = 0; a < 4; ++a) Rr[a] = row16_sum((w[a][0] + w[a][1]) + (w[a][2] + w[a][3]));   // full row sums
     double* out = partial + (long)blockIdx.x * (long)(ncov + 1);
+    {                                                 // the three scalar sums: per wave now, met behind the barrier of the loop below
+        const double s1 = wave_sum(g1), s2 = wave_sum(tq), s3 = wave_sum(g2);
+        if (lane == 0) { red16[4 * wave] = s1; red16[4 * wave + 1] = s2; red16[4 * wave + 2] = s3; }
+    }
     for (int k0 = 0; k0 < dpad; k0 += 64) {
         const int kk = (dpad - k0) < 64 ? (dpad - k0) : 64;
         if (dpad > 64) {                              // more than one chunk: the Gram pass left the LAST one in LDS
@@ -442,12 +488,10 @@ __global__ __launch_bounds__(256, 2) void hadamard_ard_kernel(const double* __re
         if (t < kk && k0 + t < cp.D)
             out[k0 + t] = ((ardA[0][t] + ardB[0][t]) + (ardA[1][t] + ardB[1][t])) + ((ardA[2][t] + ardB[2][t]) + (ardA[3][t] + ardB[3][t]));
     }
-    double v4[4] = {g1, tq, g2, 0.0};
-    block_sum4(v4, red16);
-    if (t == 0) {
-        out[cp.D] = v4[0];
-        if (KIND == 6) out[cp.D + 1] = v4[2];
-        out[ncov] = v4[1];
+    if (t == 0) {                                     // (the last barrier of the loop above made red16 visible)
+        out[cp.D] = (red16[0] + red16[4]) + (red16[8] + red16[12]);
+        if (KIND == 6) out[cp.D + 1] = (red16[2] + red16[6]) + (red16[10] + red16[14]);
+        out[ncov] = (red16[1] + red16[5]) + (red16[9] + red16[13]);
     }
 }
 
