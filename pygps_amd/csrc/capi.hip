@@ -176,6 +176,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "ep_wait_kernel")) { c->ep_wait_kernel = value; return PGP_OK; }
     if (!strcmp(name, "ep_sigma_under")) { c->ep_sigma_under = value; return PGP_OK; }
     if (!strcmp(name, "ep_recompute")) { c->ep_recompute = value; return PGP_OK; }
+    if (!strcmp(name, "ep_final_rebuild")) { c->ep_final_rebuild = value; return PGP_OK; }
     if (!strcmp(name, "ep_block")) { c->ep_block = value; return PGP_OK; }
     if (!strcmp(name, "xcd_max_k")) { c->xcd_max_k = value; return PGP_OK; }
     if (!strcmp(name, "xcd_min_tiles")) { c->xcd_min_tiles = value; return PGP_OK; }

@@ -68,6 +68,9 @@ struct pgp_ctx {
     int ep_alpha_direct = 1;            // EP: alpha = tnu - ttau o mu (identity, no solve); 0 = the reference's two triangular solves
     int ep_recompute = 0;               // EP: 1 = rebuild Sigma, mu, L after EVERY sweep like the reference (inf.py:772); 0 = carry them by exact
                                         // identities and rebuild once, from the converged site parameters
+    int ep_final_rebuild = 0;           // EP, carried posterior: 1 = _epComputeParams once more on the converged site parameters and everything
+                                        // returned comes from it (round 3); 0 = alpha / nlZ / gradients from the carried Sigma, mu, log det B
+                                        // and ONE plain Cholesky for post.L
     int ep_sigma_under = 1;             // EP: Sigma = K - V'V'^T accumulated under the sweep of the parameter recomputation (ep_fused 2)
     int ep_wait_kernel = 1;             // EP block sweep: the bulk stream waits for the chain in a one-wave kernel of its own (1) or inside
                                         // every workgroup of U = strip W (0: GemmArgs::wait_flag; 128 spinning workgroups cost 2.5 % of a fit)

@@ -1040,6 +1040,25 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     return PGP_OK;
 }
 
+// L = chol(I + sW sW' o K) of the given site parameters into w.F -- and nothing else (no V, no Sigma, no mu): what is left to
+// do when Sigma, mu and log det B were carried through the sweeps (ep_fit_core, track) and only post.L is missing.
+static int ep_factor_only(pgp_ctx* c, EpWork& w, const std::vector<double>& ttau) {
+    hipStream_t st = c->st;
+    const long n = w.n, np = w.np;
+    std::vector<double> s_h(np, 0.0);
+    for (long i = 0; i < n; ++i) s_h[i] = sqrt(ttau[i]);
+    HIP_TRY(hipMemcpyAsync(w.s_d, s_h.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
+    hipLaunchKernelGGL(ep_build_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Kd, np, w.s_d, w.F, w.ldf,
+                       (double*)nullptr, 0);
+    CHK(potrf_blocked(c, w.F, w.ldf, np, np));
+    int info = 0;
+    HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));               // (s_h goes out of scope)
+    if (info != 0) return info > (int)n ? (int)n : info;
+    return PGP_OK;
+}
+
 namespace {
 __global__ void probit_hazard_test_kernel(const double* __restrict__ z, double* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1346,9 +1365,20 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
         HIP_TRY(hipMemcpyAsync(ttau.data(), w.ttau_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(tnu.data(), w.tnu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // the posterior of the converged site parameters
-        HIP_TRY(hipStreamSynchronize(st));
-        stamp("params rebuilt from the converged sites", 2);
+        if (c->ep_final_rebuild) {
+            rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);            // the posterior rebuilt from the converged site parameters
+            HIP_TRY(hipStreamSynchronize(st));
+            stamp("params rebuilt from the converged sites", 2);
+        } else {
+            // Sigma, mu, log det B and with them nlZ are CURRENT (carried by exact identities; nlZ above is the value the
+            // convergence test just used): alpha, the gradients and the mean derivatives follow from them as they do after a
+            // rebuild.  Only post.L is missing: one plain Cholesky of I + sW sW' o K (N^3 / 3 flops instead of the 8 N^3 / 3 of
+            // _epComputeParams).  The carried Sigma is current in its lower triangle: mirror it for the gradient's kernels.
+            HIP_TRY(hipMemcpyAsync(mu.data(), w.mu_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (c->ep_sym) hipLaunchKernelGGL(ep_mirror_kernel, dim3((unsigned)(np / 64), (unsigned)(np / 64)), dim3(256), 0, st, w.Sig, np);
+            rc = ep_factor_only(c, w, ttau);
+            stamp("factor of the converged sites", 2);
+        }
         if (rc != PGP_OK) return rc;
     }
     if (sweeps_out) *sweeps_out = sweep;
@@ -1369,7 +1399,8 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
     for (long i = 0; i < n; ++i) b[i] *= sW[i];
     HIP_TRY(hipMemsetAsync(w.rhs, 0, (size_t)128 * np * sizeof(double), st));
     HIP_TRY(hipMemcpyAsync(w.rhs, b.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
-    if (c->ep_fused)                // the fused parameter recomputations do not produce the leaf inverses of the blocked solve
+    // (the fused parameter recomputations and the factor-only last step do not produce the leaf inverses of the blocked solve)
+    if (c->ep_fused || (track && sweep > 0 && !c->ep_final_rebuild))
         EP_TRY(leaf_inv_launch(w.F, ldf, w.Wd, 128, 128L * 128L, (int)(np / 128), st));
     EP_TRY(solve_lower_multi(c, w.F, ldf, w.Wd, w.rhs, np, np, 128, false));
     EP_TRY(solve_lower_multi(c, w.F, ldf, w.Wd, w.rhs, np, np, 128, true));
@@ -1391,12 +1422,12 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
             // R = sW sW' o B^-1 stays in the workspace: the caller hands the derivative matrices in one at a time
             hipLaunchKernelGGL(ep_r_from_sigma_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Sig, np, np,
                                w.ttau_d, c->Binv, np);
-        } else if (c->ep_fused == 1 && w.Ed) {
-            // Ed holds diag(sW) L^-T of the final parameters: (diag(sW) E)(diag(sW) E)' = sW sW' o B^-1 in one product
+        } else if (c->ep_fused == 1 && w.Ed && !(track && sweep > 0 && !c->ep_final_rebuild)) {
+            // Ed holds diag(sW) L^-T of the final parameters (not after a factor-only last step: Sigma is what is current then): (diag(sW) E)(diag(sW) E)' = sW sW' o B^-1 in one product
             EP_TRY(eet_lower(c, w.Ed, np, c->Binv, np, np));
             EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
                                           c->scal + 8, st, nullptr));
-        } else if (c->ep_r_direct) {
+        } else if (c->ep_r_direct || c->ep_fused == 1) {
             hipLaunchKernelGGL(ep_r_from_sigma_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Sig, np, np,
                                w.ttau_d, c->Binv, np);
             EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,

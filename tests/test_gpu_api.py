@@ -340,18 +340,19 @@ def test_G8_ep_classification_demo_and_synthetic(lib):
 
 
 @pytest.mark.parametrize("opts", [dict(ep_fused=0), dict(ep_fused=1), dict(ep_sym=0), dict(ep_alpha_direct=0, ep_r_direct=0),
-                                  dict(ep_fused=0, ep_alpha_direct=0, ep_r_direct=0, ep_sym=0), dict(ep_sigma_under=0), dict(ep_recompute=1), dict(ep_block=0), dict(ep_wait_kernel=0)])
+                                  dict(ep_fused=0, ep_alpha_direct=0, ep_r_direct=0, ep_sym=0), dict(ep_sigma_under=0), dict(ep_recompute=1), dict(ep_block=0), dict(ep_wait_kernel=0), dict(ep_final_rebuild=1)])
 def test_ep_variants_agree_with_the_reference(lib, opts):
     """Every kept variant of the EP path -- parameter recomputation by the blocked solve / through the fused inverse /
     as right-hand-side rows of the sweep (default), full or lower-triangle Sigma, alpha and sW sW' o B^-1 by the
     reference's solves or by the identities, Sigma = K - V'V' as one product or under the sweep, the posterior rebuilt after every sweep (the reference's
-    schedule) or carried by exact identities and rebuilt once at the end (default), the reference's per-site
+    schedule) or carried by exact identities (default: alpha, nlZ, gradients from the carried state and one plain Cholesky for
+    post.L; ep_final_rebuild=1: rebuilt once at the end, round 3), the reference's per-site
     update of Sigma or the block sweep (default) -- against the reference's own numbers (G8ii)."""
     import pygps_amd as pyGPs
     from pygps_amd import _lib
     from conftest import synth_cls
     ctx = _lib.ctx()
-    defaults = dict(ep_fused=2, ep_sym=1, ep_alpha_direct=1, ep_r_direct=1, ep_block=1, ep_sigma_under=1, ep_recompute=0, ep_wait_kernel=1)
+    defaults = dict(ep_fused=2, ep_sym=1, ep_alpha_direct=1, ep_r_direct=1, ep_block=1, ep_sigma_under=1, ep_recompute=0, ep_wait_kernel=1, ep_final_rebuild=0)
     try:
         for k, v in opts.items():
             _lib.check(lib.pgp_set_option(ctx, k.encode(), v))
