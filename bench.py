@@ -707,16 +707,26 @@ def main():
         fact_ms = float(np.median([t["potrf"] + t["solve"] + t["trtri"] + t["lauum"] for t in lat_stage]))
         traffic, tsrc = None, None
         import glob
+        import hashlib
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_f64_hbm_traffic.json")))
-        if cands:                                        # the newest tracked PMC measurement, with the commit it was taken on
+        if cands:            # the newest tracked PMC measurement -- only if it was taken on THIS kernel (fingerprint of its sources)
             try:
                 tj = json.load(open(cands[-1]))
-                traffic = tj.get("bytes_per_launch")
-                tsrc = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) of this command line, measured on "
-                        "commit %s -- a static file, not re-measured in this run" % (os.path.basename(cands[-1]),
-                                                                                     tj.get("measured_on_commit", "of round 2")))
-            except Exception:
-                traffic = None
+                hh = hashlib.sha256()
+                for fsrc in ("gemm_f64.hip", "gemm_tile.h", "common.h"):
+                    hh.update(open(os.path.join(ROOT, "pygps_amd", "csrc", fsrc), "rb").read())
+                cur = hh.hexdigest()[:16]
+                if tj.get("kernel_source_sha16") == cur:
+                    traffic = tj.get("bytes_per_launch")
+                    tsrc = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) of this command line, measured on "
+                            "commit %s, kernel sources %s = the ones of this run -- a static file, not re-measured in this run"
+                            % (os.path.basename(cands[-1]), tj.get("measured_on_commit"), cur))
+                else:
+                    tsrc = ("STALE: profiles/%s was measured on kernel sources %s (commit %s), this run's gemm_f64 sources are %s -- "
+                            "traffic withheld; re-run tools/make_profiles.sh" % (os.path.basename(cands[-1]), tj.get("kernel_source_sha16"),
+                                                                              tj.get("measured_on_commit"), cur))
+            except Exception as e:
+                tsrc = "traffic file unreadable: %r" % (e,)
         roof = {"kernel": "gemm_f64_kernel<128,128,false,false,true,true> (fp64 MFMA, LDS-DMA operand staging, yield poll: every trailing update of "
                           "the Cholesky sweep incl. the fused inverse, and the E E^T products)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s",

@@ -93,6 +93,10 @@ int pgp_init(int device, pgp_ctx** ctx_out) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         HIP_TRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, hi));   // panel chain = critical path
+        // EP's resident sweep kernel (st2) and the bulk launches (st) must run CONCURRENTLY: two streams of different priority
+        // never share a hardware queue.  A device without a priority range gives no such guarantee: the reference's per-site
+        // sweep then (slow, but it cannot wait for a kernel queued behind itself)
+        if (lo == hi) c->ep_block = 0;
     }
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     memset(c->last_ms, 0, sizeof(c->last_ms));
@@ -937,6 +941,7 @@ int ensure_workspace(pgp_ctx* c, long np) {
     c->W = c->T = c->Binv = c->inv16 = c->m_dev = c->rvec = c->zvec = nullptr;
     if (c->in_host) { (void)hipHostFree(c->in_host); c->in_host = nullptr; c->in_cap = 0; }
     c->ws_np = 0;          // committed again only once EVERY allocation below has succeeded
+    c->dense_ready = false;
     const size_t nn = (size_t)np * np * sizeof(double);
     HIP_TRY(hipMalloc((void**)&c->W, nn));
     HIP_TRY(hipMemsetAsync(c->W, 0, nn, c->st));
@@ -1035,6 +1040,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     if (want < 1 || want > 3) return -11;
     if (ncov < 0 || 8 + ncov + 1 > RES_INFO) return -4;
     HIP_TRY(hipSetDevice(c->device));
+    c->dense_ready = false;                          // the workspace (B^-1, alpha) is about to be rewritten
     const long n = c->n, d = c->d, np = c->np;
     const bool fused = want >= 3 && c->fused_inverse;
     const long ldf = c->ldf;                         // factor buffer = factor rows + rhs rows; the inverse rows are scratch

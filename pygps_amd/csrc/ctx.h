@@ -94,6 +94,8 @@ struct pgp_ctx {
     double *W = nullptr, *T = nullptr, *Binv = nullptr, *inv16 = nullptr, *alpha_dev = nullptr, *m_dev = nullptr,
            *rvec = nullptr, *zvec = nullptr, *partial = nullptr, *scal = nullptr;
     long partial_cap = 0;
+    bool dense_ready = false;           // the workspace holds the Q of a dense fit with want = 3 (pgp_dense_grad_term sums against it);
+    long dense_n = 0;                   // cleared by every other entry point that rewrites B^-1 / alpha
     int* info_dev = nullptr;
     // results of one fit, gathered on the device and fetched with ONE copy into pinned host memory (three separate copies
     // into pageable memory cost ~270 us per N = 8192 fit: each is staged and synchronised by the runtime)

@@ -19,12 +19,13 @@ namespace {
 // padding; only entries on or below the diagonal are written (the strict upper part of a factor buffer stays zero)
 __global__ __launch_bounds__(256) void dense_to_factor_kernel(const double* __restrict__ Kd, long n, double inv_sn2,
                                                               double* __restrict__ F, long ld, long np) {
-    const long j = blockIdx.y;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= np || i < j) return;
-    double v = (i == j) ? 1.0 : 0.0;
-    if (i < n && j < n) v = fma(Kd[i + j * n], inv_sn2, v);
-    F[i + j * ld] = v;
+    if (i >= np) return;
+    for (long j = blockIdx.y; j <= i; j += gridDim.y) {          // (grid.y is capped at 65535: columns by stride)
+        double v = (i == j) ? 1.0 : 0.0;
+        if (i < n && j < n) v = fma(Kd[i + j * n], inv_sn2, v);
+        F[i + j * ld] = v;
+    }
 }
 
 // partial[j] = sum_{i >= j} w_ij (Binv(i,j) inv_sn2 - a_i a_j) D(i,j),  w = 1 on the diagonal, 2 below (symmetric matrices)
@@ -80,6 +81,7 @@ int pgp_exact_fit_dense(pgp_ctx* c, const double* K, int64_t n, const double* r,
     if (!r) return -4;
     if (want < 1 || want > 3) return -6;
     HIP_TRY(hipSetDevice(c->device));
+    c->dense_ready = false;
     const long np = round_up(n, 128), ldf = np + 128;
     const bool fused = want >= 3;
     CHK(ensure_workspace(c, np));
@@ -105,7 +107,7 @@ int pgp_exact_fit_dense(pgp_ctx* c, const double* K, int64_t n, const double* r,
     HIP_TRY(hipMemsetAsync(zero, 0, np * sizeof(double), st));
     HIP_TRY(hipMemsetAsync(c->zvec, 0, np * sizeof(double), st));
     HIP_TRY(hipMemcpyAsync(c->zvec, r, n * sizeof(double), hipMemcpyHostToDevice, st));      // zvec doubles as the upload of r
-    hipLaunchKernelGGL(dense_to_factor_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, Kd, n, 1.0 / sn2, F,
+    hipLaunchKernelGGL(dense_to_factor_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)std::min<long>(np, 65535)), dim3(256), 0, st, Kd, n, 1.0 / sn2, F,
                        ldf, np);
     CHK(aug_rhs_launch(c->zvec, zero, n, F, ldf, np, c->rvec, st));
     if (fused) { c->eet_out = c->Binv; c->eet_ld = np; }
@@ -151,6 +153,7 @@ int pgp_exact_fit_dense(pgp_ctx* c, const double* K, int64_t n, const double* r,
         *factor_out = hg.release();
     }
     fguard.scrub = false;
+    if (want >= 3) { c->dense_ready = true; c->dense_n = n; }
     return PGP_OK;
 }
 
@@ -161,6 +164,9 @@ int pgp_dense_grad_term(pgp_ctx* c, const double* dK, int64_t n, double log_sn, 
     if (!dK) return -2;
     if (n <= 0 || round_up(n, 128) != c->ws_np) return -3;
     if (!out) return -5;
+    // the Q this term is summed against is what the LAST dense fit with want = 3 left in the workspace: any other fit on this
+    // context since then (or none at all) would give a plausible but wrong number
+    if (!c->dense_ready || c->dense_n != n) return -6;
     HIP_TRY(hipSetDevice(c->device));
     const long np = c->ws_np;
     hipStream_t st = c->st;

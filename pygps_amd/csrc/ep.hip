@@ -868,12 +868,13 @@ __global__ __launch_bounds__(256) void ep_build_kernel(const double* __restrict_
                                                        const double* __restrict__ s, double* __restrict__ F, long ldf,
                                                        double* __restrict__ Y, int colscale) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long j = blockIdx.y;
     if (i >= np) return;
-    const double k = K[i + j * np];
     const double si = s[i];
-    if (Y) Y[i + j * np] = (colscale ? s[j] : si) * k;        // colscale: Y = K diag(s) (= (diag(s) K)' : the rhs ROWS of the sweep)
-    if (i >= j) F[i + j * ldf] = (i == j ? 1.0 : 0.0) + si * s[j] * k;
+    for (long j = blockIdx.y; j < np; j += gridDim.y) {      // (grid.y is capped at 65535: columns by stride)
+        const double k = K[i + j * np];
+        if (Y) Y[i + j * np] = (colscale ? s[j] : si) * k;    // colscale: Y = K diag(s) (= (diag(s) K)' : the rhs ROWS of the sweep)
+        if (i >= j) F[i + j * ldf] = (i == j ? 1.0 : 0.0) + si * s[j] * k;
+    }
 }
 
 // Per-site terms of the EP marginal likelihood (inf.py:184-188) and, optionally, d lZ_i / d mu (inf.py:788-790) on the device:
@@ -914,17 +915,16 @@ __global__ __launch_bounds__(256) void ep_site_terms_kernel(long n, const double
 __global__ __launch_bounds__(256) void ep_r_from_sigma_kernel(const double* __restrict__ Sig, long ld, long np,
                                                               const double* __restrict__ ttau, double* __restrict__ R, long ldr) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long j = blockIdx.y;
-    if (i >= np || i < j) return;
+    if (i >= np) return;
     const double ti = ttau[i];
-    R[i + j * ldr] = (i == j ? ti : 0.0) - ti * ttau[j] * Sig[i + j * ld];
+    for (long j = blockIdx.y; j <= i; j += gridDim.y) R[i + j * ldr] = (i == j ? ti : 0.0) - ti * ttau[j] * Sig[i + j * ld];
 }
 
 // E'(k, m) = s_k E(k, m) on the block-upper part of E = L^-T (everything the sweep wrote: k < 128 (m / 128 + 1))
-__global__ __launch_bounds__(256) void ep_rowscale_upper_kernel(double* __restrict__ E, long lde, const double* __restrict__ s) {
-    const long m = blockIdx.y;
+__global__ __launch_bounds__(256) void ep_rowscale_upper_kernel(double* __restrict__ E, long lde, const double* __restrict__ s, long np) {
     const long k = (long)blockIdx.x * 256 + threadIdx.x;
-    if (k < (m / 128 + 1) * 128) E[k + m * lde] *= s[k];
+    for (long m = blockIdx.y; m < np; m += gridDim.y)
+        if (k < (m / 128 + 1) * 128) E[k + m * lde] *= s[k];
 }
 
 struct EpWork {
@@ -956,7 +956,7 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     const bool fusedp = c->ep_fused == 1 && w.Ed;
     const bool rhsp = c->ep_fused == 2;             // V' = (K diag(sW)) L^-T as dense right-hand-side ROWS of the sweep itself
     bool sigma_done = false;
-    hipLaunchKernelGGL(ep_build_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Kd, np,
+    hipLaunchKernelGGL(ep_build_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)std::min<long>(np, 65535)), dim3(256), 0, st, w.Kd, np,
                        w.s_d, w.F, w.ldf, fusedp ? nullptr : w.Vd, rhsp ? 1 : 0);
     // fused path: the sweep also yields E = L^-T, so V' = (K diag(sW)) E is ONE clipped MFMA product (no blocked multi-rhs
     // solve, no leaf inverses) and Sigma = K - V'V'^T an NT product in the LDS-DMA form
@@ -987,7 +987,7 @@ static int ep_compute_params(pgp_ctx* c, EpWork& w, const std::vector<double>& y
     HIP_TRY(hipStreamSynchronize(st));
     if (info != 0) return info > (int)n ? (int)n : info;
     if (fusedp) {
-        hipLaunchKernelGGL(ep_rowscale_upper_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Ed, np, w.s_d);
+        hipLaunchKernelGGL(ep_rowscale_upper_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)std::min<long>(np, 65535)), dim3(256), 0, st, w.Ed, np, w.s_d, np);
         GemmArgs g{};                                                                   // V'(n, m) = sum_{k <= m} K(n, k) sW_k E(k, m)
         g.A = w.Kd; g.lda = np; g.a_kc = 0;
         g.B = w.Ed; g.ldb = np; g.b_kc = 1;
@@ -1049,7 +1049,7 @@ static int ep_factor_only(pgp_ctx* c, EpWork& w, const std::vector<double>& ttau
     for (long i = 0; i < n; ++i) s_h[i] = sqrt(ttau[i]);
     HIP_TRY(hipMemcpyAsync(w.s_d, s_h.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
-    hipLaunchKernelGGL(ep_build_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Kd, np, w.s_d, w.F, w.ldf,
+    hipLaunchKernelGGL(ep_build_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)std::min<long>(np, 65535)), dim3(256), 0, st, w.Kd, np, w.s_d, w.F, w.ldf,
                        (double*)nullptr, 0);
     CHK(potrf_blocked(c, w.F, w.ldf, np, np));
     int info = 0;
@@ -1094,6 +1094,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
     if (!covhyp && !Kdense) return -3;
     if (!ttau_io || !tnu_io) return -12;
     HIP_TRY(hipSetDevice(c->device));
+    c->dense_ready = false;                          // the workspace (B^-1, alpha) is about to be rewritten
     hipStream_t st = c->st;
     const long n = c->n, d = c->d, np = c->np, ldf = c->ldf;
     const bool dense = Kdense != nullptr;
@@ -1242,6 +1243,18 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
                                    c->y_dev, w.ttau_d, w.tnu_d, w.Wb, w.gb, w.ldb, yfl, (long long*)nullptr, w.S, w.tile, w.flags,
                                    w.chain_total, w.prep_total, w.strip_total, swg);
             HIP_TRY(hipEventRecord(c->ep_ev[1], sa));
+            // from here on the resident kernel is spinning on device counters: an early return (a failed launch on the bulk stream)
+            // must stop it and wait for it before the scratch it reads and writes goes back to the pool
+            struct ChainGuard {
+                unsigned* err; hipStream_t sa, sb; bool armed = true;
+                ~ChainGuard() {
+                    if (!armed) return;
+                    const unsigned one = 1u;
+                    (void)hipMemcpy(err, &one, sizeof(one), hipMemcpyHostToDevice);   // every device-side wait gives up at once
+                    (void)hipStreamSynchronize(sa);
+                    (void)hipStreamSynchronize(sb);
+                }
+            } chain_guard{w.flags + EPF_ERR, sa, sb};
             const unsigned cbase = w.chain_total;
             w.chain_total += (unsigned)nbl;
             w.prep_total += 36u * (unsigned)nbl;
@@ -1300,6 +1313,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
             }
             HIP_TRY(hipStreamWaitEvent(st, c->ep_ev[1], 0));
             if (hipGetLastError() != hipSuccess) return PGP_ERR_HIP;
+            chain_guard.armed = false;                 // everything of this sweep is queued: the ordinary joins below take over
             if (ep_timing) {
                 long long sp[16];
                 HIP_TRY(hipMemcpyAsync(sp, w.gb + 2 * EPB, sizeof(sp), hipMemcpyDeviceToHost, st));
@@ -1420,7 +1434,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
         // F = alpha alpha' - sW sW' o B^-1 ; dnlZ.cov[j] = -sum(F o dK_j)/2 = sum((sW sW' o B^-1 - alpha alpha') o dK_j)/2
         if (dense) {
             // R = sW sW' o B^-1 stays in the workspace: the caller hands the derivative matrices in one at a time
-            hipLaunchKernelGGL(ep_r_from_sigma_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Sig, np, np,
+            hipLaunchKernelGGL(ep_r_from_sigma_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)std::min<long>(np, 65535)), dim3(256), 0, st, w.Sig, np, np,
                                w.ttau_d, c->Binv, np);
         } else if (c->ep_fused == 1 && w.Ed && !(track && sweep > 0 && !c->ep_final_rebuild)) {
             // Ed holds diag(sW) L^-T of the final parameters (not after a factor-only last step: Sigma is what is current then): (diag(sW) E)(diag(sW) E)' = sW sW' o B^-1 in one product
@@ -1428,7 +1442,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
             EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
                                           c->scal + 8, st, nullptr));
         } else if (c->ep_r_direct || c->ep_fused == 1) {
-            hipLaunchKernelGGL(ep_r_from_sigma_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, w.Sig, np, np,
+            hipLaunchKernelGGL(ep_r_from_sigma_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)std::min<long>(np, 65535)), dim3(256), 0, st, w.Sig, np, np,
                                w.ttau_d, c->Binv, np);
             EP_TRY(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, 1.0, c->Binv, np, c->alpha_dev, c->partial,
                                           c->scal + 8, st, nullptr));
@@ -1483,6 +1497,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
         HIP_TRY(hipStreamSynchronize(st));
         fguard.scrub = false;                         // a finished factor honours the pool contract (zeros above the diagonal)
     }
+    if (dense && want >= 3) { c->dense_ready = true; c->dense_n = n; }
     return PGP_OK;
 #undef EP_TRY
 }

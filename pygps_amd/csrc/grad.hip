@@ -789,9 +789,10 @@ __global__ __launch_bounds__(256) void row_scale_kernel(double* __restrict__ A, 
 
 // E(i,j) = (i == j) for j >= i (the upper trapezoid is the only part of the E region a fit ever dirties)
 __global__ __launch_bounds__(256) void identity_upper_kernel(double* __restrict__ E, long lde, long np) {
-    const long j = blockIdx.y;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i <= j && i < np) E[i + j * lde] = (i == j) ? 1.0 : 0.0;
+    if (i >= np) return;
+    for (long j = blockIdx.y; j < np; j += gridDim.y)
+        if (i <= j) E[i + j * lde] = (i == j) ? 1.0 : 0.0;
 }
 
 // partial[c*np + i] = sum_{k in chunk c, k >= i} E(i,k) z[k]   (E column-major: coalesced over i)
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(256) void upper_matvec_reduce_kernel(const double* 
 }  // namespace
 
 int identity_upper_launch(double* E, long lde, long np, hipStream_t st) {
-    hipLaunchKernelGGL(identity_upper_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, st, E, lde,
+    hipLaunchKernelGGL(identity_upper_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)(np < 65535 ? np : 65535)), dim3(256), 0, st, E, lde,
                        np);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }

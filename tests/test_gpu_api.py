@@ -598,3 +598,46 @@ def test_cfg4_as_written_eight_ranks_one_restart_each(tmp_path):
     assert np.max(np.abs(f - g["run_f"]) / np.abs(g["run_f"])) < 1e-5, (f, g["run_f"])
     near = lambda v: set(np.flatnonzero(v < v.min() + 1e-6 * abs(v.min())).tolist())
     assert near(f) == near(g["run_f"]) == {0, 2, 6} and int(np.argmin(f)) in near(g["run_f"])
+
+
+@pytest.mark.gpu
+def test_dense_gradient_term_needs_the_dense_fit_right_before_it(lib):
+    """pgp_dense_grad_term sums against the Q that the LAST dense fit with want = 3 left in the context's workspace; any other
+    fit in between (or none) must be an error, not a plausible number."""
+    import ctypes as C
+    from pygps_amd import _lib
+    rng = np.random.RandomState(0)
+    n, d = 200, 3
+    x = rng.randn(n, d)
+    y = rng.randn(n)
+    A = rng.randn(n, n)
+    K = A @ A.T / n + np.eye(n)
+    dK = np.ascontiguousarray(K * 0.5)
+    h = C.c_void_p()
+    assert lib.pgp_init(0, C.byref(h)) == 0
+    try:
+        g = np.zeros(1)
+        assert lib.pgp_set_data(h, _lib.ptr(x), n, d, _lib.ptr(y)) == 0
+        assert lib.pgp_dense_grad_term(h, _lib.ptr(dK), n, float(np.log(0.1)), _lib.ptr(g)) < 0         # no dense fit yet
+        alpha, nlZ, gl = np.zeros(n), np.zeros(1), np.zeros(1)
+        Kc, r = np.ascontiguousarray(K), np.ascontiguousarray(y)
+        assert lib.pgp_exact_fit_dense(h, _lib.ptr(Kc), n, _lib.ptr(r), float(np.log(0.1)), 3, _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(gl), None) == 0
+        assert lib.pgp_dense_grad_term(h, _lib.ptr(dK), n, float(np.log(0.1)), _lib.ptr(g)) == 0
+        good = g[0]
+        # the reference value: 1/2 sum (B^-1 / sn2 - alpha alpha') o dK
+        sn2 = 0.01
+        Binv = np.linalg.inv(K / sn2 + np.eye(n))
+        want = 0.5 * np.sum((Binv / sn2 - np.outer(alpha, alpha)) * dK)
+        assert abs(good - want) < 1e-8 * abs(want)
+        # a value-only dense fit rewrites alpha but leaves no Q: the term must be refused afterwards
+        assert lib.pgp_exact_fit_dense(h, _lib.ptr(Kc), n, _lib.ptr(r), float(np.log(0.1)), 2, _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(gl), None) == 0
+        assert lib.pgp_dense_grad_term(h, _lib.ptr(dK), n, float(np.log(0.1)), _lib.ptr(g)) == -6
+        # ... and so after an ordinary fit of the same size on this context
+        assert lib.pgp_exact_fit_dense(h, _lib.ptr(Kc), n, _lib.ptr(r), float(np.log(0.1)), 3, _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(gl), None) == 0
+        hyp, m, dm = np.array([0.0, 0.0]), np.zeros(n), np.ones((1, n))
+        gv = np.zeros(4)
+        assert lib.pgp_exact_fit(h, _lib.COV_RBF, _lib.ptr(hyp), 2, 0, 0, float(np.log(0.1)), _lib.ptr(m), _lib.ptr(dm), 1, 3,
+                                 _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(gv), None) == 0
+        assert lib.pgp_dense_grad_term(h, _lib.ptr(dK), n, float(np.log(0.1)), _lib.ptr(g)) == -6
+    finally:
+        lib.pgp_destroy(h)

@@ -6,8 +6,19 @@ Units/corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SI
 which is what gemm_f64 issues) -> x2; WRITE_SIZE is taken as is."""
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+
+def gemm_source_sha16():
+    """Fingerprint of the sources the dominant kernel is compiled from (bench.py refuses a traffic file of another kernel)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pygps_amd", "csrc")
+    h = hashlib.sha256()
+    for f in ("gemm_f64.hip", "gemm_tile.h", "common.h"):
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load(pattern, counter, match):
@@ -33,6 +44,7 @@ if __name__ == "__main__":
     fetch_b = f * 1024.0 * 2.0 / nf
     write_b = w * 1024.0 / nw
     json.dump({"kernel": DOM, "launches_sampled": nf, "measured_on_commit": head,
+               "kernel_source_sha16": gemm_source_sha16(),
                "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
                "bytes_per_launch": fetch_b + write_b,
                "all_gemm_f64_instantiations": {"launches_sampled": nfa, "bytes_per_launch": fa * 2048.0 / nfa + wa * 1024.0 / nwa},
