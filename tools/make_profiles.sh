@@ -42,6 +42,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/asm -- py
 cp $(kstats $O/asm) $O/final/r04_assembly_kernel_stats.csv
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/asm_w -- python $R/tools/gpu_probe.py asm > /dev/null 2> $O/asm_w.err
 cp $(ccsv $O/asm_w) $O/final/r04_assembly_pmc_write_counter_collection.csv
-# 6. the XCD-aware tile order: same-box A/B of speed, L2-side fetch, MFMA-pipe busy cycles, L2 hit rate
-python $R/tools/xcd_decision.py $O > $O/final/r04_xcd_order_decision.json 2> $O/xcd.err
+# 6. the probes behind EXPERIMENTS.md (round 4): stand-alone GEMM rate by K, round quantisation, narrow outputs
+( for k in 512 1024 2048 8192; do python $R/tools/gemm_only.py 8192 $k 0 1.0 128 10; done; python $R/tools/quant_probe.py; python $R/tools/narrow_probe.py ) > $O/final/r04_gemm_probes.txt 2> $O/probes.err
+# 7. timeline of one single-stream fit
+bash $R/tools/fit_trace.sh > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline.txt $O/final/r04_fit_timeline.txt
 ls -la $O/final
