@@ -18,6 +18,8 @@
 #include <mutex>
 #include <vector>
 
+#include <atomic>
+
 #include "kernels.h"
 #include "sqdist_tile.h"
 
@@ -409,6 +411,139 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(const double* __restrict_
     }
 }
 
+// ---- squared-exponential assembly in the GRAM form on the matrix cores (round 4) ---------------------------------------------
+// r^2 = |a|^2 + |b|^2 - 2 a.b on CENTRED, scaled coordinates: one v_mfma_f64_16x16x4 per 4 coordinates and 16 x 16 outputs
+// against two VALU instructions per element and coordinate of the difference form -- at d = 64 the difference form is bound by
+// the vector ALU (0.40 of its peak executed, 0.27 of the HBM roof), this one by the stores.  The reference's cdist is the
+// difference form; the Gram form's absolute error in r^2 is c eps (|a| + |b|)^2 instead of c' eps r^2, i.e. a RELATIVE error of
+// that size in K.  The host therefore selects this kernel only when a bound on max |a|^2 (sum over the coordinates of
+// (scale_k max_p |x_pk - mean_k|)^2, from the data and the length scales of the call) is <= 64: then K carries <= ~5e-14
+// relative -- below what the difference form's own sqrt(d) eps r^2 leaves at d >= 32 -- otherwise the difference form runs.
+// RBF / RBFard values only (K = sf2 exp(-r^2 / 2)).  Diagonal forced to r^2 = 0, round-off clamped.  Thread layout = MFMA
+// accumulator layout: wave w, lane (l4, l15) holds rows 16 w + 4 a + l4, columns 16 q + l15 of the 64 x 64 tile.
+constexpr int GSTP = ST + 2;
+template <int NP>
+__device__ __forceinline__ void gram_stage_pieces(const double* __restrict__ gp, long ldp, const double* __restrict__ mup,
+                                                  double* __restrict__ slp) {
+    double2_t g[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) g[i] = *(const double2_t*)(gp + (long)(4 * i) * ldp);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const double m_ = mup[4 * i];
+        *(double2_t*)(slp + 4 * i * GSTP) = double2_t{g[i][0] - m_, g[i][1] - m_};
+    }
+}
+
+typedef double gram4_t __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void cov_gram_kernel(const double* __restrict__ XT, long ldp, long n, int dpad, double sf2,
+                                                          double inv_sn2, double* __restrict__ out, long ldo,
+                                                          const int2* __restrict__ tiles, const double* __restrict__ mu,
+                                                          const double* __restrict__ nrm, int nt) {
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    const int2 tile = tiles[blockIdx.x];
+    const long r0 = (long)tile.x * ST, c0 = (long)tile.y * ST;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l4 = lane >> 4, l15 = lane & 15;
+    const int CH = dpad < 64 ? dpad : 64;
+    double* xr = gsm;
+    double* xc = gsm + CH * GSTP;
+    const int spr = lane & 31, sside = lane >> 5;
+    const int wvu = __builtin_amdgcn_readfirstlane(wave);
+    const double* sgp = XT + (sside ? c0 : r0) + 2 * spr + (long)wvu * ldp;
+    double* slp = (sside ? xc : xr) + 2 * spr + wvu * GSTP;
+    const double* mup = mu + wvu;
+    double nr[4], nc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) nr[a] = nrm[r0 + 16 * wave + 4 * a + l4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nc[q] = nrm[c0 + 16 * q + l15];
+    gram4_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = gram4_t{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < dpad; k0 += 64) {
+        const int kk = (dpad - k0) < 64 ? (dpad - k0) : 64;
+        if (k0) __syncthreads();
+        const double* gp = sgp + (long)k0 * ldp;
+        switch (kk >> 4) {
+            case 1: gram_stage_pieces<4>(gp, ldp, mup + k0, slp); break;
+            case 2: gram_stage_pieces<8>(gp, ldp, mup + k0, slp); break;
+            case 3: gram_stage_pieces<12>(gp, ldp, mup + k0, slp); break;
+            default: gram_stage_pieces<16>(gp, ldp, mup + k0, slp); break;
+        }
+        __syncthreads();
+        const double* ap = xr + l4 * GSTP + 16 * wave + l15;
+        const double* bp = xc + l4 * GSTP + l15;
+        double fa0 = ap[0], fb0[4] = {bp[0], bp[16], bp[32], bp[48]};
+        for (int ks = 0; ks < kk; ks += 8) {
+            const double* a1 = ap + (ks + 4) * GSTP;
+            const double* b1 = bp + (ks + 4) * GSTP;
+            const double fa1 = a1[0], fb1[4] = {b1[0], b1[16], b1[32], b1[48]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb0[q], acc[q], 0, 0, 0);
+            if (ks + 8 < kk) {
+                const double* a2 = ap + (ks + 8) * GSTP;
+                const double* b2 = bp + (ks + 8) * GSTP;
+                fa0 = a2[0]; fb0[0] = b2[0]; fb0[1] = b2[16]; fb0[2] = b2[32]; fb0[3] = b2[48];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb1[q], acc[q], 0, 0, 0);
+        }
+    }
+    double v[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long r = r0 + 16 * wave + 4 * a + l4, c = c0 + 16 * q + l15;
+            double s2 = fmax(fma(-2.0, acc[q][a], nr[a] + nc[q]), 0.0);
+            if (r == c) s2 = 0.0;
+            double val = sf2 * exp_nonpos(-0.5 * s2);
+            if (MODE == MODE_FACTOR) {
+                if (r < n && c < n) val = val * inv_sn2 + (r == c ? 1.0 : 0.0);
+                else val = (r == c) ? 1.0 : 0.0;
+                if (c < r) val = 0.0;                  // diagonal tiles: exact zeros below the diagonal (row-major upper view)
+            }
+            v[a][q] = val;
+        }
+    // direct store, row-major: 16 lanes = one 128-byte run of a row
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long r = r0 + 16 * wave + 4 * a + l4, c = c0 + 16 * q + l15;
+            if (MODE == MODE_FACTOR || (r < n && c < n)) {
+                double* dst = out + r * ldo + c;
+                if (nt) __builtin_nontemporal_store(v[a][q], dst); else *dst = v[a][q];
+            }
+        }
+    if (MODE == MODE_SYM && tile.x != tile.y) {
+        // mirrored store out[c][r]: transpose through LDS (the staged coordinates are dead), 64-double runs per column
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gsm[(16 * q + l15) * GSTP + 16 * wave + 4 * a + l4] = v[a][q];
+        __syncthreads();
+        const int pr = t & 31, rw = t >> 5;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int cl = p * 8 + rw;
+            const long c = c0 + cl, r = r0 + 2 * pr;
+            if (c < n) {
+                const double2_t val = *(const double2_t*)(gsm + cl * GSTP + 2 * pr);
+                if (r + 1 < n && ((ldo & 1) == 0)) {
+                    double2_t* dst = (double2_t*)(out + c * ldo + r);
+                    if (nt) __builtin_nontemporal_store(val, dst); else *dst = val;
+                } else {
+                    if (r < n) out[c * ldo + r] = val[0];
+                    if (r + 1 < n) out[c * ldo + r + 1] = val[1];
+                }
+            }
+        }
+    }
+}
+
 __global__ void self_fill_kernel(double* out, long m, double val) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) out[i] = val;
@@ -544,6 +679,47 @@ int cov_factor_launch(const double* XT, long ldp, long n, long np, int dpad, con
                       double* Bf, long ldf, hipStream_t st) {
     const long nt = np / ST;
     return cov_tile_dispatch<MODE_FACTOR>(cs, 1, nt, nt, st, XT, ldp, n, XT, ldp, n, dpad, inv_sn2, Bf, ldf);
+}
+
+// Gram-form assembly (cov_gram_kernel): RBF / RBFard values, 'train' only.  prep = [coordinate means (HADAMARD-prep layout:
+// HADAMARD_PREP_MU doubles) | squared norms of the centred points (np)], produced by hadamard_prepare_launch for the same XT.
+static int cov_gram_dispatch(int mode, const double* XT, long ldp, long n, long nt, int dpad, const CovSpec& cs, double inv_sn2,
+                             double* out, long ldo, const double* prep, hipStream_t st) {
+    const int2* tiles = nullptr;
+    long ntiles = 0;
+    { const int rc = tile_table(1, nt, nt, &tiles, &ntiles); if (rc != PGP_OK) return rc; }
+    if (ntiles == 0) return PGP_OK;
+    const int CH = dpad < 64 ? dpad : 64;
+    const size_t shm = std::max<size_t>((size_t)2 * CH * GSTP, (size_t)ST * GSTP) * sizeof(double);
+    const int nt_ = (mode != MODE_FACTOR && (double)n * (double)n * 8.0 >= 1073741824.0) ? 1 : 0;
+    static std::atomic<size_t> attr_f{0}, attr_s{0};
+    if (mode == MODE_FACTOR) {
+        if (attr_f.load(std::memory_order_acquire) < shm) {
+            (void)hipFuncSetAttribute((const void*)cov_gram_kernel<MODE_FACTOR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            attr_f.store(shm, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(cov_gram_kernel<MODE_FACTOR>, dim3((unsigned)ntiles), dim3(256), shm, st, XT, ldp, n, dpad, cs.cp.sf2, inv_sn2,
+                           out, ldo, tiles, prep, prep + HADAMARD_PREP_MU, nt_);
+    } else {
+        if (attr_s.load(std::memory_order_acquire) < shm) {
+            (void)hipFuncSetAttribute((const void*)cov_gram_kernel<MODE_SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            attr_s.store(shm, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(cov_gram_kernel<MODE_SYM>, dim3((unsigned)ntiles), dim3(256), shm, st, XT, ldp, n, dpad, cs.cp.sf2, inv_sn2,
+                           out, ldo, tiles, prep, prep + HADAMARD_PREP_MU, nt_);
+    }
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+bool cov_gram_applies(const CovSpec& cs, int dpad) {
+    return !cs.prog && (cs.cp.kind == 0 || cs.cp.kind == 1) && cs.cp.der < 0 && dpad >= 32;
+}
+int cov_factor_gram_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double inv_sn2, double* Bf,
+                           long ldf, const double* prep, hipStream_t st) {
+    return cov_gram_dispatch(MODE_FACTOR, XT, ldp, n, np / ST, dpad, cs, inv_sn2, Bf, ldf, prep, st);
+}
+int cov_sym_gram_launch(const double* XT, long ldp, long n, int dpad, const CovSpec& cs, double* out, long ldo, const double* prep,
+                        hipStream_t st) {
+    return cov_gram_dispatch(MODE_SYM, XT, ldp, n, (n + ST - 1) / ST, dpad, cs, 0.0, out, ldo > 0 ? ldo : n, prep, st);
 }
 
 // The same fused assembly for ONE column panel of the factor: columns [col0, col0 + ncols) (multiples of 64) of B = K/sn2 + I,

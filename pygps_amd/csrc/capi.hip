@@ -139,7 +139,7 @@ void pgp_destroy(pgp_ctx* c) {
     for (auto& kv : c->spool) (void)hipFree(kv.second);
     for (auto& kv : c->orders) (void)hipFree(kv.second.first);
     void* bufs[] = {c->x_dev, c->y_dev, c->XsT, c->scale_dev, c->W, c->T, c->Binv, c->inv16, c->m_dev,
-                    c->rvec, c->zvec, c->partial, c->Dk, c->dpack, c->Xs, c->res_dev};
+                    c->rvec, c->zvec, c->partial, c->Dk, c->dpack, c->Xs, c->res_dev, c->prep};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->in_host) (void)hipHostFree(c->in_host);
@@ -172,6 +172,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "gemm_dbg")) { if (value & ~(64 | 256 | 512)) return -2; c->gemm_dbg = value; return PGP_OK; }
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     if (!strcmp(name, "leaf_first")) { c->leaf_first = value; return PGP_OK; }
+    if (!strcmp(name, "gram_assembly")) { if (value < 0 || value > 2) return -2; c->gram_assembly = value; return PGP_OK; }
     if (!strcmp(name, "yield")) { c->yield = value; return PGP_OK; }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
     if (!strcmp(name, "ep_r_direct")) { c->ep_r_direct = value; return PGP_OK; }
@@ -936,9 +937,9 @@ int eet_lower(pgp_ctx* c, const double* E, long lde, double* Binv, long ldb, lon
 int ensure_workspace(pgp_ctx* c, long np) {
     if (c->ws_np == np) return PGP_OK;
     (void)hipStreamSynchronize(c->st);
-    void* olds[] = {c->W, c->T, c->Binv, c->inv16, c->m_dev, c->rvec, c->zvec};
+    void* olds[] = {c->W, c->T, c->Binv, c->inv16, c->m_dev, c->rvec, c->zvec, c->prep};
     for (void* b : olds) if (b) (void)hipFree(b);
-    c->W = c->T = c->Binv = c->inv16 = c->m_dev = c->rvec = c->zvec = nullptr;
+    c->W = c->T = c->Binv = c->inv16 = c->m_dev = c->rvec = c->zvec = c->prep = nullptr;
     if (c->in_host) { (void)hipHostFree(c->in_host); c->in_host = nullptr; c->in_cap = 0; }
     c->ws_np = 0;          // committed again only once EVERY allocation below has succeeded
     c->dense_ready = false;
@@ -953,6 +954,7 @@ int ensure_workspace(pgp_ctx* c, long np) {
     HIP_TRY(hipMalloc((void**)&c->m_dev, np * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->rvec, np * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->zvec, np * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->prep, (size_t)hadamard_prep_count(np) * sizeof(double)));
     HIP_TRY(hipMemsetAsync(c->rvec, 0, np * sizeof(double), c->st));
     c->in_cap = (size_t)(np + 1024) * sizeof(double);
     HIP_TRY(hipHostMalloc((void**)&c->in_host, c->in_cap, hipHostMallocDefault));
@@ -1024,6 +1026,14 @@ int pgp_set_data(pgp_ctx* c, const double* x, int64_t n, int64_t d, const double
     HIP_TRY(hipMemsetAsync(c->y_dev, 0, np * sizeof(double), c->st));
     if (y) HIP_TRY(hipMemcpyAsync(c->y_dev, y, n * sizeof(double), hipMemcpyHostToDevice, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
+    {   // per coordinate: the largest squared deviation from the mean (the bound behind the choice of the Gram-form assembly)
+        std::vector<double> mean((size_t)d, 0.0);
+        for (int64_t p = 0; p < n; ++p) for (int64_t k = 0; k < d; ++k) mean[k] += x[p * d + k];
+        for (int64_t k = 0; k < d; ++k) mean[k] /= (double)n;
+        c->xdev2.assign((size_t)d, 0.0);
+        for (int64_t p = 0; p < n; ++p)
+            for (int64_t k = 0; k < d; ++k) { const double v = x[p * d + k] - mean[k]; if (v * v > c->xdev2[k]) c->xdev2[k] = v * v; }
+    }
     c->n = n; c->d = d; c->np = np; c->ldf = np + 128;
     // ^ factor rows | 128 augmented rhs rows.  (The np rows of the fused inverse live in pooled scratch, not in the
     //   factor buffer: a posterior handle keeps (np + 128) np doubles, not (2 np + 128) np.)
@@ -1075,9 +1085,19 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     // ---- S1': fused assembly of B = K/sn2 + I into the factor buffer --------------------------
     HIP_TRY(hipEventRecord(c->ev[0], st));
     CHK(upload_scaled(c, c->x_dev, n, d, sc, c->XsT, np, c->dpad, c->scale_dev));
+    // RBF / RBFard at d >= 32: the Gram form on the matrix cores when a bound on the centred, scaled points' squared norms keeps
+    // its extra rounding error below ~5e-14 relative in K (csrc/assemble.hip cov_gram_kernel), else the reference's difference form
+    bool gram = false;
+    if (c->gram_assembly && cov_gram_applies(cp, c->dpad) && (long)c->xdev2.size() == d) {
+        double bound = 0.0;
+        for (long k = 0; k < d; ++k) bound += sc[k] * sc[k] * c->xdev2[k];
+        gram = c->gram_assembly == 2 || bound <= 64.0;
+    }
+    if (gram) CHK(hadamard_prepare_launch(c->XsT, np, n, np, c->dpad, cp, c->prep, st, /*force=*/true));
     {
         ProfScope ps(c, PC_ASSEMBLE, 0.0, 8.0 * (double)np * (np + 1) / 2.0 + 8.0 * (double)n * d);
-        CHK(cov_factor_launch(c->XsT, np, n, np, c->dpad, cp, 1.0 / sn2, F, ldf, st));
+        if (gram) CHK(cov_factor_gram_launch(c->XsT, np, n, np, c->dpad, cp, 1.0 / sn2, F, ldf, c->prep, st));
+        else CHK(cov_factor_launch(c->XsT, np, n, np, c->dpad, cp, 1.0 / sn2, F, ldf, st));
     }
     CHK(aug_rhs_launch(c->y_dev, c->m_dev, n, F, ldf, np, c->rvec, st));
     // ---- S2: Cholesky (forward substitution of the augmented row -- and L^-T -- ride along) ----------
@@ -1119,7 +1139,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         // alpha currently holds W^T z / sn2 = B^-1 r / sn2  (already the final alpha)
         { ProfScope ps(c, PC_HADAMARD, 0.0, 8.0 * (double)np * (np + 1) / 2.0 + 8.0 * (double)n * d);
           CHK(hadamard_reduce_launch(c->XsT, np, n, np, c->dpad, cp, ncov, sn2, c->Binv, np, c->alpha_dev, c->partial,
-                                     c->scal + 8, st)); }
+                                     c->scal + 8, st, nullptr, gram ? c->prep : nullptr)); }
     } else {
         HIP_TRY(hipEventRecord(c->ev[5], st));
     }

@@ -94,6 +94,10 @@ struct pgp_ctx {
     double *W = nullptr, *T = nullptr, *Binv = nullptr, *inv16 = nullptr, *alpha_dev = nullptr, *m_dev = nullptr,
            *rvec = nullptr, *zvec = nullptr, *partial = nullptr, *scal = nullptr;
     long partial_cap = 0;
+    double* prep = nullptr;             // [coordinate means | squared norms of the centred points] of the current XsT (hadamard_prep_count(np))
+    std::vector<double> xdev2;          // per coordinate: max_p (x_pk - mean_k)^2 of the resident x (host, pgp_set_data)
+    int gram_assembly = 1;              // RBF / RBFard assembly of a fit in the Gram form on the matrix cores: 1 when the host's bound on
+                                        // the centred, scaled points' squared norms allows it (csrc/assemble.hip), 0 never, 2 always
     bool dense_ready = false;           // the workspace holds the Q of a dense fit with want = 3 (pgp_dense_grad_term sums against it);
     long dense_n = 0;                   // cleared by every other entry point that rewrites B^-1 / alpha
     int* info_dev = nullptr;

@@ -880,10 +880,10 @@ long hadamard_block_count(long np, long tr0, long trn) {
 // the coordinate means the ARD reduce centres with (no-op for covariance functions without an ARD leaf)
 // mu: HADAMARD_PREP_MU doubles of means, then np squared norms of the centred points (plain ARD kinds: the Gram form of
 // hadamard_ard_kernel) -- hadamard_prep_count(np) doubles in all
-constexpr long HADAMARD_PREP_MU = 272;                // dpad <= 256 + slack
 long hadamard_prep_count(long np) { return HADAMARD_PREP_MU + np; }
-int hadamard_prepare_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double* mu, hipStream_t st) {
-    const bool ard = cs.prog ? cs.pg.ard_leaf >= 0 : (cs.cp.kind == 1 || cs.cp.kind == 6);
+int hadamard_prepare_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double* mu, hipStream_t st,
+                            bool force) {
+    const bool ard = force || (cs.prog ? cs.pg.ard_leaf >= 0 : (cs.cp.kind == 1 || cs.cp.kind == 6));
     if (ard) hipLaunchKernelGGL(coord_mean_kernel, dim3((unsigned)dpad), dim3(256), 0, st, XT, ldp, n, mu);
     if (ard && !cs.prog)
         hipLaunchKernelGGL(point_norm_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, XT, ldp, np, dpad, mu,
@@ -960,9 +960,13 @@ int hadamard_final_launch(const double* partial, long nblk, int ncov, double* ou
 
 int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, int ncov,
                            double sn2, const double* Binv, long ldb, const double* alpha, double* partial,
-                           double* out_dev, hipStream_t st, const double* wv) {
+                           double* out_dev, hipStream_t st, const double* wv, const double* prep) {
     const long nt = np / ST;
     const long nblk = nt * (nt + 1) / 2;
+    if (prep) {                                       // the caller already ran hadamard_prepare_launch on this XT (the Gram-form assembly)
+        CHK_RC(hadamard_partial_launch(XT, ldp, n, np, dpad, cs, ncov, sn2, Binv, ldb, alpha, wv, partial, prep, 0, nt, st));
+        return hadamard_final_launch(partial, nblk, ncov, out_dev, st);
+    }
     // ARD leaves: the per-coordinate sums run in the product form on centred coordinates (ard_dim_reduce); the means live
     // behind the per-block partials (hadamard_partial_count leaves room for them)
     double* mu = partial + nblk * (long)(ncov + 1);

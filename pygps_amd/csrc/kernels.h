@@ -36,12 +36,20 @@ int self_fill_launch(double* out, long m, double val, hipStream_t st);
 // grad.hip
 int hadamard_reduce_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, int ncov,
                            double sn2, const double* Binv, long ldb, const double* alpha, double* partial,
-                           double* out_dev, hipStream_t st, const double* wv = nullptr);
+                           double* out_dev, hipStream_t st, const double* wv = nullptr, const double* prep = nullptr);
 long hadamard_partial_count(long np, int ncov);
 // the same reduce in pieces, for a B^-1 that exists as column strips only (csrc/sharded.hip)
 long hadamard_block_count(long np, long tr0, long trn);
+constexpr long HADAMARD_PREP_MU = 272;               // prep buffer: [means of up to 256 coordinates + slack | np squared norms]
 long hadamard_prep_count(long np);
-int hadamard_prepare_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double* mu, hipStream_t st);
+int hadamard_prepare_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double* mu, hipStream_t st,
+                            bool force = false);
+// Gram-form (MFMA) assembly of RBF / RBFard values from centred coordinates; prep as written by hadamard_prepare_launch(force)
+bool cov_gram_applies(const CovSpec& cs, int dpad);
+int cov_factor_gram_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double inv_sn2, double* Bf,
+                           long ldf, const double* prep, hipStream_t st);
+int cov_sym_gram_launch(const double* XT, long ldp, long n, int dpad, const CovSpec& cs, double* out, long ldo, const double* prep,
+                        hipStream_t st);
 int hadamard_partial_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, int ncov, double sn2,
                             const double* Binv, long ldb, const double* alpha, const double* wv, double* partial,
                             const double* mu, long tr0, long trn, hipStream_t st);

@@ -296,11 +296,21 @@ int pgp_test_assemble(pgp_ctx* c, int kind, int mode, int64_t n, int64_t d, int 
     HIP_TRY(hipMemcpy(xd, x.data(), x.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(scd, sc.data(), d * 8, hipMemcpyHostToDevice));
     CHK(scale_transpose_launch(xd, n, (int)d, scd, XT, np, dpad, c->st));
+    // the form a fit would pick for this data (uniform in +-1.7, unit length scales sqrt(d): squared norms ~1): the Gram form on the
+    // matrix cores for RBF / RBFard at d >= 32 (option gram_assembly 0: the difference form).  The means / norms are part of the cost.
+    const bool gram = c->gram_assembly && cov_gram_applies(cp, dpad);
+    double* prep = nullptr;
+    if (gram) HIP_TRY(hipMalloc((void**)&prep, (size_t)hadamard_prep_count(np) * 8));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     int rc = PGP_OK;
     for (int it = -1; it < iters && rc == PGP_OK; ++it) {
         if (it == 0) HIP_TRY(hipEventRecord(e0, c->st));
+        if (gram) {
+            rc = hadamard_prepare_launch(XT, np, n, np, dpad, cp, prep, c->st, true);
+            if (rc == PGP_OK) rc = mode == 2 ? cov_factor_gram_launch(XT, np, n, np, dpad, cp, 100.0, out, ldo, prep, c->st)
+                                             : cov_sym_gram_launch(XT, np, n, dpad, cp, out, 0, prep, c->st);
+        } else
         rc = mode == 2 ? cov_factor_launch(XT, np, n, np, dpad, cp, 100.0, out, ldo, c->st)
                        : cov_sym_launch(XT, np, n, dpad, cp, out, c->st, 0);
     }
@@ -311,6 +321,7 @@ int pgp_test_assemble(pgp_ctx* c, int kind, int mode, int64_t n, int64_t d, int 
     *ms_out = ms / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(xd); (void)hipFree(XT); (void)hipFree(scd); (void)hipFree(out);
+    if (prep) (void)hipFree(prep);
     return rc;
 }
 

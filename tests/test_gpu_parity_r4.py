@@ -179,3 +179,56 @@ def test_randomised_ard_fits_up_to_130_dimensions(lib):
         e2 = np.abs(alpha - ref["alpha"].ravel()).max() / max(1e-300, np.abs(ref["alpha"]).max())
         e3 = np.abs(gvec - gref).max() / max(1.0, np.abs(gref).max())
         assert e1 < 1e-9 and e2 < 1e-7 and e3 < 1e-7, (case, n, d, kind, e1, e2, e3)
+
+
+def _fit_with(lib, option, x, y, kern, log_sn):
+    import pygps_amd as pyGPs
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    _lib.check(lib.pgp_set_option(ctx, b"gram_assembly", option))
+    try:
+        m = pyGPs.GPR()
+        m.setPrior(kernel=kern())
+        m.setNoise(log_sn)
+        m.setData(x, y)
+        nlZ, dnlZ, post = m.getPosterior()
+        return nlZ, _flat(dnlZ), np.array(post.alpha), np.asarray(post.L).copy()
+    finally:
+        lib.pgp_set_option(ctx, b"gram_assembly", 1)
+
+
+def test_gram_form_assembly_against_the_difference_form(lib):
+    """RBF / RBFard fits at d >= 32 assemble K in the Gram form on the matrix cores (csrc/assemble.hip cov_gram_kernel) when the host's
+    bound on the centred, scaled points' squared norms allows it; the reference's cdist is the difference form (Core/cov.py:804,
+    :899-901).  The measured parity argument: the same fit with the Gram form forced (2), forbidden (0) and chosen (1) --
+    * cfg-3 recipe (SEard, d = 64) and RBF d = 32: forced vs forbidden agree far inside the parity tolerances, the default picks
+      the Gram form (bit-identical to forced) and reproduces the reference's fixture;
+    * data whose norms break the bound (a cluster 1e3 length scales from the mean): the default must pick the difference form
+      (bit-identical to forbidden), and the forced Gram form shows why: it loses digits there."""
+    import pygps_amd as pyGPs
+    g = golden("G7_rbfard_d64_N2048")
+    N, d = 2048, 64
+    x, y = synth_reg(N, d)
+    kern = lambda: pyGPs.cov.RBFard(log_ell_list=[float(np.log(np.sqrt(d)))] * d, log_sigma=0.0)
+    r0, r1, r2 = (_fit_with(lib, o, x, y, kern, np.log(0.1)) for o in (0, 1, 2))
+    assert r1[0] == r2[0] and np.array_equal(r1[2], r2[2])                         # the default chose the Gram form
+    assert relerr(r2[0], r0[0]) < 1e-12 and relerr(r2[2], r0[2]) < 1e-10 and relerr(r2[1], r0[1]) < 1e-9
+    assert relerr(np.diag(r2[3]), np.diag(r0[3])) < 1e-12 and relerr(r2[3], r0[3]) < 1e-11
+    assert relerr(r1[0], g["nlZ"]) < 1e-9 and relerr(r1[2][g["alpha_idx"], 0], g["alpha_sample"]) < 1e-7
+    gref = np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])
+    assert np.max(np.abs(r1[1] - gref)) < 1e-7 * np.max(np.abs(gref))
+    # plain RBF at d = 32 (the Gram form starts at 32 coordinates)
+    x3, y3 = synth_reg(1500, 32, seed=3)
+    k3 = lambda: pyGPs.cov.RBF(np.log(np.sqrt(32.0)) + 0.1, 0.2)
+    a0, a1, a2 = (_fit_with(lib, o, x3, y3, k3, np.log(0.15)) for o in (0, 1, 2))
+    assert a1[0] == a2[0] and relerr(a2[0], a0[0]) < 1e-12 and relerr(a2[2], a0[2]) < 1e-10 and relerr(a2[1], a0[1]) < 1e-9
+    # norms far beyond the bound: a second cluster 1e3 length scales away
+    xb = x3.copy()
+    xb[::2, 0] += 6.0e3
+    b0, b1, b2 = (_fit_with(lib, o, xb, y3, k3, np.log(0.15)) for o in (0, 1, 2))
+    assert b1[0] == b0[0] and np.array_equal(b1[2], b0[2]) and np.array_equal(b1[1], b0[1])     # the default chose the difference form
+    c = float(y3.mean())
+    ref = O.exact_fit(O.RBF, np.array([np.log(np.sqrt(32.0)) + 0.1, 0.2]), 0, np.log(0.15), xb, y3, c * np.ones_like(y3), np.ones_like(y3),
+                      faithful=False)
+    assert relerr(b1[0], ref["nlZ"]) < 1e-9 and relerr(b1[2], ref["alpha"]) < 1e-7
+    assert relerr(b2[2], ref["alpha"]) > 10 * relerr(b1[2], ref["alpha"])        # ... and the forced Gram form is visibly worse here
