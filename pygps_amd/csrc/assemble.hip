@@ -610,7 +610,9 @@ static int panel_tile_table(long nt, long t0, long t1, const int2** tab, long* c
     return PGP_OK;
 }
 
-static int g_tile_grid = 2048;                     // persistent workgroups (4 resident per CU, the rest queue: dynamic balance); option "asm_grid"
+static int g_tile_grid = 4096;                     // persistent workgroups (4 resident per CU, the rest queue: dynamic balance); option "asm_grid"
+                                                   // (round 4, three alternations on one box, full symmetric RBF d = 16: N = 16384 56-58 % of the HBM peak
+                                                   //  at 2048 workgroups, 62-64 % at 4096; N = 8192 61-62 % / 62-65 %)
 void cov_tile_set_grid(int g) { g_tile_grid = g; }
 
 template <int MODE>

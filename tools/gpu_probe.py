@@ -142,7 +142,7 @@ if __name__ == "__main__":
         fit(8192, 16, want=2, prof=False)
         fit(2048, 16, prof=False)
     if "asm" in what:
-      for grid in [int(a[5:]) for a in what if a.startswith("grid=")] or [2048]:
+      for grid in [int(a[5:]) for a in what if a.startswith("grid=")] or [4096]:
         lib.pgp_set_option(ctx, b"asm_grid", grid)
         print("asm_grid", grid)
         for (kind, n, d) in ((0, 8192, 16), (0, 16384, 16), (1, 16384, 64), (2, 16384, 16), (0, 16384, 4)):
