@@ -10,6 +10,17 @@ export PYTHONPATH=$R
 cd /tmp && export TMPDIR=/tmp
 kstats() { find $1 -name "*kernel_stats.csv" | head -1; }
 ccsv() { find $1 -name "*counter_collection.csv" | head -1; }
+# 0. PMC traffic of gemm_f64 FIRST (separate passes, single stream): bench.py quotes the newest profiles/r*_gemm_f64_hbm_traffic.json whose
+#    kernel fingerprint matches, so the file has to exist before the bench line of this set is taken; then a pause (the first process
+#    after a counter pass starts at a fraction of the clock for a few seconds)
+for c in FETCH_SIZE WRITE_SIZE; do
+  d=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -- python $R/bench.py --steps 3 --windows 1 --prof-steps 1 --streams 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_$d.err
+  cp $(ccsv $O/pmc/$d) $O/final/r04_pmc_${d}_counter_collection.csv
+done
+python $R/tools/pmc_traffic.py $O/pmc $O/final/r04_gemm_f64_hbm_traffic.json $HEAD > /dev/null 2>> $O/pmc.err
+cp $O/final/r04_gemm_f64_hbm_traffic.json $R/profiles/r04_gemm_f64_hbm_traffic.json
+sleep 30; python $R/tools/two_streams.py > /dev/null 2>&1
 # 1. the bench line itself (with cpu_baseline, extras)
 timeout 1200 python $R/bench.py > $O/bench.json 2> $O/bench.err
 grep '^{' $O/bench.json > $O/final/r04_bench.json
@@ -25,13 +36,6 @@ grep '^{' $O/s2.json > $O/final/r04_bench_streams2_under_rocprof.json; cp $(ksta
 timeout 900 python $R/tools/sharded_time.py 8192 16384 32768 65536 2> $O/sharded.err | grep "N=" > $O/final/r04_sharded_fit_world1.txt
 # 2d. single- and two-stream rates of the raw C-ABI loop
 NSTREAMS=1,2 timeout 300 python $R/tools/two_streams.py 2> /dev/null | grep fits > $O/final/r04_two_streams.txt
-# 3. PMC traffic of gemm_f64 (separate passes, single stream)
-for c in FETCH_SIZE WRITE_SIZE; do
-  d=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$d -- python $R/bench.py --steps 3 --windows 1 --prof-steps 1 --streams 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_$d.err
-  cp $(ccsv $O/pmc/$d) $O/final/r04_pmc_${d}_counter_collection.csv
-done
-python $R/tools/pmc_traffic.py $O/pmc $O/final/r04_gemm_f64_hbm_traffic.json $HEAD > /dev/null 2>> $O/pmc.err
 # 4. cfg 3 (SEard N=16384 d=64) and cfg 5 (EP N=4096 d=32): per-kernel stats
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -- python $R/tools/cfg3_time.py > $O/final/r04_cfg3_time.txt 2> $O/cfg3.err
 cp $(kstats $O/cfg3) $O/final/r04_cfg3_seard_N16384_kernel_stats.csv
