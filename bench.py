@@ -176,19 +176,17 @@ def extras(lib, _lib, local, d, roof):
             roof[key] = {"ms": ms_a.value, "GBs": ba / ms_a.value / 1e6, "bound": "hbm",
                          "frac_of_hbm_peak": ba / ms_a.value / 1e6 / PEAK_HBM_GBS}
             if dd == 64:
-                # d = 64: 3 d + 25 fp64 operations per output.  The 'train' kernel computes only the tiles on or
-                # above the diagonal and stores each twice (csrc/assemble.hip), so the EXECUTED operation count is half the
-                # algorithmic one: the kernel sits under both roofs (HBM: the figure above; fp64 vector: the executed rate).
-                # Round 2 divided the algorithmic count by the time and called it a fraction of the vector peak.
-                fl = (3.0 * dd + 25.0) * na * na
+                # d = 64 (round 4): this is the form a FIT picks for such data -- squared distances in the Gram form on the matrix
+                # cores (csrc/assemble.hip cov_gram_kernel; the per-call means and norms are inside the timed loop), chosen by the
+                # host's norm bound; getCovMatrix keeps the reference's difference form (0.27 of the HBM roof, 0.40 of the fp64
+                # vector roof executed: rounds 2-3 quoted that kernel here).  MFMA flops 2 d per output on the tiles computed
+                # (upper triangle, each stored twice): far from the matrix roof -- the kernel is bound by its stores.
                 nt = -(-na // 64)
-                executed = (3.0 * dd + 25.0) * 64.0 * 64.0 * nt * (nt + 1) / 2.0
-                roof[key].update({"bound": "neither roof reached: HBM write %.2f, executed fp64 VALU %.2f" % (
-                                      ba / ms_a.value / 1e6 / PEAK_HBM_GBS, executed / ms_a.value / 1e9 / PEAK_FP64_MFMA_TF),
-                                  "algorithmic_valu_TFLOPs": fl / ms_a.value / 1e9,
-                                  "executed_valu_TFLOPs": executed / ms_a.value / 1e9,
-                                  "frac_of_fp64_vector_peak_executed": executed / ms_a.value / 1e9 / PEAK_FP64_MFMA_TF,
-                                  "frac_of_fp64_vector_peak_algorithmic": fl / ms_a.value / 1e9 / PEAK_FP64_MFMA_TF})
+                mf = 2.0 * dd * 64.0 * 64.0 * nt * (nt + 1) / 2.0
+                roof[key].update({"bound": "hbm (write): %.2f of the HBM peak; MFMA Gram products %.1f TFLOP/s"
+                                           % (ba / ms_a.value / 1e6 / PEAK_HBM_GBS, mf / ms_a.value / 1e9),
+                                  "form": "Gram form on centred coordinates (v_mfma_f64_16x16x4), selected by the host's norm bound",
+                                  "mfma_TFLOPs": mf / ms_a.value / 1e9})
     out = {}
     # ---- cfg 3 (GPR + SEard, N=16384 d=64, nlZ + 67 gradients) and the N=16384 RBF Cholesky figure ----------------
     for key, kind, dd in (("cholesky_sweep_N16384", _lib.COV_RBF, d), ("cfg3_seard_N16384_d64", _lib.COV_RBFARD, 64)):
@@ -266,25 +264,28 @@ def extras(lib, _lib, local, d, roof):
         # posterior is carried through the sweeps, not rebuilt after each)
         nblk5 = n5 // 128
         bytes_sweep = nblk5 * (4 * 8.0 * n5 * 128 + 8.0 * n5 * n5)
-        rebuilds = 1                                   # _epComputeParams runs once, on the converged site parameters
+        rebuilds = 1                                   # ONE factorisation after the sweeps (post.L of the converged site parameters)
         out["cfg5_ep_N4096_d32"] = {
             "fit_ms": t5 * 1e3, "sweeps": sw, "ms_per_sweep_incl_params": t5 * 1e3 / max(sw, 1), "nlZ": float(nlz5),
             "algorithmic_bytes_per_sweep_blocked": bytes_sweep,
             "reference_algorithm_bytes_per_sweep": 16.0 * n5 ** 3,
             "site_sweep_GB_per_sweep": bytes_sweep / 1e9,
-            # sweep + fused inverse 2 N^3 / 3, V' = K diag(sW) L^-T N^3 (clipped), Sigma = K - V'V'^T N^3 (lower tiles)
-            "epComputeParams_flops_per_sweep": 8.0 * n5 ** 3 / 3.0,
-            "epComputeParams_calls_per_fit": rebuilds,
+            # round 4: Sigma, mu, log det B are carried AND returned from; after the sweeps only post.L = chol(I + sW sW' o K) is
+            # computed afresh (N^3 / 3 flops; a full _epComputeParams is 8 N^3 / 3: option ep_final_rebuild=1)
+            "final_factor_flops": n5 ** 3 / 3.0,
+            "epComputeParams_calls_per_fit": 0,
             "schedule": "Sigma, mu, log det B carried through the sweeps by exact identities (Woodbury folds per block of 128 sites, "
-                        "determinant lemma per site); ONE rebuild from the converged site parameters (option ep_recompute=1: after "
-                        "every sweep, the reference's schedule, inf.py:772).  One resident kernel per sweep (1 chain + 36 prep "
+                        "determinant lemma per site); alpha, nlZ and the gradients come from the carried state, post.L from ONE plain "
+                        "Cholesky after the sweeps (options: ep_final_rebuild=1 one full _epComputeParams instead, ep_recompute=1 a rebuild "
+                        "after every sweep = the reference's schedule, inf.py:772).  One resident kernel per sweep (1 chain + 36 prep "
                         "workgroups) beside the bulk stream's folds; hand-overs through device counters, no launch per block",
             # the split the site sweep / parameter recomputation figures are read from (last of the two fits)
             "site_sweep_ms": ph5["solve"] / max(sw, 1), "site_sweep_GBs": bytes_sweep / (ph5["solve"] / max(sw, 1)) / 1e6,
             "site_sweep_frac_of_hbm_peak": bytes_sweep / (ph5["solve"] / max(sw, 1)) / 1e6 / PEAK_HBM_GBS,
             "site_sweep_bound": "4096 sequentially dependent site updates per sweep (~0.7 us each inside ep_chain_kernel) + a ~22 us hand-over per block of 128, not bandwidth",
-            "params_ms": ph5["potrf"] / rebuilds, "params_TFLOPs": 8.0 * n5 ** 3 / 3.0 / (ph5["potrf"] / rebuilds) / 1e9,
-            "params_frac_of_mfma_peak": 8.0 * n5 ** 3 / 3.0 / (ph5["potrf"] / rebuilds) / 1e9 / PEAK_FP64_MFMA_TF,
+            "params_ms": ph5["potrf"] / rebuilds, "params_what": "the final factorisation (chain of diagonal blocks bound at N = 4096)",
+            "params_TFLOPs": n5 ** 3 / 3.0 / (ph5["potrf"] / rebuilds) / 1e9,
+            "params_frac_of_mfma_peak": n5 ** 3 / 3.0 / (ph5["potrf"] / rebuilds) / 1e9 / PEAK_FP64_MFMA_TF,
             "first_params_and_K_ms": ph5["assemble"], "alpha_and_gradients_ms": ph5["grad"],
             "workload": "BASELINE configs[4]: GPC + RBF, infEP, N=4096 d=32 (cold start, nlZ + gradients, through model.getPosterior)"}
     except Exception as e:           # pragma: no cover

@@ -436,111 +436,179 @@ __device__ __forceinline__ void gram_stage_pieces(const double* __restrict__ gp,
 }
 
 typedef double gram4_t __attribute__((ext_vector_type(4)));
-template <int MODE>
+__device__ __forceinline__ double gram_swap_adjacent(double v) {          // value of lane l ^ 1 (DPP quad_perm [1,0,3,2])
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// NP > 0: dpad = 4 NP <= 64, ONE chunk per tile -- persistent workgroups, the next tile's coordinates and norms are fetched
+// into registers before this tile's products are issued (like cov_tile_kernel).  NP == 0: any dpad, chunk by chunk, one tile per
+// trip without the prefetch.
+template <int MODE, int NP>
 __global__ __launch_bounds__(256, 2) void cov_gram_kernel(const double* __restrict__ XT, long ldp, long n, int dpad, double sf2,
                                                           double inv_sn2, double* __restrict__ out, long ldo,
-                                                          const int2* __restrict__ tiles, const double* __restrict__ mu,
+                                                          const int2* __restrict__ tiles, long ntiles, const double* __restrict__ mu,
                                                           const double* __restrict__ nrm, int nt) {
     extern __shared__ __attribute__((aligned(16))) double gsm[];
-    const int2 tile = tiles[blockIdx.x];
-    const long r0 = (long)tile.x * ST, c0 = (long)tile.y * ST;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l4 = lane >> 4, l15 = lane & 15;
     const int CH = dpad < 64 ? dpad : 64;
     double* xr = gsm;
     double* xc = gsm + CH * GSTP;
     const int spr = lane & 31, sside = lane >> 5;
     const int wvu = __builtin_amdgcn_readfirstlane(wave);
-    const double* sgp = XT + (sside ? c0 : r0) + 2 * spr + (long)wvu * ldp;
     double* slp = (sside ? xc : xr) + 2 * spr + wvu * GSTP;
     const double* mup = mu + wvu;
-    double nr[4], nc[4];
+    constexpr int NPR = NP > 0 ? NP : 1;
+    double2_t pg[NPR];                                // the next tile's staging pieces (NP > 0)
+    double pm[NPR];                                   // the means of this thread's coordinates (tile-independent)
+    double nr[4], nc[4], nnr[4], nnc[4];
+    long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int2 tc2 = tiles[tile];
+    auto fetch = [&](int2 tl) {                       // NP > 0: pieces of tile tl -> pg, its norms -> nnr / nnc
+        const double* gp = XT + (sside ? (long)tl.y * ST : (long)tl.x * ST) + 2 * spr + (long)wvu * ldp;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) nr[a] = nrm[r0 + 16 * wave + 4 * a + l4];
+        for (int i = 0; i < NPR; ++i) pg[i] = *(const double2_t*)(gp + (long)(4 * i) * ldp);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) nc[q] = nrm[c0 + 16 * q + l15];
-    gram4_t acc[4];
+        for (int a = 0; a < 4; ++a) nnr[a] = nrm[(long)tl.x * ST + 16 * wave + 4 * a + l4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = gram4_t{0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < dpad; k0 += 64) {
-        const int kk = (dpad - k0) < 64 ? (dpad - k0) : 64;
-        if (k0) __syncthreads();
-        const double* gp = sgp + (long)k0 * ldp;
-        switch (kk >> 4) {
-            case 1: gram_stage_pieces<4>(gp, ldp, mup + k0, slp); break;
-            case 2: gram_stage_pieces<8>(gp, ldp, mup + k0, slp); break;
-            case 3: gram_stage_pieces<12>(gp, ldp, mup + k0, slp); break;
-            default: gram_stage_pieces<16>(gp, ldp, mup + k0, slp); break;
-        }
+        for (int q = 0; q < 4; ++q) nnc[q] = nrm[(long)tl.y * ST + 16 * q + l15];
+    };
+    auto commit = [&]() {                             // pg -> LDS (centred), norms -> nr / nc
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) *(double2_t*)(slp + 4 * i * GSTP) = double2_t{pg[i][0] - pm[i], pg[i][1] - pm[i]};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { nr[a] = nnr[a]; nc[a] = nnc[a]; }
+    };
+    if constexpr (NP > 0) {
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) pm[i] = mup[4 * i];
+        fetch(tc2);
+        commit();
         __syncthreads();
-        const double* ap = xr + l4 * GSTP + 16 * wave + l15;
-        const double* bp = xc + l4 * GSTP + l15;
-        double fa0 = ap[0], fb0[4] = {bp[0], bp[16], bp[32], bp[48]};
-        for (int ks = 0; ks < kk; ks += 8) {
-            const double* a1 = ap + (ks + 4) * GSTP;
-            const double* b1 = bp + (ks + 4) * GSTP;
-            const double fa1 = a1[0], fb1[4] = {b1[0], b1[16], b1[32], b1[48]};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb0[q], acc[q], 0, 0, 0);
-            if (ks + 8 < kk) {
-                const double* a2 = ap + (ks + 8) * GSTP;
-                const double* b2 = bp + (ks + 8) * GSTP;
-                fa0 = a2[0]; fb0[0] = b2[0]; fb0[1] = b2[16]; fb0[2] = b2[32]; fb0[3] = b2[48];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb1[q], acc[q], 0, 0, 0);
-        }
     }
-    double v[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long r = r0 + 16 * wave + 4 * a + l4, c = c0 + 16 * q + l15;
-            double s2 = fmax(fma(-2.0, acc[q][a], nr[a] + nc[q]), 0.0);
-            if (r == c) s2 = 0.0;
-            double val = sf2 * exp_nonpos(-0.5 * s2);
-            if (MODE == MODE_FACTOR) {
-                if (r < n && c < n) val = val * inv_sn2 + (r == c ? 1.0 : 0.0);
-                else val = (r == c) ? 1.0 : 0.0;
-                if (c < r) val = 0.0;                  // diagonal tiles: exact zeros below the diagonal (row-major upper view)
-            }
-            v[a][q] = val;
+    while (true) {
+        const long r0 = (long)tc2.x * ST, c0 = (long)tc2.y * ST;
+        const long next = tile + gridDim.x;
+        int2 nx = tc2;
+        if constexpr (NP > 0) {
+            if (next < ntiles) { nx = tiles[next]; fetch(nx); }
         }
-    // direct store, row-major: 16 lanes = one 128-byte run of a row
+        gram4_t acc[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int q = 0; q < 4; ++q) acc[q] = gram4_t{0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < dpad; k0 += 64) {
+            const int kk = (dpad - k0) < 64 ? (dpad - k0) : 64;
+            if constexpr (NP == 0) {
+                __syncthreads();
+                const double* gp = XT + (sside ? c0 : r0) + 2 * spr + (long)wvu * ldp + (long)k0 * ldp;
+                switch (kk >> 4) {
+                    case 1: gram_stage_pieces<4>(gp, ldp, mup + k0, slp); break;
+                    case 2: gram_stage_pieces<8>(gp, ldp, mup + k0, slp); break;
+                    case 3: gram_stage_pieces<12>(gp, ldp, mup + k0, slp); break;
+                    default: gram_stage_pieces<16>(gp, ldp, mup + k0, slp); break;
+                }
+                __syncthreads();
+            }
+            const double* ap = xr + l4 * GSTP + 16 * wave + l15;
+            const double* bp = xc + l4 * GSTP + l15;
+            double fa0 = ap[0], fb0[4] = {bp[0], bp[16], bp[32], bp[48]};
+            for (int ks = 0; ks < kk; ks += 8) {
+                const double* a1 = ap + (ks + 4) * GSTP;
+                const double* b1 = bp + (ks + 4) * GSTP;
+                const double fa1 = a1[0], fb1[4] = {b1[0], b1[16], b1[32], b1[48]};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long r = r0 + 16 * wave + 4 * a + l4, c = c0 + 16 * q + l15;
-            if (MODE == MODE_FACTOR || (r < n && c < n)) {
-                double* dst = out + r * ldo + c;
-                if (nt) __builtin_nontemporal_store(v[a][q], dst); else *dst = v[a][q];
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb0[q], acc[q], 0, 0, 0);
+                if (ks + 8 < kk) {
+                    const double* a2 = ap + (ks + 8) * GSTP;
+                    const double* b2 = bp + (ks + 8) * GSTP;
+                    fa0 = a2[0]; fb0[0] = b2[0]; fb0[1] = b2[16]; fb0[2] = b2[32]; fb0[3] = b2[48];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb1[q], acc[q], 0, 0, 0);
             }
         }
-    if (MODE == MODE_SYM && tile.x != tile.y) {
-        // mirrored store out[c][r]: transpose through LDS (the staged coordinates are dead), 64-double runs per column
-        __syncthreads();
+        if constexpr (NP == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) nr[a] = nrm[r0 + 16 * wave + 4 * a + l4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nc[q] = nrm[c0 + 16 * q + l15];
+        }
+        double v[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) gsm[(16 * q + l15) * GSTP + 16 * wave + 4 * a + l4] = v[a][q];
-        __syncthreads();
-        const int pr = t & 31, rw = t >> 5;
+            for (int q = 0; q < 4; ++q) {
+                const long r = r0 + 16 * wave + 4 * a + l4, c = c0 + 16 * q + l15;
+                double s2 = fmax(fma(-2.0, acc[q][a], nr[a] + nc[q]), 0.0);
+                if (r == c) s2 = 0.0;
+                double val = sf2 * exp_nonpos(-0.5 * s2);
+                if (MODE == MODE_FACTOR) {
+                    if (r < n && c < n) val = val * inv_sn2 + (r == c ? 1.0 : 0.0);
+                    else val = (r == c) ? 1.0 : 0.0;
+                    if (c < r) val = 0.0;              // diagonal tiles: exact zeros below the diagonal (row-major upper view)
+                }
+                v[a][q] = val;
+            }
+        // direct store, row-major.  Full tiles with an even leading dimension: adjacent lanes trade one value each (DPP), the even
+        // lane stores columns (c, c + 1) of row a, the odd lane columns (c - 1, c) of row a + 1: 16-byte stores, half as many
+        const bool full = MODE == MODE_FACTOR || (r0 + ST <= n && c0 + ST <= n);
+        if (full && !(ldo & 1)) {
+            const bool odd = l15 & 1;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int cl = p * 8 + rw;
-            const long c = c0 + cl, r = r0 + 2 * pr;
-            if (c < n) {
-                const double2_t val = *(const double2_t*)(gsm + cl * GSTP + 2 * pr);
-                if (r + 1 < n && ((ldo & 1) == 0)) {
-                    double2_t* dst = (double2_t*)(out + c * ldo + r);
+            for (int a = 0; a < 4; a += 2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double x0 = v[a][q], x1 = v[a + 1][q];
+                    const double n0 = gram_swap_adjacent(x0), n1 = gram_swap_adjacent(x1);
+                    const double2_t val = odd ? double2_t{n1, x1} : double2_t{x0, n0};
+                    const long r = r0 + 16 * wave + 4 * (odd ? a + 1 : a) + l4, c = c0 + 16 * q + (l15 & ~1);
+                    double2_t* dst = (double2_t*)(out + r * ldo + c);
                     if (nt) __builtin_nontemporal_store(val, dst); else *dst = val;
-                } else {
-                    if (r < n) out[c * ldo + r] = val[0];
-                    if (r + 1 < n) out[c * ldo + r + 1] = val[1];
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long r = r0 + 16 * wave + 4 * a + l4, c = c0 + 16 * q + l15;
+                    if (MODE == MODE_FACTOR || (r < n && c < n)) out[r * ldo + c] = v[a][q];
+                }
+        }
+        if (MODE == MODE_SYM && tc2.x != tc2.y) {
+            // mirrored store out[c][r]: transpose through LDS (this tile's coordinates are consumed), 64-double runs per column
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gsm[(16 * q + l15) * GSTP + 16 * wave + 4 * a + l4] = v[a][q];
+            __syncthreads();
+            const int pr = t & 31, rw = t >> 5;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int cl = p * 8 + rw;
+                const long c = c0 + cl, r = r0 + 2 * pr;
+                if (c < n) {
+                    const double2_t val = *(const double2_t*)(gsm + cl * GSTP + 2 * pr);
+                    if (r + 1 < n && ((ldo & 1) == 0)) {
+                        double2_t* dst = (double2_t*)(out + c * ldo + r);
+                        if (nt) __builtin_nontemporal_store(val, dst); else *dst = val;
+                    } else {
+                        if (r < n) out[c * ldo + r] = val[0];
+                        if (r + 1 < n) out[c * ldo + r + 1] = val[1];
+                    }
                 }
             }
         }
+        if (next >= ntiles) break;
+        tile = next;
+        if constexpr (NP > 0) {
+            __syncthreads();                            // every wave is done with the LDS image of this tile (and of its mirror)
+            commit();
+            __syncthreads();
+            tc2 = nx;
+        } else tc2 = tiles[tile];
     }
 }
 
@@ -694,22 +762,21 @@ static int cov_gram_dispatch(int mode, const double* XT, long ldp, long n, long 
     const int CH = dpad < 64 ? dpad : 64;
     const size_t shm = std::max<size_t>((size_t)2 * CH * GSTP, (size_t)ST * GSTP) * sizeof(double);
     const int nt_ = (mode != MODE_FACTOR && (double)n * (double)n * 8.0 >= 1073741824.0) ? 1 : 0;
-    static std::atomic<size_t> attr_f{0}, attr_s{0};
-    if (mode == MODE_FACTOR) {
-        if (attr_f.load(std::memory_order_acquire) < shm) {
-            (void)hipFuncSetAttribute((const void*)cov_gram_kernel<MODE_FACTOR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            attr_f.store(shm, std::memory_order_release);
-        }
-        hipLaunchKernelGGL(cov_gram_kernel<MODE_FACTOR>, dim3((unsigned)ntiles), dim3(256), shm, st, XT, ldp, n, dpad, cs.cp.sf2, inv_sn2,
-                           out, ldo, tiles, prep, prep + HADAMARD_PREP_MU, nt_);
-    } else {
-        if (attr_s.load(std::memory_order_acquire) < shm) {
-            (void)hipFuncSetAttribute((const void*)cov_gram_kernel<MODE_SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            attr_s.store(shm, std::memory_order_release);
-        }
-        hipLaunchKernelGGL(cov_gram_kernel<MODE_SYM>, dim3((unsigned)ntiles), dim3(256), shm, st, XT, ldp, n, dpad, cs.cp.sf2, inv_sn2,
-                           out, ldo, tiles, prep, prep + HADAMARD_PREP_MU, nt_);
-    }
+    const unsigned grid = (unsigned)std::min<long>(ntiles, 2048);              // persistent: 2 resident per CU, the rest queue
+#define GRAM_LAUNCH(M, NPV) do {                                                                                                  \
+        static std::atomic<int> attr_done{0};                                /* per instantiation: once */                         \
+        if (!attr_done.load(std::memory_order_acquire)) {                                                                          \
+            (void)hipFuncSetAttribute((const void*)cov_gram_kernel<M, NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, 70000);     \
+            attr_done.store(1, std::memory_order_release);                                                                         \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((cov_gram_kernel<M, NPV>), dim3(grid), dim3(256), shm, st, XT, ldp, n, dpad, cs.cp.sf2, inv_sn2, out, ldo,  \
+                           tiles, ntiles, prep, prep + HADAMARD_PREP_MU, nt_);                                                     \
+    } while (0)
+#define GRAM_MODE(M) do { switch (dpad) { case 32: GRAM_LAUNCH(M, 8); break; case 48: GRAM_LAUNCH(M, 12); break;                  \
+                                          case 64: GRAM_LAUNCH(M, 16); break; default: GRAM_LAUNCH(M, 0); } } while (0)
+    if (mode == MODE_FACTOR) GRAM_MODE(MODE_FACTOR); else GRAM_MODE(MODE_SYM);
+#undef GRAM_MODE
+#undef GRAM_LAUNCH
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 bool cov_gram_applies(const CovSpec& cs, int dpad) {
