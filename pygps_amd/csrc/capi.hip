@@ -507,6 +507,17 @@ int batch_tile_list(pgp_ctx* c, int mt0, int nt, int nb, int dmt, const int** ou
     return PGP_OK;
 }
 
+// RBF / RBFard values at d >= 32: the Gram form on the matrix cores (csrc/assemble.hip cov_gram_kernel) when a bound on the centred,
+// scaled points' squared norms -- sum_k (scale_k max_p |x_pk - mean_k|)^2, from the statistics pgp_set_data took and the scales
+// of this call -- keeps its extra rounding error below ~5e-14 relative in K; else the reference's difference form.
+bool gram_assembly_applies(pgp_ctx* c, const CovSpec& cs) {
+    if (!c->gram_assembly || !cov_gram_applies(cs, c->dpad) || (long)c->xdev2.size() != c->d || (long)cs.scale.size() < c->d) return false;
+    if (c->gram_assembly == 2) return true;
+    double bound = 0.0;
+    for (long k = 0; k < c->d; ++k) bound += cs.scale[k] * cs.scale[k] * c->xdev2[k];
+    return bound <= 64.0;
+}
+
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
     if (!st) st = c->st;
     if (g.batch < 1) g.batch = 1;
@@ -1085,14 +1096,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     // ---- S1': fused assembly of B = K/sn2 + I into the factor buffer --------------------------
     HIP_TRY(hipEventRecord(c->ev[0], st));
     CHK(upload_scaled(c, c->x_dev, n, d, sc, c->XsT, np, c->dpad, c->scale_dev));
-    // RBF / RBFard at d >= 32: the Gram form on the matrix cores when a bound on the centred, scaled points' squared norms keeps
-    // its extra rounding error below ~5e-14 relative in K (csrc/assemble.hip cov_gram_kernel), else the reference's difference form
-    bool gram = false;
-    if (c->gram_assembly && cov_gram_applies(cp, c->dpad) && (long)c->xdev2.size() == d) {
-        double bound = 0.0;
-        for (long k = 0; k < d; ++k) bound += sc[k] * sc[k] * c->xdev2[k];
-        gram = c->gram_assembly == 2 || bound <= 64.0;
-    }
+    const bool gram = gram_assembly_applies(c, cp);
     if (gram) CHK(hadamard_prepare_launch(c->XsT, np, n, np, c->dpad, cp, c->prep, st, /*force=*/true));
     {
         ProfScope ps(c, PC_ASSEMBLE, 0.0, 8.0 * (double)np * (np + 1) / 2.0 + 8.0 * (double)n * d);

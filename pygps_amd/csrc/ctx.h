@@ -313,6 +313,7 @@ int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with
                   long lde = 0);
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);
 int batch_tile_list(pgp_ctx* c, int mt0, int nt, int nb, int dmt, const int** out, int* n);
+bool gram_assembly_applies(pgp_ctx* c, const CovSpec& cs);
 int diag_block_factor(pgp_ctx* c, const double* src, long lds, int w, double* Fd, long ldf, double* Ed, long lde,
                       int info_base, hipStream_t st, hipEvent_t staged = nullptr);
 int trtri_lower(pgp_ctx* c, const double* L, long ldl, double* W, long ldw, double* T, long np);

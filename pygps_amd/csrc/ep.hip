@@ -1163,6 +1163,10 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
     if (dense) HIP_TRY(hipMemcpy2DAsync(w.Kd, np * sizeof(double), Kdense, n * sizeof(double), n * sizeof(double), n, hipMemcpyHostToDevice, st));
     else {
         EP_TRY(upload_scaled(c, c->x_dev, n, d, sc, c->XsT, np, c->dpad, c->scale_dev));
+        if (gram_assembly_applies(c, cp)) {            // RBF / RBFard at d >= 32 (cfg 5: d = 32): the Gram form on the matrix cores
+            EP_TRY(hadamard_prepare_launch(c->XsT, np, n, np, c->dpad, cp, c->prep, st, /*force=*/true));
+            EP_TRY(cov_sym_gram_launch(c->XsT, np, n, c->dpad, cp, w.Kd, np, c->prep, st));
+        } else
         EP_TRY(cov_sym_launch(c->XsT, np, n, c->dpad, cp, w.Kd, st, np));
     }
     std::vector<double> m(n, 0.0), y(n), ttau(n, 0.0), tnu(n, 0.0), mu(n, 0.0), dsig(n, kdiag);

@@ -232,3 +232,31 @@ def test_gram_form_assembly_against_the_difference_form(lib):
                       faithful=False)
     assert relerr(b1[0], ref["nlZ"]) < 1e-9 and relerr(b1[2], ref["alpha"]) < 1e-7
     assert relerr(b2[2], ref["alpha"]) > 10 * relerr(b1[2], ref["alpha"])        # ... and the forced Gram form is visibly worse here
+
+
+def test_gram_form_assembly_in_ep_cfg5_recipe(lib):
+    """EP builds the full symmetric K (csrc/ep.hip) -- for RBF at d = 32 (cfg 5's recipe) in the Gram form too (the kernel's
+    MODE_SYM: mirrored stores, ragged n).  Forbidden vs forced vs chosen at N = 300 (ragged against the 64-tiles) and against the
+    reference's fixture at N = 512."""
+    import pygps_amd as pyGPs
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    res = {}
+    try:
+        for o in (0, 1, 2):
+            _lib.check(lib.pgp_set_option(ctx, b"gram_assembly", o))
+            for N in (300, 512):
+                x, y = synth_cls(N, 32)
+                m = pyGPs.GPC()
+                m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(32.0)), 0.0))
+                nlZ, dnlZ, post = m.getPosterior(x, y)
+                res[o, N] = (nlZ, np.array(post.alpha), np.array(dnlZ.cov), np.asarray(post.L).copy(), int(m.inffunc.sweeps))
+    finally:
+        lib.pgp_set_option(ctx, b"gram_assembly", 1)
+    for N in (300, 512):
+        a0, a1, a2 = res[0, N], res[1, N], res[2, N]
+        assert a1[0] == a2[0] and np.array_equal(a1[1], a2[1])                     # the default chose the Gram form
+        assert a0[4] == a2[4] and relerr(a2[0], a0[0]) < 1e-11 and relerr(a2[1], a0[1]) < 1e-9 and relerr(a2[2], a0[2]) < 1e-8
+        assert relerr(a2[3], a0[3]) < 1e-10
+    g = golden("G8ii_ep_d32_N512")
+    assert relerr(res[1, 512][0], g["nlZ"]) < 1e-8 and relerr(res[1, 512][1], g["alpha"]) < 1e-6
