@@ -248,3 +248,22 @@ def test_G13_mean_composites_match_the_reference():
         h = [v + 0.01 for v in m.hyp]
         m.hyp = h
         assert list(m.hyp) == h                       # setter reaches the children
+
+
+def test_bench_cpu_baselines_of_the_other_configs_are_labelled_extrapolations():
+    """bench.py's CPU baselines for cfg 3 / 4 / 5: bounded oracle samples scaled by a stated model -- each object
+    says so (`extrapolated`, the sample, the reference's own recorded wall time) and carries the contract's keys."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.cpu_baseline_other_configs(0.021)
+    assert set(out) == {"cfg3", "cfg4", "cfg5"}
+    for k, v in out.items():
+        assert "error" not in v, (k, v)
+        assert v["unit"] == "fits/s" and v["kind"] == "port" and v["extrapolated"] is True and v["value"] > 0
+        assert "EXTRAPOLATED" in v["sample"] or "derived" in v["sample"]
+    assert "2969 s" in out["cfg3"]["reference_recorded"] and "43 min" in out["cfg5"]["reference_recorded"]
+    assert out["cfg4"]["value"] == 0.021
