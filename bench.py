@@ -175,6 +175,16 @@ def extras(lib, _lib, local, d, roof):
             ba = 8.0 * na * na + 8.0 * na * dd
             roof[key] = {"ms": ms_a.value, "GBs": ba / ms_a.value / 1e6, "bound": "hbm",
                          "frac_of_hbm_peak": ba / ms_a.value / 1e6 / PEAK_HBM_GBS}
+            if dd == 16:
+                # the same box's answer to "what do the stores alone cost": the 'train' tiles written twice in the same order by a
+                # kernel without any arithmetic (csrc/testhooks.hip pgp_test_store_roof; no symmetric tile pattern of
+                # tools/store_roof.hip writes faster), hipMemsetAsync and a one-store-per-thread linear fill over the same bytes
+                o3 = (ctypes.c_double * 3)()
+                if lib.pgp_test_store_roof(ctx, na, 0, 50, o3) == 0 and min(o3) > 0:
+                    roof[key].update({"stores_alone_same_pattern_ms": o3[0], "frac_of_stores_alone": o3[0] / ms_a.value,
+                                      "stores_alone_frac_of_hbm_peak": 8.0 * na * na / o3[0] / 1e6 / PEAK_HBM_GBS,
+                                      "memset_frac_of_hbm_peak": 8.0 * na * na / o3[1] / 1e6 / PEAK_HBM_GBS,
+                                      "linear_fill_frac_of_hbm_peak": 8.0 * na * na / o3[2] / 1e6 / PEAK_HBM_GBS})
             if dd == 64:
                 # d = 64 (round 4): this is the form a FIT picks for such data -- squared distances in the Gram form on the matrix
                 # cores (csrc/assemble.hip cov_gram_kernel; the per-call means and norms are inside the timed loop), chosen by the

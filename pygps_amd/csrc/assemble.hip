@@ -217,9 +217,10 @@ __device__ __forceinline__ void slab_accum(const double* __restrict__ smx, doubl
 // next.  One workgroup per tile ran the phases load -> VALU -> store of all resident workgroups in lock-step:
 // HBM idle during the VALU phase, VALU idle (55 % busy by SQ_ACTIVE_INST_VALU) during the store phase.
 __device__ double2_t g_trash[1];       // out-of-range lanes of the FAST store path write here
-// nt (uniform): outputs of a gigabyte and more are streamed past the caches (non-temporal stores): measured on one box, full
-// symmetric K at N = 16384: RBF 0.486 -> 0.470 ms, Matern 0.598 -> 0.556 ms; at N = 8192 (512 MB, half of it fits the
-// Infinity Cache) they cost 8 %, so smaller outputs keep the plain stores
+// nt (uniform): non-temporal stores, option "asm_nt" (default 0).  Round 4 first read them as a 3 % gain for outputs >= 1 GB; alternated
+// in ONE process (tools/gpu_probe.py asm nt=1 nt=0 ...) they are neutral for RBF (0.423-0.432 ms either way at N = 16384) and cost
+// Matern up to 15 % -- the earlier reading compared a process's first measurement (always ~10 % slow) with its second.  A kernel
+// that only issues this tile pattern's stores takes 0.40 ms (pgp_test_store_roof): the assembly runs at 0.93 of that
 #define TILE_STORE(dst, val) do { if (nt) __builtin_nontemporal_store((val), (dst)); else *(dst) = (val); } while (0)
 
 // FAST: ldo, n and m are even -> every store is an aligned, *unconditional* double2 store (lanes outside the matrix
@@ -682,6 +683,8 @@ static int g_tile_grid = 4096;                     // persistent workgroups (4 r
                                                    // (round 4, three alternations on one box, full symmetric RBF d = 16: N = 16384 56-58 % of the HBM peak
                                                    //  at 2048 workgroups, 62-64 % at 4096; N = 8192 61-62 % / 62-65 %)
 void cov_tile_set_grid(int g) { g_tile_grid = g; }
+static int g_tile_nt = 0;                          // non-temporal stores: 0 never (default), 1 always, -1 for outputs >= 1 GB; option "asm_nt"
+void cov_tile_set_nt(int v) { g_tile_nt = v; }
 
 template <int MODE>
 static int cov_tile_dispatch(const CovSpec& cs, int train, long ntr, long ntc_, hipStream_t st, const double* XrT, long ldr,
@@ -690,7 +693,7 @@ static int cov_tile_dispatch(const CovSpec& cs, int train, long ntr, long ntc_, 
     if (!tiles) { const int rc = tile_table(MODE != MODE_RECT, ntr, ntc_, &tiles, &ntiles); if (rc != PGP_OK) return rc; }
     if (ntiles == 0) return PGP_OK;
     const unsigned nblk = g_tile_grid > 0 ? (unsigned)std::min<long>(ntiles, g_tile_grid) : (unsigned)ntiles;
-    const int nt_ = (MODE != MODE_FACTOR && (double)n * (double)m * 8.0 >= 1073741824.0) ? 1 : 0;
+    const int nt_ = g_tile_nt >= 0 ? g_tile_nt : ((MODE != MODE_FACTOR && (double)n * (double)m * 8.0 >= 1073741824.0) ? 1 : 0);
     if (cs.prog) {
         CovProgram pg = cs.pg;
         for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = train;
@@ -761,7 +764,7 @@ static int cov_gram_dispatch(int mode, const double* XT, long ldp, long n, long 
     if (ntiles == 0) return PGP_OK;
     const int CH = dpad < 64 ? dpad : 64;
     const size_t shm = std::max<size_t>((size_t)2 * CH * GSTP, (size_t)ST * GSTP) * sizeof(double);
-    const int nt_ = (mode != MODE_FACTOR && (double)n * (double)n * 8.0 >= 1073741824.0) ? 1 : 0;
+    const int nt_ = g_tile_nt >= 0 ? g_tile_nt : ((mode != MODE_FACTOR && (double)n * (double)n * 8.0 >= 1073741824.0) ? 1 : 0);
     const unsigned grid = (unsigned)std::min<long>(ntiles, 2048);              // persistent: 2 resident per CU, the rest queue
 #define GRAM_LAUNCH(M, NPV) do {                                                                                                  \
         static std::atomic<int> attr_done{0};                                /* per instantiation: once */                         \

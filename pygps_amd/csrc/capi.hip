@@ -195,6 +195,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { cov_tile_set_grid(value); return PGP_OK; }
+    if (!strcmp(name, "asm_nt")) { cov_tile_set_nt(value); return PGP_OK; }
     return -2;
 }
 

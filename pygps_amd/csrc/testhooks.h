@@ -26,6 +26,8 @@ int pgp_test_wave_costs(pgp_ctx* ctx, double* out16);
 int pgp_test_slot_probe(pgp_ctx* ctx, int nwg, int lds_kb, int hold_us, int reserve, int probe_lds_kb, int delay_us, double* out4);
 int pgp_test_cumask_gemm(pgp_ctx* ctx, int M, int K, int reserve_per_xcd, int stride, int iters, double* out2);
 int pgp_test_assemble(pgp_ctx* ctx, int kind, int mode, int64_t n, int64_t d, int iters, double* ms_out);
+/* the stores of the 'train' assembly alone (out3[0], ms), hipMemsetAsync (out3[1]) and a linear fill (out3[2]) over 8 n^2 bytes */
+int pgp_test_store_roof(pgp_ctx* ctx, int64_t n, int grid, int iters, double* out3);
 #ifdef __cplusplus
 }
 #endif

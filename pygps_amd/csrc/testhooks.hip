@@ -304,7 +304,9 @@ int pgp_test_assemble(pgp_ctx* c, int kind, int mode, int64_t n, int64_t d, int 
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     int rc = PGP_OK;
-    for (int it = -1; it < iters && rc == PGP_OK; ++it) {
+    // warm-up = at least 100 launches: the first 30-50 ms of device work after an idle spell run up to 25 % slower (clocks ramping:
+    // 10 launches right after process start read 0.55 ms, the next tens 0.47 / 0.45, steady state 0.43: tools/first_call.py)
+    for (int it = -std::max(100, iters); it < iters && rc == PGP_OK; ++it) {
         if (it == 0) HIP_TRY(hipEventRecord(e0, c->st));
         if (gram) {
             rc = hadamard_prepare_launch(XT, np, n, np, dpad, cp, prep, c->st, true);
@@ -323,6 +325,73 @@ int pgp_test_assemble(pgp_ctx* c, int kind, int mode, int64_t n, int64_t d, int 
     (void)hipFree(xd); (void)hipFree(XT); (void)hipFree(scd); (void)hipFree(out);
     if (prep) (void)hipFree(prep);
     return rc;
+}
+
+// What the box gives a kernel that does NOTHING but the stores of the 'train' assembly: the same 64 x 64 tiles of the upper
+// triangle in the same super-tile order, each written twice (tile + mirror, 512-byte runs), persistent workgroups -- no
+// coordinates, no distances, no exp.  out3[0] = ms per launch of that kernel, out3[1] = ms of hipMemsetAsync over the same
+// 8 n^2 bytes, out3[2] = ms of a linear fill with one 16-byte store per thread.  The assembly kernel's HBM fraction is read
+// against out3[0]: no symmetric tile pattern measured in tools/store_roof.hip writes faster (0.65-0.69 of 8 TB/s box to box).
+namespace {
+__global__ __launch_bounds__(256) void store_only_sym_kernel(double* out, long n, const int2* tab, long ntiles, double v) {
+    const int t = threadIdx.x;
+    for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const int2 ij = tab[ti];
+        double* base = out + (long)ij.x * 64 * n + (long)ij.y * 64;
+        double* mir = out + (long)ij.y * 64 * n + (long)ij.x * 64;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int e = t + 256 * p, r = e >> 5, cpair = e & 31;
+            *(double2_t*)(base + (long)r * n + 2 * cpair) = double2_t{v, v + 1.0};
+        }
+        if (ij.x != ij.y) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int e = t + 256 * p, r = e >> 5, cpair = e & 31;
+                *(double2_t*)(mir + (long)r * n + 2 * cpair) = double2_t{v, v + 1.0};
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void store_only_linear_kernel(double* out, long n2, double v) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i + 1 < n2) *(double2_t*)(out + i) = double2_t{v, v + 1.0};
+}
+}  // namespace
+
+int pgp_test_store_roof(pgp_ctx* c, int64_t n, int grid, int iters, double* out3) {
+    if (!c || !out3 || n <= 0 || n % 64 || iters <= 0) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    const long nt = n / 64, S = 8, nst = (nt + S - 1) / S;
+    std::vector<int2> h;
+    for (long SI = 0; SI < nst; ++SI)
+        for (long SJ = SI; SJ < nst; ++SJ)
+            for (long i = SI * S; i < std::min(nt, SI * S + S); ++i)
+                for (long j = std::max(i, SJ * S); j < std::min(nt, SJ * S + S); ++j) h.push_back(make_int2((int)i, (int)j));
+    int2* tab; double* out;
+    HIP_TRY(hipMalloc((void**)&tab, h.size() * sizeof(int2)));
+    HIP_TRY(hipMalloc((void**)&out, (size_t)n * n * 8));
+    HIP_TRY(hipMemcpy(tab, h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const long ntl = (long)h.size(), n2 = (long)n * n;
+    const unsigned g = (unsigned)std::min<long>(ntl, grid > 0 ? grid : 4096);
+    for (int which = 0; which < 3; ++which) {
+        for (int it = -std::max(50, iters / 2); it < iters; ++it) {
+            if (it == 0) HIP_TRY(hipEventRecord(e0, c->st));
+            if (which == 0) hipLaunchKernelGGL(store_only_sym_kernel, dim3(g), dim3(256), 0, c->st, out, (long)n, tab, ntl, 1.0);
+            else if (which == 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)n2 * 8, c->st));
+            else hipLaunchKernelGGL(store_only_linear_kernel, dim3((unsigned)((n2 / 2 + 255) / 256)), dim3(256), 0, c->st, out, n2, 1.0);
+        }
+        HIP_TRY(hipEventRecord(e1, c->st));
+        HIP_TRY(hipStreamSynchronize(c->st));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        out3[which] = ms / iters;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(tab); (void)hipFree(out);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
 // Does a small panel kernel on the high-priority stream overlap a big trailing GEMM on the main stream?

@@ -142,9 +142,11 @@ if __name__ == "__main__":
         fit(8192, 16, want=2, prof=False)
         fit(2048, 16, prof=False)
     if "asm" in what:
+     for ntv in [int(a[3:]) for a in what if a.startswith("nt=")] or [-1]:
+      lib.pgp_set_option(ctx, b"asm_nt", ntv)
       for grid in [int(a[5:]) for a in what if a.startswith("grid=")] or [4096]:
         lib.pgp_set_option(ctx, b"asm_grid", grid)
-        print("asm_grid", grid)
+        print("asm_grid", grid, "asm_nt", ntv)
         for (kind, n, d) in ((0, 8192, 16), (0, 16384, 16), (1, 16384, 64), (2, 16384, 16), (0, 16384, 4)):
             for mode in (0, 2):
                 ms = C.c_double()
@@ -152,6 +154,12 @@ if __name__ == "__main__":
                 by = 8.0 * n * n * (1.0 if mode == 0 else 0.5) + 8.0 * n * d
                 print("assemble kind=%d n=%d d=%d mode=%d: %.3f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (
                     kind, n, d, mode, ms.value, by / ms.value / 1e6, by / ms.value / 1e6 / 80.0))
+    if "asm" in what or "stores" in what:
+        o3 = (C.c_double * 3)()
+        for n in (8192, 16384):
+            assert lib.pgp_test_store_roof(ctx, n, 0, 20, o3) == 0
+            print("stores alone n=%d: 'train' tile pattern %.3f ms (%.1f%% of 8 TB/s), hipMemsetAsync %.3f ms (%.1f%%), linear fill %.3f ms (%.1f%%)" % (
+                n, o3[0], 8.0 * n * n / o3[0] / 1e6 / 80.0, o3[1], 8.0 * n * n / o3[1] / 1e6 / 80.0, o3[2], 8.0 * n * n / o3[2] / 1e6 / 80.0))
     if "ep" in what:
         import pygps_amd as pyGPs
         for N in (1024, 4096):
