@@ -196,6 +196,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { cov_tile_set_grid(value); return PGP_OK; }
     if (!strcmp(name, "asm_nt")) { cov_tile_set_nt(value); return PGP_OK; }
+    if (!strcmp(name, "ard_grad_form")) { if (value < 0 || value > 2) return -3; c->ard_grad_form = value; return PGP_OK; }
     return -2;
 }
 
@@ -305,8 +306,17 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
         double iso;
         CHK(make_leaf(kind, hyp, nhyp, para, flags, d, cs.cp, iso));
         cs.scale.assign(d, iso);
-        if (kind == PGP_COV_RBFARD || kind == PGP_COV_RQARD)
+        if (kind == PGP_COV_RBFARD || kind == PGP_COV_RQARD) {
             for (long k = 0; k < d; ++k) cs.scale[k] = 1.0 / exp(hyp[k]);
+            // the gradient pass weights its sums with K in the Gram form (hadamard_ard_kernel): relative error eps (|a|^2 + |b|^2) of
+            // the scaled, centred points.  Beyond |a|^2 ~ 1e8 (2e-8 in K; dnlZ is held to 1e-7) the difference-form kernel runs
+            // instead -- data spread over ten thousand length scales; the statistics are those of the resident x (pgp_set_data)
+            double bound = 0.0;
+            if (c && (long)c->xdev2.size() == d)
+                for (long k = 0; k < d; ++k) bound += cs.scale[k] * cs.scale[k] * c->xdev2[k];
+            cs.ard_grad_diff = !(bound <= ARD_GRAM_GRAD_BOUND) || (c && c->ard_grad_form == 2);
+            if (c && c->ard_grad_form == 1) cs.ard_grad_diff = false;
+        }
         cs.ncov = nhyp;
         // Matern and PiecePoly accept der == 2 ("derivative w.r.t. the order" = zeros, cov.py:1178, 778)
         cs.nder = (kind == PGP_COV_MATERN || kind == PGP_COV_PIECEPOLY) ? 3 : nhyp;
@@ -387,6 +397,12 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
     cs.scale.assign(d, 1.0);
     cs.ncov = nhyp; cs.nder = nhyp;
     cs.cp = CovParams{};
+    if (P.ard_leaf >= 0 && c && (long)c->xdev2.size() == d) {          // as for the plain ARD kinds: per-coordinate sums in the difference form
+        double b1 = 0.0, b2 = 0.0;                                   // when a leaf's weighted, centred points lie too far out
+        for (long k = 0; k < d && k < CP_MAXARD; ++k) { b1 += P.ardw[k] * c->xdev2[k]; if (P.ard_leaf2 >= 0) b2 += P.ardw2[k] * c->xdev2[k]; }
+        cs.ard_grad_diff = !(std::max(b1, b2) <= ARD_GRAM_GRAD_BOUND);
+    }
+    if (c && P.ard_leaf >= 0 && c->ard_grad_form) cs.ard_grad_diff = c->ard_grad_form == 2;
     return PGP_OK;
 }
 

@@ -95,6 +95,7 @@ struct pgp_ctx {
            *rvec = nullptr, *zvec = nullptr, *partial = nullptr, *scal = nullptr;
     long partial_cap = 0;
     double* prep = nullptr;             // [coordinate means | squared norms of the centred points] of the current XsT (hadamard_prep_count(np))
+    int ard_grad_form = 0;              // option "ard_grad_form": 0 = by the norm bound, 1 = always the Gram-form weights, 2 = always the difference form
     std::vector<double> xdev2;          // per coordinate: max_p (x_pk - mean_k)^2 of the resident x (host, pgp_set_data)
     int gram_assembly = 1;              // RBF / RBFard assembly of a fit in the Gram form on the matrix cores: 1 when the host's bound on
                                         // the centred, scaled points' squared norms allows it (csrc/assemble.hip), 0 never, 2 always
@@ -313,6 +314,7 @@ int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with
                   long lde = 0);
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);
 int batch_tile_list(pgp_ctx* c, int mt0, int nt, int nb, int dmt, const int** out, int* n);
+constexpr double ARD_GRAM_GRAD_BOUND = 1.0e8;     // max squared norm of a scaled, centred point for the Gram-form gradient weights
 bool gram_assembly_applies(pgp_ctx* c, const CovSpec& cs);
 int diag_block_factor(pgp_ctx* c, const double* src, long lds, int w, double* Fd, long ldf, double* Ed, long lde,
                       int info_base, hipStream_t st, hipEvent_t staged = nullptr);

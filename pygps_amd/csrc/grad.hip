@@ -171,6 +171,54 @@ __device__ __forceinline__ void ard_dim_reduce(const double* __restrict__ XT, lo
     __syncthreads();                                // a second call (second ARD leaf) reuses sm and ardA / ardB
 }
 
+// The same sums in the DIFFERENCE form -- sum_rc w_rc (x_rk - x_ck)^2 term by term, what the reference's per-coordinate
+// getDerMatrix computes (Core/cov.py:924-931): three VALU instructions per element and coordinate, any D.  The fallback for data
+// whose scaled, centred points lie too far out for the product form above (its error is eps sum |w| |x|^2, this one's
+// eps sum |w| (x_r - x_c)^2): make_spec sets CovSpec::ard_grad_diff beyond |x|^2 = 1e8.  sm: 2 * SKC * STP doubles.
+__device__ __forceinline__ void ard_dim_reduce_diff(const double* __restrict__ XT, long ldp, long r0, long c0, int dpad,
+                                                    double* __restrict__ sm, const double (&w)[4][4],
+                                                    const double* __restrict__ wk, int D, double* __restrict__ out) {
+    __shared__ double dred[4][SKC];
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15, lane = t & 63, wave = t >> 6;
+    double* xr = sm;
+    double* xc = sm + SKC * STP;
+    for (int k0 = 0; k0 < dpad; k0 += SKC) {
+        __syncthreads();                            // the previous slab, its sums and the caller's use of sm are consumed
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int v = t + p * 256, k = v >> 5, pr = v & 31;
+            *(double2_t*)(xr + k * STP + 2 * pr) = *(const double2_t*)(XT + (long)(k0 + k) * ldp + r0 + 2 * pr);
+            *(double2_t*)(xc + k * STP + 2 * pr) = *(const double2_t*)(XT + (long)(k0 + k) * ldp + c0 + 2 * pr);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < SKC; ++k) {
+            const double2_t r01 = *(const double2_t*)(xr + k * STP + 4 * tr);
+            const double2_t r23 = *(const double2_t*)(xr + k * STP + 4 * tr + 2);
+            const double2_t c01 = *(const double2_t*)(xc + k * STP + 2 * tc);
+            const double2_t c23 = *(const double2_t*)(xc + k * STP + 2 * tc + 32);
+            const double rv[4] = {r01[0], r01[1], r23[0], r23[1]};
+            const double cv[4] = {c01[0], c01[1], c23[0], c23[1]};
+            double sacc = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double df = rv[a] - cv[b];
+                    sacc = fma(w[a][b], df * df, sacc);
+                }
+            sacc = wave_sum(sacc);
+            if (lane == 0) dred[wave][k] = sacc;
+        }
+        __syncthreads();
+        if (t < SKC && k0 + t < D) {
+            const double v = (dred[0][t] + dred[1][t]) + (dred[2][t] + dred[3][t]);
+            out[k0 + t] = wk ? wk[k0 + t] * v : v;
+        }
+    }
+    __syncthreads();                                // a second call (second ARD leaf) reuses sm and dred
+}
+
 // mu[k] = mean over the n points of coordinate k (fixed order); one block per coordinate
 __global__ __launch_bounds__(256) void coord_mean_kernel(const double* __restrict__ XT, long ldp, long n, double* __restrict__ mu) {
     __shared__ double red[4];
@@ -261,7 +309,9 @@ __global__ __launch_bounds__(256) void hadamard_reduce_kernel(const double* __re
     double* out = partial + (long)blockIdx.x * (long)(ncov + 1);
     __shared__ double red16[16];
     if (cov_is_ard(cp)) {
-        ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, nullptr, mu, cp.D, out);
+        // this kernel serves the plain ARD kinds only when CovSpec::ard_grad_diff is set (hadamard_partial_launch): the
+        // difference form throughout -- K above (sqdist_tile) and the per-coordinate sums here
+        ard_dim_reduce_diff(XT, ldp, r0, c0, dpad, sm, w, nullptr, cp.D, out);
         double v4[4] = {g1, tq, g2, 0.0};
         block_sum4(v4, red16);
         if (t == 0) {
@@ -647,11 +697,14 @@ __global__ __launch_bounds__(256) void hadamard_prog_kernel(const double* __rest
 #pragma unroll
         for (int e = 0; e < 16; ++e) w[e >> 2][e & 3] = sv1[e * 256];
         const int la = P.ard_leaf & 7;
-        ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, P.ardw, mu, P.leaf[la].D, out + P.hyp0[la]);
+        // mu == nullptr: the host asks for the difference form (CovSpec::ard_grad_diff, far-out data)
+        if (mu) ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w, P.ardw, mu, P.leaf[la].D, out + P.hyp0[la]);
+        else ard_dim_reduce_diff(XT, ldp, r0, c0, dpad, sm, w, P.ardw, P.leaf[la].D, out + P.hyp0[la]);
         if constexpr (PARD2) {
             const int lb = P.ard_leaf2 & 7;
             __syncthreads();
-            ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w2, P.ardw2, mu, P.leaf[lb].D, out + P.hyp0[lb]);
+            if (mu) ard_dim_reduce(XT, ldp, r0, c0, dpad, sm, w2, P.ardw2, mu, P.leaf[lb].D, out + P.hyp0[lb]);
+            else ard_dim_reduce_diff(XT, ldp, r0, c0, dpad, sm, w2, P.ardw2, P.leaf[lb].D, out + P.hyp0[lb]);
         }
     }
 #pragma unroll
@@ -904,6 +957,7 @@ int hadamard_partial_launch(const double* XT, long ldp, long n, long np, int dpa
     if (cs.prog) {
         CovProgram pg = cs.pg;
         for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = 1;
+        if (cs.ard_grad_diff) mu = nullptr;           // the kernels' switch to the difference-form per-coordinate sums
         if (pg.ard_leaf2 >= 0)
             hipLaunchKernelGGL(hadamard_prog_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
                                1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt, mu, b0);
@@ -913,7 +967,7 @@ int hadamard_partial_launch(const double* XT, long ldp, long n, long np, int dpa
         else
             hipLaunchKernelGGL(hadamard_prog_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, XT, ldp, n, dpad, pg, ncov,
                                1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt, mu, b0);
-    } else if (cs.cp.kind == 1 || cs.cp.kind == 6) {
+    } else if ((cs.cp.kind == 1 || cs.cp.kind == 6) && !cs.ard_grad_diff) {
         CovParams cp = cs.cp;
         cp.train = 1;
         const int CH = dpad < 64 ? dpad : 64;
@@ -941,6 +995,8 @@ int hadamard_partial_launch(const double* XT, long ldp, long n, long np, int dpa
                                       ncov, 1.0 / sn2, sn2, Binv, ldb, alpha, wv, partial, nt, mu, b0)
         switch (cp.kind) {
             case 0: HLAUNCH(0); break;
+            case 1: HLAUNCH(1); break;                // the plain ARD kinds with cs.ard_grad_diff: K in the difference form, the
+            case 6: HLAUNCH(6); break;                // per-coordinate sums on the matrix cores all the same (ard_dim_reduce)
             case 2: HLAUNCH(2); break;
             case 3: HLAUNCH(3); break;
             case 4: HLAUNCH(4); break;

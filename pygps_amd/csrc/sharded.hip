@@ -584,7 +584,13 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
             hipLaunchKernelGGL(panel_scalars_kernel, dim3(1), dim3(256), 0, main, Ld + (size_t)k * w * w, w, z, ldp, red + np);
         }
         hipLaunchKernelGGL(pack_status_kernel, dim3(1), dim3(1), 0, main, c->info_dev, red + np + 2);
-        if (hipGetLastError() != hipSuccess) return PGP_ERR_HIP;
+        if (hipGetLastError() != hipSuccess) {           // as inside the sweep: the others learn it from the all-reduce
+            if (world == 1) return PGP_ERR_HIP;
+            poison = PGP_ERR_HIP;
+            (void)hipDeviceSynchronize();
+            const double one = 1.0;
+            (void)hipMemcpy(red + np + 4, &one, sizeof(double), hipMemcpyHostToDevice);
+        }
     }
     CHK(comm_allreduce(m, red, (size_t)np + 5, 0, main));
     std::vector<double> head(8, 0.0);
@@ -702,7 +708,7 @@ int pgp_sharded_predict(pgp_ctx* c, pgp_comm* m, pgp_sfactor* f, const double* x
     double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *acc = nullptr, *V = nullptr;
     int arc = PGP_OK;
     auto take = [&](double** out, size_t bytes) { if (arc == PGP_OK) arc = tmp.alloc(out, bytes); };
-    CHK(tmp.alloc(&acc, NSB * sizeof(double)));
+    CHK(tmp.alloc(&acc, (NSB + 1) * sizeof(double)));            // [NSB]: "a rank failed in this batch", summed with the column sums
     take(&xd, NSB * d * sizeof(double));
     take(&XcT, (size_t)dpad * ldc * sizeof(double));
     take(&scd, dpad * sizeof(double));
@@ -722,10 +728,9 @@ int pgp_sharded_predict(pgp_ctx* c, pgp_comm* m, pgp_sfactor* f, const double* x
     HIP_TRY(hipMemcpyAsync(scd, f->cs.scale.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
     CovSpec cp = f->cs;
     cp.cp.der = -1; cp.pg.der = -1;
-    std::vector<double> acc_h(NSB);
-    for (long a = 0; a < ns; a += NSB) {
-        const long nb_ = std::min<long>(NSB, ns - a);
-        const int nrhs = (int)round_up(nb_, 128);
+    std::vector<double> acc_h(NSB + 1);
+    // one batch of test points up to the all-reduce; a failure here must not leave the other ranks inside that collective
+    auto batch = [&](long a, long nb_, int nrhs) -> int {
         HIP_TRY(hipMemcpyAsync(xd, xs + a * d, nb_ * d * sizeof(double), hipMemcpyHostToDevice, st));
         if (ms) HIP_TRY(hipMemcpyAsync(msd, ms + a, nb_ * sizeof(double), hipMemcpyHostToDevice, st));
         else HIP_TRY(hipMemsetAsync(msd, 0, nb_ * sizeof(double), st));
@@ -733,7 +738,6 @@ int pgp_sharded_predict(pgp_ctx* c, pgp_comm* m, pgp_sfactor* f, const double* x
         HIP_TRY(hipMemsetAsync(Ks, 0, (size_t)np * nrhs * sizeof(double), st));
         CHK(cov_rect_launch(XcT, ldc, nb_, f->XT, np, n, dpad, cp, Ks, np, st));     // column-major (np x nrhs): column = test point
         CHK(col_dot_full_launch(Ks, np, n, nb_, f->alpha, msd, o1, st));                 // fmu = ms + Ks' alpha (every rank, O(n ns))
-        HIP_TRY(hipMemsetAsync(acc, 0, (size_t)nrhs * sizeof(double), st));
         for (int k = 0; k < f->nloc; ++k) {
             const int p = f->me + k * f->world;
             const long rows = (long)(p + 1) * w;
@@ -749,10 +753,30 @@ int pgp_sharded_predict(pgp_ctx* c, pgp_comm* m, pgp_sfactor* f, const double* x
             CHK(gemm_prof(c, PC_GEMM_SOLVE, g, st));
             CHK(colsumsq_acc_launch(V, w, w, nb_, acc, st));
         }
-        CHK(comm_allreduce(m, acc, (size_t)nrhs, 0, st));
+        return PGP_OK;
+    };
+    for (long a = 0; a < ns; a += NSB) {
+        const long nb_ = std::min<long>(NSB, ns - a);
+        const int nrhs = (int)round_up(nb_, 128);
+        HIP_TRY(hipMemsetAsync(acc, 0, (size_t)(nrhs + 1) * sizeof(double), st));
+        const int brc = batch(a, nb_, nrhs);
+        if (brc != PGP_OK) {
+            if (m->world == 1) return brc;
+            (void)hipDeviceSynchronize();
+            (void)hipGetLastError();
+            const double one = 1.0;
+            (void)hipMemcpy(acc + nrhs, &one, sizeof(double), hipMemcpyHostToDevice);
+        }
+        CHK(comm_allreduce(m, acc, (size_t)nrhs + 1, 0, st));
         HIP_TRY(hipMemcpyAsync(fmu + a, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(acc_h.data(), acc, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(acc_h.data() + NSB, acc + nrhs, sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (acc_h[NSB] != 0.0) {
+            if (brc != PGP_OK) return brc;
+            pgp_set_last_hip_error(hipErrorUnknown, "another rank of the sharded predict failed", __FILE__, __LINE__);
+            return PGP_ERR_HIP;
+        }
         for (long j = 0; j < nb_; ++j) fs2[a + j] = std::max(f->kss - acc_h[j] / f->sn2, 0.0);
     }
     if (c->prof) prof_collect(c);

@@ -440,6 +440,8 @@ struct CovSpec {
     int ncov = 0;                   // number of hyperparameters (= gradient entries)
     int nder = 0;                   // getDerMatrix accepts der in [0, nder)
     double ell4 = 1.0;              // RQard reference-compat 'cross' derivative factor ell_der^4
+    bool ard_grad_diff = false;     // plain ARD kinds: the gradient pass must weight with the difference-form K (make_spec: the scaled,
+                                    // centred points of the resident x are too far out for the Gram form's eps |a|^2 -- grad.hip)
     double sf2() const { return cp.sf2; }
 };
 

@@ -260,3 +260,68 @@ def test_gram_form_assembly_in_ep_cfg5_recipe(lib):
         assert relerr(a2[3], a0[3]) < 1e-10
     g = golden("G8ii_ep_d32_N512")
     assert relerr(res[1, 512][0], g["nlZ"]) < 1e-8 and relerr(res[1, 512][1], g["alpha"]) < 1e-6
+
+
+def _ard_fit_with(lib, form, x, y, log_ell, log_sn=np.log(0.12), log_sf=0.1, composite=False):
+    import pygps_amd as pyGPs
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    _lib.check(lib.pgp_set_option(ctx, b"ard_grad_form", form))
+    try:
+        m = pyGPs.GPR()
+        k = pyGPs.cov.RBFard(log_ell_list=[float(v) for v in log_ell], log_sigma=float(log_sf))
+        if composite:                  # a device program with an ARD leaf (csrc/grad.hip hadamard_prog_kernel<1>)
+            k = k + pyGPs.cov.Matern(np.log(3.0), 3, -0.5)
+        m.setPrior(kernel=k)
+        m.setNoise(float(log_sn))
+        m.setData(x, y)
+        nlZ, dnlZ, post = m.getPosterior()
+        return nlZ, _flat(dnlZ), np.array(post.alpha), m
+    finally:
+        lib.pgp_set_option(ctx, b"ard_grad_form", 0)
+
+
+def test_ard_gradient_weights_gram_vs_difference_form(lib):
+    """The ARD gradient pass runs on the matrix cores in forms that cancel: K recomputed in the Gram form and the per-coordinate sums
+    as R x^2 + x (C x - 2 W'x) on centred coordinates (csrc/grad.hip hadamard_ard_kernel, ard_dim_reduce).  Their error is
+    eps |a|^2 of the scaled, centred points instead of the reference's eps (a - b)^2 (Core/cov.py:899-901, :924-931), so the host
+    (make_spec) switches to the difference form throughout -- hadamard_reduce_kernel<1> with ard_dim_reduce_diff -- beyond
+    |a|^2 = 1e8.
+    * ordinary data (d = 100, the G18 recipe): both forms agree <= 1e-10, the default IS the matrix-core form (bit-identical), and
+      the difference form alone reproduces the reference's fixture too; the same for a device program with an ARD leaf;
+    * points spread over ~2e4 length scales with near-duplicate pairs (the only off-diagonal K entries that are not 0): the default
+      must pick the difference form (bit-identical to forced) and match the oracle; the forced matrix-core form is measurably worse."""
+    g = golden("G18_fit_rbfard_d100_N1500")
+    x, y = g18_inputs(1500, 100, 3)
+    r0, r1, r2 = (_ard_fit_with(lib, f, x, y, g["cov_hyp"][:100], g["lik_hyp"][0], g["cov_hyp"][100]) for f in (0, 1, 2))
+    assert r0[0] == r1[0] and np.array_equal(r0[1], r1[1])                         # the default chose the Gram-form weights
+    assert np.max(np.abs(r2[1] - r1[1])) < 1e-10 * np.max(np.abs(r1[1]))
+    gref = np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])
+    assert np.max(np.abs(r2[1] - gref)) < 1e-7 * np.max(np.abs(gref))
+    # far-out data: 40 coordinates, points on a huge scale, every second point a near-copy of its neighbour
+    rng = np.random.RandomState(11)
+    N, d = 600, 40
+    x = rng.randn(N, d) * 2.0e4
+    x[1::2] = x[0::2] + 0.7 * rng.randn(N // 2, d)
+    y = np.sin(x[:, :1] / 2.0e4) + 0.1 * rng.randn(N, 1)
+    log_ell = np.log(np.sqrt(d)) + rng.uniform(-0.3, 0.3, d)
+    b0, b1, b2 = (_ard_fit_with(lib, f, x, y, log_ell) for f in (0, 1, 2))
+    assert b0[0] == b2[0] and np.array_equal(b0[1], b2[1])                         # the default chose the difference form
+    m = b0[3]
+    # faithful=True: one getDerMatrix per length scale like the reference (the oracle's fast branch is a product form itself)
+    ref = O.exact_fit(O.RBFARD, np.array(m.covfunc.hyp), 0, m.likfunc.hyp[0], x, y, m.meanfunc.hyp[0] * np.ones((N, 1)),
+                      np.ones((N, 1)), faithful=True)
+    want = np.concatenate([ref["dnlZ_mean"], ref["dnlZ_cov"], ref["dnlZ_lik"]])
+    e_diff = np.max(np.abs(b0[1] - want)) / np.max(np.abs(want))
+    e_gram = np.max(np.abs(b1[1] - want)) / np.max(np.abs(want))
+    assert relerr(b0[0], ref["nlZ"]) < 1e-9 and e_diff < 1e-10
+    assert e_gram > 100 * e_diff
+    # a device program with an ARD leaf: the same switch for its per-coordinate sums (K is the difference form there anyway)
+    xo, yo = g18_inputs(700, 40, 9)
+    lo = np.log(np.sqrt(40.0)) + rng.uniform(-0.3, 0.3, 40)
+    p0, p1, p2 = (_ard_fit_with(lib, f, xo, yo, lo, composite=True) for f in (0, 1, 2))
+    assert np.array_equal(p0[1], p1[1]) and np.max(np.abs(p2[1] - p1[1])) < 1e-10 * np.max(np.abs(p1[1]))
+    q0, q1, q2 = (_ard_fit_with(lib, f, x, y, log_ell, composite=True) for f in (0, 1, 2))
+    assert q0[0] == q2[0] and np.array_equal(q0[1], q2[1])
+    ard = slice(1, 41)                 # [mean | 40 length scales, ...]: the product form is visibly off out there, on its own entries
+    assert np.max(np.abs(q1[1][ard] - q2[1][ard])) > 1e-9 * np.max(np.abs(q2[1][ard]))
