@@ -94,6 +94,8 @@ TEST_SIGNATURES = {
     "pgp_test_mfma_cycles": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "pgp_test_leaf_ticks": (C.c_int, [_vp, _dp]),
     "pgp_test_assemble": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _i64, C.c_int, _dp]),
+    "pgp_test_gemm_trace": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong), _i64, C.POINTER(_i64)]),
+    "pgp_test_read_gemm_trace": (C.c_int, [_vp, C.POINTER(C.c_longlong), _i64, C.POINTER(_i64)]),
     "pgp_test_store_roof": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _dp]),
     "pgp_test_cumask_gemm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "pgp_test_wave_costs": (C.c_int, [_vp, _dp]),

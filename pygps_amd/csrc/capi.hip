@@ -143,6 +143,7 @@ void pgp_destroy(pgp_ctx* c) {
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->in_host) (void)hipHostFree(c->in_host);
+    if (c->gemm_trace) (void)hipFree(c->gemm_trace);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -196,6 +197,20 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { cov_tile_set_grid(value); return PGP_OK; }
     if (!strcmp(name, "asm_nt")) { cov_tile_set_nt(value); return PGP_OK; }
+    if (!strcmp(name, "pair_launch")) { c->pair_launch = value != 0; return PGP_OK; }
+    if (!strcmp(name, "gemm_trace")) {               // diagnostic: see ctx.h
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->gemm_trace) { (void)hipFree(c->gemm_trace); c->gemm_trace = nullptr; }
+        c->gemm_trace_cap = 0; c->gemm_trace_pos = 0;
+        if (value > 0) {
+            const long cap = (long)value * 1024;
+            HIP_TRY(hipMalloc((void**)&c->gemm_trace, (size_t)cap * 64));
+            HIP_TRY(hipMemset(c->gemm_trace, 0, (size_t)cap * 64));
+            c->gemm_trace_cap = cap;
+        }
+        return PGP_OK;
+    }
     if (!strcmp(name, "ard_grad_form")) { if (value < 0 || value > 2) return -3; c->ard_grad_form = value; return PGP_OK; }
     return -2;
 }
@@ -535,8 +550,8 @@ bool gram_assembly_applies(pgp_ctx* c, const CovSpec& cs) {
     return bound <= 64.0;
 }
 
-int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
-    if (!st) st = c->st;
+// everything gemm_prof decides about a launch before it goes out: tile order lists, the yield role, the trace slot
+static int gemm_prepare(pgp_ctx* c, GemmArgs& g) {
     if (g.batch < 1) g.batch = 1;
     g.dbg |= c->gemm_dbg;
     // XCD-aware order only for bulk launches (>= xcd_min_tiles 128-tiles, unbatched): a latency-bound grid of a few
@@ -558,8 +573,34 @@ int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
         // the chain's own small products mark their CUs; every bulk (128-tile, LDS-DMA) launch polls
         g.yield_role = c->chain_now ? 2 : (gemm_f64_uses_dma128(g) ? 1 : 0);
     }
+    if (c->gemm_trace && gemm_f64_uses_dma128(g) && g.batch == 1) {
+        const long mt = g.M / 128, nt = g.N / 128;
+        const long nb = g.order ? g.norder : (g.tri == 2 ? mt * (mt + 1) / 2 : mt * nt);
+        if (c->gemm_trace_pos + nb <= c->gemm_trace_cap) { g.trace = c->gemm_trace + 8 * c->gemm_trace_pos; c->gemm_trace_pos += nb; }
+    }
+    return PGP_OK;
+}
+
+int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st) {
+    if (!st) st = c->st;
+    CHK(gemm_prepare(c, g));
     ProfScope ps(c, cls, g.flops, 0.0, st, gemm_f64_uses_dma128(g) ? PC_KERNEL_DMA128 : -1);
     return gemm_f64_launch(g, st);
+}
+
+// two independent bulk products as ONE launch when the kernel family allows it (gemm_f64_pair_ok), else one after the other
+int gemm_prof_pair(pgp_ctx* c, int cls_a, GemmArgs a, int cls_b, GemmArgs b, hipStream_t st) {
+    if (!st) st = c->st;
+    CHK(gemm_prepare(c, a));
+    CHK(gemm_prepare(c, b));
+    if (c->pair_launch && gemm_f64_pair_ok(a, b)) {
+        ProfScope ps(c, cls_a, a.flops + b.flops, 0.0, st, PC_KERNEL_DMA128);
+        return gemm_f64_launch_pair(a, b, st);
+    }
+    { ProfScope ps(c, cls_a, a.flops, 0.0, st, gemm_f64_uses_dma128(a) ? PC_KERNEL_DMA128 : -1);
+      CHK(gemm_f64_launch(a, st)); }
+    ProfScope ps(c, cls_b, b.flops, 0.0, st, gemm_f64_uses_dma128(b) ? PC_KERNEL_DMA128 : -1);
+    return gemm_f64_launch(b, st);
 }
 
 // Blocked right-looking Cholesky of the (mrows x np) column-major lower matrix F (mrows >= np; rows
@@ -700,9 +741,7 @@ static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const doub
 }
 
 // TU: C[rows >= c0, cols c0..c1) -= P P^T, P = solved columns [k0, k1); out != nullptr: result goes to the staging buffer
-static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c0, int c1, double* out, long ldx,
-                            hipStream_t st) {
-    if (c1 <= c0) return PGP_OK;
+static GemmArgs trailing_update2_args(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c0, int c1, double* out, long ldx) {
     const long r0 = (long)c0 * 128, r1 = m.mrows + m.rows2(k1);
     GemmArgs g{};
     g.A = m.F + r0 + (long)k0 * 128 * m.ldf; g.lda = m.ldf; g.a_kc = 0;
@@ -726,7 +765,12 @@ static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c
     const long t128 = (long)(g.M / 128) * (g.N / 128) - (long)(g.N / 128) * (g.N / 128 - 1) / 2;
     g.tile = t128 < c->small_tile_below ? 64 : 128;
     g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
-    return gemm_prof(c, PC_GEMM_TRAIL, g, st);
+    return g;
+}
+static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c0, int c1, double* out, long ldx,
+                            hipStream_t st) {
+    if (c1 <= c0) return PGP_OK;
+    return gemm_prof(c, PC_GEMM_TRAIL, trailing_update2_args(c, m, k0, k1, c0, c1, out, ldx), st);
 }
 
 // Filler: B^-1 (lower) += E_p E_p^T with E_p = columns [s0, s1) of E = L^-T, which are FINAL once S(p) has run (right-
@@ -816,11 +860,18 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan, lf ? c->la_ev[2 * npanel + (p & 1)] : nullptr));
         if (lf) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * npanel + (p & 1)], 0));
         if (la) HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
-        CHK(trailing_update2(c, m, s0, s1, n1, nblk, nullptr, 0, main));   // TU_b in place, concurrent with D(p+1)
         // the first products are small (few tiles, short k) and the early trailing updates are long enough to hide D by
         // themselves: panels 0 .. eet_first go into ONE product (k = (eet_first + 1) w) behind TU_b(eet_first)
         const int pf = std::min(c->eet_first >= 0 ? c->eet_first : npanel / 6, npanel - 2);
-        if (fill_inline && p >= pf) CHK(eet_panel(c, m, p == pf ? 0 : s0, s1, c->eet_out, c->eet_ld, main));
+        const bool fill_now = fill_inline && p >= pf;
+        if (fill_now && n1 < nblk && c->pair_launch) {
+            // TU_b(p) in place (concurrent with D(p+1)) and panel p's share of E E' are independent: ONE launch, one tail
+            CHK(gemm_prof_pair(c, PC_GEMM_TRAIL, trailing_update2_args(c, m, s0, s1, n1, nblk, nullptr, 0), PC_GEMM_LAUUM,
+                               eet_panel_args(c, m, p == pf ? 0 : s0, s1, c->eet_out, c->eet_ld), main));
+        } else {
+            CHK(trailing_update2(c, m, s0, s1, n1, nblk, nullptr, 0, main));   // TU_b in place, concurrent with D(p+1)
+            if (fill_now) CHK(eet_panel(c, m, p == pf ? 0 : s0, s1, c->eet_out, c->eet_ld, main));
+        }
         if (fill2) CHK(rhs_product(s0, s1));
         if (la) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
     }

@@ -82,6 +82,10 @@ struct GemmArgs {
     // Device-side dependency (0: none): every workgroup waits until the counter *wait_flag has reached wait_target before it reads
     // anything -- an operand another RESIDENT kernel publishes (EP's sweep kernel: W of the block).  Bounded; a timeout sets *wait_err.
     unsigned* wait_flag; unsigned wait_target; unsigned* wait_err;
+    // phase stamps of every workgroup (pgp_test_gemm_trace; nullptr otherwise): 8 words per block -- 100 MHz wall clock at kernel
+    // entry, (unused), behind the k-loop, with the epilogue's stores issued, with them acknowledged; the CU key; the shader-clock
+    // counter at entry and at the end
+    long long* trace;
 };
 
 // index of the calling workgroup's CU in a yield-flag table (XCC id | shader engine, array, CU of HW_ID): < 4096
@@ -99,4 +103,6 @@ __device__ __forceinline__ void pgp_yield_mark(unsigned* flags, int delta) {
 }
 
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st);
+bool gemm_f64_pair_ok(const GemmArgs& a, const GemmArgs& b);     // may the two go out as ONE launch (gemm_f64_launch_pair)?
+int gemm_f64_launch_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t st);
 bool gemm_f64_uses_dma128(const GemmArgs& g);       // would gemm_f64_launch pick the LDS-DMA 128-tile instantiation?

@@ -60,6 +60,9 @@ struct pgp_ctx {
                                         // streams 102.6 -> 105 fits/s.  k > 1: after the (k-1)-th chain kernel (measured worse)
     int yield = 1;                      // cooperative yield: bulk GEMM workgroups sleep while a workgroup of the diagonal-panel
                                         // chain is resident on their CU (csrc/gemm_tile.h); 0 = off
+    long long* gemm_trace = nullptr;    // option "gemm_trace" = v > 0: the bulk 128-tile launches stamp their workgroups' phases and the shader
+    long gemm_trace_cap = 0;            // clock (GemmArgs::trace), one behind the other, until v * 1024 workgroups are recorded --
+    long gemm_trace_pos = 0;            // pgp_test_read_gemm_trace reads and rewinds; 0 frees the buffer
     unsigned* yield_flags = nullptr;    // the device's per-CU table (shared by every context on the device)
     int chain_now = 0;                  // set by the sweep while it queues the chain's kernels (factor_panel)
     int ep_fused = 2;                   // EP parameter recomputation: 0 blocked multi-rhs solve, 1 through the fused inverse (V' = K diag(sW)
@@ -95,6 +98,8 @@ struct pgp_ctx {
            *rvec = nullptr, *zvec = nullptr, *partial = nullptr, *scal = nullptr;
     long partial_cap = 0;
     double* prep = nullptr;             // [coordinate means | squared norms of the centred points] of the current XsT (hadamard_prep_count(np))
+    int pair_launch = 0;                // option "pair_launch": TU_b(p) and panel p's share of E E' go out as one launch (gemm_f64_pair_kernel):
+                                        // +0.8 % on two fit streams, nothing on one (EXPERIMENTS.md) -- off, the kernel statistics stay one row
     int ard_grad_form = 0;              // option "ard_grad_form": 0 = by the norm bound, 1 = always the Gram-form weights, 2 = always the difference form
     std::vector<double> xdev2;          // per coordinate: max_p (x_pk - mean_k)^2 of the resident x (host, pgp_set_data)
     int gram_assembly = 1;              // RBF / RBFard assembly of a fit in the Gram form on the matrix cores: 1 when the host's bound on
@@ -313,6 +318,7 @@ int cov_point_value(pgp_ctx* c, const CovSpec& cs, int train, double* out);
 int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with_inverse = false, double* E = nullptr,
                   long lde = 0);
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);
+int gemm_prof_pair(pgp_ctx* c, int cls_a, GemmArgs a, int cls_b, GemmArgs b, hipStream_t st = nullptr);
 int batch_tile_list(pgp_ctx* c, int mt0, int nt, int nb, int dmt, const int** out, int* n);
 constexpr double ARD_GRAM_GRAD_BOUND = 1.0e8;     // max squared norm of a scaled, centred point for the Gram-form gradient weights
 bool gram_assembly_applies(pgp_ctx* c, const CovSpec& cs);

@@ -51,6 +51,11 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs& g, int b, int T, int
 template <int TM, int TN, bool AKC, bool BKC, bool DMA = false, bool YIELD = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (g.trace) {                                   // every lane the same words: no divergent branch in here
+        long long* tr0 = g.trace + 8L * (blockIdx.x + (long)gridDim.x * blockIdx.z);
+        tr0[0] = (long long)wall_clock64();
+        tr0[6] = (long long)__builtin_readcyclecounter();     // shader clock: with [7] the frequency this workgroup ran at
+    }
     int ti, tj;
     if (!decode_tile(g, (int)blockIdx.x, TM, ti, tj)) return;
     long bz = blockIdx.z;
@@ -69,12 +74,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     if (!YIELD && g.yield_role == 2) {               // one of the chain's own small products: its CU's bulk workgroups give way
         pgp_yield_mark(g.yield_flags, +1);
-        gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, false>(g, ti, tj, bz, smem);
+        gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, false>(g, ti, tj, bz, smem, (int)(blockIdx.x + gridDim.x * blockIdx.z));
         __syncthreads();
         pgp_yield_mark(g.yield_flags, -1);
         return;
     }
-    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, YIELD>(g, ti, tj, bz, smem);
+    gemm_tile_ns::gemm_tile<TM, TN, AKC, BKC, DMA, YIELD>(g, ti, tj, bz, smem, (int)(blockIdx.x + gridDim.x * blockIdx.z));
+}
+
+// TWO independent bulk products in ONE launch (round 4: the trailing update TU_b(p) and panel p's share of E E'): workgroups
+// [0, na) run a's tiles, the rest b's.  Each launch of a few hundred tiles ends in a tail during which the chip drains (the next
+// launch of an in-order stream starts when the last workgroup has gone); merging the pair halves the number of tails per panel.
+// Both argument sets live in the kernel-argument segment; the workgroup picks one by a uniform pointer select.
+template <bool YIELD>
+__global__ __launch_bounds__(256, 2) void gemm_f64_pair_kernel(GemmArgs a, GemmArgs b, int na) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // two copies of the tile code, each reading ITS argument set straight from the kernel-argument segment: a pointer select
+    // between the two makes the compiler treat every field as divergent (the LDS-DMA bases must live in SGPRs)
+    auto run = [&](const GemmArgs& g, int bid) {
+        if (g.trace) {                               // every lane the same words: no divergent branch in here
+            long long* tr0 = g.trace + 8L * bid;
+            tr0[0] = (long long)wall_clock64();
+            tr0[6] = (long long)__builtin_readcyclecounter();
+        }
+        int ti, tj;
+        if (!decode_tile(g, bid, 128, ti, tj)) return;
+        gemm_tile_ns::gemm_tile<128, 128, false, false, true, YIELD>(g, ti, tj, 0, smem, bid);
+    };
+    if ((int)blockIdx.x < na) run(a, (int)blockIdx.x);
+    else run(b, (int)blockIdx.x - na);
 }
 
 template <int T, bool AKC, bool BKC, bool DMA = false, bool YIELD = false>
@@ -112,6 +140,35 @@ int launch_l(const GemmArgs& g, hipStream_t st) {
 }  // namespace
 
 bool gemm_f64_uses_dma128(const GemmArgs& g) { return dma_ok(g); }
+
+static unsigned launch_blocks(const GemmArgs& g) {
+    const int mt = g.M / 128, nt = g.N / 128;
+    if (g.order) return (unsigned)g.norder;
+    return (g.tri == 2) ? (unsigned)((long)mt * (mt + 1) / 2) : (unsigned)(mt * nt);
+}
+// can the two go out as one launch?  Both on the LDS-DMA 128-tile path, unbatched, no device-side waits, the same yield role
+bool gemm_f64_pair_ok(const GemmArgs& a, const GemmArgs& b) {
+    auto plain = [](const GemmArgs& g) {
+        return g.M > 0 && g.N > 0 && g.tile != 64 && dma_ok(g) && g.batch <= 1 && !g.order_z && !g.wait_flag && g.yield_role != 2;
+    };
+    return plain(a) && plain(b) && (a.yield_role == 1 && a.yield_flags) == (b.yield_role == 1 && b.yield_flags);
+}
+int gemm_f64_launch_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+    if (!gemm_f64_pair_ok(a, b)) return -2;
+    constexpr int SA_ = 128 + 16;
+    const size_t shm = 2 * (2 * BK * SA_) * sizeof(double);
+    const unsigned na = launch_blocks(a), nb = launch_blocks(b);
+    const bool yield = a.yield_role == 1 && a.yield_flags;
+    static std::atomic<int> attr_set{0};
+    if (!attr_set.load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute((const void*)gemm_f64_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute((const void*)gemm_f64_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr_set.store(1, std::memory_order_release);
+    }
+    if (yield) hipLaunchKernelGGL(gemm_f64_pair_kernel<true>, dim3(na + nb), dim3(256), shm, st, a, b, (int)na);
+    else hipLaunchKernelGGL(gemm_f64_pair_kernel<false>, dim3(na + nb), dim3(256), shm, st, a, b, (int)na);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
 
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PGP_OK;

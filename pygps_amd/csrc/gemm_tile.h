@@ -50,7 +50,7 @@ __device__ __noinline__ void gemm_yield_wait(const unsigned* yf) {
 // A stage of the k-loop is one basic block: nothing run-time selectable is tested inside it (YIELD adds one load per stage,
 // issued beside the LDS-DMA pieces and consumed after the stage's barrier, and a never-taken branch).
 template <int TM, int TN, bool AKC, bool BKC, bool DMA = false, bool YIELD = false>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, long bz, double* __restrict__ smem) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, long bz, double* __restrict__ smem, int wg = 0) {
     static_assert(!DMA || (!AKC && !BKC && TM == 128 && TN == 128), "LDS-DMA staging: 128-wide M-contiguous operands only");
     constexpr int SA = TM + 16, SB = TN + 16, SK = BK + 2;
     constexpr int ASZ = AKC ? TM * SK : BK * SA;
@@ -325,6 +325,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         }
     }
 
+    // (derived HERE, not ahead of the k-loop: two more live SGPRs in there and the LDS-DMA bases no longer fit the scalar file)
+    long long* const trc = g.trace ? g.trace + 8L * wg : nullptr;   // workgroup-uniform; wg = the workgroup's number within ITS product
+    if (trc) trc[2] = (long long)wall_clock64();             // (every lane the same word: no divergent branch)
     // ---- epilogue: C = alpha * acc ---------------------------------------------------------
     if (!diag && (g.dbg & 512) && !(ldc & 1) && !((unsigned long)C & 15ul)) {
         // 16-byte stores: adjacent lanes (rows m, m+1) trade one value each by a DPP quad_perm, then the even lane stores
@@ -360,6 +363,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
                 if (!diag || m >= n) cp[(long)(4 * r) * ldc] = g.alpha * acc[im][in][r];
             }
         }
+    }
+    if (trc) {
+        trc[3] = (long long)wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        trc[4] = (long long)wall_clock64(); trc[5] = (long long)pgp_cu_key(); trc[7] = (long long)__builtin_readcyclecounter();
     }
 }
 

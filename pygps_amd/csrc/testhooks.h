@@ -27,6 +27,9 @@ int pgp_test_slot_probe(pgp_ctx* ctx, int nwg, int lds_kb, int hold_us, int rese
 int pgp_test_cumask_gemm(pgp_ctx* ctx, int M, int K, int reserve_per_xcd, int stride, int iters, double* out2);
 int pgp_test_assemble(pgp_ctx* ctx, int kind, int mode, int64_t n, int64_t d, int iters, double* ms_out);
 /* the stores of the 'train' assembly alone (out3[0], ms), hipMemsetAsync (out3[1]) and a linear fill (out3[2]) over 8 n^2 bytes */
+/* phase stamps (100 MHz) of every workgroup of one trailing-update launch: 8 words per workgroup, see GemmArgs::trace */
+int pgp_test_gemm_trace(pgp_ctx* ctx, int M, int K, int tri, int warm, int conc, long long* out, int64_t out_words, int64_t* nblk_out);
+int pgp_test_read_gemm_trace(pgp_ctx* ctx, long long* out, int64_t words, int64_t* nwg);
 int pgp_test_store_roof(pgp_ctx* ctx, int64_t n, int grid, int iters, double* out3);
 #ifdef __cplusplus
 }

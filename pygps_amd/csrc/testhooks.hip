@@ -418,6 +418,19 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
     if (rc == PGP_OK && iters > 0 && ms_out) {
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        // warm-up: ~80 ms of the same launches.  The shader clock of an idle chip starts near 2.0 GHz and takes tens of milliseconds
+        // of load to reach 2.37 (tools/gemm_trace.py: the K = 512 product 57 TF after 5 launches, 68 TF after 100); round 4's first
+        // stand-alone tables were taken cold
+        {
+            HIP_TRY(hipEventRecord(e0, ts));
+            rc = gemm_f64_launch(g, ts);
+            HIP_TRY(hipEventRecord(e1, ts));
+            HIP_TRY(hipStreamSynchronize(ts));
+            float m1 = 0.f;
+            HIP_TRY(hipEventElapsedTime(&m1, e0, e1));
+            const int nwarm = (int)std::min(4000.0, std::max(1.0, 80.0 / std::max(1e-3, (double)m1)));
+            for (int i = 0; i < nwarm && rc == PGP_OK; ++i) rc = gemm_f64_launch(g, ts);
+        }
         HIP_TRY(hipEventRecord(e0, ts));
         for (int i = 0; i < iters; ++i) rc = gemm_f64_launch(g, ts);
         HIP_TRY(hipEventRecord(e1, ts));
@@ -429,6 +442,55 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
     }
     (void)hipFree(Ad); (void)hipFree(Bd); (void)hipFree(Cd);
     return rc;
+}
+
+// Phase stamps of every workgroup of ONE launch of the trailing-update product C -= A A' (M x M, depth K, synthetic operands, after
+// `warm` untraced launches; `conc` > 0: a second, untraced launch of the same product runs beside it on the other stream).
+// out: 8 words per workgroup (GemmArgs::trace), *nblk_out workgroups.
+int pgp_test_gemm_trace(pgp_ctx* c, int M, int K, int tri, int warm, int conc, long long* out, int64_t out_words, int64_t* nblk_out) {
+    if (!c || !out || !nblk_out || M % 128 || K % 16) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    const long mt = M / 128;
+    const long nblk = tri ? mt * (mt + 1) / 2 : mt * mt;
+    if (out_words < 8 * nblk) return -2;
+    double *A, *Cd, *C2; long long* tr;
+    HIP_TRY(hipMalloc((void**)&A, (size_t)M * K * 8)); HIP_TRY(hipMalloc((void**)&Cd, (size_t)M * M * 8));
+    HIP_TRY(hipMalloc((void**)&C2, (size_t)M * M * 8)); HIP_TRY(hipMalloc((void**)&tr, (size_t)nblk * 64));
+    HIP_TRY(hipMemset(tr, 0, (size_t)nblk * 64));
+    std::vector<double> h((size_t)M * K);
+    unsigned long long s = 88172645463325252ULL;
+    for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = ((double)(s >> 11) / 9007199254740992.0 - 0.5) * 0.01; }
+    HIP_TRY(hipMemcpy(A, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(Cd, 0, (size_t)M * M * 8)); HIP_TRY(hipMemset(C2, 0, (size_t)M * M * 8));
+    GemmArgs g{};
+    g.A = A; g.lda = M; g.B = A; g.ldb = M; g.C = Cd; g.ldc = M; g.M = M; g.N = M; g.K = K; g.alpha = -1.0; g.beta = 1.0;
+    g.tri = tri ? 2 : 0; g.mask_diag = tri ? 1 : 0; g.batch = 1; g.tile = 128; g.dbg = c->gemm_dbg;
+    int rc = PGP_OK;
+    for (int i = 0; i < warm && rc == PGP_OK; ++i) rc = gemm_f64_launch(g, c->st);
+    HIP_TRY(hipStreamSynchronize(c->st));
+    GemmArgs g2 = g; g2.C = C2;
+    if (conc > 0 && rc == PGP_OK) rc = gemm_f64_launch(g2, c->st2);
+    g.trace = tr;
+    if (rc == PGP_OK) rc = gemm_f64_launch(g, c->st);
+    HIP_TRY(hipStreamSynchronize(c->st)); HIP_TRY(hipStreamSynchronize(c->st2));
+    HIP_TRY(hipMemcpy(out, tr, (size_t)nblk * 64, hipMemcpyDeviceToHost));
+    *nblk_out = nblk;
+    (void)hipFree(A); (void)hipFree(Cd); (void)hipFree(C2); (void)hipFree(tr);
+    return rc;
+}
+
+// the stamps recorded since the last call (option "gemm_trace"): 8 words per workgroup, launch after launch; returns the number of
+// workgroups through *nwg and rewinds the recorder
+int pgp_test_read_gemm_trace(pgp_ctx* c, long long* out, int64_t words, int64_t* nwg) {
+    if (!c || !out || !nwg || !c->gemm_trace) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const long n = std::min<long>(c->gemm_trace_pos, words / 8);
+    HIP_TRY(hipMemcpy(out, c->gemm_trace, (size_t)n * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->gemm_trace, 0, (size_t)c->gemm_trace_cap * 64));
+    c->gemm_trace_pos = 0;
+    *nwg = n;
+    return PGP_OK;
 }
 
 // GemmArgs::skip_lo / skip_hi and GemmArgs::wait_flag (EP's block sweep): n x n lower-triangular update, column-major host buffers

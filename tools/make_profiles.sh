@@ -48,6 +48,14 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 cp $(ccsv $O/asm_w) $O/final/r04_assembly_pmc_write_counter_collection.csv
 # 6. the probes behind EXPERIMENTS.md (round 4): stand-alone GEMM rate by K, round quantisation, narrow outputs
 ( for k in 512 1024 2048 8192; do python $R/tools/gemm_only.py 8192 $k 0 1.0 128 10; done; python $R/tools/quant_probe.py; python $R/tools/narrow_probe.py ) > $O/final/r04_gemm_probes.txt 2> $O/probes.err
+# 6b. (round 4, last third) the clock ramp, the bulk kernel from inside (stand-alone and inside a loop of fits), its PMC passes at
+#     K = 512 / 8192, and what the assembly's stores cost by themselves
+( python $R/tools/gemm_trace.py 8192 512 0 0 5; python $R/tools/gemm_trace.py 8192 512 0 0 100; python $R/tools/gemm_trace.py 8192 8192 0 0 10;
+  python $R/tools/gemm_trace.py 2048 512 0 0 100; python $R/tools/fit_clock.py 1 12; python $R/tools/fit_clock.py 2 12;
+  python $R/tools/two_streams.py pair_launch=0; python $R/tools/two_streams.py pair_launch=1 ) > $O/final/r04_gemm_inside.txt 2> $O/inside.err
+bash $R/tools/gemm_pmc.sh > /dev/null 2>&1; cp $R/gpurun_out/gemm_pmc.txt $O/final/r04_gemm_pmc.txt
+( hipcc --offload-arch=gfx950 -O3 -o /tmp/store_roof $R/tools/store_roof.hip && /tmp/store_roof 16384;
+  python $R/tools/first_call.py 16384:10 16384:10 16384:10 16384:100 16384:100 ) > $O/final/r04_store_roof.txt 2> $O/store_roof.err
 # 7. timeline of one single-stream fit
 bash $R/tools/fit_trace.sh > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline.txt $O/final/r04_fit_timeline.txt
 ls -la $O/final

@@ -1,5 +1,8 @@
 // Store-bandwidth ceiling of the box, for reading the assembly kernel's HBM fraction against what the
-// chip delivers to a kernel that does NOTHING but write an N x N fp64 matrix (tools/store_roof.sh builds and runs it).
+// chip delivers to a kernel that does NOTHING but write an N x N fp64 matrix.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/store_roof tools/store_roof.hip && /tmp/store_roof 16384
+// (results of round 4: EXPERIMENTS.md "What the stores of the assembly cost by themselves"; the product's own pattern is also
+// timed inside bench.py through pgp_test_store_roof)
 //   linear   : grid-stride 16-byte stores over the whole buffer
 //   tiles    : 64 x 64 tiles of a row-major N x N matrix (512-byte runs, stride N*8), persistent workgroups —
 //              the assembly kernel's store pattern without its arithmetic
