@@ -641,3 +641,27 @@ def test_dense_gradient_term_needs_the_dense_fit_right_before_it(lib):
         assert lib.pgp_dense_grad_term(h, _lib.ptr(dK), n, float(np.log(0.1)), _lib.ptr(g)) == -6
     finally:
         lib.pgp_destroy(h)
+
+
+def test_measurement_hooks_gemm_trace_and_store_roof(lib):
+    """The diagnostic hooks behind EXPERIMENTS.md (round 4): every workgroup of a traced trailing-update launch leaves ordered stamps
+    (entry <= k-loop end <= stores issued <= stores acknowledged, a CU key, a shader-clock interval of a sane frequency), and the
+    store-only probe returns three positive times with the linear fill the fastest."""
+    import ctypes as C
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    M, K = 2048, 512
+    n = (M // 128) ** 2
+    buf = (C.c_longlong * (8 * n))()
+    nb = C.c_int64()
+    _lib.check(lib.pgp_test_gemm_trace(ctx, M, K, 0, 3, 0, buf, 8 * n, C.byref(nb)))
+    assert nb.value == n
+    t = np.frombuffer(buf, dtype=np.int64).reshape(n, 8)
+    assert np.all(t[:, 0] > 0) and np.all(t[:, 0] <= t[:, 2]) and np.all(t[:, 2] <= t[:, 3]) and np.all(t[:, 3] <= t[:, 4])
+    us = (t[:, 4] - t[:, 0]) / 100.0
+    mhz = (t[:, 7] - t[:, 6]) / us
+    assert 20.0 < np.median(us) < 400.0 and 1000.0 < np.median(mhz) < 2600.0
+    assert len(np.unique(t[:, 5])) >= 128                                        # the tiles were spread over the chip
+    o3 = (C.c_double * 3)()
+    _lib.check(lib.pgp_test_store_roof(ctx, 4096, 0, 5, o3))
+    assert min(o3) > 0.0 and o3[2] <= o3[0] * 1.2
