@@ -702,7 +702,8 @@ def main():
                 gl += v["launches"]; gm += v["ms"]; gf += v["flops"]
         alg = float(N) ** 3                                    # algorithmic flops of one fit that run in gemm_f64_kernel
         achieved_all = alg * nfit / max(gm, 1e-12) / 1e9
-        # the dominant kernel = ONE instantiation (one row of the rocprofv3 kernel-stats CSV): the LDS-DMA 128 x 128 tile
+        # the dominant kernel = ONE tile code (two rows of the rocprofv3 kernel-stats CSV since round 4: gemm_f64_kernel<128,128,false,false,
+        # true,true> and gemm_f64_pair_kernel<true>, the same gemm_tile behind a second entry point): the LDS-DMA 128 x 128 tile
         # kernel that runs every trailing update and E E^T product.  Its algorithmic flops: N^3 per fit minus everything
         # the OTHER gemm_f64 instantiations execute (panel solves, 64-tile updates of the leaf chain; executed >= algorithmic
         # there, so this is a lower bound)
@@ -738,8 +739,10 @@ def main():
                                                                               tj.get("measured_on_commit"), cur))
             except Exception as e:
                 tsrc = "traffic file unreadable: %r" % (e,)
-        roof = {"kernel": "gemm_f64_kernel<128,128,false,false,true,true> (fp64 MFMA, LDS-DMA operand staging, yield poll: every trailing update of "
-                          "the Cholesky sweep incl. the fused inverse, and the E E^T products)",
+        roof = {"kernel": "gemm_f64_kernel<128,128,false,false,true,true> + gemm_f64_pair_kernel<true>: ONE tile code (gemm_tile<128,128>, fp64 MFMA, "
+                          "LDS-DMA operand staging, yield poll) behind two entry points -- one product per launch, or the trailing update "
+                          "TU_b(p) and panel p's share of E E^T in one launch; every trailing update of the Cholesky sweep incl. the fused "
+                          "inverse, and the E E^T products; in a rocprofv3 kernel-stats CSV: the sum of these two rows",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_MFMA_TF, "traffic": traffic, "traffic_source": tsrc,
                 "how": "algorithmic flops of this instantiation's launches (N^3 per fit minus what the other gemm_f64 "

@@ -17,7 +17,7 @@ static const char* const kProfNames[PC_COUNT] = {
     "hadamard_reduce_kernel", "small/O(N) kernels", "gemm_f64(panel solve X E_D)", "diag_in/out staging",
     // shadow class: every launch of the dominant kernel INSTANTIATION (one row of a rocprofv3 kernel-stats CSV), whatever
     // its purpose class above -- each such launch is counted here AND in its purpose class
-    "kernel gemm_f64_kernel<128,128,false,false,true,*> (LDS-DMA 128-tile)"};
+    "kernel gemm_f64_kernel<128,128,false,false,true,*> + gemm_f64_pair_kernel (LDS-DMA 128-tile)"};
 
 struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; int shadow; };
 
@@ -98,8 +98,9 @@ struct pgp_ctx {
            *rvec = nullptr, *zvec = nullptr, *partial = nullptr, *scal = nullptr;
     long partial_cap = 0;
     double* prep = nullptr;             // [coordinate means | squared norms of the centred points] of the current XsT (hadamard_prep_count(np))
-    int pair_launch = 0;                // option "pair_launch": TU_b(p) and panel p's share of E E' go out as one launch (gemm_f64_pair_kernel):
-                                        // +0.8 % on two fit streams, nothing on one (EXPERIMENTS.md) -- off, the kernel statistics stay one row
+    int pair_launch = 1;                // option "pair_launch": TU_b(p) and panel p's share of E E' go out as ONE launch (gemm_f64_pair_kernel, the same
+                                        // tile code behind a second entry point): +0.8 ... 2.4 % on two fit streams at N = 8192, -1.2 % time at N = 16384,
+                                        // neutral for a lone N = 8192 chain; bit-identical results (EXPERIMENTS.md)
     int ard_grad_form = 0;              // option "ard_grad_form": 0 = by the norm bound, 1 = always the Gram-form weights, 2 = always the difference form
     std::vector<double> xdev2;          // per coordinate: max_p (x_pk - mean_k)^2 of the resident x (host, pgp_set_data)
     int gram_assembly = 1;              // RBF / RBFard assembly of a fit in the Gram form on the matrix cores: 1 when the host's bound on

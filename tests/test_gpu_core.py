@@ -222,12 +222,12 @@ def test_shrinking_batched_trailing_update(lib):
 @pytest.mark.parametrize("opts", [{'yield': 0}, dict(leaf_first=1), {'leaf_first': 3, 'yield': 0}, dict(lookahead=0), dict(eet_overlap=0), dict(eet_overlap=2, eet_tile=64),
                                   dict(s_tile=128), dict(eet_first=0), dict(small_tile_below=256), dict(gemm_dbg=0),
                                   dict(xcd_order=1), dict(xcd_order=1, xcd_super=4, xcd_min_tiles=64),
-                                  dict(pair_launch=1), dict(pair_launch=1, gemm_trace=64)])
+                                  dict(pair_launch=0), dict(pair_launch=1, gemm_trace=64)])
 def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
     """The kept schedule options of the Cholesky sweep -- without the cooperative yield of the bulk workgroups, the trailing
     update held back until D(p+1)'s stage-in / third chain kernel, the serial order, B^-1 = E E^T as one product after the sweep or as panel products behind every trailing update, tile
-    choices, the plain (register-staged) GEMM form, the XCD-aware tile order, TU_b(p) and panel p's share of E E' as ONE launch
-    (gemm_f64_pair_kernel), the workgroups' phase stamps switched on -- against the reference's own numbers
+    choices, the plain (register-staged) GEMM form, the XCD-aware tile order, TU_b(p) and panel p's share of E E' as TWO launches
+    instead of one (gemm_f64_pair_kernel is the default), the workgroups' phase stamps switched on -- against the reference's own numbers
     (G6: Core/inf.py:353-384 at N=2048 and at the benchmark size N=8192).  The variants that were measured and lost in
     rounds 1-2 (resident server, depth-2 look-ahead, side streams, CU reservation, merged grids, the round-1 sweep) are
     gone from the library."""
@@ -251,7 +251,7 @@ def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
         for k in opts:
             lib.pgp_set_option(ctx, k.encode(), {"lookahead": 1, "leaf_first": 0, "yield": 1, "eet_overlap": 3, "eet_tile": 128, "s_tile": 0,
                                                  "eet_first": -1, "small_tile_below": 200, "xcd_order": 0, "xcd_super": 8,
-                                                 "xcd_min_tiles": 256, "gemm_dbg": 64 | 256 | 512}.get(k, 0))
+                                                 "xcd_min_tiles": 256, "gemm_dbg": 64 | 256 | 512, "pair_launch": 1}.get(k, 0))
 
 
 def test_exact_fit_golden_G7_ard_d64(lib):

@@ -25,7 +25,8 @@ def load(pattern, counter, match):
     tot, n = 0.0, 0
     for f in glob.glob(pattern, recursive=True):
         for row in csv.DictReader(open(f)):
-            if row.get("Counter_Name") == counter and match in row.get("Kernel_Name", ""):
+            kn = row.get("Kernel_Name", "")
+            if row.get("Counter_Name") == counter and any(m_ in kn for m_ in ((match,) if isinstance(match, str) else match)):
                 tot += float(row["Counter_Value"])
                 n += 1
     return tot, n
@@ -34,16 +35,18 @@ def load(pattern, counter, match):
 if __name__ == "__main__":
     root = sys.argv[1]
     out = sys.argv[2]
-    DOM = "gemm_f64_kernel<128, 128, false, false, true"   # the dominant instantiation (LDS-DMA 128-tile kernel; with or without the yield poll)
+    # the dominant tile code (LDS-DMA 128-tile, with or without the yield poll) behind its two entry points: one product per launch, or
+    # TU_b(p) + panel p's share of E E' in one launch (gemm_f64_pair_kernel)
+    DOM = ("gemm_f64_kernel<128, 128, false, false, true", "gemm_f64_pair_kernel")
     head = sys.argv[3] if len(sys.argv) > 3 else "unknown"
     f, nf = load(root + "/fetch/**/*counter_collection.csv", "FETCH_SIZE", DOM)
     w, nw = load(root + "/write/**/*counter_collection.csv", "WRITE_SIZE", DOM)
-    fa, nfa = load(root + "/fetch/**/*counter_collection.csv", "FETCH_SIZE", "gemm_f64_kernel")
-    wa, nwa = load(root + "/write/**/*counter_collection.csv", "WRITE_SIZE", "gemm_f64_kernel")
+    fa, nfa = load(root + "/fetch/**/*counter_collection.csv", "FETCH_SIZE", ("gemm_f64_kernel", "gemm_f64_pair_kernel"))
+    wa, nwa = load(root + "/write/**/*counter_collection.csv", "WRITE_SIZE", ("gemm_f64_kernel", "gemm_f64_pair_kernel"))
     assert nf and nw, (nf, nw)
     fetch_b = f * 1024.0 * 2.0 / nf
     write_b = w * 1024.0 / nw
-    json.dump({"kernel": DOM, "launches_sampled": nf, "measured_on_commit": head,
+    json.dump({"kernel": " + ".join(DOM), "launches_sampled": nf, "measured_on_commit": head,
                "kernel_source_sha16": gemm_source_sha16(),
                "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
                "bytes_per_launch": fetch_b + write_b,
