@@ -120,7 +120,7 @@ struct pgp_ctx {
     int xcd_min_tiles = 256;            // ... to launches with at least this many 128-tiles
     int xcd_super = 8;                  // xcd_order: super-tile edge in tiles
     int solve_outer = 8;                // leaves per outer panel of the blocked multi-rhs triangular solve (K = 128 solve_outer)
-    int predict_batch = 16384;          // test points per batch of pgp_predict (scratch: np x batch doubles)
+    int predict_batch = 65536;          // test points per batch of pgp_predict (scratch: np x batch doubles, capped at 16 GiB -- predict_batch_points)
     int s_tile = 0;                     // tile size of the panel solves: 0 = automatic
     size_t Xs_bytes = 0;
     hipEvent_t ev[PGP_NSTAGE + 2];
@@ -321,6 +321,12 @@ int potrf_blocked(pgp_ctx* c, double* F, long ld, long np, long mrows, bool with
 int gemm_prof(pgp_ctx* c, int cls, GemmArgs g, hipStream_t st = nullptr);
 int gemm_prof_pair(pgp_ctx* c, int cls_a, GemmArgs a, int cls_b, GemmArgs b, hipStream_t st = nullptr);
 int batch_tile_list(pgp_ctx* c, int mt0, int nt, int nb, int dmt, const int** out, int* n);
+// test points per batch: the option, the number of points, and a 16 GiB cap on the np x batch cross-covariance block (never below 16384)
+inline long predict_batch_points(int option, long ns, long np) {
+    const long cap = std::max<long>(16384, ((long)1 << 34) / (8 * std::max<long>(np, 1)) / 128 * 128);
+    const long want = std::min<long>(option, (ns + 127) / 128 * 128);
+    return std::max<long>(128, std::min<long>(want, cap));
+}
 constexpr double ARD_GRAM_GRAD_BOUND = 1.0e8;     // max squared norm of a scaled, centred point for the Gram-form gradient weights
 bool gram_assembly_applies(pgp_ctx* c, const CovSpec& cs);
 int diag_block_factor(pgp_ctx* c, const double* src, long lds, int w, double* Fd, long ldf, double* Ed, long lde,

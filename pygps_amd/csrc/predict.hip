@@ -78,10 +78,10 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     CHK(ensure_wd(c, f));
     const long np = f->np, n = f->n;
     const int d = f->d, dpad = f->dpad;
-    // test points per batch (the reference uses 1000): up to predict_batch = 16384, so that the K = 128 updates of the
-    // blocked solve are whole waves of tiles (measured at N=8192, 65536 test points, warm: batch 1024 -> 318 ms = 13.8 TF on
-    // the N^2 flops per point of the triangular solve, 4096 -> 220 ms, 8192 -> 192 ms, 16384 -> 171 ms = 25.8 TF)
-    const long NSB = std::max<long>(128, std::min<long>(c->predict_batch, round_up(ns, 128)));
+    // test points per batch (the reference uses 1000): up to predict_batch = 65536 within 16 GiB of scratch, so that the K = 128
+    // updates of the blocked solve are many waves of tiles and the per-batch host round trip is rare (round 2, N = 8192, 65536 test
+    // points: batch 1024 -> 318 ms, 4096 -> 220, 8192 -> 192, 16384 -> 171; round 4 on one box: 16384 -> 120 ms, 65536 -> 101 ms)
+    const long NSB = predict_batch_points(c->predict_batch, ns, np);
     const long ldc = NSB;
     PoolScratch tmp(c);
     double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *o2 = nullptr;
@@ -133,7 +133,7 @@ int pgp_predict_dense(pgp_ctx* c, pgp_factor* f, const double* Ks_host, int64_t 
     hipStream_t st = c->st;
     CHK(ensure_wd(c, f));
     const long np = f->np, n = f->n;
-    const long NSB = std::max<long>(128, std::min<long>(c->predict_batch, round_up(ns, 128)));
+    const long NSB = predict_batch_points(std::min(c->predict_batch, 16384), ns, np);   // a HOST transpose block of n x batch doubles per step
     PoolScratch tmp(c);
     double *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *o2 = nullptr;
     CHK(tmp.alloc(&Ks, (size_t)np * NSB * sizeof(double)));

@@ -702,7 +702,7 @@ int pgp_sharded_predict(pgp_ctx* c, pgp_comm* m, pgp_sfactor* f, const double* x
     hipStream_t st = c->st;
     const long np = f->np, n = f->n, ldp = f->ldp;
     const int w = f->w, d = f->d, dpad = f->dpad;
-    const long NSB = std::max<long>(128, std::min<long>(c->predict_batch, round_up(ns, 128)));
+    const long NSB = predict_batch_points(c->predict_batch, ns, np);
     const long ldc = NSB;
     PoolScratch tmp(c);
     double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *acc = nullptr, *V = nullptr;
