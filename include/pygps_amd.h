@@ -63,6 +63,7 @@ int pgp_init(int device, pgp_ctx** ctx_out);
 void pgp_destroy(pgp_ctx* ctx);
 const char* pgp_strerror(int status);
 const char* pgp_version(void);
+int pgp_device_count(void);              /* visible HIP devices (0 when there is none or no driver) */
 int pgp_device_info(pgp_ctx* ctx, int* n_cu, int* sclk_mhz, double* hbm_gib, char* name, int name_len);
 
 /* ---- kernel plug-in: Kernel.getCovMatrix / getDerMatrix (Core/cov.py:81-111) ---------------
@@ -164,12 +165,23 @@ int pgp_comm_init_host(pgp_ctx* ctx, int world, int rank, pgp_host_bcast_fn bcas
 void pgp_comm_free(pgp_comm* comm);
 int pgp_comm_world(pgp_comm* comm);
 int pgp_comm_rank(pgp_comm* comm);
+/* Host collectives on the communicator: what the sharded restart search (Core/opt.py:301-327: init table + data out, one record
+ * per restart back), the sharded K-fold loop (Validation/valid.py:20-66) and a sum of nlZ / dnlZ over independent data sets
+ * (Demo/Clustering/pyGP_extension.py:54-64) exchange.  Buffers are HOST doubles; every rank calls with the same count.
+ * RCCL transport: staged through a device buffer on the communicator's stream (ncclBroadcast / ncclAllReduce / ncclAllGather);
+ * host transport: the call-backs.  pgp_comm_init_host accepts ctx = NULL for a communicator that only ever serves these
+ * three (no device is touched).  allgather: recv holds world * count doubles, rank r's at recv + r * count.  op: 0 sum, 1 max. */
+int pgp_comm_bcast_host(pgp_comm* comm, double* buf, int64_t count, int root);
+int pgp_comm_allreduce_host(pgp_comm* comm, double* buf, int64_t count, int op);
+int pgp_comm_allgather_host(pgp_comm* comm, const double* send, int64_t count, double* recv);
 /* Arguments and results as pgp_exact_fit.  timings_out (optional, 6): ms of assembly, sweep, epilogue, total; device bytes
  * this call held at its peak; device bytes the posterior handle keeps.  L_out (optional, (n,n) row-major, zero-filled by the
  * caller): THIS rank's columns of the factor in post.L's form (upper R, R'R = K/sn2 + I); the sum over the ranks is the whole
  * factor.  factor_out (optional): this rank's part of the distributed posterior (its column panels of L and of L^-T, alpha, the
  * coordinates) for pgp_sharded_predict.  Per-rank memory is O(n^2 / world): the panels, and for want = 3 the rank's column
- * strips of B^-1.  A rank that fails (out of memory, a launch error) makes EVERY rank return an error, none is left waiting. */
+ * strips of B^-1.  A rank that fails (out of memory, a launch error) makes EVERY rank return an error: its flag rides in the
+ * collectives the others wait in.  (A sticky device fault, after which no HIP call succeeds, cannot enqueue that collective: the
+ * failing rank then aborts the RCCL communicator so that the peers' collectives return with an error.) */
 typedef struct pgp_sfactor pgp_sfactor;
 int pgp_sharded_exact_fit(pgp_ctx* ctx, pgp_comm* comm, int kind, const double* covhyp, int ncov, int para, int flags,
                           double log_sn, const double* mvec, const double* dm, int nmean, int want, double* alpha_out,

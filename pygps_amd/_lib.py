@@ -35,6 +35,7 @@ SIGNATURES = {
     "pgp_destroy": (None, [_vp]),
     "pgp_strerror": (C.c_char_p, [C.c_int]),
     "pgp_version": (C.c_char_p, []),
+    "pgp_device_count": (C.c_int, []),
     "pgp_device_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_char_p, C.c_int]),
     "pgp_cov": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _i64, _dp, _i64, _i64, _dp, C.c_int, C.c_int,
                           C.c_int, _dp]),
@@ -72,6 +73,9 @@ SIGNATURES = {
     "pgp_comm_free": (None, [_vp]),
     "pgp_comm_world": (C.c_int, [_vp]),
     "pgp_comm_rank": (C.c_int, [_vp]),
+    "pgp_comm_bcast_host": (C.c_int, [_vp, _dp, _i64, C.c_int]),
+    "pgp_comm_allreduce_host": (C.c_int, [_vp, _dp, _i64, C.c_int]),
+    "pgp_comm_allgather_host": (C.c_int, [_vp, _dp, _i64, _dp]),
     "pgp_sharded_exact_fit": (C.c_int, [_vp, _vp, C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int,
                                         C.c_int, _dp, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
     "pgp_sharded_predict": (C.c_int, [_vp, _vp, _vp, _dp, _i64, _dp, _dp, _dp]),

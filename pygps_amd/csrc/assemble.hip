@@ -679,12 +679,8 @@ static int panel_tile_table(long nt, long t0, long t1, const int2** tab, long* c
     return PGP_OK;
 }
 
-static int g_tile_grid = 4096;                     // persistent workgroups (4 resident per CU, the rest queue: dynamic balance); option "asm_grid"
                                                    // (round 4, three alternations on one box, full symmetric RBF d = 16: N = 16384 56-58 % of the HBM peak
                                                    //  at 2048 workgroups, 62-64 % at 4096; N = 8192 61-62 % / 62-65 %)
-void cov_tile_set_grid(int g) { g_tile_grid = g; }
-static int g_tile_nt = 0;                          // non-temporal stores: 0 never (default), 1 always, -1 for outputs >= 1 GB; option "asm_nt"
-void cov_tile_set_nt(int v) { g_tile_nt = v; }
 
 template <int MODE>
 static int cov_tile_dispatch(const CovSpec& cs, int train, long ntr, long ntc_, hipStream_t st, const double* XrT, long ldr,
@@ -692,8 +688,8 @@ static int cov_tile_dispatch(const CovSpec& cs, int train, long ntr, long ntc_, 
                              long ldo, const int2* tiles = nullptr, long ntiles = 0) {
     if (!tiles) { const int rc = tile_table(MODE != MODE_RECT, ntr, ntc_, &tiles, &ntiles); if (rc != PGP_OK) return rc; }
     if (ntiles == 0) return PGP_OK;
-    const unsigned nblk = g_tile_grid > 0 ? (unsigned)std::min<long>(ntiles, g_tile_grid) : (unsigned)ntiles;
-    const int nt_ = g_tile_nt >= 0 ? g_tile_nt : ((MODE != MODE_FACTOR && (double)n * (double)m * 8.0 >= 1073741824.0) ? 1 : 0);
+    const unsigned nblk = cs.asm_grid > 0 ? (unsigned)std::min<long>(ntiles, cs.asm_grid) : (unsigned)ntiles;
+    const int nt_ = cs.asm_nt >= 0 ? cs.asm_nt : ((MODE != MODE_FACTOR && (double)n * (double)m * 8.0 >= 1073741824.0) ? 1 : 0);
     if (cs.prog) {
         CovProgram pg = cs.pg;
         for (int l = 0; l < pg.nleaf; ++l) pg.leaf[l].train = train;
@@ -764,7 +760,7 @@ static int cov_gram_dispatch(int mode, const double* XT, long ldp, long n, long 
     if (ntiles == 0) return PGP_OK;
     const int CH = dpad < 64 ? dpad : 64;
     const size_t shm = std::max<size_t>((size_t)2 * CH * GSTP, (size_t)ST * GSTP) * sizeof(double);
-    const int nt_ = g_tile_nt >= 0 ? g_tile_nt : ((mode != MODE_FACTOR && (double)n * (double)n * 8.0 >= 1073741824.0) ? 1 : 0);
+    const int nt_ = cs.asm_nt >= 0 ? cs.asm_nt : ((mode != MODE_FACTOR && (double)n * (double)n * 8.0 >= 1073741824.0) ? 1 : 0);
     const unsigned grid = (unsigned)std::min<long>(ntiles, 2048);              // persistent: 2 resident per CU, the rest queue
 #define GRAM_LAUNCH(M, NPV) do {                                                                                                  \
         static std::atomic<int> attr_done{0};                                /* per instantiation: once */                         \
@@ -783,7 +779,8 @@ static int cov_gram_dispatch(int mode, const double* XT, long ldp, long n, long 
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 bool cov_gram_applies(const CovSpec& cs, int dpad) {
-    return !cs.prog && (cs.cp.kind == 0 || cs.cp.kind == 1) && cs.cp.der < 0 && dpad >= 32;
+    // dpad <= HADAMARD_PREP_MU: the prep buffer holds that many coordinate means in front of the norms (plain RBF has no cap on d)
+    return !cs.prog && (cs.cp.kind == 0 || cs.cp.kind == 1) && cs.cp.der < 0 && dpad >= 32 && dpad <= HADAMARD_PREP_MU;
 }
 int cov_factor_gram_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double inv_sn2, double* Bf,
                            long ldf, const double* prep, hipStream_t st) {

@@ -44,6 +44,11 @@ void prof_collect(pgp_ctx* c) {
 extern "C" {
 
 const char* pgp_version(void) { return "pygps_amd 0.1 (gfx950)"; }
+int pgp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 
 const char* pgp_strerror(int status) {
     if (status == 0) return "ok";
@@ -195,8 +200,8 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "eet_first")) { if (value < -1) return -2; c->eet_first = value; return PGP_OK; }
     if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
-    if (!strcmp(name, "asm_grid")) { cov_tile_set_grid(value); return PGP_OK; }
-    if (!strcmp(name, "asm_nt")) { cov_tile_set_nt(value); return PGP_OK; }
+    if (!strcmp(name, "asm_grid")) { c->asm_grid = value; return PGP_OK; }
+    if (!strcmp(name, "asm_nt")) { c->asm_nt = value; return PGP_OK; }
     if (!strcmp(name, "pair_launch")) { c->pair_launch = value != 0; return PGP_OK; }
     if (!strcmp(name, "gemm_trace")) {               // diagnostic: see ctx.h
         HIP_TRY(hipSetDevice(c->device));
@@ -303,6 +308,7 @@ static int make_leaf(int kind, const double* hyp, int nhyp, int para, int flags,
 // postfix program registered with pgp_set_composite, expanded here into a sum of products.
 int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int flags, int der, long d, CovSpec& cs) {
     cs = CovSpec{};
+    if (c) { cs.asm_grid = c->asm_grid; cs.asm_nt = c->asm_nt; }
     if (!hyp && nhyp > 0) return -10;
     if (kind >= PGP_COV_GABOR && kind < PGP_COV_NKIND) {
         // trigonometric / index-dependent primitives run as one-leaf programs (see sqdist_tile.h cov_value<EXT>)
@@ -324,8 +330,8 @@ int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int f
         if (kind == PGP_COV_RBFARD || kind == PGP_COV_RQARD) {
             for (long k = 0; k < d; ++k) cs.scale[k] = 1.0 / exp(hyp[k]);
             // the gradient pass weights its sums with K in the Gram form (hadamard_ard_kernel): relative error eps (|a|^2 + |b|^2) of
-            // the scaled, centred points.  Beyond |a|^2 ~ 1e8 (2e-8 in K; dnlZ is held to 1e-7) the difference-form kernel runs
-            // instead -- data spread over ten thousand length scales; the statistics are those of the resident x (pgp_set_data)
+            // the scaled, centred points.  Beyond |a|^2 ~ 1e6 (2e-10 in K; dnlZ is held to 1e-7 and the Hadamard sum can cancel) the difference-form kernel runs
+            // instead -- data spread over a thousand length scales; the statistics are those of the resident x (pgp_set_data)
             double bound = 0.0;
             if (c && (long)c->xdev2.size() == d)
                 for (long k = 0; k < d; ++k) bound += cs.scale[k] * cs.scale[k] * c->xdev2[k];

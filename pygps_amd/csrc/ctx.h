@@ -122,6 +122,7 @@ struct pgp_ctx {
     int solve_outer = 8;                // leaves per outer panel of the blocked multi-rhs triangular solve (K = 128 solve_outer)
     int predict_batch = 65536;          // test points per batch of pgp_predict (scratch: np x batch doubles, capped at 16 GiB -- predict_batch_points)
     int s_tile = 0;                     // tile size of the panel solves: 0 = automatic
+    int asm_grid = 4096, asm_nt = 0;    // assembly kernels: persistent workgroups per launch; non-temporal stores (CovSpec::asm_grid / asm_nt)
     size_t Xs_bytes = 0;
     hipEvent_t ev[PGP_NSTAGE + 2];
     double last_ms[PGP_NSTAGE];
@@ -327,7 +328,7 @@ inline long predict_batch_points(int option, long ns, long np) {
     const long want = std::min<long>(option, (ns + 127) / 128 * 128);
     return std::max<long>(128, std::min<long>(want, cap));
 }
-constexpr double ARD_GRAM_GRAD_BOUND = 1.0e8;     // max squared norm of a scaled, centred point for the Gram-form gradient weights
+constexpr double ARD_GRAM_GRAD_BOUND = 1.0e6;     // max squared norm of a scaled, centred point for the Gram-form gradient weights
 bool gram_assembly_applies(pgp_ctx* c, const CovSpec& cs);
 int diag_block_factor(pgp_ctx* c, const double* src, long lds, int w, double* Fd, long ldf, double* Ed, long lde,
                       int info_base, hipStream_t st, hipEvent_t staged = nullptr);

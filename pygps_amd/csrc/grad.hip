@@ -174,7 +174,7 @@ __device__ __forceinline__ void ard_dim_reduce(const double* __restrict__ XT, lo
 // The same sums in the DIFFERENCE form -- sum_rc w_rc (x_rk - x_ck)^2 term by term, what the reference's per-coordinate
 // getDerMatrix computes (Core/cov.py:924-931): three VALU instructions per element and coordinate, any D.  The fallback for data
 // whose scaled, centred points lie too far out for the product form above (its error is eps sum |w| |x|^2, this one's
-// eps sum |w| (x_r - x_c)^2): make_spec sets CovSpec::ard_grad_diff beyond |x|^2 = 1e8.  sm: 2 * SKC * STP doubles.
+// eps sum |w| (x_r - x_c)^2): make_spec sets CovSpec::ard_grad_diff beyond |x|^2 = 1e6.  sm: 2 * SKC * STP doubles.
 __device__ __forceinline__ void ard_dim_reduce_diff(const double* __restrict__ XT, long ldp, long r0, long c0, int dpad,
                                                     double* __restrict__ sm, const double (&w)[4][4],
                                                     const double* __restrict__ wk, int D, double* __restrict__ out) {
@@ -937,6 +937,7 @@ long hadamard_prep_count(long np) { return HADAMARD_PREP_MU + np; }
 int hadamard_prepare_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double* mu, hipStream_t st,
                             bool force) {
     const bool ard = force || (cs.prog ? cs.pg.ard_leaf >= 0 : (cs.cp.kind == 1 || cs.cp.kind == 6));
+    if (ard && dpad > HADAMARD_PREP_MU) return PGP_ERR_HIP;            // the mean region of the prep buffer (callers gate on it)
     if (ard) hipLaunchKernelGGL(coord_mean_kernel, dim3((unsigned)dpad), dim3(256), 0, st, XT, ldp, n, mu);
     if (ard && !cs.prog)
         hipLaunchKernelGGL(point_norm_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, XT, ldp, np, dpad, mu,

@@ -29,8 +29,6 @@ int cov_factor_launch(const double* XT, long ldp, long n, long np, int dpad, con
                       double* Bf, long ldf, hipStream_t st);
 int cov_factor_panel_launch(const double* XT, long ldp, long n, long np, int dpad, const CovSpec& cs, double inv_sn2,
                             long col0, long ncols, double* panel, long ldpanel, hipStream_t st);
-void cov_tile_set_grid(int g);
-void cov_tile_set_nt(int v);
 int cov_self_launch(const CovSpec& cs, int train, double* out_dev, hipStream_t st);
 int self_fill_launch(double* out, long m, double val, hipStream_t st);
 

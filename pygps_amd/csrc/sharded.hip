@@ -61,6 +61,8 @@ struct RcclApi {
     int (*CommDestroy)(rccl_comm_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*CommAbort)(rccl_comm_t) = nullptr;             // optional
     const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -80,8 +82,10 @@ static int rccl_load(const char* path, RcclApi& api) {
     api.CommDestroy = (int (*)(rccl_comm_t))dlsym(api.dl, "ncclCommDestroy");
     api.Broadcast = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(api.dl, "ncclBroadcast");
     api.AllReduce = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(api.dl, "ncclAllReduce");
+    api.AllGather = (int (*)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t))dlsym(api.dl, "ncclAllGather");
+    api.CommAbort = (int (*)(rccl_comm_t))dlsym(api.dl, "ncclCommAbort");
     api.GetErrorString = (const char* (*)(int))dlsym(api.dl, "ncclGetErrorString");
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Broadcast || !api.AllReduce) {
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Broadcast || !api.AllReduce || !api.AllGather) {
         pgp_set_last_hip_error(hipErrorSharedObjectSymbolNotFound, "dlsym(librccl)", __FILE__, __LINE__);
         return PGP_ERR_HIP;
     }
@@ -109,6 +113,10 @@ struct pgp_comm {
     void* user = nullptr;
     void* stage = nullptr;              // pinned staging buffer of the host transport
     size_t stage_bytes = 0;
+    double* agree = nullptr;            // 8 device doubles that exist before any call can fail to allocate (comm_agree_max)
+    // host collectives of the restart / fold searches (pgp_comm_bcast_host, pgp_comm_allgather_host): device staging
+    double* hostbuf = nullptr;
+    size_t hostbuf_bytes = 0;
 };
 
 namespace {
@@ -172,6 +180,30 @@ static int comm_allreduce(pgp_comm* m, double* buf, size_t count, int op, hipStr
     }
     HIP_TRY(hipMemcpyAsync(buf, m->stage, count * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return PGP_OK;
+}
+
+// max over the ranks of one host double, through the communicator's own 8-double buffer: every copy is ordered on `st` with the
+// all-reduce (RCCL's all-reduce is asynchronous on a non-blocking stream: a plain hipMemcpy on the null stream does not wait for it)
+static int comm_agree_max(pgp_comm* m, double mine, double* all, hipStream_t st) {
+    *all = mine;
+    if (m->world <= 1) return PGP_OK;
+    if (m->kind != 1) {                              // host transport: no device round trip needed
+        CHK(comm_stage(m, sizeof(double)));
+        *(double*)m->stage = mine;
+        const int rc = m->har(m->user, (double*)m->stage, 1, 1);
+        if (rc != 0) { pgp_set_last_hip_error(hipErrorUnknown, "host all-reduce call-back failed", __FILE__, __LINE__); return PGP_ERR_HIP; }
+        *all = *(double*)m->stage;
+        return PGP_OK;
+    }
+    CHK(comm_stage(m, 2 * sizeof(double)));
+    double* h = (double*)m->stage;
+    h[0] = mine;
+    HIP_TRY(hipMemcpyAsync(m->agree, h, sizeof(double), hipMemcpyHostToDevice, st));
+    CHK(comm_allreduce(m, m->agree, 1, 1, st));
+    HIP_TRY(hipMemcpyAsync(h + 1, m->agree, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *all = h[1];
     return PGP_OK;
 }
 
@@ -301,23 +333,120 @@ int pgp_comm_init_rccl(pgp_ctx* c, int world, int rank, const char* id, const ch
     const int nrc = m->api.CommInitRank(&m->comm, world, uid, rank);
     if (nrc != 0) { rc = rccl_fail(m->api, nrc, "ncclCommInitRank"); delete m; return rc; }
     if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess) { (void)m->api.CommDestroy(m->comm); delete m; return PGP_ERR_HIP; }
+    if (hipMalloc((void**)&m->agree, 8 * sizeof(double)) != hipSuccess || comm_stage(m, 64) != PGP_OK) {
+        (void)hipStreamDestroy(m->st_comm); (void)m->api.CommDestroy(m->comm); if (m->agree) (void)hipFree(m->agree); delete m; return PGP_ERR_HIP;
+    }
     *out = m;
     return PGP_OK;
 }
 
 int pgp_comm_init_host(pgp_ctx* c, int world, int rank, pgp_host_bcast_fn bcast, pgp_host_allreduce_fn allreduce, void* user,
                        pgp_comm** out) {
-    if (!c) return -1;
     if (world < 1) return -2;
     if (rank < 0 || rank >= world) return -3;
     if (world > 1 && (!bcast || !allreduce)) return -4;
     if (!out) return -7;
-    HIP_TRY(hipSetDevice(c->device));
     pgp_comm* m = new pgp_comm();
     m->ctx = c; m->world = world; m->rank = rank; m->kind = 2;
     m->hb = bcast; m->har = allreduce; m->user = user;
-    if (hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess) { delete m; return PGP_ERR_HIP; }
+    if (c) {                                         // ctx == NULL: a communicator for the host collectives only (no device is touched)
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&m->st_comm, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError(); delete m; return PGP_ERR_HIP;
+        }
+    }
     *out = m;
+    return PGP_OK;
+}
+
+// ---- host collectives on the communicator (the restart / fold searches of pygps_amd/opt.py, valid.py: Core/opt.py:301-327 sharded) ----
+// Buffers are HOST memory.  RCCL transport: staged through a device buffer of the communicator on its own stream; host
+// transport: the call-backs, directly.  Every rank calls with the same counts.
+static int comm_hostbuf(pgp_comm* m, size_t bytes) {
+    if (m->hostbuf_bytes >= bytes) return PGP_OK;
+    if (m->hostbuf) (void)hipFree(m->hostbuf);
+    m->hostbuf = nullptr; m->hostbuf_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&m->hostbuf, bytes));
+    m->hostbuf_bytes = bytes;
+    return PGP_OK;
+}
+static int host_stage(pgp_comm* m, size_t bytes) {        // plain (pageable is fine) host staging for a ctx-less communicator
+    if (m->ctx) return comm_stage(m, bytes);
+    if (m->stage_bytes >= bytes) return PGP_OK;
+    free(m->stage);
+    m->stage = malloc(bytes); m->stage_bytes = m->stage ? bytes : 0;
+    return m->stage ? PGP_OK : PGP_ERR_HIP;
+}
+
+int pgp_comm_bcast_host(pgp_comm* m, double* buf, int64_t count, int root) {
+    if (!m) return -1;
+    if (!buf && count > 0) return -2;
+    if (count < 0) return -3;
+    if (root < 0 || root >= m->world) return -4;
+    if (count == 0 || (m->world == 1 && m->kind != 1)) return PGP_OK;
+    const size_t bytes = (size_t)count * sizeof(double);
+    if (m->kind == 1) {
+        HIP_TRY(hipSetDevice(m->ctx->device));
+        CHK(comm_hostbuf(m, bytes));
+        if (m->rank == root) HIP_TRY(hipMemcpyAsync(m->hostbuf, buf, bytes, hipMemcpyHostToDevice, m->st_comm));
+        const int rc = m->api.Broadcast(m->hostbuf, m->hostbuf, (size_t)count, RCCL_DOUBLE, root, m->comm, m->st_comm);
+        if (rc != 0) return rccl_fail(m->api, rc, "ncclBroadcast");
+        if (m->rank != root) HIP_TRY(hipMemcpyAsync(buf, m->hostbuf, bytes, hipMemcpyDeviceToHost, m->st_comm));
+        HIP_TRY(hipStreamSynchronize(m->st_comm));
+        return PGP_OK;
+    }
+    const int rc = m->hb(m->user, buf, (int64_t)bytes, root);
+    if (rc != 0) { pgp_set_last_hip_error(hipErrorUnknown, "host broadcast call-back failed", __FILE__, __LINE__); return PGP_ERR_HIP; }
+    return PGP_OK;
+}
+
+int pgp_comm_allreduce_host(pgp_comm* m, double* buf, int64_t count, int op) {
+    if (!m) return -1;
+    if (!buf && count > 0) return -2;
+    if (count < 0) return -3;
+    if (op != 0 && op != 1) return -4;
+    if (count == 0 || (m->world == 1 && m->kind != 1)) return PGP_OK;
+    const size_t bytes = (size_t)count * sizeof(double);
+    if (m->kind == 1) {
+        HIP_TRY(hipSetDevice(m->ctx->device));
+        CHK(comm_hostbuf(m, bytes));
+        HIP_TRY(hipMemcpyAsync(m->hostbuf, buf, bytes, hipMemcpyHostToDevice, m->st_comm));
+        CHK(comm_allreduce(m, m->hostbuf, (size_t)count, op, m->st_comm));
+        HIP_TRY(hipMemcpyAsync(buf, m->hostbuf, bytes, hipMemcpyDeviceToHost, m->st_comm));
+        HIP_TRY(hipStreamSynchronize(m->st_comm));
+        return PGP_OK;
+    }
+    const int rc = m->har(m->user, buf, count, op);
+    if (rc != 0) { pgp_set_last_hip_error(hipErrorUnknown, "host all-reduce call-back failed", __FILE__, __LINE__); return PGP_ERR_HIP; }
+    return PGP_OK;
+}
+
+// recv: world * count doubles, rank r's `count` doubles at recv + r * count.  Host transport: an all-reduce (sum) of a buffer
+// that is zero outside the rank's own slot -- exact (x + 0), infinities and NaNs of the slot's owner included.
+int pgp_comm_allgather_host(pgp_comm* m, const double* send, int64_t count, double* recv) {
+    if (!m) return -1;
+    if ((!send || !recv) && count > 0) return -2;
+    if (count < 0) return -3;
+    if (count == 0) return PGP_OK;
+    const size_t bytes = (size_t)count * sizeof(double);
+    if (m->kind == 1) {
+        HIP_TRY(hipSetDevice(m->ctx->device));
+        CHK(comm_hostbuf(m, bytes * (size_t)(m->world + 1)));
+        double* sd = m->hostbuf + (size_t)m->world * (size_t)count;
+        HIP_TRY(hipMemcpyAsync(sd, send, bytes, hipMemcpyHostToDevice, m->st_comm));
+        const int rc = m->api.AllGather(sd, m->hostbuf, (size_t)count, RCCL_DOUBLE, m->comm, m->st_comm);
+        if (rc != 0) return rccl_fail(m->api, rc, "ncclAllGather");
+        HIP_TRY(hipMemcpyAsync(recv, m->hostbuf, bytes * (size_t)m->world, hipMemcpyDeviceToHost, m->st_comm));
+        HIP_TRY(hipStreamSynchronize(m->st_comm));
+        return PGP_OK;
+    }
+    if (m->world == 1) { if (recv != send) memmove(recv, send, bytes); return PGP_OK; }
+    CHK(host_stage(m, bytes * (size_t)m->world));
+    double* st = (double*)m->stage;
+    memset(st, 0, bytes * (size_t)m->world);
+    memcpy(st + (size_t)m->rank * (size_t)count, send, bytes);
+    const int rc = m->har(m->user, st, count * (int64_t)m->world, 0);
+    if (rc != 0) { pgp_set_last_hip_error(hipErrorUnknown, "host all-reduce call-back failed", __FILE__, __LINE__); return PGP_ERR_HIP; }
+    memcpy(recv, st, bytes * (size_t)m->world);
     return PGP_OK;
 }
 
@@ -326,7 +455,9 @@ void pgp_comm_free(pgp_comm* m) {
     if (m->ctx) (void)hipSetDevice(m->ctx->device);
     if (m->st_comm) { (void)hipStreamSynchronize(m->st_comm); (void)hipStreamDestroy(m->st_comm); }
     if (m->kind == 1 && m->comm) (void)m->api.CommDestroy(m->comm);
-    if (m->stage) (void)hipHostFree(m->stage);
+    if (m->stage) { if (m->ctx) (void)hipHostFree(m->stage); else free(m->stage); }
+    if (m->agree) (void)hipFree(m->agree);
+    if (m->hostbuf) (void)hipFree(m->hostbuf);
     delete m;
 }
 
@@ -380,7 +511,7 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
     auto take = [&](double** out, size_t bytes) {
         if (arc == PGP_OK) { arc = scr.alloc(out, bytes); if (arc == PGP_OK) held_bytes += bytes; }
     };
-    CHK(scr.alloc(&red, (size_t)(np + 8) * sizeof(double)));
+    take(&red, (size_t)(np + 8) * sizeof(double));
     take(&Bufs, (size_t)(nloc + 1) * pbytes);
     take(&Ld, (size_t)std::max(nloc, 1) * w * w * sizeof(double));
     if (world > 1) { take(&R[0], pbytes); take(&R[1], pbytes); }
@@ -394,11 +525,8 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
         take(&partial, (size_t)(hblocks * (ncov + 1) + hadamard_prep_count(np)) * sizeof(double));
     }
     if (world > 1) {                                 // a rank that ran out of memory must not leave the others in a collective
-        const double flag = arc != PGP_OK ? 1.0 : 0.0;
-        HIP_TRY(hipMemcpy(red, &flag, sizeof(double), hipMemcpyHostToDevice));
-        CHK(comm_allreduce(m, red, 1, 1, c->st));
         double any = 0.0;
-        HIP_TRY(hipMemcpy(&any, red, sizeof(double), hipMemcpyDeviceToHost));
+        CHK(comm_agree_max(m, arc != PGP_OK ? 1.0 : 0.0, &any, c->st));
         if (arc != PGP_OK) return arc;
         if (any != 0.0) { pgp_set_last_hip_error(hipErrorOutOfMemory, "another rank of the sharded fit ran out of device memory", __FILE__, __LINE__); return PGP_ERR_HIP; }
     } else if (arc != PGP_OK) return arc;
@@ -569,7 +697,15 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
         const double one = 1.0;
         (void)hipMemcpy(red + np + 4, &one, sizeof(double), hipMemcpyHostToDevice);
     }
-    HIP_TRY(hipEventRecord(c->ev[2], main));
+    // a poisoned rank must reach the all-reduce that carries its flag: nothing before it may return (a STICKY device fault makes
+    // every HIP call fail, the all-reduce included -- then only ncclCommAbort below can release the peers)
+    if (hipEventRecord(c->ev[2], main) != hipSuccess && poison == PGP_OK) {
+        if (world == 1) return PGP_ERR_HIP;
+        poison = PGP_ERR_HIP;
+        (void)hipGetLastError();
+        const double one = 1.0;
+        (void)hipMemcpy(red + np + 4, &one, sizeof(double), hipMemcpyHostToDevice);
+    }
 
     // ---- epilogue: alpha, log det, z'z from this rank's panels; ONE all-reduce ------------------------------------------
     if (poison == PGP_OK) {
@@ -592,7 +728,13 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
             (void)hipMemcpy(red + np + 4, &one, sizeof(double), hipMemcpyHostToDevice);
         }
     }
-    CHK(comm_allreduce(m, red, (size_t)np + 5, 0, main));
+    {
+        const int arc2 = comm_allreduce(m, red, (size_t)np + 5, 0, main);
+        if (arc2 != PGP_OK) {                        // the flag cannot travel (sticky fault / transport down): abort the communicator so that
+            if (m->kind == 1 && m->api.CommAbort && m->comm) { (void)m->api.CommAbort(m->comm); m->comm = nullptr; }   // the peers' collectives return
+            return poison != PGP_OK ? poison : arc2;
+        }
+    }
     std::vector<double> head(8, 0.0);
     HIP_TRY(hipMemcpyAsync(head.data(), red + np, 5 * sizeof(double), hipMemcpyDeviceToHost, main));
     HIP_TRY(hipStreamSynchronize(main));
@@ -605,7 +747,8 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
     if (head[2] != 0.0) {                            // a non-positive pivot somewhere: every rank learns the first one
         CHK(comm_allreduce(m, red + np + 3, 1, 1, main));
         double v = 0.0;
-        HIP_TRY(hipMemcpy(&v, red + np + 3, sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(&v, red + np + 3, sizeof(double), hipMemcpyDeviceToHost, main));
+        HIP_TRY(hipStreamSynchronize(main));
         (void)hipDeviceSynchronize();
         const long piv = (long)llround(1.0e9 - v);
         return (int)(piv > n ? n : (piv < 1 ? 1 : piv));
@@ -708,7 +851,7 @@ int pgp_sharded_predict(pgp_ctx* c, pgp_comm* m, pgp_sfactor* f, const double* x
     double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *acc = nullptr, *V = nullptr;
     int arc = PGP_OK;
     auto take = [&](double** out, size_t bytes) { if (arc == PGP_OK) arc = tmp.alloc(out, bytes); };
-    CHK(tmp.alloc(&acc, (NSB + 1) * sizeof(double)));            // [NSB]: "a rank failed in this batch", summed with the column sums
+    take(&acc, (NSB + 1) * sizeof(double));                      // [NSB]: "a rank failed in this batch", summed with the column sums
     take(&xd, NSB * d * sizeof(double));
     take(&XcT, (size_t)dpad * ldc * sizeof(double));
     take(&scd, dpad * sizeof(double));
@@ -717,11 +860,8 @@ int pgp_sharded_predict(pgp_ctx* c, pgp_comm* m, pgp_sfactor* f, const double* x
     take(&o1, NSB * sizeof(double));
     take(&V, (size_t)w * NSB * sizeof(double));
     if (m->world > 1) {
-        const double flag = arc != PGP_OK ? 1.0 : 0.0;
-        HIP_TRY(hipMemcpy(acc, &flag, sizeof(double), hipMemcpyHostToDevice));
-        CHK(comm_allreduce(m, acc, 1, 1, st));
         double any = 0.0;
-        HIP_TRY(hipMemcpy(&any, acc, sizeof(double), hipMemcpyDeviceToHost));
+        CHK(comm_agree_max(m, arc != PGP_OK ? 1.0 : 0.0, &any, st));
         if (arc != PGP_OK) return arc;
         if (any != 0.0) { pgp_set_last_hip_error(hipErrorOutOfMemory, "another rank of the sharded predict ran out of device memory", __FILE__, __LINE__); return PGP_ERR_HIP; }
     } else if (arc != PGP_OK) return arc;

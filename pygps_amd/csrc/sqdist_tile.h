@@ -442,6 +442,9 @@ struct CovSpec {
     double ell4 = 1.0;              // RQard reference-compat 'cross' derivative factor ell_der^4
     bool ard_grad_diff = false;     // plain ARD kinds: the gradient pass must weight with the difference-form K (make_spec: the scaled,
                                     // centred points of the resident x are too far out for the Gram form's eps |a|^2 -- grad.hip)
+    // launch tuning of the assembly kernels, copied from the context that made the spec (options "asm_grid", "asm_nt")
+    int asm_grid = 4096;            // persistent workgroups (4 resident per CU, the rest queue: dynamic balance)
+    int asm_nt = 0;                 // non-temporal stores: 0 never (default), 1 always, -1 for outputs >= 1 GB
     double sf2() const { return cp.sf2; }
 };
 

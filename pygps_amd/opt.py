@@ -2,10 +2,14 @@
 
 ``Minimize`` is the reference's sequential restart loop around the CG minimiser; every objective
 evaluation is one device fit.  ``ShardedMinimize`` runs the SAME restarts one-per-GPU: one process
-per GPU (torch.distributed, backend nccl = RCCL over xGMI; gloo in the CPU tests), rank 0 draws the
-random initial points in the reference's RNG order and broadcasts them, every rank optimises its
-share with its own GPU, a single all-gather returns (nlZ, hyp, #line-searches, failed) per restart
-and every rank applies the reference's selection rule.  No collective touches the data path.
+per GPU, rank 0 draws the random initial points in the reference's RNG order and broadcasts them,
+every rank optimises its share with its own GPU, a single all-gather returns (nlZ, hyp,
+#line-searches, failed) per restart and every rank applies the reference's selection rule.  No
+collective touches the data path.  The three broadcasts and the all-gather go through the library's
+own communicator (``sharded.Comm`` -> ``pgp_comm_bcast_host`` / ``pgp_comm_allgather_host``: RCCL
+over xGMI, bound by the library itself); what hands the 128-byte RCCL id around is either an
+initialised ``torch.distributed`` group or -- no torch anywhere -- the socket group of
+``pygps_amd.hostgroup`` (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as any launcher exports them).
 """
 import logging
 from copy import deepcopy
@@ -154,14 +158,28 @@ class ShardedMinimize(Minimize):
     #: 10.0 instead of 12.6 ms per fit at N=8192 on MI355X (round 2).  Results do not depend on this number.
     streams_per_gpu = 2
 
-    def __init__(self, model, searchConfig=None, group=None, streams_per_gpu=None):
+    def __init__(self, model, searchConfig=None, group=None, streams_per_gpu=None, deal="auto"):
+        """group: None (the initialised torch.distributed default group if there is one, else the launcher's environment
+        through ``hostgroup.HostGroup``, else world size 1), a torch process group, a ``HostGroup`` or a ready
+        ``sharded.Comm``.  deal: "static" = restart t on rank t % world; "dynamic" = ranks take restarts from a group-wide
+        ticket counter; "auto" = static when there is at most one restart per rank (cfg 4: 8 restarts on 8 GPUs), else
+        dynamic -- line searches differ in length and the slowest rank sets the wall time.  Results do not depend on it."""
         super(ShardedMinimize, self).__init__(model, searchConfig)
-        from . import _lib
-        _lib.want_torch()               # torch.distributed carries the collectives; torch goes in before the first context
         self.group = group
+        self.comm = None
+        self.deal = deal
         self.runs = None                # per-restart records of the last findMin (all ranks)
+        self.owner = None               # rank that ran each restart of the last findMin
         if streams_per_gpu is not None:
             self.streams_per_gpu = int(streams_per_gpu)
+
+    def _get_comm(self):
+        """The communicator of the search, created on first use and shared by every ShardedMinimize of the process that
+        names the same group."""
+        if self.comm is None:
+            from . import sharded
+            self.comm = self.group if isinstance(self.group, sharded.Comm) else sharded.search_comm(self.group)
+        return self.comm
 
     @staticmethod
     def _cold_start(model):
@@ -179,31 +197,42 @@ class ShardedMinimize(Minimize):
         self._cold_start(self.model)
         return super(ShardedMinimize, self)._one(hyp0, numIters)
 
-    def _run_share(self, mine, table, numIters):
-        """Optimise the restarts `mine` (indices into table); returns {t: _Run}.  With more than one fit stream
-        the restarts are dealt to host threads, each with a private deep copy of the model and its own device
-        context (pygps_amd._lib.fit_stream); ctypes releases the GIL while a fit runs on the GPU."""
-        S = max(1, min(int(self.streams_per_gpu), len(mine)))
-        if S == 1:
-            return {t: self._one(table[t].copy(), numIters) for t in mine}
+    def _run_share(self, mine, table, numIters, take=None):
+        """Optimise restarts (indices into table); returns {t: _Run}.  `mine`: this rank's list (static deal); `take`: a
+        thread-safe callable that returns the next restart index of the whole group or None (dynamic deal).  With more
+        than one fit stream the restarts are dealt to host threads, each with a private deep copy of the model and its
+        own device context (pygps_amd._lib.fit_stream); ctypes releases the GIL while a fit runs on the GPU."""
         import threading
+        lock = threading.Lock()
+        todo = list(mine) if mine is not None else None
+
+        def next_item():
+            if take is not None:
+                return take()
+            with lock:                            # restarts are taken from a shared queue: line searches differ in length, a
+                return todo.pop(0) if todo else None   # static deal can leave one stream idle at the end
+        S = max(1, int(self.streams_per_gpu))
+        if todo is not None:
+            S = min(S, max(1, len(todo)))
+        out = {}
+        if S == 1:
+            while True:
+                t = next_item()
+                if t is None:
+                    return out
+                out[t] = self._one(table[t].copy(), numIters)
         from copy import deepcopy as _dc
         from . import _lib
-        out = {}
-
-        todo = list(mine)
-        lock = threading.Lock()
 
         def work(k):
             with _lib.fit_stream(k):
                 clone = Minimize(_dc(self.model), None)
                 clone.model.optimizer = clone
                 clone.logger = self.logger
-                while True:                       # restarts are taken from a shared queue: line searches differ in length, a
-                    with lock:                    # static deal can leave one stream idle at the end.  Results do not depend
-                        if not todo:              # on the deal: every restart starts cold (_cold_start)
-                            return
-                        t = todo.pop(0)
+                while True:                       # results do not depend on the deal: every restart starts cold (_cold_start)
+                    t = next_item()
+                    if t is None:
+                        return
                     self._cold_start(clone.model)
                     out[t] = clone._one(table[t].copy(), numIters)
         ths = [threading.Thread(target=work, args=(k,)) for k in range(S)]
@@ -221,8 +250,7 @@ class ShardedMinimize(Minimize):
         the reference's sequential bookkeeping is replayed over the concatenated runs, so the optimum returned is the one
         the sequential loop would have stopped at -- only the restarts after it inside the last wave are extra work."""
         cfg = self.searchConfig
-        dist = self._dist()
-        world = dist.get_world_size(self.group) if dist else 1
+        world = self._get_comm().world
         wave = max(2, world * max(1, int(self.streams_per_gpu)))
         runs_all, tables = [], []
         hyp_keep = self._convert_to_array()
@@ -256,28 +284,14 @@ class ShardedMinimize(Minimize):
         finally:
             cfg.num_restarts, cfg.min_threshold = saved
 
-    @staticmethod
-    def _dist():
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                return dist
-        except Exception:
-            pass
-        return None
-
     def findMin(self, x, y, numIters=200):
-        import torch
         cfg = self.searchConfig
         if not cfg or not (cfg.num_restarts or cfg.min_threshold):
             raise Exception("Specify at least one of the stop conditions")       # Core/opt.py:303-304
         if not cfg.num_restarts:
             return self._find_by_threshold(x, y, numIters)
-        dist = self._dist()
-        rank = dist.get_rank(self.group) if dist else 0
-        world = dist.get_world_size(self.group) if dist else 1
-        use_cuda = bool(dist) and dist.get_backend(self.group) == "nccl"
-        dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+        comm = self._get_comm()
+        rank, world = comm.rank, comm.world
         hyp0 = self._convert_to_array()
         nh = hyp0.shape[0]
         R = int(cfg.num_restarts)
@@ -290,37 +304,47 @@ class ShardedMinimize(Minimize):
             for t in range(0 if cont else 1, R):
                 for i in range(nh):
                     table[t, i] = np.random.uniform(low=ranges[i][0], high=ranges[i][1])
-        # the collectives run whenever a process group exists, world size 1 included: the RCCL path of a one-GPU job is
-        # then the same code that runs on eight (and is exercised by the one-GPU test tier)
-        if dist:
-            tt = torch.from_numpy(table).to(dev)
-            dist.broadcast(tt, src=0, group=self.group)                  # RCCL broadcast #1: init table
-            table = tt.cpu().numpy()
-            xt = torch.from_numpy(np.ascontiguousarray(self.model.x, dtype=np.float64)).to(dev)
-            yt = torch.from_numpy(np.ascontiguousarray(self.model.y, dtype=np.float64)).to(dev)
-            dist.broadcast(xt, src=0, group=self.group)                  # RCCL broadcast #2: X, y (~1 MB)
-            dist.broadcast(yt, src=0, group=self.group)
-            self.model.x, self.model.y = xt.cpu().numpy(), yt.cpu().numpy()
+        # the collectives run at world size 1 too: the RCCL path of a one-GPU job is then the same code that runs on eight
+        # (and is exercised by the one-GPU test tier)
+        table = comm.bcast(table, 0)                                     # broadcast #1: init table
+        xs = np.asarray(self.model.x).shape
+        ys = np.asarray(self.model.y).shape
+        self.model.x = comm.bcast(np.array(self.model.x, dtype=np.float64), 0).reshape(xs)     # broadcast #2, #3: X, y (~1 MB)
+        self.model.y = comm.bcast(np.array(self.model.y, dtype=np.float64), 0).reshape(ys)
         self.init_table = table.copy()                                   # per-restart initial points (row 0 = current hyps)
         # local share
-        rec = np.zeros((R, nh + 3))
+        rec = np.zeros((R, nh + 4))
         rec[:, 0] = np.inf
         rec[:, nh + 2] = 1.0                                             # failed unless proven otherwise
-        mine = [t for t in range(R) if t % world == rank]
-        for t, r in sorted(self._run_share(mine, table, numIters).items()):
+        seq = comm.search_seq = getattr(comm, "search_seq", 0) + 1       # the same on every rank: findMin is collective
+        dynamic = self.deal == "dynamic" or (self.deal == "auto" and R > world and world > 1)
+        take = None
+        if dynamic and comm.ticket("probe/%d" % seq) is not None:
+            import threading
+            tlock = threading.Lock()
+            name = "restart/%d" % seq
+
+            def take():
+                with tlock:
+                    t = comm.ticket(name)
+                return t if t is not None and t < R else None
+        mine = None if take else [t for t in range(R) if t % world == rank]
+        for t, r in sorted(self._run_share(mine, table, numIters, take).items()):
+            rec[t, nh + 3] = 1.0                                         # this rank ran it
             if r.ok:
                 rec[t, 0] = r.f
                 rec[t, 1:1 + nh] = r.hyp
                 rec[t, nh + 1] = r.nls
                 rec[t, nh + 2] = 0.0
-        if dist:
-            mt = torch.from_numpy(rec).to(dev)
-            # each restart is owned by exactly one rank and the others hold (inf, 0.., failed):
-            # gather all shares, then pick the owner's row
-            parts = [torch.empty_like(mt) for _ in range(world)]
-            dist.all_gather(parts, mt, group=self.group)                 # RCCL all-gather: R x (nh+3) doubles
-            full = np.stack([p.cpu().numpy() for p in parts])
-            rec = np.stack([full[t % world, t] for t in range(R)])
+        # each restart was run by exactly one rank and the others hold (inf, 0.., failed, not run): gather all shares
+        # (ONE all-gather of R x (nh+4) doubles), then pick the runner's row
+        full = comm.allgather(rec)
+        ran = full[:, :, nh + 3]
+        if not np.all(ran.sum(axis=0) == 1.0):
+            raise RuntimeError("ShardedMinimize: restarts %s were run by %s ranks" % (np.nonzero(ran.sum(axis=0) != 1.0)[0].tolist(),
+                                                                                      ran.sum(axis=0)[ran.sum(axis=0) != 1.0].tolist()))
+        self.owner = np.argmax(ran, axis=0)
+        rec = np.stack([full[self.owner[t], t] for t in range(R)])
         runs = [_Run(rec[t, nh + 2] == 0.0, rec[t, 0], rec[t, 1:1 + nh].copy(), int(rec[t, nh + 1])) for t in range(R)]
         self.runs = runs
         self.trailsCounter += R
@@ -341,3 +365,38 @@ class ShardedMinimize(Minimize):
         self.logger.warning("[Minimize] %d out of %d trails failed during optimization", self.errorCounter,
                             self.trailsCounter)
         return best.hyp, best.f
+
+
+def multi_dataset_objective(hyperparams, model, xs, ys, der=False, group=None):
+    """Sum of the negative log marginal likelihoods (and gradients) of ONE model over independent data sets -- the objective of
+    pyGPs/Demo/Clustering/pyGP_extension.py:27-76 (``gp_likelihood_independent``: covfunc.hyp <- hyperparams, then per
+    data set setData + getPosterior, ``all_nlZ += nlZ``, ``all_dnlZ.accumulateDnlZ``) -- with data set i on rank i % world
+    and ONE all-reduce of 1 + nhyp + len(xs) doubles.  Every rank passes the same lists.
+
+    Returns (all_nlZ, all_dnlZ or None, per-data-set nlZ array), identical on every rank; the reference's scalar return value
+    is ``all_nlZ`` (der False) or ``all_nlZ + sum(all_dnlZ.cov) + sum(all_dnlZ.mean)`` (der True)."""
+    from . import inf, sharded
+    comm = group if isinstance(group, sharded.Comm) else sharded.search_comm(group)
+    model.covfunc.hyp = np.asarray(hyperparams, dtype=float).tolist()
+    D = len(xs)
+    model.setData(xs[0], ys[0])                      # fixes the mean function's size (the default mean becomes Const on setData)
+    nm, nc, nl = len(model.meanfunc.hyp), len(model.covfunc.hyp), len(model.likfunc.hyp)
+    acc = np.zeros(1 + nm + nc + nl + D)
+    for i in range(comm.rank, D, comm.world):
+        model.setData(xs[i], ys[i])
+        if der:
+            nlZ, dnlZ, post = model.getPosterior(der=True)
+            acc[1:1 + nm + nc + nl] += np.array(list(dnlZ.mean) + list(dnlZ.cov) + list(dnlZ.lik), dtype=float)
+        else:
+            nlZ, post = model.getPosterior(der=False)
+        acc[0] += nlZ
+        acc[1 + nm + nc + nl + i] = nlZ
+    acc = comm.allreduce(acc, "sum")
+    all_dnlZ = None
+    if der:
+        all_dnlZ = inf.dnlZStruct(model.meanfunc, model.covfunc, model.likfunc)
+        g = acc[1:1 + nm + nc + nl]
+        all_dnlZ.mean = [np.float64(v) for v in g[:nm]]
+        all_dnlZ.cov = [np.float64(v) for v in g[nm:nm + nc]]
+        all_dnlZ.lik = [np.float64(v) for v in g[nm + nc:]]
+    return float(acc[0]), all_dnlZ, acc[1 + nm + nc + nl:].copy()

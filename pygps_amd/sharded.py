@@ -4,15 +4,20 @@ No reference counterpart -- ``Exact.evaluate`` (pyGPs/Core/inf.py:353-384) facto
 every rank calls with the same model; the factorisation is 1-D block-cyclic over column panels, panels travel by broadcast
 and everything else a fit returns (alpha, nlZ, dnlZ) needs two small all-reduces (see the header of csrc/sharded.hip).
 
-``Comm`` binds a ``torch.distributed`` process group to the library's transport (``pgp_comm``):
+``Comm`` binds the library's transport (``pgp_comm``) to a SIDE CHANNEL that only ever carries kilobytes:
 
-* backend ``nccl``: the library talks to RCCL itself (it dlopens the librccl the process already uses -- the one bundled
-  with torch -- and enqueues ``ncclBroadcast`` / ``ncclAllReduce`` on its own streams: no host synchronisation inside the
-  sweep).  ``torch.distributed`` only carries the 128-byte communicator id from rank 0 to the others.
-* backend ``gloo`` (or any other): host call-backs; the library stages device memory through pinned host memory and this
-  module broadcasts / reduces the host buffers with ``torch.distributed``.  That is the self-test transport: several ranks can
-  share the ONE GPU of a test box (RCCL refuses two ranks on one device).
-* no process group: world size 1 over the host transport (nothing moves).
+* a ``torch.distributed`` process group (backend ``nccl``: the library talks to RCCL itself -- it dlopens the librccl the
+  process already uses and enqueues ``ncclBroadcast`` / ``ncclAllReduce`` on its own streams, no host synchronisation
+  inside the sweep; torch only carries the 128-byte communicator id.  Backend ``gloo``: the library's host transport, the
+  call-backs broadcast / reduce pinned host buffers through torch -- several ranks can share the ONE GPU of a test box), or
+* a ``hostgroup.HostGroup`` (sockets, no torch anywhere: ``PYGPS_AMD_NO_TORCH=1`` or simply no initialised process group
+  while RANK / WORLD_SIZE are set): the same two transports -- RCCL with the id handed around over the sockets, or the host
+  call-backs served by the group, or
+* nothing: world size 1.
+
+Besides the sharded fit the communicator serves the HOST collectives of the restart search, the K-fold loop and the
+multi-dataset objective (``bcast`` / ``allgather`` / ``allreduce`` below -> ``pgp_comm_bcast_host`` ...: on the RCCL
+transport they are ncclBroadcast / ncclAllGather / ncclAllReduce over xGMI) and a group-wide ticket counter.
 
 ``inf.Exact(sharded=True)`` (or ``sharded=Comm(...)``) routes ``evaluate`` through it; ``post.L`` is then a
 ``DistributedFactor``: the factor stays on the ranks (every rank keeps its column panels of L and of L^-T, O(n^2 / world)
@@ -31,41 +36,125 @@ _BCAST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
 _ALLRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int)
 
 
+class _TorchSide(object):
+    """The side channel over an initialised torch.distributed process group."""
+
+    def __init__(self, dist, group):
+        self.dist, self.group = dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+
+    def _global(self, group_rank):
+        return group_rank if self.group is None else self.dist.get_global_rank(self.group, group_rank)
+
+    def _dev(self, device):
+        import torch
+        return torch.device("cuda", device) if self.backend == "nccl" else torch.device("cpu")
+
+    def bcast(self, a, root=0, device=0):
+        """a: writable numpy array, in place."""
+        import torch
+        t = torch.from_numpy(a)
+        if self.backend == "nccl":
+            t = t.to(self._dev(device))
+        self.dist.broadcast(t, src=self._global(root), group=self.group)
+        if self.backend == "nccl":
+            a[...] = t.cpu().numpy()
+        return a
+
+    def allreduce(self, a, op="sum", device=0):
+        import torch
+        t = torch.from_numpy(a)
+        if self.backend == "nccl":
+            t = t.to(self._dev(device))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op in ("max", 1) else self.dist.ReduceOp.SUM, group=self.group)
+        if self.backend == "nccl":
+            a[...] = t.cpu().numpy()
+        return a
+
+    def ticket(self, name):
+        # the default store of the process group is a key-value server with an atomic add
+        from torch.distributed import distributed_c10d as c10d
+        return int(c10d._get_default_store().add("pygps_amd/ticket/" + name, 1)) - 1
+
+
+def _find_side(group):
+    """group: None (auto), a torch process group, or a hostgroup.HostGroup."""
+    from .hostgroup import HostGroup
+    if isinstance(group, HostGroup):
+        return group
+    no_torch = bool(os.environ.get("PYGPS_AMD_NO_TORCH"))
+    if not no_torch:
+        import sys
+        if group is not None or "torch" in sys.modules:
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    return _TorchSide(dist, group)
+            except Exception:
+                pass
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        global _env_group
+        if _env_group is None:
+            _env_group = HostGroup.from_env()
+        return _env_group
+    return None
+
+
+_env_group = None
+
+
 class Comm(object):
-    """The transport of a sharded fit: a ``pgp_comm`` bound to a torch.distributed process group (or to nothing: world 1)."""
+    """A ``pgp_comm`` bound to a side channel (module docstring).  ``device="host"``: a communicator for the host
+    collectives only -- no GPU is touched (CPU-side tests of the sharded searches)."""
 
     def __init__(self, group=None, device=None, transport=None):
         self.lib = _lib.load()
         self.group = group
-        self.device = _lib.default_device() if device is None else int(device)
-        self.ctx = _lib.ctx(self.device)
-        dist = None
-        try:
-            import torch.distributed as dist_
-            if dist_.is_available() and dist_.is_initialized():
-                dist = dist_
-        except Exception:
-            dist = None
-        self.dist = dist
-        self.rank = dist.get_rank(group) if dist else 0
-        self.world = dist.get_world_size(group) if dist else 1
-        backend = dist.get_backend(group) if dist else None
+        self.side = _find_side(group)
+        self.rank = self.side.rank if self.side else 0
+        self.world = self.side.world if self.side else 1
+        self.host_only = device == "host"
+        if self.host_only:
+            self.device, self.ctx = None, None
+        else:
+            self.device = _lib.default_device() if device is None else int(device)
+            self.ctx = _lib.ctx(self.device)
+        torch_backend = getattr(self.side, "backend", None)
+        self.dist = getattr(self.side, "dist", None)
         if transport is None:
-            transport = "rccl" if backend == "nccl" else "host"
+            transport = os.environ.get("PYGPS_AMD_TRANSPORT") or None
+        if transport is None:
+            if self.host_only or torch_backend not in (None, "nccl"):
+                transport = "host"
+            elif torch_backend == "nccl":
+                transport = "rccl"
+            else:                                                       # HostGroup / nothing: RCCL when every rank has its own GPU
+                local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
+                transport = "rccl" if self.lib.pgp_device_count() >= local_world else "host"
+        if transport == "rccl" and self.host_only:
+            raise ValueError("the RCCL transport needs a device")
         self.transport = transport
         h = C.c_void_p()
         if transport == "rccl":
-            torch = _lib.want_torch()
-            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-            self._rccl_path = (path if os.path.exists(path) else "").encode()
-            ident = C.create_string_buffer(128)
+            path = ""
+            if self.dist is not None or (not os.environ.get("PYGPS_AMD_NO_TORCH") and "torch" in __import__("sys").modules):
+                torch = _lib.want_torch()                                   # one copy of librccl per process: the one torch loaded
+                cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+                path = cand if os.path.exists(cand) else ""
+            self._rccl_path = path.encode()
+            ident = np.zeros(128, dtype=np.uint8)
             if self.rank == 0:
-                _lib.check(self.lib.pgp_comm_unique_id(self._rccl_path, ident), "pgp_comm_unique_id")
-            if dist and self.world > 1:                                 # the id to everybody (the only use of torch's collectives)
-                dev = torch.device("cuda", self.device) if backend == "nccl" else torch.device("cpu")
-                t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).to(dev)
-                dist.broadcast(t, src=0, group=group)
-                ident = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+                buf = C.create_string_buffer(128)
+                _lib.check(self.lib.pgp_comm_unique_id(self._rccl_path, buf), "pgp_comm_unique_id")
+                ident[:] = np.frombuffer(buf.raw, dtype=np.uint8)
+            if self.side is not None and self.world > 1:                # the id to everybody: the side channel's only job here
+                if isinstance(self.side, _TorchSide):
+                    self.side.bcast(ident, 0, self.device)
+                else:
+                    ident = np.asarray(self.side.bcast(ident, 0), dtype=np.uint8)
+            ident = C.create_string_buffer(ident.tobytes(), 128)
             _lib.check(self.lib.pgp_comm_init_rccl(self.ctx, self.world, self.rank, ident, self._rccl_path, C.byref(h)),
                        "pgp_comm_init_rccl")
         elif transport == "host":
@@ -77,13 +166,15 @@ class Comm(object):
         self.handle = h
         self._free = self.lib.pgp_comm_free
 
-    # ---- host transport: the library hands over pinned host buffers ---------------------------------------------------
+    # ---- host transport: the library hands over (pinned) host buffers -------------------------------------------------
     def _host_bcast(self, user, buf, nbytes, root):
         try:
-            import torch
             a = np.ctypeslib.as_array((C.c_ubyte * nbytes).from_address(buf))
-            t = torch.from_numpy(a)
-            self.dist.broadcast(t, src=self._global(root), group=self.group)
+            if isinstance(self.side, _TorchSide):
+                import torch
+                self.side.dist.broadcast(torch.from_numpy(a), src=self.side._global(root), group=self.side.group)
+            else:
+                a[...] = self.side.bcast(a, root)
             return 0
         except Exception:                                              # no exception may cross the C ABI
             import traceback
@@ -92,20 +183,53 @@ class Comm(object):
 
     def _host_allreduce(self, user, buf, count, op):
         try:
-            import torch
             a = np.ctypeslib.as_array(buf, shape=(count,))
-            t = torch.from_numpy(a)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op else self.dist.ReduceOp.SUM, group=self.group)
+            if isinstance(self.side, _TorchSide):
+                import torch
+                d = self.side.dist
+                d.all_reduce(torch.from_numpy(a), op=d.ReduceOp.MAX if op else d.ReduceOp.SUM, group=self.side.group)
+            else:
+                self.side.allreduce(a, "max" if op else "sum")
             return 0
         except Exception:
             import traceback
             traceback.print_exc()
             return 1
 
-    def _global(self, group_rank):
-        if self.group is None:
-            return group_rank
-        return self.dist.get_global_rank(self.group, group_rank)
+    # ---- host collectives through the library (pgp_comm_*_host) -------------------------------------------------------
+    def bcast(self, arr, root=0):
+        """Broadcast a float64 array from ``root``; returns the array (a C-contiguous copy when the input was not one)."""
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if a is arr and not a.flags.writeable:
+            a = a.copy()
+        _lib.check(self.lib.pgp_comm_bcast_host(self.handle, _lib.ptr(a), a.size, int(root)), "pgp_comm_bcast_host")
+        return a
+
+    def allreduce(self, arr, op="sum"):
+        a = np.array(arr, dtype=np.float64, order="C")
+        _lib.check(self.lib.pgp_comm_allreduce_host(self.handle, _lib.ptr(a), a.size, 1 if op in ("max", 1) else 0),
+                   "pgp_comm_allreduce_host")
+        return a
+
+    def allgather(self, arr):
+        """(world,) + arr.shape: rank r's array at [r]."""
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        out = np.empty((self.world,) + a.shape)
+        _lib.check(self.lib.pgp_comm_allgather_host(self.handle, _lib.ptr(a), a.size, _lib.ptr(out)), "pgp_comm_allgather_host")
+        return out
+
+    def ticket(self, name="default"):
+        """Next value of a group-wide counter, or None when the side channel has none (then work is dealt statically)."""
+        if self.side is None:
+            if not hasattr(self, "_tickets"):
+                self._tickets = {}
+            v = self._tickets.get(name, 0)
+            self._tickets[name] = v + 1
+            return v
+        try:
+            return self.side.ticket(name)
+        except Exception:
+            return None
 
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle:
@@ -130,6 +254,29 @@ def default_comm(device=None):
     return _default_comm[device]
 
 
+_search_comms = {}
+
+
+def search_comm(group=None):
+    """The communicator of the restart / fold searches for ``group`` (None: the initialised torch.distributed default group,
+    else the launcher's environment, else world size 1): one per (process, group), created on first use.  Without a visible GPU
+    (the CPU-side tests of the search logic) it is a host-only communicator."""
+    side = _find_side(group)
+    if isinstance(side, _TorchSide):
+        from torch.distributed import distributed_c10d as c10d
+        key = ("torch", id(group if group is not None else c10d._get_default_group()))
+    elif side is not None:
+        key = ("hostgroup", id(side))
+    else:
+        key = ("single",)
+    c = _search_comms.get(key)
+    if c is None or not c.handle:
+        lib = _lib.load()
+        c = Comm(group=side if key[0] == "hostgroup" else group, device=None if lib.pgp_device_count() > 0 else "host")
+        _search_comms[key] = c
+    return c
+
+
 def exact_fit(comm, kind, para, flags, cov_hyp, log_sn, m, dm, nm, n, nargout=3, gather_factor=False, keep_factor=True):
     """pgp_sharded_exact_fit on the data the context of ``comm`` holds.  Returns (alpha (n,), nlZ, g (nm+nc+1,), ms (6,), L, h).
     ms: stage times (assembly, sweep, epilogue, total) in ms, then the device bytes the call held at its peak and the bytes the
@@ -150,14 +297,7 @@ def exact_fit(comm, kind, para, flags, cov_hyp, log_sn, m, dm, nm, n, nargout=3,
                                         C.byref(h) if keep_factor else None)
     _lib.check(rc, "pgp_sharded_exact_fit")
     if L is not None and comm.world > 1:
-        import torch
-        t = torch.from_numpy(L)
-        if comm.dist.get_backend(comm.group) == "nccl":
-            t = t.cuda(comm.device)
-            comm.dist.all_reduce(t, group=comm.group)
-            L = t.cpu().numpy()
-        else:
-            comm.dist.all_reduce(t, group=comm.group)
+        L = comm.allreduce(L)                        # every rank holds its own columns, zeros elsewhere
     return alpha, float(nlZ[0]), g, ms, L, (h if keep_factor else None)
 
 

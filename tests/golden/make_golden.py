@@ -335,7 +335,7 @@ def g8ii(N):
 
 
 # ----------------------------------------------------------------------------- G9 (cfg 4, restarts)
-def g9(N=512):
+def g9(N=512, iters=40, tag=""):
     d = 16
     x, y = synth_reg(N, d)
     m = pyGPs.GPR()
@@ -359,7 +359,7 @@ def g9(N=512):
     ref_opt.minimize.run = spy
     np.random.seed(123)
     try:
-        m.optimize(x, y)
+        m.optimize(x, y, numIterations=iters)
     finally:
         ref_opt.minimize.run = orig_run
     R = len(runs)
@@ -370,7 +370,7 @@ def g9(N=512):
     fopt = np.array([r.get("f", np.nan) for r in runs])
     nls = np.array([r.get("nls", -1) for r in runs])
     final = np.array(m.meanfunc.hyp + m.covfunc.hyp + m.likfunc.hyp)
-    save("G9_restarts_N%d" % N, N=N, d=d, seed=0, np_seed=123, num_restarts=8, numIterations=40,
+    save("G9_restarts_N%d%s" % (N, tag), N=N, d=d, seed=0, np_seed=123, num_restarts=8, numIterations=iters,
          hyp0=hyp0, run_X0=X0, run_ok=ok, run_Xopt=Xopt, run_f=fopt, run_nls=nls, n_runs=R,
          best_hyp=final, best_nlZ=m.nlZ)
 
@@ -659,11 +659,75 @@ def g15():
          pred_xs=xc[:5] + 0.05, pred_ym=ym, pred_lp=lp, **dn(dnlZ))
 
 
+# ----------------------------------------------------------------------------- G19 (round 5: K-fold validation, Validation/valid.py)
+def g19():
+    """Validation/valid.py:20-66 (k_fold_validation / k_fold_index) and the metrics :70-146, driven the way
+    Demo/JHUI/demo_Validation.py:70-90 drives them: per fold a fresh model, fit (+ optionally a short optimize),
+    predict on the held-out fold, metric.  Regression: the G6 N = 2048 data, K = 10.  Classification: the 8(d)
+    classification recipe N = 600, d = 8, K = 5 (GPC + EP).  valid.NLPD as written raises NameError (`log`, `math`
+    are not imported in valid.py:138); the fixture records that and the value of the docstring's formula."""
+    from pyGPs.Validation import valid
+    N, d, K = 2048, 16, 10
+    x, y = synth_reg(N, d)
+    folds_tr, folds_te = [], []
+    for tr, te in valid.k_fold_index(N, K):
+        folds_tr.append(np.array(tr)); folds_te.append(np.array(te))
+    recs = dict(nlZ=[], rmse=[], nlpd=[], ym0=[], ys20=[], opt_nlZ=[], opt_rmse=[], opt_nlpd=[], opt_hyp=[])
+    k = 0
+    for x_tr, x_te, y_tr, y_te in valid.k_fold_validation(x, y, K):
+        assert np.array_equal(x_tr, x[folds_tr[k]]) and np.array_equal(y_te, y[folds_te[k]])
+        m = pyGPs.GPR()
+        m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+        m.setNoise(np.log(0.1))
+        m.setData(x_tr, y_tr)
+        nlZ, dnlZ, post = m.getPosterior()
+        ym, ys2, fm, fs2, lp = m.predict(x_te, ys=y_te)
+        recs["nlZ"].append(nlZ); recs["rmse"].append(valid.RMSE(ym, y_te))
+        recs["nlpd"].append(np.mean(0.5 * np.log(2 * np.pi * ys2) + 0.5 * (y_te - ym) ** 2 / ys2))
+        recs["ym0"].append(ym[0, 0]); recs["ys20"].append(ys2[0, 0])
+        m.optimize(x_tr, y_tr, numIterations=5)
+        ym, ys2, fm, fs2, lp = m.predict(x_te, ys=y_te)
+        recs["opt_nlZ"].append(m.nlZ); recs["opt_rmse"].append(valid.RMSE(ym, y_te))
+        recs["opt_nlpd"].append(np.mean(0.5 * np.log(2 * np.pi * ys2) + 0.5 * (y_te - ym) ** 2 / ys2))
+        recs["opt_hyp"].append(np.array(m.meanfunc.hyp + m.covfunc.hyp + m.likfunc.hyp))
+        print("  fold", k, recs["nlZ"][-1], recs["rmse"][-1], recs["opt_rmse"][-1], flush=True)
+        k += 1
+    try:
+        valid.NLPD(y_te, ym, ys2)
+        nlpd_raises = ""
+    except Exception as e:          # NameError: name 'log' is not defined
+        nlpd_raises = type(e).__name__
+    # the randomise=True branch: shuffles np.append(x, y, axis=1) with the GLOBAL generator, y comes back 1-D
+    np.random.seed(5)
+    xr_tr, xr_te, yr_tr, yr_te = next(valid.k_fold_validation(x[:50], y[:50], 5, randomise=True))
+    # classification
+    Nc, dc, Kc = 600, 8, 5
+    xc, yc = synth_cls(Nc, dc)
+    crec = dict(acc=[], prec=[], rec=[], rmse=[], nlZ=[], ym0=[])
+    for x_tr, x_te, y_tr, y_te in valid.k_fold_validation(xc, yc, Kc):
+        m = pyGPs.GPC()
+        m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(dc)), 0.0))
+        m.setData(x_tr, y_tr)
+        nlZ = m.getPosterior()[0]
+        ym, ys2, fm, fs2, lp = m.predict(x_te, ys=y_te)
+        cls = np.sign(ym)
+        crec["acc"].append(valid.ACC(cls, y_te)); crec["prec"].append(valid.Prec(cls, y_te))
+        crec["rec"].append(valid.Recall(cls, y_te)); crec["rmse"].append(valid.RMSE(cls, y_te))
+        crec["nlZ"].append(nlZ); crec["ym0"].append(ym[0, 0])
+    save("G19_kfold", N=N, d=d, K=K, seed=0, optimize_iters=5,
+         fold0_train_idx=folds_tr[0], fold0_test_idx=folds_te[0], fold9_test_idx=folds_te[9],
+         nlpd_raises=np.array(nlpd_raises),
+         rand_seed=5, rand_x_train=xr_tr, rand_x_test=xr_te, rand_y_train=yr_tr, rand_y_test=yr_te,
+         cls_N=Nc, cls_d=dc, cls_K=Kc,
+         **{k_: np.array(v) for k_, v in recs.items()}, **{"cls_" + k_: np.array(v) for k_, v in crec.items()})
+
+
 CASES = {
     "g16": g16, "g17": g17, "g15": g15, "g14": g14, "g13": g13, "g12": g12, "g11": g11, "g10": g10, "gmin": gmin, "g1": g1, "g2": g2, "g4": g4, "g4b": g4b, "g8": g8, "g9": g9,
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
     "g8ii_2048": lambda: g8ii(2048), "g8ii_4096": lambda: g8ii(4096), "g9_2048": lambda: g9(2048),
     "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384), "g18": g18,
+    "g19": g19, "g9_8192_3ls": lambda: g9(8192, iters=3, tag="_3ls"),
 }
 
 if __name__ == "__main__":

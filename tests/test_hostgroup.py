@@ -1,0 +1,146 @@
+"""CPU: the torch-free side of the sharded searches.
+
+* ``pygps_amd.hostgroup.HostGroup``: collectives + ticket counter over sockets, 3 processes.
+* the library's host collectives (``pgp_comm_bcast_host`` / ``allreduce`` / ``allgather``) on a host-only communicator whose
+  call-backs the HostGroup serves -- no torch in the process (the worker asserts ``"torch" not in sys.modules``).
+* ``ShardedMinimize`` (Core/opt.py:301-327 sharded) over that communicator: every rank gets what the sequential ``Minimize``
+  gets, static and dynamic deal.
+* ``valid.sharded_k_fold`` (Validation/valid.py:20-66 sharded): fold -> rank bookkeeping and the one all-gather, on a numpy
+  stand-in model; ``k_fold_validation`` / ``k_fold_index`` / metrics against the fixture recorded from the reference (G19).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "workers", "search_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(world, case, out_dir, *args, no_torch=True, extra_env=None, timeout=600):
+    """`world` processes with the environment a launcher exports; returns when all have exited with status 0."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK", "PYGPS_AMD_TORCH_FIRST")}
+        env.update(RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if no_torch:
+            env["PYGPS_AMD_NO_TORCH"] = "1"
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, WORKER, case, str(out_dir)] + [json.dumps(a) for a in args], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, o[-4000:])
+    return [np.load(os.path.join(str(out_dir), "r%d.npz" % r)) for r in range(world)]
+
+
+def test_hostgroup_collectives_and_tickets(tmp_path):
+    rs = launch(3, "group_ops", tmp_path)
+    for r, z in enumerate(rs):
+        assert np.array_equal(z["b"], np.arange(5.0) + 20)                        # root = world - 1
+        assert np.array_equal(z["s"], [3.0, 6.0, np.inf]) and np.array_equal(z["mx"], [2.0, -3.0])
+        assert np.array_equal(z["ga"], [[0, 0], [1, 1], [2, 4]])
+        assert sorted(z["allt"].ravel().tolist()) == list(range(9))               # 9 tickets, each handed out exactly once
+    assert sorted(int(z["t2"]) for z in rs) == [0, 1, 2]
+
+
+def test_library_host_collectives_without_torch(tmp_path):
+    rs = launch(3, "comm_ops", tmp_path)
+    for r, z in enumerate(rs):
+        assert str(z["transport"]) == "host"
+        assert np.array_equal(z["b"], np.arange(6.0).reshape(2, 3))
+        ga = z["ga"]
+        assert ga.shape == (3, 1, 2) and np.array_equal(ga[:, 0, 0], [0, 1, 2])
+        assert np.isinf(ga[0, 0, 1]) and np.isnan(ga[1, 0, 1]) and np.isnan(ga[2, 0, 1])   # non-finite values arrive as they are
+        assert np.array_equal(z["s"], [6.0, 3.0]) and np.array_equal(z["mx"], [3.0, 0.0])
+
+
+@pytest.mark.parametrize("world,R,streams,deal", [(2, 6, 1, "auto"), (2, 5, 2, "dynamic"), (3, 7, 1, "static"), (1, 4, 2, "auto")])
+def test_sharded_minimize_without_torch_equals_sequential(tmp_path, world, R, streams, deal):
+    sys.path.insert(0, HERE)
+    from test_host_logic import _FakeModel, _conf
+    from pygps_amd import opt
+    m = _FakeModel()
+    o = opt.Minimize(m, _conf(m, R))
+    np.random.seed(7)
+    h_seq, f_seq = o.findMin(m.x, m.y, numIters=15)
+    rs = launch(world, "fake_search", tmp_path, R, streams, deal)
+    for z in rs:
+        assert float(z["f"]) == f_seq and np.array_equal(z["h"], h_seq)           # same optimum on every rank
+        assert np.array_equal(z["x"], np.arange(4.0).reshape(4, 1))               # data arrived by broadcast
+        assert np.array_equal(z["runs_f"], rs[0]["runs_f"]) and len(z["runs_f"]) == R
+        assert np.array_equal(z["owner"], rs[0]["owner"])
+    own = rs[0]["owner"]
+    if deal == "static":
+        assert np.array_equal(own, np.arange(R) % world)
+    assert set(own.tolist()) <= set(range(world))
+    if streams == 1:
+        assert sum(int(z["calls"]) for z in rs) == m.calls                        # the work was shared, nothing ran twice
+
+
+def test_k_fold_helpers_match_the_reference():
+    from pygps_amd import valid
+    g = golden("G19_kfold")
+    N, K = int(g["N"]), int(g["K"])
+    folds = list(valid.k_fold_index(N, K))
+    assert isinstance(folds[0][0], list) and len(folds) == K
+    assert np.array_equal(folds[0][0], g["fold0_train_idx"]) and np.array_equal(folds[0][1], g["fold0_test_idx"])
+    assert np.array_equal(folds[9][1], g["fold9_test_idx"])
+    from conftest import synth_reg
+    x, y = synth_reg(N, int(g["d"]))
+    for k, (xtr, xte, ytr, yte) in enumerate(valid.k_fold_validation(x, y, K)):
+        assert np.array_equal(xtr, x[folds[k][0]]) and np.array_equal(yte, y[folds[k][1]])
+    # randomise=True: the global generator shuffles [x | y]; y comes back one-dimensional (Validation/valid.py:34-38)
+    np.random.seed(int(g["rand_seed"]))
+    xtr, xte, ytr, yte = next(valid.k_fold_validation(x[:50], y[:50], 5, randomise=True))
+    assert np.array_equal(xtr, g["rand_x_train"]) and np.array_equal(xte, g["rand_x_test"])
+    assert ytr.ndim == 1 and np.array_equal(ytr, g["rand_y_train"]) and np.array_equal(yte, g["rand_y_test"])
+    # metrics (valid.py:70-146) on made-up predictions
+    p = np.array([[1.0], [-1.0], [1.0], [1.0], [-1.0]])
+    t = np.array([[1.0], [1.0], [-1.0], [1.0], [-1.0]])
+    assert valid.ACC(p, t) == 3.0 / 5 and valid.Prec(p, t) == 2.0 / 3 and valid.Recall(p, t) == 2.0 / 3
+    assert valid.RMSE(p, t) == np.sqrt(np.mean((p - t) ** 2))
+    assert str(g["nlpd_raises"]) == "NameError"                                   # the reference's NLPD cannot run as written
+    mu, s2 = np.array([[0.5], [1.0]]), np.array([[0.2], [0.3]])
+    yy = np.array([[0.0], [2.0]])
+    assert abs(valid.NLPD(yy, mu, s2) - np.mean(0.5 * np.log(2 * np.pi * s2) + 0.5 * (yy - mu) ** 2 / s2)) < 1e-15
+
+
+@pytest.mark.parametrize("world,K", [(2, 7), (3, 3)])
+def test_sharded_k_fold_bookkeeping_without_torch(tmp_path, world, K):
+    from pygps_amd import valid
+    rs = launch(world, "kfold_fake", tmp_path, K)
+    rng = np.random.RandomState(3)
+    x = rng.randn(53, 2)
+    y = x[:, :1] * 2 + 0.1 * rng.randn(53, 1)
+    want_nlZ, want_rmse, want_nlpd = [], [], []
+    for xtr, xte, ytr, yte in valid.k_fold_validation(x, y, K):
+        ym = xte[:, :1] * 2.0 + np.mean(ytr)
+        want_nlZ.append(np.sum(ytr)); want_rmse.append(valid.RMSE(ym, yte)); want_nlpd.append(valid.NLPD(yte, ym, np.full_like(ym, 0.5)))
+    for z in rs:
+        assert np.allclose(z["nlZ"], want_nlZ, rtol=1e-14) and np.allclose(z["RMSE"], want_rmse, rtol=1e-14)
+        assert np.allclose(z["NLPD"], want_nlpd, rtol=1e-14)
+        assert np.array_equal(z["owner"], rs[0]["owner"]) and set(z["owner"].tolist()) <= set(range(world))
