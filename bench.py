@@ -338,6 +338,71 @@ def extras(lib, _lib, local, d, roof):
     return out
 
 
+def flatten_roofline(out):
+    """(flat, detail): `roofline` with scalars only -- the contract members, then the north-star figures of every config as
+    flat scalars -- and the nested objects it used to carry.  Strings are cut to 120 characters in the flat form."""
+    roof = out["roofline"]
+    flat, detail = {}, {}
+    for k, v in roof.items():
+        if isinstance(v, (dict, list, tuple)):
+            detail[k] = v
+        elif isinstance(v, str) and len(v) > 120:
+            detail[k] = v
+            flat[k] = v[:117] + "..."
+        else:
+            flat[k] = v
+
+    def get(obj, *path):
+        for p_ in path:
+            if not isinstance(obj, dict) or p_ not in obj:
+                return None
+            obj = obj[p_]
+        return obj if isinstance(obj, (int, float, str, bool)) or obj is None else None
+    tw = detail.get("timed_window") or {}
+    fe = detail.get("factor_inverse_EEt") or {}
+    flat.update({
+        # cfg 2 (the headline): two-stream window, ONE dependent chain, cfg 4 as written (one chain per GPU)
+        "timed_window_frac_of_peak": tw.get("frac_of_peak"), "timed_window_streams": tw.get("streams"),
+        "factor_inverse_EEt_ms": fe.get("ms"), "factor_inverse_EEt_frac_of_peak": fe.get("frac_of_peak"),
+        "all_gemm_f64_frac": get(detail, "all_gemm_f64_instantiations", "frac"),
+        "single_stream_ms_per_fit": out.get("single_stream_ms_per_fit"),
+        "single_stream_fits_per_s": out.get("single_stream_fits_per_s"),
+        "cfg4_as_written_fits_per_s_per_gpu": out.get("cfg4_as_written_fits_per_s_per_gpu"),
+        "cfg4_as_written_fits_per_s": out.get("cfg4_as_written_fits_per_s"),
+        "api_fits_per_s": out.get("api_fits_per_s"),
+        # north star: ">= 60 % of HBM peak on kernel assembly at N = 16384", ">= 50 % of the fp64-MFMA roofline on the Cholesky panel"
+        "assembly_full_N16384_ms": get(detail, "assembly_full_N16384", "ms"),
+        "assembly_full_N16384_frac_of_hbm_peak": get(detail, "assembly_full_N16384", "frac_of_hbm_peak"),
+        "assembly_stores_alone_frac_of_hbm_peak": get(detail, "assembly_full_N16384", "stores_alone_frac_of_hbm_peak"),
+        "assembly_SEard_d64_N16384_ms": get(detail, "assembly_full_N16384_SEard_d64", "ms"),
+        "assembly_SEard_d64_N16384_frac_of_hbm_peak": get(detail, "assembly_full_N16384_SEard_d64", "frac_of_hbm_peak"),
+        "cholesky_sweep_N16384_ms": get(detail, "cholesky_sweep_N16384", "ms"),
+        "cholesky_sweep_N16384_frac_of_peak": get(detail, "cholesky_sweep_N16384", "frac_of_peak"),
+        "fit_N16384_RBF_ms": get(detail, "cholesky_sweep_N16384", "fit_ms"),
+        # cfg 3 / cfg 5 / cfg 4 / the sharded fit / predict / FITC
+        "cfg3_fit_ms": get(out, "cfg3_seard_N16384_d64", "fit_ms"),
+        "cfg3_hadamard_reduce_ms": get(out, "cfg3_seard_N16384_d64", "hadamard_reduce_ms"),
+        "cfg3_assembly_fused_ms": get(out, "cfg3_seard_N16384_d64", "assembly_fused_ms"),
+        "cfg3_cholesky_sweep_frac_of_peak": get(out, "cfg3_seard_N16384_d64", "cholesky_sweep_frac_of_peak"),
+        "cfg5_fit_ms": get(out, "cfg5_ep_N4096_d32", "fit_ms"), "cfg5_sweeps": get(out, "cfg5_ep_N4096_d32", "sweeps"),
+        "cfg5_site_sweep_ms": get(out, "cfg5_ep_N4096_d32", "site_sweep_ms"),
+        "cfg5_final_factor_ms": get(out, "cfg5_ep_N4096_d32", "params_ms"),
+        "cfg4_fits_per_s": get(out, "cfg4_restarts_N8192", "fits_per_s"), "cfg4_fits": get(out, "cfg4_restarts_N8192", "fits"),
+        "cfg4_wall_s": get(out, "cfg4_restarts_N8192", "wall_s"), "cfg4_n_gpus": get(out, "cfg4_restarts_N8192", "n_gpus"),
+        "sharded_fit_n": get(out, "sharded_fit", "n"), "sharded_fit_world": get(out, "sharded_fit", "world"),
+        "sharded_fit_seconds": get(out, "sharded_fit", "seconds"),
+        "sharded_fit_frac_of_peak_per_gpu": get(out, "sharded_fit", "frac_of_peak_per_gpu"),
+        "sharded_fit_peak_bytes_per_rank": get(out, "sharded_fit", "peak_bytes_per_rank"),
+        "sharded_fit_wait_share": get(out, "sharded_fit", "wait_share"),
+        "sharded_fit_bcast_GBs_per_rank": get(out, "sharded_fit", "bcast_GBs_per_rank"),
+        "predict_ns65536_ms": get(out, "predict_N8192_ns65536", "ms"),
+        "fitc_n131072_nu1024_fit_ms": get(out, "fitc_n131072_nu1024", "fit_ms"),
+        "kfold_K10_N8192_wall_s": get(out, "kfold_K10_N8192", "wall_s"),
+    })
+    assert all(not isinstance(v, (dict, list, tuple)) for v in flat.values())
+    return flat, detail
+
+
 def api_rate(N, d, x, y, steps):
     """fits/s through the drop-in API, the way minimize.run drives it: model.getPosterior() with hyp changing every call
     (hashes x / y for the residency check, builds postStruct / dnlZStruct, keeps post.L as a device handle)."""
@@ -408,6 +473,30 @@ def cfg4_extra(torch, dist, world, n4=8192):
                     "gradients each), wall time of the whole optimize() call of a warmed-up model (max over ranks)"}
 
 
+def kfold_extra(world, n=8192, K=10):
+    """The other half of north_star's multi-GPU sentence ("shards independent restarts / CV folds across the 8 GPUs"): the
+    reference's K-fold loop (Validation/valid.py:20-66 as Demo/JHUI/demo_Validation.py:70-90 drives it) on the cfg-2 data, fold f on
+    rank f % world -- per fold one fit (nlZ + gradients) of N (K-1)/K points and predictions on the held-out N/K; ONE all-gather
+    of K records.  Collective: every rank calls this."""
+    import pygps_amd as pyGPs
+    from pygps_amd import valid
+    d = 16
+    x, y = synth_reg(n, d)
+
+    def make():
+        m = pyGPs.GPR()
+        m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0)); m.setNoise(np.log(0.1))
+        return m
+    valid.sharded_k_fold(make, x, y, K=K)                   # builds the fit-stream contexts (one-off cost)
+    t = time.perf_counter()
+    res = valid.sharded_k_fold(make, x, y, K=K)
+    wall = time.perf_counter() - t
+    return {"n_gpus": world, "N": n, "K": K, "wall_s": wall, "folds_per_s": K / wall, "rmse_mean": float(np.mean(res["RMSE"])),
+            "nlpd_mean": float(np.mean(res["NLPD"])), "folds_per_rank": np.bincount(res["owner"], minlength=world).tolist(),
+            "what": "10-fold validation of GPR + RBF on the cfg-2 data (N=8192 d=16): per fold a fit of 7372-7373 points (nlZ + gradients) "
+                    "and predict on 819-820, folds sharded over the ranks (two fit streams per GPU), one all-gather of 10 records"}
+
+
 def sharded_fit_extra(torch, dist, n, d=16):
     """SURVEY 8(f) row 4, measured: ONE exact-GP fit (RBF, d = 16: assembly, Cholesky + fused inverse, alpha, nlZ, E E' and all
     gradients) spread over ALL ranks -- pgp_sharded_exact_fit (csrc/sharded.hip): 1-D block-cyclic column panels, panel
@@ -451,6 +540,14 @@ def sharded_fit_extra(torch, dist, n, d=16):
     bt = torch.tensor([float(lb["peak_device_bytes"]), float(lb["factor_device_bytes"])], dtype=torch.float64, device="cuda")
     dist.all_reduce(bt, op=dist.ReduceOp.MAX)
     panel_bytes = 2.0 * (npad + 128) * npad / world * 8
+    # the multi-rank timers of the library (pgp_sharded_exact_fit timings_out[6..9]), worst rank: how long the compute stream stalled
+    # for panels, how long the broadcasts took from enqueue to complete, the rate they moved their bytes at
+    lc = getattr(m.inffunc, "last_comm", None) or {}
+    ct = torch.tensor([float(lc.get("wait_panel_ms", 0.0)), float(lc.get("bcast_ms", 0.0)), float(lc.get("bcast_max_ms", 0.0))],
+                      dtype=torch.float64, device="cuda")
+    dist.all_reduce(ct, op=dist.ReduceOp.MAX)
+    wait_ms, bcast_ms, bcast_max_ms = (float(v) for v in ct.tolist())
+    bcast_bytes = float(lc.get("bcast_bytes", 0.0))
     ns_p = 16384
     xs_p = np.random.RandomState(9).randn(ns_p, d)
     m.predict(xs_p[:1024])
@@ -471,6 +568,11 @@ def sharded_fit_extra(torch, dist, n, d=16):
             "frac_of_peak_per_gpu": float(n) ** 3 / dt / 1e12 / world / PEAK_FP64_MFMA_TF,
             "sweep_frac_of_peak_per_gpu": float(npad) ** 3 / sweep_s / 1e12 / world / PEAK_FP64_MFMA_TF,
             "bytes_broadcast_per_rank": float((npad + 128) * npad * 8) * (world > 1),
+            "wait_panel_ms": wait_ms, "wait_share": wait_ms / max(stages[1], 1e-9), "bcast_ms": bcast_ms, "bcast_max_ms": bcast_max_ms,
+            "bcast_GBs_per_rank": bcast_bytes / max(bcast_ms, 1e-9) / 1e6 if bcast_ms > 0 else 0.0,
+            "bcast_bytes_over_fit_seconds_GBs": float((npad + 128) * npad * 8) * (world > 1) / dt / 1e9,
+            "comm_what": "worst rank: ms the compute stream stalled waiting for a panel (sum over panels; wait_share = / sweep ms), ms "
+                         "inside the panel broadcasts from enqueue to complete (they overlap compute), bytes / that time",
             "nlZ": float(nlZ), "residual_normal_equations": res,
             "peak_bytes_per_rank": float(bt[0].item()), "factor_bytes_per_rank": float(bt[1].item()),
             "peak_bytes_over_2x_panel_storage": float(bt[0].item()) / panel_bytes,
@@ -654,6 +756,12 @@ def main():
         fit(args.warmup + s)
         lat_stage.append(_lib.last_timings(local))
     lat_ms = (time.perf_counter() - t1) / 6 * 1e3
+    single_rates = [1e3 / lat_ms]                     # every rank's ONE-chain rate: cfg 4 as written (8 restarts on 8 GPUs) runs one chain per GPU
+    if dist:
+        sr = torch.tensor([1e3 / lat_ms], dtype=torch.float64, device=cdev)
+        parts_s = [torch.empty_like(sr) for _ in range(world)]
+        dist.all_gather(parts_s, sr)
+        single_rates = [float(p_.item()) for p_ in parts_s]
     # the same with E E^T kept OUT of the sweep (option eet_overlap=0): the stage time of the sweep + fused inverse alone,
     # the figure rounds 1-2 quote as cholesky_sweep_* (2 N^3 / 3 flops); the default schedule folds E E^T into the sweep
     sweep_stage = []
@@ -834,6 +942,10 @@ def main():
             partial["cfg4_restarts_N8192"] = cfg4_extra(torch, dist, world, args.cfg4_n)
         except Exception as e:                               # pragma: no cover
             partial["cfg4_restarts_N8192"] = {"error": repr(e), "n_gpus": world}
+        try:
+            partial["kfold_K10_N8192"] = kfold_extra(world, args.cfg4_n)
+        except Exception as e:                               # pragma: no cover
+            partial["kfold_K10_N8192"] = {"error": repr(e), "n_gpus": world}
         if sn > 0:
             try:
                 partial["sharded_fit"] = sharded_fit_extra(torch, dist, sn)
@@ -853,21 +965,14 @@ def main():
                 for key, cfg in (("cfg3_seard_N16384_d64", "cfg3"), ("cfg5_ep_N4096_d32", "cfg5"), ("cfg4_restarts_N8192", "cfg4")):
                     if isinstance(out.get(key), dict) and cfg in others:
                         out[key]["cpu_baseline"] = others[cfg]
-        # the driver's parser keeps the contract keys, `config`, `roofline` and `cpu_baseline`: the other configs' headline
-        # scalars ride inside `roofline` so that they survive in BENCH_rNN.json (the full objects stay at top level)
+        # The driver's parser keeps the contract keys, `config`, `cpu_baseline` and the SCALAR members of `roofline` (nested
+        # objects are dropped): every north-star figure rides in `roofline` as a flat scalar, the nested detail objects move to
+        # `roofline_detail` at top level, strings are cut to 120 characters (the full texts stay in `roofline_detail`).
         if out.get("roofline") is not None:
-            def pick(key, *names):
-                o = out.get(key)
-                return {n_: o.get(n_) for n_ in names if isinstance(o, dict) and n_ in o} if isinstance(o, dict) else None
-            out["roofline"]["other_configs"] = {
-                "single_stream_ms_per_fit": out.get("single_stream_ms_per_fit"),
-                "cfg3_seard_N16384_d64": pick("cfg3_seard_N16384_d64", "fit_ms", "hadamard_reduce_ms", "assembly_fused_ms",
-                                              "cholesky_sweep_frac_of_peak"),
-                "cfg5_ep_N4096_d32": pick("cfg5_ep_N4096_d32", "fit_ms", "sweeps", "site_sweep_ms", "params_ms"),
-                "cfg4_restarts_N8192": pick("cfg4_restarts_N8192", "fits_per_s", "fits", "wall_s", "n_gpus"),
-                "sharded_fit": pick("sharded_fit", "n", "world", "seconds", "frac_of_peak_per_gpu", "peak_bytes_per_rank"),
-                "predict_N8192_ns65536": pick("predict_N8192_ns65536", "ms"),
-                "fitc_n131072_nu1024": pick("fitc_n131072_nu1024", "fit_ms")}
+            out["single_stream_fits_per_s_per_rank"] = single_rates
+            out["cfg4_as_written_fits_per_s"] = float(sum(single_rates))
+            out["cfg4_as_written_fits_per_s_per_gpu"] = float(sum(single_rates)) / world
+            out["roofline"], out["roofline_detail"] = flatten_roofline(out)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.barrier()

@@ -174,8 +174,10 @@ int pgp_comm_rank(pgp_comm* comm);
 int pgp_comm_bcast_host(pgp_comm* comm, double* buf, int64_t count, int root);
 int pgp_comm_allreduce_host(pgp_comm* comm, double* buf, int64_t count, int op);
 int pgp_comm_allgather_host(pgp_comm* comm, const double* send, int64_t count, double* recv);
-/* Arguments and results as pgp_exact_fit.  timings_out (optional, 6): ms of assembly, sweep, epilogue, total; device bytes
- * this call held at its peak; device bytes the posterior handle keeps.  L_out (optional, (n,n) row-major, zero-filled by the
+/* Arguments and results as pgp_exact_fit.  timings_out (optional, 10): ms of assembly, sweep, epilogue, total; device bytes
+ * this call held at its peak; device bytes the posterior handle keeps; [6] ms the compute stream stalled waiting for a panel
+ * (sum over the panels), [7] ms of the panel broadcasts from enqueue to complete on this rank (sum), [8] bytes this rank moved
+ * in them, [9] the slowest single broadcast (ms) -- [6..9] are 0 at world size 1.  L_out (optional, (n,n) row-major, zero-filled by the
  * caller): THIS rank's columns of the factor in post.L's form (upper R, R'R = K/sn2 + I); the sum over the ranks is the whole
  * factor.  factor_out (optional): this rank's part of the distributed posterior (its column panels of L and of L^-T, alpha, the
  * coordinates) for pgp_sharded_predict.  Per-rank memory is O(n^2 / world): the panels, and for want = 3 the rank's column

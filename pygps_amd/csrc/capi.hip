@@ -153,6 +153,7 @@ void pgp_destroy(pgp_ctx* c) {
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto& e : c->la_ev) (void)hipEventDestroy(e);
+    for (auto& e : c->tm_ev) (void)hipEventDestroy(e);
     for (auto& e : c->fill_ev) (void)hipEventDestroy(e);
     for (auto& e : c->ep_ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->st);

@@ -53,6 +53,7 @@ struct pgp_ctx {
                                         // every TU_b on the main stream, 3 the same when npanel <= eet_max_panels
     int eet_max_panels = 32;
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
+    std::vector<hipEvent_t> tm_ev;      // timing events of the sharded fit's wait / broadcast timers (4 per panel)
     int lookahead = 1;
     int leaf_first = 0;                 // 1: TU_b(p) is launched only after D(p+1)'s stage-in kernel, so that the first leaf is
                                         // dispatched BEFORE the update's first wave takes every workgroup slot (a leaf dispatched

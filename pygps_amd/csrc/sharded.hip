@@ -132,11 +132,16 @@ static int comm_stage(pgp_comm* m, size_t bytes) {
 
 // Broadcast `bytes` at `buf` (device memory of this rank: the root's source, everybody else's destination).  Starts when
 // `wait_ev` has fired (null: at once), records `done_ev` on the communication stream when buf holds the data.
-static int comm_bcast(pgp_comm* m, void* buf, size_t bytes, int root, hipEvent_t wait_ev, hipEvent_t done_ev) {
+static int comm_bcast(pgp_comm* m, void* buf, size_t bytes, int root, hipEvent_t wait_ev, hipEvent_t done_ev,
+                      hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+    // t0 / t1 (optional, timing events): recorded on the communication stream right before / after the transfer -- "enqueue to
+    // complete" of this broadcast on this rank, the wait for the slowest peer included
     if (m->kind == 1) {
         if (wait_ev) HIP_TRY(hipStreamWaitEvent(m->st_comm, wait_ev, 0));
+        if (t0) HIP_TRY(hipEventRecord(t0, m->st_comm));
         const int rc = m->api.Broadcast(buf, buf, bytes / sizeof(double), RCCL_DOUBLE, root, m->comm, m->st_comm);
         if (rc != 0) return rccl_fail(m->api, rc, "ncclBroadcast");
+        if (t1) HIP_TRY(hipEventRecord(t1, m->st_comm));
         if (done_ev) HIP_TRY(hipEventRecord(done_ev, m->st_comm));
         return PGP_OK;
     }
@@ -147,6 +152,7 @@ static int comm_bcast(pgp_comm* m, void* buf, size_t bytes, int root, hipEvent_t
     }
     // host transport: blocking, through pinned host memory (self-test transport)
     if (wait_ev) HIP_TRY(hipEventSynchronize(wait_ev));
+    if (t0) HIP_TRY(hipEventRecord(t0, m->st_comm));
     CHK(comm_stage(m, bytes));
     if (m->rank == root) {
         HIP_TRY(hipMemcpyAsync(m->stage, buf, bytes, hipMemcpyDeviceToHost, m->st_comm));
@@ -160,6 +166,7 @@ static int comm_bcast(pgp_comm* m, void* buf, size_t bytes, int root, hipEvent_t
         HIP_TRY(hipMemcpyAsync(buf, m->stage, bytes, hipMemcpyHostToDevice, m->st_comm));
         HIP_TRY(hipStreamSynchronize(m->st_comm));          // the staging buffer is reused by the next call
     }
+    if (t1) HIP_TRY(hipEventRecord(t1, m->st_comm));
     if (done_ev) HIP_TRY(hipEventRecord(done_ev, m->st_comm));
     return PGP_OK;
 }
@@ -466,7 +473,7 @@ int pgp_comm_rank(pgp_comm* m) { return m ? m->rank : -1; }
 
 // Exact.evaluate over the ranks of `comm`.  Every rank passes the same data (pgp_set_data) and arguments and receives the
 // same alpha / nlZ / dnlZ.  Status as pgp_exact_fit: > 0 = first non-positive pivot, identical on every rank.
-// timings_out (optional, 6): ms of assembly, sweep (+ E E' under it), epilogue (alpha, gradient, collectives), total; then the
+// timings_out (optional, 10): ms of assembly, sweep (+ E E' under it), epilogue (alpha, gradient, collectives), total; then the
 // device bytes this call held at its peak (panels, receive buffers, strips of B^-1, scratch) and the bytes the handle keeps.
 // L_out (optional, (n,n) row-major, zero-filled by the caller): this rank's columns of the factor in post.L's form (upper R =
 // L', Core/inf.py:362): R(j, i) = L(i, j) for the owned columns j; the sum over the ranks is the whole factor.
@@ -675,6 +682,16 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
         HIP_TRY(hipEventRecord(EV_F(p), main));
         return PGP_OK;
     };
+    // timers of the first multi-GPU runs (timings_out[6..9]): per panel, how long the compute stream stalled for Y_p and how long
+    // its broadcast took on this rank from enqueue to complete
+    const bool timers = timings_out != nullptr && world > 1;
+    if (timers) {
+        while ((int)c->tm_ev.size() < 4 * npanel) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            c->tm_ev.push_back(e);
+        }
+    }
     if (0 % world == me) {                           // panel 0 on its owner, no look-ahead to hide behind
         poison = factor(0, main, nullptr);
         if (poison == PGP_OK) poison = solve(0, main);
@@ -684,10 +701,13 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
         const int owner = p % world;
         // ---- Y_p to every rank (a never-recorded event does not block: a poisoned owner still broadcasts) ----
         hipEvent_t wait = owner == me ? EV_S(p) : (p >= 2 && world > 1 ? EV_F(p - 2) : nullptr);
-        const int brc = comm_bcast(m, Yptr(p), pbytes, owner, wait, EV_Y(p));
+        const int brc = comm_bcast(m, Yptr(p), pbytes, owner, wait, EV_Y(p), timers ? c->tm_ev[4 * p] : nullptr,
+                                   timers ? c->tm_ev[4 * p + 1] : nullptr);
         if (brc != PGP_OK) { (void)hipDeviceSynchronize(); return brc; }           // the transport itself failed: nothing to agree over
         if (poison != PGP_OK) continue;
+        if (timers) (void)hipEventRecord(c->tm_ev[4 * p + 2], main);               // the compute stream is ready for Y_p ...
         if (hipStreamWaitEvent(main, EV_Y(p), 0) != hipSuccess) { poison = PGP_ERR_HIP; continue; }
+        if (timers) (void)hipEventRecord(c->tm_ev[4 * p + 3], main);               // ... and has it: the difference is the stall
         poison = body(p);
     }
     if (poison != PGP_OK) {
@@ -790,6 +810,18 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
         timings_out[0] = a; timings_out[1] = b; timings_out[2] = e; timings_out[3] = t;
         timings_out[4] = (double)(held_bytes + (size_t)(np + 8) * sizeof(double));
         timings_out[5] = factor_out ? (double)((size_t)(nloc + 1) * pbytes + xt_bytes + (size_t)np * sizeof(double)) : 0.0;
+        double wait_ms = 0.0, bc_ms = 0.0, bc_max = 0.0;
+        if (timers)
+            for (int p = 0; p < npanel; ++p) {
+                float wv = 0, bv = 0;
+                if (hipEventElapsedTime(&wv, c->tm_ev[4 * p + 2], c->tm_ev[4 * p + 3]) == hipSuccess) wait_ms += wv;
+                if (hipEventElapsedTime(&bv, c->tm_ev[4 * p], c->tm_ev[4 * p + 1]) == hipSuccess) { bc_ms += bv; bc_max = std::max(bc_max, (double)bv); }
+            }
+        (void)hipGetLastError();
+        timings_out[6] = wait_ms;                                  // compute stream stalled waiting for a panel (sum over the panels)
+        timings_out[7] = bc_ms;                                    // broadcasts, enqueue -> complete on this rank (sum; they overlap compute)
+        timings_out[8] = world > 1 ? (double)npanel * (double)pbytes : 0.0;     // bytes this rank sent or received in broadcasts
+        timings_out[9] = bc_max;                                   // the slowest single broadcast
     }
     if (L_out) {                                     // owned columns of L: the diagonal block from Ld, the rows below from Y
         for (int k = 0; k < nloc; ++k) {

@@ -254,6 +254,11 @@ class Exact(Inference):
                                                    gather_factor=self.gather_factor, keep_factor=not self.gather_factor)
         self.last_ms = ms6[:4]
         self.last_bytes = {"peak_device_bytes": int(ms6[4]), "factor_device_bytes": int(ms6[5])}
+        # the multi-rank timers of this rank: stall of the compute stream waiting for panels, time inside the broadcasts
+        self.last_comm = {"wait_panel_ms": float(ms6[6]), "bcast_ms": float(ms6[7]), "bcast_bytes": float(ms6[8]),
+                          "bcast_max_ms": float(ms6[9]),
+                          "bcast_GBs": float(ms6[8]) / max(float(ms6[7]), 1e-9) / 1e6 if ms6[7] > 0 else 0.0,
+                          "wait_share": float(ms6[6]) / max(float(ms6[1]), 1e-9) if ms6[1] > 0 else 0.0}
         post = postStruct()
         post.alpha = alpha.reshape(n, 1)
         post.sW = np.ones((n, 1)) / np.sqrt(np.exp(2 * log_sn))

@@ -278,9 +278,10 @@ def search_comm(group=None):
 
 
 def exact_fit(comm, kind, para, flags, cov_hyp, log_sn, m, dm, nm, n, nargout=3, gather_factor=False, keep_factor=True):
-    """pgp_sharded_exact_fit on the data the context of ``comm`` holds.  Returns (alpha (n,), nlZ, g (nm+nc+1,), ms (6,), L, h).
-    ms: stage times (assembly, sweep, epilogue, total) in ms, then the device bytes the call held at its peak and the bytes the
-    posterior handle keeps.  gather_factor: L = the (n,n) upper factor post.L on every rank (each rank fetches its own columns,
+    """pgp_sharded_exact_fit on the data the context of ``comm`` holds.  Returns (alpha (n,), nlZ, g (nm+nc+1,), ms (10,), L, h).
+    ms: stage times (assembly, sweep, epilogue, total) in ms, the device bytes the call held at its peak and the bytes the
+    posterior handle keeps, then the multi-rank timers: ms the compute stream stalled for a panel, ms of the broadcasts
+    (enqueue -> complete, summed), bytes moved in them, the slowest single broadcast (ms).  gather_factor: L = the (n,n) upper factor post.L on every rank (each rank fetches its own columns,
     the host arrays are summed over the ranks) -- for moderate n only: it is n^2 doubles on every host; None otherwise.
     h: the rank's part of the distributed posterior (a ``pgp_sfactor`` handle) when keep_factor, else None."""
     hyp = _lib.f64(np.asarray(cov_hyp, dtype=float))
@@ -288,7 +289,7 @@ def exact_fit(comm, kind, para, flags, cov_hyp, log_sn, m, dm, nm, n, nargout=3,
     alpha = np.empty(n)
     nlZ = np.zeros(1)
     g = np.zeros(nm + nc + 1)
-    ms = np.zeros(6)
+    ms = np.zeros(10)
     L = np.zeros((n, n)) if gather_factor else None
     h = C.c_void_p()
     rc = comm.lib.pgp_sharded_exact_fit(comm.ctx, comm.handle, int(kind), _lib.ptr(hyp), nc, int(para), int(flags),

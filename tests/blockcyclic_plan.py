@@ -1,26 +1,20 @@
-"""Groundwork for SURVEY 8(f) row 4 -- ONE exact-GP fit spread over the GPUs of a node (no reference counterpart).
+"""TEST HELPER (not product code): the partition / ownership / message plan of the 1-D block-cyclic right-looking Cholesky
+that csrc/sharded.hip executes on the device (no reference counterpart).  `tests/test_blockcyclic_gloo.py`
+runs this plan with numpy tiles on 2 gloo ranks against LAPACK: the ownership arithmetic and the look-ahead order are checked
+independently of the HIP code.
 
-Nothing here computes: this module is the partition / ownership / message plan of a 1-D block-cyclic right-looking
-Cholesky over `world` ranks (one process per GPU, RCCL over xGMI), i.e. the part of the multi-GPU fit that can be made
-correct by construction before an 8-GPU node is available.  `tests/test_blockcyclic_gloo.py` executes the plan with
-numpy tiles on 2 gloo ranks and checks it against LAPACK; the device executor (the single-GPU sweep of
-csrc/capi.hip:potrf_blocked_v2 restricted to the owned column panels, panel broadcast over RCCL) is a later round.
-
-Layout.  The (np x np) lower matrix is cut into column panels of `w` columns (w = 512 = the single-GPU sweep's outer
-panel: K = 512 trailing updates).  Panel p lives on rank p % world -- 1-D block-cyclic over COLUMNS, every rank holds
-full-height column panels.  Per step p:
+Layout.  The (np x np) lower matrix is cut into column panels of `w` columns.  Panel p lives on rank p % world -- 1-D
+block-cyclic over COLUMNS, every rank holds full-height column panels.  Per step p:
     owner(p):  D(p)  factor the diagonal block, S(p) solve the rows below  (exactly the single-GPU kernels)
-               broadcast  Y_p = the solved panel, rows >= (p+1) w                    [ (np - (p+1) w) x w doubles ]
+               broadcast  Y_p = the solved panel
     all ranks: TU(p)  C_j -= Y_p[rows of j..] Y_p[rows j]'   for every OWNED panel j > p
-Look-ahead: owner(p+1) updates panel p+1 first, factors it and starts its broadcast while the others are still in
-TU(p) -- the broadcast of step p+1 overlaps the trailing update of step p on every rank.
+Look-ahead: owner(p+1) updates panel p+1 first, factors it and starts its broadcast while the others are still in TU(p).
 
-Why 1-D: xGMI is point-to-point (7 links x ~153 GB/s per GPU).  A panel broadcast as a pipelined ring moves each byte
-once over every link of the ring: t_bcast ~ bytes / 153 GB/s, independent of world.  At np = 65536 the first panel is
-256 MiB -> 1.75 ms, against a trailing update of 2 np^2 w / world / 50 TF = 11 ms per rank at world = 8: the wire is
-hidden by a depth-1 look-ahead.  A 2-D layout would cut the panel into sqrt(world) pieces but needs two collectives
-per step and row-wise reductions; it only pays when world >> 8.  The fused inverse (E rows) and the rhs rows ride
-along as extra rows of every column panel, as on one GPU; E E' afterwards is a reduce-scatter over K.
+Wire model.  xGMI is point-to-point: 7 links per GPU, ~153 GB/s per link counted in BOTH directions, i.e. ~77 GB/s peak and
+60-75 GB/s realistic per direction.  A pipelined ring broadcast moves every byte once over every link of the ring in ONE
+direction: t_bcast ~ bytes / 64 GB/s, independent of world (round 4 budgeted 153 GB/s here: a bidirectional figure, twice
+too optimistic).  `wire_model` therefore defaults to 64 GB/s; RCCL may stripe a broadcast over several rings of the full mesh,
+which the first hardware run will show in the library's own timers (pgp_sharded_exact_fit timings_out[6..9]).
 """
 from collections import namedtuple
 
@@ -78,7 +72,7 @@ class BlockCyclic1D(object):
         f = self.flops_per_rank()
         return max(f) / (sum(f) / len(f)) if sum(f) else 1.0
 
-    def wire_model(self, link_GBs=153.0, tflops=50.0):
+    def wire_model(self, link_GBs=64.0, tflops=60.0):
         """(seconds on the wire, seconds of trailing update on the busiest rank) per step: the look-ahead hides the
         wire while the first stays below the second."""
         out = []

@@ -1,4 +1,4 @@
-"""CPU, 2 processes over gloo: the 1-D block-cyclic plan of pygps_amd/multigpu_plan.py (SURVEY 8(f) row 4 groundwork)
+"""CPU, 2 processes over gloo: the 1-D block-cyclic plan of tests/blockcyclic_plan.py (SURVEY 8(f) row 4 groundwork)
 executed with numpy tiles -- owner factors + solves its panel, broadcasts it, every rank updates the panels it owns --
 must reproduce LAPACK's Cholesky, and the plan's ownership / message / balance figures must be self-consistent.
 The numpy executor below is test infrastructure, not a product path."""
@@ -13,7 +13,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pygps_amd.multigpu_plan import BlockCyclic1D  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from blockcyclic_plan import BlockCyclic1D  # noqa: E402
 
 
 def test_plan_ownership_messages_and_balance():
@@ -31,9 +32,11 @@ def test_plan_ownership_messages_and_balance():
     ref = sum(2.0 * 512 * ((8192 - j * 512) * 512 - 0.5 * 512 * 512) * j for j in range(16))   # panel j gets j updates
     assert abs(tot - ref) < 1e-6 * ref
     assert plan.imbalance() < 1.35 and BlockCyclic1D(65536, 512, 8).imbalance() < 1.05
-    # wire hidden behind the trailing update for a matrix that needs more than one GPU
+    # a ring broadcast at a realistic 64 GB/s per direction is hidden behind the trailing update alone only for the first half of
+    # the sweep of a matrix that needs more than one GPU (updates shrink quadratically, panels linearly); the device code also
+    # runs E_p E_p' per step, which grows with p -- the library's wait timers (timings_out[6..9]) are what a hardware run reports
     big = BlockCyclic1D(131072, 512, 8).wire_model()
-    assert all(tw < tu for tw, tu in big[: len(big) * 3 // 4])
+    assert all(tw < tu for tw, tu in big[: len(big) // 2]) and not all(tw < tu for tw, tu in big[: len(big) * 3 // 4])
     with pytest.raises(ValueError):
         BlockCyclic1D(1000, 512, 2)
 

@@ -291,6 +291,16 @@ def test_bench_line_contract_small(lib):
     r = j["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert 1.0 <= r["executed_over_algorithmic_flops"] < 2.5
+    # the driver's parser keeps only SCALAR members of `roofline`: nothing nested, strings short; the north-star keys exist
+    # (None at --no-extras) and the one-chain-per-GPU rate of cfg 4 as written rides beside the two-stream value
+    assert all(not isinstance(v, (dict, list)) for v in r.values()), [k for k, v in r.items() if isinstance(v, (dict, list))]
+    assert all(len(v) <= 120 for v in r.values() if isinstance(v, str))
+    for k in ("assembly_full_N16384_frac_of_hbm_peak", "assembly_SEard_d64_N16384_frac_of_hbm_peak", "cholesky_sweep_N16384_frac_of_peak",
+              "single_stream_fits_per_s", "cfg3_fit_ms", "cfg5_fit_ms", "cfg4_fits_per_s", "sharded_fit_frac_of_peak_per_gpu",
+              "predict_ns65536_ms", "cfg4_as_written_fits_per_s_per_gpu"):
+        assert k in r, k
+    assert r["single_stream_fits_per_s"] > 0 and r["cfg4_as_written_fits_per_s_per_gpu"] > 0
+    assert isinstance(j["roofline_detail"]["timed_window"], dict) and r["timed_window_frac_of_peak"] > 0
 
 
 def test_exact_rejects_non_gaussian_and_unknown_kernel(lib):

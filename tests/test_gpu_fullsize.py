@@ -63,6 +63,8 @@ def test_cfg3_seard_N16384_d64_properties(lib):
         assert relerr(nlZ, gg["nlZ"]) < 1e-8
         assert relerr(_flat(dnlZ), np.concatenate([gg["dnlZ_mean"], gg["dnlZ_cov"], gg["dnlZ_lik"]])) < 1e-6
         assert relerr(post.alpha[gg["alpha_idx"], 0], gg["alpha_sample"]) < 1e-6
+        # every one of the 16384 diagonal entries of the reference's factor at cfg-3 size
+        assert relerr(np.diag(np.asarray(post.L)), gg["L_diag"]) < 1e-8
 
 
 def test_cfg3_scale_golden_N4096_if_recorded(lib):

@@ -1,0 +1,213 @@
+"""GPU: round 5.
+
+* K-fold validation on the device against the reference's own loop (G19: Validation/valid.py:20-66 driven as
+  Demo/JHUI/demo_Validation.py:70-90 does, G6 N = 2048 data, K = 10; GPC + EP, K = 5) -- in process and sharded over ranks with NO
+  torch in the processes (world 1: the library's RCCL transport; world 2: its host transport served by pygps_amd.hostgroup, two
+  ranks sharing the GPU).
+* cfg 4 (Core/opt.py:301-327 sharded) without torch at world 1 (RCCL) and world 2 against G9; at the stated size N = 8192 against
+  the bounded fixture recorded from the reference (8 restarts x 3 line searches).
+* the multi-dataset objective of Demo/Clustering/pyGP_extension.py:27-76.
+* plain RBF with d = 300 (the Gram-form prep buffer's mean region), the ARD gradient forms just under the bound.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden, relerr, synth_cls, synth_reg
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _flat(d):
+    return np.array(list(d.mean) + list(d.cov) + list(d.lik), dtype=float)
+
+
+def _make_reg(d):
+    import pygps_amd as pyGPs
+
+    def make():
+        m = pyGPs.GPR()
+        m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+        m.setNoise(np.log(0.1))
+        return m
+    return make
+
+
+def test_G19_k_fold_regression_in_process(lib):
+    from pygps_amd import valid
+    g = golden("G19_kfold")
+    N, d, K = int(g["N"]), int(g["d"]), int(g["K"])
+    x, y = synth_reg(N, d)
+    res = valid.sharded_k_fold(_make_reg(d), x, y, K=K, metrics=("RMSE", "NLPD"))
+    assert relerr(res["nlZ"], g["nlZ"]) < 1e-9
+    assert np.max(np.abs(res["RMSE"] - g["rmse"]) / g["rmse"]) < 1e-8
+    assert np.max(np.abs(res["NLPD"] - g["nlpd"]) / np.abs(g["nlpd"])) < 1e-7
+    # one fold by hand through the reference-style generator: first prediction of fold 0
+    import pygps_amd as pyGPs
+    xtr, xte, ytr, yte = next(valid.k_fold_validation(x, y, K))
+    m = _make_reg(d)()
+    m.setData(xtr, ytr)
+    m.getPosterior()
+    ym, ys2, fm, fs2, lp = m.predict(xte, ys=yte)
+    assert abs(ym[0, 0] - g["ym0"][0]) < 1e-8 * abs(g["ym0"][0]) and abs(ys2[0, 0] - g["ys20"][0]) < 1e-7 * g["ys20"][0]
+    # with the demo's optimize() per fold (5 line searches): the optimiser path amplifies rounding, loose tolerances
+    res = valid.sharded_k_fold(_make_reg(d), x, y, K=K, metrics=("RMSE", "NLPD"), numIterations=int(g["optimize_iters"]))
+    assert np.max(np.abs(res["nlZ"] - g["opt_nlZ"]) / np.abs(g["opt_nlZ"])) < 1e-5
+    assert np.max(np.abs(res["RMSE"] - g["opt_rmse"]) / g["opt_rmse"]) < 1e-4
+    assert np.max(np.abs(res["NLPD"] - g["opt_nlpd"]) / np.abs(g["opt_nlpd"])) < 1e-3
+
+
+def test_G19_k_fold_classification_ep(lib):
+    import pygps_amd as pyGPs
+    from pygps_amd import valid
+    g = golden("G19_kfold")
+    N, d, K = int(g["cls_N"]), int(g["cls_d"]), int(g["cls_K"])
+    x, y = synth_cls(N, d)
+
+    def make():
+        m = pyGPs.GPC()
+        m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+        return m
+    res = valid.sharded_k_fold(make, x, y, K=K, metrics=("ACC", "Prec", "Recall", "RMSE_class"))
+    assert relerr(res["nlZ"], g["cls_nlZ"]) < 1e-8
+    assert np.array_equal(res["ACC"], g["cls_acc"]) and np.array_equal(res["Prec"], g["cls_prec"])
+    assert np.array_equal(res["Recall"], g["cls_rec"]) and np.allclose(res["RMSE_class"], g["cls_rmse"], rtol=1e-14)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_G19_k_fold_sharded_without_torch(tmp_path, world):
+    from test_hostgroup import launch
+    g = golden("G19_kfold")
+    rs = launch(world, "kfold_gpu", tmp_path, timeout=900)
+    for z in rs:
+        assert relerr(z["nlZ"], g["nlZ"]) < 1e-9 and np.max(np.abs(z["RMSE"] - g["rmse"]) / g["rmse"]) < 1e-8
+        assert np.max(np.abs(z["NLPD"] - g["nlpd"]) / np.abs(g["nlpd"])) < 1e-7
+        assert np.array_equal(z["nlZ"], rs[0]["nlZ"]) and np.array_equal(z["owner"], rs[0]["owner"])
+    assert set(rs[0]["owner"].tolist()) == set(range(world))                      # every rank ran folds
+
+
+@pytest.mark.parametrize("world,streams", [(1, 2), (2, 1)])
+def test_cfg4_restart_search_without_torch(tmp_path, world, streams):
+    """BASELINE configs[3] with nothing but libpygps_amd.so + sockets for the 128-byte id: world 1 over the library's RCCL
+    transport (system librccl), world 2 over its host transport; per-restart objectives against the reference's run (G9, N = 512)."""
+    from test_hostgroup import launch
+    g = golden("G9_restarts_N512")
+    rs = launch(world, "g9_search", tmp_path, 512, streams, timeout=900)
+    want_transport = "rccl" if world == 1 else "host"
+    for z in rs:
+        assert str(z["transport"]) == want_transport
+        assert relerr(z["X0"], g["run_X0"]) < 1e-14
+        assert np.array_equal(z["f"], rs[0]["f"]) and np.array_equal(z["hyp"], rs[0]["hyp"])
+    f = rs[0]["f"]
+    ok = np.isfinite(g["run_f"])
+    assert np.array_equal(np.isfinite(f), ok)
+    assert np.max(np.abs(f[ok] - g["run_f"][ok]) / np.abs(g["run_f"][ok])) < 1e-5, (f, g["run_f"])
+    assert abs(float(rs[0]["nlZ"]) - float(g["best_nlZ"])) < 1e-6 * abs(float(g["best_nlZ"]))
+
+
+def test_cfg4_at_its_stated_size_N8192_bounded_fixture(lib):
+    """BASELINE configs[3] says N = 8192; G9_restarts_N8192_3ls is the reference's own run at that size with the search bounded to
+    3 line searches per restart (8 restarts, np.random.seed(123): ~70 reference fits).  Start table bit for bit, which restarts
+    fail, per-restart objective <= 1e-5, line-search counts."""
+    path = os.path.join(GOLDEN, "G9_restarts_N8192_3ls.npz")
+    if not os.path.exists(path):
+        pytest.skip("G9 N=8192 (3 line searches) fixture not recorded")
+    import pygps_amd as pyGPs
+    g = golden("G9_restarts_N8192_3ls")
+    N, d = int(g["N"]), int(g["d"])
+    x, y = synth_reg(N, d)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.0))
+    m.setNoise(np.log(0.1))
+    m.setData(x, y)
+    m.setOptimizer("ShardedMinimize", num_restarts=int(g["num_restarts"]))
+    np.random.seed(int(g["np_seed"]))
+    m.optimize(x, y, numIterations=int(g["numIterations"]))
+    o = m.optimizer
+    assert relerr(o.init_table, g["run_X0"]) < 1e-14
+    f = np.array([r.f for r in o.runs])
+    okr = np.array([r.ok for r in o.runs])
+    assert np.array_equal(okr, g["run_ok"])
+    ok = g["run_ok"]
+    assert np.max(np.abs(f[ok] - g["run_f"][ok]) / np.abs(g["run_f"][ok])) < 1e-5, (f, g["run_f"])
+    assert np.array_equal(np.array([r.nls for r in o.runs])[ok], g["run_nls"][ok])
+    assert abs(m.nlZ - float(g["best_nlZ"])) < 1e-6 * abs(float(g["best_nlZ"]))
+    assert relerr(o._convert_to_array(), g["best_hyp"]) < 1e-4
+
+
+def test_multi_dataset_objective_sums_like_the_clustering_demo(lib):
+    """Demo/Clustering/pyGP_extension.py:27-76: one model, several independent data sets, nlZ and dnlZ accumulated."""
+    import pygps_amd as pyGPs
+    from pygps_amd import opt
+    rng = np.random.RandomState(5)
+    xs = [rng.randn(n, 3) for n in (150, 200, 97)]
+    ys = [np.sin(x.sum(axis=1, keepdims=True)) + 0.1 * rng.randn(x.shape[0], 1) for x in xs]
+    hyp = np.array([0.3, -0.2])
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBF(0.0, 0.0))
+    m.setNoise(np.log(0.2))
+    tot, dn, each = opt.multi_dataset_objective(hyp, m, xs, ys, der=True)
+    want, wg = 0.0, np.zeros(4)
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        ref = O.exact_fit(O.RBF, hyp, 0, np.log(0.2), x, y, float(np.mean(y)) * np.ones_like(y), np.ones_like(y), faithful=False)
+        want += ref["nlZ"]
+        wg += np.concatenate([ref["dnlZ_mean"], ref["dnlZ_cov"], ref["dnlZ_lik"]])
+        assert abs(each[i] - ref["nlZ"]) < 1e-9 * abs(ref["nlZ"])
+    assert abs(tot - want) < 1e-9 * abs(want) and np.max(np.abs(_flat(dn) - wg)) < 1e-7 * np.max(np.abs(wg))
+    assert type(dn.cov[0]) is np.float64
+    tot2, dn2, _ = opt.multi_dataset_objective(hyp, m, xs, ys, der=False)
+    assert dn2 is None and abs(tot2 - want) < 1e-9 * abs(want)
+
+
+def test_rbf_with_300_dimensions_gram_vs_difference_form(lib):
+    """plain RBF has no cap on d; the Gram-form assembly's prep buffer holds 272 coordinate means in front of the
+    norms.  d = 300 pixel-like data in [0, 1] with ell ~ sqrt(d) passes the host's norm bound: the fit must not depend on the
+    gram_assembly option (beyond 272 coordinates the Gram form is not offered) and must match the oracle."""
+    import pygps_amd as pyGPs
+    from test_gpu_parity_r4 import _fit_with
+    rng = np.random.RandomState(11)
+    n, d = 900, 300
+    x = rng.rand(n, d)
+    y = np.sin(x[:, :5].sum(axis=1, keepdims=True)) + 0.05 * rng.randn(n, 1)
+    kern = lambda: pyGPs.cov.RBF(np.log(np.sqrt(d)) - 0.5, 0.1)
+    r0, r1, r2 = (_fit_with(lib, o, x, y, kern, np.log(0.1)) for o in (0, 1, 2))
+    c = float(np.mean(y))
+    ref = O.exact_fit(O.RBF, np.array([np.log(np.sqrt(d)) - 0.5, 0.1]), 0, np.log(0.1), x, y, c * np.ones_like(y), np.ones_like(y),
+                      faithful=False)
+    gref = np.concatenate([ref["dnlZ_mean"], ref["dnlZ_cov"], ref["dnlZ_lik"]])
+    for r in (r0, r1, r2):
+        assert relerr(r[0], ref["nlZ"]) < 1e-9 and relerr(r[2], ref["alpha"]) < 1e-7
+        assert np.max(np.abs(r[1] - gref)) < 1e-7 * np.max(np.abs(gref))
+    # d = 256 (16 chunks of 16: the largest dpad the Gram form takes) still runs it, forced vs forbidden agree
+    x2 = x[:, :256].copy()
+    k2 = lambda: pyGPs.cov.RBF(np.log(16.0) - 0.5, 0.1)
+    a0, a2 = (_fit_with(lib, o, x2, y, k2, np.log(0.1)) for o in (0, 2))
+    assert a0[0] != a2[0] or not np.array_equal(a0[2], a2[2])                     # two different code paths ...
+    assert relerr(a2[0], a0[0]) < 1e-12 and relerr(a2[2], a0[2]) < 1e-10 and relerr(a2[1], a0[1]) < 1e-9
+
+
+def test_ard_gradient_forms_just_under_the_bound(lib):
+    """the matrix-core form of the ARD gradient weights is used up to |x|^2 = 1e6 of the scaled, centred points (was
+    1e8).  Data just under the bound (a spread of ~900 length scales along one coordinate): default = matrix-core form, and it
+    agrees with the difference form and the oracle's per-length-scale getDerMatrix loop within the gradient tolerance."""
+    from test_gpu_parity_r4 import _ard_fit_with
+    rng = np.random.RandomState(2)
+    n, d = 600, 6
+    x = rng.randn(n, d)
+    x[:, 0] *= 300.0                                   # |x0|^2 up to ~ (3.3 * 300)^2 ~ 9.6e5 < 1e6 at ell = 1
+    x[1::2] = x[::2] + 0.3 * rng.randn(n // 2, d) * np.array([0.5, 1, 1, 1, 1, 1])    # near pairs: non-trivial K entries
+    y = np.sin(x[:, 1:].sum(axis=1, keepdims=True)) + 0.1 * rng.randn(n, 1)
+    log_ell = np.zeros(d)
+    r0, r1, r2 = (_ard_fit_with(lib, f, x, y, log_ell) for f in (0, 1, 2))
+    assert np.array_equal(r0[1], r1[1])                                            # the default is the matrix-core form here
+    c = float(np.mean(y))
+    ref = O.exact_fit(O.RBFARD, np.concatenate([log_ell, [0.1]]), 0, np.log(0.12), x, y, c * np.ones_like(y), np.ones_like(y),
+                      faithful=False)
+    gref = np.concatenate([ref["dnlZ_mean"], ref["dnlZ_cov"], ref["dnlZ_lik"]])
+    for r in (r1, r2):
+        assert np.max(np.abs(r[1] - gref)) < 1e-7 * np.max(np.abs(gref))

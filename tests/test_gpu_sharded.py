@@ -93,8 +93,17 @@ def _worker(rank, world, port, backend, case, out_dir):
             nlZ, dnlZ, post = m.getPosterior()
             _check_g6(N, nlZ, dnlZ, post)
             res = dict(nlZ=nlZ, g=_flat(dnlZ), alpha=post.alpha, ms=m.inffunc.last_ms)
-            if rank == 0:
-                print("sharded fit N=%d world=%d (%s): %s ms [assembly, sweep, epilogue, total]" % (N, world, comm.transport, np.round(m.inffunc.last_ms, 2)))
+            lc = m.inffunc.last_comm
+            # the timers a first multi-GPU run is read from (timings_out[6..9]): every rank moved every panel, the broadcasts took
+            # time, the stall is what the compute stream waited for panels (zero at world 1: nothing is moved)
+            if world > 1:
+                assert lc["bcast_ms"] > 0 and lc["bcast_max_ms"] > 0 and lc["wait_panel_ms"] >= 0 and lc["bcast_bytes"] > 0
+            else:
+                assert lc["bcast_ms"] == 0 and lc["wait_panel_ms"] == 0 and lc["bcast_bytes"] == 0
+            print("sharded fit N=%d world=%d rank %d (%s): %s ms [assembly, sweep, epilogue, total]; waited for panels %.2f ms "
+                  "(%.0f %% of the sweep), broadcasts %.2f ms enqueue->complete = %.1f GB/s, slowest %.2f ms"
+                  % (N, world, rank, comm.transport, np.round(m.inffunc.last_ms, 2), lc["wait_panel_ms"], 100 * lc["wait_share"],
+                     lc["bcast_ms"], lc["bcast_GBs"], lc["bcast_max_ms"]))
         elif case == "kernels":
             # ragged n (not a multiple of the 512 panel, nor of 128), ARD / Matern / composite kernels against the oracle
             rng = np.random.RandomState(11)
