@@ -179,6 +179,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "gemm_dbg")) { if (value & ~(64 | 256 | 512)) return -2; c->gemm_dbg = value; return PGP_OK; }
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     if (!strcmp(name, "leaf_first")) { c->leaf_first = value; return PGP_OK; }
+    if (!strcmp(name, "sched")) { if (value < 0 || value > 1) return -2; c->sched = value; return PGP_OK; }
     if (!strcmp(name, "gram_assembly")) { if (value < 0 || value > 2) return -2; c->gram_assembly = value; return PGP_OK; }
     if (!strcmp(name, "yield")) { c->yield = value; return PGP_OK; }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
@@ -850,6 +851,45 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         g.flops = (double)m.dense2 * m.dense2 * g.K;
         return gemm_prof(c, PC_GEMM_INNER, g, main);
     };
+    // sched 1 (round 5): the CRITICAL PATH  D(p) -> S(p) -> TU_a(p) -> D(p+1)  lives on the (high-priority) panel stream, the bulk --
+    // TU_b(p) + E E'(p) -- on the main stream.  The two under-filled launches of a panel (S: ~250 tile units, TU_a: ~230) then run
+    // BESIDE the previous panel's bulk launch and its tail instead of alone on the chip between two bulk launches, and D(p+1) starts
+    // without waiting for them to drain a full chip.  Events: main waits for S(p) before TU_b(p); the panel stream waits for
+    // TU_b(p-1) (which brought panel p+1's columns up to date) before TU_a(p).  Same kernels, same per-tile order: bit-identical.
+    const bool sched1 = la && c->sched == 1 && !m.dense2;
+    if (sched1) {
+        while ((int)c->la_ev.size() < 2 * npanel + 4) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->la_ev.push_back(e);
+        }
+        auto EV_S = [&](int p) { return c->la_ev[2 * p]; };           // S(p) done (panel stream)
+        auto EV_B = [&](int p) { return c->la_ev[2 * p + 1]; };       // TU_b(p) [+ E E'(p)] done (main stream)
+        hipEvent_t ev0 = c->la_ev[2 * npanel + 2];
+        HIP_TRY(hipEventRecord(ev0, main));                           // panel 0's staging copy and D(0) ran on main
+        HIP_TRY(hipStreamWaitEvent(pan, ev0, 0));
+        const int pf = std::min(c->eet_first >= 0 ? c->eet_first : npanel / 6, npanel - 2);
+        for (int p = 0; p < npanel; ++p) {
+            const int s0 = p * q, s1 = std::min(s0 + q, nblk);
+            CHK(solve_below(c, m, s0, s1, Xs, ldx, pan));
+            HIP_TRY(hipEventRecord(EV_S(p), pan));
+            HIP_TRY(hipStreamWaitEvent(main, EV_S(p), 0));
+            if (s1 >= nblk) break;
+            const int n0 = s1, n1 = std::min(s1 + q, nblk);
+            if (p >= 1) HIP_TRY(hipStreamWaitEvent(pan, EV_B(p - 1), 0));
+            CHK(trailing_update2(c, m, s0, s1, n0, n1, Xs, ldx, pan));            // TU_a -> staging
+            CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan));        // D(p+1)
+            const bool fill_now = fill_inline && p >= pf;
+            if (fill_now && n1 < nblk && c->pair_launch) {
+                CHK(gemm_prof_pair(c, PC_GEMM_TRAIL, trailing_update2_args(c, m, s0, s1, n1, nblk, nullptr, 0), PC_GEMM_LAUUM,
+                                   eet_panel_args(c, m, p == pf ? 0 : s0, s1, c->eet_out, c->eet_ld), main));
+            } else {
+                CHK(trailing_update2(c, m, s0, s1, n1, nblk, nullptr, 0, main));
+                if (fill_now) CHK(eet_panel(c, m, p == pf ? 0 : s0, s1, c->eet_out, c->eet_ld, main));
+            }
+            HIP_TRY(hipEventRecord(EV_B(p), main));
+        }
+    } else
     for (int p = 0; p < npanel; ++p) {
         const int s0 = p * q, s1 = std::min(s0 + q, nblk);
         CHK(solve_below(c, m, s0, s1, Xs, ldx, main));

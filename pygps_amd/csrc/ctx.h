@@ -55,6 +55,8 @@ struct pgp_ctx {
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     std::vector<hipEvent_t> tm_ev;      // timing events of the sharded fit's wait / broadcast timers (4 per panel)
     int lookahead = 1;
+    int sched = 0;                      // option "sched": 1 = the critical path D -> S -> TU_a on the panel stream, the bulk updates on the main
+                                        // stream (potrf_blocked_v2); 0 = round 2-4: S, TU_a, TU_b on the main stream, only D on the panel stream
     int leaf_first = 0;                 // 1: TU_b(p) is launched only after D(p+1)'s stage-in kernel, so that the first leaf is
                                         // dispatched BEFORE the update's first wave takes every workgroup slot (a leaf dispatched
                                         // into that wave waited ~140 us for it): 12.08 -> 11.72 ms per N = 8192 fit, two fit

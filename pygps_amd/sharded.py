@@ -231,6 +231,9 @@ class Comm(object):
         except Exception:
             return None
 
+    def __deepcopy__(self, memo):
+        return self                     # a communicator is shared, never copied (models that reference one are deep-copied per fit stream)
+
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle:
             self._free(self.handle)

@@ -81,7 +81,7 @@ _METRICS = {
 }
 
 
-def _one_fold(make_model, x, y, K, k, metrics, numIterations):
+def _one_fold(make_model, x, y, K, k, metrics, numIterations, set_data):
     idx = np.arange(x.shape[0])
     test = idx % K == k
     m = make_model()
@@ -90,15 +90,18 @@ def _one_fold(make_model, x, y, K, k, metrics, numIterations):
     for name in ("last_ttau", "last_tnu"):           # a fold never inherits EP warm-start state (cf. ShardedMinimize._cold_start)
         if hasattr(inf_, name):
             setattr(inf_, name, None)
-    if numIterations:
+    if set_data:                                      # the documented flow: setData (the default mean becomes Const(mean(y_train)),
+        m.setData(x_tr, y_tr)                         # Core/gp.py:154-156), then optimize() / getPosterior()
+        if numIterations:
+            m.optimize(numIterations=numIterations)
+            nlZ = m.nlZ
+        else:
+            nlZ = m.getPosterior()[0]
+    elif numIterations:                               # Demo/JHUI/demo_Validation.py:75 literally: optimize(x_train, y_train) on a fresh model
         m.optimize(x_tr, y_tr, numIterations=numIterations)
         nlZ = m.nlZ
     else:
-        if m.x is None or getattr(m, "usingDefaultMean", False):
-            m.setData(x_tr, y_tr)
-            nlZ = m.getPosterior()[0]
-        else:
-            nlZ = m.getPosterior(x_tr, y_tr)[0]
+        nlZ = m.getPosterior(x_tr, y_tr)[0]
     ym, ys2, fm, fs2, lp = m.predict(x_te, ys=y_te)
     rec = [float(nlZ)]
     for name, fn in metrics:
@@ -110,14 +113,16 @@ def _one_fold(make_model, x, y, K, k, metrics, numIterations):
 
 
 def sharded_k_fold(model, x, y, K=10, metrics=("RMSE", "NLPD"), numIterations=0, group=None, streams_per_gpu=2,
-                   deal="auto"):
+                   deal="auto", set_data=True):
     """K-fold validation of ``model`` on (x, y), the folds sharded over the ranks of ``group``.
 
     model: a zero-argument callable that returns a fresh model (``lambda: pyGPs.GPR()``, as the demo builds one per fold),
            or a model instance used as a template (deep-copied per fold, before it has seen any fold's data).
     metrics: names from RMSE / NLPD / ACC / Prec / Recall / RMSE_class, or (name, callable(ym, ys2, y_test)) pairs.
-    numIterations: 0 = fit at the model's hyper-parameters (``getPosterior``); > 0 = ``optimize(x_train, y_train,
-           numIterations)`` first, as the demo does.
+    numIterations: 0 = fit at the model's hyper-parameters (``getPosterior``); > 0 = ``optimize(numIterations)`` first.
+    set_data: True = ``setData(x_train, y_train)`` per fold before the fit (the default mean becomes Const(mean(y_train))); False =
+           the data go in through ``optimize(x_train, y_train)`` / ``getPosterior(x_train, y_train)`` as the demo writes it (a fresh
+           model keeps its Zero mean then).
     group / deal: as ``opt.ShardedMinimize`` (a torch process group, a ``hostgroup.HostGroup``, a ``sharded.Comm`` or None).
     Returns {"nlZ": (K,), <metric>: (K,), ..., "owner": (K,) rank that ran each fold}, identical on every rank.  The data are
     taken from rank 0 (one broadcast each for x and y)."""
@@ -163,7 +168,7 @@ def sharded_k_fold(model, x, y, K=10, metrics=("RMSE", "NLPD"), numIterations=0,
                 if k is None:
                     return
                 try:
-                    rec[k, :W] = _one_fold(make_model, x, y, K, k, mets, numIterations)
+                    rec[k, :W] = _one_fold(make_model, x, y, K, k, mets, numIterations, set_data)
                 except Exception as e:                 # the fold is reported as failed (NaNs), the collective still completes
                     errors.append((k, e))
                 rec[k, W] = 1.0

@@ -259,7 +259,9 @@ def test_sharded_minimize_over_rccl_world_size_1(lib):
         assert dist.get_backend() == "nccl"
         m1 = model()
         m1.setOptimizer("ShardedMinimize", num_restarts=8)
-        assert isinstance(m1.optimizer, opt.ShardedMinimize) and m1.optimizer._dist() is dist
+        assert isinstance(m1.optimizer, opt.ShardedMinimize)
+        comm = m1.optimizer._get_comm()              # the library's own RCCL transport; torch.distributed only carried the id
+        assert comm.transport == "rccl" and comm.world == 1 and comm.dist is dist
         np.random.seed(123)
         h, f = m1.optimizer.findMin(x, y, numIters=40)
         runs = m1.optimizer.runs

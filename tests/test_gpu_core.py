@@ -222,7 +222,8 @@ def test_shrinking_batched_trailing_update(lib):
 @pytest.mark.parametrize("opts", [{'yield': 0}, dict(leaf_first=1), {'leaf_first': 3, 'yield': 0}, dict(lookahead=0), dict(eet_overlap=0), dict(eet_overlap=2, eet_tile=64),
                                   dict(s_tile=128), dict(eet_first=0), dict(small_tile_below=256), dict(gemm_dbg=0),
                                   dict(xcd_order=1), dict(xcd_order=1, xcd_super=4, xcd_min_tiles=64),
-                                  dict(pair_launch=0), dict(pair_launch=1, gemm_trace=64)])
+                                  dict(pair_launch=0), dict(pair_launch=1, gemm_trace=64), dict(sched=1), dict(sched=0),
+                                  dict(sched=1, pair_launch=0, eet_overlap=2), dict(sched=1, eet_overlap=0)])
 def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
     """The kept schedule options of the Cholesky sweep -- without the cooperative yield of the bulk workgroups, the trailing
     update held back until D(p+1)'s stage-in / third chain kernel, the serial order, B^-1 = E E^T as one product after the sweep or as panel products behind every trailing update, tile
