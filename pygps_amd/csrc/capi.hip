@@ -41,6 +41,11 @@ void prof_collect(pgp_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------------------------
+DeviceGate& device_gate(int device) {
+    static DeviceGate gates[64];
+    return gates[(unsigned)device % 64u];
+}
+
 extern "C" {
 
 const char* pgp_version(void) { return "pygps_amd 0.1 (gfx950)"; }
@@ -1171,6 +1176,8 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
                   const double* mvec, const double* dm, int nmean, int want, double* alpha_out, double* nlZ_out,
                   double* dnlZ_out, pgp_factor** factor_out) {
     if (!c) return -1;
+    GateShared device_gate_hold(c);
+    if (!c) return -1;
     if (c->n <= 0) return -1;
     if (!covhyp) return -3;
     if (want < 1 || want > 3) return -11;
@@ -1313,6 +1320,8 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
 int64_t pgp_factor_n(pgp_factor* f) { return f ? f->n : 0; }
 
 int pgp_factor_to_host(pgp_ctx* c, pgp_factor* f, double* L_out) {
+    if (!c) return -1;
+    GateShared device_gate_hold(c);
     if (!c || !f) return -1;
     if (!L_out) return -3;
     HIP_TRY(hipSetDevice(c->device));
@@ -1341,6 +1350,8 @@ void pgp_factor_free(pgp_ctx* c, pgp_factor* f) {
 // ---- kernel plug-in ------------------------------------------------------------------------------
 int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n, const double* z, int64_t m,
             int64_t d, const double* hyp, int nhyp, int para, int flags, double* out) {
+    if (!c) return -1;
+    GateShared device_gate_hold(c);
     if (!c) return -1;
     if (mode < 0 || mode > 2) return -3;
     if (!hyp) return -10;
@@ -1391,6 +1402,8 @@ int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n,
 
 // ---- helper functions ------------------------------------------------------------------------------
 int pgp_potrf(pgp_ctx* c, const double* A, int64_t n, double* L_out) {
+    if (!c) return -1;
+    GateShared device_gate_hold(c);
     if (!c) return -1;
     if (!A) return -2;
     if (n <= 0) return -3;

@@ -1,7 +1,9 @@
 // Internal: context / factor structs shared by the host-side drivers (capi.hip, predict.hip, ep.hip).
 #pragma once
 #include <algorithm>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <mutex>
 #include <vector>
 
@@ -331,6 +333,32 @@ inline long predict_batch_points(int option, long ns, long np) {
     const long want = std::min<long>(option, (ns + 127) / 128 * 128);
     return std::max<long>(128, std::min<long>(want, cap));
 }
+// Per-device gate between the contexts of ONE process.  Every compute entry point holds it SHARED for the duration of its call (calls
+// are synchronous: when nobody holds it, none of this process's work is on the device).  An EP block sweep holds it EXCLUSIVELY: the
+// sweep is a resident kernel on one stream that meets bulk launches on another through device counters, and the runtime may map
+// streams of DIFFERENT contexts onto one hardware queue -- a foreign launch that waits for an event of its own context's other
+// stream, queued between the sweep's bulk launches while its producer sits behind the resident kernel, closes a cycle (seen as "a
+// device-side wait gave up" when a K-fold search ran two EP fits beside each other).  Writers are preferred (sweeps are short).
+struct DeviceGate {
+    std::mutex m;
+    std::condition_variable cv;
+    int readers = 0, writers_waiting = 0;
+    bool writer = false;
+    void lock_shared() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !writer && writers_waiting == 0; }); ++readers; }
+    void unlock_shared() { std::lock_guard<std::mutex> l(m); if (--readers == 0) cv.notify_all(); }
+    void lock() { std::unique_lock<std::mutex> l(m); ++writers_waiting; cv.wait(l, [&] { return !writer && readers == 0; }); --writers_waiting; writer = true; }
+    void unlock() { std::lock_guard<std::mutex> l(m); writer = false; cv.notify_all(); }
+};
+DeviceGate& device_gate(int device);
+struct GateShared {                     // RAII: shared for a whole entry point; exclusive() / shared_again() around an EP sweep
+    DeviceGate& g; int state = 1;       // 1 shared, 2 exclusive, 0 none
+    explicit GateShared(pgp_ctx* c) : g(device_gate(c ? c->device : 0)) { g.lock_shared(); }
+    void exclusive() { if (state == 1) { g.unlock_shared(); g.lock(); state = 2; } }
+    void shared_again() { if (state == 2) { g.unlock(); g.lock_shared(); state = 1; } }
+    ~GateShared() { if (state == 1) g.unlock_shared(); else if (state == 2) g.unlock(); }
+    GateShared(const GateShared&) = delete;
+    GateShared& operator=(const GateShared&) = delete;
+};
 constexpr double ARD_GRAM_GRAD_BOUND = 1.0e6;     // max squared norm of a scaled, centred point for the Gram-form gradient weights
 bool gram_assembly_applies(pgp_ctx* c, const CovSpec& cs);
 int diag_block_factor(pgp_ctx* c, const double* src, long lds, int w, double* Fd, long ldf, double* Ed, long lde,

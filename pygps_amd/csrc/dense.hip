@@ -76,6 +76,8 @@ extern "C" {
 int pgp_exact_fit_dense(pgp_ctx* c, const double* K, int64_t n, const double* r, double log_sn, int want, double* alpha_out,
                         double* nlZ_out, double* dnlZ_lik_out, pgp_factor** factor_out) {
     if (!c) return -1;
+    GateShared device_gate_hold(c);
+    if (!c) return -1;
     if (!K) return -2;
     if (n <= 0) return -3;
     if (!r) return -4;
@@ -160,6 +162,8 @@ int pgp_exact_fit_dense(pgp_ctx* c, const double* K, int64_t n, const double* r,
 // out = 1/2 sum_ij Q_ij dK_ij with Q = B^-1 / sn2 - alpha alpha' of the pgp_exact_fit_dense call (want = 3, same n, same log_sn)
 // that directly precedes it on this context; dK (n,n) symmetric host (Core/inf.py:376-377).
 int pgp_dense_grad_term(pgp_ctx* c, const double* dK, int64_t n, double log_sn, double* out) {
+    if (!c) return -1;
+    GateShared device_gate_hold(c);
     if (!c) return -1;
     if (!dK) return -2;
     if (n <= 0 || round_up(n, 128) != c->ws_np) return -3;

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <type_traits>
@@ -1093,6 +1094,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
     if (c->n <= 0) return -1;
     if (!covhyp && !Kdense) return -3;
     if (!ttau_io || !tnu_io) return -12;
+    GateShared gate(c);                              // shared for the fit, exclusive during each block sweep (ctx.h DeviceGate)
     HIP_TRY(hipSetDevice(c->device));
     c->dense_ready = false;                          // the workspace (B^-1, alpha) is about to be rewritten
     hipStream_t st = c->st;
@@ -1223,6 +1225,15 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
     while ((fabs(nlZ - nlZ_old) > tol && sweep < max_sweep) || sweep < min_sweep) {
         nlZ_old = nlZ;
         ++sweep;
+        // ONE block sweep per device at a time, and nothing else of this process beside it (ctx.h DeviceGate: the sweep is a resident
+        // kernel on one stream that meets bulk launches on another through device counters; a foreign launch with a cross-stream wait
+        // on a shared hardware queue can close a cycle).  Exclusive until this sweep's host synchronisation at the end of the loop
+        // body; K, the final Cholesky, alpha and the gradients of an EP fit run under the shared gate beside other contexts' work.
+        struct SweepExclusive {
+            GateShared& g; bool on;
+            SweepExclusive(GateShared& g_, bool on_) : g(g_), on(on_) { if (on) g.exclusive(); }
+            ~SweepExclusive() { if (on) g.shared_again(); }
+        } sweep_excl(gate, c->ep_block != 0);
         if (c->ep_block) {
             // block sweep: the chain stream (the high-priority panel stream) runs ONE resident kernel per sweep (chain + prep workgroups);
             // the bulk stream (main) strip(b), U(b), fold(b), mu(b) per block.  The two meet through device counters (ep_chain_kernel).

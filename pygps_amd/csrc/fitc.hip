@@ -210,6 +210,8 @@ int pgp_fitc_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para,
                  const double* xu, int64_t nu, const double* mvec, const double* dm, int nmean, int want,
                  double* alpha_out, double* L_out, double* nlZ_out, double* dnlZ_out, pgp_fitc** handle_out) {
     if (!c) return -1;
+    GateShared device_gate_hold(c);
+    if (!c) return -1;
     if (c->n <= 0) return -1;
     if (!covhyp) return -3;
     if (!xu || nu <= 0) return -8;
@@ -393,6 +395,8 @@ int pgp_fitc_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para,
 // GP.predict with the FITC posterior (Core/gp.py:395-417, dense-L branch :415):  fmu = ms + Ks' alpha,
 // fs2 = max(kss + colsum(Ks o (L Ks)), 0) with Ks = k(xu, xs)
 int pgp_fitc_predict(pgp_ctx* c, pgp_fitc* f, const double* xs, int64_t ns, const double* ms, double* fmu, double* fs2) {
+    if (!c) return -1;
+    GateShared device_gate_hold(c);
     if (!c || !f) return -1;
     if (!xs || ns <= 0) return -3;
     if (!fmu || !fs2) return -6;

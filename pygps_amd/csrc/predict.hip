@@ -68,6 +68,8 @@ extern "C" {
 
 int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const double* ms, double* fmu, double* fs2) {
     if (!c) return -1;
+    GateShared device_gate_hold(c);
+    if (!c) return -1;
     if (!f) return -2;
     if (!xs) return -3;
     if (ns <= 0) return -4;
@@ -123,6 +125,8 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
 int pgp_predict_dense(pgp_ctx* c, pgp_factor* f, const double* Ks_host, int64_t ns, const double* kss, const double* ms,
                       double* fmu, double* fs2) {
     if (!c) return -1;
+    GateShared device_gate_hold(c);
+    if (!c) return -1;
     if (!f) return -2;
     if (!Ks_host) return -3;
     if (ns <= 0) return -4;
@@ -168,6 +172,8 @@ int pgp_predict_dense(pgp_ctx* c, pgp_factor* f, const double* Ks_host, int64_t 
 }
 
 int pgp_potrs(pgp_ctx* c, const double* R, int64_t n, const double* Bm, int64_t nrhs, double* X_out) {
+    if (!c) return -1;
+    GateShared device_gate_hold(c);
     if (!c) return -1;
     if (!R) return -2;
     if (n <= 0) return -3;

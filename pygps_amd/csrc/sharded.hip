@@ -482,6 +482,8 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
                           const double* mvec, const double* dm, int nmean, int want, double* alpha_out, double* nlZ_out,
                           double* dnlZ_out, double* timings_out, double* L_out, pgp_sfactor** factor_out) {
     if (!c) return -1;
+    GateShared device_gate_hold(c);
+    if (!c) return -1;
     if (!m || m->ctx != c) return -2;
     if (c->n <= 0) return -1;
     if (!covhyp) return -4;
@@ -866,6 +868,8 @@ int pgp_sharded_exact_fit(pgp_ctx* c, pgp_comm* m, int kind, const double* covhy
 // all-reduce of ns doubles per batch finishes fs2.  No triangular solve: E = L^-T came out of the sweep.
 int pgp_sharded_predict(pgp_ctx* c, pgp_comm* m, pgp_sfactor* f, const double* xs, int64_t ns, const double* ms, double* fmu,
                         double* fs2) {
+    if (!c) return -1;
+    GateShared device_gate_hold(c);
     if (!c) return -1;
     if (!m || m->ctx != c) return -2;
     if (!f || f->world != m->world || f->me != m->rank) return -3;

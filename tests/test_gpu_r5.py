@@ -213,3 +213,36 @@ def test_ard_gradient_forms_just_under_the_bound(lib):
     gref = np.concatenate([ref["dnlZ_mean"], ref["dnlZ_cov"], ref["dnlZ_lik"]])
     for r in (r1, r2):
         assert np.max(np.abs(r[1] - gref)) < 1e-7 * np.max(np.abs(gref))
+
+
+def test_two_ep_fits_at_once_on_two_fit_streams(lib):
+    """Two EP fits on two fit streams of one GPU (what a restart / fold search over a GPC model does): a block sweep is a resident
+    kernel that meets bulk launches through device counters, and two of them at once could starve each other on shared hardware
+    queues until their bounded waits gave up (seen once in the K-fold test).  Sweeps are now serialised per device; 2 x 8 fits must
+    all succeed and reproduce the single-stream numbers bit for bit."""
+    import threading
+    import pygps_amd as pyGPs
+    from pygps_amd import _lib
+    x, y = synth_cls(1024, 8)
+
+    def fit():
+        m = pyGPs.GPC()
+        m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(8.0)), 0.0))
+        nlZ, dnlZ, post = m.getPosterior(x, y)
+        return nlZ, np.array(post.alpha)
+    ref = fit()
+    out, errs = {}, []
+
+    def work(k):
+        try:
+            with _lib.fit_stream(k):
+                out[k] = [fit() for _ in range(8)]
+        except Exception as e:           # pragma: no cover
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for k in range(2):
+        for nlZ, a in out[k]:
+            assert nlZ == ref[0] and np.array_equal(a, ref[1])
