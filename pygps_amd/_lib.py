@@ -103,6 +103,7 @@ TEST_SIGNATURES = {
     "pgp_test_store_roof": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _dp]),
     "pgp_test_cumask_gemm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "pgp_test_wave_costs": (C.c_int, [_vp, _dp]),
+    "pgp_test_stream_concurrency": (C.c_int, [_vp, C.c_int, _dp]),
     "pgp_test_slot_probe": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
 }
 

@@ -78,7 +78,7 @@ static unsigned* yield_table(int device) {
     return tab[device];
 }
 
-int pgp_init(int device, pgp_ctx** ctx_out) {
+int pgp_init(int device, pgp_ctx** ctx_out) { GateShared device_gate_hold(device);
     if (!ctx_out) return -2;
     HIP_TRY(hipSetDevice(device));
     {
@@ -138,7 +138,7 @@ static int alloc_result_buffer(pgp_ctx* c, long np) {
     return PGP_OK;
 }
 
-void pgp_destroy(pgp_ctx* c) {
+void pgp_destroy(pgp_ctx* c) { if (!c) return; GateShared device_gate_hold(c);
     if (!c) return;
     ctx_unregister(c);
     (void)hipSetDevice(c->device);
@@ -1110,7 +1110,7 @@ int pgp_ctx_count_on_device(int device) {
     for (pgp_ctx* c : g_ctxs) n += c->device == device;
     return n;
 }
-void pgp_drop_idle_pools(int device) {
+void pgp_drop_idle_pools(int device) { GateShared device_gate_hold(device);
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     for (pgp_ctx* c : g_ctxs) {
         if (c->device != device) continue;
@@ -1129,14 +1129,14 @@ static void ctx_unregister(pgp_ctx* c) {
 
 extern "C" {
 
-int pgp_set_composite(pgp_ctx* c, const int32_t* prog, int nprog) {
+int pgp_set_composite(pgp_ctx* c, const int32_t* prog, int nprog) { if (!c) return -1; GateShared device_gate_hold(c);
     if (!c) return -1;
     if (nprog < 0 || (nprog > 0 && !prog)) return -2;
     c->composite.assign(prog, prog + nprog);
     return PGP_OK;
 }
 
-int pgp_set_data(pgp_ctx* c, const double* x, int64_t n, int64_t d, const double* y) {
+int pgp_set_data(pgp_ctx* c, const double* x, int64_t n, int64_t d, const double* y) { if (!c) return -1; GateShared device_gate_hold(c);
     if (!c) return -1;
     if (!x) return -2;
     if (n <= 0) return -3;
@@ -1332,7 +1332,7 @@ int pgp_factor_to_host(pgp_ctx* c, pgp_factor* f, double* L_out) {
     return PGP_OK;
 }
 
-void pgp_factor_free(pgp_ctx* c, pgp_factor* f) {
+void pgp_factor_free(pgp_ctx* c, pgp_factor* f) { GateShared device_gate_hold(c);
     if (!f) return;
     if (c) {
         (void)hipSetDevice(c->device);

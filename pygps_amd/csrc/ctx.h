@@ -333,12 +333,16 @@ inline long predict_batch_points(int option, long ns, long np) {
     const long want = std::min<long>(option, (ns + 127) / 128 * 128);
     return std::max<long>(128, std::min<long>(want, cap));
 }
-// Per-device gate between the contexts of ONE process.  Every compute entry point holds it SHARED for the duration of its call (calls
-// are synchronous: when nobody holds it, none of this process's work is on the device).  An EP block sweep holds it EXCLUSIVELY: the
+// Per-device gate between the contexts of ONE process.  Every entry point that may reach the HIP runtime holds it SHARED for the
+// duration of its call (calls are synchronous: when nobody holds it, none of this process's work is on the device and no thread
+// sits in a device-synchronising runtime call).  An EP block sweep holds it EXCLUSIVELY: the
 // sweep is a resident kernel on one stream that meets bulk launches on another through device counters, and the runtime may map
 // streams of DIFFERENT contexts onto one hardware queue -- a foreign launch that waits for an event of its own context's other
 // stream, queued between the sweep's bulk launches while its producer sits behind the resident kernel, closes a cycle (seen as "a
-// device-side wait gave up" when a K-fold search ran two EP fits beside each other).  Writers are preferred (sweeps are short).
+// device-side wait gave up" when a K-fold search ran two EP fits beside each other).  The cycle that was actually caught (round 5,
+// tools/ep_kfold_diag.py): the OTHER host thread frees a buffer (pgp_set_data of the next fold, a posterior handle that dies) --
+// hipFree waits for the device to drain, i.e. for the resident sweep kernel, and holds the runtime's lock meanwhile, so the sweeping
+// thread cannot enqueue the strip launch the resident kernel is waiting for.  Writers are preferred (sweeps are short).
 struct DeviceGate {
     std::mutex m;
     std::condition_variable cv;
@@ -353,6 +357,7 @@ DeviceGate& device_gate(int device);
 struct GateShared {                     // RAII: shared for a whole entry point; exclusive() / shared_again() around an EP sweep
     DeviceGate& g; int state = 1;       // 1 shared, 2 exclusive, 0 none
     explicit GateShared(pgp_ctx* c) : g(device_gate(c ? c->device : 0)) { g.lock_shared(); }
+    explicit GateShared(int device) : g(device_gate(device)) { g.lock_shared(); }
     void exclusive() { if (state == 1) { g.unlock_shared(); g.lock(); state = 2; } }
     void shared_again() { if (state == 2) { g.unlock(); g.lock_shared(); state = 1; } }
     ~GateShared() { if (state == 1) g.unlock_shared(); else if (state == 2) g.unlock(); }

@@ -306,10 +306,12 @@ __device__ __forceinline__ void ep_loads_done(double (&v)[12]) {
 }
 // wait until the counter *f has reached `target`.  Bounded (~1 s, at once when another wait has already given up): a launch that
 // never came must not hang the device; the fit then fails through flags[EPF_ERR]
-__device__ __forceinline__ void ep_wait_ge(unsigned* f, unsigned target, unsigned* err) {
+// *err keeps the FIRST site that gave up (diagnostics): site | block << 8 | 1 << 31
+__device__ __forceinline__ void ep_wait_ge(unsigned* f, unsigned target, unsigned* err, unsigned site = 0u) {
     for (unsigned it = 0; (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0; ++it) {
         if (it > (1u << 22) || ((it & 1023u) == 1023u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned expected = 0u;
+            (void)__hip_atomic_compare_exchange_strong(err, &expected, site | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
         __builtin_amdgcn_s_sleep(4);
@@ -444,8 +446,8 @@ __global__ __launch_bounds__(512) void ep_chain_kernel(double* Sig, long ld, lon
         if (threadIdx.x < 256) {
             for (int b = 0; b < nbl; ++b) {
                 if (b > 0 && threadIdx.x == 0) {
-                    ep_wait_ge(flags + EPF_CHAIN, cbase + (unsigned)b, flags + EPF_ERR);
-                    ep_wait_ge(flags + EPF_STRIP, (sbase + (unsigned)b) * swg, flags + EPF_ERR);
+                    ep_wait_ge(flags + EPF_CHAIN, cbase + (unsigned)b, flags + EPF_ERR, 1u | ((unsigned)b << 8));
+                    ep_wait_ge(flags + EPF_STRIP, (sbase + (unsigned)b) * swg, flags + EPF_ERR, 2u | ((unsigned)b << 8));
                 }
                 __syncthreads();
                 ep_prep_body((int)blockIdx.x - 1, Sig, ld, (long)b * EPB, Sbuf + (long)((b + 1) & 1) * EPB * ld, Sbuf + (long)(b & 1) * EPB * ld,
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(512) void ep_chain_kernel(double* Sig, long ld, lon
             s_dt[t] = 0.0; s_dn[t] = 0.0; s_tn[t] = 0.0; s_nn[t] = 0.0;
         }
         // Sigma_BB and mu_B are the prep workgroups' to finish
-        if (t == 0) ep_wait_ge(flags + EPF_PREP, pbase + 36u * ((unsigned)b + 1u), flags + EPF_ERR);
+        if (t == 0) ep_wait_ge(flags + EPF_PREP, pbase + 36u * ((unsigned)b + 1u), flags + EPF_ERR, 3u | ((unsigned)b << 8));
         __syncthreads();
         if (t < EPB) {
             s_mu0[t] = ld_dev(Tile + EP_TILE_N + t);
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(512) void ep_chain_kernel(double* Sig, long ld, lon
 // behind it (128 workgroups of U spinning on the counter themselves: 20.2 instead of 19.7 ms per fit, option ep_wait_kernel 0)
 __global__ __launch_bounds__(64) void ep_wait_kernel(unsigned* f, unsigned target, unsigned* err) {
     if (threadIdx.x == 0) {
-        ep_wait_ge(f, target, err);
+        ep_wait_ge(f, target, err, 4u | ((target & 0xffffu) << 8));
         __threadfence();
     }
 }
@@ -1086,6 +1088,16 @@ extern "C" int pgp_test_probit_hazard(pgp_ctx* c, const double* z, double* out, 
 // dnlZ_out.  Kdense != nullptr (pgp_ep_fit_dense): K (n x n, symmetric, host) is handed in -- a covariance tree that is not
 // a device program --; dnlZ_out receives the mean gradients only, and R = sW sW' o B^-1 and alpha stay in the context's
 // workspace for the pgp_dense_grad_term calls that follow (1/2 sum (R - alpha alpha') o dK_h, inf.py:780-786).
+// a bounded device-side wait of the block sweep gave up: say which one (site 1 prep<-chain, 2 prep<-strip, 3 chain<-prep, 4 bulk<-chain)
+static int ep_wait_failed(const unsigned* eflags, unsigned chain_total, unsigned prep_total, unsigned strip_total, int line) {
+    char msg[256];
+    snprintf(msg, sizeof(msg), "EP block sweep: a device-side wait gave up (site %u, block/target %u; counters chain %u/%u prep %u/%u strip-wgs %u, strips launched %u)",
+             eflags[EPF_ERR] & 0xffu, (eflags[EPF_ERR] >> 8) & 0x7fffffu, eflags[EPF_CHAIN], chain_total, eflags[EPF_PREP], prep_total,
+             eflags[EPF_STRIP], strip_total);
+    pgp_set_last_hip_error(hipErrorLaunchTimeOut, msg, __FILE__, line);
+    return PGP_ERR_HIP;
+}
+
 static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double* covhyp, int ncov, int para, int flags,
                        const double* mvec, const double* dm, int nmean, int want, int warm, double* ttau_io, double* tnu_io,
                        double* alpha_out, double* sW_out, double* nlZ_out, double* dnlZ_out, int* sweeps_out,
@@ -1366,7 +1378,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
             memcpy(eflags, res_h + np / EPB + 1, sizeof(eflags));
             const double* const ldh = res_h;
             const double* const ph = res_h + np / EPB + 3;
-            if (eflags[EPF_ERR]) { pgp_set_last_hip_error(hipErrorLaunchTimeOut, "EP block sweep: a device-side wait gave up", __FILE__, __LINE__); return PGP_ERR_HIP; }
+            if (eflags[EPF_ERR]) return ep_wait_failed(eflags, w.chain_total, w.prep_total, w.strip_total, __LINE__);
             for (long b = 0; b < nbl; ++b) half_logdet += 0.5 * ldh[b];
             double slZ = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0, t6 = 0.0;
             for (long b = 0; b < nbt; ++b) { slZ += ph[5 * b]; t3 += ph[5 * b + 1]; t4 += ph[5 * b + 2]; t5 += ph[5 * b + 3]; t6 += ph[5 * b + 4]; }
@@ -1383,7 +1395,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
         EP_TRY(sites_to_host());
         if (c->ep_block) HIP_TRY(hipMemcpyAsync(eflags, w.flags, sizeof(eflags), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (eflags[EPF_ERR]) { pgp_set_last_hip_error(hipErrorLaunchTimeOut, "EP block sweep: a device-side wait gave up", __FILE__, __LINE__); return PGP_ERR_HIP; }
+        if (eflags[EPF_ERR]) return ep_wait_failed(eflags, w.chain_total, w.prep_total, w.strip_total, __LINE__);
         stamp("sweep done (synced)", 1);
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // inf.py:772
         HIP_TRY(hipStreamSynchronize(st));

@@ -440,7 +440,7 @@ int pgp_fitc_predict(pgp_ctx* c, pgp_fitc* f, const double* xs, int64_t ns, cons
     return PGP_OK;
 }
 
-void pgp_fitc_free(pgp_ctx* c, pgp_fitc* f) {
+void pgp_fitc_free(pgp_ctx* c, pgp_fitc* f) { GateShared device_gate_hold(c);
     if (!f) return;
     if (c) (void)hipSetDevice(c->device);
     spool_give(c, (size_t)f->dpad * f->nup * sizeof(double), f->XuT);

@@ -300,7 +300,7 @@ struct pgp_sfactor {
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" {
 
-void pgp_sfactor_free(pgp_ctx* c, pgp_sfactor* f) {
+void pgp_sfactor_free(pgp_ctx* c, pgp_sfactor* f) { GateShared device_gate_hold(c);
     if (!f) return;
     if (c) (void)hipSetDevice(c->device);
     spool_give(c, f->bufs_bytes, f->Bufs);

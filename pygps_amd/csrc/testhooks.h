@@ -31,6 +31,8 @@ int pgp_test_assemble(pgp_ctx* ctx, int kind, int mode, int64_t n, int64_t d, in
 int pgp_test_gemm_trace(pgp_ctx* ctx, int M, int K, int tri, int warm, int conc, long long* out, int64_t out_words, int64_t* nblk_out);
 int pgp_test_read_gemm_trace(pgp_ctx* ctx, long long* out, int64_t words, int64_t* nwg);
 int pgp_test_store_roof(pgp_ctx* ctx, int64_t n, int grid, int iters, double* out3);
+/* out2[0] = 1 if the context's two streams ran concurrently (a spinner on the panel stream saw a flag set from the main stream), out2[1] = us waited */
+int pgp_test_stream_concurrency(pgp_ctx* ctx, int wait_us, double* out2);
 #ifdef __cplusplus
 }
 #endif

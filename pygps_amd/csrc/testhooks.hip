@@ -677,3 +677,36 @@ extern "C" int pgp_test_cumask_gemm(pgp_ctx* c, int M, int K, int reserve_per_xc
     (void)hipStreamDestroy(ms);
     return kept;
 }
+
+// Do the two streams of a context run CONCURRENTLY right now?  A one-wave kernel on the panel stream spins (bounded: wait_us) until a
+// one-thread kernel on the main stream, launched after it, has set a flag.  out2[0] = 1 if the flag arrived, out2[1] = microseconds the
+// spinner waited.  (EP's block sweep depends on exactly this: a resident kernel on st2 meets bulk launches on st.)
+__global__ void pgp_probe_spin_kernel(unsigned* flag, long long wait_ticks, long long* out) {
+    const long long t0 = (long long)wall_clock64();
+    long long t = t0;
+    unsigned seen = 0u;
+    while ((t = (long long)wall_clock64()) - t0 < wait_ticks) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { seen = 1u; break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    if (threadIdx.x == 0) { out[0] = (long long)seen; out[1] = t - t0; }
+}
+__global__ void pgp_probe_set_kernel(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+extern "C" int pgp_test_stream_concurrency(pgp_ctx* c, int wait_us, double* out2) {
+    if (!c || !out2) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    DevScratch scr;
+    double* buf;
+    CHK(scr.alloc(&buf, 64));
+    HIP_TRY(hipMemset(buf, 0, 64));
+    unsigned* flag = (unsigned*)buf;
+    long long* res = (long long*)(buf + 2);
+    hipLaunchKernelGGL(pgp_probe_spin_kernel, dim3(1), dim3(64), 0, c->st2, flag, (long long)wait_us * 100LL, res);   // 100 MHz wall clock
+    hipLaunchKernelGGL(pgp_probe_set_kernel, dim3(1), dim3(1), 0, c->st, flag);
+    HIP_TRY(hipStreamSynchronize(c->st2));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, res, sizeof(h), hipMemcpyDeviceToHost));
+    out2[0] = (double)h[0]; out2[1] = (double)h[1] / 100.0;
+    return PGP_OK;
+}

@@ -200,7 +200,7 @@ def test_ard_gradient_forms_just_under_the_bound(lib):
     rng = np.random.RandomState(2)
     n, d = 600, 6
     x = rng.randn(n, d)
-    x[:, 0] *= 250.0                                   # |x0|^2 up to ~ (3.6 * 250)^2 ~ 8e5 < 1e6 at ell = 1
+    x[:, 0] *= 220.0                                   # |x0|^2 up to ~ (4.1 * 220)^2 ~ 8e5 < 1e6 at ell = 1
     assert np.sum(np.max(np.abs(x - x.mean(axis=0)), axis=0) ** 2) < 0.95e6
     x[1::2] = x[::2] + 0.3 * rng.randn(n // 2, d) * np.array([0.5, 1, 1, 1, 1, 1])    # near pairs: non-trivial K entries
     y = np.sin(x[:, 1:].sum(axis=1, keepdims=True)) + 0.1 * rng.randn(n, 1)
