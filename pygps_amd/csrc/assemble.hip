@@ -613,6 +613,162 @@ __global__ __launch_bounds__(256, 2) void cov_gram_kernel(const double* __restri
     }
 }
 
+// ---- the same kernel for the common case, restructured around the memory pipeline (round 5) -------------------------------------
+// dpad = 4 NP <= 64 (one chunk), every tile full (MODE_FACTOR: the padded buffer; MODE_SYM: n a multiple of 64), even leading
+// dimension.  What the general kernel above loses per tile, found in its ISA:
+//  * its loop body has run-time branches (edge tiles, non-temporal stores, "is there a next tile"), so the compiler cannot count
+//    the memory operations between the prefetch of the next tile's coordinates and their use and falls back to s_waitcnt vmcnt(0)
+//    -- on gfx9 that also waits for every STORE of the tile just finished (stores share the load counter): the workgroup drains
+//    its stores before it may touch LDS again;
+//  * __syncthreads() is a workgroup-scope fence + barrier: another vmcnt(0) at every barrier.
+// Here the body is ONE basic block (the next tile is always fetched -- the last iteration re-fetches its own; diagonal tiles of
+// MODE_SYM write their mirror too: same values), so the wait before the LDS commit is an exact vmcnt(#stores), and the barriers
+// are bare s_barrier behind an lgkmcnt(0): the stores of a tile drain under the next tile's matrix products.
+template <int V> struct GIC { static constexpr int value = V; };
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// HV = 2: the coordinates go through LDS in two halves of DP / 2 coordinates (half the LDS: four workgroups per CU instead of two,
+// for the price of two more barriers per tile) -- more waves to hide the LDS / store-issue latencies behind.  The prefetch
+// registers hold ONE half-step ahead: while half h of a tile is multiplied, the pieces of the next half-step are in flight.
+// (Measured, N = 16384, d = 64, full symmetric: general kernel 0.635 ms, HV = 1 0.622, HV = 2 0.566 with 8192 persistent workgroups.
+//  The kernel sits at the 128-register cliff of four workgroups per CU: SGPR-based addressing of the stores, a branch around the
+//  diagonal-only selects and single-buffered fragments were all tried and all SPILLED -- check .private_segment_fixed_size.)
+template <int MODE, int NP, int HV>
+__global__ __launch_bounds__(256, HV == 2 ? 4 : 2) void cov_gram_fast_kernel(const double* __restrict__ XT, long ldp, long n, double sf2,
+                                                                             double inv_sn2, double* __restrict__ out, long ldo,
+                                                                             const int2* __restrict__ tiles, long ntiles,
+                                                                             const double* __restrict__ mu, const double* __restrict__ nrm) {
+    static_assert(NP >= 4 && NP <= 16 && NP % (2 * HV) == 0, "one chunk of 16 .. 64 coordinates, an even number of k-steps per half");
+    constexpr int DP = 4 * NP, NPH = NP / HV, DPH = DP / HV;
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l4 = lane >> 4, l15 = lane & 15;
+    double* xr = gsm;
+    double* xc = gsm + DPH * GSTP;
+    const int spr = lane & 31, sside = lane >> 5;
+    const int wvu = __builtin_amdgcn_readfirstlane(wave);
+    double* slp = (sside ? xc : xr) + 2 * spr + wvu * GSTP;
+    double2_t pg[NPH];                                // the pieces of the NEXT half-step
+    double pm[NP];
+    double nr[4], nc[4], nnr[4], nnc[4];
+    long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int2 tc2 = tiles[tile];
+    auto fetch = [&](int2 tl, auto hc, bool norms) {   // half hc of tile tl -> pg (and its norms -> nnr / nnc)
+        constexpr int H = decltype(hc)::value;
+        const double* gp = XT + (sside ? (long)tl.y * ST : (long)tl.x * ST) + 2 * spr + (long)(wvu + 4 * H * NPH) * ldp;
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) pg[i] = *(const double2_t*)(gp + (long)(4 * i) * ldp);
+        if (norms) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) nnr[a] = nrm[(long)tl.x * ST + 16 * wave + 4 * a + l4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nnc[q] = nrm[(long)tl.y * ST + 16 * q + l15];
+        }
+    };
+    auto commit = [&](auto hc) {                       // pg (half hc) -> LDS, centred
+        constexpr int H = decltype(hc)::value;
+#pragma unroll
+        for (int i = 0; i < NPH; ++i)
+            *(double2_t*)(slp + 4 * i * GSTP) = double2_t{pg[i][0] - pm[H * NPH + i], pg[i][1] - pm[H * NPH + i]};
+    };
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pm[i] = mu[wvu + 4 * i];
+    fetch(tc2, GIC<0>{}, true);
+    commit(GIC<0>{});
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { nr[a] = nnr[a]; nc[a] = nnc[a]; }
+    if (HV == 2) fetch(tc2, GIC<HV - 1>{}, false);    // the first tile's second half
+    lds_barrier();
+    const double* ap = xr + l4 * GSTP + 16 * wave + l15;
+    const double* bp = xc + l4 * GSTP + l15;
+    const bool odd = l15 & 1;
+    const int pr = t & 31, rw = t >> 5;
+    while (true) {
+        const long r0 = (long)tc2.x * ST, c0 = (long)tc2.y * ST;
+        const long next = tile + gridDim.x;
+        const int2 nx = tiles[next < ntiles ? next : tile];       // always a valid tile: the body stays one basic block
+        if (HV == 1) fetch(nx, GIC<0>{}, true);
+        gram4_t acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = gram4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < HV; ++h) {
+            if (h == 1) {
+                lds_barrier();                         // every wave has read the first half
+                commit(GIC<HV - 1>{});                 // this tile's second half (in flight since the previous tile's stores)
+                lds_barrier();
+                fetch(nx, GIC<0>{}, true);             // the next tile's first half: lands under this half's products and the epilogue
+            }
+            double fa0 = ap[0], fb0[4] = {bp[0], bp[16], bp[32], bp[48]};
+#pragma unroll
+            for (int ks = 0; ks < DPH; ks += 8) {
+                const double* a1 = ap + (ks + 4) * GSTP;
+                const double* b1 = bp + (ks + 4) * GSTP;
+                const double fa1 = a1[0], fb1[4] = {b1[0], b1[16], b1[32], b1[48]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0, fb0[q], acc[q], 0, 0, 0);
+                if (ks + 8 < DPH) {
+                    const double* a2 = ap + (ks + 8) * GSTP;
+                    const double* b2 = bp + (ks + 8) * GSTP;
+                    fa0 = a2[0]; fb0[0] = b2[0]; fb0[1] = b2[16]; fb0[2] = b2[32]; fb0[3] = b2[48];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb1[q], acc[q], 0, 0, 0);
+            }
+        }
+        double v[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long r = r0 + 16 * wave + 4 * a + l4, c = c0 + 16 * q + l15;
+                double s2 = fmax(fma(-2.0, acc[q][a], nr[a] + nc[q]), 0.0);
+                s2 = r == c ? 0.0 : s2;
+                double val = sf2 * exp_nonpos(-0.5 * s2);
+                if (MODE == MODE_FACTOR) {
+                    const double live = val * inv_sn2 + (r == c ? 1.0 : 0.0), pad = r == c ? 1.0 : 0.0;
+                    val = (r < n && c < n) ? live : pad;
+                    val = c < r ? 0.0 : val;           // diagonal tiles: exact zeros below the diagonal (row-major upper view)
+                }
+                v[a][q] = val;
+            }
+        // direct stores: 8 x 16 bytes per lane (adjacent lanes trade one value each, see the general kernel)
+#pragma unroll
+        for (int a = 0; a < 4; a += 2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double x0 = v[a][q], x1 = v[a + 1][q];
+                const double n0 = gram_swap_adjacent(x0), n1 = gram_swap_adjacent(x1);
+                const double2_t val = odd ? double2_t{n1, x1} : double2_t{x0, n0};
+                const long r = r0 + 16 * wave + 4 * (odd ? a + 1 : a) + l4, c = c0 + 16 * q + (l15 & ~1);
+                *(double2_t*)(out + r * ldo + c) = val;
+            }
+        if (MODE == MODE_SYM) {
+            // mirrored store out[c][r]: transpose through LDS (this tile's coordinates are consumed), 8 x 16 bytes per lane
+            lds_barrier();
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gsm[(16 * q + l15) * GSTP + 16 * wave + 4 * a + l4] = v[a][q];
+            lds_barrier();
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int cl = p * 8 + rw;
+                *(double2_t*)(out + (c0 + cl) * ldo + r0 + 2 * pr) = *(const double2_t*)(gsm + cl * GSTP + 2 * pr);
+            }
+        }
+        if (next >= ntiles) break;
+        tile = next;
+        lds_barrier();                                 // every wave is done with the LDS image of this tile (and of its mirror)
+        commit(GIC<0>{});                              // (the wait for pg is an exact vmcnt(#stores issued since): the stores keep draining)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { nr[a] = nnr[a]; nc[a] = nnc[a]; }
+        if (HV == 2) fetch(nx, GIC<HV - 1>{}, false);
+        lds_barrier();
+        tc2 = nx;
+    }
+}
+
 __global__ void self_fill_kernel(double* out, long m, double val) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) out[i] = val;
@@ -761,7 +917,7 @@ static int cov_gram_dispatch(int mode, const double* XT, long ldp, long n, long 
     const int CH = dpad < 64 ? dpad : 64;
     const size_t shm = std::max<size_t>((size_t)2 * CH * GSTP, (size_t)ST * GSTP) * sizeof(double);
     const int nt_ = cs.asm_nt >= 0 ? cs.asm_nt : ((mode != MODE_FACTOR && (double)n * (double)n * 8.0 >= 1073741824.0) ? 1 : 0);
-    const unsigned grid = (unsigned)std::min<long>(ntiles, 2048);              // persistent: 2 resident per CU, the rest queue
+    const unsigned grid = (unsigned)std::min<long>(ntiles, cs.gram_grid > 0 ? cs.gram_grid : 2048);   // persistent: 2 resident per CU, the rest queue
 #define GRAM_LAUNCH(M, NPV) do {                                                                                                  \
         static std::atomic<int> attr_done{0};                                /* per instantiation: once */                         \
         if (!attr_done.load(std::memory_order_acquire)) {                                                                          \
@@ -773,7 +929,29 @@ static int cov_gram_dispatch(int mode, const double* XT, long ldp, long n, long 
     } while (0)
 #define GRAM_MODE(M) do { switch (dpad) { case 32: GRAM_LAUNCH(M, 8); break; case 48: GRAM_LAUNCH(M, 12); break;                  \
                                           case 64: GRAM_LAUNCH(M, 16); break; default: GRAM_LAUNCH(M, 0); } } while (0)
-    if (mode == MODE_FACTOR) GRAM_MODE(MODE_FACTOR); else GRAM_MODE(MODE_SYM);
+    // the restructured kernel: one chunk of coordinates, full tiles only, even leading dimension, ordinary stores (option "gram_fast")
+    const bool fast = cs.gram_fast && (dpad == 32 || dpad == 48 || dpad == 64) && !(ldo & 1) && !nt_ &&
+                      (mode == MODE_FACTOR || n % ST == 0);
+#define GRAM_FAST(M, NPV) do {                                                                                                    \
+        static std::atomic<int> attr_done{0};                                                                                      \
+        if (!attr_done.load(std::memory_order_acquire)) {                                                                          \
+            (void)hipFuncSetAttribute((const void*)cov_gram_fast_kernel<M, NPV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 70000); \
+            attr_done.store(1, std::memory_order_release);                                                                         \
+        }                                                                                                                          \
+        if (cs.gram_fast == 2 && (NPV) == 16)            /* two halves, four workgroups per CU: d = 64 (the smaller ones spill) */   \
+            hipLaunchKernelGGL((cov_gram_fast_kernel<M, NPV, ((NPV) == 16 ? 2 : 1)>), dim3(grid), dim3(256),                       \
+                               (size_t)ST * GSTP * sizeof(double), st, XT, ldp, n, cs.cp.sf2, inv_sn2, out, ldo, tiles, ntiles, prep, \
+                               prep + HADAMARD_PREP_MU);                                                                           \
+        else                                                                                                                       \
+        hipLaunchKernelGGL((cov_gram_fast_kernel<M, NPV, 1>), dim3(grid), dim3(256), shm, st, XT, ldp, n, cs.cp.sf2, inv_sn2, out, ldo, \
+                           tiles, ntiles, prep, prep + HADAMARD_PREP_MU);                                                          \
+    } while (0)
+#define GRAM_FAST_MODE(M) do { switch (dpad) { case 32: GRAM_FAST(M, 8); break; case 48: GRAM_FAST(M, 12); break;                 \
+                                               default: GRAM_FAST(M, 16); } } while (0)
+    if (fast) { if (mode == MODE_FACTOR) GRAM_FAST_MODE(MODE_FACTOR); else GRAM_FAST_MODE(MODE_SYM); }
+    else if (mode == MODE_FACTOR) GRAM_MODE(MODE_FACTOR); else GRAM_MODE(MODE_SYM);
+#undef GRAM_FAST_MODE
+#undef GRAM_FAST
 #undef GRAM_MODE
 #undef GRAM_LAUNCH
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;

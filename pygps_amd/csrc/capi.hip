@@ -208,6 +208,8 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { c->asm_grid = value; return PGP_OK; }
+    if (!strcmp(name, "gram_fast")) { if (value < 0 || value > 2) return -2; c->gram_fast = value; return PGP_OK; }
+    if (!strcmp(name, "gram_grid")) { if (value < 0) return -2; c->gram_grid = value; return PGP_OK; }
     if (!strcmp(name, "asm_nt")) { c->asm_nt = value; return PGP_OK; }
     if (!strcmp(name, "pair_launch")) { c->pair_launch = value != 0; return PGP_OK; }
     if (!strcmp(name, "gemm_trace")) {               // diagnostic: see ctx.h
@@ -315,7 +317,7 @@ static int make_leaf(int kind, const double* hyp, int nhyp, int para, int flags,
 // postfix program registered with pgp_set_composite, expanded here into a sum of products.
 int make_spec(pgp_ctx* c, int kind, const double* hyp, int nhyp, int para, int flags, int der, long d, CovSpec& cs) {
     cs = CovSpec{};
-    if (c) { cs.asm_grid = c->asm_grid; cs.asm_nt = c->asm_nt; }
+    if (c) { cs.asm_grid = c->asm_grid; cs.asm_nt = c->asm_nt; cs.gram_fast = c->gram_fast; cs.gram_grid = c->gram_grid; }
     if (!hyp && nhyp > 0) return -10;
     if (kind >= PGP_COV_GABOR && kind < PGP_COV_NKIND) {
         // trigonometric / index-dependent primitives run as one-leaf programs (see sqdist_tile.h cov_value<EXT>)
