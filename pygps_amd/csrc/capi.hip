@@ -1393,7 +1393,30 @@ int pgp_cov(pgp_ctx* c, int kind, int mode, int der, const double* x, int64_t n,
     }
     {
         ProfScope ps(c, PC_ASSEMBLE, 0.0, 8.0 * (double)n * mm + 8.0 * (double)(n + (mode == PGP_MODE_CROSS ? m : 0)) * d);
-        if (mode == PGP_MODE_TRAIN) CHK(cov_sym_launch(XrT, ldr, n, dpad, cp, od, st));
+        // getCovMatrix('train') of RBF / RBFard at d >= 32 and n >= 4096 (cfg 3's size): the Gram form on the matrix cores under the
+        // same host-side norm bound as the fit's assembly (gram_assembly_applies; K within ~5e-14 relative of the difference form --
+        // kernel-matrix parity is held to 1e-13); the statistics of THIS x are taken here on the host (n d operations)
+        bool gram = false;
+        if (mode == PGP_MODE_TRAIN && der < 0 && n >= 4096 && c->gram_assembly && cov_gram_applies(cp, dpad) && (long)sc.size() >= d) {
+            gram = c->gram_assembly == 2;
+            if (!gram) {
+                double bound = 0.0;
+                for (int64_t k = 0; k < d; ++k) {
+                    double mean = 0.0, dev = 0.0;
+                    for (int64_t p = 0; p < n; ++p) mean += x[p * d + k];
+                    mean /= (double)n;
+                    for (int64_t p = 0; p < n; ++p) dev = std::max(dev, fabs(x[p * d + k] - mean));
+                    bound += sc[k] * sc[k] * dev * dev;
+                }
+                gram = bound <= 64.0;
+            }
+        }
+        if (gram) {
+            double* prep = nullptr;
+            CHK(tmp.alloc(&prep, (size_t)hadamard_prep_count(ldr) * sizeof(double)));
+            CHK(hadamard_prepare_launch(XrT, ldr, n, ldr, dpad, cp, prep, st, /*force=*/true));
+            CHK(cov_sym_gram_launch(XrT, ldr, n, dpad, cp, od, n, prep, st));
+        } else if (mode == PGP_MODE_TRAIN) CHK(cov_sym_launch(XrT, ldr, n, dpad, cp, od, st));
         else CHK(cov_rect_launch(XrT, ldr, n, XcT, ldc, m, dpad, cp, od, m, st));
     }
     HIP_TRY(hipMemcpyAsync(out, od, (size_t)n * mm * sizeof(double), hipMemcpyDeviceToHost, st));

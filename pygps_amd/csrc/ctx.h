@@ -127,7 +127,7 @@ struct pgp_ctx {
     int solve_outer = 8;                // leaves per outer panel of the blocked multi-rhs triangular solve (K = 128 solve_outer)
     int predict_batch = 65536;          // test points per batch of pgp_predict (scratch: np x batch doubles, capped at 16 GiB -- predict_batch_points)
     int s_tile = 0;                     // tile size of the panel solves: 0 = automatic
-    int gram_fast = 2, gram_grid = 8192; // Gram-form assembly: restructured kernel on / off, persistent workgroups (CovSpec)
+    int gram_fast = 2, gram_grid = 32768; // Gram-form assembly: restructured kernel on / off, persistent workgroups (CovSpec)
     int asm_grid = 4096, asm_nt = 0;    // assembly kernels: persistent workgroups per launch; non-temporal stores (CovSpec::asm_grid / asm_nt)
     size_t Xs_bytes = 0;
     hipEvent_t ev[PGP_NSTAGE + 2];

@@ -446,7 +446,7 @@ struct CovSpec {
     int asm_grid = 4096;            // persistent workgroups (4 resident per CU, the rest queue: dynamic balance)
     int asm_nt = 0;                 // non-temporal stores: 0 never (default), 1 always, -1 for outputs >= 1 GB
     int gram_fast = 2;              // Gram-form assembly: 0 the general kernel, 1 the restructured one, 2 + its four-workgroups-per-CU form at d = 64
-    int gram_grid = 8192;           // Gram-form assembly: persistent workgroups per launch (option "gram_grid")
+    int gram_grid = 32768;          // Gram-form assembly: persistent workgroups per launch (option "gram_grid")
     double sf2() const { return cp.sf2; }
 };
 

@@ -246,3 +246,40 @@ def test_two_ep_fits_at_once_on_two_fit_streams(lib):
     for k in range(2):
         for nlZ, a in out[k]:
             assert nlZ == ref[0] and np.array_equal(a, ref[1])
+
+
+def test_getCovMatrix_train_at_cfg3_size_in_the_gram_form(lib):
+    """getCovMatrix('train') of RBFard at d = 64, n >= 4096 runs the Gram form on the matrix cores when the host's norm bound
+    allows it (round 5; Core/cov.py:887-904 is the difference form).  Kernel-matrix parity stays <= 1e-13: against the same call
+    with the Gram form forbidden, against the oracle's cdist form on a sample of rows; ragged n (general kernel) and n % 64 == 0
+    (restructured kernel); data beyond the bound keeps the difference form bit for bit."""
+    import pygps_amd as pyGPs
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    d = 64
+    for n in (4096, 4133):
+        x, _ = synth_reg(n, d)
+        k = pyGPs.cov.RBFard(log_ell_list=[float(np.log(np.sqrt(d)) + 0.01 * (i % 5)) for i in range(d)], log_sigma=0.2)
+        try:
+            _lib.check(lib.pgp_set_option(ctx, b"gram_assembly", 0))
+            K0 = k.getCovMatrix(x=x, mode="train")
+            _lib.check(lib.pgp_set_option(ctx, b"gram_assembly", 1))
+            K1 = k.getCovMatrix(x=x, mode="train")
+            _lib.check(lib.pgp_set_option(ctx, b"gram_assembly", 2))
+            K2 = k.getCovMatrix(x=x, mode="train")
+        finally:
+            lib.pgp_set_option(ctx, b"gram_assembly", 1)
+        assert np.array_equal(K1, K2) and not np.array_equal(K1, K0)              # the bound let the Gram form through
+        assert np.max(np.abs(K1 - K0) / K0) < 1e-13 and np.array_equal(K1, K1.T) and np.all(np.diag(K1) == np.exp(0.4))
+        rows = np.arange(0, n, 397)
+        ref = O.cov_matrix(O.RBFARD, np.array(k.hyp), 0, x=x[rows], z=x, mode="cross")
+        assert np.max(np.abs(K1[rows] - ref) / ref) < 1e-13
+        xb = x.copy()
+        xb[::2, 0] += 5.0e3                                                        # a second cluster far beyond the bound
+        K3 = k.getCovMatrix(x=xb, mode="train")
+        try:
+            _lib.check(lib.pgp_set_option(ctx, b"gram_assembly", 0))
+            K4 = k.getCovMatrix(x=xb, mode="train")
+        finally:
+            lib.pgp_set_option(ctx, b"gram_assembly", 1)
+        assert np.array_equal(K3, K4)
