@@ -144,3 +144,17 @@ def test_sharded_k_fold_bookkeeping_without_torch(tmp_path, world, K):
         assert np.allclose(z["nlZ"], want_nlZ, rtol=1e-14) and np.allclose(z["RMSE"], want_rmse, rtol=1e-14)
         assert np.allclose(z["NLPD"], want_nlpd, rtol=1e-14)
         assert np.array_equal(z["owner"], rs[0]["owner"]) and set(z["owner"].tolist()) <= set(range(world))
+
+
+def test_multi_dataset_objective_sharded_without_torch(tmp_path):
+    """Demo/Clustering/pyGP_extension.py:27-76 sharded: data set i on rank i % world, ONE all-reduce of 1 + nhyp + D doubles."""
+    rs = launch(2, "multi_fake", tmp_path)
+    rng = np.random.RandomState(4)
+    xs = [rng.randn(5 + i, 2) for i in range(5)]
+    ys = [rng.randn(5 + i, 1) for i in range(5)]
+    each = np.array([np.sum(y ** 2) * 1.3 for y in ys])
+    g = np.array([sum(np.sum(y) for y in ys), sum(np.sum(x) for x in xs), each.sum(), 5.0])
+    for z in rs:
+        assert np.allclose(z["each"], each, rtol=1e-14) and abs(float(z["tot"]) - each.sum()) < 1e-12 * each.sum()
+        assert np.allclose(z["g"], g, rtol=1e-13)
+    assert sorted(int(z["calls"]) for z in rs) == [2, 3]                          # 5 data sets over 2 ranks

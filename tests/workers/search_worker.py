@@ -88,6 +88,38 @@ def kfold_fake(out, K):
     np.savez(os.path.join(out, "r%d.npz" % rank), **res)
 
 
+def multi_fake(out):
+    """opt.multi_dataset_objective with a numpy stand-in model: data set i on rank i % world, one all-reduce"""
+    from pygps_amd import opt, inf
+
+    class H(object):
+        def __init__(self, hyp):
+            self.hyp = list(hyp)
+
+    class M(object):
+        def __init__(self):
+            self.meanfunc, self.covfunc, self.likfunc = H([0.5]), H([0.1, 0.2]), H([-1.0])
+            self.calls = 0
+
+        def setData(self, x, y):
+            self.x, self.y = x, y
+
+        def getPosterior(self, der=True):
+            self.calls += 1
+            nlZ = float(np.sum(self.y ** 2) * (1 + self.covfunc.hyp[0]))
+            if not der:
+                return nlZ, None
+            d = inf.dnlZStruct(self.meanfunc, self.covfunc, self.likfunc)
+            d.mean = [np.float64(np.sum(self.y))]; d.cov = [np.float64(np.sum(self.x)), np.float64(nlZ)]; d.lik = [np.float64(1.0)]
+            return nlZ, d, None
+    rng = np.random.RandomState(4)
+    xs = [rng.randn(5 + i, 2) for i in range(5)]
+    ys = [rng.randn(5 + i, 1) for i in range(5)]
+    m = M()
+    tot, dn, each = opt.multi_dataset_objective(np.array([0.3, 0.2]), m, xs, ys, der=True)
+    np.savez(os.path.join(out, "r%d.npz" % int(os.environ["RANK"])), tot=tot, g=np.array(dn.mean + dn.cov + dn.lik), each=each, calls=m.calls)
+
+
 def g9_search(out, N, streams):
     """cfg 4 on the device without torch: G9 data, 8 restarts; rank 0 alone holds the data and the RNG state"""
     import pygps_amd as pyGPs
@@ -135,7 +167,7 @@ if __name__ == "__main__":
     case, out = sys.argv[1], sys.argv[2]
     args = [json.loads(a) for a in sys.argv[3:]]
     {"fake_search": fake_search, "group_ops": group_ops, "comm_ops": comm_ops, "kfold_fake": kfold_fake, "g9_search": g9_search,
-     "kfold_gpu": kfold_gpu}[case](out, *args)
+     "kfold_gpu": kfold_gpu, "multi_fake": multi_fake}[case](out, *args)
     if os.environ.get("PYGPS_AMD_NO_TORCH"):
         assert "torch" not in sys.modules, "torch was imported in a PYGPS_AMD_NO_TORCH process"
     print("worker ok", flush=True)
