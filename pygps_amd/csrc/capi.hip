@@ -1187,7 +1187,10 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     HIP_TRY(hipSetDevice(c->device));
     c->dense_ready = false;                          // the workspace (B^-1, alpha) is about to be rewritten
     const long n = c->n, d = c->d, np = c->np;
-    const bool fused = want >= 3 && c->fused_inverse;
+    // value-only fits (want < 3) take the fused-inverse sweep too (round 5): alpha = E z / sn2 is one matvec, whereas the blocked
+    // back-substitution without E is a chain of np / 128 dependent steps (3.3 ms at N = 8192: an nlZ-only fit cost as much as one
+    // with all gradients).  They skip E E' and the gradient pass.
+    const bool fused = c->fused_inverse != 0;
     const long ldf = c->ldf;                         // factor buffer = factor rows + rhs rows; the inverse rows are scratch
     CovSpec cp;
     { const int rc = make_spec(c, kind, covhyp, ncov, para, flags, -1, d, cp); if (rc != PGP_OK) return rc == -11 ? -10 : rc; }
@@ -1196,7 +1199,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     double kss = 0.0;
     if (factor_out) CHK(cov_point_value(c, cp, 2, &kss));
     const long need = std::max(hadamard_partial_count(np, ncov), 32L * np);       // also the partials of upper_matvec
-    if (want >= 3 && c->partial_cap < need) {
+    if ((want >= 3 || fused) && c->partial_cap < need) {
         if (c->partial) (void)hipFree(c->partial);
         c->partial = nullptr; c->partial_cap = 0;      // a failed realloc must not leave a dangling pointer behind
         HIP_TRY(hipMalloc((void**)&c->partial, need * sizeof(double)));
@@ -1230,7 +1233,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     CHK(aug_rhs_launch(c->y_dev, c->m_dev, n, F, ldf, np, c->rvec, st));
     // ---- S2: Cholesky (forward substitution of the augmented row -- and L^-T -- ride along) ----------
     HIP_TRY(hipEventRecord(c->ev[1], st));
-    if (fused) { c->eet_out = c->Binv; c->eet_ld = np; }
+    if (fused && want >= 3) { c->eet_out = c->Binv; c->eet_ld = np; }
     c->eet_join = nullptr;
     const int prc = potrf_blocked(c, F, ldf, np, np + 128, fused, E, lde);
     c->eet_out = nullptr;
@@ -1279,7 +1282,7 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     double* alpha_h = c->res_host + RES_HEAD;
     int info = 0;
     memcpy(&info, c->res_host + RES_INFO, sizeof(int));
-    if (want < 3) for (long j = 0; j < n; ++j) alpha_h[j] /= sn2;   // the back-substitution produced L^-T z
+    if (want < 3 && !fused) for (long j = 0; j < n; ++j) alpha_h[j] /= sn2;   // the back-substitution produced L^-T z
     {
         float ms;
         const int map[6][2] = {{0, 1}, {1, 2}, {3, 4}, {2, 3}, {4, 5}, {5, 6}};   // assemble, potrf, solve, trtri, lauum, grad
