@@ -1054,7 +1054,15 @@ static int ep_factor_only(pgp_ctx* c, EpWork& w, const std::vector<double>& ttau
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
     hipLaunchKernelGGL(ep_build_kernel, dim3((unsigned)((np + 255) / 256), (unsigned)std::min<long>(np, 65535)), dim3(256), 0, st, w.Kd, np, w.s_d, w.F, w.ldf,
                        (double*)nullptr, 0);
-    CHK(potrf_blocked(c, w.F, w.ldf, np, np));
+    {
+        // a plain factorisation (no inverse rows, no E E' to fill the main stream) is bound by the chain of diagonal blocks: 1024-wide
+        // panels halve the number of panel steps (cfg 5, N = 4096: 17.8 -> 17.4 ms per fit); an explicit nb_outer option wins
+        const int keep = c->nb_outer;
+        if (keep == 0 && np >= 2048) c->nb_outer = 8;
+        const int prc = potrf_blocked(c, w.F, w.ldf, np, np);
+        c->nb_outer = keep;
+        CHK(prc);
+    }
     int info = 0;
     HIP_TRY(hipMemcpyAsync(&info, c->info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));               // (s_h goes out of scope)
