@@ -45,6 +45,10 @@ DeviceGate& device_gate(int device) {
     static DeviceGate gates[64];
     return gates[(unsigned)device % 64u];
 }
+int& device_gate_depth(int device) {
+    static thread_local int depth[64] = {0};
+    return depth[(unsigned)device % 64u];
+}
 
 extern "C" {
 

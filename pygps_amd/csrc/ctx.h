@@ -355,13 +355,17 @@ struct DeviceGate {
     void unlock() { std::lock_guard<std::mutex> l(m); writer = false; cv.notify_all(); }
 };
 DeviceGate& device_gate(int device);
+int& device_gate_depth(int device);      // per thread and device: entry points may nest (a host-transport call-back that runs a Python
+                                         // finalizer -> pgp_factor_free inside pgp_sharded_exact_fit): the inner hold is a no-op
 struct GateShared {                     // RAII: shared for a whole entry point; exclusive() / shared_again() around an EP sweep
-    DeviceGate& g; int state = 1;       // 1 shared, 2 exclusive, 0 none
-    explicit GateShared(pgp_ctx* c) : g(device_gate(c ? c->device : 0)) { g.lock_shared(); }
-    explicit GateShared(int device) : g(device_gate(device)) { g.lock_shared(); }
+    DeviceGate& g; int& depth; int state = 1;       // 1 shared, 2 exclusive, 0 nested (the outer hold covers it)
+    explicit GateShared(pgp_ctx* c) : GateShared(c ? c->device : 0) {}
+    explicit GateShared(int device) : g(device_gate(device)), depth(device_gate_depth(device)) {
+        if (depth++ > 0) state = 0; else g.lock_shared();
+    }
     void exclusive() { if (state == 1) { g.unlock_shared(); g.lock(); state = 2; } }
     void shared_again() { if (state == 2) { g.unlock(); g.lock_shared(); state = 1; } }
-    ~GateShared() { if (state == 1) g.unlock_shared(); else if (state == 2) g.unlock(); }
+    ~GateShared() { --depth; if (state == 1) g.unlock_shared(); else if (state == 2) g.unlock(); }
     GateShared(const GateShared&) = delete;
     GateShared& operator=(const GateShared&) = delete;
 };
