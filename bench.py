@@ -693,6 +693,12 @@ def main():
         for o in args.option:
             k_, v_ = o.split("=")
             _lib.check(lib.pgp_set_option(h, k_.encode(), int(v_)), "pgp_set_option")
+    # several fit streams side by side: the schedule ShardedMinimize / sharded_k_fold select for their fit streams
+    # (pygps_amd._lib.concurrent_fit_streams: option sched = 1, bit-identical results; an explicit --option sched=... wins)
+    sched_multi = S >= 2 and "sched" not in dict(o.split("=") for o in args.option)
+    if sched_multi:
+        for h in ctxs:
+            _lib.check(lib.pgp_set_option(h, b"sched", 1), "pgp_set_option")
     eet_default = int(dict(o.split("=") for o in args.option).get("eet_overlap", 3))
     bufs = [(np.empty(N), np.zeros(1), np.zeros(4)) for _ in range(S)]
 
@@ -749,7 +755,9 @@ def main():
         parts_r = [torch.empty_like(rr) for _ in range(world)]
         dist.all_gather(parts_r, rr)
         rank_rates = [float(p_.item()) for p_ in parts_r]
-    # single-stream latency of one fit in a dependent chain (what cfg 4's one-restart-per-GPU minimize.run sees)
+    # single-stream latency of one fit in a dependent chain (what cfg 4's one-restart-per-GPU minimize.run sees): the lone-chain schedule
+    if sched_multi:
+        lib.pgp_set_option(ctxs[0], b"sched", 0)
     t1 = time.perf_counter()
     lat_stage = []
     for s in range(6):
@@ -900,7 +908,7 @@ def main():
             "config": {"workload": "GPR+RBF, N=%d d=%d fp64 synthetic (SURVEY 8d recipe, seed 0), infExact nlZ + dnlZ "
                                    "(BASELINE configs[1]); x,y resident in HBM, hyp changes every step; outputs "
                                    "nlZ, dnlZ(4), alpha(N) to host per step" % (N, d),
-                       "fits_per_rank": args.steps, "fit_streams_per_gpu": S,
+                       "fits_per_rank": args.steps, "fit_streams_per_gpu": S, "sched": 1 if sched_multi else 0,
                        "parallelism": "independent fits (restart evaluations) per GPU, %d concurrent fit streams per "
                                       "GPU; RCCL broadcast + all-reduce(max) + all-gather only%s"
                                       % (S, "" if dist else " (no process group at world size 1)")},

@@ -235,6 +235,22 @@ class fit_stream(object):
         return False
 
 
+class concurrent_fit_streams(object):
+    """`with concurrent_fit_streams(): ...` inside `fit_stream(k)` when SEVERAL fit streams of one GPU run at the same time: the
+    context's Cholesky sweep then keeps its critical path (D -> S -> TU_a) on the panel stream beside the bulk updates (option
+    `sched` = 1; bit-identical results).  Measured, alternated in one process (profiles/r05_sched_ab_and_leaf_ticks.txt and three
+    more boxes): two fit streams +0.6 ... +2 % fits/s, a lone chain -3 % -- hence only while streams run side by side."""
+
+    def __enter__(self):
+        self.h = ctx()
+        load().pgp_set_option(self.h, b"sched", 1)
+        return self
+
+    def __exit__(self, *exc):
+        load().pgp_set_option(self.h, b"sched", 0)
+        return False
+
+
 def ctx(device=None, slot=None):
     """Context (one device + its HIP streams + one workspace pool) of (device, fit-stream slot); created on first use."""
     if device is None:

@@ -225,7 +225,7 @@ class ShardedMinimize(Minimize):
         from . import _lib
 
         def work(k):
-            with _lib.fit_stream(k):
+            with _lib.fit_stream(k), _lib.concurrent_fit_streams():
                 clone = Minimize(_dc(self.model), None)
                 clone.model.optimizer = clone
                 clone.logger = self.logger

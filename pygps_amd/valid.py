@@ -161,8 +161,9 @@ def sharded_k_fold(model, x, y, K=10, metrics=("RMSE", "NLPD"), numIterations=0,
                 return todo.pop(0) if todo else None
     errors = []
 
-    def work(slot):
-        with _lib.fit_stream(slot):
+    def work(slot, side_by_side=False):
+        import contextlib
+        with _lib.fit_stream(slot), (_lib.concurrent_fit_streams() if side_by_side else contextlib.nullcontext()):
             while True:
                 k = take()
                 if k is None:
@@ -176,7 +177,7 @@ def sharded_k_fold(model, x, y, K=10, metrics=("RMSE", "NLPD"), numIterations=0,
     if S == 1:
         work(_lib.current_slot())
     else:
-        ths = [threading.Thread(target=work, args=(s,)) for s in range(S)]
+        ths = [threading.Thread(target=work, args=(s, True)) for s in range(S)]
         [t.start() for t in ths]
         [t.join() for t in ths]
     full = comm.allgather(rec)                        # ONE all-gather: K x (2 + #metrics) doubles per rank
