@@ -355,6 +355,11 @@ def g9(N=512, iters=40, tag=""):
         if out is not None:
             rec.update(ok=True, Xopt=np.array(out[0], dtype=float), f=float(out[1][-1]), nls=int(out[2]),
                        nfx=len(out[1]))
+        if tag:                                      # a long run (N = 8192: ~20 min per restart here): keep what is done so far
+            done = [r for r in runs if "nls" in r or r is not rec]
+            np.savez_compressed(os.path.join(HERE, "G9_restarts_N%d%s.partial.npz" % (N, tag)),
+                                run_X0=np.stack([r["X0"] for r in done]), run_ok=np.array([r["ok"] for r in done]),
+                                run_f=np.array([r.get("f", np.nan) for r in done]), run_nls=np.array([r.get("nls", -1) for r in done]))
         return out
     ref_opt.minimize.run = spy
     np.random.seed(123)
