@@ -380,6 +380,16 @@ def g9(N=512, iters=40, tag=""):
          best_hyp=final, best_nlZ=m.nlZ)
 
 
+def g9_from_partial(N=8192, iters=3, tag="_3ls"):
+    """The restarts a g9(N, iters, tag) run had finished when it was stopped (its *.partial.npz, written after every restart)
+    as a fixture of the FIRST n_runs restarts: restart order and the RNG stream are deterministic, so a prefix is a valid
+    fixture (the test compares the start table rows, failures, objectives and line-search counts of that prefix)."""
+    z = np.load(os.path.join(HERE, "G9_restarts_N%d%s.partial.npz" % (N, tag)))
+    k = len(z["run_f"])
+    save("G9_restarts_N%d%s" % (N, tag), N=N, d=16, seed=0, np_seed=123, num_restarts=8, numIterations=iters, n_runs=k,
+         complete=False, run_X0=z["run_X0"], run_ok=z["run_ok"], run_f=z["run_f"], run_nls=z["run_nls"])
+
+
 # ----------------------------------------------------------------------------- minimize.py trajectories
 def rosen(v):
     """Pure-numpy objective (value, gradient); also defined in tests/test_host_logic.py."""
@@ -732,7 +742,7 @@ CASES = {
     "g6_2048": lambda: g6(2048), "g6_4096": lambda: g6(4096), "g6_8192": lambda: g6(8192),
     "g8ii_2048": lambda: g8ii(2048), "g8ii_4096": lambda: g8ii(4096), "g9_2048": lambda: g9(2048),
     "g7_1024": lambda: g7(1024), "g7_2048": lambda: g7(2048), "g7_4096": lambda: g7(4096), "g7_16384": lambda: g7(16384), "g18": g18,
-    "g19": g19, "g9_8192_3ls": lambda: g9(8192, iters=3, tag="_3ls"),
+    "g19": g19, "g9_8192_3ls": lambda: g9(8192, iters=3, tag="_3ls"), "g9_8192_3ls_from_partial": g9_from_partial,
 }
 
 if __name__ == "__main__":
