@@ -242,12 +242,23 @@ class concurrent_fit_streams(object):
     more boxes): two fit streams +0.6 ... +2 % fits/s, a lone chain -3 % -- hence only while streams run side by side."""
 
     def __enter__(self):
-        self.h = ctx()
-        load().pgp_set_option(self.h, b"sched", 1)
+        # nothing touches the device here: the option is set on the contexts the thread actually uses inside the scope (`ctx`),
+        # so host-only callers (a model without device work, the CPU tests of the restart bookkeeping) need no GPU
+        self.prev = getattr(_tls, "concurrent", None)
+        self.used = {}
+        _tls.concurrent = self
         return self
 
+    def _use(self, key, h):
+        if key not in self.used:
+            load().pgp_set_option(h, b"sched", 1)
+            self.used[key] = h
+
     def __exit__(self, *exc):
-        load().pgp_set_option(self.h, b"sched", 0)
+        _tls.concurrent = self.prev
+        for h in self.used.values():
+            load().pgp_set_option(h, b"sched", 0)
+        self.used = {}
         return False
 
 
@@ -258,7 +269,10 @@ def ctx(device=None, slot=None):
     if slot is None:
         slot = current_slot()
     h = _ctx.get((device, slot))            # lock-free fast path (dict reads are atomic under the GIL)
+    scope = getattr(_tls, "concurrent", None)
     if h is not None:
+        if scope is not None:
+            scope._use((device, slot), h)
         return h
     dll = load()
     with _lock:
@@ -271,6 +285,8 @@ def ctx(device=None, slot=None):
                                    % (device, dll.pgp_strerror(rc).decode()))
             h = out
             _ctx[(device, slot)] = h
+    if scope is not None:
+        scope._use((device, slot), h)
     return h
 
 

@@ -188,6 +188,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "gemm_dbg")) { if (value & ~(64 | 256 | 512)) return -2; c->gemm_dbg = value; return PGP_OK; }
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     if (!strcmp(name, "leaf_first")) { c->leaf_first = value; return PGP_OK; }
+    if (!strcmp(name, "leaf_pivot")) { if (value < 0 || value > 1) return -2; c->leaf_pivot = value; return PGP_OK; }
     if (!strcmp(name, "sched")) { if (value < 0 || value > 1) return -2; c->sched = value; return PGP_OK; }
     if (!strcmp(name, "gram_assembly")) { if (value < 0 || value > 2) return -2; c->gram_assembly = value; return PGP_OK; }
     if (!strcmp(name, "yield")) { c->yield = value; return PGP_OK; }
@@ -653,7 +654,7 @@ static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s
         double* pack = packs + (long)cb * PACK_DOUBLES;
         {
             ProfScope ps(c, PC_LEAF, 128.0 * 128.0 * 128.0 / 3.0, 0.0, st);
-            CHK(leaf_potrf_launch(Acc, ld, pack, c->info_dev, info_base + cb * 128, st, nullptr, yfl));
+            CHK(leaf_potrf_launch(Acc, ld, pack, c->info_dev, info_base + cb * 128, st, nullptr, yfl, c->leaf_pivot));
         }
         CHK(stepped());
         const long rows_below = re(cb + 1) - (long)(cb + 1) * 128;

@@ -59,6 +59,7 @@ struct pgp_ctx {
     int lookahead = 1;
     int sched = 0;                      // option "sched": 1 = the critical path D -> S -> TU_a on the panel stream, the bulk updates on the main
                                         // stream (potrf_blocked_v2); 0 = round 2-4: S, TU_a, TU_b on the main stream, only D on the panel stream
+    int leaf_pivot = 1;                 // 1: the 16 x 16 pivot blocks of a leaf on the matrix cores (panel.hip pivot_block_mfma); 0: lane per row
     int leaf_first = 0;                 // 1: TU_b(p) is launched only after D(p+1)'s stage-in kernel, so that the first leaf is
                                         // dispatched BEFORE the update's first wave takes every workgroup slot (a leaf dispatched
                                         // into that wave waited ~140 us for it): 12.08 -> 11.72 ms per N = 8192 fit, two fit

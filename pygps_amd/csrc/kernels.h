@@ -8,7 +8,7 @@ struct CovSpec;
 // panel.hip
 constexpr long PACK_DOUBLES = 36 * 256;   // per-leaf packed operand image: 28 strictly-lower L blocks + 8 inverted pivot blocks
 int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st,
-                      long long* tick = nullptr, unsigned* yield_flags = nullptr);
+                      long long* tick = nullptr, unsigned* yield_flags = nullptr, int pivot = 1);
 int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl, const double* inv16,
                      hipStream_t st, unsigned* yield_flags = nullptr);
 int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, long wstride, int nblocks, hipStream_t st);

@@ -162,6 +162,97 @@ __device__ __forceinline__ void pivot_block(double* __restrict__ s, double* __re
     if (lane == 0 && inf != 0 && *s_info == 0) *s_info = tb * 16 + inf;
 }
 
+// The same pivot block on the matrix cores (round 5).  The lane-per-row version above is bound by the issue rate of ONE
+// wave's 240 v_fmac_f64_dpp + 250 other fp64 instructions; this one needs 18 MFMAs and ~400 fp64 instructions.
+// V[q](lane) = M(row l15, col 4q + l4) is the block in the f64 16x16x4 accumulator layout (valid lower triangle; the
+// updates are symmetric, the upper triangle is never read).  Per panel t of 4 columns:
+//   * the 4x4 diagonal block comes out of reg t by v_readlane (10 values), its factor L_tt and inverse W_tt are computed
+//     redundantly by every lane (uniform values);
+//   * the UNSCALED panel Praw[r][k] = M(r, 4t + k) is reg t AS IT STANDS in the B-operand layout (lane (l15, l4) holds
+//     row l15, panel column l4), so P = Praw W_tt^T is ONE mfma with A = W_tt repeated down the 16 rows -- and its
+//     output lands in the A-operand layout P[l15][l4];
+//   * the rank-4 update of all 16 columns is ONE mfma with A = -P, B = P (the same register).
+// The inverse rides along as the rows of an appended identity (like the 2w x w scratch of the outer sweep): U holds
+// G^T (G -> L^-T) in the same layout, two more MFMAs per panel; four MFMAs against identity slices turn it into the
+// [k][j] image of W = L^-1 that leaf_tile_trsm / trsm_rows_kernel read.
+__device__ __forceinline__ void pivot_block_mfma(double* __restrict__ s, double* __restrict__ sinv, int* s_info, int tb,
+                                                 int lane, double* __restrict__ ginv) {
+    const int l15 = lane & 15, l4 = lane >> 4, m4 = l15 & 3, g4 = l15 >> 2;
+    double* blk = s + lblk(tb, tb) * 256;
+    double4_t V, U;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        V[q] = blk[q * 64 + lane];
+        U[q] = (l15 == 4 * q + l4) ? 1.0 : 0.0;
+    }
+    const bool r0m = m4 == 0, r1m = m4 == 1, r2m = m4 == 2;
+    const bool c0m = l4 == 0, c1m = l4 == 1, c2m = l4 == 2;
+    int inf = 0;
+    const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        // M(4t + a, 4t + b), a >= b: reg t of lane 16 b + 4t + a
+        const double s00 = readlane_f64(V[t], 4 * t + 0), s10 = readlane_f64(V[t], 4 * t + 1);
+        const double s20 = readlane_f64(V[t], 4 * t + 2), s30 = readlane_f64(V[t], 4 * t + 3);
+        const double s11 = readlane_f64(V[t], 16 + 4 * t + 1), s21 = readlane_f64(V[t], 16 + 4 * t + 2);
+        const double s31 = readlane_f64(V[t], 16 + 4 * t + 3);
+        const double s22 = readlane_f64(V[t], 32 + 4 * t + 2), s32 = readlane_f64(V[t], 32 + 4 * t + 3);
+        const double s33 = readlane_f64(V[t], 48 + 4 * t + 3);
+        double rr0, rr1, rr2, rr3, l00, l11, l22, l33;
+        if (!(s00 > 0.0) && inf == 0) inf = 4 * t + 1;
+        rsqrt_sqrt(s00, rr0, l00);
+        const double l10 = s10 * rr0, l20 = s20 * rr0, l30 = s30 * rr0;
+        const double d1 = fma(-l10, l10, s11);
+        if (!(d1 > 0.0) && inf == 0) inf = 4 * t + 2;
+        rsqrt_sqrt(d1, rr1, l11);
+        const double l21 = fma(-l20, l10, s21) * rr1, l31 = fma(-l30, l10, s31) * rr1;
+        const double d2 = fma(-l21, l21, fma(-l20, l20, s22));
+        if (!(d2 > 0.0) && inf == 0) inf = 4 * t + 3;
+        rsqrt_sqrt(d2, rr2, l22);
+        const double l32 = fma(-l31, l21, fma(-l30, l20, s32)) * rr2;
+        const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
+        if (!(d3 > 0.0) && inf == 0) inf = 4 * t + 4;
+        rsqrt_sqrt(d3, rr3, l33);
+        // W_tt = L_tt^-1
+        const double w10 = -(l10 * rr0) * rr1, w21 = -(l21 * rr1) * rr2, w32 = -(l32 * rr2) * rr3;
+        const double w20 = -fma(l21, w10, l20 * rr0) * rr2;
+        const double w31 = -fma(l32, w21, l31 * rr1) * rr3;
+        const double w30 = -fma(l32, w20, fma(l31, w10, l30 * rr0)) * rr3;
+        // A operand of the scaling products: W_tt[l15 & 3][l4] (repeated down the rows: every output register is a copy)
+        const double wc0 = r0m ? rr0 : (r1m ? w10 : (r2m ? w20 : w30));
+        const double wc1 = r0m ? 0.0 : (r1m ? rr1 : (r2m ? w21 : w31));
+        const double wc2 = r2m ? rr2 : ((m4 == 3) ? w32 : 0.0);
+        const double wc3 = (m4 == 3) ? rr3 : 0.0;
+        const double wrep = c0m ? wc0 : (c1m ? wc1 : (c2m ? wc2 : wc3));
+        const double4_t op = __builtin_amdgcn_mfma_f64_16x16x4f64(wrep, V[t], zero4, 0, 0, 0);   // P[l15][l4]
+        const double4_t og = __builtin_amdgcn_mfma_f64_16x16x4f64(wrep, U[t], zero4, 0, 0, 0);   // (G W_tt^T)[l15][l4]
+        U[t] = og[0];
+        // rows of the diagonal block: the factor's own entries (diagonal from the uniform values, exact zeros above)
+        const double ldiag = r0m ? l00 : (r1m ? l11 : (r2m ? l22 : l33));
+        const double lrow = (l4 < m4) ? op[0] : ((l4 == m4) ? ldiag : 0.0);
+        const bool below = g4 > t;
+        const double pupd = below ? op[0] : 0.0;
+        blk[64 * t + lane] = below ? op[0] : ((g4 == t) ? lrow : 0.0);          // column 4t + l4, row l15
+        if (t < 3) {
+            V = __builtin_amdgcn_mfma_f64_16x16x4f64(-pupd, pupd, V, 0, 0, 0);
+            U = __builtin_amdgcn_mfma_f64_16x16x4f64(-pupd, og[0], U, 0, 0, 0);
+        }
+    }
+    // U[q](l15, l4) = G[l15][4q + l4] = W[4q + l4][l15]  ->  [k][j] image of W: Wo[q](l15, l4) = W(row l15, col 4q + l4)
+    double4_t Wo = zero4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const double ik = (l15 == 4 * ks + l4) ? 1.0 : 0.0;
+        Wo = __builtin_amdgcn_mfma_f64_16x16x4f64(U[ks], ik, Wo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sinv[q * 64 + lane] = Wo[q];
+        ginv[q * 64 + lane] = Wo[q];
+    }
+    if (lane == 0 && inf != 0 && *s_info == 0) *s_info = tb * 16 + inf;
+}
+
 // C(bi,bj) -= P(bi) P(bj)^T with P = column block tb (one 16x16 tile, 4 MFMAs, two accumulation chains)
 __device__ __forceinline__ void leaf_tile_update(double* __restrict__ s, int tb, int bi, int bj, int lane) {
     double* cblk = s + lblk(bi, bj) * 256;
@@ -218,6 +309,7 @@ __device__ __forceinline__ void leaf_piece(int t, int i, int& blk, int& bi, int&
     }
 }
 
+template <bool MP>     // MP: the pivot blocks on the matrix cores (pivot_block_mfma)
 __device__ __forceinline__ void leaf_potrf_body(double* __restrict__ A, long lda, double* __restrict__ pack,
                                                 int* __restrict__ info, int info_base, long long* __restrict__ tick,
                                                 double* __restrict__ s /* LDS: 36 blocks | sinv[256] | info */) {
@@ -241,7 +333,10 @@ __device__ __forceinline__ void leaf_potrf_body(double* __restrict__ A, long lda
     }
     __syncthreads();
     TICK(1);
-    if (wave == 0) pivot_block(s, sinv, s_info, 0, lane, pack + 28 * 256);
+    if (wave == 0) {
+        if (MP) pivot_block_mfma(s, sinv, s_info, 0, lane, pack + 28 * 256);
+        else pivot_block(s, sinv, s_info, 0, lane, pack + 28 * 256);
+    }
     __syncthreads();
     TICK(2);
 
@@ -256,7 +351,8 @@ __device__ __forceinline__ void leaf_potrf_body(double* __restrict__ A, long lda
         if (nt > 0) {
             if (wave == 0) {
                 leaf_tile_update(s, tb, tb + 1, tb + 1, lane);
-                pivot_block(s, sinv, s_info, tb + 1, lane, pack + (28 + tb + 1) * 256);
+                if (MP) pivot_block_mfma(s, sinv, s_info, tb + 1, lane, pack + (28 + tb + 1) * 256);
+                else pivot_block(s, sinv, s_info, tb + 1, lane, pack + (28 + tb + 1) * 256);
             } else {
                 const int ntile = nt * (nt + 1) / 2;
                 for (int tile = wave; tile < ntile; tile += 3) {      // tile 0 = (0,0) is wave 0's
@@ -296,12 +392,13 @@ __device__ __forceinline__ void leaf_potrf_body(double* __restrict__ A, long lda
 #undef TICK
 }
 
+template <bool MP>
 __global__ __launch_bounds__(256, 2) void leaf_potrf_kernel(double* __restrict__ A, long lda,
                                                             double* __restrict__ pack, int* __restrict__ info,
                                                             int info_base, long long* __restrict__ tick, unsigned* yield_flags) {
     extern __shared__ __attribute__((aligned(16))) double s[];
     pgp_yield_mark(yield_flags, +1);                 // the bulk workgroups on this CU give way while the leaf runs (gemm_tile.h)
-    leaf_potrf_body(A, lda, pack, info, info_base, tick, s);
+    leaf_potrf_body<MP>(A, lda, pack, info, info_base, tick, s);
     __syncthreads();
     pgp_yield_mark(yield_flags, -1);
 }
@@ -403,15 +500,20 @@ __global__ __launch_bounds__(128, 1) void leaf_inv_kernel(const double* __restri
 
 }  // namespace
 
+// pivot: 1 = the pivot blocks on the matrix cores (pivot_block_mfma), 0 = lane per row (context option `leaf_pivot`)
 int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st,
-                      long long* tick, unsigned* yield_flags) {
+                      long long* tick, unsigned* yield_flags, int pivot) {
     const size_t shm = (36 * 256 + 256 + 2) * sizeof(double);
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute((const void*)leaf_potrf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute((const void*)leaf_potrf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute((const void*)leaf_potrf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(leaf_potrf_kernel, dim3(1), dim3(256), shm, st, A, lda, inv16, info, info_base, tick, yield_flags);
+    if (pivot)
+        hipLaunchKernelGGL(leaf_potrf_kernel<true>, dim3(1), dim3(256), shm, st, A, lda, inv16, info, info_base, tick, yield_flags);
+    else
+        hipLaunchKernelGGL(leaf_potrf_kernel<false>, dim3(1), dim3(256), shm, st, A, lda, inv16, info, info_base, tick, yield_flags);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 

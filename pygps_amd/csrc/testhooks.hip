@@ -167,7 +167,7 @@ int pgp_test_leaf_ticks(pgp_ctx* c, double* ticks_out) {
     HIP_TRY(hipMemset(info, 0, 4)); HIP_TRY(hipMemset(tk, 0, 24 * 8));
     for (int rep = 0; rep < 3; ++rep) {
         HIP_TRY(hipMemcpy(Ad, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-        int rc = leaf_potrf_launch(Ad, 128, pk, info, 0, c->st, tk);
+        int rc = leaf_potrf_launch(Ad, 128, pk, info, 0, c->st, tk, nullptr, c->leaf_pivot);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(c->st));
     }
