@@ -757,7 +757,7 @@ def main():
         rank_rates = [float(p_.item()) for p_ in parts_r]
     # single-stream latency of one fit in a dependent chain (what cfg 4's one-restart-per-GPU minimize.run sees): the lone-chain schedule
     if sched_multi:
-        lib.pgp_set_option(ctxs[0], b"sched", 0)
+        lib.pgp_set_option(ctxs[0], b"sched", -1)          # the library's default for a lone chain (sched 2 since round 5)
     t1 = time.perf_counter()
     lat_stage = []
     for s in range(6):
@@ -908,7 +908,7 @@ def main():
             "config": {"workload": "GPR+RBF, N=%d d=%d fp64 synthetic (SURVEY 8d recipe, seed 0), infExact nlZ + dnlZ "
                                    "(BASELINE configs[1]); x,y resident in HBM, hyp changes every step; outputs "
                                    "nlZ, dnlZ(4), alpha(N) to host per step" % (N, d),
-                       "fits_per_rank": args.steps, "fit_streams_per_gpu": S, "sched": 1 if sched_multi else 0,
+                       "fits_per_rank": args.steps, "fit_streams_per_gpu": S, "sched": 1 if sched_multi else int(dict(o.split("=") for o in args.option).get("sched", 2)),
                        "parallelism": "independent fits (restart evaluations) per GPU, %d concurrent fit streams per "
                                       "GPU; RCCL broadcast + all-reduce(max) + all-gather only%s"
                                       % (S, "" if dist else " (no process group at world size 1)")},

@@ -257,7 +257,7 @@ class concurrent_fit_streams(object):
     def __exit__(self, *exc):
         _tls.concurrent = self.prev
         for h in self.used.values():
-            load().pgp_set_option(h, b"sched", 0)
+            load().pgp_set_option(h, b"sched", -1)            # back to the library's default for a lone chain
         self.used = {}
         return False
 

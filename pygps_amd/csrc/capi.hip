@@ -189,7 +189,9 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     if (!strcmp(name, "leaf_first")) { c->leaf_first = value; return PGP_OK; }
     if (!strcmp(name, "leaf_pivot")) { if (value < 0 || value > 1) return -2; c->leaf_pivot = value; return PGP_OK; }
-    if (!strcmp(name, "sched")) { if (value < 0 || value > 1) return -2; c->sched = value; return PGP_OK; }
+    if (!strcmp(name, "sched")) { if (value < -1 || value > 2) return -2; c->sched = value < 0 ? PGP_SCHED_DEFAULT : value; return PGP_OK; }
+    if (!strcmp(name, "tud_tile")) { if (value != 64 && value != 128) return -2; c->tud_tile = value; return PGP_OK; }
+    if (!strcmp(name, "tud_mark")) { c->tud_mark = value != 0; return PGP_OK; }
     if (!strcmp(name, "gram_assembly")) { if (value < 0 || value > 2) return -2; c->gram_assembly = value; return PGP_OK; }
     if (!strcmp(name, "yield")) { c->yield = value; return PGP_OK; }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
@@ -787,6 +789,33 @@ static GemmArgs trailing_update2_args(pgp_ctx* c, const SweepMat& m, int k0, int
     g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - 0.5 * (double)g.N * g.N);
     return g;
 }
+// TU_a in two pieces (sched 2): columns [c0, c1) <- C - P P^T restricted to the row blocks [rb0, rb1) (rb1 < 0: to the last row
+// that takes part).  rb0 == c0, rb1 == c1: the DIAGONAL BLOCK of the next panel alone (lower-triangular tile set) -- all D(p+1)
+// needs; rb0 == c1: the rectangle below it.  Results go to the staging buffer like TU_a's.
+static GemmArgs trailing_update_rows_args(pgp_ctx* c, const SweepMat& m, int k0, int k1, int rb0, int rb1, int c0, int c1,
+                                          double* out, long ldx, int tile) {
+    const long r0 = (long)rb0 * 128, rend = m.mrows + m.rows2(k1);
+    const long r1 = rb1 >= 0 ? (long)rb1 * 128 : rend;
+    GemmArgs g{};
+    g.A = m.F + r0 + (long)k0 * 128 * m.ldf; g.lda = m.ldf; g.a_kc = 0;
+    g.B = m.F + (long)c0 * 128 + (long)k0 * 128 * m.ldf; g.ldb = m.ldf; g.b_kc = 0;
+    double* Cf = m.F + r0 + (long)c0 * 128 * m.ldf;
+    const bool split = m.E && r1 > m.mrows;
+    const int sp = (int)(m.mrows - r0);
+    double* Ce = split ? m.E + (long)c0 * 128 * m.lde : nullptr;
+    if (split) { g.A2 = m.E + (long)k0 * 128 * m.lde; g.lda2 = m.lde; g.a_split = sp; }
+    g.Cin = Cf; g.ldcin = m.ldf; g.Cin2 = Ce; g.ldcin2 = m.lde;
+    g.C = out + r0; g.ldc = ldx;
+    if (split) { g.C2 = out + r0 + sp; g.ldc2 = ldx; g.c_split = sp; }
+    g.M = (int)(r1 - r0); g.N = (c1 - c0) * 128; g.K = (k1 - k0) * 128;
+    g.alpha = -1.0; g.beta = 1.0; g.kmode = KM_FULL;
+    if (rb0 == c0) { g.tri = 1; g.tri_off = 0; g.mask_diag = 1; }
+    if (split && !m.dense2) g.zero_from = (int)(m.mrows + (long)k0 * 128 - r0);
+    g.tile = tile;
+    g.flops = 2.0 * (double)g.K * ((double)g.M * g.N - (rb0 == c0 ? 0.5 * (double)g.N * g.N : 0.0));
+    return g;
+}
+
 static int trailing_update2(pgp_ctx* c, const SweepMat& m, int k0, int k1, int c0, int c1, double* out, long ldx,
                             hipStream_t st) {
     if (c1 <= c0) return PGP_OK;
@@ -869,6 +898,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // without waiting for them to drain a full chip.  Events: main waits for S(p) before TU_b(p); the panel stream waits for
     // TU_b(p-1) (which brought panel p+1's columns up to date) before TU_a(p).  Same kernels, same per-tile order: bit-identical.
     const bool sched1 = la && c->sched == 1 && !m.dense2;
+    const bool sched2 = la && c->sched == 2 && !m.dense2;
     if (sched1) {
         while ((int)c->la_ev.size() < 2 * npanel + 4) {
             hipEvent_t e;
@@ -908,10 +938,28 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         if (fill2 && s1 >= nblk) CHK(rhs_product(s0, s1));
         if (s1 >= nblk) break;
         const int n0 = s1, n1 = std::min(s1 + q, nblk);              // next panel's columns
+        const long rows_end = m.mrows + m.rows2(s1);
+        if (sched2 && rows_end > (long)n1 * 128) {
+            // sched 2: D(p+1) needs the next panel's DIAGONAL BLOCK only -- that piece of TU_a (64-tiles: a K = w 128-tile alone
+            // on a CU lasts as long as the whole of TU_a) goes to the panel stream right behind S(p), the rectangle below it
+            // stays on the main stream: D(p+1) starts ~50 us earlier, and its first kernels find free slots beside the
+            // one-workgroup-per-CU rectangle instead of the first wave of the bulk launch
+            HIP_TRY(hipEventRecord(c->la_ev[2 * p], main));
+            HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
+            {
+                const int was = c->chain_now;
+                c->chain_now = c->tud_mark ? 1 : was;
+                const int rc = gemm_prof(c, PC_GEMM_TRAIL, trailing_update_rows_args(c, m, s0, s1, n0, n1, n0, n1, Xs, ldx, c->tud_tile), pan);
+                c->chain_now = was;
+                CHK(rc);
+            }
+            CHK(gemm_prof(c, PC_GEMM_TRAIL, trailing_update_rows_args(c, m, s0, s1, n1, -1, n0, n1, Xs, ldx, 128), main));
+        } else {
         CHK(trailing_update2(c, m, s0, s1, n0, n1, Xs, ldx, main));   // TU_a -> staging
         if (la) {
             HIP_TRY(hipEventRecord(c->la_ev[2 * p], main));
             HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
+        }
         }
         // leaf_first: the trailing update is held back until D(p+1)'s stage-in is done, so that the first leaf is dispatched
         // BEFORE the update's first wave takes every workgroup slot (a leaf dispatched into that wave waits ~140 us for it)

@@ -37,6 +37,8 @@ struct pgp_factor {
     double* sWv = nullptr; // per-point sW (EP); nullptr for Exact
 };
 
+constexpr int PGP_SCHED_DEFAULT = 2;
+
 struct pgp_ctx {
     int device = 0;
     std::vector<int> composite;         // postfix program of kind PGP_COV_COMPOSITE (pgp_set_composite)
@@ -57,8 +59,13 @@ struct pgp_ctx {
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     std::vector<hipEvent_t> tm_ev;      // timing events of the sharded fit's wait / broadcast timers (4 per panel)
     int lookahead = 1;
-    int sched = 0;                      // option "sched": 1 = the critical path D -> S -> TU_a on the panel stream, the bulk updates on the main
-                                        // stream (potrf_blocked_v2); 0 = round 2-4: S, TU_a, TU_b on the main stream, only D on the panel stream
+    int sched = PGP_SCHED_DEFAULT;      // option "sched" (-1 = this default).  0 = rounds 2-4: S, TU_a, TU_b on the main stream, only D on the
+                                        // panel stream; 1 = the critical path D -> S -> TU_a on the panel stream, the bulk updates on the main
+                                        // stream (what fit streams that run side by side select); 2 = like 0, but the piece of TU_a that D(p+1)
+                                        // needs -- the next panel's diagonal block -- runs on the panel stream right behind S(p)
+                                        // (potrf_blocked_v2; lone chain at N = 8192: 11.13 -> 10.90 ms)
+    int tud_tile = 64;                  // sched 2: tile size of the diagonal-block piece of TU_a on the panel stream
+    int tud_mark = 1;                   // sched 2: that piece marks its CUs like the chain's own products (yield role 2)
     int leaf_pivot = 1;                 // 1: the 16 x 16 pivot blocks of a leaf on the matrix cores (panel.hip pivot_block_mfma); 0: lane per row
     int leaf_first = 0;                 // 1: TU_b(p) is launched only after D(p+1)'s stage-in kernel, so that the first leaf is
                                         // dispatched BEFORE the update's first wave takes every workgroup slot (a leaf dispatched
