@@ -188,10 +188,11 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "gemm_dbg")) { if (value & ~(64 | 256 | 512)) return -2; c->gemm_dbg = value; return PGP_OK; }
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     if (!strcmp(name, "leaf_first")) { c->leaf_first = value; return PGP_OK; }
-    if (!strcmp(name, "leaf_pivot")) { if (value < 0 || value > 1) return -2; c->leaf_pivot = value; return PGP_OK; }
+    if (!strcmp(name, "leaf_pivot")) { if (value < 0 || value > 2) return -2; c->leaf_pivot = value; return PGP_OK; }
     if (!strcmp(name, "sched")) { if (value < -1 || value > 2) return -2; c->sched = value < 0 ? PGP_SCHED_DEFAULT : value; return PGP_OK; }
     if (!strcmp(name, "tud_tile")) { if (value != 64 && value != 128) return -2; c->tud_tile = value; return PGP_OK; }
     if (!strcmp(name, "tud_mark")) { c->tud_mark = value != 0; return PGP_OK; }
+    if (!strcmp(name, "sched2_wide")) { c->sched2_wide = value != 0; return PGP_OK; }
     if (!strcmp(name, "gram_assembly")) { if (value < 0 || value > 2) return -2; c->gram_assembly = value; return PGP_OK; }
     if (!strcmp(name, "yield")) { c->yield = value; return PGP_OK; }
     if (!strcmp(name, "ep_fused")) { c->ep_fused = value; return PGP_OK; }
@@ -898,7 +899,9 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // without waiting for them to drain a full chip.  Events: main waits for S(p) before TU_b(p); the panel stream waits for
     // TU_b(p-1) (which brought panel p+1's columns up to date) before TU_a(p).  Same kernels, same per-tile order: bit-identical.
     const bool sched1 = la && c->sched == 1 && !m.dense2;
-    const bool sched2 = la && c->sched == 2 && !m.dense2;
+    // sched 2 pays for 512-wide panels only (N = 4096: -3.6 %, N = 8192: -2.1 %); with 1024-wide panels the diagonal-block piece is
+    // 136 K = 1024 tiles and the rectangle it disturbs twice as long: N = 16384 68.9 -> 70.3 ... 71.2 ms -- those keep schedule 0
+    const bool sched2 = la && c->sched == 2 && !m.dense2 && (q <= 4 || c->sched2_wide);
     if (sched1) {
         while ((int)c->la_ev.size() < 2 * npanel + 4) {
             hipEvent_t e;

@@ -65,8 +65,10 @@ struct pgp_ctx {
                                         // needs -- the next panel's diagonal block -- runs on the panel stream right behind S(p)
                                         // (potrf_blocked_v2; lone chain at N = 8192: 11.13 -> 10.90 ms)
     int tud_tile = 64;                  // sched 2: tile size of the diagonal-block piece of TU_a on the panel stream
+    int sched2_wide = 0;                // sched 2 also with panels wider than 512 columns (measured slower: N = 16384 +2 %)
     int tud_mark = 1;                   // sched 2: that piece marks its CUs like the chain's own products (yield role 2)
-    int leaf_pivot = 1;                 // 1: the 16 x 16 pivot blocks of a leaf on the matrix cores (panel.hip pivot_block_mfma); 0: lane per row
+    int leaf_pivot = 2;                 // 2: register-resident leaf (panel.hip leaf_potrf_reg_kernel); 1: the LDS leaf with its 16 x 16 pivot blocks on
+                                        // the matrix cores (pivot_block_mfma); 0: the LDS leaf, pivot blocks lane per row
     int leaf_first = 0;                 // 1: TU_b(p) is launched only after D(p+1)'s stage-in kernel, so that the first leaf is
                                         // dispatched BEFORE the update's first wave takes every workgroup slot (a leaf dispatched
                                         // into that wave waited ~140 us for it): 12.08 -> 11.72 ms per N = 8192 fit, two fit

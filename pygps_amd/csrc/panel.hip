@@ -17,6 +17,7 @@
 // Storage: column-major lower ("L(i,j) at i + j*ld"), which is the same memory as numpy's
 // row-major UPPER factor R = L^T that pyGPs stores in post.L (Core/inf.py:362,367).
 #include <atomic>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_tile.h"
@@ -175,20 +176,34 @@ __device__ __forceinline__ void pivot_block(double* __restrict__ s, double* __re
 // The inverse rides along as the rows of an appended identity (like the 2w x w scratch of the outer sweep): U holds
 // G^T (G -> L^-T) in the same layout, two more MFMAs per panel; four MFMAs against identity slices turn it into the
 // [k][j] image of W = L^-1 that leaf_tile_trsm / trsm_rows_kernel read.
-__device__ __forceinline__ void pivot_block_mfma(double* __restrict__ s, double* __restrict__ sinv, int* s_info, int tb,
-                                                 int lane, double* __restrict__ ginv) {
+// 1/sqrt(d) from v_rsq_f64 (24 bits) and ONE third-order step  r (1 + e/2 + 3 e^2/8),  e = 1 - d r^2  (measured on gfx950,
+// tools/rsq_probe.hip: 1.24 ulp against 2.14 for two Newton steps, four dependent operations instead of six); sqrt(d) = d r
+// with one correction.
+__device__ __forceinline__ void rsqrt_sqrt3(double d, double& rinv, double& s) {
+    const double r0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * r0), r0, 1.0);
+    const double r = fma(r0 * e, fma(0.375, e, 0.5), r0);
+    const double q = d * r;
+    rinv = r;
+    s = fma(fma(-q, q, d), 0.5 * r, q);
+}
+
+// The core: V (the block in accumulator layout, by value) -> info (0, or 1 + the first column whose pivot is not positive),
+// Wo = the [k][j] image of W = L^-1 (Wo[q](lane) = W(row l15, col 4q + l4)); store_panel(t, v) receives the factor's columns
+// 4t .. 4t+3 in the A-operand layout (lane (l15, l4): L(l15, 4t + l4), exact zeros above the diagonal).
+template <class StoreL>
+__device__ __forceinline__ int pivot16_mfma(double4_t V, int lane, double4_t& Wo, StoreL&& store_panel) {
     const int l15 = lane & 15, l4 = lane >> 4, m4 = l15 & 3, g4 = l15 >> 2;
-    double* blk = s + lblk(tb, tb) * 256;
-    double4_t V, U;
+    double4_t U;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        V[q] = blk[q * 64 + lane];
-        U[q] = (l15 == 4 * q + l4) ? 1.0 : 0.0;
-    }
+    for (int q = 0; q < 4; ++q) U[q] = (l15 == 4 * q + l4) ? 1.0 : 0.0;
     const bool r0m = m4 == 0, r1m = m4 == 1, r2m = m4 == 2;
     const bool c0m = l4 == 0, c1m = l4 == 1, c2m = l4 == 2;
     int inf = 0;
     const double4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+    // Panels of FOUR columns: a dependent mfma -> VALU round trip costs ~300 cycles on this chip, so the fewer the better.  The
+    // column-by-column form (one rank-1 mfma per column, no 4 x 4 arithmetic, no scaling product) was built and measured:
+    // 7070 cycles per block against 5340 (EXPERIMENTS.md).
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         // M(4t + a, 4t + b), a >= b: reg t of lane 16 b + 4t + a
@@ -200,19 +215,19 @@ __device__ __forceinline__ void pivot_block_mfma(double* __restrict__ s, double*
         const double s33 = readlane_f64(V[t], 48 + 4 * t + 3);
         double rr0, rr1, rr2, rr3, l00, l11, l22, l33;
         if (!(s00 > 0.0) && inf == 0) inf = 4 * t + 1;
-        rsqrt_sqrt(s00, rr0, l00);
+        rsqrt_sqrt3(s00, rr0, l00);
         const double l10 = s10 * rr0, l20 = s20 * rr0, l30 = s30 * rr0;
         const double d1 = fma(-l10, l10, s11);
         if (!(d1 > 0.0) && inf == 0) inf = 4 * t + 2;
-        rsqrt_sqrt(d1, rr1, l11);
+        rsqrt_sqrt3(d1, rr1, l11);
         const double l21 = fma(-l20, l10, s21) * rr1, l31 = fma(-l30, l10, s31) * rr1;
         const double d2 = fma(-l21, l21, fma(-l20, l20, s22));
         if (!(d2 > 0.0) && inf == 0) inf = 4 * t + 3;
-        rsqrt_sqrt(d2, rr2, l22);
+        rsqrt_sqrt3(d2, rr2, l22);
         const double l32 = fma(-l31, l21, fma(-l30, l20, s32)) * rr2;
         const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
         if (!(d3 > 0.0) && inf == 0) inf = 4 * t + 4;
-        rsqrt_sqrt(d3, rr3, l33);
+        rsqrt_sqrt3(d3, rr3, l33);
         // W_tt = L_tt^-1
         const double w10 = -(l10 * rr0) * rr1, w21 = -(l21 * rr1) * rr2, w32 = -(l32 * rr2) * rr3;
         const double w20 = -fma(l21, w10, l20 * rr0) * rr2;
@@ -232,19 +247,29 @@ __device__ __forceinline__ void pivot_block_mfma(double* __restrict__ s, double*
         const double lrow = (l4 < m4) ? op[0] : ((l4 == m4) ? ldiag : 0.0);
         const bool below = g4 > t;
         const double pupd = below ? op[0] : 0.0;
-        blk[64 * t + lane] = below ? op[0] : ((g4 == t) ? lrow : 0.0);          // column 4t + l4, row l15
+        store_panel(t, below ? op[0] : ((g4 == t) ? lrow : 0.0));          // column 4t + l4, row l15
         if (t < 3) {
             V = __builtin_amdgcn_mfma_f64_16x16x4f64(-pupd, pupd, V, 0, 0, 0);
             U = __builtin_amdgcn_mfma_f64_16x16x4f64(-pupd, og[0], U, 0, 0, 0);
         }
     }
     // U[q](l15, l4) = G[l15][4q + l4] = W[4q + l4][l15]  ->  [k][j] image of W: Wo[q](l15, l4) = W(row l15, col 4q + l4)
-    double4_t Wo = zero4;
+    Wo = zero4;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const double ik = (l15 == 4 * ks + l4) ? 1.0 : 0.0;
         Wo = __builtin_amdgcn_mfma_f64_16x16x4f64(U[ks], ik, Wo, 0, 0, 0);
     }
+    return inf;
+}
+
+__device__ __forceinline__ void pivot_block_mfma(double* __restrict__ s, double* __restrict__ sinv, int* s_info, int tb,
+                                                 int lane, double* __restrict__ ginv) {
+    double* blk = s + lblk(tb, tb) * 256;
+    double4_t V, Wo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) V[q] = blk[q * 64 + lane];
+    const int inf = pivot16_mfma(V, lane, Wo, [&](int t, double v) { blk[64 * t + lane] = v; });
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         sinv[q * 64 + lane] = Wo[q];
@@ -403,6 +428,175 @@ __global__ __launch_bounds__(256, 2) void leaf_potrf_kernel(double* __restrict__
     pgp_yield_mark(yield_flags, -1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// leaf_potrf_reg_kernel (round 5): the same factorisation with the 128 x 128 block REGISTER-RESIDENT.  Every 16 x 16 tile
+// lives in the MFMA accumulator registers of the wave that owns it, from the global load to the global store:
+//   wave 0        the 8 diagonal tiles -- and the pivot blocks (pivot16_mfma works on the registers as they stand);
+//   waves 1 .. 3  the 28 tiles below the diagonal, tile (bi, bj) on wave 1 + (bi + bj) % 3 (2-3 panel tiles and an equal
+//                 share of the trailing tiles per wave in every step).
+// LDS holds only FINAL blocks of L (the operand images the updates read) and the current inverted pivot block: no staging
+// of the matrix, no round trip of C through LDS per update (the LDS version spends ~1100 cycles per tile update on them),
+// 59 KB instead of 76 KB.  The solve X <- X W^T of a panel tile uses the accumulator registers directly as B operand
+// (the trsm_rows_kernel trick).  Wave 0 brings only the NEXT diagonal tile up to date before it factors it; the other
+// diagonal tiles receive a column's update one phase later, while waves 1 .. 3 solve the next panel.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+constexpr int rl_owner(int bi, int bj) { return bi == bj ? 0 : 1 + (bi + bj) % 3; }
+constexpr int rl_slot(int bi, int bj) {                // position of (bi, bj) among its owner's tiles
+    const int w = rl_owner(bi, bj);
+    int n = 0;
+    for (int j = 0; j < 8; ++j)
+        for (int i = j; i < 8; ++i) {
+            if (i == bi && j == bj) return n;
+            if (rl_owner(i, j) == w) ++n;
+        }
+    return -1;
+}
+constexpr int rl_tile(int w, int slot) {                // 8 bi + bj of wave w's slot (slots beyond its last tile repeat it)
+    int last = 0;
+    for (int j = 0; j < 8; ++j)
+        for (int i = j; i < 8; ++i)
+            if (rl_owner(i, j) == w) {
+                last = 8 * i + j;
+                if (rl_slot(i, j) == slot) return last;
+            }
+    return last;
+}
+constexpr int RL_NT = 10;                              // most tiles on one wave
+constexpr int rl_blk(int bi, int bj) { return bi * (bi - 1) / 2 + bj; }     // strictly lower blocks: the packed image's order
+
+template <class F>
+__device__ __forceinline__ void role_dispatch(int wave, F&& f) {
+    if (wave == 0) f(std::integral_constant<int, 0>{});
+    else if (wave == 1) f(std::integral_constant<int, 1>{});
+    else if (wave == 2) f(std::integral_constant<int, 2>{});
+    else f(std::integral_constant<int, 3>{});
+}
+
+__global__ __launch_bounds__(256, 2) void leaf_potrf_reg_kernel(double* __restrict__ A, long lda, double* __restrict__ pack,
+                                                                int* __restrict__ info, int info_base,
+                                                                long long* __restrict__ tick, unsigned* yield_flags) {
+    extern __shared__ __attribute__((aligned(16))) double s[];          // 28 final blocks | sinv[256]
+    pgp_yield_mark(yield_flags, +1);
+#define TICK(i) do { if (tick && threadIdx.x == 0) tick[i] = __builtin_readcyclecounter(); } while (0)
+    TICK(0);
+    double* sinv = s + 28 * 256;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double4_t acc[RL_NT];
+    int binfo = 0;                                                       // wave 0: first bad pivot (1-based column of the leaf)
+    // ---- load: every wave its own tiles, straight into the accumulator layout (reg q: row l15, column 4q + l4).  ONE code path
+    // for the four roles, the tile of (wave, slot) picked at run time: stores into acc[] from four role branches are sunk
+    // into one store through a pointer phi by the optimiser, and the array then stays in scratch
+    static_for<0, RL_NT>([&](auto slc) __attribute__((always_inline)) {
+        constexpr int sl = decltype(slc)::value;
+        constexpr int c0 = rl_tile(0, sl), c1 = rl_tile(1, sl), c2 = rl_tile(2, sl), c3 = rl_tile(3, sl);
+        const int code = wave == 0 ? c0 : (wave == 1 ? c1 : (wave == 2 ? c2 : c3));
+        const int bi = code >> 3, bj = code & 7;
+        const double* src = A + (long)(16 * bi + l15) + (long)(16 * bj + l4) * lda;
+        const double4_t v = {src[0], src[4 * lda], src[8 * lda], src[12 * lda]};
+        acc[sl] = v;
+    });
+    TICK(1);
+    // the pivot block of column block `tb` on wave 0's registers: factor -> global (lower part), inverse -> LDS + packed image
+    auto pivot = [&](auto tbc) __attribute__((always_inline)) {
+        constexpr int tb = decltype(tbc)::value;
+        double* Ad = A + (long)(16 * tb) * (1 + lda);
+        double4_t Wo;
+        const int inf = pivot16_mfma(acc[tb], lane, Wo, [&](int tt, double v) __attribute__((always_inline)) {
+            if (l15 >= 4 * tt + l4) Ad[l15 + (long)(4 * tt + l4) * lda] = v;
+        });
+        double* ginv = pack + (28 + tb) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sinv[q * 64 + lane] = Wo[q];
+            ginv[q * 64 + lane] = Wo[q];
+        }
+        if (inf != 0 && binfo == 0) binfo = tb * 16 + inf;
+    };
+    // acc -= P(bi, c) P(bj, c)^T from the final blocks of column block c in LDS (bi == bj: one operand image)
+    auto update = [&](double4_t& a, auto bic, auto bjc, auto cc) __attribute__((always_inline)) {
+        constexpr int bi = decltype(bic)::value, bj = decltype(bjc)::value, c = decltype(cc)::value;
+        const double* pa = s + rl_blk(bj, c) * 256;
+        const double* pb = s + rl_blk(bi, c) * 256;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[ks * 64 + lane], pb[ks * 64 + lane], a, 0, 0, 0);
+    };
+    if (wave == 0) pivot(std::integral_constant<int, 0>{});
+    __syncthreads();                                                     // B1(0): the inverted pivot block is in LDS
+    TICK(2);
+    static_for<0, 7>([&](auto tbc) __attribute__((always_inline)) {
+        constexpr int tb = decltype(tbc)::value;
+        // ---- b: waves 1..3 solve their tiles of panel column tb; wave 0 applies column tb-1 to the diagonal tiles behind the next
+        role_dispatch(wave, [&](auto Wc) __attribute__((always_inline)) {
+            constexpr int W = decltype(Wc)::value;
+            if constexpr (W == 0) {
+                if constexpr (tb >= 1)
+                    static_for<tb + 1, 8>([&](auto kc) __attribute__((always_inline)) { update(acc[decltype(kc)::value], kc, kc, std::integral_constant<int, tb - 1>{}); });
+            } else {
+                double fa[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[ks] = sinv[ks * 64 + lane];
+                static_for<tb + 1, 8>([&](auto bic) __attribute__((always_inline)) {
+                    constexpr int bi = decltype(bic)::value;
+                    if constexpr (rl_owner(bi, tb) == W) {
+                        constexpr int sl = rl_slot(bi, tb);
+                        double4_t y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+                        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0], acc[sl][0], y0, 0, 0, 0);
+                        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1], acc[sl][1], y1, 0, 0, 0);
+                        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[2], acc[sl][2], y0, 0, 0, 0);
+                        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[3], acc[sl][3], y1, 0, 0, 0);
+                        y0 += y1;
+                        double* lb = s + rl_blk(bi, tb) * 256;
+                        double* gp = pack + rl_blk(bi, tb) * 256;
+                        double* ga = A + (long)(16 * bi + l15) + (long)(16 * tb + l4) * lda;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            lb[q * 64 + lane] = y0[q];
+                            gp[q * 64 + lane] = y0[q];
+                            ga[(long)(4 * q) * lda] = y0[q];
+                        }
+                    }
+                });
+            }
+        });
+        __syncthreads();                                                 // B2(tb): panel column tb is final in LDS
+        TICK(3 + 2 * tb);
+        // ---- c: waves 1..3 update their trailing tiles with column tb; wave 0 the next diagonal tile, then its pivot block
+        role_dispatch(wave, [&](auto Wc) __attribute__((always_inline)) {
+            constexpr int W = decltype(Wc)::value;
+            if constexpr (W == 0) {
+                update(acc[tb + 1], std::integral_constant<int, tb + 1>{}, std::integral_constant<int, tb + 1>{}, tbc);
+                pivot(std::integral_constant<int, tb + 1>{});
+            } else {
+                static_for<tb + 1, 8>([&](auto bjc) __attribute__((always_inline)) {
+                    static_for<tb + 2, 8>([&](auto bic) __attribute__((always_inline)) {
+                        constexpr int bj = decltype(bjc)::value, bi = decltype(bic)::value;
+                        if constexpr (bi > bj && rl_owner(bi, bj) == W) {
+                            constexpr int sl = rl_slot(bi, bj);
+                            update(acc[sl], bic, bjc, tbc);
+                        }
+                    });
+                });
+            }
+        });
+        __syncthreads();                                                 // B1(tb + 1)
+        TICK(4 + 2 * tb);
+    });
+    if (t == 0 && binfo != 0) atomicCAS(info, 0, info_base + binfo);
+    TICK(19);
+    if (tick && t == 0) tick[20] = tick[19];
+#undef TICK
+    __syncthreads();
+    pgp_yield_mark(yield_flags, -1);
+}
+
 // X (nrows x 128, column-major, ld) <- X * L^-T, L = 128x128 lower at Ld (ld), inv16 = 8 inverted
 // pivot blocks (column-major 16x16 each).  One wave per 16 rows.  The 36 lower 16x16 blocks of L and the
 // 8 inverted pivot blocks are staged ONCE per workgroup into LDS in MFMA A-operand order
@@ -508,9 +702,13 @@ int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_ba
     if (!attr_set.load(std::memory_order_acquire)) {
         (void)hipFuncSetAttribute((const void*)leaf_potrf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         (void)hipFuncSetAttribute((const void*)leaf_potrf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute((const void*)leaf_potrf_reg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         attr_set.store(true, std::memory_order_release);
     }
-    if (pivot)
+    if (pivot == 2) {
+        const size_t shm2 = (28 * 256 + 256) * sizeof(double);
+        hipLaunchKernelGGL(leaf_potrf_reg_kernel, dim3(1), dim3(256), shm2, st, A, lda, inv16, info, info_base, tick, yield_flags);
+    } else if (pivot)
         hipLaunchKernelGGL(leaf_potrf_kernel<true>, dim3(1), dim3(256), shm, st, A, lda, inv16, info, info_base, tick, yield_flags);
     else
         hipLaunchKernelGGL(leaf_potrf_kernel<false>, dim3(1), dim3(256), shm, st, A, lda, inv16, info, info_base, tick, yield_flags);

@@ -85,9 +85,9 @@ if __name__ == "__main__":
         gemm(8192, 384, 128, tile=128)
         gemm(4096, 4096, 4096)
     if "leaf" in what:
-      for pv in (0, 1):
+      for pv in (0, 1, 2):
         assert lib.pgp_set_option(ctx, b"leaf_pivot", pv) == 0
-        print("leaf_pivot =", pv, "(1 = pivot blocks on the matrix cores)")
+        print("leaf_pivot =", pv, "(0: LDS leaf, lane-per-row pivot blocks; 1: LDS leaf, pivot blocks on the matrix cores; 2: register-resident leaf)")
         tk = np.zeros(24)
         assert lib.pgp_test_leaf_ticks(ctx, _lib.ptr(tk)) == 0
         names = ["start", "loaded", "pivot0"] + ["b%d" % (i // 2) if i % 2 == 0 else "c%d" % (i // 2) for i in range(16)]
@@ -97,7 +97,7 @@ if __name__ == "__main__":
         for nm, v in seq:
             print("  %-10s +%7.0f cycles (%6.2f us)  total %8.0f" % (nm, v - prev, (v - prev) / 2400.0, v - base))
             prev = v
-      lib.pgp_set_option(ctx, b"leaf_pivot", 1)
+      lib.pgp_set_option(ctx, b"leaf_pivot", 2)
     if "dvfs" in what:
         for v in (0, 7):
             lib.pgp_set_option(ctx, b"gemm_dbg", v)
