@@ -884,6 +884,33 @@ def main():
                 "cholesky_sweep_ms": potrf_ms,
                 "cholesky_sweep_TFLOPs": (2.0 * N ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12,
                 "cholesky_sweep_frac_of_peak": (2.0 * N ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TF}
+        # the same profiled pass under the round 2-4 schedule (sched 0: TU_a as ONE 254-tile launch alone on the chip).  The default since
+        # round 5 (sched 2) moves the diagonal-block piece of TU_a to the panel stream and lets D(p+1)'s first kernels run beside the
+        # rectangle that is left: the fit is faster (single_stream_ms_per_fit), but that rectangle's launch of THIS kernel lasts ~100 us
+        # instead of ~77 (its CUs' workgroups give way to the chain), which lowers `frac` -- both are in the line so that the kernel's
+        # own rate is not confused with the schedule's
+        try:
+            if lib.pgp_set_option(ctx, b"sched", 0) == 0:
+                lib.pgp_profile_reset(ctx)
+                t0s = time.perf_counter()
+                for s_ in range(4):
+                    fit(args.warmup + s_)
+                s0_ms = (time.perf_counter() - t0s) / 4 * 1e3
+                lib.pgp_set_profiling(ctx, 1)
+                for s_ in range(args.prof_steps):
+                    fit(args.warmup + s_)
+                lib.pgp_set_profiling(ctx, 0)
+                prof0 = _lib.profile(local)
+                kd0 = next((v for k_, v in prof0.items() if k_.startswith("kernel gemm_f64_kernel<128,128,false,false,true")), None)
+                gf0 = sum(v["flops"] for k_, v in prof0.items() if k_.startswith("gemm_f64"))
+                if kd0 and kd0["launches"]:
+                    ach0 = (alg * nfit - (gf0 - kd0["flops"])) / max(kd0["ms"], 1e-12) / 1e9
+                    roof["frac_sched0"] = ach0 / PEAK_FP64_MFMA_TF
+                    roof["avg_launch_ms_sched0"] = kd0["ms"] / kd0["launches"]
+                    roof["single_stream_ms_per_fit_sched0"] = s0_ms
+        finally:
+            lib.pgp_set_option(ctx, b"sched", int(dict(o.split("=") for o in args.option).get("sched", -1)))
+            lib.pgp_profile_reset(ctx)
         asm = prof.get("cov_tile_kernel(assemble)")
         if asm and asm["launches"]:
             roof["assembly_fused_GBs"] = asm["bytes"] / asm["ms"] / 1e6
