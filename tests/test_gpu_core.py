@@ -94,6 +94,40 @@ def test_potrf_reports_first_bad_pivot(lib):
     assert rc == 151
 
 
+@pytest.mark.parametrize("leaf_pivot", [0, 1, 2])
+def test_leaf_kernels_agree_with_lapack_and_on_the_first_bad_pivot(lib, leaf_pivot):
+    """The three leaf kernels (Core/tools.py:31-77 jitchol's dpotrf on a 128 x 128 diagonal block): 0 = LDS leaf with lane-per-row
+    pivot blocks (rounds 2-4), 1 = LDS leaf with the pivot blocks on the matrix cores, 2 = the register-resident leaf (default).
+    Badly scaled and correlated blocks against LAPACK; the FIRST non-positive pivot wherever it sits inside a 16-column pivot
+    block, a 4-column panel or a leaf; the triangular part above the diagonal stays exactly zero."""
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    _lib.check(lib.pgp_set_option(ctx, b"leaf_pivot", leaf_pivot))
+    try:
+        for n, seed, scale in ((128, 1, 1.0), (257, 2, 1e6), (640, 3, 1e-6), (1024, 4, 1.0)):
+            rng = np.random.RandomState(seed)
+            t = np.sort(rng.rand(n))[:, None]
+            A = scale * (np.exp(-0.5 * (t - t.T) ** 2 / 0.05 ** 2) * 50.0 + np.eye(n))      # strongly correlated neighbours
+            L = np.zeros((n, n))
+            assert lib.pgp_potrf(ctx, _lib.ptr(A), n, _lib.ptr(L)) == 0
+            ref = np.linalg.cholesky(A)
+            assert relerr(L, ref) < 1e-11, (n, relerr(L, ref))
+            assert np.abs(L @ L.T - A).max() / np.abs(A).max() < 1e-14
+            assert np.all(np.triu(L, 1) == 0)
+        for bad in (0, 1, 3, 4, 15, 16, 17, 127, 128, 129, 150, 255, 299):
+            n = 300
+            rng = np.random.RandomState(bad)
+            G = rng.randn(n, n)
+            A = G @ G.T / n + np.eye(n)
+            A[bad, bad] = -1.0 if bad % 2 else 0.0                                        # zero counts as non-positive, too
+            if bad % 2 == 0:
+                A[bad, :] = 0.0; A[:, bad] = 0.0
+            L = np.zeros((n, n))
+            assert lib.pgp_potrf(ctx, _lib.ptr(A), n, _lib.ptr(L)) == bad + 1, bad
+    finally:
+        lib.pgp_set_option(ctx, b"leaf_pivot", 2)
+
+
 def _fit(lib, kind, cov_hyp, para, log_sn, x, y, m, dm, want=3, flags=0, factor=True):
     from pygps_amd import _lib
     n, d = x.shape

@@ -56,12 +56,13 @@ cp $(ccsv $O/asm_w) $O/final/r05_assembly_pmc_write_counter_collection.csv
 bash $R/tools/gemm_pmc.sh > /dev/null 2>&1; cp $R/gpurun_out/gemm_pmc.txt $O/final/r05_gemm_pmc.txt
 ( hipcc --offload-arch=gfx950 -O3 -o /tmp/store_roof $R/tools/store_roof.hip && /tmp/store_roof 16384;
   python $R/tools/first_call.py 16384:10 16384:10 16384:10 16384:100 16384:100 ) > $O/final/r05_store_roof.txt 2> $O/store_roof.err
-# 7. timeline of one single-stream fit: the kept schedule and sched=1 (critical path on the panel stream, EXPERIMENTS.md round 5)
-bash $R/tools/fit_trace.sh fit_timeline > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline.txt $O/final/r05_fit_timeline.txt
+# 7. timeline of one single-stream fit: sched 0 (rounds 2-4), sched 1 (critical path on the panel stream), sched 2 (the default for a lone chain)
+bash $R/tools/fit_trace.sh fit_timeline sched=0 > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline.txt $O/final/r05_fit_timeline.txt
 bash $R/tools/fit_trace.sh fit_timeline_sched1 sched=1 > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline_sched1.txt $O/final/r05_fit_timeline_sched1.txt
+bash $R/tools/fit_trace.sh fit_timeline_sched2 sched=2 > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline_sched2.txt $O/final/r05_fit_timeline_sched2.txt
 # 8. round 5: the Gram-form assembly kernels (general / restructured / four workgroups per CU), sched 0 / 1 alternated, the leaf's phases
 ( python $R/tools/gram_probe.py -- "gram_fast=0,gram_grid=2048" "gram_fast=1,gram_grid=2048" "gram_fast=2,gram_grid=8192" "gram_fast=2,gram_grid=32768";
   python $R/tools/gram_probe.py d=32 -- "gram_fast=0,gram_grid=2048" "gram_fast=2,gram_grid=32768" ) > $O/final/r05_gram_probe.txt 2> $O/gram.err
-( python $R/tools/ab_options.py N=8192 STEPS=40 ROUNDS=3 -- "sched=0" "sched=1"; python $R/tools/gpu_probe.py leaf ) > $O/final/r05_sched_ab_and_leaf_ticks.txt 2> $O/ab.err
+( python $R/tools/ab_options.py N=8192 STEPS=40 ROUNDS=3 -- "sched=0" "sched=1" "sched=2" "sched=2,leaf_pivot=0"; python $R/tools/ab_options.py N=4096 STEPS=40 ROUNDS=3 -- "sched=0" "sched=2" "sched=2,leaf_pivot=0"; python $R/tools/gpu_probe.py leaf ) > $O/final/r05_sched_ab_and_leaf_ticks.txt 2> $O/ab.err
 ( REPS=20 python $R/tools/ep_kfold_diag.py 2>&1 | grep -E "rep|probe|gave" ) > $O/final/r05_ep_two_fit_streams_soak.txt
 ls -la $O/final
