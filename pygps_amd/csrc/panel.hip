@@ -254,14 +254,12 @@ __device__ __forceinline__ int pivot16_mfma(double4_t V, int lane, double4_t& Wo
         }
     }
     // U[q](l15, l4) = G[l15][4q + l4] = W[4q + l4][l15]  ->  [k][j] image of W: Wo[q](l15, l4) = W(row l15, col 4q + l4)
-    double4_t Wa = zero4, Wb = zero4;                          // two independent accumulation chains
+    Wo = zero4;
 #pragma unroll
-    for (int ks = 0; ks < 4; ks += 2) {
-        const double ik0 = (l15 == 4 * ks + l4) ? 1.0 : 0.0, ik1 = (l15 == 4 * ks + 4 + l4) ? 1.0 : 0.0;
-        Wa = __builtin_amdgcn_mfma_f64_16x16x4f64(U[ks], ik0, Wa, 0, 0, 0);
-        Wb = __builtin_amdgcn_mfma_f64_16x16x4f64(U[ks + 1], ik1, Wb, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) {
+        const double ik = (l15 == 4 * ks + l4) ? 1.0 : 0.0;
+        Wo = __builtin_amdgcn_mfma_f64_16x16x4f64(U[ks], ik, Wo, 0, 0, 0);
     }
-    Wo = Wa + Wb;
     return inf;
 }
 
@@ -526,12 +524,9 @@ __global__ __launch_bounds__(256, 2) void leaf_potrf_reg_kernel(double* __restri
         constexpr int bi = decltype(bic)::value, bj = decltype(bjc)::value, c = decltype(cc)::value;
         const double* pa = s + rl_blk(bj, c) * 256;
         const double* pb = s + rl_blk(bi, c) * 256;
-        double4_t a1 = {0.0, 0.0, 0.0, 0.0};                      // two independent accumulation chains
-        a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[lane], pb[lane], a, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[64 + lane], pb[64 + lane], a1, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[128 + lane], pb[128 + lane], a, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[192 + lane], pb[192 + lane], a1, 0, 0, 0);
-        a += a1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[ks * 64 + lane], pb[ks * 64 + lane], a, 0, 0, 0);
     };
     if (wave == 0) pivot(std::integral_constant<int, 0>{});
     __syncthreads();                                                     // B1(0): the inverted pivot block is in LDS
