@@ -45,7 +45,21 @@ for k in range(2):
     ctxs.append(h)
 
 
+# library defaults of the options a set may name: every option that ANY set of the run names goes back to its default before a
+# set is applied (round 5: sets like "sched=2,tud_tile=128" followed by "sched=2" silently kept tud_tile=128 -- two tables of that
+# round had to be re-read from their first alternation)
+DEFAULTS = {"sched": -1, "tud_mark": 1, "tud_tile": 64, "sched2_wide": 0, "leaf_pivot": 2, "nb_outer": 0, "pair_launch": 1, "leaf_first": 0,
+            "yield": 1, "eet_overlap": 3, "eet_tile": 128, "eet_first": -1, "s_tile": 0, "lookahead": 1, "xcd_order": 0, "small_tile_below": 200,
+            "gram_assembly": 1, "gram_fast": 2}
+NAMED = sorted({o.split("=")[0] for sp in sets for o in sp.split(",") if o})
+for k_ in NAMED:
+    assert k_ in DEFAULTS, "add the default of option %r to DEFAULTS" % k_
+
+
 def apply(spec, reset=False):
+    for k_ in NAMED:
+        for h in ctxs:
+            assert lib.pgp_set_option(h, k_.encode(), DEFAULTS[k_]) == 0, k_
     for o in spec.split(","):
         if not o:
             continue
