@@ -60,16 +60,38 @@ def hyp_for(step, rank, d):
     return np.array([np.log(np.sqrt(d)) + eps, 0.0 - eps]), float(np.log(0.1) + 0.5 * eps)
 
 
+def usable_cpus():
+    """Cores this process may actually use: the affinity mask, capped by the container's CFS quota (cgroup v2 cpu.max / v1
+    cfs_quota_us).  The GPU boxes show 256 cores and grant 16: a BLAS pool of 128-256 threads is throttled there, not faster."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(np.ceil(float(q) / float(p)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(np.ceil(q / p))))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(N, d, budget_s=150.0):
     """Reference-faithful CPU path (oracle) on the host cores: ONE full fit at (N, d) unless a half-size fit predicts more
     than budget_s (then the half-size time is scaled and labelled as such).  Also returns the measured exponent between
     N/2 and N (SURVEY section 6 measured x5.5 for 4096 -> 8192 on 8 cores, i.e. not a clean N^3)."""
     from oracle import gp_oracle as O
+    ncpu = usable_cpus()
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
+        # one BLAS thread per core the container may use (kept for the rest of the process: the CPU legs run after the timed region)
+        cpu_baseline._limit = threadpool_limits(limits=ncpu)
         thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        thr = os.cpu_count() or 1
+        thr = ncpu
 
     def one(n, faithful=True):
         x, y = synth_reg(n, d)
@@ -81,7 +103,7 @@ def cpu_baseline(N, d, budget_s=150.0):
 
     one(512)                                            # warm the BLAS threads
     th = one(N // 2)
-    out = {"unit": "fits/s", "cores": int(thr), "kind": "port", "host_cpu_count": os.cpu_count(),
+    out = {"unit": "fits/s", "cores": int(thr), "kind": "port", "host_cpu_count": os.cpu_count(), "usable_cpus": ncpu,
            "half_size_fit_s": th}
     if th * 8 <= budget_s:
         t = one(N)

@@ -1,8 +1,28 @@
 import os
 import sys
 
+# BLAS threads: the oracle's LAPACK / BLAS calls and up to eight worker processes per test each start one thread per VISIBLE core
+# (256 on the GPU boxes) -- on a box whose container may only use some of them that oversubscription made the same suite take
+# 13 minutes instead of 3.4 (round 5).  Cap them at the cores this process may run on, at most 32; children inherit the variables.
+_NT = max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+try:                                    # ... and at the container's CFS quota (the GPU boxes: 256 cores visible, 16 granted)
+    _q, _p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+    if _q != "max":
+        _NT = max(1, min(_NT, -(-int(_q) // int(_p))))
+except Exception:
+    pass
+_NT = str(_NT)
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, _NT)
+
 import numpy as np
 import pytest
+
+try:                                    # numpy may have been imported by a plugin before the variables were set
+    from threadpoolctl import threadpool_limits
+    _BLAS_LIMIT = threadpool_limits(limits=int(os.environ["OPENBLAS_NUM_THREADS"]))
+except Exception:                       # pragma: no cover
+    _BLAS_LIMIT = None
 
 os.environ.setdefault("PYGPS_AMD_TORCH_FIRST", "1")     # this process uses torch.distributed beside the library (see _lib._torch_first)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
