@@ -104,7 +104,9 @@ def test_leaf_kernels_agree_with_lapack_and_on_the_first_bad_pivot(lib, leaf_piv
     ctx = _lib.ctx()
     _lib.check(lib.pgp_set_option(ctx, b"leaf_pivot", leaf_pivot))
     try:
-        for n, seed, scale in ((128, 1, 1.0), (257, 2, 1e6), (640, 3, 1e-6), (1024, 4, 1.0)):
+        # (2304 / 4096: the look-ahead sweep WITHOUT inverse rows -- jitchol's shape -- under the default schedule: sched 2's two
+        #  pieces of TU_a with a single row piece, a last panel of two leaves, no rows below the last panel)
+        for n, seed, scale in ((128, 1, 1.0), (257, 2, 1e6), (640, 3, 1e-6), (1024, 4, 1.0), (2304, 5, 1.0), (4096, 6, 1.0)):
             rng = np.random.RandomState(seed)
             t = np.sort(rng.rand(n))[:, None]
             A = scale * (np.exp(-0.5 * (t - t.T) ** 2 / 0.05 ** 2) * 50.0 + np.eye(n))      # strongly correlated neighbours
