@@ -446,8 +446,10 @@ __global__ __launch_bounds__(512) void ep_chain_kernel(double* Sig, long ld, lon
         if (threadIdx.x < 256) {
             for (int b = 0; b < nbl; ++b) {
                 if (b > 0 && threadIdx.x == 0) {
-                    ep_wait_ge(flags + EPF_CHAIN, cbase + (unsigned)b, flags + EPF_ERR, 1u | ((unsigned)b << 8));
+                    // (the strip is there long before the chain is through: its poll -- one agent-scope round trip even when satisfied --
+                    //  comes first, so that nothing stands between the chain's counter and the loads)
                     ep_wait_ge(flags + EPF_STRIP, (sbase + (unsigned)b) * swg, flags + EPF_ERR, 2u | ((unsigned)b << 8));
+                    ep_wait_ge(flags + EPF_CHAIN, cbase + (unsigned)b, flags + EPF_ERR, 1u | ((unsigned)b << 8));
                 }
                 __syncthreads();
                 ep_prep_body((int)blockIdx.x - 1, Sig, ld, (long)b * EPB, Sbuf + (long)((b + 1) & 1) * EPB * ld, Sbuf + (long)(b & 1) * EPB * ld,
