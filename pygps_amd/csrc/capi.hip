@@ -901,7 +901,11 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     const bool sched1 = la && c->sched == 1 && !m.dense2;
     // sched 2 pays for 512-wide panels only (N = 4096: -3.6 %, N = 8192: -2.1 %); with 1024-wide panels the diagonal-block piece is
     // 136 K = 1024 tiles and the rectangle it disturbs twice as long: N = 16384 68.9 -> 70.3 ... 71.2 ms -- those keep schedule 0
-    const bool sched2 = la && c->sched == 2 && !m.dense2 && (q <= 4 || c->sched2_wide);
+    // ... and only with the fused inverse rows in the sweep: a plain factorisation (jitchol, EP's post.L) is bound by the chain on a
+    // mostly idle chip, where the extra event and the marked piece only add to it (EP's final factor with 512-wide panels: 17.5 ->
+    // 18.0 ms per fit with sched 2)
+    // ... and from N = 4096 on (measured: N = 2048 1.267 -> 1.313 ms, N = 4096 2.94 -> 2.88, N = 8192 11.13 -> 10.90)
+    const bool sched2 = la && c->sched == 2 && !m.dense2 && m.E != nullptr && ((q <= 4 && nblk >= 32) || c->sched2_wide);
     if (sched1) {
         while ((int)c->la_ev.size() < 2 * npanel + 4) {
             hipEvent_t e;
