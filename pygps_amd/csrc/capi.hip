@@ -905,7 +905,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // mostly idle chip, where the extra event and the marked piece only add to it (EP's final factor with 512-wide panels: 17.5 ->
     // 18.0 ms per fit with sched 2)
     // ... and from N = 4096 on (measured: N = 2048 1.267 -> 1.313 ms, N = 4096 2.94 -> 2.88, N = 8192 11.13 -> 10.90)
-    const bool sched2 = la && c->sched == 2 && !m.dense2 && m.E != nullptr && ((q <= 4 && nblk >= 32) || c->sched2_wide);
+    const bool sched2 = la && c->sched == 2 && !m.dense2 && m.E != nullptr && ((q <= 4 && nblk >= 32 && nblk < 72) || c->sched2_wide);     // N = 6144: 6.08 -> 5.78 ms; N = 10240: 19.67 -> 19.76
     if (sched1) {
         while ((int)c->la_ev.size() < 2 * npanel + 4) {
             hipEvent_t e;
