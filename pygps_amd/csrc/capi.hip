@@ -898,14 +898,18 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // BESIDE the previous panel's bulk launch and its tail instead of alone on the chip between two bulk launches, and D(p+1) starts
     // without waiting for them to drain a full chip.  Events: main waits for S(p) before TU_b(p); the panel stream waits for
     // TU_b(p-1) (which brought panel p+1's columns up to date) before TU_a(p).  Same kernels, same per-tile order: bit-identical.
-    const bool sched1 = la && c->sched == 1 && !m.dense2;
+    // sched 1 is what fit streams that run side by side ask for (_lib.concurrent_fit_streams); it pays from N ~ 7000 on (two streams,
+    // N = 8192: 109.5 vs 107.7 fits/s with sched 2) and costs below (N = 6144: 218.5 vs 225.3; N = 4096: 467 vs 513 / 521 with
+    // sched 2 / 0): smaller sweeps take the default schedule instead
+    const int sched_eff = (c->sched == 1 && nblk < 56) ? PGP_SCHED_DEFAULT : c->sched;
+    const bool sched1 = la && sched_eff == 1 && !m.dense2;
     // sched 2 pays for 512-wide panels only (N = 4096: -3.6 %, N = 8192: -2.1 %); with 1024-wide panels the diagonal-block piece is
     // 136 K = 1024 tiles and the rectangle it disturbs twice as long: N = 16384 68.9 -> 70.3 ... 71.2 ms -- those keep schedule 0
     // ... and only with the fused inverse rows in the sweep: a plain factorisation (jitchol, EP's post.L) is bound by the chain on a
     // mostly idle chip, where the extra event and the marked piece only add to it (EP's final factor with 512-wide panels: 17.5 ->
     // 18.0 ms per fit with sched 2)
     // ... and from N = 4096 on (measured: N = 2048 1.267 -> 1.313 ms, N = 4096 2.94 -> 2.88, N = 8192 11.13 -> 10.90)
-    const bool sched2 = la && c->sched == 2 && !m.dense2 && m.E != nullptr && ((q <= 4 && nblk >= 32 && nblk < 72) || c->sched2_wide);     // N = 6144: 6.08 -> 5.78 ms; N = 10240: 19.67 -> 19.76
+    const bool sched2 = la && sched_eff == 2 && !m.dense2 && m.E != nullptr && ((q <= 4 && nblk >= 32 && nblk < 72) || c->sched2_wide);     // N = 6144: 6.08 -> 5.78 ms; N = 10240: 19.67 -> 19.76
     if (sched1) {
         while ((int)c->la_ev.size() < 2 * npanel + 4) {
             hipEvent_t e;
