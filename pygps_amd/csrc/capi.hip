@@ -191,6 +191,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "leaf_pivot")) { if (value < 0 || value > 2) return -2; c->leaf_pivot = value; return PGP_OK; }
     if (!strcmp(name, "sched")) { if (value < -1 || value > 2) return -2; c->sched = value < 0 ? PGP_SCHED_DEFAULT : value; return PGP_OK; }
     if (!strcmp(name, "tud_tile")) { if (value != 64 && value != 128) return -2; c->tud_tile = value; return PGP_OK; }
+    if (!strcmp(name, "s_pan")) { if (value < -1 || value > 2) return -2; c->s_pan = value; return PGP_OK; }
     if (!strcmp(name, "tud_mark")) { c->tud_mark = value != 0; return PGP_OK; }
     if (!strcmp(name, "sched2_wide")) { c->sched2_wide = value != 0; return PGP_OK; }
     if (!strcmp(name, "gram_assembly")) { if (value < 0 || value > 2) return -2; c->gram_assembly = value; return PGP_OK; }
@@ -910,6 +911,13 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // 18.0 ms per fit with sched 2)
     // ... and from N = 4096 on (measured: N = 2048 1.267 -> 1.313 ms, N = 4096 2.94 -> 2.88, N = 8192 11.13 -> 10.90)
     const bool sched2 = la && sched_eff == 2 && !m.dense2 && m.E != nullptr && ((q <= 4 && nblk >= 32 && nblk < 72) || c->sched2_wide);     // N = 6144: 6.08 -> 5.78 ms; N = 10240: 19.67 -> 19.76
+    const bool span = sched2 && !c->leaf_first && (c->s_pan > 0 || (c->s_pan < 0 && nblk >= 60));
+    if (span)
+        while ((int)c->la_ev.size() < 4 * npanel + 4) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->la_ev.push_back(e);
+        }
     if (sched1) {
         while ((int)c->la_ev.size() < 2 * npanel + 4) {
             hipEvent_t e;
@@ -945,6 +953,18 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     } else
     for (int p = 0; p < npanel; ++p) {
         const int s0 = p * q, s1 = std::min(s0 + q, nblk);
+        if (span && p >= 1) {
+            // s_pan: S(p) does not wait for the END of the paired launch of panel p - 1 (which D(p) beats by ~35 us): it follows
+            // D(p) on the panel stream and runs in that launch's tail.  It reads the staging rows TU_r(p-1) wrote (main stream)
+            HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * npanel + 2 + 2 * (p - 1)], 0));
+            const int was = c->chain_now;
+            c->chain_now = c->s_pan == 2 ? 1 : was;
+            const int rc = solve_below(c, m, s0, s1, Xs, ldx, pan);
+            c->chain_now = was;
+            CHK(rc);
+            HIP_TRY(hipEventRecord(c->la_ev[2 * npanel + 3 + 2 * (p - 1)], pan));
+            HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * npanel + 3 + 2 * (p - 1)], 0));
+        } else
         CHK(solve_below(c, m, s0, s1, Xs, ldx, main));
         if (fill2 && s1 >= nblk) CHK(rhs_product(s0, s1));
         if (s1 >= nblk) break;
@@ -972,6 +992,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
             HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
         }
         }
+        if (span) HIP_TRY(hipEventRecord(c->la_ev[2 * npanel + 2 + 2 * p], main));     // TU_a(p)'s rows below the diagonal block are staged
         // leaf_first: the trailing update is held back until D(p+1)'s stage-in is done, so that the first leaf is dispatched
         // BEFORE the update's first wave takes every workgroup slot (a leaf dispatched into that wave waits ~140 us for it)
         const bool lf = la && c->leaf_first;

@@ -66,6 +66,9 @@ struct pgp_ctx {
                                         // (potrf_blocked_v2; lone chain at N = 8192: 11.13 -> 10.90 ms)
     int tud_tile = 64;                  // sched 2: tile size of the diagonal-block piece of TU_a on the panel stream
     int sched2_wide = 0;                // sched 2 also with panels wider than 512 columns (measured slower: N = 16384 +2 %)
+    int s_pan = -1;                     // sched 2: S(p), p >= 1, on the panel stream right behind D(p): it runs in the tail of the previous
+                                        // paired launch instead of after it (1; 2 = marked like the chain's products; 0 = on the main stream;
+                                        // -1 = from N = 7680 on: N = 8192 10.84 -> 10.65 ms, 7680 9.45 -> 9.22, 7168 neutral, 4096 / 6144 +2.5 %)
     int tud_mark = 1;                   // sched 2: that piece marks its CUs like the chain's own products (yield role 2)
     int leaf_pivot = 2;                 // 2: register-resident leaf (panel.hip leaf_potrf_reg_kernel); 1: the LDS leaf with its 16 x 16 pivot blocks on
                                         // the matrix cores (pivot_block_mfma); 0: the LDS leaf, pivot blocks lane per row
