@@ -192,6 +192,8 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "sched")) { if (value < -1 || value > 2) return -2; c->sched = value < 0 ? PGP_SCHED_DEFAULT : value; return PGP_OK; }
     if (!strcmp(name, "tud_tile")) { if (value != 64 && value != 128) return -2; c->tud_tile = value; return PGP_OK; }
     if (!strcmp(name, "s_pan")) { if (value < -1 || value > 2) return -2; c->s_pan = value; return PGP_OK; }
+    if (!strcmp(name, "s_pan_direct")) { c->s_pan_direct = value != 0; return PGP_OK; }
+    if (!strcmp(name, "s_pan_out")) { c->s_pan_out = value != 0; return PGP_OK; }
     if (!strcmp(name, "tud_mark")) { c->tud_mark = value != 0; return PGP_OK; }
     if (!strcmp(name, "sched2_wide")) { c->sched2_wide = value != 0; return PGP_OK; }
     if (!strcmp(name, "gram_assembly")) { if (value < 0 || value > 2) return -2; c->gram_assembly = value; return PGP_OK; }
@@ -724,15 +726,22 @@ static int ensure_stage(pgp_ctx* c, long rows, int w) {
 
 // D: factor the w x w block `src` (leading dimension lds, lower part) and produce E_D = L_D^-T beside it: L_D -> Fd (ldf),
 // E_D -> Ed (lde; may be null), E_D also stays in c->Dk + w (leading dimension 2w) for the panel solve that follows
-int diag_block_factor(pgp_ctx* c, const double* src, long lds, int w, double* Fd, long ldf, double* Ed, long lde,
-                      int info_base, hipStream_t st, hipEvent_t staged) {
+// Dk: the 2w x w scratch (null: c->Dk); skip_out: the stage-out is left to the caller (diag_block_out, possibly on another stream)
+static int diag_block_factor_in(pgp_ctx* c, const double* src, long lds, int w, int info_base, hipStream_t st, hipEvent_t staged,
+                                double* Dk) {
     const long ldd = 2L * w;
     { ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
-      CHK(diag_in_launch(src, lds, c->Dk, ldd, w, st)); }
-    CHK(factor_panel(c, c->Dk, ldd, RowEnd{(long)w, true}, 0, w / 128, st, c->dpack, info_base, staged, c->leaf_first - 1));
-    { ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
-      CHK(diag_out_launch(c->Dk, ldd, w, Fd, ldf, Ed, lde, st)); }
-    return PGP_OK;
+      CHK(diag_in_launch(src, lds, Dk, ldd, w, st)); }
+    return factor_panel(c, Dk, ldd, RowEnd{(long)w, true}, 0, w / 128, st, c->dpack, info_base, staged, c->leaf_first - 1);
+}
+static int diag_block_out(pgp_ctx* c, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st, const double* Dk) {
+    ProfScope ps(c, PC_DIAG, 0.0, 8.0 * 3.0 * w * w, st);
+    return diag_out_launch(Dk, 2L * w, w, Fd, ldf, Ed, lde, st);
+}
+int diag_block_factor(pgp_ctx* c, const double* src, long lds, int w, double* Fd, long ldf, double* Ed, long lde,
+                      int info_base, hipStream_t st, hipEvent_t staged) {
+    CHK(diag_block_factor_in(c, src, lds, w, info_base, st, staged, c->Dk));
+    return diag_block_out(c, w, Fd, ldf, Ed, lde, st, c->Dk);
 }
 
 // D(p): the diagonal block of columns [s0, s1) (block units), src = its (updated) image with leading dim lds
@@ -741,15 +750,24 @@ static int diag_factor(pgp_ctx* c, const SweepMat& m, int s0, int s1, const doub
     return diag_block_factor(c, src, lds, (s1 - s0) * 128, m.F + (long)s0 * 128 * (1 + m.ldf), m.ldf,
                              (m.E && !m.dense2) ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, s0 * 128, st, staged);
 }
+// D(p) in two halves (s_pan_out): stage-in + leaf chain in the scratch Dk, and -- later, on a stream of the caller's choice -- the stage-out
+static int diag_factor_in(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* src, long lds, hipStream_t st, double* Dk) {
+    return diag_block_factor_in(c, src, lds, (s1 - s0) * 128, s0 * 128, st, nullptr, Dk);
+}
+static int diag_factor_out(pgp_ctx* c, const SweepMat& m, int s0, int s1, hipStream_t st, const double* Dk) {
+    return diag_block_out(c, (s1 - s0) * 128, m.F + (long)s0 * 128 * (1 + m.ldf), m.ldf,
+                          (m.E && !m.dense2) ? m.E + (long)s0 * 128 * (1 + m.lde) : nullptr, m.lde, st, Dk);
+}
 
 // S(p): rows below the diagonal block of panel [s0, s1):  Y = X E_D, X read from the staging buffer (logical rows, ldx)
-static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* Xs, long ldx, hipStream_t st) {
+static int solve_below(pgp_ctx* c, const SweepMat& m, int s0, int s1, const double* Xs, long ldx, hipStream_t st,
+                       const double* Dk = nullptr) {
     const int w = (s1 - s0) * 128;
     const long r0 = (long)s1 * 128, r1 = m.mrows + m.rows2(s0);
     if (r1 <= r0) return PGP_OK;
     GemmArgs g{};
     g.A = Xs + r0; g.lda = ldx; g.a_kc = 0;
-    g.B = c->Dk + w; g.ldb = 2L * w; g.b_kc = 1;              // B(n,k) = E_D(k,n): K-contiguous
+    g.B = (Dk ? Dk : c->Dk) + w; g.ldb = 2L * w; g.b_kc = 1;  // B(n,k) = E_D(k,n): K-contiguous
     g.C = m.F + r0 + (long)s0 * 128 * m.ldf; g.ldc = m.ldf;
     if (m.E && r1 > m.mrows) { g.C2 = m.E + (long)s0 * 128 * m.lde; g.ldc2 = m.lde; g.c_split = (int)(m.mrows - r0); }
     g.M = (int)(r1 - r0); g.N = w; g.K = w; g.alpha = 1.0; g.beta = 0.0;
@@ -912,8 +930,12 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // ... and from N = 4096 on (measured: N = 2048 1.267 -> 1.313 ms, N = 4096 2.94 -> 2.88, N = 8192 11.13 -> 10.90)
     const bool sched2 = la && sched_eff == 2 && !m.dense2 && m.E != nullptr && ((q <= 4 && nblk >= 32 && nblk < 72) || c->sched2_wide);     // N = 6144: 6.08 -> 5.78 ms; N = 10240: 19.67 -> 19.76
     const bool span = sched2 && !c->leaf_first && (c->s_pan > 0 || (c->s_pan < 0 && nblk >= 60));
+    // the stage-out of D(p) off the chain; the scratch is double-buffered by panel parity (2w x w doubles each, w <= 512: the two
+    // halves of c->Dk), so that D(p+1) may stage in while S(p) / the stage-out of D(p) still read D(p)'s
+    const bool span_out = span && c->s_pan_out && q <= 4;
+    auto Dkp = [&](int p) -> double* { return span_out ? c->Dk + (size_t)(p & 1) * 1024 * 1024 : c->Dk; };
     if (span)
-        while ((int)c->la_ev.size() < 4 * npanel + 4) {
+        while ((int)c->la_ev.size() < 5 * npanel + 5) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             c->la_ev.push_back(e);
@@ -953,13 +975,18 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     } else
     for (int p = 0; p < npanel; ++p) {
         const int s0 = p * q, s1 = std::min(s0 + q, nblk);
+        if (span_out && p >= 1) {
+            // s_pan_out: D(p)'s stage-out (L_D -> F, E_D -> E; S(p) reads E_D from the scratch) is off the chain: it runs on the main stream
+            // (which has waited for D(p)'s leaf chain) beside S(p), ahead of TU_r(p) -- the first reader of E_D's copy in E
+            CHK(diag_factor_out(c, m, s0, s1, main, Dkp(p)));
+        }
         if (span && p >= 1) {
             // s_pan: S(p) does not wait for the END of the paired launch of panel p - 1 (which D(p) beats by ~35 us): it follows
             // D(p) on the panel stream and runs in that launch's tail.  It reads the staging rows TU_r(p-1) wrote (main stream)
             HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * npanel + 2 + 2 * (p - 1)], 0));
             const int was = c->chain_now;
             c->chain_now = c->s_pan == 2 ? 1 : was;
-            const int rc = solve_below(c, m, s0, s1, Xs, ldx, pan);
+            const int rc = solve_below(c, m, s0, s1, Xs, ldx, pan, Dkp(p));
             c->chain_now = was;
             CHK(rc);
             HIP_TRY(hipEventRecord(c->la_ev[2 * npanel + 3 + 2 * (p - 1)], pan));
@@ -975,8 +1002,14 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
             // on a CU lasts as long as the whole of TU_a) goes to the panel stream right behind S(p), the rectangle below it
             // stays on the main stream: D(p+1) starts ~50 us earlier, and its first kernels find free slots beside the
             // one-workgroup-per-CU rectangle instead of the first wave of the bulk launch
+            if (span && p >= 1 && c->s_pan_direct) {
+                // S(p) sits on the panel stream already: the piece only needs the paired launch of panel p - 1 (its event), not a
+                // round trip through the main stream's wait for S(p) (26 us between S(p) and the piece before)
+                HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[4 * npanel + 4 + (p - 1)], 0));
+            } else {
             HIP_TRY(hipEventRecord(c->la_ev[2 * p], main));
             HIP_TRY(hipStreamWaitEvent(pan, c->la_ev[2 * p], 0));
+            }
             {
                 const int was = c->chain_now;
                 c->chain_now = c->tud_mark ? 1 : was;
@@ -996,6 +1029,8 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
         // leaf_first: the trailing update is held back until D(p+1)'s stage-in is done, so that the first leaf is dispatched
         // BEFORE the update's first wave takes every workgroup slot (a leaf dispatched into that wave waits ~140 us for it)
         const bool lf = la && c->leaf_first;
+        if (span_out) CHK(diag_factor_in(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan, Dkp(p + 1)));
+        else
         CHK(diag_factor(c, m, n0, n1, Xs + (long)n0 * 128, ldx, pan, lf ? c->la_ev[2 * npanel + (p & 1)] : nullptr));
         if (lf) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * npanel + (p & 1)], 0));
         if (la) HIP_TRY(hipEventRecord(c->la_ev[2 * p + 1], pan));
@@ -1012,6 +1047,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
             if (fill_now) CHK(eet_panel(c, m, p == pf ? 0 : s0, s1, c->eet_out, c->eet_ld, main));
         }
         if (fill2) CHK(rhs_product(s0, s1));
+        if (span) HIP_TRY(hipEventRecord(c->la_ev[4 * npanel + 4 + p], main));          // TU_b(p) [+ E E'(p)] queued: what TU_d(p+1) waits for
         if (la) HIP_TRY(hipStreamWaitEvent(main, c->la_ev[2 * p + 1], 0));
     }
     if (fill_inline) {

@@ -69,6 +69,8 @@ struct pgp_ctx {
     int s_pan = -1;                     // sched 2: S(p), p >= 1, on the panel stream right behind D(p): it runs in the tail of the previous
                                         // paired launch instead of after it (1; 2 = marked like the chain's products; 0 = on the main stream;
                                         // -1 = from N = 7680 on: N = 8192 10.84 -> 10.65 ms, 7680 9.45 -> 9.22, 7168 neutral, 4096 / 6144 +2.5 %)
+    int s_pan_direct = 1;               // s_pan: TU_d(p) waits for the paired launch of panel p - 1 by its own event (0: through the main stream)
+    int s_pan_out = 1;                  // s_pan: D(p)'s stage-out on the main stream beside S(p) instead of on the chain (scratch double-buffered)
     int tud_mark = 1;                   // sched 2: that piece marks its CUs like the chain's own products (yield role 2)
     int leaf_pivot = 2;                 // 2: register-resident leaf (panel.hip leaf_potrf_reg_kernel); 1: the LDS leaf with its 16 x 16 pivot blocks on
                                         // the matrix cores (pivot_block_mfma); 0: the LDS leaf, pivot blocks lane per row

@@ -262,7 +262,7 @@ def test_shrinking_batched_trailing_update(lib):
                                   dict(sched=1, pair_launch=0, eet_overlap=2), dict(sched=1, eet_overlap=0),
                                   dict(sched=2), dict(sched=2, tud_tile=128, tud_mark=1), dict(sched=2, nb_outer=6, leaf_pivot=0),
                                   dict(sched=2, pair_launch=0, eet_overlap=0, nb_outer=8), dict(leaf_pivot=0), dict(leaf_pivot=1),
-                                  dict(s_pan=0), dict(s_pan=1), dict(s_pan=2), dict(sched=2, s_pan=1, nb_outer=6), dict(s_pan=1, pair_launch=0, eet_overlap=0)])
+                                  dict(s_pan=0), dict(s_pan=1), dict(s_pan=2), dict(sched=2, s_pan=1, nb_outer=6), dict(s_pan=1, pair_launch=0, eet_overlap=0), dict(s_pan=1, s_pan_direct=0), dict(s_pan=1, s_pan_out=0), dict(s_pan=2, s_pan_out=1, pair_launch=0)])
 def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
     """The kept schedule options of the Cholesky sweep -- without the cooperative yield of the bulk workgroups, the trailing
     update held back until D(p+1)'s stage-in / third chain kernel, the serial order, B^-1 = E E^T as one product after the sweep or as panel products behind every trailing update, tile
@@ -292,7 +292,7 @@ def test_cholesky_sweep_variants_agree_with_the_reference(lib, opts):
             lib.pgp_set_option(ctx, k.encode(), {"lookahead": 1, "leaf_first": 0, "yield": 1, "eet_overlap": 3, "eet_tile": 128, "s_tile": 0,
                                                  "eet_first": -1, "small_tile_below": 200, "xcd_order": 0, "xcd_super": 8,
                                                  "xcd_min_tiles": 256, "gemm_dbg": 64 | 256 | 512, "pair_launch": 1, "leaf_pivot": 2, "sched": -1,
-                                                 "tud_tile": 64, "s_pan": -1}.get(k, 0))
+                                                 "tud_tile": 64, "s_pan": -1, "s_pan_direct": 1, "s_pan_out": 1}.get(k, 0))
 
 
 def test_exact_fit_golden_G7_ard_d64(lib):
