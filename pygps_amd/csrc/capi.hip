@@ -929,7 +929,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // 18.0 ms per fit with sched 2)
     // ... and from N = 4096 on (measured: N = 2048 1.267 -> 1.313 ms, N = 4096 2.94 -> 2.88, N = 8192 11.13 -> 10.90)
     const bool sched2 = la && sched_eff == 2 && !m.dense2 && m.E != nullptr && ((q <= 4 && nblk >= 32 && nblk < 72) || c->sched2_wide);     // N = 6144: 6.08 -> 5.78 ms; N = 10240: 19.67 -> 19.76
-    const bool span = sched2 && !c->leaf_first && (c->s_pan > 0 || (c->s_pan < 0 && nblk >= 60));
+    const bool span = sched2 && !c->leaf_first && c->s_pan != 0;
     // the stage-out of D(p) off the chain; the scratch is double-buffered by panel parity (2w x w doubles each, w <= 512: the two
     // halves of c->Dk), so that D(p+1) may stage in while S(p) / the stage-out of D(p) still read D(p)'s
     const bool span_out = span && c->s_pan_out && q <= 4;

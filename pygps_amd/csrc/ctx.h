@@ -66,9 +66,10 @@ struct pgp_ctx {
                                         // (potrf_blocked_v2; lone chain at N = 8192: 11.13 -> 10.90 ms)
     int tud_tile = 64;                  // sched 2: tile size of the diagonal-block piece of TU_a on the panel stream
     int sched2_wide = 0;                // sched 2 also with panels wider than 512 columns (measured slower: N = 16384 +2 %)
-    int s_pan = -1;                     // sched 2: S(p), p >= 1, on the panel stream right behind D(p): it runs in the tail of the previous
-                                        // paired launch instead of after it (1; 2 = marked like the chain's products; 0 = on the main stream;
-                                        // -1 = from N = 7680 on: N = 8192 10.84 -> 10.65 ms, 7680 9.45 -> 9.22, 7168 neutral, 4096 / 6144 +2.5 %)
+    int s_pan = -1;                     // sched 2: S(p), p >= 1, on the panel stream right behind D(p)'s leaf chain: it runs in the tail of the
+                                        // previous paired launch instead of after it (-1 / 1 = on; 2 = on and marked like the chain's products;
+                                        // 0 = on the main stream).  With s_pan_direct and s_pan_out: N = 8192 10.93 -> 10.53 ms, 7168 7.91 -> 7.80,
+                                        // 6144 5.71 -> 5.61, 5120 neutral, 4096 2.84 -> 2.78
     int s_pan_direct = 1;               // s_pan: TU_d(p) waits for the paired launch of panel p - 1 by its own event (0: through the main stream)
     int s_pan_out = 1;                  // s_pan: D(p)'s stage-out on the main stream beside S(p) instead of on the chain (scratch double-buffered)
     int tud_mark = 1;                   // sched 2: that piece marks its CUs like the chain's own products (yield role 2)
