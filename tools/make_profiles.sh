@@ -59,7 +59,8 @@ bash $R/tools/gemm_pmc.sh > /dev/null 2>&1; cp $R/gpurun_out/gemm_pmc.txt $O/fin
 # 7. timeline of one single-stream fit: sched 0 (rounds 2-4), sched 1 (critical path on the panel stream), sched 2 (the default for a lone chain)
 bash $R/tools/fit_trace.sh fit_timeline sched=0 > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline.txt $O/final/r05_fit_timeline.txt
 bash $R/tools/fit_trace.sh fit_timeline_sched1 sched=1 > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline_sched1.txt $O/final/r05_fit_timeline_sched1.txt
-bash $R/tools/fit_trace.sh fit_timeline_sched2 sched=2 > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline_sched2.txt $O/final/r05_fit_timeline_sched2.txt
+bash $R/tools/fit_trace.sh fit_timeline_sched2 sched=2 s_pan=0 > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline_sched2.txt $O/final/r05_fit_timeline_sched2.txt
+bash $R/tools/fit_trace.sh fit_timeline_sched2_s_pan sched=2 > /dev/null 2>&1; cp $R/gpurun_out/fit_timeline_sched2_s_pan.txt $O/final/r05_fit_timeline_sched2_s_pan.txt
 # 8. round 5: the Gram-form assembly kernels (general / restructured / four workgroups per CU), sched 0 / 1 alternated, the leaf's phases
 ( python $R/tools/gram_probe.py -- "gram_fast=0,gram_grid=2048" "gram_fast=1,gram_grid=2048" "gram_fast=2,gram_grid=8192" "gram_fast=2,gram_grid=32768";
   python $R/tools/gram_probe.py d=32 -- "gram_fast=0,gram_grid=2048" "gram_fast=2,gram_grid=32768" ) > $O/final/r05_gram_probe.txt 2> $O/gram.err
