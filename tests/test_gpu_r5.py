@@ -285,3 +285,46 @@ def test_getCovMatrix_train_at_cfg3_size_in_the_gram_form(lib):
         finally:
             lib.pgp_set_option(ctx, b"gram_assembly", 1)
         assert np.array_equal(K3, K4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [4096, 4608, 5120, 8064, 9088])
+def test_s_pan_schedule_is_bit_identical_to_the_main_stream_solve(lib, N):
+    """End of round 5: under sched=2 the panel solve S(p) runs on the panel stream behind D(p)'s leaf chain, TU_d waits for the paired
+    launch by its own event and D's stage-out runs on the main stream from a double-buffered scratch (csrc/capi.hip potrf_blocked_v2,
+    options s_pan / s_pan_direct / s_pan_out).  Same kernels, same per-tile order: every output of Exact.evaluate
+    (Core/inf.py:353-384) -- nlZ, alpha, dnlZ, the factor -- must equal the s_pan=0 schedule's BIT FOR BIT, at even and odd panel
+    counts (N = 4608: 9 panels, 5120: 10) and with a partial last panel (N = 8064 = 15.75 panels, 9088 = 17.75)."""
+    import ctypes as C
+    from pygps_amd import _lib
+    d = 16
+    x, y = synth_reg(N, d, seed=N)
+    x = _lib.f64(x); y = _lib.f64(y).ravel()
+    hyp = _lib.f64(np.array([np.log(np.sqrt(d)), 0.2])); m = np.full(N, float(y.mean())); dm = np.ones((1, N))
+    ctx = _lib.ctx()
+    _lib.check(lib.pgp_set_data(ctx, _lib.ptr(x), N, d, _lib.ptr(y)))
+    res = {}
+    sets = {"off": dict(sched=2, s_pan=0), "on": dict(sched=2, s_pan=1), "marked": dict(sched=2, s_pan=2),
+            "no_direct": dict(sched=2, s_pan=1, s_pan_direct=0), "no_out": dict(sched=2, s_pan=1, s_pan_out=0)}
+    try:
+        for name, opts in sets.items():
+            for k, v in dict(s_pan=-1, s_pan_direct=1, s_pan_out=1).items():
+                _lib.check(lib.pgp_set_option(ctx, k.encode(), v))
+            for k, v in opts.items():
+                _lib.check(lib.pgp_set_option(ctx, k.encode(), v))
+            for rep in range(2):
+                alpha = np.zeros(N); nlZ = np.zeros(1); g = np.zeros(4); fh = C.c_void_p()
+                _lib.check(lib.pgp_exact_fit(ctx, 0, _lib.ptr(hyp), 2, 0, 0, float(np.log(0.1)), _lib.ptr(m), _lib.ptr(dm), 1, 3,
+                                             _lib.ptr(alpha), _lib.ptr(nlZ), _lib.ptr(g), C.byref(fh)))
+                L = np.zeros((N, N))
+                _lib.check(lib.pgp_factor_to_host(ctx, fh, _lib.ptr(L)))
+                lib.pgp_factor_free(ctx, fh)
+                res[name, rep] = (nlZ.copy(), alpha.copy(), g.copy(), np.tril(L))
+    finally:
+        for k, v in dict(sched=-1, s_pan=-1, s_pan_direct=1, s_pan_out=1).items():
+            lib.pgp_set_option(ctx, k.encode(), v)
+    ref = res["off", 0]
+    assert np.isfinite(ref[0]).all() and np.isfinite(ref[1]).all()
+    for key, got in res.items():
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), key
