@@ -302,6 +302,18 @@ def test_bench_line_contract_small(lib):
               "predict_ns65536_ms", "cfg4_as_written_fits_per_s_per_gpu"):
         assert k in r, k
     assert r["single_stream_fits_per_s"] > 0 and r["cfg4_as_written_fits_per_s_per_gpu"] > 0
+    # the driver's record keeps only the leading members: the contract members and every north-star scalar are the FIRST keys
+    sys.path.insert(0, root)
+    import bench
+    head = list(r)[:len(bench.ROOFLINE_HEAD)]
+    assert head == list(bench.ROOFLINE_HEAD) and len(head) <= 24
+    first20 = list(r)[:20]
+    for k in ("frac", "traffic", "assembly_full_N16384_frac_of_hbm_peak", "assembly_SEard_d64_N16384_frac_of_hbm_peak",
+              "cholesky_sweep_N16384_frac_of_peak", "single_stream_ms_per_fit", "cfg4_as_written_fits_per_s_per_gpu", "cfg3_fit_ms",
+              "cfg5_fit_ms", "predict_ns65536_ms", "sharded_fit_wait_share"):
+        assert k in first20, (k, first20)
+    assert not any(k.endswith("_what") or k.endswith("_sched0") or k in ("how", "traffic_source") for k in r)
+    assert "how" in j["roofline_detail"] and len(j["roofline_detail"]["kernel"]) > 120
     assert isinstance(j["roofline_detail"]["timed_window"], dict) and r["timed_window_frac_of_peak"] > 0
 
 

@@ -267,3 +267,27 @@ def test_bench_cpu_baselines_of_the_other_configs_are_labelled_extrapolations():
         assert "EXTRAPOLATED" in v["sample"] or "derived" in v["sample"]
     assert "2969 s" in out["cfg3"]["reference_recorded"] and "43 min" in out["cfg5"]["reference_recorded"]
     assert out["cfg4"]["value"] == 0.021
+
+
+def test_bench_roofline_head_order_is_what_the_driver_record_keeps():
+    """bench.flatten_roofline: the contract members and the north-star scalars lead `roofline` in ROOFLINE_HEAD's order (the driver's
+    record keeps the leading members only); long strings, `*_what`, the sched-0 diagnostics and nested objects go to the detail."""
+    import bench
+    roof = {"kernel": "k" * 300, "bound": "mfma", "achieved": 55.0, "peak": 78.6, "unit": "TFLOP/s", "frac": 0.7, "traffic": 8.1e8,
+            "traffic_source": "t" * 200, "how": "h" * 200, "launches_per_fit": 31.0, "cholesky_sweep_what": "short", "cholesky_sweep_frac_of_peak": 0.6,
+            "frac_sched0": 0.71, "timed_window": {"frac_of_peak": 0.76, "streams": 2}, "factor_inverse_EEt": {"ms": 9.0, "frac_of_peak": 0.7},
+            "assembly_full_N16384": {"ms": 0.43, "frac_of_hbm_peak": 0.63, "stores_alone_frac_of_hbm_peak": 0.66},
+            "assembly_full_N16384_SEard_d64": {"ms": 0.5, "frac_of_hbm_peak": 0.5, "frac_of_fp64_pipe": 0.8},
+            "cholesky_sweep_N16384": {"ms": 47.0, "frac_of_peak": 0.79, "fit_ms": 67.0}, "assembly_fused_frac_of_hbm_peak": 0.4}
+    out = {"roofline": roof, "single_stream_ms_per_fit": 10.5, "single_stream_fits_per_s": 95.0, "per_gpu_fits_per_s": 108.0,
+           "cfg4_as_written_fits_per_s_per_gpu": 95.0, "cfg4_as_written_fits_per_s": 95.0, "cfg3_seard_N16384_d64": {"fit_ms": 70.0},
+           "cfg5_ep_N4096_d32": {"fit_ms": 17.0, "sweeps": 4}, "predict_N8192_ns65536": {"ms": 78.0, "device_ms": 60.0},
+           "sharded_fit": {"wait_share": 0.01, "n": 65536}}
+    flat, detail = bench.flatten_roofline(out)
+    keys = list(flat)
+    assert keys[:len(bench.ROOFLINE_HEAD)] == list(bench.ROOFLINE_HEAD) and len(bench.ROOFLINE_HEAD) <= 24
+    assert all(flat[k] is not None for k in bench.ROOFLINE_HEAD), [k for k in bench.ROOFLINE_HEAD if flat[k] is None]
+    assert flat["frac"] == 0.7 and flat["predict_ns65536_device_ms"] == 60.0 and flat["two_stream_fits_per_s_per_gpu"] == 108.0
+    assert all(not isinstance(v, (dict, list)) for v in flat.values()) and all(len(v) <= 120 for v in flat.values() if isinstance(v, str))
+    assert "how" not in flat and "frac_sched0" not in flat and "cholesky_sweep_what" not in flat
+    assert detail["kernel"] == "k" * 300 and detail["how"] and detail["frac_sched0"] == 0.71 and isinstance(detail["timed_window"], dict)
