@@ -2,7 +2,7 @@
 
 The restart search (pyGPs/Core/opt.py:301-327 sharded over GPUs), the K-fold loop (pyGPs/Validation/valid.py:20-66) and
 the RCCL rendezvous of ``sharded.Comm`` exchange a 128-byte id, one table, the data and one record per work item.  A pyGPs
-user should not need ``torch`` for that: ``HostGroup`` is ~200 lines of sockets -- rank 0 listens on
+user should not need ``torch`` for that: ``HostGroup`` is ~250 lines of sockets and fixed binary frames (no pickle: nothing received is ever evaluated) -- rank 0 listens on
 ``MASTER_ADDR:MASTER_PORT`` (the variables ``torchrun`` / any launcher exports), every other rank keeps ONE connection
 to it, and rank 0 serves
 
@@ -15,8 +15,9 @@ It serves two purposes: (i) the side channel that carries RCCL's unique id to ``
 call-backs of the library's host transport (``pgp_comm_init_host``), so that several ranks can share ONE GPU in tests.
 No data-path traffic of a fit ever goes through it.
 """
+import hashlib
+import hmac
 import os
-import pickle
 import socket
 import struct
 import threading
@@ -24,10 +25,29 @@ import time
 
 import numpy as np
 
+# ---- wire format: fixed binary frames, nothing on the wire is ever evaluated ------------------------------------------
+# header  <4s B B B B Q q Q 6Q> = magic, kind, op, dtype, ndim, seq, arg, nbytes, shape[6]   (84 bytes), then `nbytes` raw bytes
+#   kind   HELLO (arg = rank, payload = the token)  COLL (op, arg = root, payload = the array)  TICKET (payload = the name, utf-8)
+#          BYE  OK (COLL: the combined array; TICKET: arg = the value)  ERR (payload = the message, utf-8)
+#   dtype  0 = no array (barrier, a non-root's bcast contribution), else an index into _DTYPES
+# A frame that does not parse (magic, kind, dtype, ndim, a payload size that is not shape x itemsize or above the cap) closes
+# the connection.  The hello is read under a timeout and carries HMAC-SHA256(secret, "pygps_amd.hostgroup|world|rank") when
+# PYGPS_AMD_GROUP_SECRET is set (every rank must then share it); rank 0 binds the address the launcher exported (127.0.0.1
+# for a single node).
+_MAGIC = b"PGHG"
+_HDR = struct.Struct("<4sBBBBQqQ6Q")
+_HELLO, _COLL, _TICKET, _BYE, _OK, _ERR = 1, 2, 3, 4, 5, 6
+_OPS = ("bcast", "barrier", "sum", "max", "gather")
+_DTYPES = (None, np.dtype("<f8"), np.dtype("u1"), np.dtype("<i8"), np.dtype("<f4"), np.dtype("<i4"), np.dtype("<u8"))
+_CODE = {dt.str: i for i, dt in enumerate(_DTYPES) if dt is not None}     # by name: `None == np.dtype("f8")` is True in numpy
+_MAX_PAYLOAD = 1 << 32                                  # 4 GiB: far above X, y and any record table; a bound, not a feature
 
-def _send(sock, obj):
-    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
-    sock.sendall(struct.pack("<Q", len(data)) + data)
+
+def _token(world, rank):
+    secret = os.environ.get("PYGPS_AMD_GROUP_SECRET", "")
+    if not secret:
+        return b""
+    return hmac.new(secret.encode(), b"pygps_amd.hostgroup|%d|%d" % (world, rank), hashlib.sha256).digest()
 
 
 def _recv_exact(sock, n):
@@ -40,9 +60,39 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
-def _recv(sock):
-    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+def _send_frame(sock, kind, op=0, seq=0, arg=0, arr=None, raw=b""):
+    """One frame: an array (`arr`) or raw bytes (`raw`), never both."""
+    if arr is not None:
+        a = np.ascontiguousarray(arr)
+        if a.dtype.str not in _CODE:
+            a = a.astype(np.float64)                   # anything else numeric travels as float64 (bool / small ints are exact)
+        if a.ndim > 6:
+            raise ValueError("pygps_amd.hostgroup: at most 6 dimensions")
+        code = _CODE[a.dtype.str]
+        shape = tuple(a.shape) + (0,) * (6 - a.ndim)
+        payload = a.tobytes()
+        hdr = _HDR.pack(_MAGIC, kind, op, code, a.ndim, seq, int(arg), len(payload), *shape)
+    else:
+        payload = bytes(raw)
+        hdr = _HDR.pack(_MAGIC, kind, op, 0, 0, seq, int(arg), len(payload), 0, 0, 0, 0, 0, 0)
+    sock.sendall(hdr + payload)
+
+
+def _recv_frame(sock):
+    """(kind, op, seq, arg, array or None, raw bytes)."""
+    magic, kind, op, code, ndim, seq, arg, nbytes, *shape = _HDR.unpack(_recv_exact(sock, _HDR.size))
+    if magic != _MAGIC or not _HELLO <= kind <= _ERR or code >= len(_DTYPES) or ndim > 6 or nbytes > _MAX_PAYLOAD or op >= len(_OPS):
+        raise ConnectionError("pygps_amd.hostgroup: malformed frame")
+    if code == 0:
+        return kind, op, seq, arg, None, _recv_exact(sock, nbytes) if nbytes else b""
+    dt = _DTYPES[code]
+    count = 1
+    for s_ in shape[:ndim]:
+        count *= s_
+    if count * dt.itemsize != nbytes:
+        raise ConnectionError("pygps_amd.hostgroup: malformed frame (shape x itemsize != payload)")
+    a = np.frombuffer(_recv_exact(sock, nbytes), dtype=dt).reshape(shape[:ndim]).copy()
+    return kind, op, seq, arg, a, b""
 
 
 class HostGroup(object):
@@ -81,11 +131,16 @@ class HostGroup(object):
                     raise TimeoutError("pygps_amd.hostgroup: %d of %d ranks connected to %s:%d within %.0f s"
                                        % (len(self._conns) + 1, self.world, addr, self.port, self.timeout))
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.settimeout(None)
-                r = _recv(c)
-                if not isinstance(r, int) or r <= 0 or r >= self.world or r in seen:
+                c.settimeout(max(0.1, min(10.0, deadline - time.time())))   # a connector that says nothing is dropped, not waited for
+                try:
+                    kind, _, _, r, _, tok = _recv_frame(c)
+                except (ConnectionError, OSError, struct.error):
                     c.close()
-                    raise RuntimeError("pygps_amd.hostgroup: unexpected hello %r" % (r,))
+                    continue
+                if kind != _HELLO or r <= 0 or r >= self.world or r in seen or not hmac.compare_digest(tok, _token(self.world, r)):
+                    c.close()                           # not one of ours (or a wrong secret): keep listening until the deadline
+                    continue
+                c.settimeout(None)
                 seen.add(r)
                 self._conns.append(c)
                 th = threading.Thread(target=self._serve, args=(c, r), daemon=True)
@@ -104,7 +159,7 @@ class HostGroup(object):
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(None)
-            _send(s, self.rank)
+            _send_frame(s, _HELLO, arg=self.rank, raw=_token(self.world, self.rank))
             self._sock = s
 
     @classmethod
@@ -168,19 +223,20 @@ class HostGroup(object):
     def _serve(self, conn, rank):
         try:
             while True:
-                msg = _recv(conn)
-                kind = msg[0]
-                if kind == "coll":
-                    _, seq, op, arg, payload = msg
+                kind, op, seq, arg, payload, raw = _recv_frame(conn)
+                if kind == _COLL:
                     try:
-                        _send(conn, ("ok", self._deposit(seq, op, arg, rank, payload)))
+                        res = self._deposit(seq, _OPS[op], arg, rank, payload)
+                        _send_frame(conn, _OK, op, seq, arr=res)
                     except Exception as e:             # the peer gets the error instead of a hang
-                        _send(conn, ("err", repr(e)))
-                elif kind == "ticket":
-                    _send(conn, ("ok", self._ticket_local(msg[1])))
-                elif kind == "bye":
+                        _send_frame(conn, _ERR, op, seq, raw=repr(e).encode())
+                elif kind == _TICKET:
+                    _send_frame(conn, _OK, seq=seq, arg=self._ticket_local(raw.decode("utf-8", "replace")))
+                elif kind == _BYE:
                     return
-        except (ConnectionError, OSError, EOFError):
+                else:
+                    return                              # a peer never sends HELLO / OK / ERR here: drop the connection
+        except (ConnectionError, OSError, EOFError, struct.error):
             return
 
     # ---- every rank ---------------------------------------------------------------------------------------------------
@@ -192,10 +248,10 @@ class HostGroup(object):
             self._seq += 1
             if self.rank == 0:
                 return self._deposit(seq, op, arg, 0, payload)
-            _send(self._sock, ("coll", seq, op, arg, payload))
-            status, res = _recv(self._sock)
-            if status != "ok":
-                raise RuntimeError("pygps_amd.hostgroup: %s" % res)
+            _send_frame(self._sock, _COLL, _OPS.index(op), seq, 0 if arg is None else arg, arr=payload)
+            kind, _, rseq, _, res, raw = _recv_frame(self._sock)
+            if kind != _OK or rseq != seq:
+                raise RuntimeError("pygps_amd.hostgroup: %s" % (raw.decode("utf-8", "replace") if kind == _ERR else "reply out of sequence"))
             return res
 
     def bcast(self, arr, root=0):
@@ -229,8 +285,10 @@ class HostGroup(object):
         if self.world == 1 or self.rank == 0:
             return self._ticket_local(name)
         with self._lock:
-            _send(self._sock, ("ticket", name))
-            status, v = _recv(self._sock)
+            _send_frame(self._sock, _TICKET, raw=str(name).encode("utf-8"))
+            kind, _, _, v, _, raw = _recv_frame(self._sock)
+            if kind != _OK:
+                raise RuntimeError("pygps_amd.hostgroup: %s" % raw.decode("utf-8", "replace"))
             return v
 
     def __deepcopy__(self, memo):
@@ -256,7 +314,7 @@ class HostGroup(object):
                 self._srv.close()
             else:
                 try:
-                    _send(self._sock, ("bye",))
+                    _send_frame(self._sock, _BYE)
                 except OSError:
                     pass
                 self._sock.close()

@@ -158,3 +158,77 @@ def test_multi_dataset_objective_sharded_without_torch(tmp_path):
         assert np.allclose(z["each"], each, rtol=1e-14) and abs(float(z["tot"]) - each.sum()) < 1e-12 * each.sum()
         assert np.allclose(z["g"], g, rtol=1e-13)
     assert sorted(int(z["calls"]) for z in rs) == [2, 3]                          # 5 data sets over 2 ranks
+
+
+def test_hostgroup_wire_is_fixed_frames_and_survives_strangers(tmp_path):
+    """nothing received is unpickled.  A stranger that connects and sends a pickle, one that sends nothing and one
+    with a wrong secret are dropped while the rendezvous goes on; the real rank (right secret) gets its collectives."""
+    import pickle
+    import threading
+    import time
+    from pygps_amd import hostgroup
+    src = open(hostgroup.__file__).read()
+    assert "import pickle" not in src and "pickle.loads" not in src
+    port = _free_port()
+    os.environ["PYGPS_AMD_GROUP_SECRET"] = "s3cret"
+    try:
+        res = {}
+
+        def rank0():
+            g = hostgroup.HostGroup(0, 2, "127.0.0.1", port, timeout=60.0)
+            res["sum"] = g.allreduce(np.array([1.0, 2.0]), "sum")
+            res["t"] = g.ticket("x")
+            g.barrier()
+            g.close()
+        th = threading.Thread(target=rank0)
+        th.start()
+
+        def connect():
+            for _ in range(200):
+                try:
+                    return socket.create_connection(("127.0.0.1", port), timeout=5.0)
+                except OSError:
+                    time.sleep(0.05)
+            raise AssertionError("rank 0 never listened")
+        bad = connect()
+        bad.sendall(struct_pack_q(1 << 20) + pickle.dumps(("coll", 0, "sum", None, np.ones(3))))     # the round-5 wire format
+        silent = connect()                                                                            # says nothing
+        wrong = connect()
+        hostgroup._send_frame(wrong, hostgroup._HELLO, arg=1, raw=b"\x00" * 32)                       # wrong token
+        time.sleep(0.3)
+        g1 = hostgroup.HostGroup(1, 2, "127.0.0.1", port, timeout=60.0)
+        s1 = g1.allreduce(np.array([10.0, 20.0]), "sum")
+        t1 = g1.ticket("x")
+        g1.barrier()
+        g1.close()
+        th.join(timeout=60.0)
+        assert not th.is_alive()
+        for s_ in (bad, silent, wrong):
+            s_.close()
+        assert np.array_equal(s1, [11.0, 22.0]) and np.array_equal(res["sum"], [11.0, 22.0]) and {t1, res["t"]} == {0, 1}
+    finally:
+        del os.environ["PYGPS_AMD_GROUP_SECRET"]
+
+
+def struct_pack_q(n):
+    import struct
+    return struct.pack("<Q", n)
+
+
+def test_hostgroup_frame_rejects_inconsistent_headers():
+    from pygps_amd import hostgroup
+    a, b = socket.socketpair()
+    try:
+        hostgroup._send_frame(a, hostgroup._COLL, 2, 7, 0, arr=np.arange(6, dtype=np.int64).reshape(2, 3))
+        kind, op, seq, arg, arr, raw = hostgroup._recv_frame(b)
+        assert (kind, op, seq) == (hostgroup._COLL, 2, 7) and arr.dtype == np.int64 and arr.shape == (2, 3) and arr[1, 2] == 5
+        hdr = hostgroup._HDR.pack(b"PGHG", hostgroup._COLL, 0, 1, 1, 0, 0, 16, 3, 0, 0, 0, 0, 0)    # 3 doubles announced, 16 bytes of payload
+        a.sendall(hdr + b"\x00" * 16)
+        with pytest.raises(ConnectionError):
+            hostgroup._recv_frame(b)
+        a.sendall(hostgroup._HDR.pack(b"XXXX", 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+        with pytest.raises(ConnectionError):
+            hostgroup._recv_frame(b)
+    finally:
+        a.close()
+        b.close()
