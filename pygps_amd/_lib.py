@@ -237,8 +237,9 @@ class fit_stream(object):
 
 class concurrent_fit_streams(object):
     """`with concurrent_fit_streams(): ...` inside `fit_stream(k)` when SEVERAL fit streams of one GPU run at the same time: the
-    context's Cholesky sweep then keeps its critical path (D -> S -> TU_a) on the panel stream beside the bulk updates (option
-    `sched` = 1; bit-identical results).  Measured, alternated in one process (profiles/r05_sched_ab_and_leaf_ticks.txt and three
+    context's Cholesky sweep then keeps its critical path (D -> S -> TU_a) on the panel stream beside the bulk updates (the hint
+    `concurrent_streams`: the sweep then runs as under `sched` = 1 UNLESS the caller has set `sched` explicitly -- an explicit
+    setting is neither overridden nor lost on exit; bit-identical results).  Measured, alternated in one process (profiles/r05_sched_ab_and_leaf_ticks.txt and three
     more boxes): two fit streams +0.6 ... +2 % fits/s, a lone chain -3 % -- hence only while streams run side by side."""
 
     def __enter__(self):
@@ -251,13 +252,15 @@ class concurrent_fit_streams(object):
 
     def _use(self, key, h):
         if key not in self.used:
-            load().pgp_set_option(h, b"sched", 1)
+            load().pgp_set_option(h, b"concurrent_streams", 1)
             self.used[key] = h
 
     def __exit__(self, *exc):
         _tls.concurrent = self.prev
-        for h in self.used.values():
-            load().pgp_set_option(h, b"sched", -1)            # back to the library's default for a lone chain
+        for key, h in self.used.items():
+            if self.prev is not None and key in self.prev.used:
+                continue                                     # an enclosing scope still runs streams side by side on this context
+            load().pgp_set_option(h, b"concurrent_streams", 0)  # the hint only: a user's own `sched` setting stays as it was
         self.used = {}
         return False
 

@@ -644,6 +644,11 @@ __global__ __launch_bounds__(256, HV == 2 ? 4 : 2) void cov_gram_fast_kernel(con
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l4 = lane >> 4, l15 = lane & 15;
     double* xr = gsm;
     double* xc = gsm + DPH * GSTP;
+    // round 6: the scalar map by table (sqdist_tile.h exp_nonpos_tab), pre-scaled by the prefactor of this mode
+    constexpr int TAB_OFF = 2 * DPH * GSTP > ST * GSTP ? 2 * DPH * GSTP : ST * GSTP;
+    const double* etab = gsm + TAB_OFF;
+    const double cpre = MODE == MODE_FACTOR ? sf2 * inv_sn2 : sf2;
+    exp_tab_fill(gsm + TAB_OFF, cpre, t);
     const int spr = lane & 31, sside = lane >> 5;
     const int wvu = __builtin_amdgcn_readfirstlane(wave);
     double* slp = (sside ? xc : xr) + 2 * spr + wvu * GSTP;
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(256, HV == 2 ? 4 : 2) void cov_gram_fast_kernel(con
     fetch(tc2, GIC<0>{}, true);
     commit(GIC<0>{});
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { nr[a] = nnr[a]; nc[a] = nnc[a]; }
+    for (int a = 0; a < 4; ++a) { nr[a] = -0.5 * nnr[a]; nc[a] = -0.5 * nnc[a]; }      // halved, negated: see the accumulators
     if (HV == 2) fetch(tc2, GIC<HV - 1>{}, false);    // the first tile's second half
     lds_barrier();
     const double* ap = xr + l4 * GSTP + 16 * wave + l15;
@@ -688,9 +693,13 @@ __global__ __launch_bounds__(256, HV == 2 ? 4 : 2) void cov_gram_fast_kernel(con
         const long next = tile + gridDim.x;
         const int2 nx = tiles[next < ntiles ? next : tile];       // always a valid tile: the body stays one basic block
         if (HV == 1) fetch(nx, GIC<0>{}, true);
+        // the accumulators start at -(|a|^2 + |b|^2) / 2: what comes out of the products is x = -r^2 / 2 itself (the same terms
+        // as |a|^2 + |b|^2 - 2 a.b, scaled by the exact factor -1/2; the diagonal is forced below)
         gram4_t acc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = gram4_t{0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[q][a] = nr[a] + nc[q];
 #pragma unroll
         for (int h = 0; h < HV; ++h) {
             if (h == 1) {
@@ -720,29 +729,43 @@ __global__ __launch_bounds__(256, HV == 2 ? 4 : 2) void cov_gram_fast_kernel(con
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long r = r0 + 16 * wave + 4 * a + l4, c = c0 + 16 * q + l15;
-                double s2 = fmax(fma(-2.0, acc[q][a], nr[a] + nc[q]), 0.0);
-                s2 = r == c ? 0.0 : s2;
-                double val = sf2 * exp_nonpos(-0.5 * s2);
-                if (MODE == MODE_FACTOR) {
-                    const double live = val * inv_sn2 + (r == c ? 1.0 : 0.0), pad = r == c ? 1.0 : 0.0;
-                    val = (r < n && c < n) ? live : pad;
-                    val = c < r ? 0.0 : val;           // diagonal tiles: exact zeros below the diagonal (row-major upper view)
+            for (int q = 0; q < 4; ++q) v[a][q] = exp_nonpos_tab(clamp_exp_arg(acc[q][a]), etab);   // = cpre * exp(-r^2 / 2)
+        // The exact entries -- K_ii = sf2 (r^2 = 0 by definition, not by cancellation), and in the factor form the unit diagonal,
+        // the identity on the padding and the zeros below the diagonal -- only exist on diagonal tiles and on the last tile row /
+        // column: a uniform branch without memory operations (the body above stays what the memory pipeline was counted for).
+        const int nrl = (int)(n - r0 < ST ? n - r0 : ST), ncl = (int)(n - c0 < ST ? n - c0 : ST);    // live rows / columns of this tile
+        if (tc2.x == tc2.y || (MODE == MODE_FACTOR && (nrl < ST || ncl < ST))) {
+            const bool dtile = tc2.x == tc2.y;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rl = 16 * wave + 4 * a + l4, cl = 16 * q + l15;
+                    const bool same = dtile && rl == cl;
+                    double val = same ? cpre : v[a][q];
+                    if (MODE == MODE_FACTOR) {
+                        const double live = val + (same ? 1.0 : 0.0), pad = same ? 1.0 : 0.0;
+                        val = (rl < nrl && cl < ncl) ? live : pad;
+                        val = (dtile && cl < rl) ? 0.0 : val;      // exact zeros below the diagonal (row-major upper view)
+                    }
+                    v[a][q] = val;
                 }
-                v[a][q] = val;
-            }
+        }
         // direct stores: 8 x 16 bytes per lane (adjacent lanes trade one value each, see the general kernel)
+        {
+            // one 64-bit row pointer per lane; the (a, q) pieces are a row step of 8 ldo and immediate column offsets
+            double* rowp = out + (r0 + 16 * wave + (odd ? 4 : 0) + l4) * ldo + c0 + (l15 & ~1);
 #pragma unroll
-        for (int a = 0; a < 4; a += 2)
+            for (int a = 0; a < 4; a += 2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double x0 = v[a][q], x1 = v[a + 1][q];
-                const double n0 = gram_swap_adjacent(x0), n1 = gram_swap_adjacent(x1);
-                const double2_t val = odd ? double2_t{n1, x1} : double2_t{x0, n0};
-                const long r = r0 + 16 * wave + 4 * (odd ? a + 1 : a) + l4, c = c0 + 16 * q + (l15 & ~1);
-                *(double2_t*)(out + r * ldo + c) = val;
+                for (int q = 0; q < 4; ++q) {
+                    const double x0 = v[a][q], x1 = v[a + 1][q];
+                    const double n0 = gram_swap_adjacent(x0), n1 = gram_swap_adjacent(x1);
+                    *(double2_t*)(rowp + 16 * q) = odd ? double2_t{n1, x1} : double2_t{x0, n0};
+                }
+                rowp += 8 * ldo;
             }
+        }
         if (MODE == MODE_SYM) {
             // mirrored store out[c][r]: transpose through LDS (this tile's coordinates are consumed), 8 x 16 bytes per lane
             lds_barrier();
@@ -751,10 +774,11 @@ __global__ __launch_bounds__(256, HV == 2 ? 4 : 2) void cov_gram_fast_kernel(con
 #pragma unroll
                 for (int q = 0; q < 4; ++q) gsm[(16 * q + l15) * GSTP + 16 * wave + 4 * a + l4] = v[a][q];
             lds_barrier();
+            double* colp = out + (c0 + rw) * ldo + r0 + 2 * pr;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const int cl = p * 8 + rw;
-                *(double2_t*)(out + (c0 + cl) * ldo + r0 + 2 * pr) = *(const double2_t*)(gsm + cl * GSTP + 2 * pr);
+                *(double2_t*)colp = *(const double2_t*)(gsm + (p * 8 + rw) * GSTP + 2 * pr);
+                colp += 8 * ldo;
             }
         }
         if (next >= ntiles) break;
@@ -762,7 +786,7 @@ __global__ __launch_bounds__(256, HV == 2 ? 4 : 2) void cov_gram_fast_kernel(con
         lds_barrier();                                 // every wave is done with the LDS image of this tile (and of its mirror)
         commit(GIC<0>{});                              // (the wait for pg is an exact vmcnt(#stores issued since): the stores keep draining)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { nr[a] = nnr[a]; nc[a] = nnc[a]; }
+        for (int a = 0; a < 4; ++a) { nr[a] = -0.5 * nnr[a]; nc[a] = -0.5 * nnc[a]; }      // halved, negated: see the accumulators
         if (HV == 2) fetch(nx, GIC<HV - 1>{}, false);
         lds_barrier();
         tc2 = nx;
@@ -919,11 +943,7 @@ static int cov_gram_dispatch(int mode, const double* XT, long ldp, long n, long 
     const int nt_ = cs.asm_nt >= 0 ? cs.asm_nt : ((mode != MODE_FACTOR && (double)n * (double)n * 8.0 >= 1073741824.0) ? 1 : 0);
     const unsigned grid = (unsigned)std::min<long>(ntiles, cs.gram_grid > 0 ? cs.gram_grid : 2048);   // persistent: 2 resident per CU, the rest queue
 #define GRAM_LAUNCH(M, NPV) do {                                                                                                  \
-        static std::atomic<int> attr_done{0};                                /* per instantiation: once */                         \
-        if (!attr_done.load(std::memory_order_acquire)) {                                                                          \
-            (void)hipFuncSetAttribute((const void*)cov_gram_kernel<M, NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, 70000);     \
-            attr_done.store(1, std::memory_order_release);                                                                         \
-        }                                                                                                                          \
+        func_max_dynamic_lds((const void*)cov_gram_kernel<M, NPV>, 70000);   /* once per instantiation and device */              \
         hipLaunchKernelGGL((cov_gram_kernel<M, NPV>), dim3(grid), dim3(256), shm, st, XT, ldp, n, dpad, cs.cp.sf2, inv_sn2, out, ldo,  \
                            tiles, ntiles, prep, prep + HADAMARD_PREP_MU, nt_);                                                     \
     } while (0)
@@ -933,17 +953,13 @@ static int cov_gram_dispatch(int mode, const double* XT, long ldp, long n, long 
     const bool fast = cs.gram_fast && (dpad == 32 || dpad == 48 || dpad == 64) && !(ldo & 1) && !nt_ &&
                       (mode == MODE_FACTOR || n % ST == 0);
 #define GRAM_FAST(M, NPV) do {                                                                                                    \
-        static std::atomic<int> attr_done{0};                                                                                      \
-        if (!attr_done.load(std::memory_order_acquire)) {                                                                          \
-            (void)hipFuncSetAttribute((const void*)cov_gram_fast_kernel<M, NPV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 70000); \
-            attr_done.store(1, std::memory_order_release);                                                                         \
-        }                                                                                                                          \
+        func_max_dynamic_lds((const void*)cov_gram_fast_kernel<M, NPV, 1>, 70000);                                                 \
         if (cs.gram_fast == 2 && (NPV) == 16)            /* two halves, four workgroups per CU: d = 64 (the smaller ones spill) */   \
             hipLaunchKernelGGL((cov_gram_fast_kernel<M, NPV, ((NPV) == 16 ? 2 : 1)>), dim3(grid), dim3(256),                       \
-                               (size_t)ST * GSTP * sizeof(double), st, XT, ldp, n, cs.cp.sf2, inv_sn2, out, ldo, tiles, ntiles, prep, \
+                               ((size_t)ST * GSTP + 64) * sizeof(double), st, XT, ldp, n, cs.cp.sf2, inv_sn2, out, ldo, tiles, ntiles, prep, \
                                prep + HADAMARD_PREP_MU);                                                                           \
         else                                                                                                                       \
-        hipLaunchKernelGGL((cov_gram_fast_kernel<M, NPV, 1>), dim3(grid), dim3(256), shm, st, XT, ldp, n, cs.cp.sf2, inv_sn2, out, ldo, \
+        hipLaunchKernelGGL((cov_gram_fast_kernel<M, NPV, 1>), dim3(grid), dim3(256), shm + 64 * sizeof(double), st, XT, ldp, n, cs.cp.sf2, inv_sn2, out, ldo, \
                            tiles, ntiles, prep, prep + HADAMARD_PREP_MU);                                                          \
     } while (0)
 #define GRAM_FAST_MODE(M) do { switch (dpad) { case 32: GRAM_FAST(M, 8); break; case 48: GRAM_FAST(M, 12); break;                 \

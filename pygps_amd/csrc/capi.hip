@@ -189,7 +189,8 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "lookahead")) { c->lookahead = value; return PGP_OK; }
     if (!strcmp(name, "leaf_first")) { c->leaf_first = value; return PGP_OK; }
     if (!strcmp(name, "leaf_pivot")) { if (value < 0 || value > 2) return -2; c->leaf_pivot = value; return PGP_OK; }
-    if (!strcmp(name, "sched")) { if (value < -1 || value > 2) return -2; c->sched = value < 0 ? PGP_SCHED_DEFAULT : value; return PGP_OK; }
+    if (!strcmp(name, "sched")) { if (value < -1 || value > 2) return -2; c->sched = value < 0 ? PGP_SCHED_DEFAULT : value; c->sched_explicit = value >= 0; return PGP_OK; }
+    if (!strcmp(name, "concurrent_streams")) { c->concurrent_streams = value != 0; return PGP_OK; }   // a HINT: an explicit "sched" wins
     if (!strcmp(name, "tud_tile")) { if (value != 64 && value != 128) return -2; c->tud_tile = value; return PGP_OK; }
     if (!strcmp(name, "s_pan")) { if (value < -1 || value > 2) return -2; c->s_pan = value; return PGP_OK; }
     if (!strcmp(name, "s_pan_direct")) { c->s_pan_direct = value != 0; return PGP_OK; }
@@ -218,12 +219,14 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "eet_first")) { if (value < -1) return -2; c->eet_first = value; return PGP_OK; }
     if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
+    if (!strcmp(name, "fused_value_max_np")) { c->fused_value_max_np = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { c->asm_grid = value; return PGP_OK; }
     if (!strcmp(name, "gram_fast")) { if (value < 0 || value > 2) return -2; c->gram_fast = value; return PGP_OK; }
     if (!strcmp(name, "gram_grid")) { if (value < 0) return -2; c->gram_grid = value; return PGP_OK; }
     if (!strcmp(name, "asm_nt")) { c->asm_nt = value; return PGP_OK; }
     if (!strcmp(name, "pair_launch")) { c->pair_launch = value != 0; return PGP_OK; }
     if (!strcmp(name, "gemm_trace")) {               // diagnostic: see ctx.h
+        GateShared device_gate_hold(c);
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipDeviceSynchronize());
         if (c->gemm_trace) { (void)hipFree(c->gemm_trace); c->gemm_trace = nullptr; }
@@ -920,7 +923,8 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
     // sched 1 is what fit streams that run side by side ask for (_lib.concurrent_fit_streams); it pays from N ~ 7000 on (two streams,
     // N = 8192: 109.5 vs 107.7 fits/s with sched 2) and costs below (N = 6144: 218.5 vs 225.3; N = 4096: 467 vs 513 / 521 with
     // sched 2 / 0): smaller sweeps take the default schedule instead
-    const int sched_eff = (c->sched == 1 && nblk < 56) ? PGP_SCHED_DEFAULT : c->sched;
+    const int sched_req = (c->concurrent_streams && !c->sched_explicit) ? 1 : c->sched;     // fit streams side by side: sched 1 unless the user chose
+    const int sched_eff = (sched_req == 1 && nblk < 56) ? PGP_SCHED_DEFAULT : sched_req;
     const bool sched1 = la && sched_eff == 1 && !m.dense2;
     // sched 2 pays for 512-wide panels only (N = 4096: -3.6 %, N = 8192: -2.1 %); with 1024-wide panels the diagonal-block piece is
     // 136 K = 1024 tiles and the rectangle it disturbs twice as long: N = 16384 68.9 -> 70.3 ... 71.2 ms -- those keep schedule 0
@@ -1311,7 +1315,12 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     // value-only fits (want < 3) take the fused-inverse sweep too (round 5): alpha = E z / sn2 is one matvec, whereas the blocked
     // back-substitution without E is a chain of np / 128 dependent steps (3.3 ms at N = 8192: an nlZ-only fit cost as much as one
     // with all gradients).  They skip E E' and the gradient pass.
-    const bool fused = c->fused_inverse != 0;
+    // with all gradients).  They skip E E' and the gradient pass.  That is a win while the sweep is bound by its dependent chain
+    // (measured at N <= 8192); the inverse rows double the sweep's flops and need np x np of scratch, so beyond
+    // `fused_value_max_np` (default 12288, where the sweep turns compute-bound) -- or when that scratch cannot be had -- a
+    // value-only fit takes the plain factorisation + blocked back-substitution again.
+    bool fused = c->fused_inverse != 0;
+    if (want < 3 && fused && c->fused_value_max_np >= 0 && np > c->fused_value_max_np) fused = false;
     const long ldf = c->ldf;                         // factor buffer = factor rows + rhs rows; the inverse rows are scratch
     CovSpec cp;
     { const int rc = make_spec(c, kind, covhyp, ncov, para, flags, -1, d, cp); if (rc != PGP_OK) return rc == -11 ? -10 : rc; }
@@ -1333,7 +1342,13 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     PoolScratch pscr(c);
     double* E = nullptr;                             // E(i,j) at E[i + j*lde]: ends up as W^T = L^-T (upper triangular)
     const long lde = np;
-    if (fused) CHK(pscr.alloc(&E, (size_t)np * np * sizeof(double)));
+    if (fused) {
+        const int erc = pscr.alloc(&E, (size_t)np * np * sizeof(double));
+        if (erc != PGP_OK) {
+            if (want >= 3) return erc;
+            (void)hipGetLastError(); fused = false; E = nullptr;      // value-only: the plain sweep needs no inverse rows
+        }
+    }
     hipStream_t st = c->st;
     HIP_TRY(hipMemsetAsync(c->info_dev, 0, sizeof(int), st));
     if (mvec) {                                      // through pinned memory: an async copy from pageable memory is staged

@@ -106,3 +106,8 @@ int gemm_f64_launch(const GemmArgs& g, hipStream_t st);
 bool gemm_f64_pair_ok(const GemmArgs& a, const GemmArgs& b);     // may the two go out as ONE launch (gemm_f64_launch_pair)?
 int gemm_f64_launch_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t st);
 bool gemm_f64_uses_dma128(const GemmArgs& g);       // would gemm_f64_launch pick the LDS-DMA 128-tile instantiation?
+
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that needs more than 64 KB of dynamic LDS: applied once per
+// (kernel, DEVICE, size) -- the attribute belongs to the device's code object, a process may hold contexts on several devices
+// (_lib.ctx(device)), and two fit streams (host threads) launch concurrently (capi.hip).
+void func_max_dynamic_lds(const void* fn, size_t bytes);

@@ -59,6 +59,8 @@ struct pgp_ctx {
     std::vector<hipEvent_t> la_ev;      // look-ahead hand-off events
     std::vector<hipEvent_t> tm_ev;      // timing events of the sharded fit's wait / broadcast timers (4 per panel)
     int lookahead = 1;
+    bool sched_explicit = false;        // "sched" was set to a value >= 0 by the caller: the concurrent-streams hint does not override it
+    bool concurrent_streams = false;    // option "concurrent_streams" (set by _lib.concurrent_fit_streams while fit streams run side by side)
     int sched = PGP_SCHED_DEFAULT;      // option "sched" (-1 = this default).  0 = rounds 2-4: S, TU_a, TU_b on the main stream, only D on the
                                         // panel stream; 1 = the critical path D -> S -> TU_a on the panel stream, the bulk updates on the main
                                         // stream (what fit streams that run side by side select); 2 = like 0, but the piece of TU_a that D(p+1)
@@ -101,6 +103,7 @@ struct pgp_ctx {
     int ep_sym = 1;                     // EP: Sigma kept current in its lower triangle only (folds and K - V'V on the lower tiles)
     int ep_block = 1;                   // EP site sweep: 1 = one chain launch per 128 sites + Woodbury fold beside the next chain (round 3),
                                         // 0 = the reference's arithmetic literally: Sigma updated per site
+    int fused_value_max_np = 12288;     // value-only fits (want < 3) take the fused-inverse sweep up to this padded size; < 0: always
     int fused_inverse = 1;              // 1: L^-T falls out of the Cholesky sweep (appended identity rows); 0: recursive trtri
     hipDeviceProp_t prop;
     // pooled device buffers, keyed by byte size

@@ -22,6 +22,29 @@
 
 #include "gemm_tile.h"
 
+void func_max_dynamic_lds(const void* fn, size_t bytes) {
+    constexpr int MAXF = 64, MAXD = 16;
+    static std::atomic<const void*> fns[MAXF];
+    static std::atomic<size_t> done[MAXF][MAXD];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXD) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); return; }
+    int slot = -1;
+    for (int i = 0; i < MAXF; ++i) {
+        const void* cur = fns[i].load(std::memory_order_acquire);
+        if (cur == fn) { slot = i; break; }
+        if (cur == nullptr) {
+            const void* expect = nullptr;
+            if (fns[i].compare_exchange_strong(expect, fn, std::memory_order_acq_rel) || expect == fn) { slot = i; break; }
+        }
+    }
+    if (slot < 0) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); return; }   // table full: every time
+    if (done[slot][dev].load(std::memory_order_acquire) >= bytes) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    size_t prev = done[slot][dev].load(std::memory_order_relaxed);
+    while (prev < bytes && !done[slot][dev].compare_exchange_weak(prev, bytes, std::memory_order_release)) {}
+}
+
+
 namespace {
 
 using gemm_tile_ns::BK;
@@ -115,12 +138,7 @@ int launch_t(const GemmArgs& g, hipStream_t st) {
     unsigned nblk = (g.tri == 2) ? (unsigned)((long)mt * (mt + 1) / 2) : (unsigned)(mt * nt);
     if (g.order) nblk = (unsigned)g.norder;
     dim3 grid(nblk, 1, (g.batch > 0 && !g.order_z) ? g.batch : 1);
-    static std::atomic<size_t> attr_set{0};          // two fit streams (host threads) launch concurrently
-    if (attr_set.load(std::memory_order_acquire) < shm) {
-        (void)hipFuncSetAttribute((const void*)gemm_f64_kernel<T, T, AKC, BKC, DMA, YIELD>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set.store(shm, std::memory_order_release);
-    }
+    func_max_dynamic_lds((const void*)gemm_f64_kernel<T, T, AKC, BKC, DMA, YIELD>, shm);
     hipLaunchKernelGGL((gemm_f64_kernel<T, T, AKC, BKC, DMA, YIELD>), grid, dim3(256), shm, st, g);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
@@ -159,12 +177,7 @@ int gemm_f64_launch_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
     const size_t shm = 2 * (2 * BK * SA_) * sizeof(double);
     const unsigned na = launch_blocks(a), nb = launch_blocks(b);
     const bool yield = a.yield_role == 1 && a.yield_flags;
-    static std::atomic<int> attr_set{0};
-    if (!attr_set.load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute((const void*)gemm_f64_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        (void)hipFuncSetAttribute((const void*)gemm_f64_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set.store(1, std::memory_order_release);
-    }
+    func_max_dynamic_lds((const void*)(yield ? gemm_f64_pair_kernel<true> : gemm_f64_pair_kernel<false>), shm);
     if (yield) hipLaunchKernelGGL(gemm_f64_pair_kernel<true>, dim3(na + nb), dim3(256), shm, st, a, b, (int)na);
     else hipLaunchKernelGGL(gemm_f64_pair_kernel<false>, dim3(na + nb), dim3(256), shm, st, a, b, (int)na);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;

@@ -973,19 +973,12 @@ int hadamard_partial_launch(const double* XT, long ldp, long n, long np, int dpa
         cp.train = 1;
         const int CH = dpad < 64 ? dpad : 64;
         const size_t shm = (size_t)2 * CH * STP * sizeof(double);
-        static std::atomic<size_t> attr1{0}, attr6{0};
         if (cp.kind == 1) {
-            if (attr1.load(std::memory_order_acquire) < shm) {
-                (void)hipFuncSetAttribute((const void*)hadamard_ard_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-                attr1.store(shm, std::memory_order_release);
-            }
+            func_max_dynamic_lds((const void*)hadamard_ard_kernel<1>, shm);
             hipLaunchKernelGGL(hadamard_ard_kernel<1>, dim3((unsigned)nblk), dim3(256), shm, st, XT, ldp, n, dpad, cp, ncov, 1.0 / sn2,
                                sn2, Binv, ldb, alpha, wv, partial, nt, mu, mu + HADAMARD_PREP_MU, b0);
         } else {
-            if (attr6.load(std::memory_order_acquire) < shm) {
-                (void)hipFuncSetAttribute((const void*)hadamard_ard_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-                attr6.store(shm, std::memory_order_release);
-            }
+            func_max_dynamic_lds((const void*)hadamard_ard_kernel<6>, shm);
             hipLaunchKernelGGL(hadamard_ard_kernel<6>, dim3((unsigned)nblk), dim3(256), shm, st, XT, ldp, n, dpad, cp, ncov, 1.0 / sn2,
                                sn2, Binv, ldb, alpha, wv, partial, nt, mu, mu + HADAMARD_PREP_MU, b0);
         }

@@ -698,13 +698,7 @@ __global__ __launch_bounds__(128, 1) void leaf_inv_kernel(const double* __restri
 int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st,
                       long long* tick, unsigned* yield_flags, int pivot) {
     const size_t shm = (36 * 256 + 256 + 2) * sizeof(double);
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute((const void*)leaf_potrf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        (void)hipFuncSetAttribute((const void*)leaf_potrf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        (void)hipFuncSetAttribute((const void*)leaf_potrf_reg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set.store(true, std::memory_order_release);
-    }
+    func_max_dynamic_lds(pivot == 2 ? (const void*)leaf_potrf_reg_kernel : pivot ? (const void*)leaf_potrf_kernel<true> : (const void*)leaf_potrf_kernel<false>, shm);
     if (pivot == 2) {
         const size_t shm2 = (28 * 256 + 256) * sizeof(double);
         hipLaunchKernelGGL(leaf_potrf_reg_kernel, dim3(1), dim3(256), shm2, st, A, lda, inv16, info, info_base, tick, yield_flags);
@@ -720,22 +714,14 @@ int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl
     if (nrows <= 0) return PGP_OK;
     const unsigned nblk = (unsigned)((nrows + 63) / 64);
     const size_t shm = 36 * 256 * sizeof(double);
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute((const void*)trsm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set.store(true, std::memory_order_release);
-    }
+    func_max_dynamic_lds((const void*)trsm_rows_kernel, shm);
     hipLaunchKernelGGL(trsm_rows_kernel, dim3(nblk), dim3(256), shm, st, X, ldx, nrows, Ld, ldl, inv16, yield_flags);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
 int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, long wstride, int nblocks, hipStream_t st) {
     const size_t shm = (size_t)NB * NB * sizeof(double);
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute((const void*)leaf_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set.store(true, std::memory_order_release);
-    }
+    func_max_dynamic_lds((const void*)leaf_inv_kernel, shm);
     hipLaunchKernelGGL(leaf_inv_kernel, dim3(nblocks), dim3(128), shm, st, L, ldl, W, ldw, wstride);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }

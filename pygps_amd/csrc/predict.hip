@@ -6,6 +6,7 @@
 // with W_kk = inv(L_kk) from leaf_inv_kernel (the reference instead LU-factorises the triangular
 // L for every 1000-point batch, gp.py:415).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -85,6 +86,10 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     // points: batch 1024 -> 318 ms, 4096 -> 220, 8192 -> 192, 16384 -> 171; round 4 on one box: 16384 -> 120 ms, 65536 -> 101 ms)
     const long NSB = predict_batch_points(c->predict_batch, ns, np);
     const long ldc = NSB;
+    // pgp_last_timings after a predict: [ASSEMBLE] = host ms spent getting the scratch (a first call at a new batch shape pays a
+    // multi-GiB hipMalloc here: 4 GiB at N = 8192 and 65536 points -- tens of ms on a fast host, hundreds on a slow one; later calls
+    // take it from the pool), [SOLVE] = host wall ms of the whole call, [TOTAL] = device ms between the first and the last event.
+    const auto t_call = std::chrono::steady_clock::now();
     PoolScratch tmp(c);
     double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *o2 = nullptr;
     CHK(tmp.alloc(&xd, NSB * d * sizeof(double)));
@@ -94,6 +99,8 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     CHK(tmp.alloc(&msd, NSB * sizeof(double)));
     CHK(tmp.alloc(&o1, NSB * sizeof(double)));
     CHK(tmp.alloc(&o2, NSB * sizeof(double)));
+    const double alloc_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+    HIP_TRY(hipEventRecord(c->ev[0], st));
     HIP_TRY(hipMemcpyAsync(scd, f->cs.scale.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
     CovSpec cp = f->cs;
     cp.cp.der = -1; cp.pg.der = -1;
@@ -113,7 +120,16 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
         CHK(col_sumsq_launch(Ks, np, n, nb_, f->kss, f->sWv ? 1.0 : f->sw * f->sw, o2, st));
         HIP_TRY(hipMemcpyAsync(fmu + a, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(fs2 + a, o2, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (a + NSB >= ns) HIP_TRY(hipEventRecord(c->ev[1], st));
         HIP_TRY(hipStreamSynchronize(st));
+    }
+    {
+        float dev_ms = 0.f;
+        (void)hipEventElapsedTime(&dev_ms, c->ev[0], c->ev[1]);
+        for (double& v : c->last_ms) v = 0.0;
+        c->last_ms[PGP_STAGE_ASSEMBLE] = alloc_ms;
+        c->last_ms[PGP_STAGE_SOLVE] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+        c->last_ms[PGP_STAGE_TOTAL] = dev_ms;
     }
     if (c->prof) prof_collect(c);
     return PGP_OK;

@@ -117,6 +117,7 @@ struct pgp_comm {
     // host collectives of the restart / fold searches (pgp_comm_bcast_host, pgp_comm_allgather_host): device staging
     double* hostbuf = nullptr;
     size_t hostbuf_bytes = 0;
+    std::vector<void*> hostbuf_retired;   // outgrown staging buffers: freed with the communicator, never beside a resident EP sweep
 };
 
 namespace {
@@ -330,6 +331,7 @@ int pgp_comm_init_rccl(pgp_ctx* c, int world, int rank, const char* id, const ch
     if (rank < 0 || rank >= world) return -3;
     if (!id) return -4;
     if (!out) return -6;
+    GateShared device_gate_hold(c);
     HIP_TRY(hipSetDevice(c->device));
     pgp_comm* m = new pgp_comm();
     m->ctx = c; m->world = world; m->rank = rank; m->kind = 1;
@@ -370,10 +372,13 @@ int pgp_comm_init_host(pgp_ctx* c, int world, int rank, pgp_host_bcast_fn bcast,
 // transport: the call-backs, directly.  Every rank calls with the same counts.
 static int comm_hostbuf(pgp_comm* m, size_t bytes) {
     if (m->hostbuf_bytes >= bytes) return PGP_OK;
-    if (m->hostbuf) (void)hipFree(m->hostbuf);
+    if (m->hostbuf) m->hostbuf_retired.push_back(m->hostbuf);      // grow-only (doubling): no hipFree on this path
     m->hostbuf = nullptr; m->hostbuf_bytes = 0;
-    HIP_TRY(hipMalloc((void**)&m->hostbuf, bytes));
-    m->hostbuf_bytes = bytes;
+    const size_t want = std::max(bytes, (size_t)1 << 16);
+    size_t cap = (size_t)1 << 16;
+    while (cap < want) cap <<= 1;
+    HIP_TRY(hipMalloc((void**)&m->hostbuf, cap));
+    m->hostbuf_bytes = cap;
     return PGP_OK;
 }
 static int host_stage(pgp_comm* m, size_t bytes) {        // plain (pageable is fine) host staging for a ctx-less communicator
@@ -392,6 +397,7 @@ int pgp_comm_bcast_host(pgp_comm* m, double* buf, int64_t count, int root) {
     if (count == 0 || (m->world == 1 && m->kind != 1)) return PGP_OK;
     const size_t bytes = (size_t)count * sizeof(double);
     if (m->kind == 1) {
+        GateShared device_gate_hold(m->ctx);             // these touch the runtime: never beside a resident EP sweep (ctx.h DeviceGate)
         HIP_TRY(hipSetDevice(m->ctx->device));
         CHK(comm_hostbuf(m, bytes));
         if (m->rank == root) HIP_TRY(hipMemcpyAsync(m->hostbuf, buf, bytes, hipMemcpyHostToDevice, m->st_comm));
@@ -414,6 +420,7 @@ int pgp_comm_allreduce_host(pgp_comm* m, double* buf, int64_t count, int op) {
     if (count == 0 || (m->world == 1 && m->kind != 1)) return PGP_OK;
     const size_t bytes = (size_t)count * sizeof(double);
     if (m->kind == 1) {
+        GateShared device_gate_hold(m->ctx);
         HIP_TRY(hipSetDevice(m->ctx->device));
         CHK(comm_hostbuf(m, bytes));
         HIP_TRY(hipMemcpyAsync(m->hostbuf, buf, bytes, hipMemcpyHostToDevice, m->st_comm));
@@ -436,6 +443,7 @@ int pgp_comm_allgather_host(pgp_comm* m, const double* send, int64_t count, doub
     if (count == 0) return PGP_OK;
     const size_t bytes = (size_t)count * sizeof(double);
     if (m->kind == 1) {
+        GateShared device_gate_hold(m->ctx);
         HIP_TRY(hipSetDevice(m->ctx->device));
         CHK(comm_hostbuf(m, bytes * (size_t)(m->world + 1)));
         double* sd = m->hostbuf + (size_t)m->world * (size_t)count;
@@ -459,12 +467,14 @@ int pgp_comm_allgather_host(pgp_comm* m, const double* send, int64_t count, doub
 
 void pgp_comm_free(pgp_comm* m) {
     if (!m) return;
+    GateShared device_gate_hold(m->ctx);
     if (m->ctx) (void)hipSetDevice(m->ctx->device);
     if (m->st_comm) { (void)hipStreamSynchronize(m->st_comm); (void)hipStreamDestroy(m->st_comm); }
     if (m->kind == 1 && m->comm) (void)m->api.CommDestroy(m->comm);
     if (m->stage) { if (m->ctx) (void)hipHostFree(m->stage); else free(m->stage); }
     if (m->agree) (void)hipFree(m->agree);
     if (m->hostbuf) (void)hipFree(m->hostbuf);
+    for (void* p : m->hostbuf_retired) (void)hipFree(p);
     delete m;
 }
 

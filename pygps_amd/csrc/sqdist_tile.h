@@ -268,6 +268,51 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     return ldexp(p, (int)kc);
 }
 
+// exp by table (round 6; the compute-bound kernels -- Gram-form assembly at d = 64, the ARD gradient pass): x = (64 k + j) ln2/64 + r,
+// |r| <= ln2/128, exp(x) = 2^k * T[j] * (1 + q(r)), q = expm1 by a degree-5 Taylor polynomial (remainder < 3.5e-17 relative).
+// The reduction uses the "magic number" rounding: u = x * 64/ln2 + 1.5 * 2^52 holds round(x * 64/ln2) as a two's-complement integer
+// in its low dword (no v_rndne / v_cvt), T comes from a 64-entry table in LDS that the caller has PRE-SCALED by `c` (sf2, or
+// sf2 / sn2: the product with the prefactor costs nothing), the 2^k by v_ldexp (gradual underflow and exact zeros by itself).
+// 14 VALU instructions + one ds_read_b64 against 20 for exp_nonpos + the prefactor's multiplication; <= 1 ulp of c * exp(x).
+// Valid for -745 <= x <= 0 (the caller clamps: beyond, the low dword no longer holds the integer).
+static __device__ const double EXP2_TAB64[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+// min(max(x, -745), 0).  Plain fmin / fmax on purpose: the argument comes straight out of MFMA accumulators, and inline assembly
+// that reads them is invisible to the compiler's hazard recogniser (an asm v_min_f64 right behind the last v_mfma_f64 read stale
+// registers in one instantiation: the DGEMM -> VALU read needs 18 wait states that only the compiler inserts).  The price is one
+// canonicalising v_max per value.
+__device__ __forceinline__ double clamp_exp_arg(double x) { return fmax(fmin(x, 0.0), -745.0); }
+// every thread t < 64 of the workgroup writes one entry; the caller's next barrier publishes the table
+__device__ __forceinline__ void exp_tab_fill(double* tab, double c, int t) { if (t < 64) tab[t] = c * EXP2_TAB64[t]; }
+__device__ __forceinline__ double exp_nonpos_tab(double x, const double* tab) {      // = c * exp(x), -745 <= x <= 0
+    const double u = fma(x, 92.33248261689366, 6755399441055744.0);                   // 64 / ln2, 1.5 * 2^52
+    const double m = u - 6755399441055744.0;
+    double r = fma(m, -0x1.62e42fee00000p-7, x);                                      // ln2 / 64: 32 leading bits (m * hi is exact)
+    r = fma(m, -2.9815858269852933e-12, r);
+    const int mi = __double2loint(u);
+    const double T = tab[mi & 63];
+    double p = fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    const double q = fma(p, r * r, r);
+    return ldexp(fma(T, q, T), mi >> 6);
+}
+
 // covariance value k(x,z) from the scaled squared distance s; same = "row and column are the same training point"
 // EXT = false leaves out the trigonometric / index-dependent kinds (7..10): the primitive hot-path kernels are
 // instantiated without them (they run as one-leaf programs), which keeps their register count where it was.

@@ -44,6 +44,10 @@ class _TorchSide(object):
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        # tickets live in the DEFAULT store whatever the group: two disjoint sub-groups searching at the same sequence number must
+        # not share a counter -- the key carries the group's member list
+        members = list(range(self.world)) if group is None else [dist.get_global_rank(group, r) for r in range(self.world)]
+        self.group_key = "all" if group is None else "g" + "-".join(str(m) for m in members)
 
     def _global(self, group_rank):
         return group_rank if self.group is None else self.dist.get_global_rank(self.group, group_rank)
@@ -76,7 +80,7 @@ class _TorchSide(object):
     def ticket(self, name):
         # the default store of the process group is a key-value server with an atomic add
         from torch.distributed import distributed_c10d as c10d
-        return int(c10d._get_default_store().add("pygps_amd/ticket/" + name, 1)) - 1
+        return int(c10d._get_default_store().add("pygps_amd/ticket/%s/%s" % (self.group_key, name), 1)) - 1
 
 
 def _find_side(group):

@@ -1,0 +1,41 @@
+"""GPU: round 6.
+
+* value-only fits (Exact.evaluate nargout 1 / 2, Core/inf.py:382-384) beyond `fused_value_max_np` -- and whenever the
+  inverse rows' scratch is not to be had -- take the plain factorisation + blocked back-substitution; same numbers either way.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, synth_reg
+from test_gpu_core import _fit
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+@pytest.mark.parametrize("opts", [dict(fused_value_max_np=1024), dict(fused_inverse=0), dict(fused_value_max_np=-1), {}])
+def test_value_only_fit_with_and_without_the_fused_inverse_rows(lib, opts):
+    """want = 1 / 2 at N = 2048 and 4096 against G6 (the reference's numbers): the fused-inverse sweep (default below
+    fused_value_max_np), the plain sweep forced by the size bound, and fused_inverse = 0."""
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    try:
+        for k, v in opts.items():
+            _lib.check(lib.pgp_set_option(ctx, k.encode(), v))
+        for N in (2048, 4096):
+            g = golden("G6_rbf_d16_N%d" % N)
+            x, y = synth_reg(N, 16)
+            for want in (2, 1):
+                got = _fit(lib, 0, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, g["mean_hyp"][0] * np.ones(N), np.ones((1, N)), want=want)
+                if want == 2:
+                    assert relerr(got["nlZ"], g["nlZ"]) < 1e-9
+                assert relerr(got["alpha"][g["alpha_idx"], 0], g["alpha_sample"]) < 1e-7
+                assert relerr(got["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-8
+    finally:
+        lib.pgp_set_option(ctx, b"fused_value_max_np", 12288)
+        lib.pgp_set_option(ctx, b"fused_inverse", 1)
