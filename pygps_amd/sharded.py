@@ -142,8 +142,10 @@ class Comm(object):
         self.transport = transport
         h = C.c_void_p()
         if transport == "rccl":
-            path = ""
-            if self.dist is not None or (not os.environ.get("PYGPS_AMD_NO_TORCH") and "torch" in __import__("sys").modules):
+            path = os.environ.get("PYGPS_AMD_RCCL_PATH", "")            # an explicit librccl (tests: tests/stub_rccl, the RCCL branch on one GPU)
+            if path:
+                pass
+            elif self.dist is not None or (not os.environ.get("PYGPS_AMD_NO_TORCH") and "torch" in __import__("sys").modules):
                 torch = _lib.want_torch()                                   # one copy of librccl per process: the one torch loaded
                 cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
                 path = cand if os.path.exists(cand) else ""

@@ -35,6 +35,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def build_stub_rccl():
+    """tests/stub_rccl/librccl_stub.so (test infrastructure: the library's RCCL branch on one GPU); built by __graft_entry__.build(),
+    and here when it is missing (hipcc is on the GPU box too)."""
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub_rccl")
+    so, src = os.path.join(d, "librccl_stub.so"), os.path.join(d, "rccl_stub.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src, "-lrt"])
+    return so
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 

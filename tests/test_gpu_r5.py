@@ -92,14 +92,18 @@ def test_G19_k_fold_sharded_without_torch(tmp_path, world):
     assert set(rs[0]["owner"].tolist()) == set(range(world))                      # every rank ran folds
 
 
-@pytest.mark.parametrize("world,streams", [(1, 2), (2, 1)])
-def test_cfg4_restart_search_without_torch(tmp_path, world, streams):
+@pytest.mark.parametrize("world,streams,stub", [(1, 2, False), (2, 1, False), (2, 1, True), (4, 2, True)])
+def test_cfg4_restart_search_without_torch(tmp_path, world, streams, stub):
     """BASELINE configs[3] with nothing but libpygps_amd.so + sockets for the 128-byte id: world 1 over the library's RCCL
-    transport (system librccl), world 2 over its host transport; per-restart objectives against the reference's run (G9, N = 512)."""
+    transport (system librccl), world 2 over its host transport -- and (round 6) world 2 / 4 over the library's RCCL BRANCH
+    (ncclBroadcast of the start table and the data, ncclAllGather of the records, staged through device buffers) bound to the
+    shared-memory stand-in of tests/stub_rccl; per-restart objectives against the reference's run (G9, N = 512)."""
     from test_hostgroup import launch
+    from conftest import build_stub_rccl
     g = golden("G9_restarts_N512")
-    rs = launch(world, "g9_search", tmp_path, 512, streams, timeout=900)
-    want_transport = "rccl" if world == 1 else "host"
+    env = dict(PYGPS_AMD_TRANSPORT="rccl", PYGPS_AMD_RCCL_PATH=build_stub_rccl()) if stub else None
+    rs = launch(world, "g9_search", tmp_path, 512, streams, timeout=900, extra_env=env)
+    want_transport = "rccl" if world == 1 or stub else "host"
     for z in rs:
         assert str(z["transport"]) == want_transport
         assert relerr(z["X0"], g["run_X0"]) < 1e-14

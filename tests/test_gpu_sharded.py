@@ -21,6 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from conftest import golden, relerr, synth_reg  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+STUB_RCCL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub_rccl", "librccl_stub.so")
 
 
 def _free_port():
@@ -76,6 +77,10 @@ def _worker(rank, world, port, backend, case, out_dir):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
+    stub = backend == "stub"           # the library's RCCL branch over tests/stub_rccl (shared memory), the id travels over gloo
+    if stub:
+        os.environ.update(PYGPS_AMD_TRANSPORT="rccl", PYGPS_AMD_RCCL_PATH=STUB_RCCL)
+        backend = "gloo"
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
@@ -85,7 +90,7 @@ def _worker(rank, world, port, backend, case, out_dir):
         from pygps_amd import sharded
         from oracle import gp_oracle as O
         comm = sharded.Comm()
-        assert comm.world == world and comm.rank == rank and comm.transport == ("rccl" if backend == "nccl" else "host")
+        assert comm.world == world and comm.rank == rank and comm.transport == ("rccl" if backend == "nccl" or stub else "host")
         res = {}
         if case.startswith("g6_"):
             N = int(case[3:])
@@ -264,3 +269,47 @@ def test_cfg3_size_over_8_ranks_against_the_reference(tmp_path):
     out = _run(tmp_path, 8, "gloo", "g7_16384")
     for r in out[1:]:
         assert r["nlZ"] == out[0]["nlZ"] and np.array_equal(r["alpha"], out[0]["alpha"]) and np.array_equal(r["g"], out[0]["g"])
+
+
+# ---- round 6: the RCCL BRANCH of the library at world > 1 on one GPU ---------------------------------------------
+# Real RCCL refuses two ranks on one device, and no multi-GPU box has ever run this code: tests/stub_rccl/librccl_stub.so implements
+# the six entry points the library binds (ncclGetUniqueId, ncclCommInitRank, ncclBroadcast, ncclAllReduce, ncclAllGather,
+# ncclCommDestroy) over shared host memory, each ordered on the stream it is given.  What runs is pgp_comm kind 1: the communicator
+# set-up at world > 1, the panel broadcasts on the communication stream behind the producers' events with depth-1 look-ahead, the
+# all-reduces of the epilogue, failure agreement, the predict path's all-reduce -- not the host-call-back branch the gloo tests take.
+@pytest.fixture(scope="module")
+def stub_rccl():
+    from conftest import build_stub_rccl
+    return build_stub_rccl()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rccl_branch_G6_N8192_over_the_stub_transport(tmp_path, stub_rccl, world):
+    out = _run(tmp_path, world, "stub", "g6_8192")
+    for r in out[1:]:
+        assert r["nlZ"] == out[0]["nlZ"] and np.array_equal(r["alpha"], out[0]["alpha"]) and np.array_equal(r["g"], out[0]["g"])
+
+
+def test_rccl_branch_equals_the_host_transport_bit_for_bit(tmp_path, stub_rccl):
+    """Same ranks, same panels, same arithmetic: the transport must not change a bit of the answer."""
+    a = _run(tmp_path, 2, "stub", "g6_4096")
+    b = _run(tmp_path, 2, "gloo", "g6_4096")
+    assert a[0]["nlZ"] == b[0]["nlZ"] and np.array_equal(a[0]["alpha"], b[0]["alpha"]) and np.array_equal(a[0]["g"], b[0]["g"])
+
+
+def test_rccl_branch_world_8_one_panel_per_rank(tmp_path, stub_rccl):
+    out = _run(tmp_path, 8, "stub", "g6_4096")
+    for r in out[1:]:
+        assert r["nlZ"] == out[0]["nlZ"] and np.array_equal(r["alpha"], out[0]["alpha"])
+
+
+def test_rccl_branch_ragged_sizes_kernels_and_failure_agreement(tmp_path, stub_rccl):
+    out = _run(tmp_path, 3, "stub", "kernels")
+    assert set(out[0]) == {"ard", "matern", "sum", "tiny", "one"} and all(out[0][k] == out[2][k] for k in out[0])
+    out = _run(tmp_path, 2, "stub", "nonpd")
+    assert out[0]["msg"] == out[1]["msg"] and "first bad pivot" in out[0]["msg"]
+
+
+def test_rccl_branch_predict_on_the_distributed_posterior(tmp_path, stub_rccl):
+    out = _run(tmp_path, 2, "stub", "predict_g17")
+    assert np.array_equal(out[0]["fm"], out[1]["fm"]) and np.array_equal(out[0]["fs2"], out[1]["fs2"])
