@@ -133,10 +133,12 @@ static int alloc_result_buffer(pgp_ctx* c, long np) {
     const size_t bytes = (size_t)(RES_HEAD + np) * sizeof(double);
     if (c->res_dev) (void)hipFree(c->res_dev);
     if (c->res_host) (void)hipHostFree(c->res_host);
-    c->res_dev = c->res_host = nullptr; c->scal = c->alpha_dev = nullptr; c->info_dev = nullptr; c->res_cap = 0;
+    c->res_dev = c->res_host = c->res_host_dev = nullptr; c->scal = c->alpha_dev = nullptr; c->info_dev = nullptr; c->res_cap = 0;
     HIP_TRY(hipMalloc((void**)&c->res_dev, bytes));
     HIP_TRY(hipMemset(c->res_dev, 0, bytes));
-    HIP_TRY(hipHostMalloc((void**)&c->res_host, bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->res_host, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    c->res_host_dev = nullptr;
+    if (hipHostGetDevicePointer((void**)&c->res_host_dev, c->res_host, 0) != hipSuccess) { (void)hipGetLastError(); c->res_host_dev = nullptr; }
     c->scal = c->res_dev; c->info_dev = (int*)(c->res_dev + RES_INFO); c->alpha_dev = c->res_dev + RES_HEAD;
     c->res_cap = bytes;
     return PGP_OK;
@@ -219,6 +221,8 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "eet_first")) { if (value < -1) return -2; c->eet_first = value; return PGP_OK; }
     if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
+    if (!strcmp(name, "trsm_lean")) { if (value < 0 || value > 2) return -2; c->trsm_lean = value; return PGP_OK; }
+    if (!strcmp(name, "publish")) { c->publish = value != 0; return PGP_OK; }
     if (!strcmp(name, "fused_value_max_np")) { c->fused_value_max_np = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { c->asm_grid = value; return PGP_OK; }
     if (!strcmp(name, "gram_fast")) { if (value < 0 || value > 2) return -2; c->gram_fast = value; return PGP_OK; }
@@ -669,7 +673,7 @@ static int factor_panel(pgp_ctx* c, double* F, long ld, RowEnd re, int s0, int s
         const long rows_below = re(cb + 1) - (long)(cb + 1) * 128;
         if (rows_below > 0) {
             ProfScope ps(c, PC_TRSM, (double)rows_below * 128.0 * 128.0, 0.0, st);
-            CHK(trsm_rows_launch(Acc + 128, ld, rows_below, Acc, ld, pack, st, yfl));
+            CHK(trsm_rows_launch(Acc + 128, ld, rows_below, Acc, ld, pack, st, yfl, c->trsm_lean == 2 || (c->trsm_lean == 1 && chain)));
         }
         CHK(stepped());
         if (cb + 1 < s1) {               // inner update of the rest of this outer panel, K = 128
@@ -1412,7 +1416,10 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
     }
     HIP_TRY(hipEventRecord(c->ev[6], st));
     // ---- results to host: ONE copy of [scalars | status | alpha] into pinned memory ---------------------
-    HIP_TRY(hipMemcpyAsync(c->res_host, c->res_dev, (size_t)(RES_HEAD + n) * sizeof(double), hipMemcpyDeviceToHost, st));
+    // (round 6) the LAST KERNEL of the fit writes them into the pinned buffer through its device-side address: a copy command
+    // behind the last kernel cost a lone chain ~100 us (final_reduce's end to the copy's start in the kernel trace); option publish = 0
+    if (c->publish && c->res_host_dev) CHK(publish_launch(c->res_dev, c->res_host_dev, RES_HEAD + n, st));
+    else HIP_TRY(hipMemcpyAsync(c->res_host, c->res_dev, (size_t)(RES_HEAD + n) * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const double* sc_host = c->res_host;
     double* alpha_h = c->res_host + RES_HEAD;

@@ -136,6 +136,10 @@ struct pgp_ctx {
     // into pageable memory cost ~270 us per N = 8192 fit: each is staged and synchronised by the runtime)
     double* res_dev = nullptr;          // [info | 8 scalars + ncov + 1 gradient sums | alpha (np)]
     double* res_host = nullptr;         // pinned
+    double* res_host_dev = nullptr;     // the same pinned buffer in the device's address space (option "publish": the last kernel of a fit
+                                        // writes the results straight into it; no copy command behind the fit)
+    int trsm_lean = 0;                  // option "trsm_lean": 1 = the LDS-free panel solve for the diagonal-block chain beside bulk work, 0 never, 2 always
+    int publish = 1;                    // option "publish" 1 / 0
     double* in_host = nullptr;          // pinned staging of the per-fit inputs (prior mean, scales)
     size_t res_cap = 0, in_cap = 0;
     // Cholesky sweep: diagonal-panel scratch (2w x w, w <= 1024), its leaf operand images, column staging buffer

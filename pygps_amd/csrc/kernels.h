@@ -10,13 +10,14 @@ constexpr long PACK_DOUBLES = 36 * 256;   // per-leaf packed operand image: 28 s
 int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_base, hipStream_t st,
                       long long* tick = nullptr, unsigned* yield_flags = nullptr, int pivot = 1);
 int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl, const double* inv16,
-                     hipStream_t st, unsigned* yield_flags = nullptr);
+                     hipStream_t st, unsigned* yield_flags = nullptr, bool lean = false);   // lean: no LDS, < 64 VGPRs (beside bulk work)
 int leaf_inv_launch(const double* L, long ldl, double* W, long ldw, long wstride, int nblocks, hipStream_t st);
 int trsv_bwd_launch(const double* L, long ldl, const double* W, long ldw, double* z, double* a_out, int nblk,
                     hipStream_t st);
 int diag_in_launch(const double* src, long lds, double* D, long ldd, int w, hipStream_t st);
 int diag_out_launch(const double* D, long ldd, int w, double* Fd, long ldf, double* Ed, long lde, hipStream_t st);
 int gather_strided_launch(const double* src, long stride, long n, double* dst, hipStream_t st);
+int publish_launch(const double* src_dev, double* dst_host_mapped, long count, hipStream_t st);    // results -> pinned host memory, by a kernel
 
 // assemble.hip
 int scale_transpose_launch(const double* x, long n, int d, const double* scale_dev, double* XsT, long ldp, int dpad,

@@ -660,6 +660,75 @@ __device__ __forceinline__ void trsm_rows_body(double* __restrict__ X, long ldx,
     }
 }
 
+// ---- the same solve without LDS and on < 64 VGPRs (round 6) --------------------------------------------------------------------
+// Beside a trailing update every CU holds two bulk workgroups (2 x 74 KB of LDS, 2 x 208 VGPRs per SIMD): what is left is 12 KB and
+// 96 registers per SIMD lane.  trsm_rows_kernel (72 KB) therefore waits for a bulk workgroup to leave -- ~100 us when the bulk launch
+// has just filled the chip (kernel trace: 98 us in flight against 10 alone, once per panel).  This form fits the gap: LEFT-looking
+// over the eight column blocks, one 16 x 16 accumulator in flight,
+//     X_c <- (X_c - sum_{tb < c} Y_tb L(c, tb)') inv(L_cc)',
+// every operand fragment straight from the L2 (the packed image is 72 KB and hot; the finished Y_tb are re-read from X itself through
+// agent-scope loads -- the newest one is kept in registers).  Same products in the same order as the LDS form: bit-identical.
+__global__ __launch_bounds__(256, 5) void trsm_rows_lean_kernel(double* __restrict__ X, long ldx, long nrows,
+                                                             const double* __restrict__ img /* packed image */,
+                                                             unsigned* yield_flags) {
+    pgp_yield_mark(yield_flags, +1);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long r0 = ((long)blockIdx.x * 4 + wave) * 16;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    if (r0 < nrows) {
+        // addresses = wave-uniform 64-bit base (SGPRs: the kernel arguments and the loop counters) + one 32-bit byte offset per lane
+        const char* ib = (const char*)img;                                  // fragment (block b, k-step ks) at ib + (b * 256 + ks * 64) * 8 + ioff
+        const unsigned ioff = (unsigned)(l4 * 16 + l15) * 8u;
+        char* xb = (char*)X;                                                // element (column j) at xb + j * ldx * 8 + xoff
+        const unsigned xoff = (unsigned)((r0 + l15 + (long)l4 * ldx) * 8);
+        const size_t cstep = (size_t)ldx * 8;
+        double4_t ylast = {0.0, 0.0, 0.0, 0.0};
+        // rolled loops; the operands of step tb + 1 are in flight while step tb multiplies
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {
+            double4_t acc, iv;
+            char* xc = xb + (size_t)(16 * c) * cstep;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = *(const double*)(xc + (size_t)(4 * q) * cstep + xoff);
+            const char* ic = ib + (size_t)((28 + c) * 256) * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) iv[ks] = *(const double*)(ic + ks * 512 + ioff);
+            if (c >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores of Y_0 .. Y_{c-2} have left this wave
+            double4_t ya = {0.0, 0.0, 0.0, 0.0}, la = ya;
+            const char* lc = ib + (size_t)(c * (c - 1) / 2 * 256) * 8;     // tri_blk(c, 0)
+            auto fetch = [&](int tb, double4_t& yv, double4_t& lv) {
+                const char* lp = lc + (size_t)tb * 2048;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) lv[ks] = *(const double*)(lp + ks * 512 + ioff);
+                const char* yp = xb + (size_t)(16 * tb) * cstep;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    yv[q] = __hip_atomic_load((const double*)(yp + (size_t)(4 * q) * cstep + xoff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            if (c > 0) fetch(0, ya, la);
+#pragma unroll 1
+            for (int tb = 0; tb < c; ++tb) {
+                double4_t yn = ya, ln = la;
+                if (tb + 1 < c) fetch(tb + 1, yn, ln);
+                const double4_t y = tb == c - 1 ? ylast : ya;              // the newest Y never went to memory and back
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[ks], y[ks], acc, 0, 0, 0);
+                ya = yn; la = ln;
+            }
+            double4_t y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+            y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[0], acc[0], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[1], acc[1], y1, 0, 0, 0);
+            y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[2], acc[2], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[3], acc[3], y1, 0, 0, 0);
+            ylast = y0 + y1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(double*)(xc + (size_t)(4 * q) * cstep + xoff) = ylast[q];
+        }
+    }
+    __syncthreads();
+    pgp_yield_mark(yield_flags, -1);
+}
+
 __global__ __launch_bounds__(256, 2) void trsm_rows_kernel(double* __restrict__ X, long ldx, long nrows,
                                                            const double* __restrict__ Ld, long ldl,
                                                            const double* __restrict__ inv16 /* packed image */,
@@ -669,6 +738,14 @@ __global__ __launch_bounds__(256, 2) void trsm_rows_kernel(double* __restrict__ 
     trsm_rows_body(X, ldx, nrows, inv16, blockIdx.x, sl);
     __syncthreads();
     pgp_yield_mark(yield_flags, -1);
+}
+
+// dst (pinned host memory, mapped into the device's address space) <- src: 16 bytes per thread; visible to the host when the kernel
+// has completed (coherent host memory, the end of a kernel is a system-scope release)
+__global__ __launch_bounds__(256) void publish_kernel(const double* __restrict__ src, double* __restrict__ dst, long count) {
+    const long i = 2 * ((long)blockIdx.x * 256 + threadIdx.x);
+    if (i + 1 < count) *(double2_t*)(dst + i) = *(const double2_t*)(src + i);
+    else if (i < count) dst[i] = src[i];
 }
 
 // W_kk = inv(L_kk) for every 128x128 diagonal block k (blockIdx.x), written into W (same layout).
@@ -710,12 +787,21 @@ int leaf_potrf_launch(double* A, long lda, double* inv16, int* info, int info_ba
 }
 
 int trsm_rows_launch(double* X, long ldx, long nrows, const double* Ld, long ldl, const double* inv16,
-                     hipStream_t st, unsigned* yield_flags) {
+                     hipStream_t st, unsigned* yield_flags, bool lean) {
     if (nrows <= 0) return PGP_OK;
     const unsigned nblk = (unsigned)((nrows + 63) / 64);
+    if (lean) {
+        hipLaunchKernelGGL(trsm_rows_lean_kernel, dim3(nblk), dim3(256), 0, st, X, ldx, nrows, inv16, yield_flags);
+        return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+    }
     const size_t shm = 36 * 256 * sizeof(double);
     func_max_dynamic_lds((const void*)trsm_rows_kernel, shm);
     hipLaunchKernelGGL(trsm_rows_kernel, dim3(nblk), dim3(256), shm, st, X, ldx, nrows, Ld, ldl, inv16, yield_flags);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
+int publish_launch(const double* src_dev, double* dst_host_mapped, long count, hipStream_t st) {
+    hipLaunchKernelGGL(publish_kernel, dim3((unsigned)((count + 511) / 512)), dim3(256), 0, st, src_dev, dst_host_mapped, count);
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 

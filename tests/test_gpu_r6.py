@@ -64,3 +64,28 @@ def test_predict_wall_time_is_device_time(lib):
         assert np.array_equal(ym, ref)
         assert lt["total"] > 0 and lt["assemble"] < 1.0, lt
         assert wall <= 1.5 * lt["total"] + 5.0, (wall, lt)
+
+
+@pytest.mark.parametrize("N", [2048, 4608, 8192])
+def test_lean_panel_solve_is_bit_identical_to_the_lds_form(lib, N):
+    """trsm_rows_lean_kernel (round 6: the panel solve of the diagonal-block chain without LDS, on < 96 registers, so that it is
+    resident beside two bulk workgroups per CU) does the same products in the same order as trsm_rows_kernel: every output of a
+    fit -- nlZ, alpha, dnlZ, the factor -- is bit-identical with the lean form off (0), on for the chain (1, default) and everywhere (2);
+    and each reproduces G6 (Core/inf.py:353-384)."""
+    from pygps_amd import _lib
+    ctx = _lib.ctx()
+    x, y = synth_reg(N, 16)
+    hyp = np.array([np.log(4.0), 0.0])
+    out = {}
+    try:
+        for v in (0, 1, 2):
+            _lib.check(lib.pgp_set_option(ctx, b"trsm_lean", v))
+            out[v] = _fit(lib, 0, hyp, 0, np.log(0.1), x, y, float(y.mean()) * np.ones(N), np.ones((1, N)))
+    finally:
+        lib.pgp_set_option(ctx, b"trsm_lean", 1)
+    for v in (1, 2):
+        assert out[v]["nlZ"] == out[0]["nlZ"] and np.array_equal(out[v]["alpha"], out[0]["alpha"])
+        assert np.array_equal(out[v]["dnlZ"], out[0]["dnlZ"]) and np.array_equal(out[v]["L"], out[0]["L"])
+    if N in (2048, 8192):
+        g = golden("G6_rbf_d16_N%d" % N)
+        assert relerr(out[1]["nlZ"], g["nlZ"]) < 1e-9 and relerr(out[1]["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-8
