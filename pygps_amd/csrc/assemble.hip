@@ -725,54 +725,48 @@ __global__ __launch_bounds__(256, HV == 2 ? 4 : 2) void cov_gram_fast_kernel(con
                 for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1, fb1[q], acc[q], 0, 0, 0);
             }
         }
-        double v[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[a][q] = exp_nonpos_tab(clamp_exp_arg(acc[q][a]), etab);   // = cpre * exp(-r^2 / 2)
-        // The exact entries -- K_ii = sf2 (r^2 = 0 by definition, not by cancellation), and in the factor form the unit diagonal,
-        // the identity on the padding and the zeros below the diagonal -- only exist on diagonal tiles and on the last tile row /
-        // column: a uniform branch without memory operations (the body above stays what the memory pipeline was counted for).
+        // The scalar map, the direct stores and the LDS writes of the mirror image are ONE pass over the accumulators, two values at
+        // a time: the 8 direct store instructions go out spread over the ~1700 cycles of the map instead of as a burst behind it.
+        // The exact entries -- K_ii = sf2 (r^2 = 0 by definition, not by cancellation), and in the factor form the unit diagonal, the
+        // identity on the padding and the zeros below the diagonal -- only exist on diagonal tiles and on the last tile row / column:
+        // a uniform branch per pair that touches the two values only (two separate code paths for the tile kinds SPILL: the
+        // allocator keeps both alive).
         const int nrl = (int)(n - r0 < ST ? n - r0 : ST), ncl = (int)(n - c0 < ST ? n - c0 : ST);    // live rows / columns of this tile
-        if (tc2.x == tc2.y || (MODE == MODE_FACTOR && (nrl < ST || ncl < ST))) {
-            const bool dtile = tc2.x == tc2.y;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int rl = 16 * wave + 4 * a + l4, cl = 16 * q + l15;
-                    const bool same = dtile && rl == cl;
-                    double val = same ? cpre : v[a][q];
-                    if (MODE == MODE_FACTOR) {
-                        const double live = val + (same ? 1.0 : 0.0), pad = same ? 1.0 : 0.0;
-                        val = (rl < nrl && cl < ncl) ? live : pad;
-                        val = (dtile && cl < rl) ? 0.0 : val;      // exact zeros below the diagonal (row-major upper view)
-                    }
-                    v[a][q] = val;
-                }
-        }
-        // direct stores: 8 x 16 bytes per lane (adjacent lanes trade one value each, see the general kernel)
+        const bool dtile = tc2.x == tc2.y;
+        const bool special = dtile || (MODE == MODE_FACTOR && (nrl < ST || ncl < ST));
+        auto exact = [&](double val, int a, int q) -> double {
+            const int rl = 16 * wave + 4 * a + l4, cl = 16 * q + l15;
+            const bool same = dtile && rl == cl;
+            val = same ? cpre : val;
+            if (MODE == MODE_FACTOR) {
+                const double live = val + (same ? 1.0 : 0.0), pad = same ? 1.0 : 0.0;
+                val = (rl < nrl && cl < ncl) ? live : pad;
+                val = (dtile && cl < rl) ? 0.0 : val;              // exact zeros below the diagonal (row-major upper view)
+            }
+            return val;
+        };
+        if (MODE == MODE_SYM) lds_barrier();           // every wave has read this tile's coordinates: the region takes the mirror image
         {
-            // one 64-bit row pointer per lane; the (a, q) pieces are a row step of 8 ldo and immediate column offsets
             double* rowp = out + (r0 + 16 * wave + (odd ? 4 : 0) + l4) * ldo + c0 + (l15 & ~1);
 #pragma unroll
             for (int a = 0; a < 4; a += 2) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const double x0 = v[a][q], x1 = v[a + 1][q];
+                    double x0 = exp_nonpos_tab(clamp_exp_arg(acc[q][a]), etab), x1 = exp_nonpos_tab(clamp_exp_arg(acc[q][a + 1]), etab);
+                    if (special) { x0 = exact(x0, a, q); x1 = exact(x1, a + 1, q); }
+                    if (MODE == MODE_SYM) {
+                        gsm[(16 * q + l15) * GSTP + 16 * wave + 4 * a + l4] = x0;
+                        gsm[(16 * q + l15) * GSTP + 16 * wave + 4 * (a + 1) + l4] = x1;
+                    }
                     const double n0 = gram_swap_adjacent(x0), n1 = gram_swap_adjacent(x1);
                     *(double2_t*)(rowp + 16 * q) = odd ? double2_t{n1, x1} : double2_t{x0, n0};
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 rowp += 8 * ldo;
             }
         }
         if (MODE == MODE_SYM) {
-            // mirrored store out[c][r]: transpose through LDS (this tile's coordinates are consumed), 8 x 16 bytes per lane
-            lds_barrier();
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) gsm[(16 * q + l15) * GSTP + 16 * wave + 4 * a + l4] = v[a][q];
+            // mirrored store out[c][r]: the transposed image in LDS, 8 x 16 bytes per lane
             lds_barrier();
             double* colp = out + (c0 + rw) * ldo + r0 + 2 * pr;
 #pragma unroll
