@@ -525,8 +525,8 @@ def test_device_out_of_memory_raises_and_the_context_recovers(lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 8])
-def test_bench_collective_extras_ranks_sharing_one_gpu(tmp_path, world):
+@pytest.mark.parametrize("world,stub", [(2, False), (8, False), (2, True), (4, True)])
+def test_bench_collective_extras_ranks_sharing_one_gpu(tmp_path, world, stub):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with
     all ranks on the one GPU of the box and the collectives through gloo: the weak-scaled timed region, then the collective
     extras -- cfg 4's restart search sharded over the ranks (world 8: BASELINE configs[3] as written, one restart per rank)
@@ -535,6 +535,9 @@ def test_bench_collective_extras_ranks_sharing_one_gpu(tmp_path, world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYGPS_BENCH_BACKEND="gloo")
+    if stub:       # round 6: the extras over the library's RCCL BRANCH (what an 8-GPU node runs), bound to tests/stub_rccl's shared-memory stand-in
+        from conftest import build_stub_rccl
+        env.update(PYGPS_AMD_TRANSPORT="rccl", PYGPS_AMD_RCCL_PATH=build_stub_rccl())
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                           "--gpus", str(world), "--steps", "4", "--warmup", "2", "--windows", "1",   # (no --n: torchrun's parser trips on it)
@@ -549,6 +552,8 @@ def test_bench_collective_extras_ranks_sharing_one_gpu(tmp_path, world):
     assert c4["n_gpus"] == world and c4["restarts"] == 8 and c4["fits"] > 8 and np.isfinite(c4["nlZ_best"]), c4
     sf = j["sharded_fit"]
     assert sf["world"] == world and sf["panels"] == 8 and sf["residual_normal_equations"] < 1e-10 and np.isfinite(sf["nlZ"]), sf
+    if stub:
+        assert sf.get("transport", "rccl") == "rccl"
 
 
 @pytest.mark.gpu
