@@ -222,6 +222,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "eet_tile")) { if (value != 64 && value != 128) return -2; c->eet_tile = value; return PGP_OK; }
     if (!strcmp(name, "fused_inverse")) { c->fused_inverse = value; return PGP_OK; }
     if (!strcmp(name, "trsm_lean")) { if (value < 0 || value > 2) return -2; c->trsm_lean = value; return PGP_OK; }
+    if (!strcmp(name, "ep_merge12")) { c->ep_merge12 = value != 0; return PGP_OK; }
     if (!strcmp(name, "publish")) { c->publish = value != 0; return PGP_OK; }
     if (!strcmp(name, "fused_value_max_np")) { c->fused_value_max_np = value; return PGP_OK; }
     if (!strcmp(name, "asm_grid")) { c->asm_grid = value; return PGP_OK; }

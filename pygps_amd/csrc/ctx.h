@@ -138,6 +138,7 @@ struct pgp_ctx {
     double* res_host = nullptr;         // pinned
     double* res_host_dev = nullptr;     // the same pinned buffer in the device's address space (option "publish": the last kernel of a fit
                                         // writes the results straight into it; no copy command behind the fit)
+    int ep_merge12 = 1;                 // option "ep_merge12": EP's first two (unconditional) sweeps queued back to back, one host round trip for both
     int trsm_lean = 0;                  // option "trsm_lean": 1 = the LDS-free panel solve for the diagonal-block chain beside bulk work, 0 never, 2 always
     int publish = 1;                    // option "publish" 1 / 0
     double* in_host = nullptr;          // pinned staging of the per-fit inputs (prior mean, scales)

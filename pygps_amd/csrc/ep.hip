@@ -1244,18 +1244,28 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
     const int max_sweep = 10, min_sweep = 2;
     double nlZ_old = INFINITY;
     int sweep = 0;
+    // ONE block sweep per device at a time, and nothing else of this process beside it (ctx.h DeviceGate: the sweep is a resident
+    // kernel on one stream that meets bulk launches on another through device counters; a foreign launch with a cross-stream wait
+    // on a shared hardware queue can close a cycle).  Exclusive from a sweep's first launch until the host synchronisation that
+    // follows it; K, the final Cholesky, alpha and the gradients of an EP fit run under the shared gate beside other contexts' work.
+    struct SweepExclusive {
+        GateShared& g; bool on, held = false;
+        SweepExclusive(GateShared& g_, bool on_) : g(g_), on(on_) {}
+        void acquire() { if (on && !held) { g.exclusive(); held = true; } }
+        void release() { if (held) { g.shared_again(); held = false; } }
+        ~SweepExclusive() { release(); }
+    } sweep_excl(gate, c->ep_block != 0);
+    // (round 6) The first two sweeps are unconditional (min_sweep = 2, inf.py:732): sweep 2 is queued straight behind sweep 1 -- no
+    // host round trip between them.  What the host needs of sweep 1 (its blocks' log det factors and the per-site partial sums:
+    // nlZ after sweep 1 is what sweep 2's convergence test compares with) waits in a second slot of the result buffer and comes
+    // back with sweep 2's in one copy.  Option ep_merge12 = 0: a synchronisation after every sweep, as before.
+    const bool merge12 = track && c->ep_block && c->ep_merge12 && min_sweep >= 2 && !ep_timing;
+    const long res_len = np / EPB + 3 + 5 * ((n + 255) / 256), res_slot = (res_len + 15) & ~15L;   // [log det factors | counters | partial sums]
+    bool deferred = false;                             // sweep 1's results are in the second slot
     while ((fabs(nlZ - nlZ_old) > tol && sweep < max_sweep) || sweep < min_sweep) {
         nlZ_old = nlZ;
         ++sweep;
-        // ONE block sweep per device at a time, and nothing else of this process beside it (ctx.h DeviceGate: the sweep is a resident
-        // kernel on one stream that meets bulk launches on another through device counters; a foreign launch with a cross-stream wait
-        // on a shared hardware queue can close a cycle).  Exclusive until this sweep's host synchronisation at the end of the loop
-        // body; K, the final Cholesky, alpha and the gradients of an EP fit run under the shared gate beside other contexts' work.
-        struct SweepExclusive {
-            GateShared& g; bool on;
-            SweepExclusive(GateShared& g_, bool on_) : g(g_), on(on_) { if (on) g.exclusive(); }
-            ~SweepExclusive() { if (on) g.shared_again(); }
-        } sweep_excl(gate, c->ep_block != 0);
+        sweep_excl.acquire();
         if (c->ep_block) {
             // block sweep: the chain stream (the high-priority panel stream) runs ONE resident kernel per sweep (chain + prep workgroups);
             // the bulk stream (main) strip(b), U(b), fold(b), mu(b) per block.  The two meet through device counters (ep_chain_kernel).
@@ -1383,16 +1393,29 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
             EP_TRY(gather_strided_launch(w.Sig, np + 1, np, w.diag_d, st));
             hipLaunchKernelGGL(ep_site_terms_kernel, dim3((unsigned)nbt), dim3(256), 0, st, n, c->y_dev, w.m_d, w.mu_d, w.diag_d, 0.0,
                                w.ttau_d, w.tnu_d, 1, part_d, (double*)nullptr);
-            HIP_TRY(hipMemcpyAsync((void*)res_h, w.ldb, (size_t)(np / EPB + 3 + 5 * nbt) * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (merge12 && sweep == 1 && 2 * res_slot <= np) {
+                HIP_TRY(hipMemcpyAsync(w.ldb + res_slot, w.ldb, (size_t)res_len * sizeof(double), hipMemcpyDeviceToDevice, st));
+                deferred = true;
+                continue;                              // sweep 2 follows at once; the gate stays exclusive
+            }
+            HIP_TRY(hipMemcpyAsync((void*)res_h, w.ldb, (size_t)(deferred ? res_slot + res_len : res_len) * sizeof(double), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            sweep_excl.release();
             memcpy(eflags, res_h + np / EPB + 1, sizeof(eflags));
-            const double* const ldh = res_h;
-            const double* const ph = res_h + np / EPB + 3;
             if (eflags[EPF_ERR]) return ep_wait_failed(eflags, w.chain_total, w.prep_total, w.strip_total, __LINE__);
-            for (long b = 0; b < nbl; ++b) half_logdet += 0.5 * ldh[b];
-            double slZ = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0, t6 = 0.0;
-            for (long b = 0; b < nbt; ++b) { slZ += ph[5 * b]; t3 += ph[5 * b + 1]; t4 += ph[5 * b + 2]; t5 += ph[5 * b + 3]; t6 += ph[5 * b + 4]; }
-            nlZ = half_logdet - slZ - 0.5 * t3 - 0.5 * t4 + 0.5 * t5 - 0.5 * t6;
+            auto nlz_from = [&](const double* r) -> double {      // inf.py:184-188 from one slot; half_logdet accumulates over the sweeps
+                const double* const ph = r + np / EPB + 3;
+                for (long b = 0; b < nbl; ++b) half_logdet += 0.5 * r[b];
+                double slZ = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0, t6 = 0.0;
+                for (long b = 0; b < nbt; ++b) { slZ += ph[5 * b]; t3 += ph[5 * b + 1]; t4 += ph[5 * b + 2]; t5 += ph[5 * b + 3]; t6 += ph[5 * b + 4]; }
+                return half_logdet - slZ - 0.5 * t3 - 0.5 * t4 + 0.5 * t5 - 0.5 * t6;
+            };
+            if (deferred) {                            // sweep 1 first: its nlZ is what this sweep's convergence test compares with
+                const double nlZ1 = nlz_from(res_h + res_slot);
+                nlZ_old = std::isfinite(nlZ1) ? nlZ1 : INFINITY;
+                deferred = false;
+            }
+            nlZ = nlz_from(res_h);
             if (!std::isfinite(nlZ)) {                 // let the rebuild say what is wrong (first bad pivot)
                 EP_TRY(sites_to_host());
                 HIP_TRY(hipStreamSynchronize(st));
@@ -1405,6 +1428,7 @@ static int ep_fit_core(pgp_ctx* c, const double* Kdense, int kind, const double*
         EP_TRY(sites_to_host());
         if (c->ep_block) HIP_TRY(hipMemcpyAsync(eflags, w.flags, sizeof(eflags), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        sweep_excl.release();
         if (eflags[EPF_ERR]) return ep_wait_failed(eflags, w.chain_total, w.prep_total, w.strip_total, __LINE__);
         stamp("sweep done (synced)", 1);
         rc = ep_compute_params(c, w, y, m, ttau, tnu, &nlZ, mu, dsig);                // inf.py:772

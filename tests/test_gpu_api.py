@@ -162,7 +162,8 @@ def test_tools_jitchol_solve_chol(lib):
         tools.solve_chol(np.eye(3), np.ones((4, 1)))
 
 
-def test_G9_restarts_sequential_and_sharded_single_rank(lib):
+def test_G9_restarts_sequential_and_sharded_single_rank_winner_in_tied_set_RELAXED(lib):
+    """G9 N = 512 through Minimize and ShardedMinimize; 'which restart wins' relaxed to the tied set (see the N = 2048 test)."""
     import pygps_amd as pyGPs
     g = golden("G9_restarts_N512")
     N, d = int(g["N"]), int(g["d"])
@@ -193,8 +194,10 @@ def test_G9_restarts_sequential_and_sharded_single_rank(lib):
             assert near(f) == near(g["run_f"]) and int(np.argmin(f)) in near(g["run_f"])
 
 
-def test_G9_restarts_at_the_specified_size_N2048(lib):
-    """SURVEY 8(c) G9 as specified: the G6 N=2048 data, np.random.seed(123), 8 restarts x 40 line searches, recorded from
+def test_G9_restarts_N2048_winner_within_the_tied_set_RELAXED_from_survey_8c(lib):
+    """(The name says it: SURVEY 8(c) asks for an exact match on WHICH restart wins; this test relaxes that to 'the winner lies in the
+    set of restarts that tie to 2e-8' -- the builder's relaxation, argued below; the selection RULE itself is replayed bit for bit on
+    recorded objectives in tests/test_host_logic.py.)  SURVEY 8(c) G9 as specified: the G6 N=2048 data, np.random.seed(123), 8 restarts x 40 line searches, recorded from
     the reference (Core/opt.py:282-328 + Optimization/minimize.py:41-172; 29 min of reference run time).  Every restart's
     final objective must agree to 1e-5 relative (the line-search path amplifies rounding) and the number of
     line searches per restart exactly.  Three restarts (0, 2, 6) reach the same optimum to 2e-8 relative -- `which one
@@ -364,7 +367,7 @@ def test_G8_ep_classification_demo_and_synthetic(lib):
 
 
 @pytest.mark.parametrize("opts", [dict(ep_fused=0), dict(ep_fused=1), dict(ep_sym=0), dict(ep_alpha_direct=0, ep_r_direct=0),
-                                  dict(ep_fused=0, ep_alpha_direct=0, ep_r_direct=0, ep_sym=0), dict(ep_sigma_under=0), dict(ep_recompute=1), dict(ep_block=0), dict(ep_wait_kernel=0), dict(ep_final_rebuild=1)])
+                                  dict(ep_fused=0, ep_alpha_direct=0, ep_r_direct=0, ep_sym=0), dict(ep_sigma_under=0), dict(ep_recompute=1), dict(ep_block=0), dict(ep_wait_kernel=0), dict(ep_final_rebuild=1), dict(ep_merge12=0)])
 def test_ep_variants_agree_with_the_reference(lib, opts):
     """Every kept variant of the EP path -- parameter recomputation by the blocked solve / through the fused inverse /
     as right-hand-side rows of the sweep (default), full or lower-triangle Sigma, alpha and sW sW' o B^-1 by the
@@ -376,7 +379,7 @@ def test_ep_variants_agree_with_the_reference(lib, opts):
     from pygps_amd import _lib
     from conftest import synth_cls
     ctx = _lib.ctx()
-    defaults = dict(ep_fused=2, ep_sym=1, ep_alpha_direct=1, ep_r_direct=1, ep_block=1, ep_sigma_under=1, ep_recompute=0, ep_wait_kernel=1, ep_final_rebuild=0)
+    defaults = dict(ep_fused=2, ep_sym=1, ep_alpha_direct=1, ep_r_direct=1, ep_block=1, ep_sigma_under=1, ep_recompute=0, ep_wait_kernel=1, ep_final_rebuild=0, ep_merge12=1)
     try:
         for k, v in opts.items():
             _lib.check(lib.pgp_set_option(ctx, k.encode(), v))

@@ -89,3 +89,32 @@ def test_lean_panel_solve_is_bit_identical_to_the_lds_form(lib, N):
     if N in (2048, 8192):
         g = golden("G6_rbf_d16_N%d" % N)
         assert relerr(out[1]["nlZ"], g["nlZ"]) < 1e-9 and relerr(out[1]["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-8
+
+
+@pytest.mark.parametrize("N", [128, 2048, 4096])
+def test_ep_first_two_sweeps_back_to_back_change_nothing(lib, N):
+    """EP.evaluate (Core/inf.py:731-806): the first two sweeps are unconditional (inf.py:732), so sweep 2 is queued behind sweep 1
+    without a host round trip (round 6, option ep_merge12) and sweep 1's nlZ comes back with sweep 2's.  Same sweeps, same
+    arithmetic: sweep count, nlZ, alpha, sW, the gradients and the factor are bit-identical with the option off, and both
+    reproduce the reference's fixture (G8ii)."""
+    import pygps_amd as pyGPs
+    from pygps_amd import _lib
+    from conftest import synth_cls
+    ctx = _lib.ctx()
+    g = golden("G8ii_ep_d32_N%d" % N)
+    x, y = synth_cls(N, 32)
+    res = {}
+    try:
+        for v in (1, 0):
+            _lib.check(lib.pgp_set_option(ctx, b"ep_merge12", v))
+            m = pyGPs.GPC()
+            m.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(32.0)), 0.0))
+            nlZ, dnlZ, post = m.getPosterior(x, y)
+            res[v] = (nlZ, np.array(dnlZ.cov), post.alpha.copy(), post.sW.copy(), np.diag(np.asarray(post.L)).copy(), int(m.inffunc.sweeps))
+    finally:
+        lib.pgp_set_option(ctx, b"ep_merge12", 1)
+    a, b = res[1], res[0]
+    assert a[5] == b[5] == int(g["n_sweeps"]) and a[0] == b[0]
+    for u, v in zip(a[1:5], b[1:5]):
+        assert np.array_equal(u, v)
+    assert relerr(a[0], g["nlZ"]) < 1e-8 and relerr(a[2], g["alpha"]) < 1e-6 and relerr(a[4], g["L_diag"]) < 1e-7
