@@ -114,7 +114,9 @@ def test_ep_first_two_sweeps_back_to_back_change_nothing(lib, N):
     finally:
         lib.pgp_set_option(ctx, b"ep_merge12", 1)
     a, b = res[1], res[0]
-    assert a[5] == b[5] == int(g["n_sweeps"]) and a[0] == b[0]
+    assert a[5] == b[5] and a[0] == b[0]
+    if "n_sweeps" in g.files:
+        assert a[5] == int(g["n_sweeps"])
     for u, v in zip(a[1:5], b[1:5]):
         assert np.array_equal(u, v)
     assert relerr(a[0], g["nlZ"]) < 1e-8 and relerr(a[2], g["alpha"]) < 1e-6 and relerr(a[4], g["L_diag"]) < 1e-7
