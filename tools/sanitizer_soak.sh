@@ -11,7 +11,7 @@ export PYGPS_AMD_LIB=$R/pygps_amd/libpygps_amd_ubsan.so
 export UBSAN_OPTIONS=print_stacktrace=1
 export LD_PRELOAD=$(/opt/rocm/bin/hipcc -print-file-name=libclang_rt.ubsan_standalone-x86_64.so)
 cd $R
-timeout 900 python -m pytest tests/test_gpu_api.py tests/test_gpu_fitc.py tests/test_gpu_core.py tests/test_gpu_sharded.py tests/test_gpu_composite.py tests/test_gpu_parity_r3.py tests/test_gpu_parity_r4.py tests/test_gpu_r5.py -m gpu -x -q -k "not bench and not rccl and not world" 2>&1 | grep -E "passed|failed|error|runtime error" | tail -5
+timeout 900 python -m pytest tests/test_gpu_api.py tests/test_gpu_fitc.py tests/test_gpu_core.py tests/test_gpu_sharded.py tests/test_gpu_composite.py tests/test_gpu_parity_r3.py tests/test_gpu_parity_r4.py tests/test_gpu_r5.py tests/test_gpu_r6.py -m gpu -x -q -k "not bench and not rccl and not world" 2>&1 | grep -E "passed|failed|error|runtime error" | tail -5
 timeout 600 python tools/two_streams.py 2>&1 | tail -2
 REPS=10 timeout 600 python tools/ep_kfold_diag.py 2>&1 | grep -E "rep|gave" | tail -3
 timeout 600 python tools/mixed_soak.py 2>&1 | tail -3
