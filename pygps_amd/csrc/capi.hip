@@ -194,6 +194,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "sched")) { if (value < -1 || value > 2) return -2; c->sched = value < 0 ? PGP_SCHED_DEFAULT : value; c->sched_explicit = value >= 0; return PGP_OK; }
     if (!strcmp(name, "concurrent_streams")) { c->concurrent_streams = value != 0; return PGP_OK; }   // a HINT: an explicit "sched" wins
     if (!strcmp(name, "tud_tile")) { if (value != 64 && value != 128) return -2; c->tud_tile = value; return PGP_OK; }
+    if (!strcmp(name, "tur_tile")) { if (value != 0 && value != 64 && value != 128 && value != 1264) return -2; c->tur_tile = value; return PGP_OK; }
     if (!strcmp(name, "s_pan")) { if (value < -1 || value > 2) return -2; c->s_pan = value; return PGP_OK; }
     if (!strcmp(name, "s_pan_direct")) { c->s_pan_direct = value != 0; return PGP_OK; }
     if (!strcmp(name, "s_pan_out")) { c->s_pan_out = value != 0; return PGP_OK; }
@@ -592,7 +593,7 @@ static int gemm_prepare(pgp_ctx* c, GemmArgs& g) {
     // tiles would be serialised on one or two XCDs by it; and only up to K = xcd_max_k (measured: N = 8192, K = 512:
     // same speed, -40 % FETCH_SIZE per launch; N = 16384, K = 1024: 6 % slower)
     bool xcd = false;
-    if (c->xcd_order && !g.order && g.tile != 64 && g.batch == 1 && g.K <= c->xcd_max_k) {
+    if (c->xcd_order && !g.order && g.tile != 64 && g.tile != 1264 && g.batch == 1 && g.K <= c->xcd_max_k) {
         const long mt = g.M / 128, nt = g.N / 128;
         const long tiles = g.tri == 2 ? mt * (mt + 1) / 2 : (g.tri == 1 ? mt * nt - nt * (nt - 1) / 2 : mt * nt);
         xcd = tiles >= c->xcd_min_tiles;
@@ -605,7 +606,7 @@ static int gemm_prepare(pgp_ctx* c, GemmArgs& g) {
     if (c->yield && c->yield_flags) {
         g.yield_flags = c->yield_flags;
         // the chain's own small products mark their CUs; every bulk (128-tile, LDS-DMA) launch polls
-        g.yield_role = c->chain_now ? 2 : (gemm_f64_uses_dma128(g) ? 1 : 0);
+        g.yield_role = c->chain_now ? 2 : (gemm_f64_uses_dma(g) ? 1 : 0);
     }
     if (c->gemm_trace && gemm_f64_uses_dma128(g) && g.batch == 1) {
         const long mt = g.M / 128, nt = g.N / 128;
@@ -1026,7 +1027,7 @@ static int potrf_blocked_v2(pgp_ctx* c, const SweepMat& m) {
                 c->chain_now = was;
                 CHK(rc);
             }
-            CHK(gemm_prof(c, PC_GEMM_TRAIL, trailing_update_rows_args(c, m, s0, s1, n1, -1, n0, n1, Xs, ldx, 128), main));
+            CHK(gemm_prof(c, PC_GEMM_TRAIL, trailing_update_rows_args(c, m, s0, s1, n1, -1, n0, n1, Xs, ldx, c->tur_tile ? c->tur_tile : (nblk <= 40 ? 1264 : 128)), main));
         } else {
         CHK(trailing_update2(c, m, s0, s1, n0, n1, Xs, ldx, main));   // TU_a -> staging
         if (la) {

@@ -48,7 +48,7 @@ struct GemmArgs {
     int mask_diag;
     int kmode; int koff;
     int batch; long sA, sB, sC;   // batch strides in elements
-    int tile;               // 128 or 64
+    int tile;               // 128 or 64; 1264 = 128 x 64 LDS-DMA tiles (plain rectangles only; anything else falls back to 128)
     const int* order;       // optional (ti,tj) pairs per block (XCD-aware / LPT tile order built on the host); grid = norder
     int norder;
     int order_z;            // 1: the list spans a whole batch -- ti carries the batch index in its bits 16.. (grid.z = 1): a shrinking
@@ -105,6 +105,7 @@ __device__ __forceinline__ void pgp_yield_mark(unsigned* flags, int delta) {
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st);
 bool gemm_f64_pair_ok(const GemmArgs& a, const GemmArgs& b);     // may the two go out as ONE launch (gemm_f64_launch_pair)?
 int gemm_f64_launch_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t st);
+bool gemm_f64_uses_dma(const GemmArgs& g);          // ... or any LDS-DMA tile (128 x 128, or 128 x 64 = GemmArgs::tile 1264)?
 bool gemm_f64_uses_dma128(const GemmArgs& g);       // would gemm_f64_launch pick the LDS-DMA 128-tile instantiation?
 
 // hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that needs more than 64 KB of dynamic LDS: applied once per

@@ -66,6 +66,10 @@ struct pgp_ctx {
                                         // stream (what fit streams that run side by side select); 2 = like 0, but the piece of TU_a that D(p+1)
                                         // needs -- the next panel's diagonal block -- runs on the panel stream right behind S(p)
                                         // (potrf_blocked_v2; lone chain at N = 8192: 11.13 -> 10.90 ms)
+    int tur_tile = 0;                   // sched 2: tiles of the rectangle below it (TU_r, main stream): 128, or 1264 = 128 x 64 LDS-DMA tiles (two workgroups per
+                                        // CU: 78 -> 70 us alone on the chip at N = 8192); 0 = by size: 1264 up to N = 5120 (N = 4096: two streams +2 ... 3 %,
+                                        // single chain equal), 128 beyond (N = 8192: the chain's kernels find no free slot beside two workgroups per CU:
+                                        // single chain 10.52 -> 10.63 ms)
     int tud_tile = 64;                  // sched 2: tile size of the diagonal-block piece of TU_a on the panel stream
     int sched2_wide = 0;                // sched 2 also with panels wider than 512 columns (measured slower: N = 16384 +2 %)
     int s_pan = -1;                     // sched 2: S(p), p >= 1, on the panel stream right behind D(p)'s leaf chain: it runs in the tail of the

@@ -50,7 +50,7 @@ namespace {
 using gemm_tile_ns::BK;
 
 // tile (ti, tj) of workgroup number b of a launch described by g; false: padding entry, nothing to do
-__device__ __forceinline__ bool decode_tile(const GemmArgs& g, int b, int T, int& ti, int& tj) {
+__device__ __forceinline__ bool decode_tile(const GemmArgs& g, int b, int T, int TNc, int& ti, int& tj) {
     if (g.order) {                                  // host-built tile order (see tile_order() in capi.hip)
         ti = g.order[2 * b];
         tj = g.order[2 * b + 1];
@@ -67,7 +67,7 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs& g, int b, int T, int
     const int mt = g.M / T;
     ti = b % mt;
     tj = b / mt;
-    if (g.rev_cols) tj = g.N / T - 1 - tj;
+    if (g.rev_cols) tj = g.N / TNc - 1 - tj;
     return true;
 }
 
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         tr0[6] = (long long)__builtin_readcyclecounter();     // shader clock: with [7] the frequency this workgroup ran at
     }
     int ti, tj;
-    if (!decode_tile(g, (int)blockIdx.x, TM, ti, tj)) return;
+    if (!decode_tile(g, (int)blockIdx.x, TM, TN, ti, tj)) return;
     long bz = blockIdx.z;
     if (g.order_z) { bz = ti >> 16; ti &= 0xffff; }
     if (g.wait_flag) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_pair_kernel(GemmArgs a, GemmA
             tr0[6] = (long long)__builtin_readcyclecounter();
         }
         int ti, tj;
-        if (!decode_tile(g, bid, 128, ti, tj)) return;
+        if (!decode_tile(g, bid, 128, 128, ti, tj)) return;
         gemm_tile_ns::gemm_tile<128, 128, false, false, true, YIELD>(g, ti, tj, 0, smem, bid);
     };
     if ((int)blockIdx.x < na) run(a, (int)blockIdx.x);
@@ -143,6 +143,21 @@ int launch_t(const GemmArgs& g, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
+// the 128 x 64 LDS-DMA tile (GemmArgs::tile == 1264): plain rectangles only -- no triangular tile set, no host-built order, no batch
+static bool dma_ok(const GemmArgs& g);
+static bool dma1264_ok(const GemmArgs& g) {
+    return g.tile == 1264 && dma_ok(g) && !g.tri && !g.order && g.batch <= 1 && !g.order_z && (g.N % 64) == 0 && (g.M % 128) == 0 && g.kmode == KM_FULL;
+}
+template <bool YIELD>
+int launch_1264(const GemmArgs& g, hipStream_t st) {
+    constexpr int SA_ = 128 + 16;
+    const size_t shm = 2 * (BK * SA_ + (BK / 2) * SA_) * sizeof(double);
+    dim3 grid((unsigned)((g.M / 128) * (g.N / 64)), 1, 1);
+    func_max_dynamic_lds((const void*)gemm_f64_kernel<128, 64, false, false, true, YIELD>, shm);
+    hipLaunchKernelGGL((gemm_f64_kernel<128, 64, false, false, true, YIELD>), grid, dim3(256), shm, st, g);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
 static bool dma_ok(const GemmArgs& g) {
     return g.tile != 64 && (g.dbg & 64) && !g.a_kc && !g.b_kc && (g.K % 16) == 0 && (g.koff % 16) == 0 && (g.batch_dk % 16) == 0;
 }
@@ -157,7 +172,8 @@ int launch_l(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
-bool gemm_f64_uses_dma128(const GemmArgs& g) { return dma_ok(g); }
+bool gemm_f64_uses_dma128(const GemmArgs& g) { return dma_ok(g) && !dma1264_ok(g); }
+bool gemm_f64_uses_dma(const GemmArgs& g) { return dma_ok(g); }           // any LDS-DMA tile (128 x 128 or 128 x 64): the yield poll's side
 
 static unsigned launch_blocks(const GemmArgs& g) {
     const int mt = g.M / 128, nt = g.N / 128;
@@ -186,6 +202,7 @@ int gemm_f64_launch_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PGP_OK;
     if (g.tile == 64) return launch_l<64>(g, st);
+    if (dma1264_ok(g)) return (g.yield_role == 1 && g.yield_flags) ? launch_1264<true>(g, st) : launch_1264<false>(g, st);
     // LDS-DMA staging (dbg bit 64): 128 x 128 tiles of M-contiguous operands, whole 16-deep k-tiles
     if (dma_ok(g)) return (g.yield_role == 1 && g.yield_flags) ? launch_t<128, false, false, true, true>(g, st)
                                                                : launch_t<128, false, false, true>(g, st);

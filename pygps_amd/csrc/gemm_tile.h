@@ -51,10 +51,16 @@ __device__ __noinline__ void gemm_yield_wait(const unsigned* yf) {
 // issued beside the LDS-DMA pieces and consumed after the stage's barrier, and a never-taken branch).
 template <int TM, int TN, bool AKC, bool BKC, bool DMA = false, bool YIELD = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, long bz, double* __restrict__ smem, int wg = 0) {
-    static_assert(!DMA || (!AKC && !BKC && TM == 128 && TN == 128), "LDS-DMA staging: 128-wide M-contiguous operands only");
-    constexpr int SA = TM + 16, SB = TN + 16, SK = BK + 2;
+    static_assert(!DMA || (!AKC && !BKC && TM == 128 && (TN == 128 || TN == 64)), "LDS-DMA staging: M-contiguous operands, 128 x 128 or 128 x 64 tiles");
+    // BH (round 6, the 128 x 64 LDS-DMA tile: TWO workgroups per CU for a launch of fewer 128 x 128 tiles than CUs): a k-row of the B
+    // operand is 64 doubles = half a 1 KiB LDS-DMA piece, so one piece carries the k-rows (k, k + 4) -- lanes 0-31 fetch row k,
+    // lanes 32-63 row k + 4, landing 512 bytes apart -- and the four k-rows a fragment read touches (4 ks + l4) sit in four
+    // DIFFERENT pieces, SA doubles apart like the A operand's rows (the same conflict-free bank pattern):
+    //   row k -> piece (k & 3) + 4 (k >> 3), half (k >> 2) & 1;  8 pieces per stage, wave w stages pieces w and w + 4
+    constexpr bool BH = DMA && TN == 64;
+    constexpr int SA = TM + 16, SB = BH ? TM + 16 : TN + 16, SK = BK + 2;
     constexpr int ASZ = AKC ? TM * SK : BK * SA;
-    constexpr int BSZ = BKC ? TN * SK : BK * SB;
+    constexpr int BSZ = BKC ? TN * SK : (BH ? (BK / 2) * SB : BK * SB);
     constexpr int STAGE = ASZ + BSZ;
     constexpr int FM = TM / 32, FN = TN / 32;      // 16x16 fragments per wave in M and N
     constexpr int AV = TM * BK / 2 / 256;          // double2 vectors staged per thread
@@ -102,7 +108,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
     const bool wantc = g.beta != 0.0 && !(zero_from > 0 && i0 >= zero_from);
     // LDS-DMA variant: the staging registers it frees hold one quarter of the C tile at a time, fetched DURING the k-loop
     // and folded into the accumulators two k-steps later ("lazy C": the pre-load no longer delays the first MFMA)
-    const bool lazyc = DMA && wantc && (g.dbg & 256) && (k1 - k0) >= (FN * FM + 2) * BK;
+    // (the prologue is LZ = 16 k-steps for BOTH LDS-DMA tile shapes, and an element's C value is folded in at the same k-step in
+    //  both -- step 4 q + 2 (im / 2) + 1 for the element's 16-column group q of its 64-column slab: the 128 x 64 tile reproduces the
+    //  128 x 128 tile bit for bit)
+    constexpr int LZ = 16;
+    const bool lazyc = DMA && wantc && (g.dbg & 256) && (k1 - k0) >= (LZ + 2) * BK;
     const bool preload = wantc && !lazyc;
 #pragma unroll
     for (int im = 0; im < FM; ++im)
@@ -150,20 +160,33 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
     const double* db[4];
     unsigned lds_w = 0;                            // LDS byte address of k-row `wave` of stage buffer 0 (wave-uniform)
     const unsigned dvoff = (unsigned)lane * 16u;   // this lane's 16 bytes inside the 1 KiB row piece
+    unsigned dvoff_b = dvoff;                      // BH: lanes 32-63 fetch the k-row four further down
+    if constexpr (BH) dvoff_b = (unsigned)(lane & 31) * 16u + (unsigned)(lane >> 5) * (unsigned)(4L * g.ldb * 8L);
     const unsigned smem_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem;
     if constexpr (DMA) {
         static_assert(SA == SB, "one LDS row stride for both operands");
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             da[p] = uniform_ptr(A + (long)i0 + (long)(k0 + wave + 4 * p) * lda);
-            db[p] = uniform_ptr(B + (long)j0 + (long)(k0 + wave + 4 * p) * g.ldb);
+            // BH: two pieces per wave, k-rows (wave, wave + 4) and (wave + 8, wave + 12)
+            db[p] = uniform_ptr(B + (long)j0 + (long)(k0 + wave + (BH ? 8 * (p & 1) : 4 * p)) * g.ldb);
         }
         lds_w = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)wave * (unsigned)(SA * 8));
     }
     const long dstep_a = (long)BK * lda, dstep_b = (long)BK * g.ldb;
     auto dma_stage = [&](auto bufc) {
         constexpr int O = decltype(bufc)::value * STAGE * 8;
-        if constexpr (DMA) {
+        if constexpr (DMA && BH) {
+            lds_dma_1k_s<O + 0 * SA * 8>(dvoff, da[0], lds_w);
+            lds_dma_1k_s<O + ASZ * 8 + 0 * SB * 8>(dvoff_b, db[0], lds_w);
+            lds_dma_1k_s<O + 4 * SA * 8>(dvoff, da[1], lds_w);
+            lds_dma_1k_s<O + 8 * SA * 8>(dvoff, da[2], lds_w);
+            lds_dma_1k_s<O + ASZ * 8 + 4 * SB * 8>(dvoff_b, db[1], lds_w);
+            lds_dma_1k_s<O + 12 * SA * 8>(dvoff, da[3], lds_w);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) da[p] += dstep_a;
+            db[0] += dstep_b; db[1] += dstep_b;
+        } else if constexpr (DMA) {
             lds_dma_1k_s<O + 0 * SA * 8>(dvoff, da[0], lds_w);
             lds_dma_1k_s<O + ASZ * 8 + 0 * SB * 8>(dvoff, db[0], lds_w);
             lds_dma_1k_s<O + 4 * SA * 8>(dvoff, da[1], lds_w);
@@ -244,7 +267,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
 #pragma unroll
             for (int in = 0; in < FN; ++in) {
                 const int n = wn + in * 16 + l15;
-                fb[slot][in] = BKC ? sb[n * SK + k] : sb[k * SB + n];
+                if constexpr (BH) fb[slot][in] = sb[(l4 + 4 * (ks >> 1)) * SB + (ks & 1) * 64 + n];
+                else fb[slot][in] = BKC ? sb[n * SK + k] : sb[k * SB + n];
             }
         };
         auto mfmas = [&](int slot) {
@@ -285,17 +309,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int ti, int tj, lon
         if constexpr (DMA) {
             if (lazyc) {          // first 2 FM FN / 2 k-steps, fully unrolled: chunk c = two accumulator tiles, fetched at step 2c,
                 double4_t creg[2];   // folded in at step 2c + 1 (16 VGPRs in flight; every accumulator index is a constant)
+                static_assert(FM == 4 && (FN == 4 || FN == 2), "lazy C: 64-row wave tiles, 64 or 32 columns");
+                // BH: a wave owns 32 columns = two of the four 16-column groups of a 64-column slab; the waves of the slab's first half
+                // fold theirs during steps 0-7, those of the second half during steps 8-15 (wave-uniform predicate)
+                const int my_half = __builtin_amdgcn_readfirstlane(wave >> 1);
 #pragma unroll
-                for (int st = 0; st < FN * FM; ++st) {
-                    const int chunk = st >> 1, in = chunk / (FM / 2), hf = chunk % (FM / 2);
+                for (int st = 0; st < LZ; ++st) {
+                    const int chunk = (BH ? (st & 7) : st) >> 1, in = chunk / (FM / 2), hf = chunk % (FM / 2);
+                    const bool act = !BH || my_half == (st >> 3);
                     if (!(st & 1)) {
+                        if (act) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const double* cp = Cin + (long)(i0 + wm + (2 * hf + q) * 16 + l15) + (long)(j0 + wn + in * 16 + l4) * ldcin;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) creg[q][r] = cp[(long)(4 * r) * ldcin];
                         }
-                    } else {
+                        }
+                    } else if (act) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q)
 #pragma unroll

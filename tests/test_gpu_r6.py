@@ -120,3 +120,57 @@ def test_ep_first_two_sweeps_back_to_back_change_nothing(lib, N):
     for u, v in zip(a[1:5], b[1:5]):
         assert np.array_equal(u, v)
     assert relerr(a[0], g["nlZ"]) < 1e-8 and relerr(a[2], g["alpha"]) < 1e-6 and relerr(a[4], g["L_diag"]) < 1e-7
+
+
+@pytest.mark.parametrize("M,N,K,pad", [(128, 64, 160, 0), (1024, 512, 512, 0), (896, 192, 528, 136), (256, 64, 16, 0), (384, 128, 48, 8), (512, 256, 288, 0),
+                                         (640, 128, 304, 24)])
+def test_gemm_128x64_lds_dma_tile_against_numpy(lib, M, N, K, pad):
+    """The 128 x 64 LDS-DMA tile (GemmArgs::tile 1264: the rectangle TU_r of the sweep's trailing update, Core/tools.py:31-62 is the
+    factorisation it serves) on plain rectangles: C <- beta C + alpha A B' against numpy, short K (no lazy C), K not a multiple of
+    the lazy-C prologue, leading dimensions beyond the operand heights; and the 128 x 128 tile on the same inputs."""
+    from pygps_amd import _lib
+    rng = np.random.RandomState(M + N + K)
+    lda, ldb, ldc = M + pad, N + pad, M + 2 * pad
+    A = np.asfortranarray(rng.randn(lda, K))
+    B = np.asfortranarray(rng.randn(ldb, K))
+    C0 = np.asfortranarray(rng.randn(ldc, N))
+    ref = C0.copy()
+    ref[:M] = 0.5 * C0[:M] - 1.0 * (A[:M] @ B[:N].T)
+    outs = {}
+    for tile in (1264, 128) if N % 128 == 0 else (1264,):
+        Cw = C0.copy(order="F")
+        ms = C.c_double()
+        rc = lib.pgp_test_gemm(_lib.ctx(), tile, 0, 0, 0, 0, 0, 0, -1.0, 0.5, A.ctypes.data_as(_lib._dp), lda, B.ctypes.data_as(_lib._dp), ldb,
+                               Cw.ctypes.data_as(_lib._dp), ldc, M, N, K, 0, C.byref(ms))
+        assert rc == 0, _lib.strerror(rc)
+        assert np.max(np.abs(Cw - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), (tile, np.max(np.abs(Cw - ref)))
+        assert np.array_equal(Cw[M:], C0[M:])                       # rows beyond M untouched
+        outs[tile] = Cw
+    if 128 in outs:                                                 # both tile shapes fold C in at the same k-step: bit for bit
+        assert np.array_equal(outs[1264], outs[128])
+
+
+@pytest.mark.parametrize("N", [4096, 8192])
+def test_fit_with_the_128x64_rectangle_against_G6(lib, N):
+    """sched 2's rectangle TU_r as 128 x 64 LDS-DMA tiles (tur_tile = 1264; the default up to N = 5120) and as 128 x 128 tiles (tur_tile = 128): both
+    reproduce the reference's G6 numbers (Exact.evaluate, Core/inf.py:353-384), and each other bit for bit (an element's C value is
+    folded into its accumulator at the same k-step in both tile shapes)."""
+    from pygps_amd import _lib
+    g = golden("G6_rbf_d16_N%d" % N)
+    x, y = synth_reg(N, 16)
+    ctx = _lib.ctx()
+    res = {}
+    try:
+        for tile in (1264, 128):
+            _lib.check(lib.pgp_set_option(ctx, b"tur_tile", tile))
+            got = _fit(lib, 0, g["cov_hyp"], 0, g["lik_hyp"][0], x, y, g["mean_hyp"][0] * np.ones(N), np.ones((1, N)), want=3)
+            assert relerr(got["nlZ"], g["nlZ"]) < 1e-9
+            assert relerr(got["alpha"][g["alpha_idx"], 0], g["alpha_sample"]) < 1e-7
+            assert relerr(got["L"].ravel()[g["L_flat_idx"]], g["L_sample"]) < 1e-8
+            assert relerr(got["dnlZ"], np.concatenate([g["dnlZ_mean"], g["dnlZ_cov"], g["dnlZ_lik"]])) < 1e-7
+            res[tile] = got
+    finally:
+        lib.pgp_set_option(ctx, b"tur_tile", 0)
+    assert res[1264]["nlZ"] == res[128]["nlZ"]
+    for k in ("alpha", "dnlZ", "L"):
+        assert np.array_equal(res[1264][k], res[128][k]), k

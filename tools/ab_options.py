@@ -50,7 +50,7 @@ for k in range(2):
 # round had to be re-read from their first alternation)
 DEFAULTS = {"sched": -1, "tud_mark": 1, "tud_tile": 64, "sched2_wide": 0, "leaf_pivot": 2, "nb_outer": 0, "pair_launch": 1, "leaf_first": 0,
             "yield": 1, "eet_overlap": 3, "eet_tile": 128, "eet_first": -1, "s_tile": 0, "lookahead": 1, "xcd_order": 0, "small_tile_below": 200,
-            "gram_assembly": 1, "gram_fast": 2, "s_pan": -1, "s_pan_direct": 1, "s_pan_out": 1, "publish": 1, "trsm_lean": 1, "tail_split": 1}
+            "gram_assembly": 1, "gram_fast": 2, "s_pan": -1, "s_pan_direct": 1, "s_pan_out": 1, "publish": 1, "trsm_lean": 1, "tail_split": 1, "tur_tile": 0}
 NAMED = sorted({o.split("=")[0] for sp in sets for o in sp.split(",") if o})
 for k_ in NAMED:
     assert k_ in DEFAULTS, "add the default of option %r to DEFAULTS" % k_
