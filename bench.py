@@ -356,6 +356,20 @@ def extras(lib, _lib, local, d, roof):
             "TFLOPs": (1.0 * n6 * n6 * ns) / tp / 1e12,     # fs2 needs V = L^-1 Ks: a triangular solve, N^2 flops per test point
             "what": "GP.predict (ym, ys2, fm, fs2, lp) of 65536 test points on the N=8192 posterior; host arrays in and out; median of "
                     "3 warm calls (wall), device time from the library's own events"}
+        # round 6: the product form (V = L^-1 Ks as one fold-rows MFMA product with the posterior's cached W = L^-1; the default for
+        # batches >= 1024 points) beside the blocked triangular solve, at the reference's own batch size (1000 points, gp.py:395) and
+        # at 8192; the 65536-point figure above is the same for both (a sustained full-chip fp64 burst settles at the power limit)
+        sm = {}
+        for mode, tag in ((1, "product_form"), (0, "blocked_solve")):
+            _lib.check(lib.pgp_set_option(_lib.ctx(local), b"predict_inverse", mode))
+            for pts in (1000, 8192):
+                m6.predict(xs6[:pts])
+                ts_ = []
+                for it in range(5):
+                    t = time.perf_counter(); m6.predict(xs6[:pts]); ts_.append((time.perf_counter() - t) * 1e3)
+                sm["ns%d_%s_ms" % (pts, tag)] = float(np.median(ts_))
+        _lib.check(lib.pgp_set_option(_lib.ctx(local), b"predict_inverse", 1))
+        out["predict_N8192_small_batches"] = sm
         nf, nuf, df = 131072, 1024, 16
         rng = np.random.RandomState(0)
         xf = rng.randn(nf, df); wf = rng.randn(df, 1)

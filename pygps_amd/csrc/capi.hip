@@ -215,6 +215,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "xcd_min_tiles")) { c->xcd_min_tiles = value; return PGP_OK; }
     if (!strcmp(name, "xcd_super")) { c->xcd_super = value; return PGP_OK; }
     if (!strcmp(name, "solve_outer")) { if (value < 1) return -2; c->solve_outer = value; return PGP_OK; }
+    if (!strcmp(name, "predict_inverse")) { if (value < 0 || value > 2) return -2; c->predict_inverse = value; return PGP_OK; }
     if (!strcmp(name, "predict_batch")) { if (value < 128 || value % 128) return -2; c->predict_batch = value; return PGP_OK; }
     if (!strcmp(name, "s_tile")) { if (value != 0 && value != 64 && value != 128) return -2; c->s_tile = value; return PGP_OK; }
     if (!strcmp(name, "eet_overlap")) { if (value != 0 && value != 2 && value != 3) return -2; c->eet_overlap = value; return PGP_OK; }
@@ -1489,6 +1490,7 @@ void pgp_factor_free(pgp_ctx* c, pgp_factor* f) { GateShared device_gate_hold(c)
         // augmented rows / upper tiles of a pooled buffer must be zero when it is reused: the factor only ever
         // wrote the lower triangle + row np, and row np is rewritten by every fit, so it can go back as is.
         pool_free(c, (size_t)f->ldf * f->np * sizeof(double), f->F);
+        if (f->Linv) pool_free(c, (size_t)f->ldf * f->np * sizeof(double), f->Linv);    // (lower triangle only, zero augmented rows: the pool contract holds)
     }
     spool_give(c, (size_t)f->np * sizeof(double), f->alpha);
     spool_give(c, (size_t)f->dpad * f->np * sizeof(double), f->XsT);

@@ -64,6 +64,8 @@ struct GemmArgs {
     // C = beta*Cin + alpha*A*B' (the look-ahead Cholesky redirects the next panel's columns into a staging buffer).
     const double* Cin; long ldcin; const double* Cin2; long ldcin2;
     int rev_cols;           // rectangular grids: tile columns enumerated last-to-first (KM_LT_J: the long-k tiles start first)
+    int rev_rows;           // ... tile rows last-to-first (KM_LT_I: the long-k tiles start first)
+    int fold_rows;          // plain LDS-DMA 128-tile rectangles: one workgroup runs the tile rows mt - 1 - r AND r (gemm_f64_fold_kernel)
     int zero_from;          // > 0: tile rows i0 >= zero_from take beta = 0 (rows touched for the first time: never read)
     // Batched launches whose products shrink with the batch index z (the owned column panels of a block-cyclic sweep):
     // product z has M - z * batch_dm rows (tiles beyond them exit at once) and its first-touch row moves up with it.

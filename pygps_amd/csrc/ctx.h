@@ -29,6 +29,7 @@ struct pgp_factor {
     double* alpha;        // n
     double* XsT;          // dpad x np scaled coordinates used for this fit
     double* Wd;           // np x 128 : inverted diagonal blocks (lazy, for predict)
+    double* Linv = nullptr; // ldf x np : W = L^-1 (lazy: the product form of predict, predict.hip ensure_linv; from the factor pool)
     int dpad, d;
     CovSpec cs;           // covariance functor / program of this fit (predict re-evaluates it in 'cross' mode)
     double kss = 0.0;     // k(z,z) of 'self_test' mode
@@ -153,6 +154,7 @@ struct pgp_ctx {
     int xcd_min_tiles = 256;            // ... to launches with at least this many 128-tiles
     int xcd_super = 8;                  // xcd_order: super-tile edge in tiles
     int solve_outer = 8;                // leaves per outer panel of the blocked multi-rhs triangular solve (K = 128 solve_outer)
+    int predict_inverse = 1;            // pgp_predict: 0 = blocked solve, 1 = product form with W = L^-1 for batches >= 1024 points (or once W exists), 2 = always
     int predict_batch = 65536;          // test points per batch of pgp_predict (scratch: np x batch doubles, capped at 16 GiB -- predict_batch_points)
     int s_tile = 0;                     // tile size of the panel solves: 0 = automatic
     int gram_fast = 2, gram_grid = 32768; // Gram-form assembly: restructured kernel on / off, persistent workgroups (CovSpec)

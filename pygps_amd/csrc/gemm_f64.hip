@@ -68,6 +68,7 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs& g, int b, int T, int
     ti = b % mt;
     tj = b / mt;
     if (g.rev_cols) tj = g.N / TNc - 1 - tj;
+    if (g.rev_rows) ti = mt - 1 - ti;
     return true;
 }
 
@@ -126,6 +127,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_pair_kernel(GemmArgs a, GemmA
     };
     if ((int)blockIdx.x < na) run(a, (int)blockIdx.x);
     else run(b, (int)blockIdx.x - na);
+}
+
+// TWO tile rows per workgroup (GemmArgs::fold_rows): rows mt - 1 - r and r of the same tile column, one after the other.  For a
+// product whose k-range grows with the tile row (KM_LT_I: a lower-triangular A, GP.predict's V = L^-1 Ks) the pair's work is the
+// same for every workgroup.  It matters on this chip because the workgroup distributor hands out slots in a fixed rotation and
+// BLOCKS on the engine whose turn it is (EXPERIMENTS.md, round 3): a grid of tiles that last 1x .. 64x leaves the slots of the
+// short ones idle until the rotation comes round -- M = N = K = 8192 clipped to the triangle ran at 47 TF of algorithmic flops
+// against 75 TF unclipped (tools/_gemm_clip.py).
+template <bool YIELD>
+__global__ __launch_bounds__(256, 2) void gemm_f64_fold_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int mt = g.M / 128, half = (mt + 1) / 2;
+    const int r = (int)blockIdx.x % half, tj = (int)blockIdx.x / half;
+    const int hi = mt - 1 - r;
+    const long bz = blockIdx.z;
+    gemm_tile_ns::gemm_tile<128, 128, false, false, true, YIELD>(g, hi, tj, bz, smem, 0);
+    if (hi != r) {
+        __syncthreads();                             // (the first tile's last LDS reads are over before the second tile stages)
+        gemm_tile_ns::gemm_tile<128, 128, false, false, true, YIELD>(g, r, tj, bz, smem, 0);
+    }
 }
 
 template <int T, bool AKC, bool BKC, bool DMA = false, bool YIELD = false>
@@ -199,9 +220,23 @@ int gemm_f64_launch_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
 }
 
+static int launch_fold(const GemmArgs& g, hipStream_t st) {
+    constexpr int SA_ = 128 + 16;
+    const size_t shm = 2 * (2 * BK * SA_) * sizeof(double);
+    const int mt = g.M / 128, nt = g.N / 128;
+    dim3 grid((unsigned)(((mt + 1) / 2) * nt), 1, g.batch > 0 ? g.batch : 1);
+    const bool yield = g.yield_role == 1 && g.yield_flags;
+    func_max_dynamic_lds((const void*)(yield ? gemm_f64_fold_kernel<true> : gemm_f64_fold_kernel<false>), shm);
+    if (yield) hipLaunchKernelGGL(gemm_f64_fold_kernel<true>, grid, dim3(256), shm, st, g);
+    else hipLaunchKernelGGL(gemm_f64_fold_kernel<false>, grid, dim3(256), shm, st, g);
+    return hipGetLastError() == hipSuccess ? PGP_OK : PGP_ERR_HIP;
+}
+
 int gemm_f64_launch(const GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return PGP_OK;
     if (g.tile == 64) return launch_l<64>(g, st);
+    if (g.fold_rows && g.tile == 128 && dma_ok(g) && !g.tri && !g.order && !g.order_z && !g.wait_flag && g.yield_role != 2 && !g.trace)
+        return launch_fold(g, st);
     if (dma1264_ok(g)) return (g.yield_role == 1 && g.yield_flags) ? launch_1264<true>(g, st) : launch_1264<false>(g, st);
     // LDS-DMA staging (dbg bit 64): 128 x 128 tiles of M-contiguous operands, whole 16-deep k-tiles
     if (dma_ok(g)) return (g.yield_role == 1 && g.yield_flags) ? launch_t<128, false, false, true, true>(g, st)

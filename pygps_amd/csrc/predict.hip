@@ -65,6 +65,103 @@ static int ensure_wd(pgp_ctx* c, pgp_factor* f) {
     return leaf_inv_launch(f->F, f->ldf, f->Wd, 128, 128L * 128L, (int)(f->np / 128), c->st);
 }
 
+// ---- the product form (round 6): V = L^-1 (sW o Ks) as ONE fp64 MFMA GEMM ----------------------------------------------------------
+// The blocked solve above is a chain of np / 128 dependent steps per batch (three launches each): 65536 points at N = 8192 run
+// at 45 TF, 8192 points take ~18 ms.  With W = L^-1 at hand the same V is the NT product  V(m, j) = sum_{k <= m} W(m, k) KsT(j, k)
+// on the LDS-DMA 128 x 128 tile (k clipped to the triangle), if the cross-covariances are laid out test-point-contiguous
+// (KsT: nrhs x np, column = training point) -- the tile kernel writes them that way when the two point sets swap roles.
+// W costs one trtri (N^3 / 3 flops) at the first predict that wants it and stays with the posterior handle (ldf x np doubles, from
+// the factor pool) until the handle is freed.  Option predict_inverse: 0 = never (the blocked solve), 1 = for batches of >= 1024
+// points or whenever W exists already (default), 2 = always.  Reference: Core/gp.py:395-417 (V = solve(L', sW o Ks)).
+namespace {
+// KsT lives in SLABS of SW test points: slab s is an (SW x np) column-major matrix (leading dimension SW) at KsT + s SW np, so that
+// the k-rows a GEMM tile streams through are 8 SW bytes apart, not 8 nrhs (nrhs = 65536: 512 KiB between k-rows, one TLB entry
+// per four of them: the product ran at the blocked solve's 46 TF); element (test j, training k) at (j / SW) SW np + j % SW + k SW.
+// part[kc * ldp + j] = sum_{k in chunk kc} KsT(j, k) v[k]      (thread j: coalesced within its slab)
+__global__ __launch_bounds__(256) void kst_dot_part_kernel(const double* __restrict__ KsT, long SW, long np, long ncols, long ntrain, long chunk,
+                                                           const double* __restrict__ v, double* __restrict__ part, long ldp) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols) return;
+    const double* col = KsT + (j / SW) * SW * np + j % SW;
+    const long k0 = (long)blockIdx.y * chunk, k1 = k0 + chunk < ntrain ? k0 + chunk : ntrain;
+    double s0 = 0.0, s1 = 0.0;
+    long k = k0;
+    for (; k + 1 < k1; k += 2) { s0 = fma(col[k * SW], v[k], s0); s1 = fma(col[(k + 1) * SW], v[k + 1], s1); }
+    if (k < k1) s0 = fma(col[k * SW], v[k], s0);
+    part[(long)blockIdx.y * ldp + j] = s0 + s1;
+}
+// out[j] = add[j] + sum_kc part[kc][j]   (fixed order)
+__global__ __launch_bounds__(256) void kst_dot_finish_kernel(const double* __restrict__ part, long ldp, int nchunk, long ncols,
+                                                             const double* __restrict__ add, double* __restrict__ out) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols) return;
+    double s = 0.0;
+    for (int kc = 0; kc < nchunk; ++kc) s += part[(long)kc * ldp + j];
+    out[j] = (add ? add[j] : 0.0) + s;
+}
+// KsT(:, k) *= s[k]   (EP: sW o Ks)
+__global__ __launch_bounds__(256) void kst_col_scale_kernel(double* __restrict__ KsT, long SW, long np, long ncols, const double* __restrict__ s) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols) return;
+    KsT[(j / SW) * SW * np + j % SW + (long)blockIdx.y * SW] *= s[blockIdx.y];
+}
+}  // namespace
+
+static int ensure_linv(pgp_ctx* c, pgp_factor* f) {
+    if (f->Linv) return PGP_OK;
+    hipStream_t st = c->st;
+    double* W = nullptr;
+    CHK(alloc_factor_buffer(c, f->np, f->ldf, &W));
+    const size_t bytes = (size_t)f->ldf * f->np * sizeof(double);
+    PoolScratch tmp(c);
+    double* T = nullptr;
+    int rc = tmp.alloc(&T, std::max<size_t>((size_t)f->np * f->np / 4, (size_t)128 * 128) * sizeof(double));
+    if (rc == PGP_OK && hipMemsetAsync(W, 0, bytes, st) != hipSuccess) rc = PGP_ERR_HIP;     // (a pooled buffer: only its strict-upper tiles are known to be zero)
+    if (rc == PGP_OK) rc = trtri_lower(c, f->F, f->ldf, W, f->ldf, T, f->np);
+    if (rc == PGP_OK && hipStreamSynchronize(st) != hipSuccess) rc = PGP_ERR_HIP;            // (T goes back to the pool)
+    if (rc != PGP_OK) {
+        (void)hipStreamSynchronize(st);
+        (void)hipMemsetAsync(W, 0, bytes, st);                                                // the pool contract: zero strict-upper tiles and augmented rows
+        (void)hipStreamSynchronize(st);
+        pool_free(c, bytes, W);
+        return rc;
+    }
+    f->Linv = W;
+    return PGP_OK;
+}
+
+// one batch through the product form: xd (nb_ points, scaled + transposed into XcT), results in o1 (fmu) and o2 (fs2)
+static int predict_batch_product(pgp_ctx* c, pgp_factor* f, const CovSpec& cp, const double* XcT, long ldc, long nb_, int nrhs, const double* msd,
+                                 double* KsT, double* V, double* part, double* o1, double* o2, hipStream_t st) {
+    const long np = f->np, n = f->n;
+    long SW = 1024;                                                                          // slab width: the largest of 1024 .. 128 that divides nrhs
+    while (nrhs % SW) SW >>= 1;
+    const int nslab = (int)(nrhs / SW);
+    HIP_TRY(hipMemsetAsync(KsT, 0, (size_t)np * nrhs * sizeof(double), st));               // padding rows / columns: exact zeros
+    // rows = training points, columns = the slab's test points in the tile kernel's view: out[test + train * SW]
+    for (int sl = 0; sl < nslab; ++sl) {
+        const long cnt = std::min<long>(SW, nb_ - (long)sl * SW);
+        if (cnt <= 0) break;
+        CHK(cov_rect_launch(f->XsT, np, n, XcT + (long)sl * SW, ldc, cnt, f->dpad, cp, KsT + (long)sl * SW * np, SW, st));
+    }
+    constexpr int NCH = 16;
+    const long chunk = (n + NCH - 1) / NCH;
+    hipLaunchKernelGGL(kst_dot_part_kernel, dim3((unsigned)((nb_ + 255) / 256), NCH), dim3(256), 0, st, KsT, SW, np, nb_, n, chunk, f->alpha, part, (long)nrhs);
+    hipLaunchKernelGGL(kst_dot_finish_kernel, dim3((unsigned)((nb_ + 255) / 256)), dim3(256), 0, st, part, (long)nrhs, NCH, nb_, msd, o1);   // fmu = ms + Ks' alpha
+    if (f->sWv) hipLaunchKernelGGL(kst_col_scale_kernel, dim3((unsigned)((nb_ + 255) / 256), (unsigned)n), dim3(256), 0, st, KsT, SW, np, nb_, f->sWv);
+    if (hipGetLastError() != hipSuccess) return PGP_ERR_HIP;
+    GemmArgs g{};                                                                            // one product per slab, ONE launch
+    g.A = f->Linv; g.lda = f->ldf; g.a_kc = 0;
+    g.B = KsT; g.ldb = SW; g.b_kc = 0;
+    g.C = V; g.ldc = np;
+    g.M = (int)np; g.N = (int)SW; g.K = (int)np; g.alpha = 1.0; g.beta = 0.0;
+    g.batch = nslab; g.sA = 0; g.sB = SW * np; g.sC = SW * np;
+    g.kmode = KM_LT_I; g.koff = 0; g.tile = 128; g.fold_rows = 1;                           // (tile rows r and mt - 1 - r in one workgroup: uniform work)
+    g.flops = (double)np * (double)np * nrhs;
+    CHK(gemm_prof(c, PC_GEMM_INNER, g, st));
+    return col_sumsq_launch(V, np, n, nb_, f->kss, f->sWv ? 1.0 : f->sw * f->sw, o2, st);
+}
+
 extern "C" {
 
 int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const double* ms, double* fmu, double* fs2) {
@@ -78,9 +175,12 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     if (!fs2) return -7;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->st;
-    CHK(ensure_wd(c, f));
     const long np = f->np, n = f->n;
     const int d = f->d, dpad = f->dpad;
+    // the product form (W = L^-1, one GEMM per batch) or the blocked solve: see predict_batch_product
+    const bool product = np >= 1024 && (c->predict_inverse == 2 || (c->predict_inverse == 1 && (f->Linv != nullptr || ns >= 1024)));
+    if (product) CHK(ensure_linv(c, f));
+    else CHK(ensure_wd(c, f));
     // test points per batch (the reference uses 1000): up to predict_batch = 65536 within 16 GiB of scratch, so that the K = 128
     // updates of the blocked solve are many waves of tiles and the per-batch host round trip is rare (round 2, N = 8192, 65536 test
     // points: batch 1024 -> 318 ms, 4096 -> 220, 8192 -> 192, 16384 -> 171; round 4 on one box: 16384 -> 120 ms, 65536 -> 101 ms)
@@ -96,6 +196,11 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     CHK(tmp.alloc(&XcT, (size_t)dpad * ldc * sizeof(double)));
     CHK(tmp.alloc(&scd, dpad * sizeof(double)));
     CHK(tmp.alloc(&Ks, (size_t)np * NSB * sizeof(double)));
+    double *Vp = nullptr, *part = nullptr;
+    if (product) {
+        CHK(tmp.alloc(&Vp, (size_t)np * NSB * sizeof(double)));
+        CHK(tmp.alloc(&part, (size_t)16 * NSB * sizeof(double)));
+    }
     CHK(tmp.alloc(&msd, NSB * sizeof(double)));
     CHK(tmp.alloc(&o1, NSB * sizeof(double)));
     CHK(tmp.alloc(&o2, NSB * sizeof(double)));
@@ -111,6 +216,8 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
         if (ms) HIP_TRY(hipMemcpyAsync(msd, ms + a, nb_ * sizeof(double), hipMemcpyHostToDevice, st));
         else HIP_TRY(hipMemsetAsync(msd, 0, nb_ * sizeof(double), st));
         CHK(scale_transpose_launch(xd, nb_, d, scd, XcT, ldc, dpad, st));
+        if (product) CHK(predict_batch_product(c, f, cp, XcT, ldc, nb_, nrhs, msd, Ks, Vp, part, o1, o2, st));
+        else {
         // Ks as column-major (np x nrhs): rows = test points, columns = training points in the tile kernel's view
         HIP_TRY(hipMemsetAsync(Ks, 0, (size_t)np * nrhs * sizeof(double), st));
         CHK(cov_rect_launch(XcT, ldc, nb_, f->XsT, np, n, dpad, cp, Ks, np, st));
@@ -118,6 +225,7 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
         if (f->sWv) CHK(row_scale_launch(Ks, np, n, nrhs, f->sWv, st));                   // EP: sW o Ks
         CHK(solve_lower_multi(c, f->F, f->ldf, f->Wd, Ks, np, np, nrhs, false));
         CHK(col_sumsq_launch(Ks, np, n, nb_, f->kss, f->sWv ? 1.0 : f->sw * f->sw, o2, st));
+        }
         HIP_TRY(hipMemcpyAsync(fmu + a, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(fs2 + a, o2, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
         if (a + NSB >= ns) HIP_TRY(hipEventRecord(c->ev[1], st));

@@ -411,6 +411,7 @@ int pgp_test_gemm(pgp_ctx* ctx, int tile, int a_kc, int b_kc, int tri, int mask_
     g.A = Ad; g.lda = lda; g.a_kc = a_kc; g.B = Bd; g.ldb = ldb; g.b_kc = b_kc; g.C = Cd; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.tri = tri; g.tri_off = 0; g.mask_diag = mask_diag;
     g.kmode = kmode; g.koff = koff; g.batch = 1; g.tile = tile; g.dbg = c->gemm_dbg;
+    if (getenv("PGP_TEST_GEMM_FOLD")) g.fold_rows = 1;                 // (tools: the two-tile-rows-per-workgroup kernel on the same arguments)
     hipStream_t ts = c->st;
     int rc = gemm_f64_launch(g, ts);
     HIP_TRY(hipStreamSynchronize(ts));

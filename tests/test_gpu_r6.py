@@ -174,3 +174,59 @@ def test_fit_with_the_128x64_rectangle_against_G6(lib, N):
     assert res[1264]["nlZ"] == res[128]["nlZ"]
     for k in ("alpha", "dnlZ", "L"):
         assert np.array_equal(res[1264][k], res[128][k]), k
+
+
+def test_predict_product_form_equals_the_blocked_solve(lib):
+    """GP.predict (Core/gp.py:395-417): V = L^-1 (sW o Ks) as one MFMA product with the cached W = L^-1 (predict_inverse 2; the default for
+    batches of >= 1024 points) against the blocked triangular solve (predict_inverse 0) and the oracle -- GPR at a ragged size, test
+    points that include near-duplicates of training points (fs2 -> small), a count that is not a multiple of anything; and GPC + EP
+    (per-point sW)."""
+    import pygps_amd as pyGPs
+    from pygps_amd import _lib
+    from oracle import gp_oracle as O
+    ctx = _lib.ctx()
+    n, d, ns = 3000, 7, 2501
+    x, y = synth_reg(n, d, seed=11)
+    rng = np.random.RandomState(5)
+    xs = rng.randn(ns, d)
+    xs[:300] = x[rng.randint(0, n, 300)] + 1e-3 * rng.randn(300, d)
+    m = pyGPs.GPR()
+    m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.2))
+    m.setNoise(np.log(0.05))
+    m.setData(x, y)
+    m.getPosterior()
+    out = {}
+    try:
+        for mode in (0, 2, 1):
+            _lib.check(lib.pgp_set_option(ctx, b"predict_inverse", mode))
+            out[mode] = [np.array(v) for v in m.predict(xs)[:4]]
+            out[(mode, "small")] = [np.array(v) for v in m.predict(xs[:37])[:4]]
+    finally:
+        lib.pgp_set_option(ctx, b"predict_inverse", 1)
+    for a, b in ((0, 2), (0, 1), ((0, "small"), (2, "small"))):
+        for u, v, tol in zip(out[a], out[b], (1e-11, 1e-9, 1e-11, 1e-9)):
+            assert np.max(np.abs(u - v)) <= tol * max(1.0, float(np.max(np.abs(u)))), (a, b, np.max(np.abs(u - v)))
+    assert np.array_equal(out[(1, "small")][2], out[(2, "small")][2])       # W exists by then: the default takes the product form for 37 points too
+    c = m.meanfunc.hyp[0]
+    ref = O.exact_fit(O.RBF, np.array(m.covfunc.hyp), 0, m.likfunc.hyp[0], x, y, c * np.ones((n, 1)), np.ones((n, 1)), nargout=2, faithful=False)
+    rym, rys2, rfm, rfs2 = O.predict(O.RBF, np.array(m.covfunc.hyp), 0, m.likfunc.hyp[0], x, ref["alpha"], ref["L"], ref["sW"], xs,
+                                     c * np.ones((ns, 1)), faithful=False)
+    assert np.max(np.abs(out[2][2] - rfm)) < 1e-8 * float(np.max(np.abs(rfm))) and np.max(np.abs(out[2][3] - rfs2)) < 1e-7 * float(np.max(rfs2))
+    # GPC + EP: per-point sW scales the cross-covariances
+    nc, dc = 1500, 5
+    rng = np.random.RandomState(3)
+    xc = rng.randn(nc, dc); wc = rng.randn(dc, 1)
+    yc = np.sign(xc @ wc / np.sqrt(dc) + 0.3 * rng.randn(nc, 1)); yc[yc == 0] = 1
+    mc = pyGPs.GPC()
+    mc.setPrior(mean=pyGPs.mean.Zero(), kernel=pyGPs.cov.RBF(np.log(np.sqrt(dc)), 0.3))
+    mc.getPosterior(xc, yc)
+    xcs = rng.randn(1100, dc)
+    outc = {}
+    try:
+        for mode in (0, 2):
+            _lib.check(lib.pgp_set_option(ctx, b"predict_inverse", mode))
+            outc[mode] = [np.array(v) for v in mc.predict(xcs, ys=np.ones((1100, 1)))]
+    finally:
+        lib.pgp_set_option(ctx, b"predict_inverse", 1)
+    for u, v in zip(outc[0], outc[2]):
+        assert np.max(np.abs(u - v)) <= 1e-9 * max(1.0, float(np.max(np.abs(u))))

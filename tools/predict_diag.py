@@ -24,6 +24,13 @@ one("warm-up, 4096 points (what bench.py r5 did)", 4096)
 one("FIRST call, 65536 points, batch 65536")
 for i in range(4):
     one("call %d" % (i + 2))
+for pts in (1024, 8192):
+    one("%d points" % pts, pts); one("%d points again" % pts, pts)
+lib.pgp_set_option(ctx, b"predict_inverse", 0)
+print("predict_inverse = 0: the blocked triangular solve")
+one("65536 points"); one("65536 points again")
+for pts in (1024, 8192):
+    one("%d points" % pts, pts); one("%d points again" % pts, pts)
 for pb in (8192, 16384, 32768, 65536):
     lib.pgp_set_option(ctx, b"predict_batch", pb)
     one("batch %d: first" % pb)
