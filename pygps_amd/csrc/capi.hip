@@ -159,6 +159,7 @@ void pgp_destroy(pgp_ctx* c) { if (!c) return; GateShared device_gate_hold(c);
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->in_host) (void)hipHostFree(c->in_host);
+    if (c->pred_host) (void)hipHostFree(c->pred_host);
     if (c->gemm_trace) (void)hipFree(c->gemm_trace);
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);

@@ -147,6 +147,8 @@ struct pgp_ctx {
     int trsm_lean = 0;                  // option "trsm_lean": 1 = the LDS-free panel solve for the diagonal-block chain beside bulk work, 0 never, 2 always
     int publish = 1;                    // option "publish" 1 / 0
     double* in_host = nullptr;          // pinned staging of the per-fit inputs (prior mean, scales)
+    double* pred_host = nullptr;        // pinned staging of pgp_predict's inputs and outputs (grow-only: predict.hip pred_stage)
+    size_t pred_cap = 0;
     size_t res_cap = 0, in_cap = 0;
     // Cholesky sweep: diagonal-panel scratch (2w x w, w <= 1024), its leaf operand images, column staging buffer
     double *Dk = nullptr, *dpack = nullptr, *Xs = nullptr;

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -162,6 +164,22 @@ static int predict_batch_product(pgp_ctx* c, pgp_factor* f, const CovSpec& cp, c
     return col_sumsq_launch(V, np, n, nb_, f->kss, f->sWv ? 1.0 : f->sw * f->sw, o2, st);
 }
 
+// Pinned staging of a batch's inputs (test points, prior mean) and outputs (fmu, fs2).  The callers' arrays are pageable: an
+// "asynchronous" copy from / to them is staged by the runtime's host threads, i.e. the DEVICE timeline of a predict call hangs on
+// the host's scheduling.  Seen on the GPU boxes (256 cores visible, 16 granted): the reference's host code around the call woke a
+// 256-thread BLAS pool, the container's CPU quota throttled the whole process to the next 100 ms period, and every predict call --
+// 32768 ... 98304 points, either form -- took 99 ms on the device timeline (34 ... 98 ms of kernels); rounds 3-5 read that as "a
+// hot chip" (tools/_pred_q.py, _pred_t.py; pygps_amd/_threads.py caps the pools).  One memcpy through a pinned buffer of our own
+// (grow-only, per context) keeps the copies true DMA whatever the host is doing.
+static int pred_stage(pgp_ctx* c, size_t doubles) {
+    const size_t bytes = doubles * sizeof(double);
+    if (c->pred_cap >= bytes) return PGP_OK;
+    if (c->pred_host) { (void)hipStreamSynchronize(c->st); (void)hipHostFree(c->pred_host); c->pred_host = nullptr; c->pred_cap = 0; }
+    HIP_TRY(hipHostMalloc((void**)&c->pred_host, bytes, hipHostMallocDefault));
+    c->pred_cap = bytes;
+    return PGP_OK;
+}
+
 extern "C" {
 
 int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const double* ms, double* fmu, double* fs2) {
@@ -190,6 +208,10 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     // multi-GiB hipMalloc here: 4 GiB at N = 8192 and 65536 points -- tens of ms on a fast host, hundreds on a slow one; later calls
     // take it from the pool), [SOLVE] = host wall ms of the whole call, [TOTAL] = device ms between the first and the last event.
     const auto t_call = std::chrono::steady_clock::now();
+    static const bool pred_timing = getenv("PGP_PRED_TIMING") != nullptr;
+    auto stamp = [&](const char* what) {
+        if (pred_timing) fprintf(stderr, "[predict] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
+    };
     PoolScratch tmp(c);
     double *xd = nullptr, *XcT = nullptr, *scd = nullptr, *Ks = nullptr, *msd = nullptr, *o1 = nullptr, *o2 = nullptr;
     CHK(tmp.alloc(&xd, NSB * d * sizeof(double)));
@@ -204,17 +226,25 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     CHK(tmp.alloc(&msd, NSB * sizeof(double)));
     CHK(tmp.alloc(&o1, NSB * sizeof(double)));
     CHK(tmp.alloc(&o2, NSB * sizeof(double)));
+    CHK(pred_stage(c, (size_t)NSB * (d + 3) + d));
+    double* const h_x = c->pred_host, *const h_ms = h_x + (size_t)NSB * d, *const h_o1 = h_ms + NSB, *const h_o2 = h_o1 + NSB, *const h_sc = h_o2 + NSB;
     const double alloc_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     HIP_TRY(hipEventRecord(c->ev[0], st));
-    HIP_TRY(hipMemcpyAsync(scd, f->cs.scale.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
+    memcpy(h_sc, f->cs.scale.data(), d * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(scd, h_sc, d * sizeof(double), hipMemcpyHostToDevice, st));
     CovSpec cp = f->cs;
     cp.cp.der = -1; cp.pg.der = -1;
     for (long a = 0; a < ns; a += NSB) {
         const long nb_ = std::min<long>(NSB, ns - a);
         const int nrhs = (int)round_up(nb_, 128);
-        HIP_TRY(hipMemcpyAsync(xd, xs + a * d, nb_ * d * sizeof(double), hipMemcpyHostToDevice, st));
-        if (ms) HIP_TRY(hipMemcpyAsync(msd, ms + a, nb_ * sizeof(double), hipMemcpyHostToDevice, st));
-        else HIP_TRY(hipMemsetAsync(msd, 0, nb_ * sizeof(double), st));
+        stamp("batch start");
+        memcpy(h_x, xs + a * d, (size_t)nb_ * d * sizeof(double));             // (the previous batch ended with a stream synchronisation)
+        stamp("inputs staged");
+        HIP_TRY(hipMemcpyAsync(xd, h_x, nb_ * d * sizeof(double), hipMemcpyHostToDevice, st));
+        if (ms) {
+            memcpy(h_ms, ms + a, nb_ * sizeof(double));
+            HIP_TRY(hipMemcpyAsync(msd, h_ms, nb_ * sizeof(double), hipMemcpyHostToDevice, st));
+        } else HIP_TRY(hipMemsetAsync(msd, 0, nb_ * sizeof(double), st));
         CHK(scale_transpose_launch(xd, nb_, d, scd, XcT, ldc, dpad, st));
         if (product) CHK(predict_batch_product(c, f, cp, XcT, ldc, nb_, nrhs, msd, Ks, Vp, part, o1, o2, st));
         else {
@@ -226,10 +256,14 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
         CHK(solve_lower_multi(c, f->F, f->ldf, f->Wd, Ks, np, np, nrhs, false));
         CHK(col_sumsq_launch(Ks, np, n, nb_, f->kss, f->sWv ? 1.0 : f->sw * f->sw, o2, st));
         }
-        HIP_TRY(hipMemcpyAsync(fmu + a, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(fs2 + a, o2, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_o1, o1, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_o2, o2, nb_ * sizeof(double), hipMemcpyDeviceToHost, st));
         if (a + NSB >= ns) HIP_TRY(hipEventRecord(c->ev[1], st));
+        stamp("batch queued");
         HIP_TRY(hipStreamSynchronize(st));
+        stamp("batch done on the device");
+        memcpy(fmu + a, h_o1, nb_ * sizeof(double));
+        memcpy(fs2 + a, h_o2, nb_ * sizeof(double));
     }
     {
         float dev_ms = 0.f;
@@ -239,6 +273,7 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
         c->last_ms[PGP_STAGE_SOLVE] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
         c->last_ms[PGP_STAGE_TOTAL] = dev_ms;
     }
+    stamp("timings read");
     if (c->prof) prof_collect(c);
     return PGP_OK;
 }

@@ -291,3 +291,39 @@ def test_bench_roofline_head_order_is_what_the_driver_record_keeps():
     assert all(not isinstance(v, (dict, list)) for v in flat.values()) and all(len(v) <= 120 for v in flat.values() if isinstance(v, str))
     assert "how" not in flat and "frac_sched0" not in flat and "cholesky_sweep_what" not in flat
     assert detail["kernel"] == "k" * 300 and detail["how"] and detail["frac_sched0"] == 0.71 and isinstance(detail["timed_window"], dict)
+
+
+def test_thread_pools_follow_the_cpu_quota(monkeypatch, tmp_path):
+    import os
+    """pygps_amd/_threads.py: a container CPU quota below the visible core count caps the BLAS / OpenMP pools (the reference's host code
+    around a device call -- numpy.linalg.norm in lik.Gauss.evaluate, Core/lik.py:134-158 -- otherwise wakes one thread per VISIBLE
+    core and the cgroup throttles the process); no quota, or PYGPS_AMD_KEEP_THREADS, changes nothing."""
+    import builtins
+    from pygps_amd import _threads
+    real_open = builtins.open
+
+    def fake_open(quota):
+        def _open(path, *a, **k):
+            if str(path) == "/sys/fs/cgroup/cpu.max":
+                f = tmp_path / "cpu.max"
+                f.write_text(quota)
+                return real_open(f, *a, **k)
+            return real_open(path, *a, **k)
+        return _open
+    for v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.delenv("PYGPS_AMD_KEEP_THREADS", raising=False)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake_open("1600000 100000"))
+    assert _threads.cpu_quota() == 16
+    assert _threads.respect_cpu_quota() == 16 and os.environ["OPENBLAS_NUM_THREADS"] == "16"
+    monkeypatch.setattr(builtins, "open", fake_open("150000 100000"))
+    assert _threads.cpu_quota() == 2
+    monkeypatch.setattr(builtins, "open", fake_open("max 100000"))
+    assert _threads.cpu_quota() is None and _threads.respect_cpu_quota() is None
+    monkeypatch.setattr(builtins, "open", fake_open("1600000 100000"))
+    monkeypatch.setenv("PYGPS_AMD_KEEP_THREADS", "1")
+    assert _threads.respect_cpu_quota() is None
+    if _threads._LIMIT is not None:                     # (leave this test process as it was)
+        _threads._LIMIT.restore_original_limits()
+        _threads._LIMIT = None
