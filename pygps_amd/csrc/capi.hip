@@ -216,6 +216,7 @@ int pgp_set_option(pgp_ctx* c, const char* name, int value) {
     if (!strcmp(name, "xcd_min_tiles")) { c->xcd_min_tiles = value; return PGP_OK; }
     if (!strcmp(name, "xcd_super")) { c->xcd_super = value; return PGP_OK; }
     if (!strcmp(name, "solve_outer")) { if (value < 1) return -2; c->solve_outer = value; return PGP_OK; }
+    if (!strcmp(name, "keep_inverse")) { c->keep_inverse = value != 0; return PGP_OK; }
     if (!strcmp(name, "predict_inverse")) { if (value < 0 || value > 2) return -2; c->predict_inverse = value; return PGP_OK; }
     if (!strcmp(name, "predict_batch")) { if (value < 128 || value % 128) return -2; c->predict_batch = value; return PGP_OK; }
     if (!strcmp(name, "s_tile")) { if (value != 0 && value != 64 && value != 128) return -2; c->s_tile = value; return PGP_OK; }
@@ -1463,6 +1464,12 @@ int pgp_exact_fit(pgp_ctx* c, int kind, const double* covhyp, int ncov, int para
         CHK(spool_take(c, (size_t)c->dpad * np * sizeof(double), (void**)&f->XsT));
         HIP_TRY(hipMemcpyAsync(f->XsT, c->XsT, (size_t)c->dpad * np * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
+        // (round 6) the fused inverse rows E = L^-T are what GP.predict's product form needs (W = L^-1 = E'): the handle keeps the
+        // scratch buffer instead of the pool, the first predict transposes it (predict.hip ensure_linv) -- no trtri
+        if (fused && E && c->keep_inverse && np <= 16384) {
+            const size_t eb = pscr.release(E);
+            if (eb) { f->Eraw = E; f->Eraw_bytes = eb; }
+        }
         *factor_out = hg.release();
     }
     fguard.scrub = false;                             // a finished factor honours the pool contract as it is
@@ -1497,6 +1504,7 @@ void pgp_factor_free(pgp_ctx* c, pgp_factor* f) { GateShared device_gate_hold(c)
     spool_give(c, (size_t)f->dpad * f->np * sizeof(double), f->XsT);
     spool_give(c, (size_t)128 * f->np * sizeof(double), f->Wd);
     spool_give(c, (size_t)f->np * sizeof(double), f->sWv);
+    if (f->Eraw) spool_give(c, f->Eraw_bytes, f->Eraw);
     delete f;
 }
 

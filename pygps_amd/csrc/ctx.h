@@ -30,6 +30,8 @@ struct pgp_factor {
     double* XsT;          // dpad x np scaled coordinates used for this fit
     double* Wd;           // np x 128 : inverted diagonal blocks (lazy, for predict)
     double* Linv = nullptr; // ldf x np : W = L^-1 (lazy: the product form of predict, predict.hip ensure_linv; from the factor pool)
+    double* Eraw = nullptr; // np x np  : the fit's fused inverse rows E = L^-T as the sweep left them (option keep_inverse; scratch-pool buffer of
+    size_t Eraw_bytes = 0;  //            Eraw_bytes): the first predict transposes them into Linv instead of running a trtri
     int dpad, d;
     CovSpec cs;           // covariance functor / program of this fit (predict re-evaluates it in 'cross' mode)
     double kss = 0.0;     // k(z,z) of 'self_test' mode
@@ -156,6 +158,7 @@ struct pgp_ctx {
     int xcd_min_tiles = 256;            // ... to launches with at least this many 128-tiles
     int xcd_super = 8;                  // xcd_order: super-tile edge in tiles
     int solve_outer = 8;                // leaves per outer panel of the blocked multi-rhs triangular solve (K = 128 solve_outer)
+    int keep_inverse = 1;               // a fit with the fused inverse rows hands E = L^-T to its posterior handle (np <= 16384): predict's W without a trtri
     int predict_inverse = 1;            // pgp_predict: 0 = blocked solve, 1 = product form with W = L^-1 for batches >= 1024 points (or once W exists), 2 = always
     int predict_batch = 65536;          // test points per batch of pgp_predict (scratch: np x batch doubles, capped at 16 GiB -- predict_batch_points)
     int s_tile = 0;                     // tile size of the panel solves: 0 = automatic
@@ -326,6 +329,12 @@ struct PoolScratch {
         held.push_back({bytes, p});
         *out = (T*)p;
         return PGP_OK;
+    }
+    // hand a buffer on to another owner (a posterior handle): it no longer goes back to the pool with this scope; returns its size
+    size_t release(void* p) {
+        for (size_t i = 0; i < held.size(); ++i)
+            if (held[i].second == p) { const size_t b = held[i].first; held.erase(held.begin() + (long)i); return b; }
+        return 0;
     }
 };
 

@@ -73,8 +73,9 @@ static int ensure_wd(pgp_ctx* c, pgp_factor* f) {
 // on the LDS-DMA 128 x 128 tile (k clipped to the triangle), if the cross-covariances are laid out test-point-contiguous
 // (KsT: nrhs x np, column = training point) -- the tile kernel writes them that way when the two point sets swap roles.
 // W costs one trtri (N^3 / 3 flops) at the first predict that wants it and stays with the posterior handle (ldf x np doubles, from
-// the factor pool) until the handle is freed.  Option predict_inverse: 0 = never (the blocked solve), 1 = for batches of >= 1024
-// points or whenever W exists already (default), 2 = always.  Reference: Core/gp.py:395-417 (V = solve(L', sW o Ks)).
+// the factor pool) until the handle is freed -- or one transpose when the fit handed its fused inverse rows E = L^-T to the handle
+// (option keep_inverse, the default up to np = 16384: W = E').  Option predict_inverse: 0 = never (the blocked solve), 1 = whenever
+// W or E is at hand, else for batches of >= 1024 points (default), 2 = always.  Reference: Core/gp.py:395-417 (V = solve(L', sW o Ks)).
 namespace {
 // KsT lives in SLABS of SW test points: slab s is an (SW x np) column-major matrix (leading dimension SW) at KsT + s SW np, so that
 // the k-rows a GEMM tile streams through are 8 SW bytes apart, not 8 nrhs (nrhs = 65536: 512 KiB between k-rows, one TLB entry
@@ -101,6 +102,18 @@ __global__ __launch_bounds__(256) void kst_dot_finish_kernel(const double* __res
     for (int kc = 0; kc < nchunk; ++kc) s += part[(long)kc * ldp + j];
     out[j] = (add ? add[j] : 0.0) + s;
 }
+// W (lower) <- E' for an upper-triangular E: 64 x 64 tiles through LDS; blockIdx = (tile row of W, tile column of W), row >= column
+__global__ __launch_bounds__(256) void linv_from_e_kernel(const double* __restrict__ E, long lde, double* __restrict__ W, long ldw) {
+    if (blockIdx.x < blockIdx.y) return;
+    __shared__ double tile[64][65];
+    const long m0 = 64L * blockIdx.x, k0 = 64L * blockIdx.y;         // W(m0 + a, k0 + q) = E(k0 + q, m0 + a)
+    const int a = threadIdx.x & 63, b = threadIdx.x >> 6;
+    for (int q = b; q < 64; q += 4) tile[q][a] = E[k0 + a + (m0 + q) * lde];      // tile[q][a] = E(k0 + a, m0 + q)
+    __syncthreads();
+    const bool diag = blockIdx.x == blockIdx.y;
+    for (int q = b; q < 64; q += 4)
+        if (!diag || a >= q) W[m0 + a + (k0 + q) * ldw] = tile[a][q];             // W(m0 + a, k0 + q) = E(k0 + q, m0 + a)
+}
 // KsT(:, k) *= s[k]   (EP: sW o Ks)
 __global__ __launch_bounds__(256) void kst_col_scale_kernel(double* __restrict__ KsT, long SW, long np, long ncols, const double* __restrict__ s) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
@@ -119,6 +132,11 @@ static int ensure_linv(pgp_ctx* c, pgp_factor* f) {
     double* T = nullptr;
     int rc = tmp.alloc(&T, std::max<size_t>((size_t)f->np * f->np / 4, (size_t)128 * 128) * sizeof(double));
     if (rc == PGP_OK && hipMemsetAsync(W, 0, bytes, st) != hipSuccess) rc = PGP_ERR_HIP;     // (a pooled buffer: only its strict-upper tiles are known to be zero)
+    if (rc == PGP_OK && f->Eraw) {
+        // the fit left E = L^-T (upper triangular, np x np; whatever lies below its diagonal was never written): W(m, k) = E(k, m), k <= m
+        hipLaunchKernelGGL(linv_from_e_kernel, dim3((unsigned)(f->np / 64), (unsigned)(f->np / 64)), dim3(256), 0, st, f->Eraw, f->np, W, f->ldf);
+        if (hipGetLastError() != hipSuccess) rc = PGP_ERR_HIP;
+    } else
     if (rc == PGP_OK) rc = trtri_lower(c, f->F, f->ldf, W, f->ldf, T, f->np);
     if (rc == PGP_OK && hipStreamSynchronize(st) != hipSuccess) rc = PGP_ERR_HIP;            // (T goes back to the pool)
     if (rc != PGP_OK) {
@@ -129,6 +147,7 @@ static int ensure_linv(pgp_ctx* c, pgp_factor* f) {
         return rc;
     }
     f->Linv = W;
+    if (f->Eraw) { spool_give(c, f->Eraw_bytes, f->Eraw); f->Eraw = nullptr; f->Eraw_bytes = 0; }     // (the transpose is done: synchronised above)
     return PGP_OK;
 }
 
@@ -196,7 +215,7 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     const long np = f->np, n = f->n;
     const int d = f->d, dpad = f->dpad;
     // the product form (W = L^-1, one GEMM per batch) or the blocked solve: see predict_batch_product
-    const bool product = np >= 1024 && (c->predict_inverse == 2 || (c->predict_inverse == 1 && (f->Linv != nullptr || ns >= 1024)));
+    const bool product = np >= 1024 && (c->predict_inverse == 2 || (c->predict_inverse == 1 && (f->Linv != nullptr || f->Eraw != nullptr || ns >= 1024)));
     if (product) CHK(ensure_linv(c, f));
     else CHK(ensure_wd(c, f));
     // test points per batch (the reference uses 1000): up to predict_batch = 65536 within 16 GiB of scratch, so that the K = 128

@@ -194,19 +194,23 @@ def test_predict_product_form_equals_the_blocked_solve(lib):
     m.setPrior(kernel=pyGPs.cov.RBF(np.log(np.sqrt(d)), 0.2))
     m.setNoise(np.log(0.05))
     m.setData(x, y)
-    m.getPosterior()
     out = {}
-    try:
-        for mode in (0, 2, 1):
-            _lib.check(lib.pgp_set_option(ctx, b"predict_inverse", mode))
-            out[mode] = [np.array(v) for v in m.predict(xs)[:4]]
-            out[(mode, "small")] = [np.array(v) for v in m.predict(xs[:37])[:4]]
-    finally:
-        lib.pgp_set_option(ctx, b"predict_inverse", 1)
-    for a, b in ((0, 2), (0, 1), ((0, "small"), (2, "small"))):
-        for u, v, tol in zip(out[a], out[b], (1e-11, 1e-9, 1e-11, 1e-9)):
-            assert np.max(np.abs(u - v)) <= tol * max(1.0, float(np.max(np.abs(u)))), (a, b, np.max(np.abs(u - v)))
-    assert np.array_equal(out[(1, "small")][2], out[(2, "small")][2])       # W exists by then: the default takes the product form for 37 points too
+    # keep_inverse 1 (default): W = L^-1 is the transpose of the fit's own fused inverse rows; 0: a trtri at the first predict
+    for keep in (1, 0):
+        try:
+            _lib.check(lib.pgp_set_option(ctx, b"keep_inverse", keep))
+            m.getPosterior()
+            for mode in (0, 2, 1):
+                _lib.check(lib.pgp_set_option(ctx, b"predict_inverse", mode))
+                out[mode] = [np.array(v) for v in m.predict(xs)[:4]]
+                out[(mode, "small")] = [np.array(v) for v in m.predict(xs[:37])[:4]]
+        finally:
+            lib.pgp_set_option(ctx, b"predict_inverse", 1)
+            lib.pgp_set_option(ctx, b"keep_inverse", 1)
+        for a, b in ((0, 2), (0, 1), ((0, "small"), (2, "small"))):
+            for u, v, tol in zip(out[a], out[b], (1e-11, 1e-9, 1e-11, 1e-9)):
+                assert np.max(np.abs(u - v)) <= tol * max(1.0, float(np.max(np.abs(u)))), (keep, a, b, np.max(np.abs(u - v)))
+        assert np.array_equal(out[(1, "small")][2], out[(2, "small")][2])   # W exists by then: the default takes the product form for 37 points too
     c = m.meanfunc.hyp[0]
     ref = O.exact_fit(O.RBF, np.array(m.covfunc.hyp), 0, m.likfunc.hyp[0], x, y, c * np.ones((n, 1)), np.ones((n, 1)), nargout=2, faithful=False)
     rym, rys2, rfm, rfs2 = O.predict(O.RBF, np.array(m.covfunc.hyp), 0, m.likfunc.hyp[0], x, ref["alpha"], ref["L"], ref["sW"], xs,
