@@ -101,6 +101,10 @@ int pgp_init(int device, pgp_ctx** ctx_out) { GateShared device_gate_hold(device
     }
     pgp_ctx* c = new pgp_ctx();
     c->device = device;
+    // process-wide defaults of two options that model code has no handle on (the contexts of fit streams are made inside the
+    // searches): PYGPS_AMD_PREDICT_INVERSE = 0 / 1 / 2, PYGPS_AMD_KEEP_INVERSE = 0 / 1 (pgp_set_option still wins per context)
+    if (const char* e = getenv("PYGPS_AMD_PREDICT_INVERSE")) { const int v = atoi(e); if (v >= 0 && v <= 2) c->predict_inverse = v; }
+    if (const char* e = getenv("PYGPS_AMD_KEEP_INVERSE")) c->keep_inverse = atoi(e) != 0;
     HIP_TRY(hipGetDeviceProperties(&c->prop, device));
     HIP_TRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
     {

@@ -1,7 +1,10 @@
 // Internal: context / factor structs shared by the host-side drivers (capi.hip, predict.hip, ep.hip).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <mutex>
@@ -196,6 +199,24 @@ struct pgp_ctx {
 int pgp_ctx_count_on_device(int device);
 void pgp_drop_idle_pools(int device);
 
+// PGP_POOL_TRACE=1: every hipMalloc / hipFree the pools fall through to, with its size and duration (stderr)
+static inline bool pool_trace_on() { static const bool on = getenv("PGP_POOL_TRACE") != nullptr; return on; }
+static inline hipError_t pool_hip_malloc(void** out, size_t bytes, const char* who) {
+    if (!pool_trace_on()) return hipMalloc(out, bytes);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMalloc(out, bytes);
+    fprintf(stderr, "[pool] hipMalloc %8.1f MiB  %8.3f ms  (%s)%s\n", bytes / 1048576.0,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), who, e == hipSuccess ? "" : " FAILED");
+    return e;
+}
+static inline void pool_hip_free(void* p, size_t bytes, const char* who) {
+    if (!pool_trace_on()) { (void)hipFree(p); return; }
+    const auto t0 = std::chrono::steady_clock::now();
+    (void)hipFree(p);
+    fprintf(stderr, "[pool] hipFree   %8.1f MiB  %8.3f ms  (%s)\n", bytes / 1048576.0,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), who);
+}
+
 static inline size_t pool_idle_cap(pgp_ctx* c) {
     return (size_t)c->prop.totalGlobalMem / 3 / (size_t)std::max(1, pgp_ctx_count_on_device(c->device));
 }
@@ -214,10 +235,10 @@ static inline int pool_alloc(pgp_ctx* c, size_t bytes, void** out, bool* fresh =
         }
     }
     if (fresh) *fresh = true;
-    if (hipMalloc(out, bytes) != hipSuccess) {           // out of memory: drop every idle pool on this device, retry once
+    if (pool_hip_malloc(out, bytes, "factor pool") != hipSuccess) {           // out of memory: drop every idle pool on this device, retry once
         (void)hipGetLastError();
         pgp_drop_idle_pools(c->device);
-        HIP_TRY(hipMalloc(out, bytes));
+        HIP_TRY(pool_hip_malloc(out, bytes, "factor pool, retry"));
     }
     return PGP_OK;
 }
@@ -226,7 +247,7 @@ static inline void pool_free(pgp_ctx* c, size_t bytes, void* p) {
     if (!p) return;
     const size_t cap = pool_idle_cap(c);
     std::lock_guard<std::mutex> lk(c->pool_mu);
-    if (c->pool_bytes + bytes > cap) { (void)hipFree(p); return; }
+    if (c->pool_bytes + bytes > cap) { pool_hip_free(p, bytes, "factor pool over its cap"); return; }
     c->pool.insert({bytes, p});
     c->pool_bytes += bytes;
 }
@@ -245,7 +266,7 @@ static inline int spool_take(pgp_ctx* c, size_t bytes, void** out) {
             return PGP_OK;
         }
     }
-    hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    hipError_t e = pool_hip_malloc(out, bytes ? bytes : 8, "handle buffer");
     if (e != hipSuccess) { pgp_set_last_hip_error(e, "hipMalloc(handle buffer)", __FILE__, __LINE__); return PGP_ERR_HIP; }
     return PGP_OK;
 }
@@ -254,7 +275,7 @@ static inline void spool_give(pgp_ctx* c, size_t bytes, void* p) {
     if (!c) { (void)hipFree(p); return; }
     const size_t cap = pool_idle_cap(c);
     std::lock_guard<std::mutex> lk(c->pool_mu);
-    if (c->spool_bytes + bytes > cap) { (void)hipFree(p); return; }
+    if (c->spool_bytes + bytes > cap) { pool_hip_free(p, bytes, "scratch pool over its cap (handle buffer)"); return; }
     c->spool.insert({bytes, p});
     c->spool_bytes += bytes;
 }
@@ -306,7 +327,7 @@ struct PoolScratch {
         const size_t cap = pool_idle_cap(c);
         std::lock_guard<std::mutex> lk(c->pool_mu);
         for (auto& h : held) {
-            if (c->spool_bytes + h.first > cap) { (void)hipFree(h.second); continue; }
+            if (c->spool_bytes + h.first > cap) { pool_hip_free(h.second, h.first, "scratch pool over its cap"); continue; }
             c->spool.insert({h.first, h.second});
             c->spool_bytes += h.first;
         }
@@ -320,10 +341,10 @@ struct PoolScratch {
             auto it = c->spool.find(bytes);
             if (it != c->spool.end()) { p = it->second; c->spool.erase(it); c->spool_bytes -= bytes; }
         }
-        if (!p && hipMalloc(&p, bytes) != hipSuccess) {       // out of memory: drop every idle pool on this device, retry once
+        if (!p && pool_hip_malloc(&p, bytes, "scratch pool") != hipSuccess) {       // out of memory: drop every idle pool on this device, retry once
             (void)hipGetLastError();
             pgp_drop_idle_pools(c->device);
-            hipError_t e = hipMalloc(&p, bytes);
+            hipError_t e = pool_hip_malloc(&p, bytes, "scratch pool, retry");
             if (e != hipSuccess) { pgp_set_last_hip_error(e, "hipMalloc(pool scratch)", __FILE__, __LINE__); return PGP_ERR_HIP; }
         }
         held.push_back({bytes, p});

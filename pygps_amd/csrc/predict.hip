@@ -245,7 +245,9 @@ int pgp_predict(pgp_ctx* c, pgp_factor* f, const double* xs, int64_t ns, const d
     CHK(tmp.alloc(&msd, NSB * sizeof(double)));
     CHK(tmp.alloc(&o1, NSB * sizeof(double)));
     CHK(tmp.alloc(&o2, NSB * sizeof(double)));
+    stamp("device scratch");
     CHK(pred_stage(c, (size_t)NSB * (d + 3) + d));
+    stamp("pinned staging");
     double* const h_x = c->pred_host, *const h_ms = h_x + (size_t)NSB * d, *const h_o1 = h_ms + NSB, *const h_o2 = h_o1 + NSB, *const h_sc = h_o2 + NSB;
     const double alloc_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     HIP_TRY(hipEventRecord(c->ev[0], st));
