@@ -234,3 +234,33 @@ def test_predict_product_form_equals_the_blocked_solve(lib):
         lib.pgp_set_option(ctx, b"predict_inverse", 1)
     for u, v in zip(outc[0], outc[2]):
         assert np.max(np.abs(u - v)) <= 1e-9 * max(1.0, float(np.max(np.abs(u))))
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 256, 1024), (896, 128, 896), (128, 128, 128), (1152, 384, 1152)])
+def test_gemm_fold_rows_kernel_against_numpy(lib, M, N, K, monkeypatch):
+    """gemm_f64_fold_kernel (GemmArgs::fold_rows: tile rows mt-1-r and r in one workgroup -- GP.predict's V = L^-1 Ks, Core/gp.py:395-417)
+    on a product clipped to a lower-triangular A (KM_LT_I: k < i0 + 128): against numpy with the same clipping, an odd number of tile
+    rows (the middle row is its own pair), a single tile; and bit for bit against the plain kernel on the same arguments."""
+    from pygps_amd import _lib
+    rng = np.random.RandomState(M + N)
+    A = np.asfortranarray(np.tril(rng.randn(M, K)))
+    B = np.asfortranarray(rng.randn(N, K))
+    C0 = np.asfortranarray(rng.randn(M, N))
+    ref = np.empty_like(C0)
+    for i0 in range(0, M, 128):
+        k1 = min(K, i0 + 128)
+        ref[i0:i0 + 128] = A[i0:i0 + 128, :k1] @ B[:, :k1].T
+    outs = []
+    for fold in (True, False):
+        if fold:
+            monkeypatch.setenv("PGP_TEST_GEMM_FOLD", "1")
+        else:
+            monkeypatch.delenv("PGP_TEST_GEMM_FOLD", raising=False)
+        Cw = C0.copy(order="F")
+        ms = C.c_double()
+        rc = lib.pgp_test_gemm(_lib.ctx(), 128, 0, 0, 0, 0, 3, 0, 1.0, 0.0, A.ctypes.data_as(_lib._dp), M, B.ctypes.data_as(_lib._dp), N,
+                               Cw.ctypes.data_as(_lib._dp), M, M, N, K, 0, C.byref(ms))
+        assert rc == 0, _lib.strerror(rc)
+        assert np.max(np.abs(Cw - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), (fold, np.max(np.abs(Cw - ref)))
+        outs.append(Cw)
+    assert np.array_equal(outs[0], outs[1])

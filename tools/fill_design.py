@@ -52,6 +52,11 @@ v["PRED_MS"] = "%.0f" % p["ms"]
 v["PRED_DEV"] = "%.0f" % p["device_ms"]
 v["PRED_FIRST"] = "%.0f" % p["first_call_ms"]
 v["PRED_ALLOC"] = "%.1f" % p["first_call_scratch_alloc_ms"]
+sm = j.get("predict_N8192_small_batches", {})
+v["PRED1K"] = "%.1f" % sm.get("ns1000_product_form_ms", float("nan"))
+v["PRED1K_SOLVE"] = "%.1f" % sm.get("ns1000_blocked_solve_ms", float("nan"))
+v["PRED8K"] = "%.1f" % sm.get("ns8192_product_form_ms", float("nan"))
+v["PRED8K_SOLVE"] = "%.1f" % sm.get("ns8192_blocked_solve_ms", float("nan"))
 v["KFOLD_MS"] = "%.0f" % (1e3 * j.get("kfold_K10_N8192", {}).get("wall_s", float("nan")))
 v["FITC_MS"] = "%.1f" % j["fitc_n131072_nu1024"]["fit_ms"]
 sf = j.get("sharded_fit", {})

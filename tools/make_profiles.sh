@@ -65,5 +65,11 @@ bash $R/tools/fit_trace.sh fit_timeline_sched2_s_pan sched=2 > /dev/null 2>&1; c
   python $R/tools/gram_probe.py d=32 -- "gram_fast=0,gram_grid=2048" "gram_fast=2,gram_grid=32768" ) > $O/final/${RT}_gram_probe.txt 2> $O/gram.err
 ( python $R/tools/ab_options.py N=8192 STEPS=40 ROUNDS=3 -- "sched=2" "sched=0" "trsm_lean=1" "trsm_lean=2" "publish=0"; python $R/tools/ab_options.py N=4096 STEPS=40 ROUNDS=3 -- "sched=2" "trsm_lean=1" "publish=0"; python $R/tools/gpu_probe.py leaf ) > $O/final/${RT}_option_ab_and_leaf_ticks.txt 2> $O/ab.err
 ( python $R/tools/predict_diag.py ) > $O/final/${RT}_predict_diag.txt 2> $O/predict.err
+# 9. round 6, second half: the 128 x 64 tile and the folded kernel for clipped triangles; predict's two forms, the first predict after a
+#    fit, and the same call with the BLAS pool left at one thread per visible core (the "hot chip" of rounds 3-5)
+( python $R/tools/tur_probe.py; python $R/tools/_gemm_clip.py 3; echo "folded (gemm_f64_fold_kernel):"; PGP_TEST_GEMM_FOLD=1 python $R/tools/_gemm_clip.py 3 | sed -n 3,5p;
+  python $R/tools/ab_options.py N=8192 STEPS=40 ROUNDS=3 -- "tur_tile=128" "tur_tile=1264"; python $R/tools/ab_options.py N=4096 STEPS=60 ROUNDS=3 -- "tur_tile=128" "tur_tile=1264" ) > $O/final/${RT}_tile_128x64_and_fold.txt 2> $O/tile.err
+( python $R/tools/_pred_q.py; python $R/tools/_pred_first.py; echo "pools capped at the CPU quota (default):"; python $R/tools/_pred_t.py;
+  echo "PYGPS_AMD_KEEP_THREADS=1:"; PYGPS_AMD_KEEP_THREADS=1 python $R/tools/_pred_t.py ) > $O/final/${RT}_predict_forms_and_host_threads.txt 2> $O/predict2.err
 ( REPS=20 python $R/tools/ep_kfold_diag.py 2>&1 | grep -E "rep|probe|gave" ) > $O/final/${RT}_ep_two_fit_streams_soak.txt
 ls -la $O/final
