@@ -115,10 +115,11 @@ __global__ __launch_bounds__(256) void linv_from_e_kernel(const double* __restri
         if (!diag || a >= q) W[m0 + a + (k0 + q) * ldw] = tile[a][q];             // W(m0 + a, k0 + q) = E(k0 + q, m0 + a)
 }
 // KsT(:, k) *= s[k]   (EP: sW o Ks)
-__global__ __launch_bounds__(256) void kst_col_scale_kernel(double* __restrict__ KsT, long SW, long np, long ncols, const double* __restrict__ s) {
+__global__ __launch_bounds__(256) void kst_col_scale_kernel(double* __restrict__ KsT, long SW, long np, long ncols, long ntrain, const double* __restrict__ s) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     if (j >= ncols) return;
-    KsT[(j / SW) * SW * np + j % SW + (long)blockIdx.y * SW] *= s[blockIdx.y];
+    double* col = KsT + (j / SW) * SW * np + j % SW;
+    for (long k = blockIdx.y; k < ntrain; k += gridDim.y) col[k * SW] *= s[k];
 }
 }  // namespace
 
@@ -169,7 +170,7 @@ static int predict_batch_product(pgp_ctx* c, pgp_factor* f, const CovSpec& cp, c
     const long chunk = (n + NCH - 1) / NCH;
     hipLaunchKernelGGL(kst_dot_part_kernel, dim3((unsigned)((nb_ + 255) / 256), NCH), dim3(256), 0, st, KsT, SW, np, nb_, n, chunk, f->alpha, part, (long)nrhs);
     hipLaunchKernelGGL(kst_dot_finish_kernel, dim3((unsigned)((nb_ + 255) / 256)), dim3(256), 0, st, part, (long)nrhs, NCH, nb_, msd, o1);   // fmu = ms + Ks' alpha
-    if (f->sWv) hipLaunchKernelGGL(kst_col_scale_kernel, dim3((unsigned)((nb_ + 255) / 256), (unsigned)n), dim3(256), 0, st, KsT, SW, np, nb_, f->sWv);
+    if (f->sWv) hipLaunchKernelGGL(kst_col_scale_kernel, dim3((unsigned)((nb_ + 255) / 256), (unsigned)std::min<long>(n, 32768)), dim3(256), 0, st, KsT, SW, np, nb_, n, f->sWv);
     if (hipGetLastError() != hipSuccess) return PGP_ERR_HIP;
     GemmArgs g{};                                                                            // one product per slab, ONE launch
     g.A = f->Linv; g.lda = f->ldf; g.a_kc = 0;
