@@ -117,8 +117,8 @@ def test_cfg4_restart_search_without_torch(tmp_path, world, streams, stub):
 
 def test_cfg4_at_its_stated_size_N8192_bounded_fixture(lib):
     """BASELINE configs[3] says N = 8192; G9_restarts_N8192_3ls is the reference's own run at that size with the search bounded to
-    3 line searches per restart (8 restarts, np.random.seed(123): ~70 reference fits).  Start table bit for bit, which restarts
-    fail, per-restart objective <= 1e-5, line-search counts."""
+    3 line searches per restart (8 restarts, np.random.seed(123): 3.4 h of reference fits; the complete run).  Start table bit for bit,
+    which restarts fail, per-restart objective <= 1e-5, line-search counts, the optimum the reference settled on."""
     path = os.path.join(GOLDEN, "G9_restarts_N8192_3ls.npz")
     assert os.path.exists(path), "tests/golden/G9_restarts_N8192_3ls.npz is missing: record it (make_golden.py g9_8192_3ls), cfg 4 is not pinned at its size without it"
     import pygps_amd as pyGPs
@@ -133,7 +133,7 @@ def test_cfg4_at_its_stated_size_N8192_bounded_fixture(lib):
     np.random.seed(int(g["np_seed"]))
     m.optimize(x, y, numIterations=int(g["numIterations"]))
     o = m.optimizer
-    k = int(g["n_runs"])                               # a fixture of a stopped run holds the first n_runs restarts (make_golden.g9_from_partial)
+    k = int(g["n_runs"])                               # 8: the complete run (a fixture of a stopped run would hold its first n_runs restarts: make_golden.g9_from_partial)
     assert k >= 3 and relerr(o.init_table[:k], g["run_X0"]) < 1e-14
     f = np.array([r.f for r in o.runs])[:k]
     okr = np.array([r.ok for r in o.runs])[:k]
