@@ -211,6 +211,17 @@ def test_predict_product_form_equals_the_blocked_solve(lib):
             for u, v, tol in zip(out[a], out[b], (1e-11, 1e-9, 1e-11, 1e-9)):
                 assert np.max(np.abs(u - v)) <= tol * max(1.0, float(np.max(np.abs(u)))), (keep, a, b, np.max(np.abs(u - v)))
         assert np.array_equal(out[(1, "small")][2], out[(2, "small")][2])   # W exists by then: the default takes the product form for 37 points too
+    # several device batches (predict_batch 1024: 2501 points = 1024 + 1024 + 453) give what one batch gives, bit for bit, in both forms
+    try:
+        _lib.check(lib.pgp_set_option(ctx, b"predict_batch", 1024))
+        for mode in (2, 0):
+            _lib.check(lib.pgp_set_option(ctx, b"predict_inverse", mode))
+            got = [np.array(v) for v in m.predict(xs)[:4]]
+            for u, v in zip(got, out[mode]):
+                assert np.array_equal(u, v), mode
+    finally:
+        lib.pgp_set_option(ctx, b"predict_batch", 65536)
+        lib.pgp_set_option(ctx, b"predict_inverse", 1)
     c = m.meanfunc.hyp[0]
     ref = O.exact_fit(O.RBF, np.array(m.covfunc.hyp), 0, m.likfunc.hyp[0], x, y, c * np.ones((n, 1)), np.ones((n, 1)), nargout=2, faithful=False)
     rym, rys2, rfm, rfs2 = O.predict(O.RBF, np.array(m.covfunc.hyp), 0, m.likfunc.hyp[0], x, ref["alpha"], ref["L"], ref["sW"], xs,
