@@ -684,11 +684,33 @@ def main():
     # `python3 bench.py --gpus N` with N > 1 and no launcher around it: become the launcher (one rank per GPU under
     # torch.distributed.run, rendezvous on 127.0.0.1) and hand its output through -- rank 0 of the children prints the line
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        import random
         import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
+        # a rendezvous port BELOW the kernel's ephemeral range: one obtained by bind(0) may be handed to an outgoing connection of
+        # another process before the ranks (which first import torch) get to listen on it (EADDRINUSE, seen once in the GPU suite)
+        try:
+            eph_lo = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+        except Exception:
+            eph_lo = 32768
+        rnd = random.Random(os.getpid() * 1000003 + time.time_ns())
+        port = None
+        for _ in range(500):
+            cand = rnd.randrange(20000, max(20100, min(eph_lo, 32000) - 32))
+            ok = True
+            for q in (cand, cand + 17):                       # (+ 17: hostgroup's side channel)
+                with socket.socket() as sk:
+                    try:
+                        sk.bind(("127.0.0.1", q))
+                    except OSError:
+                        ok = False
+            if ok:
+                port = cand
+                break
+        if port is None:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))

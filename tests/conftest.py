@@ -46,6 +46,51 @@ def build_stub_rccl():
     return so
 
 
+def free_port():
+    """A TCP port for a rendezvous on 127.0.0.1, taken BELOW the kernel's ephemeral range (and with port + 17 free as well: hostgroup's
+    side channel).  A port obtained by bind(("", 0)) IS ephemeral: by the time the spawned workers have imported torch (seconds on a
+    warm box, a minute on a fresh one) the kernel may have handed it to some outgoing connection -- seen once in the round-6 GPU suite:
+    "The server socket has failed to listen ... port 34699 ... EADDRINUSE" in test_G6_N8192_over_gloo_ranks_sharing_one_gpu[3]."""
+    import random
+    import socket
+    import time
+    try:
+        eph_lo = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+    except Exception:
+        eph_lo = 32768
+    lo, hi = 20000, max(20100, min(eph_lo, 32000) - 32)
+    rnd = random.Random(os.getpid() * 1000003 + time.time_ns())
+    for _ in range(500):
+        p = rnd.randrange(lo, hi)
+        ok = True
+        for q in (p, p + 17):
+            sk = socket.socket()
+            try:
+                sk.bind(("127.0.0.1", q))
+            except OSError:
+                ok = False
+            finally:
+                sk.close()
+        if ok:
+            return p
+    raise RuntimeError("no free rendezvous port found")
+
+
+def spawn_with_port(fn, make_args, nprocs, attempts=3):
+    """torch.multiprocessing.spawn(fn, args=make_args(port), nprocs) on a fresh port; a lost race for the port (EADDRINUSE at the
+    rendezvous) is retried on another one, every other failure propagates."""
+    import torch.multiprocessing as mp
+    for k in range(attempts):
+        try:
+            mp.spawn(fn, args=make_args(free_port()), nprocs=nprocs, join=True)
+            return
+        except Exception as e:                      # ProcessRaisedException carries the worker's traceback as text
+            msg = str(e)
+            if k + 1 < attempts and ("EADDRINUSE" in msg or "address already in use" in msg.lower()):
+                continue
+            raise
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 

@@ -41,12 +41,7 @@ def test_plan_ownership_messages_and_balance():
         BlockCyclic1D(1000, 512, 2)
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from conftest import spawn_with_port  # noqa: E402  (a rendezvous port below the ephemeral range; a lost race is retried)
 
 
 def _worker(rank, world, port, n, w, out_dir):
@@ -83,8 +78,7 @@ def _worker(rank, world, port, n, w, out_dir):
 
 @pytest.mark.parametrize("n,w", [(96, 16), (80, 16)])
 def test_blockcyclic_sweep_two_ranks_matches_lapack(tmp_path, n, w):
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, n, w, str(tmp_path)), nprocs=2, join=True)
+    spawn_with_port(_worker, lambda port: (2, port, n, w, str(tmp_path)), 2)
     rng = np.random.RandomState(5)
     G = rng.randn(n, n)
     A = G @ G.T / n + np.eye(n)

@@ -240,7 +240,8 @@ def test_sharded_minimize_over_rccl_world_size_1(lib):
     import torch.distributed as dist
     import pygps_amd as pyGPs
     from pygps_amd import opt
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    from conftest import free_port
+    port = free_port()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     g = golden("G9_restarts_N512")
     N, d = int(g["N"]), int(g["d"])
@@ -535,7 +536,8 @@ def test_bench_collective_extras_ranks_sharing_one_gpu(tmp_path, world, stub):
     extras -- cfg 4's restart search sharded over the ranks (world 8: BASELINE configs[3] as written, one restart per rank)
     and ONE exact-GP fit over the ranks."""
     import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    from conftest import free_port
+    port = free_port()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYGPS_BENCH_BACKEND="gloo")
     if stub:       # round 6: the extras over the library's RCCL BRANCH (what an 8-GPU node runs), bound to tests/stub_rccl's shared-memory stand-in
@@ -619,8 +621,8 @@ def test_cfg4_as_written_eight_ranks_one_restart_each(tmp_path):
     table and the data reach the ranks by broadcast from rank 0."""
     import socket
     import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_g9_world8_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    from conftest import spawn_with_port
+    spawn_with_port(_g9_world8_worker, lambda port: (8, port, str(tmp_path)), 8)
     g = golden("G9_restarts_N2048")
     rs = [np.load(os.path.join(str(tmp_path), "r%d.npz" % k)) for k in range(8)]
     for r in rs:

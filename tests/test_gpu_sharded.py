@@ -24,12 +24,7 @@ pytestmark = pytest.mark.gpu
 STUB_RCCL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub_rccl", "librccl_stub.so")
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from conftest import free_port as _free_port, spawn_with_port  # noqa: E402  (ports below the ephemeral range; a lost race is retried)
 
 
 def _flat(d):
@@ -207,8 +202,7 @@ def _worker(rank, world, port, backend, case, out_dir):
 
 
 def _run(tmp_path, world, backend, case):
-    import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(world, _free_port(), backend, case, str(tmp_path)), nprocs=world, join=True)
+    spawn_with_port(_worker, lambda port: (world, port, backend, case, str(tmp_path)), world)
     return [np.load(os.path.join(str(tmp_path), "r%d.npy" % r), allow_pickle=True)[0] for r in range(world)]
 
 

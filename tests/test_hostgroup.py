@@ -23,16 +23,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "workers", "search_worker.py")
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from conftest import free_port as _free_port  # noqa: E402  (below the ephemeral range, port + 17 free as well)
 
 
 def launch(world, case, out_dir, *args, no_torch=True, extra_env=None, timeout=600):
     """`world` processes with the environment a launcher exports; returns when all have exited with status 0."""
+    return _launch_once(world, case, out_dir, args, no_torch, extra_env, timeout, attempts_left=2)
+
+
+def _launch_once(world, case, out_dir, args, no_torch, extra_env, timeout, attempts_left):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -52,6 +51,8 @@ def launch(world, case, out_dir, *args, no_torch=True, extra_env=None, timeout=6
                 q.kill()
             raise
         outs.append(o)
+    if attempts_left > 0 and any(p.returncode != 0 and ("EADDRINUSE" in o or "ddress already in use" in o) for p, o in zip(procs, outs)):
+        return _launch_once(world, case, out_dir, args, no_torch, extra_env, timeout, attempts_left - 1)   # a lost race for the port
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d:\n%s" % (r, o[-4000:])
     return [np.load(os.path.join(str(out_dir), "r%d.npz" % r)) for r in range(world)]

@@ -15,12 +15,7 @@ import torch.multiprocessing as mp
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from conftest import spawn_with_port  # noqa: E402  (a rendezvous port below the ephemeral range; a lost race is retried)
 
 
 def _worker(rank, world, port, R, out_dir, streams):
@@ -54,8 +49,7 @@ def test_sharded_minimize_two_ranks_equals_sequential(tmp_path, R, streams):
     o = opt.Minimize(m, _conf(m, R))
     np.random.seed(7)
     h_seq, f_seq = o.findMin(m.x, m.y, numIters=15)
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, R, str(tmp_path), streams), nprocs=2, join=True)
+    spawn_with_port(_worker, lambda port: (2, port, R, str(tmp_path), streams), 2)
     r0 = np.load(tmp_path / "r0.npz")
     r1 = np.load(tmp_path / "r1.npz")
     for r in (r0, r1):
@@ -78,8 +72,7 @@ def test_sharded_minimize_world_8_one_restart_per_rank(tmp_path):
     o = opt.Minimize(m, _conf(m, R))
     np.random.seed(7)
     h_seq, f_seq = o.findMin(m.x, m.y, numIters=15)
-    port = _free_port()
-    mp.spawn(_worker, args=(8, port, R, str(tmp_path), 1), nprocs=8, join=True)
+    spawn_with_port(_worker, lambda port: (8, port, R, str(tmp_path), 1), 8)
     rs = [np.load(tmp_path / ("r%d.npz" % k)) for k in range(8)]
     for r in rs:
         assert float(r["f"]) == f_seq and np.array_equal(r["h"], h_seq)
